@@ -1,0 +1,231 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures under tests/golden/ by running the UNMODIFIED reference
+(/root/reference, CPU fp32, torch-fallback RoPE) on seeded synthetic weights and frames.
+
+Only runs in the build container (the GPU box has no /root/reference); the resulting
+*.npz files are committed.  Usage:  python tests/golden/make_golden.py [tiny] [full] [memory]
+
+What is dumped (SURVEY.md §8c "recommended dumps"):
+  spann3r_tiny.npz    enc_depth=2 / dec_depth=10 model, 4 frames of 64x80, every stage tensor
+  spann3r_full224.npz 24/12 model, 5 frames of 224x224 (BASELINE config 1), outputs subsampled
+  memory_bank.npz     reference SpatialMemory driven stand-alone for 32 frames of P=196:
+                      similarity skip, working->long-term hand-over and one prune (5096->4000)
+"""
+import argparse
+import os
+import sys
+import time
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, REPO)
+sys.path.insert(0, HERE)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+torch.serialization.add_safe_globals([argparse.Namespace])
+
+from spann3r_amd.config import TINY, FULL  # noqa: E402
+from spann3r_amd.weights import (synth_state_dict, synth_frames, state_dict_fingerprint,  # noqa: E402
+                                 hash_uniform, _stream_id)
+
+
+def build_reference(cfg, sd, tag):
+    """Instantiate the reference through its real loader (dust3r/model.py:27-51)."""
+    from spann3r.model import Spann3R
+    path = "/tmp/golden_dust3r_%s.pth" % tag
+    torch.save({"args": argparse.Namespace(model=cfg.ctor_string()),
+                "model": {k[len("dust3r."):]: v for k, v in sd.items() if k.startswith("dust3r.")}}, path)
+    m = Spann3R(dus3r_name=path, use_feat=False)
+    missing = m.load_state_dict(sd, strict=True)
+    print(missing)
+    os.remove(path)
+    return m.eval()
+
+
+def run_with_taps(m, frames):
+    """Wrap the reference's stage methods (no edits to the reference) and record their outputs."""
+    from spann3r.model import SpatialMemory
+    steps = []
+    cur = {}
+
+    def wrap(name, fn, rec):
+        def inner(*a, **k):
+            out = fn(*a, **k)
+            rec(out, a)
+            return out
+        return inner
+
+    m.encode_frames = wrap("encode_frames", m.encode_frames,
+                           lambda o, a: cur.update(feat1=o[0], feat2=o[1], pos1=o[2], pos2=o[3]))
+
+    def rec_decode(o, a):
+        d1, d2 = list(o[0]), list(o[1])
+        cur.update(feat_fuse=a[0], dec1=d1, dec2=d2)
+    orig_decode = m.decode
+
+    def decode(*a):
+        d1, d2 = orig_decode(*a)
+        d1, d2 = list(d1), list(d2)
+        rec_decode((d1, d2), a)
+        return d1, d2
+    m.decode = decode
+
+    orig_key = m.encode_feat_key
+
+    def key(f1, f2, num=1):
+        o = orig_key(f1, f2, num)
+        cur["feat_k%d" % num] = o
+        return o
+    m.encode_feat_key = key
+
+    orig_head = m.downstream_head
+
+    def head(dec, shape, num=1):
+        o = orig_head(dec, shape, num)
+        cur["pts%d" % num] = o["pts3d"].clone()
+        cur["conf%d" % num] = o["conf"].clone()
+        return o
+    m.downstream_head = head
+
+    orig_val = m.encode_cur_value
+
+    def val(*a):
+        o = orig_val(*a)
+        cur["cur_v"] = o
+        steps.append(dict(cur))
+        cur.clear()
+        return o
+    m.encode_cur_value = val
+
+    reads = []
+    orig_read = SpatialMemory.memory_read
+
+    def read(self, feat, res=True):
+        o = orig_read(self, feat, res)
+        reads.append(o)
+        return o
+    SpatialMemory.memory_read = read
+    try:
+        with torch.no_grad():
+            preds, preds_all, sp = m(frames, return_memory=True)
+    finally:
+        SpatialMemory.memory_read = orig_read
+    return preds, preds_all, sp, steps
+
+
+def npf(t):
+    return t.detach().cpu().numpy().astype(np.float32)
+
+
+def make_tiny():
+    cfg, H, W, NF = TINY, 64, 80, 4
+    sd = synth_state_dict(0, cfg)
+    m = build_reference(cfg, sd, "tiny")
+    frames = synth_frames(NF, H, W)
+    preds, preds_all, sp, steps = run_with_taps(m, frames)
+    out = {"meta_hw": np.array([H, W]), "meta_frames": np.array(NF), "meta_seed": np.array(0),
+           "fingerprint": np.array(state_dict_fingerprint(sd))}
+    hooks = cfg.hooks
+    for i, s in enumerate(steps):
+        for k in ("feat1", "feat2", "feat_fuse", "feat_k1", "feat_k2", "cur_v", "pts1", "conf1", "pts2", "conf2"):
+            out["s%d_%s" % (i, k)] = npf(s[k])
+        for side in ("dec1", "dec2"):
+            for h in hooks:
+                if i == 0 or h == hooks[-1]:
+                    out["s%d_%s_%d" % (i, side, h)] = npf(s[side][h])
+    for j, p in enumerate(preds):
+        out["pred%d_pts" % j] = npf(p["pts3d" if j == 0 else "pts3d_in_other_view"])
+        out["pred%d_conf" % j] = npf(p["conf"])
+    out["mem_k"], out["mem_v"] = npf(sp.mem_k), npf(sp.mem_v)
+    out["mem_count"], out["mem_attn"] = npf(sp.mem_count), npf(sp.mem_attn)
+    out["mem_wm_lm"] = np.array([sp.wm, sp.lm])
+    # growing-bank (train-mode memory policy, dropout off) variant: final predictions only
+    m2 = build_reference(cfg, sd, "tiny")
+    m2.train()
+    m2.mem_dropout.eval()
+    with torch.no_grad():
+        preds_t, _, sp_t = m2(frames, return_memory=True)
+    for j, p in enumerate(preds_t):
+        out["train_pred%d_pts" % j] = npf(p["pts3d" if j == 0 else "pts3d_in_other_view"])
+        out["train_pred%d_conf" % j] = npf(p["conf"])
+    out["train_mem_attn"] = npf(sp_t.mem_attn)
+    np.savez_compressed(os.path.join(HERE, "spann3r_tiny.npz"), **out)
+    print("tiny: %d arrays" % len(out))
+
+
+def make_full():
+    cfg, H, W, NF = FULL, 224, 224, 5
+    sd = synth_state_dict(0, cfg)
+    m = build_reference(cfg, sd, "full")
+    frames = synth_frames(NF, H, W)
+    t = time.time()
+    preds, preds_all, sp, steps = run_with_taps(m, frames)
+    dt = time.time() - t
+    print("reference forward: %.2f s  (%.2f frames/s, %d threads)" % (dt, NF / dt, torch.get_num_threads()))
+    out = {"meta_hw": np.array([H, W]), "meta_frames": np.array(NF), "meta_seed": np.array(0),
+           "fingerprint": np.array(state_dict_fingerprint(sd)), "ref_seconds": np.array(dt),
+           "ref_threads": np.array(torch.get_num_threads())}
+    S = 4
+    for j, p in enumerate(preds):
+        pts = p["pts3d" if j == 0 else "pts3d_in_other_view"]
+        out["pred%d_pts_sub" % j] = npf(pts[:, ::S, ::S])
+        out["pred%d_conf_sub" % j] = npf(p["conf"][:, ::S, ::S])
+        out["pred%d_stats" % j] = np.array([float(pts.double().mean()), float(pts.double().abs().mean()),
+                                            float(p["conf"].double().mean())])
+    for i, s in enumerate(steps):
+        for k in ("feat2", "feat_fuse", "feat_k1", "feat_k2", "cur_v"):
+            out["s%d_%s_sub" % (i, k)] = npf(s[k][:, ::7, ::16])
+        out["s%d_dec1_last_sub" % i] = npf(s["dec1"][-1][:, ::7, ::16])
+        out["s%d_dec2_last_sub" % i] = npf(s["dec2"][-1][:, ::7, ::16])
+    out["mem_k_sub"], out["mem_v_sub"] = npf(sp.mem_k[:, ::7, ::16]), npf(sp.mem_v[:, ::7, ::16])
+    out["mem_count"], out["mem_attn"] = npf(sp.mem_count), npf(sp.mem_attn)
+    out["mem_wm_lm"] = np.array([sp.wm, sp.lm])
+    np.savez_compressed(os.path.join(HERE, "spann3r_full224.npz"), **out)
+    print("full224: %d arrays" % len(out))
+
+
+from memory_inputs import memory_inputs  # noqa: E402  (shared with the tests)
+
+
+def make_memory():
+    from spann3r.model import SpatialMemory
+    sd = synth_state_dict(0, TINY)
+    norms = {}
+    for n in ("norm_q", "norm_k", "norm_v"):
+        ln = torch.nn.LayerNorm(1024)
+        ln.weight.data.copy_(sd[n + ".weight"])
+        ln.bias.data.copy_(sd[n + ".bias"])
+        norms[n] = ln
+    sp = SpatialMemory(norms["norm_q"], norms["norm_k"], norms["norm_v"])
+    out = {"n_steps": np.array(32)}
+    events = []
+    with torch.no_grad():
+        for step in range(32):
+            k, v, q = memory_inputs(step)
+            if sp.mem_k is not None:
+                o = sp.memory_read(q, res=True)
+                out["read%d_sub" % step] = npf(o[:, ::7, ::16])
+                out["read%d_mean" % step] = np.array(float(o.double().mean()))
+            before = None if sp.mem_k is None else sp.mem_k.shape[1]
+            sp.add_mem_check(k, v)
+            after = sp.mem_k.shape[1]
+            events.append([step, -1 if before is None else before, after, sp.wm, sp.lm])
+    out["events"] = np.array(events)
+    out["mem_count"], out["mem_attn"] = npf(sp.mem_count), npf(sp.mem_attn)
+    out["mem_k_sub"], out["mem_v_sub"] = npf(sp.mem_k[:, :, ::64]), npf(sp.mem_v[:, :, ::64])
+    np.savez_compressed(os.path.join(HERE, "memory_bank.npz"), **out)
+    print("memory: events\n", np.array(events))
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["tiny", "full", "memory"]
+    if "tiny" in what:
+        make_tiny()
+    if "memory" in what:
+        make_memory()
+    if "full" in what:
+        make_full()

@@ -1,0 +1,94 @@
+"""Pins the CPU oracle (oracle/spann3r_oracle.py) against dumps of the unmodified reference
+(tests/golden/*.npz, produced by tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+from oracle import spann3r_oracle as O
+from spann3r_amd.config import TINY, FULL
+from spann3r_amd.weights import synth_frames, state_dict_fingerprint
+
+TOL = 2e-5   # oracle and reference are both torch-CPU fp32; only op grouping differs
+
+
+def test_fingerprint(tiny_sd):
+    g = load_golden("spann3r_tiny.npz")
+    assert state_dict_fingerprint(tiny_sd) == float(g["fingerprint"])
+
+
+def test_tiny_stages_and_outputs(tiny_sd):
+    g = load_golden("spann3r_tiny.npz")
+    H, W = map(int, g["meta_hw"])
+    frames = synth_frames(int(g["meta_frames"]), H, W)
+    taps = {}
+    preds, preds_all, mem = O.forward(frames, tiny_sd, TINY, return_memory=True, taps=taps)
+    worst = 0.0
+    for i, s in enumerate(taps["steps"]):
+        for k in ("feat1", "feat2", "feat_fuse", "feat_k1", "feat_k2", "cur_v", "pts1", "conf1", "pts2", "conf2"):
+            e = rel_err(s[k], g["s%d_%s" % (i, k)])
+            worst = max(worst, e)
+            assert e < TOL, (i, k, e)
+        for side in ("dec1", "dec2"):
+            for h in TINY.hooks:
+                key = "s%d_%s_%d" % (i, side, h)
+                if key in g:
+                    e = rel_err(s[side][h], g[key])
+                    assert e < TOL, (key, e)
+    for j, p in enumerate(preds):
+        assert rel_err(p["pts3d" if j == 0 else "pts3d_in_other_view"], g["pred%d_pts" % j]) < TOL
+        assert rel_err(p["conf"], g["pred%d_conf" % j]) < TOL
+    assert rel_err(mem.mem_k, g["mem_k"]) < TOL and rel_err(mem.mem_v, g["mem_v"]) < TOL
+    assert np.array_equal(mem.mem_count.numpy(), g["mem_count"])
+    assert rel_err(mem.mem_attn, g["mem_attn"]) < 1e-4
+    assert [mem.wm, mem.lm] == list(g["mem_wm_lm"])
+    # aliasing contract of the boundary: preds[j] is preds_all[j][0]
+    assert preds[0] is preds_all[0][0] and preds[-1] is preds_all[-1][1]
+
+
+def test_tiny_training_policy(tiny_sd):
+    g = load_golden("spann3r_tiny.npz")
+    H, W = map(int, g["meta_hw"])
+    frames = synth_frames(int(g["meta_frames"]), H, W)
+    preds, _, mem = O.forward(frames, tiny_sd, TINY, training_policy=True, return_memory=True)
+    for j, p in enumerate(preds):
+        assert rel_err(p["pts3d" if j == 0 else "pts3d_in_other_view"], g["train_pred%d_pts" % j]) < TOL
+        assert rel_err(p["conf"], g["train_pred%d_conf" % j]) < TOL
+    assert rel_err(mem.mem_attn, g["train_mem_attn"]) < 1e-4
+
+
+def test_memory_bank(tiny_sd):
+    """Stand-alone SpatialMemory: similarity skips, working->long-term hand-over, one prune."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location(
+        "make_golden_inputs", os.path.join(os.path.dirname(__file__), "golden", "memory_inputs.py"))
+    mi = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mi)
+    g = load_golden("memory_bank.npz")
+    mem = O.SpatialMemoryOracle(tiny_sd)
+    events = []
+    for step in range(int(g["n_steps"])):
+        k, v, q = mi.memory_inputs(step)
+        if mem.mem_k is not None:
+            o = mem.memory_read(q)
+            assert rel_err(o[:, ::7, ::16], g["read%d_sub" % step]) < 1e-4, step
+        before = -1 if mem.mem_k is None else mem.mem_k.shape[1]
+        mem.add_mem_check(k, v)
+        events.append([step, before, mem.mem_k.shape[1], mem.wm, mem.lm])
+    assert np.array_equal(np.array(events), g["events"])
+    assert np.array_equal(mem.mem_count.numpy(), g["mem_count"])
+    assert rel_err(mem.mem_attn, g["mem_attn"]) < 1e-4
+    assert rel_err(mem.mem_k[:, :, ::64], g["mem_k_sub"]) < 1e-6
+
+
+@pytest.mark.slow
+def test_full224(full_sd):
+    g = load_golden("spann3r_full224.npz")
+    assert state_dict_fingerprint(full_sd) == float(g["fingerprint"])
+    frames = synth_frames(int(g["meta_frames"]), 224, 224)
+    preds, _, mem = O.forward(frames, full_sd, FULL, return_memory=True)
+    for j, p in enumerate(preds):
+        pts = p["pts3d" if j == 0 else "pts3d_in_other_view"]
+        assert rel_err(pts[:, ::4, ::4], g["pred%d_pts_sub" % j]) < 1e-4
+        assert rel_err(p["conf"][:, ::4, ::4], g["pred%d_conf_sub" % j]) < 1e-4
+    assert rel_err(mem.mem_k[:, ::7, ::16], g["mem_k_sub"]) < 1e-4
