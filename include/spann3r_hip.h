@@ -1,0 +1,175 @@
+/*
+ * spann3r_hip.h -- C-ABI of libspann3r_hip.so: the MI355X (gfx950) hot-path kernels of
+ * Spann3R's per-frame forward.
+ *
+ * The reference is Python on PyTorch; its ONLY native FFI is the `curope` extension
+ * (`rope_2d`, croco/models/curope/curope.cpp:49-69).  Everything else on the hot path is an
+ * ATen op reached through nn.Module.forward.  This header therefore declares
+ *   (1) `sp3_rope_2d`   -- the drop-in for the curope FFI, and
+ *   (2) one entry point per ATen-level operator the reference's hot path calls, each citing the
+ *       reference call site(s) it replaces.
+ * A maintainer binds these with ctypes; spann3r_amd/lib.py is that binding.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in `_host`
+ *   - `stream` is a hipStream_t passed as void* (use the caller's CURRENT stream; the reference's
+ *     curope launches on stream 0, kernels.cu:102 -- a latent bug we do not reproduce)
+ *   - return value: 0 on success, non-zero error code otherwise; `sp3_last_error()` gives the text
+ *     (the Python binding raises RuntimeError, matching TORCH_CHECK -> RuntimeError)
+ *   - activations are fp32 in memory; `wdtype` selects the MFMA arithmetic:
+ *       SP3_F32  : v_mfma_f32_16x16x4_f32  (exact fp32; the <=1e-3 parity mode)
+ *       SP3_BF16 : v_mfma_f32_16x16x32_bf16 (bf16 operands, fp32 accumulate; the bench mode)
+ *   - no function allocates, frees or synchronises: all of them are hipGraph-capturable
+ */
+#ifndef SPANN3R_HIP_H
+#define SPANN3R_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { SP3_F32 = 0, SP3_BF16 = 1 };
+enum { SP3_ACT_NONE = 0, SP3_ACT_GELU = 1, SP3_ACT_RELU = 2 };
+enum { SP3_EPI_PLAIN = 0, SP3_EPI_ROPE_VT = 1, SP3_EPI_PIXSHUF = 2 };
+enum { SP3_LOAD_PLAIN = 0, SP3_LOAD_CONV3X3 = 1 };
+
+const char* sp3_last_error(void);
+int sp3_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * sp3_gemm : C = epilogue( alpha * A[M,K] . W[N,K]^T )
+ * Replaces every nn.Linear / 1x1 Conv2d / 3x3 Conv2d / ConvTranspose2d(k==stride) / einsum on the
+ * path: croco/models/blocks.py:74-77,97,110,154-156,167 ; dust3r/model.py:190-191 ;
+ * spann3r/model.py:154,174,301,309 ; croco/models/dpt_block.py:33-75,95-113,180-188,318-324,
+ * 356-410 ; dust3r/patch_embed.py:24 (after sp3_im2col_patch).
+ * A is fp32 [M, lda]; W is [N, K] in `wdtype`; bias fp32 [N].
+ * loader CONV3X3: A is an NHWC fp32 map [batchless B*H*W, Cin]; row m = output pixel, K = 9*Cin
+ *                 ordered (tap, ci); pad 1; stride conv_stride.
+ * epilogue ROPE_VT (fused qkv / kv / q projection of an attention layer): columns
+ *   [0, rope_cols) get bias then 2-D RoPE (tables + per-row int32 (y,x) positions) and are stored
+ *   row-major to C (ldc) in `wdtype`; columns >= rope_cols are V: stored transposed per head to
+ *   vt[((b*heads + h)*64 + d) * vt_ld + n] in `wdtype` (head_dim is 64 on this path).
+ * epilogue PIXSHUF: N = ks*ks*Cout, ConvTranspose2d(k=s=ks) scatter into NHWC [B, ks*H, ks*W, Cout].
+ */
+typedef struct sp3_gemm_desc {
+  const float* A;
+  const float* A2;        /* optional second A source for k >= K1 (torch.cat(..., dim=-1) without the copy:
+                             spann3r/model.py:300); K1 % 64 == 0; A2 row stride lda2 */
+  const void* W;
+  void* C;
+  const float* bias;
+  const float* res1;      /* optional residuals, added after activation: C += res1 (+ res2) */
+  const float* res2;
+  int32_t M, N, K;
+  int32_t batch;          /* grid.y; strides below in elements */
+  int32_t K1;             /* k < K1 reads A, k >= K1 reads A2 (set K1 = K when A2 is null) */
+  int64_t lda, lda2, ldw, ldc, ldr1, ldr2;   /* ldw: W row stride (>= K) */
+  int64_t strideA, strideW, strideC;
+  float alpha;
+  int32_t wdtype;         /* SP3_F32 | SP3_BF16 : dtype of W and of the MFMA */
+  int32_t act;            /* SP3_ACT_* applied after bias */
+  int32_t out_bf16;       /* plain epilogue: store C as bf16 instead of fp32 */
+  int32_t relu_in;        /* apply ReLU to A on load (ResidualConvUnit pre-activation) */
+  int32_t loader;         /* SP3_LOAD_* */
+  int32_t conv_H, conv_W, conv_C, conv_OH, conv_OW, conv_stride;
+  int32_t epi;            /* SP3_EPI_* */
+  const float* rope_cos;  /* [max_pos, 16] */
+  const float* rope_sin;
+  const int32_t* pos;     /* [M, 2] (y, x) */
+  int32_t rope_cols;
+  void* vt;
+  int32_t tokens;         /* rows per image (N tokens): b = m / tokens, n = m % tokens */
+  int32_t heads;
+  int64_t vt_ld;
+  int32_t ps_k, ps_H, ps_W, ps_C;
+  int32_t tile;           /* -1 auto; 0: 32x32 split-K4; 1: 64x64; 2: 64x128 */
+} sp3_gemm_desc;
+int sp3_gemm(const sp3_gemm_desc* desc_host, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * sp3_layernorm : nn.LayerNorm over the last dim (croco/models/blocks.py:128-129,187-190 eps 1e-6;
+ * dust3r/model.py:153,204; spann3r/model.py:154,174,308 -- norm_q/k/v eps 1e-5).
+ * x fp32 [rows, ldx] -> out [rows, ldo] (fp32, or bf16 if out_bf16). C % 4 == 0, C <= 4096.
+ */
+int sp3_layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
+                  void* out, int64_t ldo, int out_bf16, int rows, int C, void* stream);
+/* Same, but stores the result TRANSPOSED: out[c * ldo + row] (used to append LN_v(value) columns
+ * to the [1024, capacity] V^T bank of the spatial memory). */
+int sp3_layernorm_t(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
+                    void* out, int64_t ldo, int out_bf16, int rows, int C, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * sp3_rope_2d : drop-in for curope.rope_2d (curope.cpp:49-69, kernels.cu:17-108).
+ * tokens [B,N,H,D] modified in place; element (b,n,h,d) at tokens + b*sB + n*sN + h*sH + d
+ * (the reference only requires stride(3)==1 && stride(2)==D, kernels.cu:91; sH generalises it);
+ * positions int64 [B,N,2] contiguous; D % 4 == 0; dtype SP3_F32 | SP3_BF16; fwd = +1 / -1.
+ */
+int sp3_rope_2d(void* tokens, int dtype, int B, int N, int H, int D, int64_t sB, int64_t sN, int64_t sH,
+                const int64_t* positions, float base, float fwd, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * sp3_attention : softmax(q k^T * scale) v per head, head_dim 64
+ * (croco/models/blocks.py:105-109 and 162-166).  q [B,Nq,heads,64] / k [B,Nk,heads,64] with row
+ * strides ldq/ldk and batch strides sq/sk (elements, `dtype`), already RoPE'd; vt as written by
+ * the ROPE_VT epilogue; out fp32 [B*Nq, ldo] with head h at columns [64h, 64h+64).
+ */
+int sp3_attention(const void* q, int64_t sq, int64_t ldq, const void* k, int64_t sk, int64_t ldk,
+                  const void* vt, int64_t vt_ld, float* out, int64_t ldo,
+                  int B, int heads, int Nq, int Nk, float scale, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Spatial-memory kernels (spann3r/model.py:97-210).
+ * sp3_softmax_thresh: rows of S fp32 [rows, ld] -> P fp32 [rows, ld]: softmax over the first M
+ *   columns; if thresh > 0, p < thresh -> 0 and renormalise (:160,170-172); columns [M, Mpad) are
+ *   written as 0 so that P can be the A operand of the P.V GEMM.  batch in grid.y via strideS.
+ * sp3_colsum_accum : mem_attn[j] += sum_r P[r, j]  (:180-181).
+ * sp3_cos_sim      : score[t] = mean_p cos(k[p,:], wm[t,p,:]) for t < T (:102-112); k fp32 [P,C],
+ *   wm fp32 [T,P,C] contiguous. Deterministic reduction order.
+ * sp3_mem_append   : count[0..M) += 1; count[M..M+P) = 0; attn[M..M+P) = 0  (:84-90).
+ * sp3_prune_select : w = attn/count, w[count < protect] = 1e8; sel[0..top_k) = indices of the top_k
+ *   weights, sorted by weight descending, ties by index ascending (:187-193). M <= 8192.
+ * sp3_gather_rows  : dst[i, :] = src[sel[i], :] (row gather of a [*, C] matrix, elem_size bytes/elem).
+ * sp3_gather_cols  : dst[c, i] = src[c, sel[i]] for c < C (the V^T bank), zero-fills [n_sel, n_fill).
+ * sp3_gather_1d    : dst[i] = src[sel[i]] fp32.
+ */
+int sp3_softmax_thresh(const float* S, float* P, int64_t ld, int64_t strideS, int rows, int M, int Mpad,
+                       float thresh, int batch, void* stream);
+int sp3_colsum_accum(const float* P, int64_t ld, int rows, int M, float* mem_attn, void* stream);
+int sp3_cos_sim(const float* k, const float* wm, int T, int P, int C, float* score, void* stream);
+int sp3_mem_append(float* count, float* attn, int M, int P, void* stream);
+int sp3_prune_select(const float* attn, const float* count, int M, float protect, int top_k,
+                     int32_t* sel, void* stream);
+int sp3_gather_rows(const void* src, void* dst, const int32_t* sel, int n_sel, int C, int elem_size, void* stream);
+int sp3_gather_cols(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, const int32_t* sel, int n_sel,
+                    int n_fill, int C, int elem_size, void* stream);
+int sp3_gather_1d(const float* src, float* dst, const int32_t* sel, int n_sel, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * DPT-head helpers (all maps NHWC fp32).
+ * sp3_im2col_patch : non-overlapping p x p patches -> rows [B*(H/p)*(W/p), C*p*p], k = (c, py, px)
+ *   so the Conv2d weight [E, C, p, p] is used unchanged as W[E, C*p*p] (dust3r/patch_embed.py:24,
+ *   spann3r/model.py:317). Source element (b,c,y,x) at img + b*sb + c*sc + y*sy + x*sx.
+ * sp3_upsample2x   : F.interpolate(scale_factor=2, mode='bilinear', align_corners=True)
+ *   (croco/models/dpt_block.py:214-216, 253-258) on [B,H,W,C] -> [B,2H,2W,C]; optional crop of the
+ *   output to [outH, outW] (dust3r/heads/dpt_head.py:57).
+ * sp3_head_final   : head.4 1x1 conv (128->4) + postprocess (dust3r/heads/postprocess.py:22-58):
+ *   pts3d = xyz/max(|xyz|,1e-8) * expm1(|xyz|), conf = 1 + exp(c).  feat [pixels, C] fp32,
+ *   w fp32 [4, C], b fp32 [4] -> pts [pixels,3], conf [pixels], raw [pixels,4] (optional).
+ */
+int sp3_im2col_patch(const float* img, int64_t sb, int64_t sc, int64_t sy, int64_t sx, int B, int C, int H, int W,
+                     int p, float* out, void* stream);
+int sp3_upsample2x(const float* in, float* out, int B, int H, int W, int C, int outH, int outW, void* stream);
+int sp3_head_final(const float* feat, const float* w, const float* b, int64_t pixels, int C, float* pts,
+                   float* conf, float* raw, void* stream);
+
+/* small utilities */
+int sp3_copy2d_f32(const float* src, int64_t lds, float* dst, int64_t ldd, int rows, int cols, void* stream);
+int sp3_fill_f32(float* p, float v, int64_t n, void* stream);
+int sp3_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,186 @@
+// sp3_attention: softmax(q k^T * scale) v for head_dim 64 on gfx950, flash-style (online softmax),
+// one wave per 16 query rows, all operands streamed straight from global/L2 into MFMA registers.
+//
+// Layout trick (DESIGN.md §"Attention"): compute S^T = K.Q^T and O^T = V^T.P^T, i.e. keys / head-dim
+// on the MFMA row axis and the 16 query rows on the MFMA column axis (lane&15).  Then
+//   * a lane owns ONE query row q = lane&15 in both S^T and O^T: row max, row sum and the online
+//     rescale are lane-local (plus two shuffles across the four 16-lane groups);
+//   * the exponentiated probabilities a lane holds (keys 16t+4g+r, g = lane>>4) are exactly the
+//     B-operand slots of the P^T operand of the second MFMA: P never leaves registers;
+//   * V is consumed as V^T[d][key], which the QKV GEMM epilogue writes directly (per head, key axis
+//     contiguous, zero padded), so the A operand of the second MFMA is contiguous 8/16-byte loads.
+// bf16: v_mfma_f32_16x16x32_bf16; fp32: v_mfma_f32_16x16x4_f32 (exact fp32, parity mode).
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+template <typename T> struct AttnT;
+
+template <> struct AttnT<__bf16> {
+  // ---- S^T block: 16 keys x 16 queries, contraction over d = 64 in two MFMAs
+  struct QReg { bf16x8 v[2]; };
+  static __device__ __forceinline__ void loadQ(QReg& r, const __bf16* row, int g) {
+    r.v[0] = *reinterpret_cast<const bf16x8*>(row + 8 * g);
+    r.v[1] = *reinterpret_cast<const bf16x8*>(row + 32 + 8 * g);
+  }
+  static __device__ __forceinline__ f32x4 qk(const __bf16* krow, int g, const QReg& q) {
+    const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(krow + 8 * g);
+    const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(krow + 32 + 8 * g);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, q.v[0], s, 0, 0, 0);
+    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, q.v[1], s, 0, 0, 0);
+    return s;
+  }
+  // ---- O^T += V^T . P^T over the 64 keys of a tile: p[t][r] is key 16t+4g+r of query lane&15
+  static __device__ __forceinline__ void pv(f32x4 (&o)[4], const __bf16* vt_head, int64_t vt_ld, int kbase, int g,
+                                            int dl, const f32x4 (&p)[4]) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      bf16x8 pb;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pb[j] = (__bf16)p[2 * u + (j >> 2)][j & 3];
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        const __bf16* vr = vt_head + (int64_t)(db * 16 + dl) * vt_ld + kbase + 32 * u + 4 * g;
+        const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vr);
+        const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vr + 16);
+        bf16x8 va;
+        va[0] = lo[0]; va[1] = lo[1]; va[2] = lo[2]; va[3] = lo[3];
+        va[4] = hi[0]; va[5] = hi[1]; va[6] = hi[2]; va[7] = hi[3];
+        o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, pb, o[db], 0, 0, 0);
+      }
+    }
+  }
+};
+
+template <> struct AttnT<float> {
+  struct QReg { float4 v[4]; };
+  static __device__ __forceinline__ void loadQ(QReg& r, const float* row, int g) {
+    const float4* p = reinterpret_cast<const float4*>(row + 16 * g);
+    r.v[0] = p[0]; r.v[1] = p[1]; r.v[2] = p[2]; r.v[3] = p[3];
+  }
+  static __device__ __forceinline__ f32x4 qk(const float* krow, int g, const QReg& q) {
+    const float4* p = reinterpret_cast<const float4*>(krow + 16 * g);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 kv = p[i];
+      s = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.x, q.v[i].x, s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.y, q.v[i].y, s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.z, q.v[i].z, s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.w, q.v[i].w, s, 0, 0, 0);
+    }
+    return s;
+  }
+  static __device__ __forceinline__ void pv(f32x4 (&o)[4], const float* vt_head, int64_t vt_ld, int kbase, int g, int dl,
+                                            const f32x4 (&p)[4]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        const float4 va = *reinterpret_cast<const float4*>(vt_head + (int64_t)(db * 16 + dl) * vt_ld + kbase + 16 * t + 4 * g);
+        o[db] = __builtin_amdgcn_mfma_f32_16x16x4f32(va.x, p[t][0], o[db], 0, 0, 0);
+        o[db] = __builtin_amdgcn_mfma_f32_16x16x4f32(va.y, p[t][1], o[db], 0, 0, 0);
+        o[db] = __builtin_amdgcn_mfma_f32_16x16x4f32(va.z, p[t][2], o[db], 0, 0, 0);
+        o[db] = __builtin_amdgcn_mfma_f32_16x16x4f32(va.w, p[t][3], o[db], 0, 0, 0);
+      }
+    }
+  }
+};
+
+template <typename T>
+__global__ __launch_bounds__(64) void attention_kernel(const T* __restrict__ Q, int64_t sq, int64_t ldq,
+                                                       const T* __restrict__ K, int64_t sk, int64_t ldk,
+                                                       const T* __restrict__ VT, int64_t vt_ld, float* __restrict__ O,
+                                                       int64_t ldo, int heads, int Nq, int Nk, float scale) {
+  using A = AttnT<T>;
+  const int lane = threadIdx.x, g = lane >> 4, ql = lane & 15;
+  const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int q0 = qt * 16;
+  int qrow = q0 + ql;
+  qrow = qrow < Nq ? qrow : Nq - 1;
+  typename A::QReg qreg;
+  A::loadQ(qreg, Q + (int64_t)b * sq + (int64_t)qrow * ldq + h * 64, g);
+  const T* kbase_ptr = K + (int64_t)b * sk + h * 64;
+  const T* vt_head = VT + (int64_t)(b * heads + h) * 64 * vt_ld;
+
+  f32x4 o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+
+  for (int kb = 0; kb < Nk; kb += 64) {
+    f32x4 s[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      int krow = kb + 16 * t + ql;               // A-operand row = key
+      krow = krow < Nk ? krow : Nk - 1;
+      s[t] = A::qk(kbase_ptr + (int64_t)krow * ldk, g, qreg);
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kb + 16 * t + 4 * g + r;
+        const float v = key < Nk ? s[t][r] * scale : -INFINITY;
+        s[t][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);          // finite: every tile has >= 1 valid key
+    const float alpha = expf(m_run - m_new);       // exp(-inf) = 0 on the first tile
+    float ps = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = expf(s[t][r] - m_new);
+        s[t][r] = e;
+        ps += e;
+      }
+    l_run = l_run * alpha + ps;
+    m_run = m_new;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[db][r] *= alpha;
+    A::pv(o, vt_head, vt_ld, kb, g, ql, s);
+  }
+  l_run += __shfl_xor(l_run, 16);
+  l_run += __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l_run;
+  // O^T[d = 16*db + 4*g + r][q = lane&15]
+  if (q0 + ql < Nq) {
+    float* orow = O + ((int64_t)b * Nq + q0 + ql) * ldo + h * 64;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+      *reinterpret_cast<float4*>(orow + db * 16 + 4 * g) = make_float4(o[db][0] * inv, o[db][1] * inv, o[db][2] * inv, o[db][3] * inv);
+  }
+}
+
+}  // namespace
+
+extern "C" int sp3_attention(const void* q, int64_t sq, int64_t ldq, const void* k, int64_t sk, int64_t ldk, const void* vt,
+                             int64_t vt_ld, float* out, int64_t ldo, int B, int heads, int Nq, int Nk, float scale, int dtype,
+                             void* stream) {
+  SP3_CHECK(q && k && vt && out, "sp3_attention: null pointer");
+  SP3_CHECK(B > 0 && heads > 0 && Nq > 0 && Nk > 0, "sp3_attention: bad shape");
+  SP3_CHECK(vt_ld >= ((Nk + 63) / 64) * 64 && vt_ld % 8 == 0, "sp3_attention: vt_ld=%lld must be >= Nk padded to 64", (long long)vt_ld);
+  SP3_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && ldo % 4 == 0, "sp3_attention: row strides must keep 16-byte alignment");
+  SP3_CHECK(dtype == SP3_F32 || dtype == SP3_BF16, "sp3_attention: bad dtype %d", dtype);
+  dim3 grid((Nq + 15) / 16, heads, B);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == SP3_BF16)
+    hipLaunchKernelGGL(attention_kernel<__bf16>, grid, dim3(64), 0, st, reinterpret_cast<const __bf16*>(q), sq, ldq,
+                       reinterpret_cast<const __bf16*>(k), sk, ldk, reinterpret_cast<const __bf16*>(vt), vt_ld, out, ldo,
+                       heads, Nq, Nk, scale);
+  else
+    hipLaunchKernelGGL(attention_kernel<float>, grid, dim3(64), 0, st, reinterpret_cast<const float*>(q), sq, ldq,
+                       reinterpret_cast<const float*>(k), sk, ldk, reinterpret_cast<const float*>(vt), vt_ld, out, ldo, heads,
+                       Nq, Nk, scale);
+  SP3_LAUNCH_CHECK("sp3_attention");
+  return 0;
+}

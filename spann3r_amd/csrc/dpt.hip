@@ -1,0 +1,136 @@
+// DPT-head helpers: patch im2col, bilinear x2 (align_corners=True), final 1x1 conv + postprocess.
+// All feature maps are NHWC fp32 so that 1x1 convs are plain sp3_gemm calls on the token matrix and
+// 3x3 convs are sp3_gemm's implicit-GEMM loader (reference: croco/models/dpt_block.py, dust3r/heads).
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+// out[(b*nh*nw + py_*nw + px_), c*p*p + iy*p + ix] = img[b, c, py_*p+iy, px_*p+ix]  (generic strides)
+__global__ __launch_bounds__(256) void im2col_patch_kernel(const float* __restrict__ img, int64_t sb, int64_t sc, int64_t sy,
+                                                           int64_t sx, int C, int H, int W, int p, float* __restrict__ out,
+                                                           int64_t total) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int K = C * p * p;
+  const int64_t row = idx / K;
+  const int k = (int)(idx - row * K);
+  const int nw = W / p, nh = H / p;
+  const int b = (int)(row / (nh * nw));
+  const int rem = (int)(row - (int64_t)b * nh * nw);
+  const int ty = rem / nw, tx = rem - ty * nw;
+  const int c = k / (p * p), r2 = k - c * p * p;
+  const int iy = r2 / p, ix = r2 - iy * p;
+  out[idx] = img[b * sb + c * sc + (int64_t)(ty * p + iy) * sy + (int64_t)(tx * p + ix) * sx];
+}
+
+// F.interpolate(scale_factor=2, bilinear, align_corners=True) on NHWC; optional crop to [outH,outW].
+// Source index as ATen computes it: scale = (in-1)/(out-1) in float, src = scale * dst.
+__global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W,
+                                                         int C, int outH, int outW, int64_t total4) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total4) return;
+  const int c4 = C >> 2;
+  const int cc = (int)(idx % c4);
+  int64_t pix = idx / c4;
+  const int ox = (int)(pix % outW);
+  pix /= outW;
+  const int oy = (int)(pix % outH);
+  const int b = (int)(pix / outH);
+  const int OH = 2 * H, OW = 2 * W;
+  const float sh = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
+  const float sw = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
+  const float fy = sh * (float)oy, fx = sw * (float)ox;
+  int y0 = (int)fy, x0 = (int)fx;
+  y0 = y0 < H - 1 ? y0 : H - 1;
+  x0 = x0 < W - 1 ? x0 : W - 1;
+  const int y1 = y0 < H - 1 ? y0 + 1 : y0, x1 = x0 < W - 1 ? x0 + 1 : x0;
+  const float ly = fy - (float)y0, lx = fx - (float)x0;
+  const float hy = 1.f - ly, hx = 1.f - lx;
+  const float4* base = reinterpret_cast<const float4*>(in + (int64_t)b * H * W * C);
+  const float4 v00 = base[((int64_t)y0 * W + x0) * c4 + cc];
+  const float4 v01 = base[((int64_t)y0 * W + x1) * c4 + cc];
+  const float4 v10 = base[((int64_t)y1 * W + x0) * c4 + cc];
+  const float4 v11 = base[((int64_t)y1 * W + x1) * c4 + cc];
+  float4 o;
+  // same association as ATen's upsample_bilinear2d: hy*(hx*v00 + lx*v01) + ly*(hx*v10 + lx*v11)
+  o.x = hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
+  o.y = hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
+  o.z = hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
+  o.w = hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
+  reinterpret_cast<float4*>(out)[idx] = o;
+}
+
+// 8 lanes per pixel: each lane dots C/8 channels against the 4 output filters, xor-shuffle reduce.
+__global__ __launch_bounds__(256) void head_final_kernel(const float* __restrict__ feat, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, int64_t pixels, int C,
+                                                         float* __restrict__ pts, float* __restrict__ conf,
+                                                         float* __restrict__ raw) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t pix = gid >> 3;
+  const int sub = (int)(gid & 7);
+  const bool valid = pix < pixels;
+  const int64_t pp = valid ? pix : pixels - 1;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  const float* f = feat + pp * C;
+  for (int c = sub * 4; c < C; c += 32) {
+    const float4 x = *reinterpret_cast<const float4*>(f + c);
+    const float4 w0 = *reinterpret_cast<const float4*>(w + c);
+    const float4 w1 = *reinterpret_cast<const float4*>(w + C + c);
+    const float4 w2 = *reinterpret_cast<const float4*>(w + 2 * C + c);
+    const float4 w3 = *reinterpret_cast<const float4*>(w + 3 * C + c);
+    a0 += (x.x * w0.x + x.y * w0.y) + (x.z * w0.z + x.w * w0.w);
+    a1 += (x.x * w1.x + x.y * w1.y) + (x.z * w1.z + x.w * w1.w);
+    a2 += (x.x * w2.x + x.y * w2.y) + (x.z * w2.z + x.w * w2.w);
+    a3 += (x.x * w3.x + x.y * w3.y) + (x.z * w3.z + x.w * w3.w);
+  }
+#pragma unroll
+  for (int o = 1; o < 8; o <<= 1) {
+    a0 += __shfl_xor(a0, o); a1 += __shfl_xor(a1, o); a2 += __shfl_xor(a2, o); a3 += __shfl_xor(a3, o);
+  }
+  if (valid && sub == 0) {
+    const float x = a0 + bias[0], y = a1 + bias[1], z = a2 + bias[2], c = a3 + bias[3];
+    if (raw) { raw[pix * 4 + 0] = x; raw[pix * 4 + 1] = y; raw[pix * 4 + 2] = z; raw[pix * 4 + 3] = c; }
+    // dust3r/heads/postprocess.py:36-46: d = |xyz|; xyz / clip(d, 1e-8) * expm1(d)
+    const float d = sqrtf(x * x + y * y + z * z);
+    const float sc = expm1f(d) / fmaxf(d, 1e-8f);
+    pts[pix * 3 + 0] = x * sc; pts[pix * 3 + 1] = y * sc; pts[pix * 3 + 2] = z * sc;
+    conf[pix] = 1.0f + expf(c);                                   // postprocess.py:54
+  }
+}
+
+}  // namespace
+
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+
+extern "C" int sp3_im2col_patch(const float* img, int64_t sb, int64_t sc, int64_t sy, int64_t sx, int B, int C, int H, int W,
+                                int p, float* out, void* stream) {
+  SP3_CHECK(img && out && B > 0 && C > 0 && p > 0, "sp3_im2col_patch: bad arguments");
+  // same assertion as dust3r/patch_embed.py:22-23
+  SP3_CHECK(H % p == 0 && W % p == 0, "Input image size (%d,%d) is not a multiple of patch size (%d)", H, W, p);
+  const int64_t total = (int64_t)B * (H / p) * (W / p) * C * p * p;
+  hipLaunchKernelGGL(im2col_patch_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ST(stream), img, sb, sc, sy, sx,
+                     C, H, W, p, out, total);
+  SP3_LAUNCH_CHECK("sp3_im2col_patch");
+  return 0;
+}
+
+extern "C" int sp3_upsample2x(const float* in, float* out, int B, int H, int W, int C, int outH, int outW, void* stream) {
+  SP3_CHECK(in && out && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "sp3_upsample2x: bad arguments");
+  SP3_CHECK(outH > 0 && outH <= 2 * H && outW > 0 && outW <= 2 * W, "sp3_upsample2x: bad crop");
+  const int64_t total4 = (int64_t)B * outH * outW * (C / 4);
+  hipLaunchKernelGGL(upsample2x_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, ST(stream), in, out, H, W, C,
+                     outH, outW, total4);
+  SP3_LAUNCH_CHECK("sp3_upsample2x");
+  return 0;
+}
+
+extern "C" int sp3_head_final(const float* feat, const float* w, const float* b, int64_t pixels, int C, float* pts, float* conf,
+                              float* raw, void* stream) {
+  SP3_CHECK(feat && w && b && pts && conf && pixels > 0 && C > 0 && C % 32 == 0, "sp3_head_final: bad arguments");
+  const int64_t threads = pixels * 8;
+  hipLaunchKernelGGL(head_final_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ST(stream), feat, w, b, pixels, C,
+                     pts, conf, raw);
+  SP3_LAUNCH_CHECK("sp3_head_final");
+  return 0;
+}

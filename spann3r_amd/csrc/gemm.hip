@@ -1,0 +1,458 @@
+// sp3_gemm: MFMA GEMM / implicit-GEMM convolution for gfx950 (MI355X).
+//
+//   C[M,N] = epilogue(alpha * A[M,K] . W[N,K]^T)
+//
+// Design (DESIGN.md §"GEMM"):
+//  * The hot path is small-M (M = 196 tokens) weight streaming: 1.3 GB of bf16 weights per frame,
+//    AI ~= 265 FLOP/B.  Every wave streams its operands STRAIGHT from global memory into MFMA
+//    operand registers (no LDS staging, no barrier in the K loop) with a register double buffer,
+//    so a workgroup's latency chain is K/(WK*KB) dependent round trips.
+//  * Both operands are K-contiguous (nn.Linear layout), so the contraction index may be permuted
+//    freely as long as A and W use the same permutation: lane group g = lane>>4 owns CH contiguous
+//    elements [kb*KB + g*CH, +CH) of every row -> each row is read as ONE contiguous 128-byte line
+//    per k-block (bf16) instead of the 64-byte fragment-shaped pieces of the textbook mapping.
+//  * Small-M tiles (32x32) split K over the 4 waves of the workgroup (WK=4) and reduce through LDS;
+//    large-M tiles (64x64, 64x128) give each wave its own output sub-tile.  Either way the
+//    accumulators go through LDS once, which decouples the MFMA C layout from the store layout:
+//    the epilogue (bias, exact-erf GELU / ReLU, residuals, 2-D RoPE, per-head V^T store,
+//    ConvTranspose pixel-shuffle) runs on coalesced 16-byte row segments.
+//  * blockIdx -> tile mapping is XCD-aware (block b runs on XCD b%8): all tiles that share a weight
+//    panel (small M) or an activation panel (large M) are placed on the same XCD, adjacent in
+//    dispatch order, so the shared panel is fetched from HBM/MALL into ONE L2.
+//  * fp32 mode uses v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain), bf16 mode v_mfma_f32_16x16x32_bf16
+//    with fp32 activations converted on load (v_cvt_pk_bf16_f32) and fp32 accumulation.
+#include "common.h"
+
+namespace {
+
+struct GemmArgs {
+  sp3_gemm_desc d;
+};
+
+// ------------------------------------------------------------------ per-dtype operand handling
+template <typename TW> struct MM;
+
+template <> struct MM<__bf16> {
+  static constexpr int KB = 64;   // k elements per block
+  static constexpr int CH = 16;   // k elements per lane per block
+  struct AReg { float4 v[4]; };
+  struct WReg { bf16x8 v[2]; };
+  static __device__ __forceinline__ void loadA(AReg& r, const float* p, bool v0, bool v1, bool relu) {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4* q = reinterpret_cast<const float4*>(p);
+    const float4* q1 = v1 ? q + 2 : q;       // never touch bytes past K
+    r.v[0] = q[0]; r.v[1] = q[1]; r.v[2] = q1[0]; r.v[3] = q1[1];
+    if (!v0) { r.v[0] = z; r.v[1] = z; }
+    if (!v1) { r.v[2] = z; r.v[3] = z; }
+    if (relu) { r.v[0] = relu4(r.v[0]); r.v[1] = relu4(r.v[1]); r.v[2] = relu4(r.v[2]); r.v[3] = relu4(r.v[3]); }
+  }
+  static __device__ __forceinline__ void loadW(WReg& r, const __bf16* p, bool v0, bool v1) {
+    const bf16x8* q = reinterpret_cast<const bf16x8*>(p);
+    bf16x8 z;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) z[i] = (__bf16)0.f;
+    r.v[0] = q[0]; r.v[1] = v1 ? q[1] : q[0];
+    if (!v0) r.v[0] = z;
+    if (!v1) r.v[1] = z;
+  }
+  template <int MF, int NF>
+  static __device__ __forceinline__ void mma(f32x4 (&acc)[MF][NF], const AReg (&a)[MF], const WReg (&w)[NF]) {
+#pragma unroll
+    for (int m = 0; m < MF; ++m) {
+      const bf16x8 a0 = cvt8(a[m].v[0], a[m].v[1]);
+      const bf16x8 a1 = cvt8(a[m].v[2], a[m].v[3]);
+#pragma unroll
+      for (int n = 0; n < NF; ++n) {
+        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, w[n].v[0], acc[m][n], 0, 0, 0);
+        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, w[n].v[1], acc[m][n], 0, 0, 0);
+      }
+    }
+  }
+};
+
+template <> struct MM<float> {
+  static constexpr int KB = 32;
+  static constexpr int CH = 8;
+  struct AReg { float4 v[2]; };
+  struct WReg { float4 v[2]; };
+  static __device__ __forceinline__ void loadA(AReg& r, const float* p, bool v0, bool v1, bool relu) {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4* q = reinterpret_cast<const float4*>(p);
+    r.v[0] = q[0]; r.v[1] = v1 ? q[1] : q[0];
+    if (!v0) r.v[0] = z;
+    if (!v1) r.v[1] = z;
+    if (relu) { r.v[0] = relu4(r.v[0]); r.v[1] = relu4(r.v[1]); }
+  }
+  static __device__ __forceinline__ void loadW(WReg& r, const float* p, bool v0, bool v1) {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4* q = reinterpret_cast<const float4*>(p);
+    r.v[0] = q[0]; r.v[1] = v1 ? q[1] : q[0];
+    if (!v0) r.v[0] = z;
+    if (!v1) r.v[1] = z;
+  }
+  template <int MF, int NF>
+  static __device__ __forceinline__ void mma(f32x4 (&acc)[MF][NF], const AReg (&a)[MF], const WReg (&w)[NF]) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int m = 0; m < MF; ++m) {
+#pragma unroll
+        for (int n = 0; n < NF; ++n) {
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].v[h].x, w[n].v[h].x, acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].v[h].y, w[n].v[h].y, acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].v[h].z, w[n].v[h].z, acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].v[h].w, w[n].v[h].w, acc[m][n], 0, 0, 0);
+        }
+      }
+    }
+  }
+};
+
+// ------------------------------------------------------------------ A-row addressing
+// PLAIN: row m at A + m*lda.  CONV3X3: row m is output pixel (b, oy, ox) of an NHWC map.
+template <int LOADER, int MF> struct ARows;
+
+template <int MF> struct ARows<SP3_LOAD_PLAIN, MF> {
+  const float* base[MF];
+  const float* base2[MF];
+  __device__ __forceinline__ void init(const sp3_gemm_desc& d, const float* A, int row0, int lane) {
+#pragma unroll
+    for (int m = 0; m < MF; ++m) {
+      int r = row0 + m * 16 + (lane & 15);
+      r = r < d.M ? r : d.M - 1;
+      base[m] = A + (int64_t)r * d.lda;
+      base2[m] = d.A2 ? d.A2 + (int64_t)r * d.lda2 - d.K1 : base[m];
+    }
+  }
+  // pointer of this lane's chunk starting at k (k < K guaranteed by caller through clamping)
+  __device__ __forceinline__ const float* ptr(const sp3_gemm_desc& d, int m, int k, bool& inb) const {
+    inb = true;
+    return (k < d.K1 ? base[m] : base2[m]) + k;
+  }
+};
+
+template <int MF> struct ARows<SP3_LOAD_CONV3X3, MF> {
+  const float* img[MF];
+  int iy0[MF], ix0[MF];
+  const float* safe;
+  __device__ __forceinline__ void init(const sp3_gemm_desc& d, const float* A, int row0, int lane) {
+    safe = A;
+#pragma unroll
+    for (int m = 0; m < MF; ++m) {
+      int r = row0 + m * 16 + (lane & 15);
+      r = r < d.M ? r : d.M - 1;
+      const int per = d.conv_OH * d.conv_OW;
+      const int b = r / per;
+      const int rem = r - b * per;
+      const int oy = rem / d.conv_OW;
+      const int ox = rem - oy * d.conv_OW;
+      img[m] = A + (int64_t)b * d.conv_H * d.conv_W * d.conv_C;
+      iy0[m] = oy * d.conv_stride - 1;
+      ix0[m] = ox * d.conv_stride - 1;
+    }
+  }
+  __device__ __forceinline__ const float* ptr(const sp3_gemm_desc& d, int m, int k, bool& inb) const {
+    const int tap = k / d.conv_C;
+    const int ci = k - tap * d.conv_C;
+    const int dy = tap / 3;
+    const int iy = iy0[m] + dy;
+    const int ix = ix0[m] + (tap - dy * 3);
+    inb = (iy >= 0) && (iy < d.conv_H) && (ix >= 0) && (ix < d.conv_W);
+    return inb ? img[m] + ((int64_t)iy * d.conv_W + ix) * d.conv_C + ci : safe;
+  }
+};
+
+// ------------------------------------------------------------------ the kernel
+template <typename TW, int LOADER, int MF, int NF, int WM, int WN, int WK>
+__global__ __launch_bounds__(64 * WM * WN * WK) void gemm_kernel(const GemmArgs args) {
+  const sp3_gemm_desc& d = args.d;
+  using M_ = MM<TW>;
+  constexpr int BM = MF * 16 * WM, BN = NF * 16 * WN, NT = 64 * WM * WN * WK;
+  constexpr int KB = M_::KB, CH = M_::CH;
+  constexpr int LDS_LD = BN + 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [WK][BM][LDS_LD]
+
+  const int mt = (d.M + BM - 1) / BM, nt = (d.N + BN - 1) / BN;
+  // XCD-aware tile mapping (block b -> XCD b & 7); grid is padded, out-of-range tiles exit.
+  int tile_m, tile_n;
+  {
+    const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
+    if (mt >= nt) {          // large M: the tiles that share an A panel sit on one XCD
+      tile_n = j % nt;
+      tile_m = (j / nt) * 8 + xcd;
+    } else {                 // small M: the tiles that share a W panel sit on one XCD
+      tile_m = j % mt;
+      tile_n = (j / mt) * 8 + xcd;
+    }
+  }
+  if (tile_m >= mt || tile_n >= nt) return;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
+  const int g = lane >> 4;
+  const int bz = blockIdx.y;
+  const float* A = d.A + (int64_t)bz * d.strideA;
+  const TW* W = reinterpret_cast<const TW*>(d.W) + (int64_t)bz * d.strideW;
+
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  ARows<LOADER, MF> arows;
+  arows.init(d, A, m0 + wm * MF * 16, lane);
+  const TW* wrow[NF];
+#pragma unroll
+  for (int n = 0; n < NF; ++n) {
+    int c = n0 + wn * NF * 16 + n * 16 + (lane & 15);
+    c = c < d.N ? c : d.N - 1;
+    wrow[n] = W + (int64_t)c * d.ldw;
+  }
+
+  f32x4 acc[MF][NF];
+#pragma unroll
+  for (int m = 0; m < MF; ++m)
+#pragma unroll
+    for (int n = 0; n < NF; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nkb = (d.K + KB - 1) / KB;
+  const bool relu = d.relu_in != 0;
+
+  typename M_::AReg a0[MF], a1[MF];
+  typename M_::WReg w0[NF], w1[NF];
+
+  auto load = [&](typename M_::AReg (&a)[MF], typename M_::WReg (&w)[NF], int kb) {
+    const int k = kb * KB + g * CH;
+    const bool v0 = k < d.K, v1 = (k + CH / 2) < d.K;
+    const int kc = v0 ? k : 0;              // clamp: always a legal address, zeroed by v0/v1
+#pragma unroll
+    for (int m = 0; m < MF; ++m) {
+      bool inb;
+      const float* p = arows.ptr(d, m, kc, inb);
+      M_::loadA(a[m], p, v0 && inb, v1 && inb, relu);
+    }
+#pragma unroll
+    for (int n = 0; n < NF; ++n) M_::loadW(w[n], wrow[n] + kc, v0, v1);
+  };
+
+  int kb = wk;
+  if (kb < nkb) {
+    load(a0, w0, kb);
+    for (;;) {
+      const bool has1 = (kb + WK) < nkb;
+      if (has1) load(a1, w1, kb + WK);
+      M_::template mma<MF, NF>(acc, a0, w0);
+      if (!has1) break;
+      const bool has2 = (kb + 2 * WK) < nkb;
+      if (has2) load(a0, w0, kb + 2 * WK);
+      M_::template mma<MF, NF>(acc, a1, w1);
+      if (!has2) break;
+      kb += 2 * WK;
+    }
+  }
+
+  // ---- accumulators -> LDS (C layout: col = lane&15, row = 4*(lane>>4) + reg)
+  {
+    float* slab = smem + (size_t)wk * BM * LDS_LD;
+#pragma unroll
+    for (int m = 0; m < MF; ++m)
+#pragma unroll
+      for (int n = 0; n < NF; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = wm * MF * 16 + m * 16 + 4 * g + r;
+          const int col = wn * NF * 16 + n * 16 + (lane & 15);
+          slab[row * LDS_LD + col] = acc[m][n][r];
+        }
+  }
+  __syncthreads();
+
+  auto lds_sum4 = [&](int row, int c4) -> float4 {
+    float4 v = *reinterpret_cast<const float4*>(smem + row * LDS_LD + c4);
+#pragma unroll
+    for (int s = 1; s < WK; ++s) {
+      const float4 t = *reinterpret_cast<const float4*>(smem + (size_t)s * BM * LDS_LD + row * LDS_LD + c4);
+      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    return v;
+  };
+
+  const float alpha = d.alpha;
+
+  if (d.epi == SP3_EPI_ROPE_VT && n0 >= d.rope_cols) {
+    // ---------------- V part: store transposed per head, vt[((b*heads+h)*64+dd)*vt_ld + n]
+    TW* vt = reinterpret_cast<TW*>(d.vt);
+    for (int idx = tid; idx < BM * BN; idx += NT) {
+      const int row = idx % BM, col = idx / BM;
+      const int gm = m0 + row, gn = n0 + col;
+      if (gm >= d.M || gn >= d.N) continue;
+      float v = smem[row * LDS_LD + col];
+#pragma unroll
+      for (int s = 1; s < WK; ++s) v += smem[(size_t)s * BM * LDS_LD + row * LDS_LD + col];
+      v = v * alpha + (d.bias ? d.bias[gn] : 0.f);
+      const int vc = gn - d.rope_cols;
+      const int h = vc >> 6, dd = vc & 63;
+      const int b = gm / d.tokens, n = gm - b * d.tokens;
+      vt[((int64_t)(b * d.heads + h) * 64 + dd) * d.vt_ld + n] = (TW)v;
+    }
+    return;
+  }
+
+  for (int idx = tid; idx < BM * (BN / 4); idx += NT) {
+    const int row = idx / (BN / 4), c4 = (idx % (BN / 4)) * 4;
+    const int gm = m0 + row, gn = n0 + c4;
+    if (gm >= d.M || gn >= d.N) continue;
+    float4 acc4 = lds_sum4(row, c4);
+    float v[4] = {acc4.x * alpha, acc4.y * alpha, acc4.z * alpha, acc4.w * alpha};
+    const int nvalid = (d.N - gn) < 4 ? (d.N - gn) : 4;
+
+    if (d.epi == SP3_EPI_ROPE_VT) {
+      // bias, then RoPE with the partner column (col ^ 16 inside the 64-wide head)
+      float4 part4 = lds_sum4(row, c4 ^ 16);
+      float pv[4] = {part4.x * alpha, part4.y * alpha, part4.z * alpha, part4.w * alpha};
+      const int hc = gn & 63;
+      const int axis = hc >> 5, is_v = (hc >> 4) & 1, i0 = hc & 15;
+      const int pos = d.pos[(int64_t)gm * 2 + axis];
+      TW* out = reinterpret_cast<TW*>(d.C) + (int64_t)bz * d.strideC + (int64_t)gm * d.ldc + gn;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float self = v[e] + (d.bias ? d.bias[gn + e] : 0.f);
+        const float other = pv[e] + (d.bias ? d.bias[(gn + e) ^ 16] : 0.f);
+        const float cs = d.rope_cos[pos * 16 + i0 + e], sn = d.rope_sin[pos * 16 + i0 + e];
+        const float o = is_v ? (self * cs + other * sn) : (self * cs - other * sn);
+        out[e] = (TW)o;
+      }
+      continue;
+    }
+
+    // bias + activation
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (e < nvalid) {
+        float x = v[e];
+        if (d.epi == SP3_EPI_PIXSHUF) x += d.bias ? d.bias[(gn + e) % d.ps_C] : 0.f;
+        else x += d.bias ? d.bias[gn + e] : 0.f;
+        if (d.act == SP3_ACT_GELU) x = gelu_erf(x);
+        else if (d.act == SP3_ACT_RELU) x = fmaxf(x, 0.f);
+        v[e] = x;
+      }
+    }
+
+    int64_t off;
+    if (d.epi == SP3_EPI_PIXSHUF) {
+      const int kk = gn / d.ps_C, co = gn - kk * d.ps_C;
+      const int ky = kk / d.ps_k, kx = kk - ky * d.ps_k;
+      const int per = d.ps_H * d.ps_W;
+      const int b = gm / per, rem = gm - b * per;
+      const int y = rem / d.ps_W, x = rem - y * d.ps_W;
+      off = (((int64_t)b * d.ps_H * d.ps_k + y * d.ps_k + ky) * ((int64_t)d.ps_W * d.ps_k) + x * d.ps_k + kx) * d.ps_C + co;
+    } else {
+      off = (int64_t)bz * d.strideC + (int64_t)gm * d.ldc + gn;
+    }
+    if (d.res1) {
+      const float* r = d.res1 + ((int64_t)bz * d.M + gm) * d.ldr1 + gn;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (e < nvalid) v[e] += r[e];
+    }
+    if (d.res2) {
+      const float* r = d.res2 + ((int64_t)bz * d.M + gm) * d.ldr2 + gn;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (e < nvalid) v[e] += r[e];
+    }
+    if (d.out_bf16) {
+      __bf16* o = reinterpret_cast<__bf16*>(d.C) + off;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (e < nvalid) o[e] = (__bf16)v[e];
+    } else {
+      float* o = reinterpret_cast<float*>(d.C) + off;
+      if (nvalid == 4 && ((off & 3) == 0)) {
+        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (e < nvalid) o[e] = v[e];
+      }
+    }
+  }
+}
+
+template <typename TW, int LOADER, int MF, int NF, int WM, int WN, int WK>
+int launch(const sp3_gemm_desc& d, hipStream_t stream) {
+  constexpr int BM = MF * 16 * WM, BN = NF * 16 * WN, NT = 64 * WM * WN * WK;
+  const int mt = (d.M + BM - 1) / BM, nt = (d.N + BN - 1) / BN;
+  int blocks;
+  if (mt >= nt) blocks = ((mt + 7) / 8) * 8 * nt;
+  else blocks = ((nt + 7) / 8) * 8 * mt;
+  const size_t lds = (size_t)WK * BM * (BN + 4) * sizeof(float);
+  GemmArgs a;
+  a.d = d;
+  auto kern = gemm_kernel<TW, LOADER, MF, NF, WM, WN, WK>;
+  hipLaunchKernelGGL(kern, dim3(blocks, d.batch > 0 ? d.batch : 1, 1), dim3(NT), lds, stream, a);
+  SP3_LAUNCH_CHECK("sp3_gemm");
+  return 0;
+}
+
+template <typename TW, int LOADER>
+int dispatch_tile(const sp3_gemm_desc& d, int tile, hipStream_t stream) {
+  switch (tile) {
+    case 0: return launch<TW, LOADER, 2, 2, 1, 1, 4>(d, stream);   // 32x32, K split over 4 waves
+    case 1: return launch<TW, LOADER, 2, 2, 2, 2, 1>(d, stream);   // 64x64
+    case 2: return launch<TW, LOADER, 2, 4, 2, 2, 1>(d, stream);   // 64x128
+    default: sp3_set_error("sp3_gemm: bad tile %d", tile); return 1;
+  }
+}
+
+}  // namespace
+
+extern "C" int sp3_gemm(const sp3_gemm_desc* dp, void* stream_) {
+  SP3_CHECK(dp != nullptr, "sp3_gemm: null descriptor");
+  sp3_gemm_desc d = *dp;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  SP3_CHECK(d.A && d.W && d.C, "sp3_gemm: null A/W/C");
+  SP3_CHECK(d.M > 0 && d.N > 0 && d.K > 0, "sp3_gemm: bad shape M=%d N=%d K=%d", d.M, d.N, d.K);
+  SP3_CHECK(d.K % 8 == 0, "sp3_gemm: K=%d must be a multiple of 8", d.K);
+  SP3_CHECK(d.wdtype == SP3_F32 || d.wdtype == SP3_BF16, "sp3_gemm: bad wdtype %d", d.wdtype);
+  SP3_CHECK((reinterpret_cast<uintptr_t>(d.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(d.W) & 15) == 0,
+            "sp3_gemm: A and W must be 16-byte aligned");
+  if (d.batch <= 0) d.batch = 1;
+  if (d.ldw <= 0) d.ldw = d.K;
+  if (!d.A2) d.K1 = d.K;
+  SP3_CHECK(d.ldw >= d.K && d.ldw % 8 == 0, "sp3_gemm: ldw=%lld must be >= K and a multiple of 8", (long long)d.ldw);
+  SP3_CHECK(!d.A2 || (d.loader == SP3_LOAD_PLAIN && d.K1 % 64 == 0 && d.K1 > 0 && d.K1 < d.K && d.lda2 % 4 == 0 && d.batch == 1),
+            "sp3_gemm: bad split-A configuration (K1=%d)", d.K1);
+  if (d.loader == SP3_LOAD_PLAIN) {
+    SP3_CHECK(d.lda % 4 == 0 && d.lda >= d.K1, "sp3_gemm: lda=%lld must be >= K and a multiple of 4", (long long)d.lda);
+  } else if (d.loader == SP3_LOAD_CONV3X3) {
+    SP3_CHECK(d.conv_C % 16 == 0, "sp3_gemm: conv Cin=%d must be a multiple of 16", d.conv_C);
+    SP3_CHECK(d.K == 9 * d.conv_C, "sp3_gemm: conv K=%d != 9*Cin", d.K);
+    SP3_CHECK(d.conv_stride == 1 || d.conv_stride == 2, "sp3_gemm: conv stride %d", d.conv_stride);
+    SP3_CHECK(d.M % (d.conv_OH * d.conv_OW) == 0, "sp3_gemm: conv M=%d not a multiple of OH*OW", d.M);
+  } else {
+    SP3_CHECK(false, "sp3_gemm: bad loader %d", d.loader);
+  }
+  if (d.epi == SP3_EPI_ROPE_VT) {
+    SP3_CHECK(d.rope_cols % 64 == 0 && d.N % 64 == 0, "sp3_gemm: ROPE_VT needs 64-wide heads (N=%d rope_cols=%d)", d.N, d.rope_cols);
+    SP3_CHECK(d.rope_cols == 0 || (d.rope_cos && d.rope_sin && d.pos), "sp3_gemm: ROPE_VT needs tables and positions");
+    SP3_CHECK(d.rope_cols == d.N || (d.vt && d.tokens > 0 && d.heads > 0 && d.vt_ld >= d.tokens), "sp3_gemm: ROPE_VT needs vt/tokens/heads");
+    SP3_CHECK(d.batch == 1, "sp3_gemm: ROPE_VT is unbatched (rows carry the batch)");
+  } else if (d.epi == SP3_EPI_PIXSHUF) {
+    SP3_CHECK(d.ps_k > 0 && d.ps_C > 0 && d.ps_C % 4 == 0 && d.N == d.ps_k * d.ps_k * d.ps_C && d.M % (d.ps_H * d.ps_W) == 0,
+              "sp3_gemm: bad PIXSHUF geometry");
+  } else {
+    SP3_CHECK(d.epi == SP3_EPI_PLAIN, "sp3_gemm: bad epilogue %d", d.epi);
+  }
+  int tile = d.tile;
+  if (tile < 0) {
+    // enough 32x32 tiles to fill 256 CUs?  otherwise bigger tiles for arithmetic intensity
+    const long t32 = (long)((d.M + 31) / 32) * ((d.N + 31) / 32) * d.batch;
+    const long t64 = (long)((d.M + 63) / 64) * ((d.N + 63) / 64) * d.batch;
+    const long t128 = (long)((d.M + 63) / 64) * ((d.N + 127) / 128) * d.batch;
+    if (t128 >= 1024 && d.N % 128 == 0) tile = 2;
+    else if (t64 >= 512) tile = 1;
+    else tile = 0;
+    (void)t32;
+  }
+  if (d.epi == SP3_EPI_ROPE_VT && tile == 0) tile = 0;   // all tiles are >= 32 wide: RoPE partner stays in-tile
+  if (d.wdtype == SP3_BF16) {
+    if (d.loader == SP3_LOAD_PLAIN) return dispatch_tile<__bf16, SP3_LOAD_PLAIN>(d, tile, stream);
+    return dispatch_tile<__bf16, SP3_LOAD_CONV3X3>(d, tile, stream);
+  } else {
+    if (d.loader == SP3_LOAD_PLAIN) return dispatch_tile<float, SP3_LOAD_PLAIN>(d, tile, stream);
+    return dispatch_tile<float, SP3_LOAD_CONV3X3>(d, tile, stream);
+  }
+}

@@ -1,0 +1,195 @@
+// LayerNorm (row-major and transposed-store) and the stand-alone 2-D RoPE kernel (curope drop-in).
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+constexpr int LN_MAX_V4 = 16;   // C <= 64 lanes * 16 float4 * 4 = 4096
+
+// One wave per row; the row lives in registers; two-pass mean / variance in fp32
+// (torch.nn.functional.layer_norm numerics: var = mean((x-mean)^2), biased).
+__device__ __forceinline__ void ln_row(const float* __restrict__ xr, int C, const float* __restrict__ gamma,
+                                       const float* __restrict__ beta, float eps, int lane,
+                                       float4 (&v)[LN_MAX_V4], int& nv) {
+  const int c4 = C >> 2;
+  nv = 0;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_V4; ++i) {
+    const int j = lane + i * 64;
+    if (j < c4) {
+      v[i] = reinterpret_cast<const float4*>(xr)[j];
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+      nv = i + 1;
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_V4; ++i) {
+    const int j = lane + i * 64;
+    if (j < c4) {
+      const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+      q += (a * a + b * b) + (c * c + d * d);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < LN_MAX_V4; ++i) {
+    const int j = lane + i * 64;
+    if (j < c4) {
+      const float4 gm = reinterpret_cast<const float4*>(gamma)[j];
+      const float4 bt = reinterpret_cast<const float4*>(beta)[j];
+      v[i].x = (v[i].x - mean) * rstd * gm.x + bt.x;
+      v[i].y = (v[i].y - mean) * rstd * gm.y + bt.y;
+      v[i].z = (v[i].z - mean) * rstd * gm.z + bt.z;
+      v[i].w = (v[i].w - mean) * rstd * gm.w + bt.w;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t ldx,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float eps, void* __restrict__ out, int64_t ldo, int out_bf16,
+                                                        int rows, int C) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float4 v[LN_MAX_V4];
+  int nv;
+  ln_row(x + (int64_t)row * ldx, C, gamma, beta, eps, lane, v, nv);
+  const int c4 = C >> 2;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_V4; ++i) {
+    const int j = lane + i * 64;
+    if (j < c4) {
+      if (out_bf16) {
+        bf16x4 o;
+        o[0] = (__bf16)v[i].x; o[1] = (__bf16)v[i].y; o[2] = (__bf16)v[i].z; o[3] = (__bf16)v[i].w;
+        reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(out) + (int64_t)row * ldo)[j] = o;
+      } else {
+        reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (int64_t)row * ldo)[j] = v[i];
+      }
+    }
+  }
+}
+
+// Transposed store: a block normalises 8 consecutive rows (4 waves x 2 rows), parks them in LDS and
+// writes out[c*ldo + row0 .. row0+7] as 8-element contiguous runs.
+constexpr int LNT_ROWS = 8;    // 1024 x 9 floats = 36 KB of LDS
+__global__ __launch_bounds__(256) void layernorm_t_kernel(const float* __restrict__ x, int64_t ldx,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float eps, void* __restrict__ out, int64_t ldo, int out_bf16,
+                                                          int rows, int C) {
+  extern __shared__ __attribute__((aligned(16))) float tile[];   // [C][LNT_ROWS+1]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row0 = blockIdx.x * LNT_ROWS;
+  const int c4 = C >> 2;
+  for (int rr = 0; rr < LNT_ROWS / 4; ++rr) {
+    const int lr = wave * (LNT_ROWS / 4) + rr;
+    const int row = row0 + lr;
+    if (row < rows) {
+      float4 v[LN_MAX_V4];
+      int nv;
+      ln_row(x + (int64_t)row * ldx, C, gamma, beta, eps, lane, v, nv);
+#pragma unroll
+      for (int i = 0; i < LN_MAX_V4; ++i) {
+        const int j = lane + i * 64;
+        if (j < c4) {
+          tile[(j * 4 + 0) * (LNT_ROWS + 1) + lr] = v[i].x;
+          tile[(j * 4 + 1) * (LNT_ROWS + 1) + lr] = v[i].y;
+          tile[(j * 4 + 2) * (LNT_ROWS + 1) + lr] = v[i].z;
+          tile[(j * 4 + 3) * (LNT_ROWS + 1) + lr] = v[i].w;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int nr = (rows - row0) < LNT_ROWS ? (rows - row0) : LNT_ROWS;
+  for (int idx = threadIdx.x; idx < C * LNT_ROWS; idx += 256) {
+    const int c = idx / LNT_ROWS, r = idx % LNT_ROWS;
+    if (r < nr) {
+      const float val = tile[c * (LNT_ROWS + 1) + r];
+      if (out_bf16) reinterpret_cast<__bf16*>(out)[(int64_t)c * ldo + row0 + r] = (__bf16)val;
+      else reinterpret_cast<float*>(out)[(int64_t)c * ldo + row0 + r] = val;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ stand-alone RoPE (curope drop-in)
+// One wave handles one token (b, n) for all heads.  Lane i < D/2 owns the pair (u_i, v_i):
+// i in [0,Q) -> Y quarter pair (d=i, d=i+Q); i in [Q,2Q) -> X pair (d=2Q+i-Q, d=3Q+i-Q).
+template <typename T>
+__global__ __launch_bounds__(256) void rope2d_kernel(T* __restrict__ tokens, int B, int N, int H, int D, int64_t sB,
+                                                     int64_t sN, int64_t sH, const int64_t* __restrict__ pos,
+                                                     float base, float fwd) {
+  const int lane = threadIdx.x & 63;
+  const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tok >= B * N) return;
+  const int b = tok / N, n = tok - b * N;
+  const int Q = D >> 2;
+  T* t0 = tokens + (int64_t)b * sB + (int64_t)n * sN;
+  for (int i = lane; i < 2 * Q; i += 64) {
+    const int axis = i / Q, f = i - axis * Q;
+    const float p = (float)pos[(int64_t)tok * 2 + axis];
+    const float inv_freq = fwd / powf(base, (float)f / (float)Q);
+    const float ang = p * inv_freq;
+    const float cs = cosf(ang), sn = sinf(ang);
+    const int du = axis * 2 * Q + f, dv = du + Q;
+    for (int h = 0; h < H; ++h) {
+      T* th = t0 + (int64_t)h * sH;
+      const float u = (float)th[du], v = (float)th[dv];
+      th[du] = (T)(u * cs - v * sn);
+      th[dv] = (T)(v * cs + u * sn);
+    }
+  }
+}
+
+}  // namespace
+
+static int ln_check(const float* x, int64_t ldx, const float* gamma, const float* beta, void* out, int rows, int C) {
+  SP3_CHECK(x && gamma && beta && out, "sp3_layernorm: null pointer");
+  SP3_CHECK(rows > 0 && C > 0 && C % 4 == 0 && C <= 64 * 4 * LN_MAX_V4, "sp3_layernorm: bad rows=%d C=%d", rows, C);
+  SP3_CHECK(ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "sp3_layernorm: x must be 16-byte aligned rows");
+  return 0;
+}
+
+extern "C" int sp3_layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, void* out,
+                             int64_t ldo, int out_bf16, int rows, int C, void* stream) {
+  if (ln_check(x, ldx, gamma, beta, out, rows, C)) return 1;
+  SP3_CHECK(ldo % 4 == 0, "sp3_layernorm: ldo must be a multiple of 4");
+  hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, ldx,
+                     gamma, beta, eps, out, ldo, out_bf16, rows, C);
+  SP3_LAUNCH_CHECK("sp3_layernorm");
+  return 0;
+}
+
+extern "C" int sp3_layernorm_t(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, void* out,
+                               int64_t ldo, int out_bf16, int rows, int C, void* stream) {
+  if (ln_check(x, ldx, gamma, beta, out, rows, C)) return 1;
+  const size_t lds = (size_t)C * (LNT_ROWS + 1) * sizeof(float);
+  SP3_CHECK(lds <= 160 * 1024, "sp3_layernorm_t: C=%d too large for LDS", C);
+  hipLaunchKernelGGL(layernorm_t_kernel, dim3((rows + LNT_ROWS - 1) / LNT_ROWS), dim3(256), lds,
+                     reinterpret_cast<hipStream_t>(stream), x, ldx, gamma, beta, eps, out, ldo, out_bf16, rows, C);
+  SP3_LAUNCH_CHECK("sp3_layernorm_t");
+  return 0;
+}
+
+extern "C" int sp3_rope_2d(void* tokens, int dtype, int B, int N, int H, int D, int64_t sB, int64_t sN, int64_t sH,
+                           const int64_t* positions, float base, float fwd, void* stream) {
+  // same argument checks as curope.cpp:54-59 / kernels.cu:91-94
+  SP3_CHECK(tokens && positions, "rope_2d: null pointer");
+  SP3_CHECK(B > 0 && N > 0 && H > 0 && D > 0, "rope_2d: bad shape");
+  SP3_CHECK(D % 4 == 0, "token dim must be multiple of 4");
+  SP3_CHECK(dtype == SP3_F32 || dtype == SP3_BF16, "rope_2d: bad dtype %d", dtype);
+  const int blocks = (B * N + 3) / 4;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (dtype == SP3_F32)
+    hipLaunchKernelGGL(rope2d_kernel<float>, dim3(blocks), dim3(256), 0, st, reinterpret_cast<float*>(tokens), B, N, H, D,
+                       sB, sN, sH, positions, base, fwd);
+  else
+    hipLaunchKernelGGL(rope2d_kernel<__bf16>, dim3(blocks), dim3(256), 0, st, reinterpret_cast<__bf16*>(tokens), B, N, H,
+                       D, sB, sN, sH, positions, base, fwd);
+  SP3_LAUNCH_CHECK("sp3_rope_2d");
+  return 0;
+}

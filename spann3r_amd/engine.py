@@ -1,0 +1,365 @@
+"""Stage-level host code of the hot path: packs weights for the kernels and sequences the launches.
+
+One `Engine` per (model, device, precision).  Every method mirrors one reference stage
+(file:line cited per method) and only launches HIP kernels through spann3r_amd.ops; activations
+live in a persistent workspace (stable addresses -> the per-frame step is hipGraph-capturable).
+
+Precision: 'fp32' -> fp32 weights, v_mfma_f32_16x16x4_f32 (parity mode, <=1e-3 vs the CPU oracle);
+           'bf16' -> bf16 weights / q,k,v / memory bank, v_mfma_f32_16x16x32_bf16, fp32 accumulate,
+                     fp32 residual stream, LayerNorm, softmax and DPT feature maps (bench mode).
+"""
+import math
+
+import torch
+
+from . import ops
+from .lib import ACT_NONE, ACT_GELU, ACT_RELU
+from .config import Spann3RConfig
+
+
+def _rope_tables(max_pos, base, device):
+    """cos/sin [max_pos, 16] exactly as the reference's torch fallback builds them
+    (croco/models/pos_embed.py:118-129 with D = head_dim/2 = 32)."""
+    half = 32
+    inv_freq = 1.0 / (base ** (torch.arange(0, half, 2).float() / half))
+    t = torch.arange(max_pos, dtype=torch.float32)
+    ang = torch.einsum("i,j->ij", t, inv_freq)
+    return ang.cos().contiguous().to(device), ang.sin().contiguous().to(device)
+
+
+class Engine:
+    def __init__(self, cfg: Spann3RConfig, params: dict, device, precision="fp32"):
+        assert precision in ("fp32", "bf16")
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.precision = precision
+        self.wdt = torch.float32 if precision == "fp32" else torch.bfloat16
+        self._ws = {}
+        self._pos_cache = {}
+        self.max_pos = 0
+        self.cos = self.sin = None
+        self.w = {}
+        self._pack(params)
+
+    # ------------------------------------------------------------------ weights
+    def _pack(self, p):
+        cfg, dev, wdt = self.cfg, self.device, self.wdt
+        w = self.w
+
+        def mat(t):      # MFMA operand: [N, K] in the compute dtype
+            return t.detach().to(dev, torch.float32).reshape(t.shape[0], -1).to(wdt).contiguous()
+
+        def vec(t):      # biases / LN parameters stay fp32
+            return t.detach().to(dev, torch.float32).contiguous()
+
+        def conv3(t):    # [Cout,Cin,3,3] -> [Cout, (ky,kx,ci)]
+            return t.detach().to(dev, torch.float32).permute(0, 2, 3, 1).reshape(t.shape[0], -1).to(wdt).contiguous()
+
+        def convt(t):    # ConvTranspose2d [Cin,Cout,k,k] -> [(ky,kx,co), ci]
+            return t.detach().to(dev, torch.float32).permute(2, 3, 1, 0).reshape(-1, t.shape[0]).to(wdt).contiguous()
+
+        def block(dst, src):
+            for n in ("norm1", "norm2"):
+                w[dst + n + ".w"], w[dst + n + ".b"] = vec(p[src + n + ".weight"]), vec(p[src + n + ".bias"])
+            w[dst + "qkv.w"], w[dst + "qkv.b"] = mat(p[src + "attn.qkv.weight"]), vec(p[src + "attn.qkv.bias"])
+            w[dst + "proj.w"], w[dst + "proj.b"] = mat(p[src + "attn.proj.weight"]), vec(p[src + "attn.proj.bias"])
+            w[dst + "fc1.w"], w[dst + "fc1.b"] = mat(p[src + "mlp.fc1.weight"]), vec(p[src + "mlp.fc1.bias"])
+            w[dst + "fc2.w"], w[dst + "fc2.b"] = mat(p[src + "mlp.fc2.weight"]), vec(p[src + "mlp.fc2.bias"])
+
+        w["patch.w"], w["patch.b"] = mat(p["dust3r.patch_embed.proj.weight"]), vec(p["dust3r.patch_embed.proj.bias"])
+        w["pospatch.w"], w["pospatch.b"] = mat(p["pos_patch_embed.proj.weight"]), vec(p["pos_patch_embed.proj.bias"])
+        for i in range(cfg.enc_depth):
+            block("enc%d." % i, "dust3r.enc_blocks.%d." % i)
+        for i in range(cfg.val_depth):
+            block("val%d." % i, "value_encoder.%d." % i)
+        for n, s in (("enc_norm", "dust3r.enc_norm"), ("dec_norm", "dust3r.dec_norm"), ("value_norm", "value_norm"),
+                     ("norm_q", "norm_q"), ("norm_k", "norm_k"), ("norm_v", "norm_v")):
+            w[n + ".w"], w[n + ".b"] = vec(p[s + ".weight"]), vec(p[s + ".bias"])
+        w["dec_embed.w"], w["dec_embed.b"] = mat(p["dust3r.decoder_embed.weight"]), vec(p["dust3r.decoder_embed.bias"])
+        w["value_out.w"], w["value_out.b"] = mat(p["value_out.weight"]), vec(p["value_out.bias"])
+        for side, name in ((1, "dec_blocks"), (2, "dec_blocks2")):
+            for i in range(cfg.dec_depth):
+                src, dst = "dust3r.%s.%d." % (name, i), "dec%d_%d." % (side, i)
+                block(dst, src)
+                for n in ("norm3", "norm_y"):
+                    w[dst + n + ".w"], w[dst + n + ".b"] = vec(p[src + n + ".weight"]), vec(p[src + n + ".bias"])
+                ca = src + "cross_attn."
+                w[dst + "cq.w"], w[dst + "cq.b"] = mat(p[ca + "projq.weight"]), vec(p[ca + "projq.bias"])
+                # projk and projv read the same input (norm_y of the other side): one GEMM, N = 2*768
+                w[dst + "ckv.w"] = mat(torch.cat((p[ca + "projk.weight"].detach(), p[ca + "projv.weight"].detach()), 0))
+                w[dst + "ckv.b"] = vec(torch.cat((p[ca + "projk.bias"].detach(), p[ca + "projv.bias"].detach()), 0))
+                w[dst + "cproj.w"], w[dst + "cproj.b"] = mat(p[ca + "proj.weight"]), vec(p[ca + "proj.bias"])
+        for h in (1, 2):
+            s, d_ = "attn_head_%d." % h, "key%d." % h
+            w[d_ + "0.w"], w[d_ + "0.b"] = mat(p[s + "0.weight"]), vec(p[s + "0.bias"])
+            w[d_ + "2.w"], w[d_ + "2.b"] = mat(p[s + "2.weight"]), vec(p[s + "2.bias"])
+            s, d_ = "dust3r.downstream_head%d.dpt." % h, "dpt%d." % h
+            a = s + "act_postprocess."
+            for i in range(4):
+                w[d_ + "pp%d.w" % i], w[d_ + "pp%d.b" % i] = mat(p[a + "%d.0.weight" % i]), vec(p[a + "%d.0.bias" % i])
+                w[d_ + "rn%d.w" % i] = conv3(p[s + "scratch.layer%d_rn.weight" % (i + 1)])
+            w[d_ + "pp0t.w"], w[d_ + "pp0t.b"] = convt(p[a + "0.1.weight"]), vec(p[a + "0.1.bias"])
+            w[d_ + "pp1t.w"], w[d_ + "pp1t.b"] = convt(p[a + "1.1.weight"]), vec(p[a + "1.1.bias"])
+            w[d_ + "pp3c.w"], w[d_ + "pp3c.b"] = conv3(p[a + "3.1.weight"]), vec(p[a + "3.1.bias"])
+            for r in (1, 2, 3, 4):
+                rs, rd = s + "scratch.refinenet%d." % r, d_ + "ref%d." % r
+                w[rd + "out.w"], w[rd + "out.b"] = mat(p[rs + "out_conv.weight"]), vec(p[rs + "out_conv.bias"])
+                for u in (1, 2):
+                    for c in (1, 2):
+                        w[rd + "u%dc%d.w" % (u, c)] = conv3(p[rs + "resConfUnit%d.conv%d.weight" % (u, c)])
+                        w[rd + "u%dc%d.b" % (u, c)] = vec(p[rs + "resConfUnit%d.conv%d.bias" % (u, c)])
+            w[d_ + "h0.w"], w[d_ + "h0.b"] = conv3(p[s + "head.0.weight"]), vec(p[s + "head.0.bias"])
+            w[d_ + "h2.w"], w[d_ + "h2.b"] = conv3(p[s + "head.2.weight"]), vec(p[s + "head.2.bias"])
+            w[d_ + "h4.w"] = p[s + "head.4.weight"].detach().to(dev, torch.float32).reshape(4, -1).contiguous()
+            w[d_ + "h4.b"] = vec(p[s + "head.4.bias"])
+
+    def weight_bytes(self):
+        return sum(t.numel() * t.element_size() for t in self.w.values())
+
+    # ------------------------------------------------------------------ workspace
+    def ws(self, name, shape, dtype=torch.float32, zero=False):
+        key = (name, tuple(shape), dtype)
+        t = self._ws.get(key)
+        if t is None:
+            t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
+            self._ws[key] = t
+        return t
+
+    def positions(self, B, nh, nw):
+        """PositionGetter (croco/models/blocks.py:195-207): int32 [B*nh*nw, 2] (y, x) for the kernels,
+        plus the int64 [B, P, 2] tensor the reference API hands around."""
+        key = (B, nh, nw)
+        if key not in self._pos_cache:
+            ys, xs = torch.meshgrid(torch.arange(nh), torch.arange(nw), indexing="ij")
+            pos = torch.stack((ys.reshape(-1), xs.reshape(-1)), -1)[None].expand(B, -1, -1).contiguous()
+            need = max(nh, nw)
+            if need > self.max_pos:
+                self.max_pos = max(need, 64)
+                self.cos, self.sin = _rope_tables(self.max_pos, self.cfg.rope_base, self.device)
+            self._pos_cache[key] = (pos.to(self.device), pos.reshape(-1, 2).to(torch.int32).to(self.device).contiguous(),
+                                    torch.zeros(B * nh * nw, 2, dtype=torch.int32, device=self.device))
+        return self._pos_cache[key]
+
+    # ------------------------------------------------------------------ transformer pieces
+    def _self_attn(self, x, R, B, P, C, heads, pre, pos32, out, res):
+        """x fp32 [R,C] (already LayerNormed) -> out = proj(attn(x)) + res.  croco/models/blocks.py:94-112."""
+        w = self.w
+        npad = (P + 63) // 64 * 64
+        qk = self.ws("qk", (R, 2 * C), self.wdt)
+        vt = self.ws("vt", (B * heads * 64, npad), self.wdt, zero=True)
+        ao = self.ws("attn_out", (R, C))
+        ops.proj_rope_vt(x, w[pre + "qkv.w"], w[pre + "qkv.b"], qk, 2 * C, vt, npad, M=R, N=3 * C, K=C, lda=C,
+                         rope_cols=2 * C, pos=pos32, cos=self.cos, sin=self.sin, tokens=P, heads=heads)
+        ops.attention(qk, P * 2 * C, 2 * C, qk[:, C:], P * 2 * C, 2 * C, vt, npad, ao, C, B=B, heads=heads, Nq=P, Nk=P,
+                      scale=64 ** -0.5)
+        ops.gemm(ao, w[pre + "proj.w"], out, M=R, N=C, K=C, lda=C, ldc=C, bias=w[pre + "proj.b"], res1=res, ldr1=C)
+
+    def _mlp(self, x, R, C, pre, out, res):
+        """croco/models/blocks.py:73-79: fc1 -> exact-erf GELU -> fc2, + residual."""
+        w = self.w
+        Hd = C * self.cfg.mlp_ratio
+        h = self.ws("mlp_hidden", (R, Hd))
+        ops.gemm(x, w[pre + "fc1.w"], h, M=R, N=Hd, K=C, lda=C, ldc=Hd, bias=w[pre + "fc1.b"], act=ACT_GELU)
+        ops.gemm(h, w[pre + "fc2.w"], out, M=R, N=C, K=Hd, lda=Hd, ldc=C, bias=w[pre + "fc2.b"], res1=res, ldr1=C)
+
+    def _block(self, x, R, B, P, C, heads, pre, pos32):
+        """Pre-LN ViT block in place on x (croco/models/blocks.py:127-130), LayerNorm eps 1e-6."""
+        w = self.w
+        ln = self.ws("ln", (R, C))
+        ops.layernorm(x, w[pre + "norm1.w"], w[pre + "norm1.b"], 1e-6, ln, rows=R, C_=C)
+        self._self_attn(ln, R, B, P, C, heads, pre, pos32, x, x)
+        ops.layernorm(x, w[pre + "norm2.w"], w[pre + "norm2.b"], 1e-6, ln, rows=R, C_=C)
+        self._mlp(ln, R, C, pre, x, x)
+
+    # ------------------------------------------------------------------ stages
+    def encode_image(self, img, out=None):
+        """dust3r._encode_image (dust3r/model.py:131-154): patch embed -> enc_depth blocks -> enc_norm.
+        img fp32 [B,3,H,W] on device -> feat [B,P,1024] (written to `out` if given), pos int64 [B,P,2]."""
+        cfg, w = self.cfg, self.w
+        B, Cin, H, W_ = img.shape
+        p = cfg.patch
+        assert Cin == 3 and H % p == 0 and W_ % p == 0, "Input image size is not a multiple of patch size"
+        nh, nw = H // p, W_ // p
+        P, E = nh * nw, cfg.enc_dim
+        R = B * P
+        pos64, pos32, _ = self.positions(B, nh, nw)
+        col = self.ws("im2col", (R, 3 * p * p))
+        ops.im2col_patch(img, col, B=B, C_=3, H=H, W_=W_, p=p, strides=img.stride())
+        x = self.ws("enc_x", (R, E))
+        ops.gemm(col, w["patch.w"], x, M=R, N=E, K=3 * p * p, lda=3 * p * p, ldc=E, bias=w["patch.b"])
+        for i in range(cfg.enc_depth):
+            self._block(x, R, B, P, E, cfg.enc_heads, "enc%d." % i, pos32)
+        if out is None:
+            out = torch.empty(B, P, E, device=self.device)
+        ops.layernorm(x, w["enc_norm.w"], w["enc_norm.b"], 1e-6, out, rows=R, C_=E)
+        return out, pos64
+
+    def decoder(self, f1, f2, B, nh1, nw1, nh2, nw2):
+        """dust3r._decoder (dust3r/model.py:186-205).  f1, f2 fp32 [B,P,1024].
+        Returns two lists of dec_depth+1 tensors ([B,P,1024] then [B,P,768] ...), last one dec_norm'ed."""
+        cfg, w = self.cfg, self.w
+        E, D, Hh = cfg.enc_dim, cfg.dec_dim, cfg.dec_heads
+        P1, P2 = nh1 * nw1, nh2 * nw2
+        R1, R2 = B * P1, B * P2
+        pos = {1: self.positions(B, nh1, nw1)[1], 2: self.positions(B, nh2, nw2)[1]}
+        Rs, Ps = {1: R1, 2: R2}, {1: P1, 2: P2}
+        f = {1: f1, 2: f2}
+        outs = {1: [f1], 2: [f2]}
+        prev = {}
+        for s in (1, 2):
+            prev[s] = self.ws("dec%d_l0" % s, (Rs[s], D))
+            ops.gemm(f[s], w["dec_embed.w"], prev[s], M=Rs[s], N=D, K=E, lda=E, ldc=D, bias=w["dec_embed.b"])
+        for i in range(cfg.dec_depth):
+            new = {}
+            for s in (1, 2):
+                o = 3 - s
+                pre = "dec%d_%d." % (s, i)
+                R, P, Ro, Po = Rs[s], Ps[s], Rs[o], Ps[o]
+                x = self.ws("dec%d_l%d" % (s, i + 1), (R, D))
+                ln = self.ws("ln_dec", (max(R1, R2), D))
+                # self attention (croco/models/blocks.py:187)
+                ops.layernorm(prev[s], w[pre + "norm1.w"], w[pre + "norm1.b"], 1e-6, ln, rows=R, C_=D)
+                self._self_attn(ln, R, B, P, D, Hh, pre, pos[s], x, prev[s])
+                # cross attention to the other side's previous-layer tokens (:188-189)
+                yn = self.ws("ln_y", (max(R1, R2), D))
+                ops.layernorm(prev[o], w[pre + "norm_y.w"], w[pre + "norm_y.b"], 1e-6, yn, rows=Ro, C_=D)
+                npad = (Po + 63) // 64 * 64
+                kbuf = self.ws("ck", (max(R1, R2), D), self.wdt)
+                vt = self.ws("cvt", (B * Hh * 64, (max(P1, P2) + 63) // 64 * 64), self.wdt, zero=True)
+                vt_ld = vt.shape[1]
+                ops.proj_rope_vt(yn, w[pre + "ckv.w"], w[pre + "ckv.b"], kbuf, D, vt, vt_ld, M=Ro, N=2 * D, K=D, lda=D,
+                                 rope_cols=D, pos=pos[o], cos=self.cos, sin=self.sin, tokens=Po, heads=Hh)
+                ops.layernorm(x, w[pre + "norm2.w"], w[pre + "norm2.b"], 1e-6, ln, rows=R, C_=D)
+                qbuf = self.ws("cq", (max(R1, R2), D), self.wdt)
+                ops.proj_rope_vt(ln, w[pre + "cq.w"], w[pre + "cq.b"], qbuf, D, None, 0, M=R, N=D, K=D, lda=D,
+                                 rope_cols=D, pos=pos[s], cos=self.cos, sin=self.sin, tokens=P, heads=Hh)
+                ao = self.ws("attn_out_dec", (max(R1, R2), D))
+                ops.attention(qbuf, P * D, D, kbuf, Po * D, D, vt, vt_ld, ao, D, B=B, heads=Hh, Nq=P, Nk=Po, scale=64 ** -0.5)
+                ops.gemm(ao, w[pre + "cproj.w"], x, M=R, N=D, K=D, lda=D, ldc=D, bias=w[pre + "cproj.b"], res1=x, ldr1=D)
+                # MLP (:190)
+                ops.layernorm(x, w[pre + "norm3.w"], w[pre + "norm3.b"], 1e-6, ln, rows=R, C_=D)
+                self._mlp(ln, R, D, pre, x, x)
+                new[s] = x
+            for s in (1, 2):
+                prev[s] = new[s]
+                outs[s].append(new[s].view(B, Ps[s], D))
+        for s in (1, 2):
+            last = self.ws("dec%d_normed" % s, (Rs[s], D))
+            ops.layernorm(prev[s], w["dec_norm.w"], w["dec_norm.b"], 1e-6, last, rows=Rs[s], C_=D)
+            outs[s][-1] = last.view(B, Ps[s], D)
+        return outs[1], outs[2]
+
+    def encode_feat_key(self, feat, dec_last, R, num, out):
+        """spann3r/model.py:299-303: Linear(1792,1792) -> GELU -> Linear(1792,1024) on cat(feat, dec[-1]);
+        the concatenation is never materialised (split-A GEMM)."""
+        cfg, w = self.cfg, self.w
+        E, D, Kd = cfg.enc_dim, cfg.dec_dim, cfg.key_dim
+        h = self.ws("key_hidden", (R, Kd))
+        pre = "key%d." % num
+        ops.gemm(feat, w[pre + "0.w"], h, M=R, N=Kd, K=Kd, lda=E, ldc=Kd, bias=w[pre + "0.b"], act=ACT_GELU,
+                 A2=dec_last, lda2=D, K1=E)
+        ops.gemm(h, w[pre + "2.w"], out, M=R, N=E, K=Kd, lda=Kd, ldc=E, bias=w[pre + "2.b"])
+        return out
+
+    def _rcu(self, x, pre, B, H, W_, out, extra_res=None):
+        """ResidualConvUnit_custom (croco/models/dpt_block.py:120-142): conv2(relu(conv1(relu(x)))) + x [+ extra]."""
+        w, F = self.w, self.cfg.dpt_feat
+        t = self.ws("rcu_tmp", (B * H * W_, F))
+        ops.conv3x3(x, w[pre + "c1.w"], t, B=B, H=H, W_=W_, Cin=F, Cout=F, bias=w[pre + "c1.b"], relu_in=True, act=ACT_RELU)
+        ops.conv3x3(t, w[pre + "c2.w"], out, B=B, H=H, W_=W_, Cin=F, Cout=F, bias=w[pre + "c2.b"], res1=x, res2=extra_res)
+        return out
+
+    def _fusion(self, pre, B, H, W_, x0, x1, tag, crop=None):
+        """FeatureFusionBlock_custom (croco/models/dpt_block.py:190-218).  The 1x1 out_conv is applied BEFORE the
+        bilinear x2 (both are linear and the interpolation weights sum to 1, so the two commute exactly in real
+        arithmetic): 4x fewer FLOPs in out_conv.  x0/x1 NHWC [B,H,W,256]; returns ([B,2H,2W,256] or cropped, OH, OW)."""
+        w, F = self.w, self.cfg.dpt_feat
+        M = B * H * W_
+        cur = x0
+        if x1 is not None:
+            s = self.ws("fus_sum_" + tag, (M, F))
+            self._rcu(x1, pre + "u1", B, H, W_, s, extra_res=x0)
+            cur = s
+        r = self.ws("fus_rcu2_" + tag, (M, F))
+        self._rcu(cur, pre + "u2", B, H, W_, r)
+        oc = self.ws("fus_oc_" + tag, (M, F))
+        ops.gemm(r, w[pre + "out.w"], oc, M=M, N=F, K=F, lda=F, ldc=F, bias=w[pre + "out.b"])
+        OH, OW = (2 * H, 2 * W_) if crop is None else crop
+        up = self.ws("fus_up_" + tag, (B * OH * OW, F))
+        ops.upsample2x(oc, up, B=B, H=H, W_=W_, C_=F, outH=OH, outW=OW)
+        return up, OH, OW
+
+    def dpt_head(self, dec, B, nh, nw, num, want_raw=False):
+        """DPTOutputAdapter_fix.forward + postprocess (dust3r/heads/dpt_head.py:34-65, postprocess.py:10-58).
+        dec: list of dec_depth+1 token tensors; tokens ARE the NHWC map [B,nh,nw,C]."""
+        cfg, w = self.cfg, self.w
+        F, Lc = cfg.dpt_feat, cfg.dpt_last
+        pre = "dpt%d." % num
+        R = B * nh * nw
+        hk = cfg.hooks
+        dims = (cfg.enc_dim, cfg.dec_dim, cfg.dec_dim, cfg.dec_dim)
+        ld = (96, 192, 384, 768)
+        t = []
+        for i in range(4):
+            o = self.ws("dpt_pp%d" % i, (R, ld[i]))
+            ops.gemm(dec[hk[i]], w[pre + "pp%d.w" % i], o, M=R, N=ld[i], K=dims[i], lda=dims[i], ldc=ld[i], bias=w[pre + "pp%d.b" % i])
+            t.append(o)
+        # act_postprocess tails (croco/models/dpt_block.py:356-410)
+        l0 = self.ws("dpt_l0", (B * 16 * nh * nw, ld[0]))
+        ops.conv_transpose_ks(t[0], w[pre + "pp0t.w"], l0, B=B, H=nh, W_=nw, Cin=ld[0], Cout=ld[0], ks=4, bias=w[pre + "pp0t.b"])
+        l1 = self.ws("dpt_l1", (B * 4 * nh * nw, ld[1]))
+        ops.conv_transpose_ks(t[1], w[pre + "pp1t.w"], l1, B=B, H=nh, W_=nw, Cin=ld[1], Cout=ld[1], ks=2, bias=w[pre + "pp1t.b"])
+        l2 = t[2]
+        h3, w3 = (nh - 1) // 2 + 1, (nw - 1) // 2 + 1
+        l3 = self.ws("dpt_l3", (B * h3 * w3, ld[3]))
+        ops.conv3x3(t[3], w[pre + "pp3c.w"], l3, B=B, H=nh, W_=nw, Cin=ld[3], Cout=ld[3], stride=2, bias=w[pre + "pp3c.b"])
+        # scratch.layer_rn (3x3, no bias) -> 256 channels
+        geo = ((4 * nh, 4 * nw), (2 * nh, 2 * nw), (nh, nw), (h3, w3))
+        rn = []
+        for i, src in enumerate((l0, l1, l2, l3)):
+            Hh, Ww = geo[i]
+            o = self.ws("dpt_rn%d" % i, (B * Hh * Ww, F))
+            ops.conv3x3(src, w[pre + "rn%d.w" % i], o, B=B, H=Hh, W_=Ww, Cin=ld[i], Cout=F)
+            rn.append(o)
+        # refinenets; path_4 is cropped to layer 3's size (dust3r/heads/dpt_head.py:57)
+        p4, H4, W4 = self._fusion(pre + "ref4.", B, h3, w3, rn[3], None, "4", crop=(nh, nw))
+        p3, H3, W3 = self._fusion(pre + "ref3.", B, H4, W4, p4, rn[2], "3")
+        p2, H2, W2 = self._fusion(pre + "ref2.", B, H3, W3, p3, rn[1], "2")
+        p1, H1, W1 = self._fusion(pre + "ref1.", B, H2, W2, p2, rn[0], "1")
+        # head: conv3x3(256->128) -> x2 -> conv3x3(128->128) + ReLU -> 1x1(128->4) + postprocess
+        a = self.ws("dpt_h0", (B * H1 * W1, Lc))
+        ops.conv3x3(p1, w[pre + "h0.w"], a, B=B, H=H1, W_=W1, Cin=F, Cout=Lc, bias=w[pre + "h0.b"])
+        OH, OW = 2 * H1, 2 * W1
+        u = self.ws("dpt_h0up", (B * OH * OW, Lc))
+        ops.upsample2x(a, u, B=B, H=H1, W_=W1, C_=Lc)
+        c = self.ws("dpt_h2", (B * OH * OW, Lc))
+        ops.conv3x3(u, w[pre + "h2.w"], c, B=B, H=OH, W_=OW, Cin=Lc, Cout=Lc, bias=w[pre + "h2.b"], act=ACT_RELU)
+        pts = self.ws("dpt_pts%d" % num, (B, OH, OW, 3))
+        conf = self.ws("dpt_conf%d" % num, (B, OH, OW))
+        raw = self.ws("dpt_raw%d" % num, (B, OH, OW, 4)) if want_raw else None
+        ops.head_final(c, w[pre + "h4.w"], w[pre + "h4.b"], B * OH * OW, Lc, pts, conf, raw)
+        return pts, conf, raw
+
+    def encode_cur_value(self, pts3d, out, res):
+        """spann3r/model.py:305-320 (use_feat=False): pos_patch_embed(pts3d as a 3-channel image) -> 6 blocks without
+        RoPE -> value_norm -> value_out; `res` (feat_k1) is added in the last GEMM's epilogue (:519/:521 `cur_v+feat_k1`)
+        only if given.  pts3d fp32 [B,H,W,3] (any strides)."""
+        cfg, w = self.cfg, self.w
+        B, H, W_, _ = pts3d.shape
+        p, E = cfg.patch, cfg.enc_dim
+        nh, nw = H // p, W_ // p
+        P = nh * nw
+        R = B * P
+        _, _, zero_pos = self.positions(B, nh, nw)
+        col = self.ws("im2col", (R, 3 * p * p))
+        sb, sy, sx, sc = pts3d.stride()
+        ops.im2col_patch(pts3d, col, B=B, C_=3, H=H, W_=W_, p=p, strides=(sb, sc, sy, sx))
+        x = self.ws("val_x", (R, E))
+        ops.gemm(col, w["pospatch.w"], x, M=R, N=E, K=3 * p * p, lda=3 * p * p, ldc=E, bias=w["pospatch.b"])
+        for i in range(cfg.val_depth):
+            # rope=None in the reference (mem_pos_enc=False): all-zero positions make the fused RoPE the identity
+            self._block(x, R, B, P, E, cfg.enc_heads, "val%d." % i, zero_pos)
+        ln = self.ws("ln", (R, E))
+        ops.layernorm(x, w["value_norm.w"], w["value_norm.b"], 1e-6, ln, rows=R, C_=E)
+        ops.gemm(ln, w["value_out.w"], out, M=R, N=E, K=E, lda=E, ldc=E, bias=w["value_out.b"], res1=res, ldr1=E)
+        return out

@@ -1,0 +1,108 @@
+"""ctypes binding of libspann3r_hip.so (include/spann3r_hip.h).
+
+This is the whole host<->device boundary: plain pointers, sizes and a stream handle.  There is no
+CPU fallback anywhere in the product path: if the library is missing or a call fails, we raise.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libspann3r_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
+EPI_PLAIN, EPI_ROPE_VT, EPI_PIXSHUF = 0, 1, 2
+LOAD_PLAIN, LOAD_CONV3X3 = 0, 1
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("A2", C.c_void_p), ("W", C.c_void_p), ("C", C.c_void_p), ("bias", C.c_void_p),
+        ("res1", C.c_void_p), ("res2", C.c_void_p),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("batch", C.c_int32),
+        ("K1", C.c_int32),
+        ("lda", C.c_int64), ("lda2", C.c_int64), ("ldw", C.c_int64), ("ldc", C.c_int64),
+        ("ldr1", C.c_int64), ("ldr2", C.c_int64),
+        ("strideA", C.c_int64), ("strideW", C.c_int64), ("strideC", C.c_int64),
+        ("alpha", C.c_float), ("wdtype", C.c_int32), ("act", C.c_int32), ("out_bf16", C.c_int32),
+        ("relu_in", C.c_int32), ("loader", C.c_int32),
+        ("conv_H", C.c_int32), ("conv_W", C.c_int32), ("conv_C", C.c_int32),
+        ("conv_OH", C.c_int32), ("conv_OW", C.c_int32), ("conv_stride", C.c_int32),
+        ("epi", C.c_int32),
+        ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p), ("pos", C.c_void_p),
+        ("rope_cols", C.c_int32), ("vt", C.c_void_p), ("tokens", C.c_int32), ("heads", C.c_int32),
+        ("vt_ld", C.c_int64),
+        ("ps_k", C.c_int32), ("ps_H", C.c_int32), ("ps_W", C.c_int32), ("ps_C", C.c_int32),
+        ("tile", C.c_int32),
+    ]
+
+
+_lib = None
+
+_PROTOS = {
+    "sp3_gemm": [C.POINTER(GemmDesc), C.c_void_p],
+    "sp3_layernorm": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_int,
+                      C.c_int, C.c_int, C.c_void_p],
+    "sp3_layernorm_t": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_int,
+                        C.c_int, C.c_int, C.c_void_p],
+    "sp3_rope_2d": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64,
+                    C.c_void_p, C.c_float, C.c_float, C.c_void_p],
+    "sp3_attention": [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
+                      C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p],
+    "sp3_softmax_thresh": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float,
+                           C.c_int, C.c_void_p],
+    "sp3_colsum_accum": [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
+    "sp3_cos_sim": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
+    "sp3_mem_append": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p],
+    "sp3_prune_select": [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p],
+    "sp3_gather_rows": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "sp3_gather_cols": [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                        C.c_int, C.c_void_p],
+    "sp3_gather_1d": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p],
+    "sp3_im2col_patch": [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
+                         C.c_int, C.c_void_p, C.c_void_p],
+    "sp3_upsample2x": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "sp3_head_final": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                       C.c_void_p],
+    "sp3_fill_f32": [C.c_void_p, C.c_float, C.c_int64, C.c_void_p],
+    "sp3_cast_f32_to_bf16": [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
+    "sp3_copy2d_f32": [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p],
+}
+EXPORTS = sorted(list(_PROTOS) + ["sp3_last_error", "sp3_version"])
+
+
+def load():
+    """dlopen the in-tree library; raises (never falls back) if it is not there."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libspann3r_hip.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback for the hot path)")
+    lib = C.CDLL(LIB_PATH)
+    lib.sp3_last_error.restype = C.c_char_p
+    lib.sp3_last_error.argtypes = []
+    lib.sp3_version.restype = C.c_int
+    for name, argtypes in _PROTOS.items():
+        fn = getattr(lib, name)
+        fn.restype = C.c_int
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().sp3_last_error().decode(errors="replace")
+        raise RuntimeError("%s failed (%d): %s" % (what, rc, msg))
+
+
+def stream_ptr():
+    """The caller's CURRENT HIP stream (also the capturing stream under torch.cuda.graph)."""
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()

@@ -1,0 +1,405 @@
+"""Drop-in for `spann3r.model` (reference: /root/reference/spann3r/model.py).
+
+`Spann3R` keeps the reference's constructor, state-dict keys, `.dust3r`
+attribute and `forward(frames, return_memory=False) -> (preds, preds_all[, sp_mem])` contract;
+`SpatialMemory` keeps the reference's policy (working/long-term memory, similarity gate, prune)
+but is a static-capacity device arena with LayerNorm applied once at write time.
+All arithmetic runs in the HIP kernels of libspann3r_hip.so; there is no CPU / eager-torch path.
+"""
+import argparse
+import os
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .config import Spann3RConfig, FULL
+from .engine import Engine
+from .weights import param_spec, alias_of, synth_state_dict
+
+
+# ----------------------------------------------------------------------------- parameter tree
+def _build_param_tree(root: nn.Module, spec):
+    """Registers one nn.Parameter per state-dict key under the same dotted path the reference's
+    module tree produces (so load_state_dict / state_dict / parameters() behave identically)."""
+    made = {}
+    for key, shape in spec.items():
+        parts = key.split(".")
+        mod = root
+        for name in parts[:-1]:
+            if not hasattr(mod, name) or not isinstance(getattr(mod, name), nn.Module):
+                mod.add_module(name, nn.Module())
+            mod = getattr(mod, name)
+        src = alias_of(key)
+        if src is not None:                      # same Parameter object under a second name
+            mod.register_parameter(parts[-1], made[src])
+            continue
+        prm = nn.Parameter(torch.empty(shape))
+        mod.register_parameter(parts[-1], prm)
+        made[key] = prm
+    return made
+
+
+class SpatialMemory:
+    """Device-resident spatial memory (reference: spann3r/model.py:11-210).
+
+    Bank layout per batch element (capacity `cap` rows, fixed for the sequence):
+      mem_k_raw [cap,1024] fp32  = reference mem_k          mem_v_raw [cap,1024] fp32 = reference mem_v
+      k_hat     [cap,1024] wdt   = LN_k(mem_k)              v_hat_t   [1024,cap] wdt  = LN_v(mem_v)^T
+      mem_attn  [cap] fp32, mem_count [cap] fp32
+    """
+
+    def __init__(self, engine: Engine, batch, num_patches, capacity, attn_thresh=5e-4, long_mem_size=4000,
+                 work_mem_size=5, sim_thresh=0.95):
+        self.eng = engine
+        self.B, self.P, self.C = batch, num_patches, engine.cfg.enc_dim
+        self.attn_thresh = attn_thresh
+        self.long_mem_size = long_mem_size
+        self.work_mem_size = work_mem_size
+        self.top_k = long_mem_size
+        self.sim_thresh = sim_thresh
+        self.num_patches = num_patches
+        self.cap = (capacity + 63) // 64 * 64
+        dev, wdt = engine.device, engine.wdt
+        self._banks = [self._alloc(dev, wdt), None]   # second bank allocated on first prune
+        self._cur = 0
+        self.M = 0
+        self.wm = 0
+        self.lm = 0
+        self.events = []
+        self._score = torch.zeros(batch, max(work_mem_size, 1), device=dev)
+        self._sel = torch.zeros(batch, max(long_mem_size, 1), dtype=torch.int32, device=dev)
+
+    def _alloc(self, dev, wdt):
+        B, cap, C = self.B, self.cap, self.C
+        return dict(k_raw=torch.zeros(B, cap, C, device=dev), v_raw=torch.zeros(B, cap, C, device=dev),
+                    k_hat=torch.zeros(B, cap, C, dtype=wdt, device=dev), v_hat_t=torch.zeros(B, C, cap, dtype=wdt, device=dev),
+                    attn=torch.zeros(B, cap, device=dev), count=torch.zeros(B, cap, device=dev))
+
+    @property
+    def bank(self):
+        return self._banks[self._cur]
+
+    # reference-compatible views (what return_memory=True exposes)
+    @property
+    def mem_k(self):
+        return None if self.M == 0 else self.bank["k_raw"][:, :self.M]
+
+    @property
+    def mem_v(self):
+        return None if self.M == 0 else self.bank["v_raw"][:, :self.M]
+
+    @property
+    def mem_attn(self):
+        return None if self.M == 0 else self.bank["attn"][:, :self.M, None]
+
+    @property
+    def mem_count(self):
+        return None if self.M == 0 else self.bank["count"][:, :self.M, None]
+
+    # ------------------------------------------------------------------ read (:145-183)
+    def memory_read(self, feat, out):
+        """feat fp32 [B,P,1024] (the query, feat_k2) -> out = attn . LN_v(mem_v) + feat ; mem_attn += colsum(attn)."""
+        eng, bk, w = self.eng, self.bank, self.eng.w
+        B, P, C, M = self.B, self.P, self.C, self.M
+        assert M > 0
+        Mpad = (M + 7) // 8 * 8
+        ld = (self.cap + 7) // 8 * 8
+        qn = eng.ws("mem_qn", (B * P, C))
+        ops.layernorm(feat, w["norm_q.w"], w["norm_q.b"], 1e-5, qn, rows=B * P, C_=C)
+        S = eng.ws("mem_S", (B, P, ld))
+        Pm = eng.ws("mem_P", (B, P, ld))
+        ops.gemm(qn, bk["k_hat"], S, M=P, N=M, K=C, lda=C, ldc=ld, alpha=1.0 / (C ** 0.5), batch=B,
+                 strideA=P * C, strideW=self.cap * C, strideC=P * ld)
+        ops.softmax_thresh(S, Pm, ld=ld, rows=P, M=M, Mpad=Mpad, thresh=self.attn_thresh, batch=B, strideS=P * ld)
+        ops.gemm(Pm, bk["v_hat_t"], out, M=P, N=C, K=Mpad, lda=ld, ldc=C, ldw=self.cap, res1=feat, ldr1=C, batch=B,
+                 strideA=P * ld, strideW=C * self.cap, strideC=P * C)
+        for b in range(B):
+            ops.colsum_accum(Pm[b], ld, P, M, bk["attn"][b])
+        return out
+
+    # ------------------------------------------------------------------ write (:80-95)
+    def stage_write(self, feat_k, feat_v):
+        """Speculatively writes frame (k, v) into rows [M, M+P) of the bank; `commit()` makes it visible.
+        (A skipped frame simply never advances M, so the slot is overwritten by the next write.)"""
+        eng, bk, w = self.eng, self.bank, self.eng.w
+        B, P, C, M = self.B, self.P, self.C, self.M
+        assert M + P <= self.cap, "spatial memory capacity exceeded"
+        for b in range(B):
+            ops.copy2d(feat_k[b], C, bk["k_raw"][b, M:], C, P, C)
+            ops.copy2d(feat_v[b], C, bk["v_raw"][b, M:], C, P, C)
+            ops.layernorm(feat_k[b], w["norm_k.w"], w["norm_k.b"], 1e-5, bk["k_hat"][b, M:], rows=P, C_=C)
+            ops.layernorm(feat_v[b], w["norm_v.w"], w["norm_v.b"], 1e-5, bk["v_hat_t"][b, :, M:], rows=P, C_=C,
+                          ldo=self.cap, transposed=True)
+
+    def commit(self):
+        bk = self.bank
+        for b in range(self.B):
+            ops.mem_append(bk["count"][b], bk["attn"][b], self.M, self.P)
+        self.M += self.P
+
+    def add_mem(self, feat_k, feat_v):
+        self.stage_write(feat_k, feat_v)
+        self.commit()
+
+    # ------------------------------------------------------------------ similarity gate (:97-118)
+    def sim_scores(self, feat_k):
+        """[B, wm] mean cosine similarity of feat_k against each of the last `wm` stored frames."""
+        B, P, C = self.B, self.P, self.C
+        n = self.wm * P
+        for b in range(B):
+            ops.cos_sim(feat_k[b], self.bank["k_raw"][b, self.M - n:self.M], self.wm, P, C, self._score[b])
+        return self._score[:, :self.wm]
+
+    def check_sim(self, feat_k):
+        if self.M == 0 or self.sim_thresh == 1.0 or self.wm == 0:
+            return False
+        if self.wm * self.P > self.M:
+            # the reference reshapes mem_k[:, -wm*P:] and raises here (SURVEY.md §7 quirk ii, 512x512 after a prune)
+            raise RuntimeError("working memory (%d tokens) larger than the bank (%d): reference check_sim is undefined"
+                               % (self.wm * self.P, self.M))
+        mx = max(self.sim_scores(feat_k).cpu().reshape(-1).tolist())      # host sync, as in the reference (:114)
+        if mx > self.sim_thresh:
+            print("Similarity detected:", mx)
+            return True
+        return False
+
+    def add_mem_check(self, feat_k, feat_v):
+        """Eval-mode write policy (:120-143)."""
+        if self.check_sim(feat_k):
+            self.events.append("skip")
+            return
+        self.add_mem(feat_k, feat_v)
+        self.wm += 1
+        if self.wm > self.work_mem_size:
+            self.wm -= 1
+            if self.long_mem_size == 0:
+                raise NotImplementedError("long_mem_size == 0 (sliding window) is not used by Spann3R.forward")
+            self.lm += self.P
+        if self.lm > self.long_mem_size:
+            self.memory_prune()
+            self.lm = self.top_k - self.wm * self.P
+
+    # ------------------------------------------------------------------ prune (:185-210)
+    def memory_prune(self):
+        """Keep the top_k tokens by mem_attn/mem_count (tokens younger than work_mem_size+5 steps protected).
+        The kept tokens are stored sorted by weight descending, ties by index ascending (the reference's torch.topk
+        leaves the tie order implementation-defined, SURVEY.md §7 quirk i)."""
+        B, C, M, k = self.B, self.C, self.M, self.top_k
+        src = self.bank
+        if self._banks[1 - self._cur] is None:
+            self._banks[1 - self._cur] = self._alloc(self.eng.device, self.eng.wdt)
+        dst = self._banks[1 - self._cur]
+        for b in range(B):
+            ops.prune_select(src["attn"][b], src["count"][b], M, self.work_mem_size + 5, k, self._sel[b])
+            sel = self._sel[b]
+            ops.gather_rows(src["k_raw"][b], dst["k_raw"][b], sel, k, C)
+            ops.gather_rows(src["v_raw"][b], dst["v_raw"][b], sel, k, C)
+            ops.gather_rows(src["k_hat"][b], dst["k_hat"][b], sel, k, C)
+            ops.gather_cols(src["v_hat_t"][b], self.cap, dst["v_hat_t"][b], self.cap, sel, k, self.cap, C)
+            ops.gather_1d(src["attn"][b], dst["attn"][b], sel, k)
+            ops.gather_1d(src["count"][b], dst["count"][b], sel, k)
+        print("Memory pruned:", M, "->", k)
+        self.events.append("prune %d->%d" % (M, k))
+        self._cur = 1 - self._cur
+        self.M = k
+
+
+class Spann3R(nn.Module):
+    """MI355X drop-in for spann3r.model.Spann3R (spann3r/model.py:213-539)."""
+
+    def __init__(self, dus3r_name="./checkpoints/DUSt3R_ViTLarge_BaseDecoder_512_dpt.pth",
+                 use_feat=False, mem_pos_enc=False, memory_dropout=0.15, cfg: Spann3RConfig = None,
+                 init_weights=True):
+        super().__init__()
+        if use_feat:
+            raise NotImplementedError("use_feat=True (value encoder on 768-d decoder features, 48-d heads) is not on the "
+                                      "hot path the MI355X build covers; demo/eval/app all use use_feat=False")
+        if mem_pos_enc:
+            raise NotImplementedError("mem_pos_enc=True is not used by any reference entry point")
+        self.use_feat = use_feat
+        self.mem_pos_enc = mem_pos_enc
+        # spann3r/model.py:248: only its .training flag and p matter for the forward-only build
+        self.mem_dropout = nn.Dropout(memory_dropout)
+        ckpt = None
+        if dus3r_name is not None and os.path.isfile(dus3r_name):
+            # dust3r/model.py:27-51: the checkpoint carries its own constructor string
+            torch.serialization.add_safe_globals([argparse.Namespace])
+            ckpt = torch.load(dus3r_name, map_location="cpu", weights_only=True)
+            cfg = Spann3RConfig.from_ctor_string(ckpt["args"].model)
+        self.cfg = cfg or FULL
+        self._params = _build_param_tree(self, param_spec(self.cfg))
+        # no network: without a checkpoint file the weights are seeded synthetic ones
+        if init_weights:
+            with torch.no_grad():
+                for k, v in synth_state_dict(0, self.cfg).items():
+                    if alias_of(k) is None:
+                        self._params[k].copy_(v)
+        if ckpt is not None:
+            sd = {("dust3r." + k): v for k, v in ckpt["model"].items()}
+            if not any(k.startswith("dust3r.dec_blocks2") for k in sd):          # dust3r/model.py:94-101
+                for k, v in list(sd.items()):
+                    if k.startswith("dust3r.dec_blocks."):
+                        sd[k.replace("dust3r.dec_blocks.", "dust3r.dec_blocks2.")] = v
+            own = self.state_dict()
+            with torch.no_grad():
+                for k, v in sd.items():
+                    if k in own:
+                        own[k].copy_(v)
+                # spann3r/model.py:241-242: pos_patch_embed starts as a copy of the DUSt3R patch embed
+                self._params["pos_patch_embed.proj.weight"].copy_(self._params["dust3r.patch_embed.proj.weight"])
+                self._params["pos_patch_embed.proj.bias"].copy_(self._params["dust3r.patch_embed.proj.bias"])
+        self.precision = "fp32"
+        self._engine = None
+        self._engine_key = None
+        self._pinned = None
+
+    # ------------------------------------------------------------------ engine management
+    def set_precision(self, precision):
+        assert precision in ("fp32", "bf16")
+        self.precision = precision
+        return self
+
+    def _versions(self):
+        return tuple(p._version for p in self._params.values())
+
+    @property
+    def engine(self) -> Engine:
+        if self._pinned is not None:          # inside forward(): weights cannot change, skip the version scan
+            return self._pinned
+        dev = self._params["norm_q.weight"].device
+        if dev.type != "cuda":
+            raise RuntimeError("spann3r_amd.Spann3R runs on an MI355X only: call .to('cuda') first "
+                               "(there is no CPU fallback; the CPU reference lives in oracle/ for tests)")
+        key = (dev, self.precision, self._versions())
+        if self._engine is None or self._engine_key != key:
+            self._engine = Engine(self.cfg, dict(self._params), dev, self.precision)
+            self._engine_key = key
+        return self._engine
+
+    # ------------------------------------------------------------------ reference-shaped stage methods
+    @staticmethod
+    def _true_shape(view):
+        img = view["img"]
+        return view.get("true_shape", torch.tensor(img.shape[-2:])[None].repeat(img.shape[0], 1))
+
+    def encode_image(self, view):                                           # spann3r/model.py:263-270
+        img = view["img"]
+        feat, pos = self.engine.encode_image(img.float())
+        return feat, pos, self._true_shape(view)
+
+    def encode_image_pairs(self, view1, view2):                             # :272-287
+        img = torch.cat((view1["img"], view2["img"]), dim=0).float()
+        feat, pos = self.engine.encode_image(img)
+        f1, f2 = feat.chunk(2, dim=0)
+        p1, p2 = pos.chunk(2, dim=0)
+        return f1.contiguous(), f2.contiguous(), p1, p2, self._true_shape(view1), self._true_shape(view2)
+
+    def encode_frames(self, view1, view2, feat1, feat2, pos1, pos2, shape1, shape2):   # :289-297
+        if feat1 is None:
+            return self.encode_image_pairs(view1, view2)
+        feat1, pos1, shape1 = feat2, pos2, shape2
+        feat2, pos2, shape2 = self.encode_image(view2)
+        return feat1, feat2, pos1, pos2, shape1, shape2
+
+    @staticmethod
+    def _grid(shape, patch):
+        """token grid (nh, nw) the encoder produced for images of `true_shape` (PatchEmbedDust3R keeps raster order)."""
+        h, w = int(shape[0, 0]), int(shape[0, 1])
+        return h // patch, w // patch
+
+    def decode(self, feat1, pos1, feat2, pos2, shape1=None, shape2=None):   # :322-325
+        B, P1 = feat1.shape[:2]
+        g1 = self._grid(shape1, self.cfg.patch) if shape1 is not None else self._grid_from_pos(pos1)
+        g2 = self._grid(shape2, self.cfg.patch) if shape2 is not None else self._grid_from_pos(pos2)
+        return self.engine.decoder(feat1, feat2, B, g1[0], g1[1], g2[0], g2[1])
+
+    @staticmethod
+    def _grid_from_pos(pos):
+        return int(pos[0, :, 0].max()) + 1, int(pos[0, :, 1].max()) + 1
+
+    def encode_feat_key(self, feat1, feat2, num=1):                         # :299-303
+        B, P = feat1.shape[:2]
+        out = torch.empty(B, P, self.cfg.enc_dim, device=feat1.device)
+        return self.engine.encode_feat_key(feat1, feat2, B * P, num, out)
+
+    def downstream_head(self, dec, true_shape, num=1):                      # :327-331 + dust3r/utils/misc.py:54-96
+        hs, ws = true_shape[:, 0], true_shape[:, 1]
+        B = dec[-1].shape[0]
+        H, W = int(true_shape[0, 0]), int(true_shape[0, 1])
+        if not bool((true_shape == true_shape[0:1]).all()):
+            raise NotImplementedError("mixed portrait/landscape batch")
+        p = self.cfg.patch
+        pts, conf, _ = self.engine.dpt_head(dec, B, H // p, W // p, num)
+        res = {"pts3d": pts.clone(), "conf": conf.clone()}
+        if bool((ws < hs).all()):        # landscape_only wrapper: portrait results come back axis-swapped
+            res = {k: v.swapaxes(1, 2) for k, v in res.items()}
+        return res
+
+    def encode_cur_value(self, res1, dec1, pos1, shape1, add=None):         # :312-320
+        pts = res1["pts3d"]
+        B = pts.shape[0]
+        P = (pts.shape[1] // self.cfg.patch) * (pts.shape[2] // self.cfg.patch)
+        out = torch.empty(B, P, self.cfg.enc_dim, device=pts.device)
+        return self.engine.encode_cur_value(pts, out, add)
+
+    # ------------------------------------------------------------------ forward (:473-539)
+    @torch.no_grad()
+    def forward(self, frames, return_memory=False):
+        if self.training and self.mem_dropout.training and self.mem_dropout.p > 0:
+            # train-mode memory policy needs a dropout mask on the attention (spann3r/model.py:167-168); the
+            # forward-only build runs it with dropout disabled, the same idiom the survey probe used on the reference
+            raise NotImplementedError("training-mode forward with active memory dropout (backward is a §8f 'next' row); "
+                                      "call model.mem_dropout.eval() for the deterministic growing-bank policy")
+        self._pinned = None
+        eng = self.engine
+        self._pinned = eng
+        try:
+            return self._forward(eng, frames, return_memory)
+        finally:
+            self._pinned = None
+
+    def _forward(self, eng, frames, return_memory):
+        n = len(frames)
+        if n < 2:
+            raise ValueError("need at least two frames")
+        img0 = frames[0]["img"]
+        B = img0.shape[0]
+        p = self.cfg.patch
+        P = (img0.shape[-2] // p) * (img0.shape[-1] // p)
+        if self.training:
+            sp_mem = SpatialMemory(eng, B, P, capacity=(n - 1) * P, attn_thresh=0.0)
+        else:
+            sp_mem = SpatialMemory(eng, B, P, capacity=4000 + 8 * P)
+        feat1 = feat2 = pos1 = pos2 = shape1 = shape2 = None
+        feat_k2 = None
+        preds, preds_all = None, []
+        for i in range(n - 1):
+            view1, view2 = frames[i], frames[i + 1]
+            feat1, feat2, pos1, pos2, shape1, shape2 = self.encode_frames(view1, view2, feat1, feat2, pos1, pos2,
+                                                                          shape1, shape2)
+            if feat_k2 is not None:
+                feat_fuse = sp_mem.memory_read(feat_k2, torch.empty_like(feat1))
+            else:
+                feat_fuse = feat1
+            dec1, dec2 = self.decode(feat_fuse, pos1, feat2, pos2, shape1, shape2)
+            feat_k1 = self.encode_feat_key(feat1, dec1[-1], 1)
+            feat_k2 = self.encode_feat_key(feat2, dec2[-1], 2)
+            res1 = self.downstream_head(dec1, shape1, 1)
+            res2 = self.downstream_head(dec2, shape2, 2)
+            cur_v = self.encode_cur_value(res1, dec1, pos1, shape1, add=feat_k1)     # = cur_v + feat_k1
+            if self.training:
+                sp_mem.add_mem(feat_k1, cur_v)
+            else:
+                sp_mem.add_mem_check(feat_k1, cur_v)
+            res2["pts3d_in_other_view"] = res2.pop("pts3d")
+            if preds is None:
+                preds = [res1]
+            else:
+                res1["pts3d_in_other_view"] = res1.pop("pts3d")
+                preds.append(res1)
+            preds_all.append((res1, res2))
+        preds.append(res2)
+        if return_memory:
+            return preds, preds_all, sp_mem
+        return preds, preds_all

@@ -1,0 +1,200 @@
+"""Operator-level host wrappers: torch tensors in, HIP kernels (via the C-ABI) do the work.
+
+Each function mirrors one ATen-level operator of the reference's hot path (citations in
+include/spann3r_hip.h).  Tensors are only used as typed device pointers; nothing here computes
+with torch.  All launches go to torch's CURRENT stream, so the whole per-frame step can be
+captured in a hipGraph with torch.cuda.graph().
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+from .lib import GemmDesc, F32, BF16, ACT_NONE, ACT_GELU, ACT_RELU  # noqa: F401
+
+
+def wdtype_of(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError("weights must be float32 or bfloat16, got %s" % t.dtype)
+
+
+def _f32(t, name):
+    if t is not None and (t.dtype != torch.float32 or not t.is_cuda):
+        raise TypeError("%s must be a float32 CUDA(HIP) tensor" % name)
+
+
+def gemm(A, W, out, *, M, N, K, lda, ldc, bias=None, res1=None, ldr1=0, res2=None, ldr2=0, act=ACT_NONE, alpha=1.0,
+         out_bf16=False, relu_in=False, tile=-1, batch=1, strideA=0, strideW=0, strideC=0, ldw=0,
+         A2=None, lda2=0, K1=0):
+    """out[M,N] = act(alpha * A[M,K] @ W[N,K]^T + bias) (+ res1 + res2).  nn.Linear / 1x1 conv / einsum."""
+    _f32(A, "A")
+    d = GemmDesc()
+    d.A, d.A2, d.W, d.C = A.data_ptr(), L.ptr(A2), W.data_ptr(), out.data_ptr()
+    d.bias, d.res1, d.res2 = L.ptr(bias), L.ptr(res1), L.ptr(res2)
+    d.M, d.N, d.K, d.batch, d.K1 = M, N, K, batch, K1
+    d.lda, d.lda2, d.ldw, d.ldc, d.ldr1, d.ldr2 = lda, lda2, ldw, ldc, ldr1, ldr2
+    d.strideA, d.strideW, d.strideC = strideA, strideW, strideC
+    d.alpha, d.wdtype, d.act, d.out_bf16, d.relu_in = alpha, wdtype_of(W), act, int(out_bf16), int(relu_in)
+    d.loader, d.epi, d.tile = L.LOAD_PLAIN, L.EPI_PLAIN, tile
+    L.check(L.load().sp3_gemm(C.byref(d), L.stream_ptr()), "sp3_gemm")
+    return out
+
+
+def conv3x3(x, Wp, out, *, B, H, W_, Cin, Cout, stride=1, bias=None, res1=None, res2=None, act=ACT_NONE,
+            relu_in=False, tile=-1):
+    """3x3 Conv2d, padding 1, on an NHWC fp32 map [B,H,W,Cin] -> [B,OH,OW,Cout] (implicit GEMM).
+    Wp is the weight packed as [Cout, 9*Cin] with k = (ky*3+kx)*Cin + ci."""
+    _f32(x, "x")
+    OH, OW = (H - 1) // stride + 1, (W_ - 1) // stride + 1
+    d = GemmDesc()
+    d.A, d.W, d.C = x.data_ptr(), Wp.data_ptr(), out.data_ptr()
+    d.bias, d.res1, d.res2 = L.ptr(bias), L.ptr(res1), L.ptr(res2)
+    d.M, d.N, d.K, d.batch = B * OH * OW, Cout, 9 * Cin, 1
+    d.lda, d.ldc, d.ldr1, d.ldr2 = Cin, Cout, Cout, Cout
+    d.alpha, d.wdtype, d.act, d.relu_in = 1.0, wdtype_of(Wp), act, int(relu_in)
+    d.loader, d.epi, d.tile = L.LOAD_CONV3X3, L.EPI_PLAIN, tile
+    d.conv_H, d.conv_W, d.conv_C, d.conv_OH, d.conv_OW, d.conv_stride = H, W_, Cin, OH, OW, stride
+    L.check(L.load().sp3_gemm(C.byref(d), L.stream_ptr()), "sp3_gemm(conv3x3)")
+    return out
+
+
+def conv_transpose_ks(x, Wp, out, *, B, H, W_, Cin, Cout, ks, bias=None, tile=-1):
+    """ConvTranspose2d with kernel == stride == ks on NHWC [B,H,W,Cin] -> [B,ks*H,ks*W,Cout].
+    Wp is packed [(ky*ks+kx)*Cout + co, ci]."""
+    _f32(x, "x")
+    d = GemmDesc()
+    d.A, d.W, d.C, d.bias = x.data_ptr(), Wp.data_ptr(), out.data_ptr(), L.ptr(bias)
+    d.M, d.N, d.K, d.batch = B * H * W_, ks * ks * Cout, Cin, 1
+    d.lda, d.ldc = Cin, Cout
+    d.alpha, d.wdtype = 1.0, wdtype_of(Wp)
+    d.loader, d.epi, d.tile = L.LOAD_PLAIN, L.EPI_PIXSHUF, tile
+    d.ps_k, d.ps_H, d.ps_W, d.ps_C = ks, H, W_, Cout
+    L.check(L.load().sp3_gemm(C.byref(d), L.stream_ptr()), "sp3_gemm(conv_transpose)")
+    return out
+
+
+def proj_rope_vt(A, W, bias, out_qk, ldc, vt, vt_ld, *, M, N, K, lda, rope_cols, pos, cos, sin, tokens, heads, tile=-1):
+    """Fused q/k(/v) projection of an attention layer: bias + 2-D RoPE on columns [0, rope_cols)
+    (stored row-major to out_qk) and per-head transposed store of the V columns to vt."""
+    _f32(A, "A")
+    d = GemmDesc()
+    d.A, d.W, d.C, d.bias = A.data_ptr(), W.data_ptr(), L.ptr(out_qk), L.ptr(bias)
+    d.M, d.N, d.K, d.batch = M, N, K, 1
+    d.lda, d.ldc = lda, ldc
+    d.alpha, d.wdtype = 1.0, wdtype_of(W)
+    d.loader, d.epi, d.tile = L.LOAD_PLAIN, L.EPI_ROPE_VT, tile
+    d.rope_cos, d.rope_sin, d.pos, d.rope_cols = cos.data_ptr(), sin.data_ptr(), pos.data_ptr(), rope_cols
+    d.vt, d.vt_ld, d.tokens, d.heads = L.ptr(vt), vt_ld, tokens, heads
+    if out_qk is None:
+        d.C = vt.data_ptr()           # unused by the kernel when rope_cols == 0, but must be non-null
+    L.check(L.load().sp3_gemm(C.byref(d), L.stream_ptr()), "sp3_gemm(rope_vt)")
+
+
+def layernorm(x, gamma, beta, eps, out, *, rows, C_, ldx=None, ldo=None, transposed=False):
+    _f32(x, "x")
+    ldx = C_ if ldx is None else ldx
+    ldo = C_ if ldo is None else ldo
+    fn = L.load().sp3_layernorm_t if transposed else L.load().sp3_layernorm
+    L.check(fn(x.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(), eps, out.data_ptr(), ldo,
+               int(out.dtype == torch.bfloat16), rows, C_, L.stream_ptr()), "sp3_layernorm")
+    return out
+
+
+def rope_2d(tokens, positions, base, fwd):
+    """In-place 2-D RoPE on a [B,N,H,D] view (curope.rope_2d drop-in; curope.cpp:49-69)."""
+    if tokens.dim() != 4:
+        raise RuntimeError("tokens must have 4 dimensions")
+    if positions.dim() != 3:
+        raise RuntimeError("positions must have 3 dimensions")
+    if tokens.size(0) != positions.size(0):
+        raise RuntimeError("batch size differs between tokens & positions")
+    if tokens.size(1) != positions.size(1):
+        raise RuntimeError("seq_length differs between tokens & positions")
+    if positions.size(2) != 2:
+        raise RuntimeError("positions.shape[2] must be equal to 2")
+    if tokens.is_cuda != positions.is_cuda:
+        raise RuntimeError("tokens and positions are not on the same device")
+    if not tokens.is_cuda:
+        raise RuntimeError("spann3r_amd rope_2d is the MI355X kernel: tokens must be on the GPU (no CPU fallback)")
+    if tokens.stride(3) != 1:
+        raise RuntimeError("tokens are not contiguous")
+    if not positions.is_contiguous() or positions.dtype != torch.int64:
+        raise RuntimeError("positions are not contiguous int64")
+    B, N, H, D = tokens.shape
+    dt = wdtype_of(tokens)
+    L.check(L.load().sp3_rope_2d(tokens.data_ptr(), dt, B, N, H, D, tokens.stride(0), tokens.stride(1), tokens.stride(2),
+                                 positions.data_ptr(), float(base), float(fwd), L.stream_ptr()), "sp3_rope_2d")
+    return tokens
+
+
+def attention(q, sq, ldq, k, sk, ldk, vt, vt_ld, out, ldo, *, B, heads, Nq, Nk, scale):
+    L.check(L.load().sp3_attention(q.data_ptr(), sq, ldq, k.data_ptr(), sk, ldk, vt.data_ptr(), vt_ld, out.data_ptr(), ldo,
+                                   B, heads, Nq, Nk, float(scale), wdtype_of(vt), L.stream_ptr()), "sp3_attention")
+    return out
+
+
+def softmax_thresh(S, P, *, ld, rows, M, Mpad, thresh, batch=1, strideS=0):
+    L.check(L.load().sp3_softmax_thresh(S.data_ptr(), P.data_ptr(), ld, strideS, rows, M, Mpad, float(thresh), batch,
+                                        L.stream_ptr()), "sp3_softmax_thresh")
+
+
+def colsum_accum(P, ld, rows, M, mem_attn):
+    L.check(L.load().sp3_colsum_accum(P.data_ptr(), ld, rows, M, mem_attn.data_ptr(), L.stream_ptr()), "sp3_colsum_accum")
+
+
+def cos_sim(k, wm, T, P, C_, score):
+    L.check(L.load().sp3_cos_sim(k.data_ptr(), wm.data_ptr(), T, P, C_, score.data_ptr(), L.stream_ptr()), "sp3_cos_sim")
+
+
+def mem_append(count, attn, M, P):
+    L.check(L.load().sp3_mem_append(count.data_ptr(), attn.data_ptr(), M, P, L.stream_ptr()), "sp3_mem_append")
+
+
+def prune_select(attn, count, M, protect, top_k, sel):
+    L.check(L.load().sp3_prune_select(attn.data_ptr(), count.data_ptr(), M, float(protect), top_k, sel.data_ptr(),
+                                      L.stream_ptr()), "sp3_prune_select")
+
+
+def gather_rows(src, dst, sel, n_sel, C_):
+    L.check(L.load().sp3_gather_rows(src.data_ptr(), dst.data_ptr(), sel.data_ptr(), n_sel, C_, src.element_size(),
+                                     L.stream_ptr()), "sp3_gather_rows")
+
+
+def gather_cols(src, ld_src, dst, ld_dst, sel, n_sel, n_fill, C_):
+    L.check(L.load().sp3_gather_cols(src.data_ptr(), ld_src, dst.data_ptr(), ld_dst, sel.data_ptr(), n_sel, n_fill, C_,
+                                     src.element_size(), L.stream_ptr()), "sp3_gather_cols")
+
+
+def gather_1d(src, dst, sel, n_sel):
+    L.check(L.load().sp3_gather_1d(src.data_ptr(), dst.data_ptr(), sel.data_ptr(), n_sel, L.stream_ptr()), "sp3_gather_1d")
+
+
+def im2col_patch(img, out, *, B, C_, H, W_, p, strides):
+    _f32(img, "img")
+    sb, sc, sy, sx = strides
+    L.check(L.load().sp3_im2col_patch(img.data_ptr(), sb, sc, sy, sx, B, C_, H, W_, p, out.data_ptr(), L.stream_ptr()),
+            "sp3_im2col_patch")
+    return out
+
+
+def upsample2x(x, out, *, B, H, W_, C_, outH=None, outW=None):
+    outH = 2 * H if outH is None else outH
+    outW = 2 * W_ if outW is None else outW
+    L.check(L.load().sp3_upsample2x(x.data_ptr(), out.data_ptr(), B, H, W_, C_, outH, outW, L.stream_ptr()), "sp3_upsample2x")
+    return out
+
+
+def head_final(feat, w, b, pixels, C_, pts, conf, raw=None):
+    L.check(L.load().sp3_head_final(feat.data_ptr(), w.data_ptr(), b.data_ptr(), pixels, C_, pts.data_ptr(), conf.data_ptr(),
+                                    L.ptr(raw), L.stream_ptr()), "sp3_head_final")
+
+
+def fill(t, v):
+    L.check(L.load().sp3_fill_f32(t.data_ptr(), float(v), t.numel(), L.stream_ptr()), "sp3_fill_f32")
+
+
+def copy2d(src, lds, dst, ldd, rows, cols):
+    L.check(L.load().sp3_copy2d_f32(src.data_ptr(), lds, dst.data_ptr(), ldd, rows, cols, L.stream_ptr()), "sp3_copy2d_f32")

@@ -1,0 +1,197 @@
+"""Hot-path parity on an MI355X: spann3r_amd.Spann3R (HIP kernels through the C-ABI) against
+ (a) the golden dumps of the unmodified reference (tests/golden/*.npz) and
+ (b) the CPU oracle run live on the same seeded inputs.
+The bar (BASELINE.json north_star): pointmaps / confidences within 1e-3 relative in fp32 mode."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOL_FP32 = 1e-3          # north_star tolerance; measured errors are ~1e-5 and are printed
+TOL_BF16 = 6e-2          # bf16 operands, fp32 accumulate: reported, not the parity claim
+
+
+@pytest.fixture(scope="module")
+def tiny_model(tiny_sd):
+    from spann3r_amd import Spann3R, TINY
+    m = Spann3R(dus3r_name=None, cfg=TINY, init_weights=False)
+    m.load_state_dict(tiny_sd, strict=True)
+    return m.to(DEV).eval()
+
+
+def to_dev(frames):
+    return [{k: (v.to(DEV) if k == "img" else v) for k, v in f.items()} for f in frames]
+
+
+def test_native_library_is_loaded():
+    from spann3r_amd import lib
+    l = lib.load()
+    assert l.sp3_version() >= 1
+    maps = open("/proc/self/maps").read()
+    assert "libspann3r_hip.so" in maps
+
+
+def test_tiny_stages_vs_golden(tiny_model):
+    """Stage by stage (SURVEY.md §8a rows a2,a6-a10) on the reference's own intermediate tensors."""
+    from spann3r_amd import TINY
+    from spann3r_amd.weights import synth_frames
+    g = load_golden("spann3r_tiny.npz")
+    H, W = map(int, g["meta_hw"])
+    m = tiny_model
+    frames = to_dev(synth_frames(int(g["meta_frames"]), H, W))
+    errs = {}
+    # a2: encoder (first pair batched, then single)
+    f1, f2, p1, p2, s1, s2 = m.encode_image_pairs(frames[0], frames[1])
+    errs["enc_feat1"] = rel_err(f1.cpu(), g["s0_feat1"])
+    errs["enc_feat2"] = rel_err(f2.cpu(), g["s0_feat2"])
+    # a7: decoder on the reference's inputs
+    gf = lambda k: torch.from_numpy(g[k]).to(DEV)
+    dec1, dec2 = m.decode(gf("s0_feat_fuse"), p1, gf("s0_feat2"), p2, s1, s2)
+    for h in TINY.hooks[1:]:
+        errs["dec1_%d" % h] = rel_err(dec1[h].reshape(g["s0_dec1_%d" % h].shape).cpu(), g["s0_dec1_%d" % h])
+        errs["dec2_%d" % h] = rel_err(dec2[h].reshape(g["s0_dec2_%d" % h].shape).cpu(), g["s0_dec2_%d" % h])
+    # a8: key MLPs
+    last = TINY.hooks[-1]
+    k1 = m.encode_feat_key(gf("s0_feat1"), gf("s0_dec1_%d" % last), 1)
+    k2 = m.encode_feat_key(gf("s0_feat2"), gf("s0_dec2_%d" % last), 2)
+    errs["feat_k1"], errs["feat_k2"] = rel_err(k1.cpu(), g["s0_feat_k1"]), rel_err(k2.cpu(), g["s0_feat_k2"])
+    # a9: DPT heads on the decoder outputs we just produced
+    r1 = m.downstream_head(dec1, s1, 1)
+    r2 = m.downstream_head(dec2, s2, 2)
+    errs["pts1"], errs["conf1"] = rel_err(r1["pts3d"].cpu(), g["s0_pts1"]), rel_err(r1["conf"].cpu(), g["s0_conf1"])
+    errs["pts2"], errs["conf2"] = rel_err(r2["pts3d"].cpu(), g["s0_pts2"]), rel_err(r2["conf"].cpu(), g["s0_conf2"])
+    # a10: value encoder on the reference's pointmap
+    cv = m.encode_cur_value({"pts3d": gf("s0_pts1")}, None, None, None)
+    errs["cur_v"] = rel_err(cv.cpu(), g["s0_cur_v"])
+    print("stage errors (fp32):", {k: "%.2e" % v for k, v in errs.items()})
+    bad = {k: v for k, v in errs.items() if not v < TOL_FP32}
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", TOL_FP32), ("bf16", TOL_BF16)])
+def test_tiny_forward_vs_golden(tiny_model, precision, tol):
+    from spann3r_amd.weights import synth_frames
+    g = load_golden("spann3r_tiny.npz")
+    H, W = map(int, g["meta_hw"])
+    m = tiny_model.set_precision(precision)
+    try:
+        frames = to_dev(synth_frames(int(g["meta_frames"]), H, W))
+        preds, preds_all, mem = m(frames, return_memory=True)
+    finally:
+        m.set_precision("fp32")
+    assert len(preds) == len(frames) and len(preds_all) == len(frames) - 1
+    assert preds[0] is preds_all[0][0] and preds[-1] is preds_all[-1][1]          # aliasing contract, SURVEY.md §8b
+    worst = 0.0
+    for j, p in enumerate(preds):
+        key = "pts3d" if j == 0 else "pts3d_in_other_view"
+        assert set(p.keys()) == {key, "conf"}
+        assert p[key].dtype == torch.float32 and tuple(p[key].shape) == (1, H, W, 3)
+        e1, e2 = rel_err(p[key].cpu(), g["pred%d_pts" % j]), rel_err(p["conf"].cpu(), g["pred%d_conf" % j])
+        worst = max(worst, e1, e2)
+    print("tiny forward %s: worst rel err %.3e" % (precision, worst))
+    assert worst < tol
+    if precision == "fp32":
+        assert rel_err(mem.mem_k.cpu(), g["mem_k"]) < tol and rel_err(mem.mem_v.cpu(), g["mem_v"]) < tol
+        assert np.array_equal(mem.mem_count.cpu().numpy(), g["mem_count"])
+        assert rel_err(mem.mem_attn.cpu(), g["mem_attn"]) < tol
+        assert [mem.wm, mem.lm] == list(g["mem_wm_lm"])
+
+
+def test_tiny_training_policy(tiny_model):
+    """Growing bank: train-mode memory policy with dropout disabled (the oracle for BASELINE config 3)."""
+    from spann3r_amd.weights import synth_frames
+    g = load_golden("spann3r_tiny.npz")
+    H, W = map(int, g["meta_hw"])
+    m = tiny_model
+    m.train()
+    m.mem_dropout.eval()
+    try:
+        preds, _, mem = m(to_dev(synth_frames(int(g["meta_frames"]), H, W)), return_memory=True)
+    finally:
+        m.eval()
+    for j, p in enumerate(preds):
+        assert rel_err(p["pts3d" if j == 0 else "pts3d_in_other_view"].cpu(), g["train_pred%d_pts" % j]) < TOL_FP32
+        assert rel_err(p["conf"].cpu(), g["train_pred%d_conf" % j]) < TOL_FP32
+    assert rel_err(mem.mem_attn.cpu(), g["train_mem_attn"]) < TOL_FP32
+
+
+def test_tiny_vs_live_oracle_batch2_portrait(tiny_model, tiny_sd):
+    """Oracle run live on the GPU box's CPU: batch of 2 sequences, portrait 80x48 frames, other seeds."""
+    from oracle import spann3r_oracle as O
+    from spann3r_amd import TINY
+    from spann3r_amd.weights import synth_frames
+    frames = synth_frames(3, 80, 48, batch=2, seed=77)
+    ref, _ = O.forward(frames, tiny_sd, TINY)
+    got, _ = tiny_model(to_dev(frames))
+    for j in range(len(ref)):
+        key = "pts3d" if j == 0 else "pts3d_in_other_view"
+        assert tuple(got[j][key].shape) == tuple(ref[j][key].shape)
+        assert rel_err(got[j][key].cpu(), ref[j][key]) < TOL_FP32
+        assert rel_err(got[j]["conf"].cpu(), ref[j]["conf"]) < TOL_FP32
+
+
+def test_memory_bank_fixture(tiny_model):
+    """Stand-alone spatial memory over 32 frames of P=196: similarity skips, working->long-term hand-over and one
+    prune (5096 -> 4000), against the dump of the reference's SpatialMemory."""
+    import importlib.util
+    from spann3r_amd.model import SpatialMemory
+    spec = importlib.util.spec_from_file_location("memory_inputs", os.path.join(os.path.dirname(__file__), "golden", "memory_inputs.py"))
+    mi = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mi)
+    g = load_golden("memory_bank.npz")
+    eng = tiny_model.engine
+    mem = SpatialMemory(eng, 1, 196, capacity=4000 + 8 * 196)
+    events, worst = [], 0.0
+    for step in range(int(g["n_steps"])):
+        k, v, q = (t.to(DEV) for t in mi.memory_inputs(step))
+        if mem.M > 0:
+            o = mem.memory_read(q, torch.empty_like(q))
+            e = rel_err(o[:, ::7, ::16].cpu(), g["read%d_sub" % step])
+            worst = max(worst, e)
+            assert e < TOL_FP32, (step, e)
+        before = -1 if mem.M == 0 else mem.M
+        mem.add_mem_check(k, v)
+        events.append([step, before, mem.M, mem.wm, mem.lm])
+    print("memory fixture: worst read err %.2e" % worst)
+    assert np.array_equal(np.array(events), g["events"])
+    # after the prune the reference's bank order is topk's (ties implementation-defined): compare as multisets
+    cnt, ref_cnt = mem.mem_count.cpu().numpy().ravel(), g["mem_count"].ravel()
+    assert np.array_equal(np.sort(cnt), np.sort(ref_cnt))
+    assert rel_err(np.sort(mem.mem_attn.cpu().numpy().ravel()), np.sort(g["mem_attn"].ravel())) < TOL_FP32
+
+
+def test_full224_vs_golden(full_sd):
+    """BASELINE config 1 geometry (24/12 layers, 5 frames of 224x224), fp32 mode, against the reference dump."""
+    from spann3r_amd import Spann3R, FULL
+    from spann3r_amd.weights import synth_frames, state_dict_fingerprint
+    g = load_golden("spann3r_full224.npz")
+    assert state_dict_fingerprint(full_sd) == float(g["fingerprint"])
+    m = Spann3R(dus3r_name=None, cfg=FULL, init_weights=False)
+    m.load_state_dict(full_sd, strict=True)
+    m = m.to(DEV).eval()
+    preds, _, mem = m(to_dev(synth_frames(int(g["meta_frames"]), 224, 224)), return_memory=True)
+    worst = 0.0
+    for j, p in enumerate(preds):
+        pts = p["pts3d" if j == 0 else "pts3d_in_other_view"]
+        worst = max(worst, rel_err(pts[:, ::4, ::4].cpu(), g["pred%d_pts_sub" % j]),
+                    rel_err(p["conf"][:, ::4, ::4].cpu(), g["pred%d_conf_sub" % j]))
+    print("full224 fp32: worst rel err %.3e" % worst)
+    assert worst < TOL_FP32
+    assert rel_err(mem.mem_k[:, ::7, ::16].cpu(), g["mem_k_sub"]) < TOL_FP32
+    # bf16 bench mode: accuracy is REPORTED against the fp32 reference
+    m.set_precision("bf16")
+    preds_b, _ = m(to_dev(synth_frames(int(g["meta_frames"]), 224, 224)))
+    wb = 0.0
+    for j, p in enumerate(preds_b):
+        pts = p["pts3d" if j == 0 else "pts3d_in_other_view"]
+        wb = max(wb, rel_err(pts[:, ::4, ::4].cpu(), g["pred%d_pts_sub" % j]), rel_err(p["conf"][:, ::4, ::4].cpu(), g["pred%d_conf_sub" % j]))
+    print("full224 bf16: worst rel err %.3e" % wb)
+    assert wb < TOL_BF16
+    # size-independent properties at full size: determinism and independence of calls (a new memory per forward)
+    preds2, _ = m(to_dev(synth_frames(int(g["meta_frames"]), 224, 224)))
+    assert all(torch.equal(a["conf"], b["conf"]) for a, b in zip(preds_b, preds2))

@@ -1,0 +1,329 @@
+"""Kernel-level parity tests (need an MI355X): every C-ABI op against a CPU fp32/fp64 restatement
+(oracle/spann3r_oracle.py where the op exists there, plain torch-CPU formulas otherwise).
+Tolerances: fp32 MFMA path 2e-5 relative (summation order only); bf16 path is compared against
+the same formula evaluated on bf16-rounded operands with fp32 accumulation."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _ops():
+    from spann3r_amd import ops
+    return ops
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def bf(t):
+    return t.to(torch.bfloat16).float()
+
+
+TOL = {torch.float32: 2e-5, torch.bfloat16: 2e-3}
+
+
+# ----------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("wdt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(196, 1024, 1024), (392, 3072, 1024), (20, 768, 768), (100, 96, 1024),
+                                   (196, 588, 1024), (49, 256, 96), (196, 1024, 1736), (7, 32, 8), (300, 160, 200)])
+@pytest.mark.parametrize("tile", [-1, 0, 1, 2])
+def test_gemm_plain(wdt, M, N, K, tile):
+    ops = _ops()
+    A, W = rnd(M, K, seed=1), rnd(N, K, seed=2)
+    # asymmetric content so a transposed write cannot pass
+    A[:, 0] += torch.arange(M) * 0.01
+    W[:, 1] += torch.arange(N) * 0.02
+    Ad, Wd = A.to(DEV), W.to(DEV).to(wdt)
+    out = torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm(Ad, Wd, out, M=M, N=N, K=K, lda=K, ldc=N, tile=tile)
+    ref = (bf(A) if wdt == torch.bfloat16 else A).double() @ (bf(W) if wdt == torch.bfloat16 else W).double().T
+    assert not torch.isnan(out).any()
+    assert rel_err(out.cpu(), ref) < TOL[wdt], (M, N, K, tile)
+
+
+@pytest.mark.parametrize("wdt", [torch.float32, torch.bfloat16])
+def test_gemm_epilogue_bias_gelu_residuals(wdt):
+    ops = _ops()
+    M, N, K = 196, 1024, 1024
+    A, W, b, r1, r2 = rnd(M, K, seed=1), rnd(N, K, seed=2) * 0.05, rnd(N, seed=3), rnd(M, N, seed=4), rnd(M, N, seed=5)
+    Ad, Wd = A.to(DEV), W.to(DEV).to(wdt)
+    out = torch.empty(M, N, device=DEV)
+    ops.gemm(Ad, Wd, out, M=M, N=N, K=K, lda=K, ldc=N, bias=b.to(DEV), res1=r1.to(DEV), ldr1=N, res2=r2.to(DEV), ldr2=N,
+             act=ops.ACT_GELU, alpha=0.5)
+    Ar, Wr = (bf(A), bf(W)) if wdt == torch.bfloat16 else (A, W)
+    ref = F.gelu(0.5 * (Ar.double() @ Wr.double().T) + b.double()) + r1.double() + r2.double()
+    assert rel_err(out.cpu(), ref) < TOL[wdt]
+    # in-place residual (C aliases res1), ReLU, bf16 output
+    x = r1.clone().to(DEV)
+    ops.gemm(Ad, Wd, x, M=M, N=N, K=K, lda=K, ldc=N, bias=b.to(DEV), res1=x, ldr1=N)
+    assert rel_err(x.cpu(), (Ar.double() @ Wr.double().T) + b.double() + r1.double()) < TOL[wdt]
+    ob = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    ops.gemm(Ad, Wd, ob, M=M, N=N, K=K, lda=K, ldc=N, act=ops.ACT_RELU, out_bf16=True)
+    assert rel_err(ob.float().cpu(), F.relu(Ar.double() @ Wr.double().T)) < 5e-3
+
+
+@pytest.mark.parametrize("wdt", [torch.float32, torch.bfloat16])
+def test_gemm_split_a_ldw_batch(wdt):
+    ops = _ops()
+    # split-A (cat along K without the copy), as used by encode_feat_key
+    M, N, K1, K2 = 40, 128, 1024, 768
+    A1, A2, W = rnd(M, K1, seed=1), rnd(M, K2, seed=2), rnd(N, K1 + K2, seed=3)
+    out = torch.empty(M, N, device=DEV)
+    ops.gemm(A1.to(DEV), W.to(DEV).to(wdt), out, M=M, N=N, K=K1 + K2, lda=K1, ldc=N, A2=A2.to(DEV), lda2=K2, K1=K1)
+    cat = torch.cat((A1, A2), 1)
+    Ar, Wr = (bf(cat), bf(W)) if wdt == torch.bfloat16 else (cat, W)
+    assert rel_err(out.cpu(), Ar.double() @ Wr.double().T) < TOL[wdt]
+    # batched with W row stride (the memory-read P.V^T GEMM): W [N, ldw] uses only the first K columns
+    B, M, N, K, ldw, lda = 2, 20, 64, 40, 128, 48
+    A, W = rnd(B, M, lda, seed=4), rnd(B, N, ldw, seed=5)
+    res = rnd(B, M, N, seed=6)
+    out = torch.empty(B, M, N, device=DEV)
+    ops.gemm(A.to(DEV), W.to(DEV).to(wdt), out, M=M, N=N, K=K, lda=lda, ldc=N, ldw=ldw, batch=B, strideA=M * lda,
+             strideW=N * ldw, strideC=M * N, res1=res.to(DEV), ldr1=N)
+    Ar, Wr = (bf(A), bf(W)) if wdt == torch.bfloat16 else (A, W)
+    ref = torch.einsum("bmk,bnk->bmn", Ar[:, :, :K].double(), Wr[:, :, :K].double()) + res.double()
+    assert rel_err(out.cpu(), ref) < TOL[wdt]
+
+
+@pytest.mark.parametrize("wdt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride", [(1, 14, 14, 96, 256, 1), (2, 5, 4, 768, 768, 2), (1, 56, 56, 256, 256, 1),
+                                                   (1, 9, 7, 128, 128, 1), (1, 4, 5, 384, 256, 1)])
+def test_conv3x3(wdt, B, H, W, Cin, Cout, stride):
+    ops = _ops()
+    x, w, b = rnd(B, Cin, H, W, seed=1), rnd(Cout, Cin, 3, 3, seed=2) * 0.05, rnd(Cout, seed=3)
+    OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
+    r1, r2 = rnd(B, Cout, OH, OW, seed=4), rnd(B, Cout, OH, OW, seed=5)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous()
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous()
+    out = torch.empty(B, OH, OW, Cout, device=DEV)
+    ops.conv3x3(nhwc(x).to(DEV), wp.to(DEV).to(wdt), out, B=B, H=H, W_=W, Cin=Cin, Cout=Cout, stride=stride,
+                bias=b.to(DEV), res1=nhwc(r1).to(DEV), res2=nhwc(r2).to(DEV), relu_in=True, act=ops.ACT_RELU)
+    xr, wr = (bf(F.relu(x)), bf(w)) if wdt == torch.bfloat16 else (F.relu(x), w)
+    ref = F.relu(F.conv2d(xr.double(), wr.double(), b.double(), stride=stride, padding=1)) + r1.double() + r2.double()
+    assert rel_err(out.cpu(), nhwc(ref)) < TOL[wdt]
+
+
+@pytest.mark.parametrize("wdt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("ks,C", [(4, 96), (2, 192)])
+def test_conv_transpose(wdt, ks, C):
+    ops = _ops()
+    B, H, W = 2, 4, 5
+    x, w, b = rnd(B, C, H, W, seed=1), rnd(C, C, ks, ks, seed=2) * 0.1, rnd(C, seed=3)
+    wp = w.permute(2, 3, 1, 0).reshape(-1, C).contiguous()
+    out = torch.empty(B, ks * H, ks * W, C, device=DEV)
+    ops.conv_transpose_ks(x.permute(0, 2, 3, 1).contiguous().to(DEV), wp.to(DEV).to(wdt), out, B=B, H=H, W_=W, Cin=C, Cout=C,
+                          ks=ks, bias=b.to(DEV))
+    xr, wr = (bf(x), bf(w)) if wdt == torch.bfloat16 else (x, w)
+    ref = F.conv_transpose2d(xr.double(), wr.double(), b.double(), stride=ks)
+    assert rel_err(out.cpu(), ref.permute(0, 2, 3, 1)) < TOL[wdt]
+
+
+# ----------------------------------------------------------------------------- RoPE / projection / attention
+def _pos(B, nh, nw):
+    from oracle import spann3r_oracle as O
+    return O.positions(B, nh, nw)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("fwd", [1.0, -1.0])
+def test_rope_2d_dropin(dtype, fwd):
+    """sp3_rope_2d == curope.rope_2d semantics: in place on the [B,N,H,D] strided view of a [B,H,N,D] tensor."""
+    from oracle import spann3r_oracle as O
+    ops = _ops()
+    B, H, nh, nw, D = 2, 12, 5, 7, 64
+    N = nh * nw
+    tok = rnd(B, H, N, D, seed=3)
+    pos = _pos(B, nh, nw)
+    t = tok.to(dtype).to(DEV)
+    ops.rope_2d(t.transpose(1, 2), pos.to(DEV), 100.0, fwd)       # the call cuRoPE2D.forward makes (curope2d.py:39)
+    ref = O.rope2d(tok.to(dtype).float(), pos, 100.0, fwd)
+    assert rel_err(t.float().cpu(), ref) < (1e-5 if dtype == torch.float32 else 8e-3)
+    with pytest.raises(RuntimeError):
+        ops.rope_2d(t, pos[:1].to(DEV), 100.0, 1.0)               # batch mismatch -> RuntimeError like TORCH_CHECK
+
+
+@pytest.mark.parametrize("wdt", [torch.float32, torch.bfloat16])
+def test_proj_rope_vt(wdt):
+    """Fused qkv projection: bias + RoPE(q,k) + per-head V^T store vs Linear -> reshape -> rope2d."""
+    from oracle import spann3r_oracle as O
+    from spann3r_amd.engine import _rope_tables
+    ops = _ops()
+    B, nh, nw, C, heads = 2, 4, 5, 768, 12
+    P = nh * nw
+    R = B * P
+    x, W, b = rnd(R, C, seed=1), rnd(3 * C, C, seed=2) * 0.05, rnd(3 * C, seed=3)
+    pos = _pos(B, nh, nw)
+    cos, sin = _rope_tables(64, 100.0, DEV)
+    npad = 64
+    qk = torch.zeros(R, 2 * C, device=DEV, dtype=wdt)
+    vt = torch.zeros(B * heads * 64, npad, device=DEV, dtype=wdt)
+    ops.proj_rope_vt(x.to(DEV), W.to(DEV).to(wdt), b.to(DEV), qk, 2 * C, vt, npad, M=R, N=3 * C, K=C, lda=C, rope_cols=2 * C,
+                     pos=pos.reshape(-1, 2).to(torch.int32).to(DEV), cos=cos, sin=sin, tokens=P, heads=heads)
+    xr, Wr = (bf(x), bf(W)) if wdt == torch.bfloat16 else (x, W)
+    y = (xr.double() @ Wr.double().T + b.double()).float().reshape(B, P, 3, heads, 64)
+    q, k, v = (y[:, :, i].transpose(1, 2) for i in range(3))
+    q, k = O.rope2d(q, pos), O.rope2d(k, pos)
+    tol = 1e-5 if wdt == torch.float32 else 8e-3
+    got = qk.float().cpu().reshape(B, P, 2, heads, 64)
+    assert rel_err(got[:, :, 0].transpose(1, 2), q) < tol
+    assert rel_err(got[:, :, 1].transpose(1, 2), k) < tol
+    gv = vt.float().cpu().reshape(B, heads, 64, npad)
+    assert rel_err(gv[..., :P], v.transpose(-1, -2)) < tol
+    assert float(gv[..., P:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("wdt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,heads,Nq,Nk", [(1, 16, 196, 196), (2, 12, 20, 20), (1, 12, 50, 300), (1, 2, 1024, 1024), (2, 3, 17, 65)])
+def test_attention(wdt, B, heads, Nq, Nk):
+    ops = _ops()
+    C = heads * 64
+    q, k, v = rnd(B, Nq, heads, 64, seed=1), rnd(B, Nk, heads, 64, seed=2), rnd(B, Nk, heads, 64, seed=3)
+    q = q * 2.0
+    npad = (Nk + 63) // 64 * 64
+    vt = torch.zeros(B, heads, 64, npad)
+    vt[..., :Nk] = v.permute(0, 2, 3, 1)
+    out = torch.empty(B * Nq, C, device=DEV)
+    ops.attention(q.to(DEV).to(wdt), Nq * C, C, k.to(DEV).to(wdt), Nk * C, C, vt.reshape(-1, npad).to(DEV).to(wdt), npad, out, C,
+                  B=B, heads=heads, Nq=Nq, Nk=Nk, scale=0.125)
+    if wdt == torch.bfloat16:
+        q, k, v = bf(q), bf(k), bf(v)
+    a = torch.softmax(torch.einsum("bqhd,bkhd->bhqk", q.double(), k.double()) * 0.125, -1)
+    ref = torch.einsum("bhqk,bkhd->bqhd", a, v.double()).reshape(B * Nq, C)
+    assert rel_err(out.cpu(), ref) < (2e-5 if wdt == torch.float32 else 1e-2)
+
+
+# ----------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("C", [768, 1024, 1792, 96])
+def test_layernorm(C):
+    ops = _ops()
+    rows = 197
+    x, g, b = rnd(rows, C, seed=1) * 3 + 0.5, rnd(C, seed=2) + 1, rnd(C, seed=3)
+    ref = F.layer_norm(x.double(), (C,), g.double(), b.double(), 1e-6)
+    out = torch.empty(rows, C, device=DEV)
+    ops.layernorm(x.to(DEV), g.to(DEV), b.to(DEV), 1e-6, out, rows=rows, C_=C)
+    assert rel_err(out.cpu(), ref) < 1e-5
+    # strided output (writes into the right half of a wider buffer), bf16 output
+    wide = torch.zeros(rows, 2 * C, device=DEV)
+    ops.layernorm(x.to(DEV), g.to(DEV), b.to(DEV), 1e-6, wide[:, C:], rows=rows, C_=C, ldo=2 * C)
+    assert rel_err(wide[:, C:].cpu(), ref) < 1e-5 and float(wide[:, :C].abs().max()) == 0.0
+    ob = torch.empty(rows, C, device=DEV, dtype=torch.bfloat16)
+    ops.layernorm(x.to(DEV), g.to(DEV), b.to(DEV), 1e-6, ob, rows=rows, C_=C)
+    assert rel_err(ob.float().cpu(), ref) < 5e-3
+    # transposed store into a [C, cap] bank at column offset 24
+    cap = 256
+    bank = torch.zeros(C, cap, device=DEV)
+    ops.layernorm(x.to(DEV), g.to(DEV), b.to(DEV), 1e-5, bank[:, 24:], rows=rows, C_=C, ldo=cap, transposed=True)
+    ref5 = F.layer_norm(x.double(), (C,), g.double(), b.double(), 1e-5)
+    assert rel_err(bank[:, 24:24 + rows].cpu(), ref5.T) < 1e-5
+    assert float(bank[:, :24].abs().max()) == 0.0 and float(bank[:, 24 + rows:].abs().max()) == 0.0
+
+
+# ----------------------------------------------------------------------------- spatial-memory kernels
+@pytest.mark.parametrize("thresh", [0.0, 5e-4])
+def test_softmax_thresh_and_colsum(thresh):
+    ops = _ops()
+    B, rows, M, ld = 2, 37, 1765, 1792
+    S = rnd(B, rows, ld, seed=1) * 4
+    Pm = torch.full((B, rows, ld), float("nan"), device=DEV)
+    Mpad = (M + 7) // 8 * 8
+    ops.softmax_thresh(S.to(DEV), Pm, ld=ld, rows=rows, M=M, Mpad=Mpad, thresh=thresh, batch=B, strideS=rows * ld)
+    a = torch.softmax(S[..., :M].double(), -1)
+    if thresh > 0:
+        a32 = torch.softmax(S[..., :M], -1)
+        a = torch.where(a32 < thresh, torch.zeros_like(a), a)
+        a = a / a.sum(-1, keepdim=True)
+    got = Pm.cpu()
+    # entries within 1e-6 of the threshold may legitimately flip; compare row-wise with an L1 budget
+    assert float((got[..., :M].double() - a).abs().sum(-1).max()) < 5e-3
+    assert float(got[..., M:Mpad].abs().max()) == 0.0
+    attn = rnd(M, seed=9).abs().to(DEV)
+    before = attn.clone()
+    ops.colsum_accum(Pm[0], ld, rows, M, attn)
+    assert rel_err((attn - before).cpu(), got[0, :, :M].double().sum(0)) < 1e-5
+
+
+def test_cos_sim_append_prune_gather():
+    ops = _ops()
+    T, P, C = 3, 50, 1024
+    k, wm = rnd(P, C, seed=1), rnd(T, P, C, seed=2)
+    wm[1] = k * 1.7 + 0.01 * wm[1]
+    score = torch.zeros(T, device=DEV)
+    ops.cos_sim(k.to(DEV), wm.to(DEV), T, P, C, score)
+    ref = torch.einsum("pc,tpc->tp", F.normalize(k.double(), dim=-1), F.normalize(wm.double(), dim=-1)).mean(-1)
+    assert rel_err(score.cpu(), ref) < 1e-5 and float(score[1]) > 0.95
+    # append bookkeeping
+    M = 120
+    count, attn = torch.arange(200.).to(DEV), torch.ones(200, device=DEV)
+    ops.mem_append(count, attn, M, P)
+    c = count.cpu()
+    assert torch.equal(c[:M], torch.arange(M).float() + 1) and float(c[M:M + P].abs().max()) == 0
+    assert float(attn[M:M + P].abs().max()) == 0 and float(attn[:M].min()) == 1
+    # prune selection: weight = attn/count, protected (count < 10) = 1e8, ties by index
+    M, top_k = 5096, 4000
+    cnt = torch.arange(M - 1, -1, -1).float() // 196
+    at = rnd(M, seed=5).abs() * (cnt + 1)
+    sel = torch.zeros(top_k, dtype=torch.int32, device=DEV)
+    ops.prune_select(at.to(DEV), cnt.to(DEV), M, 10.0, top_k, sel)
+    wgt = torch.where(cnt < 10, torch.full_like(at, 1e8), at / cnt)
+    order = sorted(range(M), key=lambda j: (-float(wgt[j]), j))[:top_k]
+    assert sel.cpu().tolist() == order
+    # gathers
+    src = rnd(M, 64, seed=6)
+    dst = torch.zeros(top_k, 64, device=DEV)
+    ops.gather_rows(src.to(DEV), dst, sel, top_k, 64)
+    assert torch.equal(dst.cpu(), src[order])
+    srcb = src.to(torch.bfloat16)
+    dstb = torch.zeros(top_k, 64, device=DEV, dtype=torch.bfloat16)
+    ops.gather_rows(srcb.to(DEV), dstb, sel, top_k, 64)
+    assert torch.equal(dstb.cpu(), srcb[order])
+    cap = 5120
+    st = torch.zeros(16, cap)
+    st[:, :M] = rnd(16, M, seed=7)
+    dt = torch.full((16, cap), 7.0, device=DEV)
+    ops.gather_cols(st.to(DEV), cap, dt, cap, sel, top_k, cap, 16)
+    assert torch.equal(dt[:, :top_k].cpu(), st[:, order]) and float(dt[:, top_k:].abs().max()) == 0
+    d1 = torch.zeros(top_k, device=DEV)
+    ops.gather_1d(at.to(DEV), d1, sel, top_k)
+    assert torch.equal(d1.cpu(), at[order])
+
+
+# ----------------------------------------------------------------------------- DPT helpers
+def test_im2col_upsample_headfinal():
+    from oracle import spann3r_oracle as O
+    ops = _ops()
+    B, H, W, p = 2, 32, 48, 16
+    img = rnd(B, 3, H, W, seed=1)
+    col = torch.empty(B * (H // p) * (W // p), 3 * p * p, device=DEV)
+    ops.im2col_patch(img.to(DEV), col, B=B, C_=3, H=H, W_=W, p=p, strides=img.stride())
+    ref = F.unfold(img, p, stride=p).transpose(1, 2).reshape(-1, 3 * p * p)
+    assert torch.equal(col.cpu(), ref)
+    nhwc = img.permute(0, 2, 3, 1).contiguous()          # pts3d layout
+    sb, sy, sx, sc = nhwc.stride()
+    ops.im2col_patch(nhwc.to(DEV), col, B=B, C_=3, H=H, W_=W, p=p, strides=(sb, sc, sy, sx))
+    assert torch.equal(col.cpu(), ref)
+    # bilinear x2, align_corners=True, with the dpt_head.py:57 crop
+    x = rnd(B, 8, 4, 3, seed=2)
+    up = torch.empty(B, 7, 5, 8, device=DEV)
+    ops.upsample2x(x.permute(0, 2, 3, 1).contiguous().to(DEV), up, B=B, H=4, W_=3, C_=8, outH=7, outW=5)
+    ref = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)[:, :, :7, :5]
+    assert rel_err(up.cpu(), ref.permute(0, 2, 3, 1)) < 1e-6
+    # final 1x1 conv + postprocess
+    pix, C = 1000, 128
+    f, w, b = F.relu(rnd(pix, C, seed=3)), rnd(4, C, seed=4) * 0.1, rnd(4, seed=5)
+    pts, conf, raw = torch.empty(pix, 3, device=DEV), torch.empty(pix, device=DEV), torch.empty(pix, 4, device=DEV)
+    ops.head_final(f.to(DEV), w.to(DEV), b.to(DEV), pix, C, pts, conf, raw)
+    r = (f.double() @ w.double().T + b.double()).float()
+    assert rel_err(raw.cpu(), r) < 1e-5
+    post = O.postprocess(r.T.reshape(1, 4, 1, pix))
+    assert rel_err(pts.cpu(), post["pts3d"].reshape(pix, 3)) < 1e-5
+    assert rel_err(conf.cpu(), post["conf"].reshape(pix)) < 1e-5
