@@ -13,6 +13,82 @@ from . import lib as L
 from .lib import GemmDesc, F32, BF16, ACT_NONE, ACT_GELU, ACT_RELU  # noqa: F401
 
 
+# ----------------------------------------------------------------------------- optional per-launch profiler
+_prof = None
+
+
+class Profiler:
+    """Brackets every launch with HIP events on the launch stream (torch's current stream) and books the
+    ALGORITHMIC flops / bytes of the launch (bench.py's `roofline` object is computed from this)."""
+
+    def __init__(self):
+        self.rec = []
+
+    def begin(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def end(self, key, e0, flops, nbytes):
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.rec.append((key, e0, e1, float(flops), float(nbytes)))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for key, e0, e1, fl, by in self.rec:
+            a = agg.setdefault(key, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            a["launches"] += 1
+            a["ms"] += e0.elapsed_time(e1)
+            a["flops"] += fl
+            a["bytes"] += by
+        return agg
+
+
+def set_profiler(p):
+    global _prof
+    _prof = p
+
+
+_TILE_NAMES = {0: "32x32xk4", 1: "64x64", 2: "64x128"}
+
+
+def pick_tile(M, N, batch=1):
+    """Mirror of the auto heuristic in csrc/gemm.hip (kept in sync so profiles can be keyed by instantiation)."""
+    t64 = ((M + 63) // 64) * ((N + 63) // 64) * batch
+    t128 = ((M + 63) // 64) * ((N + 127) // 128) * batch
+    if t128 >= 1024 and N % 128 == 0:
+        return 2
+    if t64 >= 512:
+        return 1
+    return 0
+
+
+def _gemm_launch(d, what, loader_name):
+    if d.tile < 0:
+        d.tile = pick_tile(d.M, d.N, max(d.batch, 1))
+    if _prof is None:
+        L.check(L.load().sp3_gemm(C.byref(d), L.stream_ptr()), what)
+        return
+    e0 = _prof.begin()
+    L.check(L.load().sp3_gemm(C.byref(d), L.stream_ptr()), what)
+    b = max(d.batch, 1)
+    wsz = 4 if d.wdtype == F32 else 2
+    flops = 2.0 * d.M * d.N * d.K * b
+    nbytes = b * (4.0 * d.M * d.K + wsz * d.N * d.K + 4.0 * d.M * d.N)
+    _prof.end("gemm<%s,%s,%s>" % ("f32" if d.wdtype == F32 else "bf16", loader_name, _TILE_NAMES[d.tile]), e0, flops, nbytes)
+
+
+def _timed(key, flops, nbytes, fn, *args):
+    if _prof is None:
+        return fn(*args)
+    e0 = _prof.begin()
+    r = fn(*args)
+    _prof.end(key, e0, flops, nbytes)
+    return r
+
+
 def wdtype_of(t):
     if t.dtype == torch.float32:
         return F32
@@ -39,7 +115,7 @@ def gemm(A, W, out, *, M, N, K, lda, ldc, bias=None, res1=None, ldr1=0, res2=Non
     d.strideA, d.strideW, d.strideC = strideA, strideW, strideC
     d.alpha, d.wdtype, d.act, d.out_bf16, d.relu_in = alpha, wdtype_of(W), act, int(out_bf16), int(relu_in)
     d.loader, d.epi, d.tile = L.LOAD_PLAIN, L.EPI_PLAIN, tile
-    L.check(L.load().sp3_gemm(C.byref(d), L.stream_ptr()), "sp3_gemm")
+    _gemm_launch(d, "sp3_gemm", "plain")
     return out
 
 
@@ -57,7 +133,7 @@ def conv3x3(x, Wp, out, *, B, H, W_, Cin, Cout, stride=1, bias=None, res1=None, 
     d.alpha, d.wdtype, d.act, d.relu_in = 1.0, wdtype_of(Wp), act, int(relu_in)
     d.loader, d.epi, d.tile = L.LOAD_CONV3X3, L.EPI_PLAIN, tile
     d.conv_H, d.conv_W, d.conv_C, d.conv_OH, d.conv_OW, d.conv_stride = H, W_, Cin, OH, OW, stride
-    L.check(L.load().sp3_gemm(C.byref(d), L.stream_ptr()), "sp3_gemm(conv3x3)")
+    _gemm_launch(d, "sp3_gemm(conv3x3)", "conv3x3")
     return out
 
 
@@ -72,7 +148,7 @@ def conv_transpose_ks(x, Wp, out, *, B, H, W_, Cin, Cout, ks, bias=None, tile=-1
     d.alpha, d.wdtype = 1.0, wdtype_of(Wp)
     d.loader, d.epi, d.tile = L.LOAD_PLAIN, L.EPI_PIXSHUF, tile
     d.ps_k, d.ps_H, d.ps_W, d.ps_C = ks, H, W_, Cout
-    L.check(L.load().sp3_gemm(C.byref(d), L.stream_ptr()), "sp3_gemm(conv_transpose)")
+    _gemm_launch(d, "sp3_gemm(conv_transpose)", "plain")
     return out
 
 
@@ -90,7 +166,7 @@ def proj_rope_vt(A, W, bias, out_qk, ldc, vt, vt_ld, *, M, N, K, lda, rope_cols,
     d.vt, d.vt_ld, d.tokens, d.heads = L.ptr(vt), vt_ld, tokens, heads
     if out_qk is None:
         d.C = vt.data_ptr()           # unused by the kernel when rope_cols == 0, but must be non-null
-    L.check(L.load().sp3_gemm(C.byref(d), L.stream_ptr()), "sp3_gemm(rope_vt)")
+    _gemm_launch(d, "sp3_gemm(rope_vt)", "plain")
 
 
 def layernorm(x, gamma, beta, eps, out, *, rows, C_, ldx=None, ldo=None, transposed=False):
@@ -98,8 +174,9 @@ def layernorm(x, gamma, beta, eps, out, *, rows, C_, ldx=None, ldo=None, transpo
     ldx = C_ if ldx is None else ldx
     ldo = C_ if ldo is None else ldo
     fn = L.load().sp3_layernorm_t if transposed else L.load().sp3_layernorm
-    L.check(fn(x.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(), eps, out.data_ptr(), ldo,
-               int(out.dtype == torch.bfloat16), rows, C_, L.stream_ptr()), "sp3_layernorm")
+    _timed("layernorm_t" if transposed else "layernorm", 8.0 * rows * C_, rows * C_ * (4.0 + out.element_size()),
+           lambda: L.check(fn(x.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(), eps, out.data_ptr(), ldo,
+                              int(out.dtype == torch.bfloat16), rows, C_, L.stream_ptr()), "sp3_layernorm"))
     return out
 
 
@@ -131,14 +208,19 @@ def rope_2d(tokens, positions, base, fwd):
 
 
 def attention(q, sq, ldq, k, sk, ldk, vt, vt_ld, out, ldo, *, B, heads, Nq, Nk, scale):
-    L.check(L.load().sp3_attention(q.data_ptr(), sq, ldq, k.data_ptr(), sk, ldk, vt.data_ptr(), vt_ld, out.data_ptr(), ldo,
-                                   B, heads, Nq, Nk, float(scale), wdtype_of(vt), L.stream_ptr()), "sp3_attention")
+    es = vt.element_size()
+    _timed("attention<%s>" % ("f32" if es == 4 else "bf16"), 4.0 * B * heads * Nq * Nk * 64,
+           B * heads * 64.0 * (es * (Nq + 2 * Nk) + 4 * Nq),
+           lambda: L.check(L.load().sp3_attention(q.data_ptr(), sq, ldq, k.data_ptr(), sk, ldk, vt.data_ptr(), vt_ld,
+                                                  out.data_ptr(), ldo, B, heads, Nq, Nk, float(scale), wdtype_of(vt),
+                                                  L.stream_ptr()), "sp3_attention"))
     return out
 
 
 def softmax_thresh(S, P, *, ld, rows, M, Mpad, thresh, batch=1, strideS=0):
-    L.check(L.load().sp3_softmax_thresh(S.data_ptr(), P.data_ptr(), ld, strideS, rows, M, Mpad, float(thresh), batch,
-                                        L.stream_ptr()), "sp3_softmax_thresh")
+    _timed("softmax_thresh", 8.0 * batch * rows * M, 8.0 * batch * rows * M,
+           lambda: L.check(L.load().sp3_softmax_thresh(S.data_ptr(), P.data_ptr(), ld, strideS, rows, M, Mpad, float(thresh),
+                                                       batch, L.stream_ptr()), "sp3_softmax_thresh"))
 
 
 def colsum_accum(P, ld, rows, M, mem_attn):
@@ -183,13 +265,16 @@ def im2col_patch(img, out, *, B, C_, H, W_, p, strides):
 def upsample2x(x, out, *, B, H, W_, C_, outH=None, outW=None):
     outH = 2 * H if outH is None else outH
     outW = 2 * W_ if outW is None else outW
-    L.check(L.load().sp3_upsample2x(x.data_ptr(), out.data_ptr(), B, H, W_, C_, outH, outW, L.stream_ptr()), "sp3_upsample2x")
+    _timed("upsample2x", 8.0 * B * outH * outW * C_, 4.0 * B * C_ * (H * W_ + outH * outW),
+           lambda: L.check(L.load().sp3_upsample2x(x.data_ptr(), out.data_ptr(), B, H, W_, C_, outH, outW, L.stream_ptr()),
+                           "sp3_upsample2x"))
     return out
 
 
 def head_final(feat, w, b, pixels, C_, pts, conf, raw=None):
-    L.check(L.load().sp3_head_final(feat.data_ptr(), w.data_ptr(), b.data_ptr(), pixels, C_, pts.data_ptr(), conf.data_ptr(),
-                                    L.ptr(raw), L.stream_ptr()), "sp3_head_final")
+    _timed("head_final", 8.0 * pixels * C_, 4.0 * pixels * (C_ + 4),
+           lambda: L.check(L.load().sp3_head_final(feat.data_ptr(), w.data_ptr(), b.data_ptr(), pixels, C_, pts.data_ptr(),
+                                                   conf.data_ptr(), L.ptr(raw), L.stream_ptr()), "sp3_head_final"))
 
 
 def fill(t, v):
