@@ -32,7 +32,7 @@ extern "C" {
 
 enum { SP3_F32 = 0, SP3_BF16 = 1 };
 enum { SP3_ACT_NONE = 0, SP3_ACT_GELU = 1, SP3_ACT_RELU = 2 };
-enum { SP3_EPI_PLAIN = 0, SP3_EPI_ROPE_VT = 1, SP3_EPI_PIXSHUF = 2 };
+enum { SP3_EPI_PLAIN = 0, SP3_EPI_ROPE_VT = 1, SP3_EPI_PIXSHUF = 2, SP3_EPI_PARTIAL = 3 };
 enum { SP3_LOAD_PLAIN = 0, SP3_LOAD_CONV3X3 = 1 };
 
 const char* sp3_last_error(void);
@@ -52,6 +52,10 @@ int sp3_version(void);
  *   row-major to C (ldc) in `wdtype`; columns >= rope_cols are V: stored transposed per head to
  *   vt[((b*heads + h)*64 + d) * vt_ld + n] in `wdtype` (head_dim is 64 on this path).
  * epilogue PIXSHUF: N = ks*ks*Cout, ConvTranspose2d(k=s=ks) scatter into NHWC [B, ks*H, ks*W, Cout].
+ * epilogue PARTIAL: K is split over `splitk` workgroups (grid.z); slice z stores its raw fp32 partial sums to
+ *   C + z*M*ldc (no bias/activation); sp3_reduce_ln finishes the op (bias + residual + LayerNorm(s)).
+ * a_bf16: A (and A2) hold bf16 instead of fp32 (bf16 mode keeps GEMM inputs in bf16: same numerics as converting
+ *   on load, half the L2 traffic).  Requires wdtype == SP3_BF16.
  */
 typedef struct sp3_gemm_desc {
   const float* A;
@@ -84,7 +88,9 @@ typedef struct sp3_gemm_desc {
   int32_t heads;
   int64_t vt_ld;
   int32_t ps_k, ps_H, ps_W, ps_C;
-  int32_t tile;           /* -1 auto; 0: 32x32 split-K4; 1: 64x64; 2: 64x128 */
+  int32_t tile;           /* -1 auto; 0: 32x32 (K over 4 waves); 1: 64x64; 2: 64x128; 3: 64x64 (K over 4 waves) */
+  int32_t a_bf16;
+  int32_t splitk;         /* >= 1; > 1 only with SP3_EPI_PARTIAL */
 } sp3_gemm_desc;
 int sp3_gemm(const sp3_gemm_desc* desc_host, void* stream);
 
@@ -101,6 +107,28 @@ int sp3_layernorm_t(const float* x, int64_t ldx, const float* gamma, const float
                     void* out, int64_t ldo, int out_bf16, int rows, int C, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * sp3_reduce_ln : finishes a split-K GEMM and fuses what the reference does next on the residual stream:
+ *   x = sum_s partial[s] + bias (+ res);  x_out = x (fp32, optional);
+ *   out1 = LayerNorm(x; g1,b1) (optional), out2 = LayerNorm(x; g2,b2) (optional)  -- fp32 or bf16.
+ * Replaces `x = x + drop_path(proj/fc2(...))` followed by the next norm1/norm2/norm3/norm_y/enc_norm/dec_norm
+ * (croco/models/blocks.py:128-129,187-190; dust3r/model.py:153,204).  One wave per row; C % 4 == 0, C <= 4096.
+ */
+typedef struct sp3_reduce_ln_desc {
+  const float* partial;   /* [splits][rows][C] fp32, split stride in elements */
+  int64_t split_stride;
+  const float* bias;      /* [C] or null */
+  const float* res;       /* [rows, ldres] or null */
+  int64_t ldres;
+  float* x_out;           /* [rows, ldx] or null (may alias res) */
+  int64_t ldx;
+  const float* g1; const float* b1; void* out1; int64_t ld1; int32_t out1_bf16;
+  const float* g2; const float* b2; void* out2; int64_t ld2; int32_t out2_bf16;
+  float eps;
+  int32_t splits, rows, C;
+} sp3_reduce_ln_desc;
+int sp3_reduce_ln(const sp3_reduce_ln_desc* desc_host, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * sp3_rope_2d : drop-in for curope.rope_2d (curope.cpp:49-69, kernels.cu:17-108).
  * tokens [B,N,H,D] modified in place; element (b,n,h,d) at tokens + b*sB + n*sN + h*sH + d
  * (the reference only requires stride(3)==1 && stride(2)==D, kernels.cu:91; sH generalises it);
@@ -113,10 +141,10 @@ int sp3_rope_2d(void* tokens, int dtype, int B, int N, int H, int D, int64_t sB,
  * sp3_attention : softmax(q k^T * scale) v per head, head_dim 64
  * (croco/models/blocks.py:105-109 and 162-166).  q [B,Nq,heads,64] / k [B,Nk,heads,64] with row
  * strides ldq/ldk and batch strides sq/sk (elements, `dtype`), already RoPE'd; vt as written by
- * the ROPE_VT epilogue; out fp32 [B*Nq, ldo] with head h at columns [64h, 64h+64).
+ * the ROPE_VT epilogue; out fp32 (or bf16 if out_bf16) [B*Nq, ldo] with head h at columns [64h, 64h+64).
  */
 int sp3_attention(const void* q, int64_t sq, int64_t ldq, const void* k, int64_t sk, int64_t ldk,
-                  const void* vt, int64_t vt_ld, float* out, int64_t ldo,
+                  const void* vt, int64_t vt_ld, void* out, int64_t ldo, int out_bf16,
                   int B, int heads, int Nq, int Nk, float scale, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -159,7 +187,7 @@ int sp3_gather_1d(const float* src, float* dst, const int32_t* sel, int n_sel, v
  *   w fp32 [4, C], b fp32 [4] -> pts [pixels,3], conf [pixels], raw [pixels,4] (optional).
  */
 int sp3_im2col_patch(const float* img, int64_t sb, int64_t sc, int64_t sy, int64_t sx, int B, int C, int H, int W,
-                     int p, float* out, void* stream);
+                     int p, void* out, int out_bf16, void* stream);
 int sp3_upsample2x(const float* in, float* out, int B, int H, int W, int C, int outH, int outW, void* stream);
 int sp3_head_final(const float* feat, const float* w, const float* b, int64_t pixels, int C, float* pts,
                    float* conf, float* raw, void* stream);

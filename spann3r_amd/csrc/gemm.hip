@@ -5,22 +5,25 @@
 // Design (DESIGN.md §"GEMM"):
 //  * The hot path is small-M (M = 196 tokens) weight streaming: 1.3 GB of bf16 weights per frame,
 //    AI ~= 265 FLOP/B.  Every wave streams its operands STRAIGHT from global memory into MFMA
-//    operand registers (no LDS staging, no barrier in the K loop) with a register double buffer,
-//    so a workgroup's latency chain is K/(WK*KB) dependent round trips.
+//    operand registers (no LDS staging, no barrier in the K loop) through a STAGES-deep register
+//    ring, so a workgroup keeps (STAGES-1) k-blocks of loads in flight per wave.
 //  * Both operands are K-contiguous (nn.Linear layout), so the contraction index may be permuted
 //    freely as long as A and W use the same permutation: lane group g = lane>>4 owns CH contiguous
 //    elements [kb*KB + g*CH, +CH) of every row -> each row is read as ONE contiguous 128-byte line
 //    per k-block (bf16) instead of the 64-byte fragment-shaped pieces of the textbook mapping.
-//  * Small-M tiles (32x32) split K over the 4 waves of the workgroup (WK=4) and reduce through LDS;
-//    large-M tiles (64x64, 64x128) give each wave its own output sub-tile.  Either way the
-//    accumulators go through LDS once, which decouples the MFMA C layout from the store layout:
-//    the epilogue (bias, exact-erf GELU / ReLU, residuals, 2-D RoPE, per-head V^T store,
-//    ConvTranspose pixel-shuffle) runs on coalesced 16-byte row segments.
+//  * Small-M tiles split K over the 4 waves of the workgroup (WK=4: no operand is loaded twice inside
+//    a workgroup) and, when a GEMM has too few tiles to fill 256 CUs, additionally over `splitk`
+//    workgroups (grid.z) whose fp32 partials are finished by sp3_reduce_ln (bias + residual + the
+//    LayerNorm that follows on the residual stream).  Large-M tiles give each wave its own sub-tile.
+//    Either way the accumulators go through LDS once, which decouples the MFMA C layout from the
+//    store layout: the epilogue (bias, exact-erf GELU / ReLU, residuals, 2-D RoPE, per-head V^T
+//    store, ConvTranspose pixel-shuffle) runs on coalesced 16-byte row segments.
 //  * blockIdx -> tile mapping is XCD-aware (block b runs on XCD b%8): all tiles that share a weight
 //    panel (small M) or an activation panel (large M) are placed on the same XCD, adjacent in
 //    dispatch order, so the shared panel is fetched from HBM/MALL into ONE L2.
 //  * fp32 mode uses v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain), bf16 mode v_mfma_f32_16x16x32_bf16
-//    with fp32 activations converted on load (v_cvt_pk_bf16_f32) and fp32 accumulation.
+//    with fp32 accumulation; bf16-mode activations are either already bf16 (a_bf16) or fp32 converted
+//    on load (v_cvt_pk_bf16_f32).
 #include "common.h"
 
 namespace {
@@ -30,31 +33,46 @@ struct GemmArgs {
 };
 
 // ------------------------------------------------------------------ per-dtype operand handling
-template <typename TW> struct MM;
+// MM<TA, TW>: TA = dtype of A in memory, TW = dtype of W = MFMA dtype.
+template <typename TA, typename TW> struct MM;
 
-template <> struct MM<__bf16> {
+__device__ __forceinline__ bf16x8 zero8() {
+  bf16x8 z;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) z[i] = (__bf16)0.f;
+  return z;
+}
+
+__device__ __forceinline__ bf16x8 relu8(bf16x8 v) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (float)v[i] > 0.f ? v[i] : (__bf16)0.f;
+  return v;
+}
+
+struct WRegB { bf16x8 v[2]; };
+__device__ __forceinline__ void loadW_b(WRegB& r, const __bf16* p, bool v0, bool v1) {
+  const bf16x8* q = reinterpret_cast<const bf16x8*>(p);
+  r.v[0] = q[0];
+  r.v[1] = v1 ? q[1] : q[0];          // never touch bytes past K
+  if (!v0) r.v[0] = zero8();
+  if (!v1) r.v[1] = zero8();
+}
+
+template <> struct MM<float, __bf16> {
   static constexpr int KB = 64;   // k elements per block
   static constexpr int CH = 16;   // k elements per lane per block
   struct AReg { float4 v[4]; };
-  struct WReg { bf16x8 v[2]; };
+  using WReg = WRegB;
   static __device__ __forceinline__ void loadA(AReg& r, const float* p, bool v0, bool v1, bool relu) {
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     const float4* q = reinterpret_cast<const float4*>(p);
-    const float4* q1 = v1 ? q + 2 : q;       // never touch bytes past K
+    const float4* q1 = v1 ? q + 2 : q;
     r.v[0] = q[0]; r.v[1] = q[1]; r.v[2] = q1[0]; r.v[3] = q1[1];
     if (!v0) { r.v[0] = z; r.v[1] = z; }
     if (!v1) { r.v[2] = z; r.v[3] = z; }
     if (relu) { r.v[0] = relu4(r.v[0]); r.v[1] = relu4(r.v[1]); r.v[2] = relu4(r.v[2]); r.v[3] = relu4(r.v[3]); }
   }
-  static __device__ __forceinline__ void loadW(WReg& r, const __bf16* p, bool v0, bool v1) {
-    const bf16x8* q = reinterpret_cast<const bf16x8*>(p);
-    bf16x8 z;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) z[i] = (__bf16)0.f;
-    r.v[0] = q[0]; r.v[1] = v1 ? q[1] : q[0];
-    if (!v0) r.v[0] = z;
-    if (!v1) r.v[1] = z;
-  }
+  static __device__ __forceinline__ void loadW(WReg& r, const __bf16* p, bool v0, bool v1) { loadW_b(r, p, v0, v1); }
   template <int MF, int NF>
   static __device__ __forceinline__ void mma(f32x4 (&acc)[MF][NF], const AReg (&a)[MF], const WReg (&w)[NF]) {
 #pragma unroll
@@ -70,7 +88,33 @@ template <> struct MM<__bf16> {
   }
 };
 
-template <> struct MM<float> {
+template <> struct MM<__bf16, __bf16> {
+  static constexpr int KB = 64;
+  static constexpr int CH = 16;
+  struct AReg { bf16x8 v[2]; };
+  using WReg = WRegB;
+  static __device__ __forceinline__ void loadA(AReg& r, const __bf16* p, bool v0, bool v1, bool relu) {
+    const bf16x8* q = reinterpret_cast<const bf16x8*>(p);
+    r.v[0] = q[0];
+    r.v[1] = v1 ? q[1] : q[0];
+    if (!v0) r.v[0] = zero8();
+    if (!v1) r.v[1] = zero8();
+    if (relu) { r.v[0] = relu8(r.v[0]); r.v[1] = relu8(r.v[1]); }
+  }
+  static __device__ __forceinline__ void loadW(WReg& r, const __bf16* p, bool v0, bool v1) { loadW_b(r, p, v0, v1); }
+  template <int MF, int NF>
+  static __device__ __forceinline__ void mma(f32x4 (&acc)[MF][NF], const AReg (&a)[MF], const WReg (&w)[NF]) {
+#pragma unroll
+    for (int m = 0; m < MF; ++m)
+#pragma unroll
+      for (int n = 0; n < NF; ++n) {
+        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m].v[0], w[n].v[0], acc[m][n], 0, 0, 0);
+        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m].v[1], w[n].v[1], acc[m][n], 0, 0, 0);
+      }
+  }
+};
+
+template <> struct MM<float, float> {
   static constexpr int KB = 32;
   static constexpr int CH = 8;
   struct AReg { float4 v[2]; };
@@ -109,33 +153,33 @@ template <> struct MM<float> {
 };
 
 // ------------------------------------------------------------------ A-row addressing
-// PLAIN: row m at A + m*lda.  CONV3X3: row m is output pixel (b, oy, ox) of an NHWC map.
-template <int LOADER, int MF> struct ARows;
+// PLAIN: row m at A + m*lda (optionally a second source A2 for k >= K1).
+// CONV3X3: row m is output pixel (b, oy, ox) of an NHWC map.
+template <typename TA, int LOADER, int MF> struct ARows;
 
-template <int MF> struct ARows<SP3_LOAD_PLAIN, MF> {
-  const float* base[MF];
-  const float* base2[MF];
-  __device__ __forceinline__ void init(const sp3_gemm_desc& d, const float* A, int row0, int lane) {
+template <typename TA, int MF> struct ARows<TA, SP3_LOAD_PLAIN, MF> {
+  const TA* base[MF];
+  const TA* base2[MF];
+  __device__ __forceinline__ void init(const sp3_gemm_desc& d, const TA* A, int row0, int lane) {
 #pragma unroll
     for (int m = 0; m < MF; ++m) {
       int r = row0 + m * 16 + (lane & 15);
       r = r < d.M ? r : d.M - 1;
       base[m] = A + (int64_t)r * d.lda;
-      base2[m] = d.A2 ? d.A2 + (int64_t)r * d.lda2 - d.K1 : base[m];
+      base2[m] = d.A2 ? reinterpret_cast<const TA*>(d.A2) + (int64_t)r * d.lda2 - d.K1 : base[m];
     }
   }
-  // pointer of this lane's chunk starting at k (k < K guaranteed by caller through clamping)
-  __device__ __forceinline__ const float* ptr(const sp3_gemm_desc& d, int m, int k, bool& inb) const {
+  __device__ __forceinline__ const TA* ptr(const sp3_gemm_desc& d, int m, int k, bool& inb) const {
     inb = true;
     return (k < d.K1 ? base[m] : base2[m]) + k;
   }
 };
 
-template <int MF> struct ARows<SP3_LOAD_CONV3X3, MF> {
-  const float* img[MF];
+template <typename TA, int MF> struct ARows<TA, SP3_LOAD_CONV3X3, MF> {
+  const TA* img[MF];
   int iy0[MF], ix0[MF];
-  const float* safe;
-  __device__ __forceinline__ void init(const sp3_gemm_desc& d, const float* A, int row0, int lane) {
+  const TA* safe;
+  __device__ __forceinline__ void init(const sp3_gemm_desc& d, const TA* A, int row0, int lane) {
     safe = A;
 #pragma unroll
     for (int m = 0; m < MF; ++m) {
@@ -151,7 +195,7 @@ template <int MF> struct ARows<SP3_LOAD_CONV3X3, MF> {
       ix0[m] = ox * d.conv_stride - 1;
     }
   }
-  __device__ __forceinline__ const float* ptr(const sp3_gemm_desc& d, int m, int k, bool& inb) const {
+  __device__ __forceinline__ const TA* ptr(const sp3_gemm_desc& d, int m, int k, bool& inb) const {
     const int tap = k / d.conv_C;
     const int ci = k - tap * d.conv_C;
     const int dy = tap / 3;
@@ -163,10 +207,10 @@ template <int MF> struct ARows<SP3_LOAD_CONV3X3, MF> {
 };
 
 // ------------------------------------------------------------------ the kernel
-template <typename TW, int LOADER, int MF, int NF, int WM, int WN, int WK>
+template <typename TA, typename TW, int LOADER, int MF, int NF, int WM, int WN, int WK, int STAGES>
 __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_kernel(const GemmArgs args) {
   const sp3_gemm_desc& d = args.d;
-  using M_ = MM<TW>;
+  using M_ = MM<TA, TW>;
   constexpr int BM = MF * 16 * WM, BN = NF * 16 * WN, NT = 64 * WM * WN * WK;
   constexpr int KB = M_::KB, CH = M_::CH;
   constexpr int LDS_LD = BN + 4;
@@ -191,11 +235,12 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_kernel(const GemmArgs 
   const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
   const int g = lane >> 4;
   const int bz = blockIdx.y;
-  const float* A = d.A + (int64_t)bz * d.strideA;
+  const int kz = blockIdx.z;
+  const TA* A = reinterpret_cast<const TA*>(d.A) + (int64_t)bz * d.strideA;
   const TW* W = reinterpret_cast<const TW*>(d.W) + (int64_t)bz * d.strideW;
 
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  ARows<LOADER, MF> arows;
+  ARows<TA, LOADER, MF> arows;
   arows.init(d, A, m0 + wm * MF * 16, lane);
   const TW* wrow[NF];
 #pragma unroll
@@ -211,39 +256,46 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_kernel(const GemmArgs 
 #pragma unroll
     for (int n = 0; n < NF; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nkb = (d.K + KB - 1) / KB;
+  // k-blocks of this workgroup's K slice (split-K over grid.z), interleaved over the WK waves
+  const int nkb_all = (d.K + KB - 1) / KB;
+  const int per = (nkb_all + d.splitk - 1) / d.splitk;
+  const int kb_lo = kz * per;
+  const int kb_hi = (kb_lo + per) < nkb_all ? (kb_lo + per) : nkb_all;
   const bool relu = d.relu_in != 0;
 
-  typename M_::AReg a0[MF], a1[MF];
-  typename M_::WReg w0[NF], w1[NF];
+  typename M_::AReg a[STAGES][MF];
+  typename M_::WReg w[STAGES][NF];
 
-  auto load = [&](typename M_::AReg (&a)[MF], typename M_::WReg (&w)[NF], int kb) {
+  auto load = [&](typename M_::AReg (&ar)[MF], typename M_::WReg (&wr)[NF], int kb) {
     const int k = kb * KB + g * CH;
     const bool v0 = k < d.K, v1 = (k + CH / 2) < d.K;
     const int kc = v0 ? k : 0;              // clamp: always a legal address, zeroed by v0/v1
 #pragma unroll
     for (int m = 0; m < MF; ++m) {
       bool inb;
-      const float* p = arows.ptr(d, m, kc, inb);
-      M_::loadA(a[m], p, v0 && inb, v1 && inb, relu);
+      const TA* p = arows.ptr(d, m, kc, inb);
+      M_::loadA(ar[m], p, v0 && inb, v1 && inb, relu);
     }
 #pragma unroll
-    for (int n = 0; n < NF; ++n) M_::loadW(w[n], wrow[n] + kc, v0, v1);
+    for (int n = 0; n < NF; ++n) M_::loadW(wr[n], wrow[n] + kc, v0, v1);
   };
 
-  int kb = wk;
-  if (kb < nkb) {
-    load(a0, w0, kb);
-    for (;;) {
-      const bool has1 = (kb + WK) < nkb;
-      if (has1) load(a1, w1, kb + WK);
-      M_::template mma<MF, NF>(acc, a0, w0);
-      if (!has1) break;
-      const bool has2 = (kb + 2 * WK) < nkb;
-      if (has2) load(a0, w0, kb + 2 * WK);
-      M_::template mma<MF, NF>(acc, a1, w1);
-      if (!has2) break;
-      kb += 2 * WK;
+  // STAGES-deep register ring: (STAGES-1) k-blocks of loads in flight per wave
+  {
+    const int kb0 = kb_lo + wk;
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+      if (kb0 + s * WK < kb_hi) load(a[s], w[s], kb0 + s * WK);
+    for (int kb = kb0; kb < kb_hi; kb += STAGES * WK) {
+#pragma unroll
+      for (int s = 0; s < STAGES; ++s) {
+        const int kcur = kb + s * WK;
+        if (kcur < kb_hi) {
+          const int knext = kcur + (STAGES - 1) * WK;
+          if (knext < kb_hi) load(a[(s + STAGES - 1) % STAGES], w[(s + STAGES - 1) % STAGES], knext);
+          M_::template mma<MF, NF>(acc, a[s], w[s]);
+        }
+      }
     }
   }
 
@@ -302,6 +354,14 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_kernel(const GemmArgs 
     float v[4] = {acc4.x * alpha, acc4.y * alpha, acc4.z * alpha, acc4.w * alpha};
     const int nvalid = (d.N - gn) < 4 ? (d.N - gn) : 4;
 
+    if (d.epi == SP3_EPI_PARTIAL) {
+      float* o = reinterpret_cast<float*>(d.C) + ((int64_t)kz * d.M + gm) * d.ldc + gn;
+      if (nvalid == 4) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+      else
+        for (int e = 0; e < nvalid; ++e) o[e] = v[e];
+      continue;
+    }
+
     if (d.epi == SP3_EPI_ROPE_VT) {
       // bias, then RoPE with the partner column (col ^ 16 inside the 64-wide head)
       float4 part4 = lds_sum4(row, c4 ^ 16);
@@ -338,8 +398,8 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_kernel(const GemmArgs 
     if (d.epi == SP3_EPI_PIXSHUF) {
       const int kk = gn / d.ps_C, co = gn - kk * d.ps_C;
       const int ky = kk / d.ps_k, kx = kk - ky * d.ps_k;
-      const int per = d.ps_H * d.ps_W;
-      const int b = gm / per, rem = gm - b * per;
+      const int pp = d.ps_H * d.ps_W;
+      const int b = gm / pp, rem = gm - b * pp;
       const int y = rem / d.ps_W, x = rem - y * d.ps_W;
       off = (((int64_t)b * d.ps_H * d.ps_k + y * d.ps_k + ky) * ((int64_t)d.ps_W * d.ps_k) + x * d.ps_k + kx) * d.ps_C + co;
     } else {
@@ -357,8 +417,14 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_kernel(const GemmArgs 
     }
     if (d.out_bf16) {
       __bf16* o = reinterpret_cast<__bf16*>(d.C) + off;
+      if (nvalid == 4 && ((off & 3) == 0)) {
+        bf16x4 ob;
+        ob[0] = (__bf16)v[0]; ob[1] = (__bf16)v[1]; ob[2] = (__bf16)v[2]; ob[3] = (__bf16)v[3];
+        *reinterpret_cast<bf16x4*>(o) = ob;
+      } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) if (e < nvalid) o[e] = (__bf16)v[e];
+        for (int e = 0; e < 4; ++e) if (e < nvalid) o[e] = (__bf16)v[e];
+      }
     } else {
       float* o = reinterpret_cast<float*>(d.C) + off;
       if (nvalid == 4 && ((off & 3) == 0)) {
@@ -371,7 +437,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_kernel(const GemmArgs 
   }
 }
 
-template <typename TW, int LOADER, int MF, int NF, int WM, int WN, int WK>
+template <typename TA, typename TW, int LOADER, int MF, int NF, int WM, int WN, int WK, int STAGES>
 int launch(const sp3_gemm_desc& d, hipStream_t stream) {
   constexpr int BM = MF * 16 * WM, BN = NF * 16 * WN, NT = 64 * WM * WN * WK;
   const int mt = (d.M + BM - 1) / BM, nt = (d.N + BN - 1) / BN;
@@ -379,20 +445,29 @@ int launch(const sp3_gemm_desc& d, hipStream_t stream) {
   if (mt >= nt) blocks = ((mt + 7) / 8) * 8 * nt;
   else blocks = ((nt + 7) / 8) * 8 * mt;
   const size_t lds = (size_t)WK * BM * (BN + 4) * sizeof(float);
+  auto kern = gemm_kernel<TA, TW, LOADER, MF, NF, WM, WN, WK, STAGES>;
+  if (lds > 64 * 1024) {
+    static bool raised = false;     // one-time opt-in to > 64 KiB of dynamic LDS for this instantiation
+    if (!raised) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) { sp3_set_error("sp3_gemm: cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e)); return 2; }
+      raised = true;
+    }
+  }
   GemmArgs a;
   a.d = d;
-  auto kern = gemm_kernel<TW, LOADER, MF, NF, WM, WN, WK>;
-  hipLaunchKernelGGL(kern, dim3(blocks, d.batch > 0 ? d.batch : 1, 1), dim3(NT), lds, stream, a);
+  hipLaunchKernelGGL(kern, dim3(blocks, d.batch, d.splitk), dim3(NT), lds, stream, a);
   SP3_LAUNCH_CHECK("sp3_gemm");
   return 0;
 }
 
-template <typename TW, int LOADER>
+template <typename TA, typename TW, int LOADER>
 int dispatch_tile(const sp3_gemm_desc& d, int tile, hipStream_t stream) {
   switch (tile) {
-    case 0: return launch<TW, LOADER, 2, 2, 1, 1, 4>(d, stream);   // 32x32, K split over 4 waves
-    case 1: return launch<TW, LOADER, 2, 2, 2, 2, 1>(d, stream);   // 64x64
-    case 2: return launch<TW, LOADER, 2, 4, 2, 2, 1>(d, stream);   // 64x128
+    case 0: return launch<TA, TW, LOADER, 2, 2, 1, 1, 4, 3>(d, stream);   // 32x32, K over 4 waves
+    case 1: return launch<TA, TW, LOADER, 2, 2, 2, 2, 1, 2>(d, stream);   // 64x64, wave tile 32x32
+    case 2: return launch<TA, TW, LOADER, 2, 4, 2, 2, 1, 2>(d, stream);   // 64x128, wave tile 32x64
+    case 3: return launch<TA, TW, LOADER, 4, 4, 1, 1, 4, 3>(d, stream);   // 64x64, K over 4 waves
     default: sp3_set_error("sp3_gemm: bad tile %d", tile); return 1;
   }
 }
@@ -407,16 +482,20 @@ extern "C" int sp3_gemm(const sp3_gemm_desc* dp, void* stream_) {
   SP3_CHECK(d.M > 0 && d.N > 0 && d.K > 0, "sp3_gemm: bad shape M=%d N=%d K=%d", d.M, d.N, d.K);
   SP3_CHECK(d.K % 8 == 0, "sp3_gemm: K=%d must be a multiple of 8", d.K);
   SP3_CHECK(d.wdtype == SP3_F32 || d.wdtype == SP3_BF16, "sp3_gemm: bad wdtype %d", d.wdtype);
+  SP3_CHECK(!d.a_bf16 || d.wdtype == SP3_BF16, "sp3_gemm: a_bf16 needs wdtype bf16");
   SP3_CHECK((reinterpret_cast<uintptr_t>(d.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(d.W) & 15) == 0,
             "sp3_gemm: A and W must be 16-byte aligned");
   if (d.batch <= 0) d.batch = 1;
+  if (d.splitk <= 0) d.splitk = 1;
   if (d.ldw <= 0) d.ldw = d.K;
   if (!d.A2) d.K1 = d.K;
+  const int aalign = d.a_bf16 ? 8 : 4;    // elements per 16 bytes
   SP3_CHECK(d.ldw >= d.K && d.ldw % 8 == 0, "sp3_gemm: ldw=%lld must be >= K and a multiple of 8", (long long)d.ldw);
-  SP3_CHECK(!d.A2 || (d.loader == SP3_LOAD_PLAIN && d.K1 % 64 == 0 && d.K1 > 0 && d.K1 < d.K && d.lda2 % 4 == 0 && d.batch == 1),
+  SP3_CHECK(!d.A2 || (d.loader == SP3_LOAD_PLAIN && d.K1 % 64 == 0 && d.K1 > 0 && d.K1 < d.K && d.lda2 % aalign == 0 && d.batch == 1),
             "sp3_gemm: bad split-A configuration (K1=%d)", d.K1);
+  SP3_CHECK(d.splitk == 1 || d.epi == SP3_EPI_PARTIAL, "sp3_gemm: splitk > 1 needs the PARTIAL epilogue");
   if (d.loader == SP3_LOAD_PLAIN) {
-    SP3_CHECK(d.lda % 4 == 0 && d.lda >= d.K1, "sp3_gemm: lda=%lld must be >= K and a multiple of 4", (long long)d.lda);
+    SP3_CHECK(d.lda % aalign == 0 && d.lda >= d.K1, "sp3_gemm: lda=%lld must be >= K and keep 16-byte rows", (long long)d.lda);
   } else if (d.loader == SP3_LOAD_CONV3X3) {
     SP3_CHECK(d.conv_C % 16 == 0, "sp3_gemm: conv Cin=%d must be a multiple of 16", d.conv_C);
     SP3_CHECK(d.K == 9 * d.conv_C, "sp3_gemm: conv K=%d != 9*Cin", d.K);
@@ -433,26 +512,33 @@ extern "C" int sp3_gemm(const sp3_gemm_desc* dp, void* stream_) {
   } else if (d.epi == SP3_EPI_PIXSHUF) {
     SP3_CHECK(d.ps_k > 0 && d.ps_C > 0 && d.ps_C % 4 == 0 && d.N == d.ps_k * d.ps_k * d.ps_C && d.M % (d.ps_H * d.ps_W) == 0,
               "sp3_gemm: bad PIXSHUF geometry");
+  } else if (d.epi == SP3_EPI_PARTIAL) {
+    SP3_CHECK(d.batch == 1 && d.ldc % 4 == 0 && d.ldc >= d.N, "sp3_gemm: PARTIAL needs batch 1 and ldc %% 4 == 0");
   } else {
     SP3_CHECK(d.epi == SP3_EPI_PLAIN, "sp3_gemm: bad epilogue %d", d.epi);
   }
   int tile = d.tile;
   if (tile < 0) {
-    // enough 32x32 tiles to fill 256 CUs?  otherwise bigger tiles for arithmetic intensity
-    const long t32 = (long)((d.M + 31) / 32) * ((d.N + 31) / 32) * d.batch;
-    const long t64 = (long)((d.M + 63) / 64) * ((d.N + 63) / 64) * d.batch;
+    const long sk = d.splitk;
+    const long t64 = (long)((d.M + 63) / 64) * ((d.N + 63) / 64) * d.batch * sk;
     const long t128 = (long)((d.M + 63) / 64) * ((d.N + 127) / 128) * d.batch;
-    if (t128 >= 1024 && d.N % 128 == 0) tile = 2;
-    else if (t64 >= 512) tile = 1;
-    else tile = 0;
-    (void)t32;
+    if (d.loader == SP3_LOAD_CONV3X3 || d.M > 2048) {
+      if (t128 >= 1024 && d.N % 128 == 0) tile = 2;
+      else if (t64 >= 512) tile = 1;
+      else tile = 0;
+    } else {
+      tile = (t64 >= 128) ? 3 : 0;      // weight-streaming shapes: biggest tile that still fills the CUs
+    }
   }
-  if (d.epi == SP3_EPI_ROPE_VT && tile == 0) tile = 0;   // all tiles are >= 32 wide: RoPE partner stays in-tile
   if (d.wdtype == SP3_BF16) {
-    if (d.loader == SP3_LOAD_PLAIN) return dispatch_tile<__bf16, SP3_LOAD_PLAIN>(d, tile, stream);
-    return dispatch_tile<__bf16, SP3_LOAD_CONV3X3>(d, tile, stream);
+    if (d.a_bf16) {
+      if (d.loader == SP3_LOAD_PLAIN) return dispatch_tile<__bf16, __bf16, SP3_LOAD_PLAIN>(d, tile, stream);
+      return dispatch_tile<__bf16, __bf16, SP3_LOAD_CONV3X3>(d, tile, stream);
+    }
+    if (d.loader == SP3_LOAD_PLAIN) return dispatch_tile<float, __bf16, SP3_LOAD_PLAIN>(d, tile, stream);
+    return dispatch_tile<float, __bf16, SP3_LOAD_CONV3X3>(d, tile, stream);
   } else {
-    if (d.loader == SP3_LOAD_PLAIN) return dispatch_tile<float, SP3_LOAD_PLAIN>(d, tile, stream);
-    return dispatch_tile<float, SP3_LOAD_CONV3X3>(d, tile, stream);
+    if (d.loader == SP3_LOAD_PLAIN) return dispatch_tile<float, float, SP3_LOAD_PLAIN>(d, tile, stream);
+    return dispatch_tile<float, float, SP3_LOAD_CONV3X3>(d, tile, stream);
   }
 }

@@ -116,6 +116,81 @@ __global__ __launch_bounds__(256) void layernorm_t_kernel(const float* __restric
   }
 }
 
+// ------------------------------------------------------------------ split-K finish + residual + LayerNorm(s)
+// One wave per row.  x = sum_s partial[s][row] + bias + res[row]; optional x_out; up to two LayerNorms of x
+// (they share mean / rstd).  Same two-pass fp32 statistics as layernorm_kernel.
+struct ReduceLnArgs { sp3_reduce_ln_desc d; };
+
+__device__ __forceinline__ void store_row4(void* out, int64_t ld, int bf, int row, int j, float4 v) {
+  if (bf) {
+    bf16x4 o;
+    o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
+    reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(out) + (int64_t)row * ld)[j] = o;
+  } else {
+    reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (int64_t)row * ld)[j] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void reduce_ln_kernel(const ReduceLnArgs args) {
+  const sp3_reduce_ln_desc& d = args.d;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= d.rows) return;
+  const int C = d.C, c4 = C >> 2;
+  float4 v[LN_MAX_V4];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_V4; ++i) {
+    const int j = lane + i * 64;
+    if (j < c4) {
+      float4 x = reinterpret_cast<const float4*>(d.partial + (int64_t)row * C)[j];
+      for (int sp = 1; sp < d.splits; ++sp) {
+        const float4 t = reinterpret_cast<const float4*>(d.partial + sp * d.split_stride + (int64_t)row * C)[j];
+        x.x += t.x; x.y += t.y; x.z += t.z; x.w += t.w;
+      }
+      if (d.bias) {
+        const float4 b = reinterpret_cast<const float4*>(d.bias)[j];
+        x.x += b.x; x.y += b.y; x.z += b.z; x.w += b.w;
+      }
+      if (d.res) {
+        const float4 r = reinterpret_cast<const float4*>(d.res + (int64_t)row * d.ldres)[j];
+        x.x += r.x; x.y += r.y; x.z += r.z; x.w += r.w;
+      }
+      if (d.x_out) reinterpret_cast<float4*>(d.x_out + (int64_t)row * d.ldx)[j] = x;
+      v[i] = x;
+      s += (x.x + x.y) + (x.z + x.w);
+    }
+  }
+  if (!d.out1 && !d.out2) return;
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAX_V4; ++i) {
+    const int j = lane + i * 64;
+    if (j < c4) {
+      const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, e = v[i].w - mean;
+      q += (a * a + b * b) + (c * c + e * e);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + d.eps);
+#pragma unroll
+  for (int i = 0; i < LN_MAX_V4; ++i) {
+    const int j = lane + i * 64;
+    if (j < c4) {
+      float4 n;
+      n.x = (v[i].x - mean) * rstd; n.y = (v[i].y - mean) * rstd; n.z = (v[i].z - mean) * rstd; n.w = (v[i].w - mean) * rstd;
+      if (d.out1) {
+        const float4 gm = reinterpret_cast<const float4*>(d.g1)[j], bt = reinterpret_cast<const float4*>(d.b1)[j];
+        store_row4(d.out1, d.ld1, d.out1_bf16, row, j, make_float4(n.x * gm.x + bt.x, n.y * gm.y + bt.y, n.z * gm.z + bt.z, n.w * gm.w + bt.w));
+      }
+      if (d.out2) {
+        const float4 gm = reinterpret_cast<const float4*>(d.g2)[j], bt = reinterpret_cast<const float4*>(d.b2)[j];
+        store_row4(d.out2, d.ld2, d.out2_bf16, row, j, make_float4(n.x * gm.x + bt.x, n.y * gm.y + bt.y, n.z * gm.z + bt.z, n.w * gm.w + bt.w));
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ stand-alone RoPE (curope drop-in)
 // One wave handles one token (b, n) for all heads.  Lane i < D/2 owns the pair (u_i, v_i):
 // i in [0,Q) -> Y quarter pair (d=i, d=i+Q); i in [Q,2Q) -> X pair (d=2Q+i-Q, d=3Q+i-Q).
@@ -161,6 +236,21 @@ extern "C" int sp3_layernorm(const float* x, int64_t ldx, const float* gamma, co
   hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, ldx,
                      gamma, beta, eps, out, ldo, out_bf16, rows, C);
   SP3_LAUNCH_CHECK("sp3_layernorm");
+  return 0;
+}
+
+extern "C" int sp3_reduce_ln(const sp3_reduce_ln_desc* dp, void* stream) {
+  SP3_CHECK(dp && dp->partial, "sp3_reduce_ln: null descriptor / partial");
+  const sp3_reduce_ln_desc& d = *dp;
+  SP3_CHECK(d.rows > 0 && d.C > 0 && d.C % 4 == 0 && d.C <= 64 * 4 * LN_MAX_V4 && d.splits >= 1, "sp3_reduce_ln: bad rows=%d C=%d splits=%d", d.rows, d.C, d.splits);
+  SP3_CHECK(!d.out1 || (d.g1 && d.b1 && d.ld1 % 4 == 0), "sp3_reduce_ln: LayerNorm 1 needs gamma/beta");
+  SP3_CHECK(!d.out2 || (d.g2 && d.b2 && d.ld2 % 4 == 0), "sp3_reduce_ln: LayerNorm 2 needs gamma/beta");
+  SP3_CHECK(!d.res || d.ldres % 4 == 0, "sp3_reduce_ln: ldres must be a multiple of 4");
+  SP3_CHECK(!d.x_out || d.ldx % 4 == 0, "sp3_reduce_ln: ldx must be a multiple of 4");
+  ReduceLnArgs a;
+  a.d = d;
+  hipLaunchKernelGGL(reduce_ln_kernel, dim3((d.rows + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+  SP3_LAUNCH_CHECK("sp3_reduce_ln");
   return 0;
 }
 

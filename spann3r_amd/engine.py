@@ -34,6 +34,7 @@ class Engine:
         self.device = torch.device(device)
         self.precision = precision
         self.wdt = torch.float32 if precision == "fp32" else torch.bfloat16
+        self.adt = self.wdt          # dtype of activations that only feed GEMMs
         self._ws = {}
         self._pos_cache = {}
         self.max_pos = 0
@@ -141,41 +142,72 @@ class Engine:
         return self._pos_cache[key]
 
     # ------------------------------------------------------------------ transformer pieces
-    def _self_attn(self, x, R, B, P, C, heads, pre, pos32, out, res):
-        """x fp32 [R,C] (already LayerNormed) -> out = proj(attn(x)) + res.  croco/models/blocks.py:94-112."""
+    # Activations that only feed a GEMM (LayerNorm outputs, attention outputs, GELU outputs) are stored in `adt`
+    # (bf16 in bf16 mode: exactly the rounding the MFMA operand conversion would apply on load, at half the traffic);
+    # the residual stream, LayerNorm statistics and everything the API returns stay fp32.
+    def _attn_core(self, x, R, B, P, C, heads, pre, pos32, ao):
+        """qkv projection with fused bias + 2-D RoPE + per-head V^T store, then softmax(qk^T/8)v
+        (croco/models/blocks.py:94-109).  x [R,C] LayerNormed input -> ao [R,C]."""
         w = self.w
         npad = (P + 63) // 64 * 64
         qk = self.ws("qk", (R, 2 * C), self.wdt)
         vt = self.ws("vt", (B * heads * 64, npad), self.wdt, zero=True)
-        ao = self.ws("attn_out", (R, C))
         ops.proj_rope_vt(x, w[pre + "qkv.w"], w[pre + "qkv.b"], qk, 2 * C, vt, npad, M=R, N=3 * C, K=C, lda=C,
                          rope_cols=2 * C, pos=pos32, cos=self.cos, sin=self.sin, tokens=P, heads=heads)
         ops.attention(qk, P * 2 * C, 2 * C, qk[:, C:], P * 2 * C, 2 * C, vt, npad, ao, C, B=B, heads=heads, Nq=P, Nk=P,
                       scale=64 ** -0.5)
-        ops.gemm(ao, w[pre + "proj.w"], out, M=R, N=C, K=C, lda=C, ldc=C, bias=w[pre + "proj.b"], res1=res, ldr1=C)
 
-    def _mlp(self, x, R, C, pre, out, res):
-        """croco/models/blocks.py:73-79: fc1 -> exact-erf GELU -> fc2, + residual."""
+    def _linear_reduce(self, A, W, bias, R, N, K, lda, *, res=None, x_out=None, ln1=None, out1=None, ln2=None, out2=None,
+                       eps=1e-6, A2=None, lda2=0, K1=0):
+        """x = A.W^T + bias (+ res) as a split-K GEMM finished by the fused reduce + residual + LayerNorm kernel
+        (`x = x + proj(...)` and the norm(s) that follow, croco/models/blocks.py:128-129,187-190)."""
+        S = ops.pick_splitk(R, N, K)
+        part = self.ws("splitk_partial", (8 * R * max(N, 1),))
+        if part.numel() < S * R * N:
+            part = self.ws("splitk_partial_%d" % (S * R * N), (S * R * N,))
+        ops.gemm(A, W, part, M=R, N=N, K=K, lda=lda, ldc=N, splitk=S, A2=A2, lda2=lda2, K1=K1)
+        ops.reduce_ln(part, S, R, N, bias=bias, res=res, x_out=x_out, ln1=ln1, out1=out1, ln2=ln2, out2=out2, eps=eps)
+
+    def _norm(self, name):
+        return (self.w[name + ".w"], self.w[name + ".b"])
+
+    def _block(self, x, ln_in, R, B, P, C, heads, pre, pos32, next_norm, next_out, keep_x=True):
+        """Pre-LN ViT block on the fp32 stream x (croco/models/blocks.py:127-130).  `ln_in` = norm1(x) (computed by the
+        producer of x); the block's last kernel also emits next_out = LayerNorm(x_new; next_norm)."""
         w = self.w
+        ao = self.ws("attn_out", (R, C), self.adt)
+        self._attn_core(ln_in, R, B, P, C, heads, pre, pos32, ao)
+        ln2 = self.ws("ln_b", (R, C), self.adt)
+        self._linear_reduce(ao, w[pre + "proj.w"], w[pre + "proj.b"], R, C, C, C, res=x, x_out=x,
+                            ln1=self._norm(pre + "norm2"), out1=ln2)
         Hd = C * self.cfg.mlp_ratio
-        h = self.ws("mlp_hidden", (R, Hd))
-        ops.gemm(x, w[pre + "fc1.w"], h, M=R, N=Hd, K=C, lda=C, ldc=Hd, bias=w[pre + "fc1.b"], act=ACT_GELU)
-        ops.gemm(h, w[pre + "fc2.w"], out, M=R, N=C, K=Hd, lda=Hd, ldc=C, bias=w[pre + "fc2.b"], res1=res, ldr1=C)
-
-    def _block(self, x, R, B, P, C, heads, pre, pos32):
-        """Pre-LN ViT block in place on x (croco/models/blocks.py:127-130), LayerNorm eps 1e-6."""
-        w = self.w
-        ln = self.ws("ln", (R, C))
-        ops.layernorm(x, w[pre + "norm1.w"], w[pre + "norm1.b"], 1e-6, ln, rows=R, C_=C)
-        self._self_attn(ln, R, B, P, C, heads, pre, pos32, x, x)
-        ops.layernorm(x, w[pre + "norm2.w"], w[pre + "norm2.b"], 1e-6, ln, rows=R, C_=C)
-        self._mlp(ln, R, C, pre, x, x)
+        h = self.ws("mlp_hidden", (R, Hd), self.adt)
+        ops.gemm(ln2, w[pre + "fc1.w"], h, M=R, N=Hd, K=C, lda=C, ldc=Hd, bias=w[pre + "fc1.b"], act=ACT_GELU)
+        self._linear_reduce(h, w[pre + "fc2.w"], w[pre + "fc2.b"], R, C, Hd, Hd, res=x, x_out=x if keep_x else None,
+                            ln1=self._norm(next_norm), out1=next_out)
 
     # ------------------------------------------------------------------ stages
+    def _vit(self, col, R, B, P, patch_w, prefix, depth, pos32, final_norm, final_out):
+        """patch-embed GEMM + `depth` blocks + final norm; every LayerNorm rides on the producing kernel."""
+        cfg, w = self.cfg, self.w
+        E = cfg.enc_dim
+        K0 = col.shape[1]
+        x = self.ws("vit_x", (R, E))
+        lnA = self.ws("ln_a", (R, E), self.adt)
+        first = (prefix + "0.norm1") if depth > 0 else final_norm
+        self._linear_reduce(col, w[patch_w + ".w"], w[patch_w + ".b"], R, E, K0, K0, x_out=x, ln1=self._norm(first),
+                            out1=lnA if depth > 0 else final_out)
+        for i in range(depth):
+            last = i == depth - 1
+            nxt = final_norm if last else prefix + "%d.norm1" % (i + 1)
+            self._block(x, lnA, R, B, P, E, cfg.enc_heads, prefix + "%d." % i, pos32, nxt, final_out if last else lnA,
+                        keep_x=not last)
+        return final_out
+
     def encode_image(self, img, out=None):
         """dust3r._encode_image (dust3r/model.py:131-154): patch embed -> enc_depth blocks -> enc_norm.
         img fp32 [B,3,H,W] on device -> feat [B,P,1024] (written to `out` if given), pos int64 [B,P,2]."""
-        cfg, w = self.cfg, self.w
+        cfg = self.cfg
         B, Cin, H, W_ = img.shape
         p = cfg.patch
         assert Cin == 3 and H % p == 0 and W_ % p == 0, "Input image size is not a multiple of patch size"
@@ -183,15 +215,11 @@ class Engine:
         P, E = nh * nw, cfg.enc_dim
         R = B * P
         pos64, pos32, _ = self.positions(B, nh, nw)
-        col = self.ws("im2col", (R, 3 * p * p))
+        col = self.ws("im2col", (R, 3 * p * p), self.adt)
         ops.im2col_patch(img, col, B=B, C_=3, H=H, W_=W_, p=p, strides=img.stride())
-        x = self.ws("enc_x", (R, E))
-        ops.gemm(col, w["patch.w"], x, M=R, N=E, K=3 * p * p, lda=3 * p * p, ldc=E, bias=w["patch.b"])
-        for i in range(cfg.enc_depth):
-            self._block(x, R, B, P, E, cfg.enc_heads, "enc%d." % i, pos32)
         if out is None:
             out = torch.empty(B, P, E, device=self.device)
-        ops.layernorm(x, w["enc_norm.w"], w["enc_norm.b"], 1e-6, out, rows=R, C_=E)
+        self._vit(col, R, B, P, "patch", "enc", cfg.enc_depth, pos32, "enc_norm", out)
         return out, pos64
 
     def decoder(self, f1, f2, B, nh1, nw1, nh2, nw2):
@@ -200,53 +228,68 @@ class Engine:
         cfg, w = self.cfg, self.w
         E, D, Hh = cfg.enc_dim, cfg.dec_dim, cfg.dec_heads
         P1, P2 = nh1 * nw1, nh2 * nw2
-        R1, R2 = B * P1, B * P2
+        Rs, Ps = {1: B * P1, 2: B * P2}, {1: P1, 2: P2}
+        Rmax, Pmax = max(Rs.values()), max(P1, P2)
         pos = {1: self.positions(B, nh1, nw1)[1], 2: self.positions(B, nh2, nw2)[1]}
-        Rs, Ps = {1: R1, 2: R2}, {1: P1, 2: P2}
         f = {1: f1, 2: f2}
         outs = {1: [f1], 2: [f2]}
+        depth = cfg.dec_depth
+        # per side, double-buffered by layer parity: ln1 = norm1(own previous layer), yn = norm_y(OTHER side's previous layer)
+        ln1 = {s: [self.ws("dec_ln1_%d_%d" % (s, j), (Rs[s], D), self.adt) for j in (0, 1)] for s in (1, 2)}
+        yn = {s: [self.ws("dec_yn_%d_%d" % (s, j), (Rs[3 - s], D), self.adt) for j in (0, 1)] for s in (1, 2)}
         prev = {}
         for s in (1, 2):
+            o = 3 - s
             prev[s] = self.ws("dec%d_l0" % s, (Rs[s], D))
-            ops.gemm(f[s], w["dec_embed.w"], prev[s], M=Rs[s], N=D, K=E, lda=E, ldc=D, bias=w["dec_embed.b"])
-        for i in range(cfg.dec_depth):
+            # decoder_embed (dust3r/model.py:190-191); emits norm1 for side s and norm_y for side o's first block
+            self._linear_reduce(f[s], w["dec_embed.w"], w["dec_embed.b"], Rs[s], D, E, E, x_out=prev[s],
+                                ln1=self._norm("dec%d_0.norm1" % s), out1=ln1[s][0],
+                                ln2=self._norm("dec%d_0.norm_y" % o), out2=yn[o][0])
+        for i in range(depth):
+            cur, nx = i % 2, (i + 1) % 2
+            last = i == depth - 1
             new = {}
             for s in (1, 2):
                 o = 3 - s
                 pre = "dec%d_%d." % (s, i)
                 R, P, Ro, Po = Rs[s], Ps[s], Rs[o], Ps[o]
                 x = self.ws("dec%d_l%d" % (s, i + 1), (R, D))
-                ln = self.ws("ln_dec", (max(R1, R2), D))
                 # self attention (croco/models/blocks.py:187)
-                ops.layernorm(prev[s], w[pre + "norm1.w"], w[pre + "norm1.b"], 1e-6, ln, rows=R, C_=D)
-                self._self_attn(ln, R, B, P, D, Hh, pre, pos[s], x, prev[s])
-                # cross attention to the other side's previous-layer tokens (:188-189)
-                yn = self.ws("ln_y", (max(R1, R2), D))
-                ops.layernorm(prev[o], w[pre + "norm_y.w"], w[pre + "norm_y.b"], 1e-6, yn, rows=Ro, C_=D)
-                npad = (Po + 63) // 64 * 64
-                kbuf = self.ws("ck", (max(R1, R2), D), self.wdt)
-                vt = self.ws("cvt", (B * Hh * 64, (max(P1, P2) + 63) // 64 * 64), self.wdt, zero=True)
+                ao = self.ws("attn_out_dec", (Rmax, D), self.adt)
+                self._attn_core(ln1[s][cur], R, B, P, D, Hh, pre, pos[s], ao)
+                ln2 = self.ws("dec_ln_b", (Rmax, D), self.adt)
+                self._linear_reduce(ao, w[pre + "proj.w"], w[pre + "proj.b"], R, D, D, D, res=prev[s], x_out=x,
+                                    ln1=self._norm(pre + "norm2"), out1=ln2)
+                # cross attention to the other side's previous-layer tokens through norm_y (:188-189)
+                kbuf = self.ws("ck", (Rmax, D), self.wdt)
+                vt = self.ws("cvt", (B * Hh * 64, (Pmax + 63) // 64 * 64), self.wdt, zero=True)
                 vt_ld = vt.shape[1]
-                ops.proj_rope_vt(yn, w[pre + "ckv.w"], w[pre + "ckv.b"], kbuf, D, vt, vt_ld, M=Ro, N=2 * D, K=D, lda=D,
+                ops.proj_rope_vt(yn[s][cur], w[pre + "ckv.w"], w[pre + "ckv.b"], kbuf, D, vt, vt_ld, M=Ro, N=2 * D, K=D, lda=D,
                                  rope_cols=D, pos=pos[o], cos=self.cos, sin=self.sin, tokens=Po, heads=Hh)
-                ops.layernorm(x, w[pre + "norm2.w"], w[pre + "norm2.b"], 1e-6, ln, rows=R, C_=D)
-                qbuf = self.ws("cq", (max(R1, R2), D), self.wdt)
-                ops.proj_rope_vt(ln, w[pre + "cq.w"], w[pre + "cq.b"], qbuf, D, None, 0, M=R, N=D, K=D, lda=D,
+                qbuf = self.ws("cq", (Rmax, D), self.wdt)
+                ops.proj_rope_vt(ln2, w[pre + "cq.w"], w[pre + "cq.b"], qbuf, D, None, 0, M=R, N=D, K=D, lda=D,
                                  rope_cols=D, pos=pos[s], cos=self.cos, sin=self.sin, tokens=P, heads=Hh)
-                ao = self.ws("attn_out_dec", (max(R1, R2), D))
                 ops.attention(qbuf, P * D, D, kbuf, Po * D, D, vt, vt_ld, ao, D, B=B, heads=Hh, Nq=P, Nk=Po, scale=64 ** -0.5)
-                ops.gemm(ao, w[pre + "cproj.w"], x, M=R, N=D, K=D, lda=D, ldc=D, bias=w[pre + "cproj.b"], res1=x, ldr1=D)
-                # MLP (:190)
-                ops.layernorm(x, w[pre + "norm3.w"], w[pre + "norm3.b"], 1e-6, ln, rows=R, C_=D)
-                self._mlp(ln, R, D, pre, x, x)
-                new[s] = x
+                ln3 = self.ws("dec_ln_c", (Rmax, D), self.adt)
+                self._linear_reduce(ao, w[pre + "cproj.w"], w[pre + "cproj.b"], R, D, D, D, res=x, x_out=x,
+                                    ln1=self._norm(pre + "norm3"), out1=ln3)
+                # MLP (:190); its finishing kernel emits the next layer's norm1 (own side) and norm_y (other side)
+                Hd = D * cfg.mlp_ratio
+                h = self.ws("mlp_hidden_dec", (Rmax, Hd), self.adt)
+                ops.gemm(ln3, w[pre + "fc1.w"], h, M=R, N=Hd, K=D, lda=D, ldc=Hd, bias=w[pre + "fc1.b"], act=ACT_GELU)
+                if last:
+                    normed = self.ws("dec%d_normed" % s, (R, D))
+                    self._linear_reduce(h, w[pre + "fc2.w"], w[pre + "fc2.b"], R, D, Hd, Hd, res=x, x_out=None,
+                                        ln1=self._norm("dec_norm"), out1=normed)
+                    new[s] = normed
+                else:
+                    self._linear_reduce(h, w[pre + "fc2.w"], w[pre + "fc2.b"], R, D, Hd, Hd, res=x, x_out=x,
+                                        ln1=self._norm("dec%d_%d.norm1" % (s, i + 1)), out1=ln1[s][nx],
+                                        ln2=self._norm("dec%d_%d.norm_y" % (o, i + 1)), out2=yn[o][nx])
+                    new[s] = x
             for s in (1, 2):
                 prev[s] = new[s]
                 outs[s].append(new[s].view(B, Ps[s], D))
-        for s in (1, 2):
-            last = self.ws("dec%d_normed" % s, (Rs[s], D))
-            ops.layernorm(prev[s], w["dec_norm.w"], w["dec_norm.b"], 1e-6, last, rows=Rs[s], C_=D)
-            outs[s][-1] = last.view(B, Ps[s], D)
         return outs[1], outs[2]
 
     def encode_feat_key(self, feat, dec_last, R, num, out):
@@ -254,7 +297,7 @@ class Engine:
         the concatenation is never materialised (split-A GEMM)."""
         cfg, w = self.cfg, self.w
         E, D, Kd = cfg.enc_dim, cfg.dec_dim, cfg.key_dim
-        h = self.ws("key_hidden", (R, Kd))
+        h = self.ws("key_hidden", (R, Kd), self.adt)
         pre = "key%d." % num
         ops.gemm(feat, w[pre + "0.w"], h, M=R, N=Kd, K=Kd, lda=E, ldc=Kd, bias=w[pre + "0.b"], act=ACT_GELU,
                  A2=dec_last, lda2=D, K1=E)
@@ -342,7 +385,7 @@ class Engine:
 
     def encode_cur_value(self, pts3d, out, res):
         """spann3r/model.py:305-320 (use_feat=False): pos_patch_embed(pts3d as a 3-channel image) -> 6 blocks without
-        RoPE -> value_norm -> value_out; `res` (feat_k1) is added in the last GEMM's epilogue (:519/:521 `cur_v+feat_k1`)
+        RoPE -> value_norm -> value_out; `res` (feat_k1) is added by the finishing kernel (:519/:521 `cur_v+feat_k1`)
         only if given.  pts3d fp32 [B,H,W,3] (any strides)."""
         cfg, w = self.cfg, self.w
         B, H, W_, _ = pts3d.shape
@@ -351,15 +394,11 @@ class Engine:
         P = nh * nw
         R = B * P
         _, _, zero_pos = self.positions(B, nh, nw)
-        col = self.ws("im2col", (R, 3 * p * p))
+        col = self.ws("im2col", (R, 3 * p * p), self.adt)
         sb, sy, sx, sc = pts3d.stride()
         ops.im2col_patch(pts3d, col, B=B, C_=3, H=H, W_=W_, p=p, strides=(sb, sc, sy, sx))
-        x = self.ws("val_x", (R, E))
-        ops.gemm(col, w["pospatch.w"], x, M=R, N=E, K=3 * p * p, lda=3 * p * p, ldc=E, bias=w["pospatch.b"])
-        for i in range(cfg.val_depth):
-            # rope=None in the reference (mem_pos_enc=False): all-zero positions make the fused RoPE the identity
-            self._block(x, R, B, P, E, cfg.enc_heads, "val%d." % i, zero_pos)
-        ln = self.ws("ln", (R, E))
-        ops.layernorm(x, w["value_norm.w"], w["value_norm.b"], 1e-6, ln, rows=R, C_=E)
-        ops.gemm(ln, w["value_out.w"], out, M=R, N=E, K=E, lda=E, ldc=E, bias=w["value_out.b"], res1=res, ldr1=E)
+        # rope=None in the reference (mem_pos_enc=False): all-zero positions make the fused RoPE the identity
+        vn = self.ws("val_normed", (R, E), self.adt)
+        self._vit(col, R, B, P, "pospatch", "val", cfg.val_depth, zero_pos, "value_norm", vn)
+        self._linear_reduce(vn, w["value_out.w"], w["value_out.b"], R, E, E, E, res=res, x_out=out)
         return out

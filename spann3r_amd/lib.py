@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libspann3r_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
-EPI_PLAIN, EPI_ROPE_VT, EPI_PIXSHUF = 0, 1, 2
+EPI_PLAIN, EPI_ROPE_VT, EPI_PIXSHUF, EPI_PARTIAL = 0, 1, 2, 3
 LOAD_PLAIN, LOAD_CONV3X3 = 0, 1
 
 
@@ -35,7 +35,17 @@ class GemmDesc(C.Structure):
         ("rope_cols", C.c_int32), ("vt", C.c_void_p), ("tokens", C.c_int32), ("heads", C.c_int32),
         ("vt_ld", C.c_int64),
         ("ps_k", C.c_int32), ("ps_H", C.c_int32), ("ps_W", C.c_int32), ("ps_C", C.c_int32),
-        ("tile", C.c_int32),
+        ("tile", C.c_int32), ("a_bf16", C.c_int32), ("splitk", C.c_int32),
+    ]
+
+
+class ReduceLnDesc(C.Structure):
+    _fields_ = [
+        ("partial", C.c_void_p), ("split_stride", C.c_int64), ("bias", C.c_void_p), ("res", C.c_void_p),
+        ("ldres", C.c_int64), ("x_out", C.c_void_p), ("ldx", C.c_int64),
+        ("g1", C.c_void_p), ("b1", C.c_void_p), ("out1", C.c_void_p), ("ld1", C.c_int64), ("out1_bf16", C.c_int32),
+        ("g2", C.c_void_p), ("b2", C.c_void_p), ("out2", C.c_void_p), ("ld2", C.c_int64), ("out2_bf16", C.c_int32),
+        ("eps", C.c_float), ("splits", C.c_int32), ("rows", C.c_int32), ("C", C.c_int32),
     ]
 
 
@@ -45,12 +55,13 @@ _PROTOS = {
     "sp3_gemm": [C.POINTER(GemmDesc), C.c_void_p],
     "sp3_layernorm": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_int,
                       C.c_int, C.c_int, C.c_void_p],
+    "sp3_reduce_ln": [C.POINTER(ReduceLnDesc), C.c_void_p],
     "sp3_layernorm_t": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_int,
                         C.c_int, C.c_int, C.c_void_p],
     "sp3_rope_2d": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64,
                     C.c_void_p, C.c_float, C.c_float, C.c_void_p],
     "sp3_attention": [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
-                      C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p],
+                      C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p],
     "sp3_softmax_thresh": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float,
                            C.c_int, C.c_void_p],
     "sp3_colsum_accum": [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
@@ -62,7 +73,7 @@ _PROTOS = {
                         C.c_int, C.c_void_p],
     "sp3_gather_1d": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p],
     "sp3_im2col_patch": [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
-                         C.c_int, C.c_void_p, C.c_void_p],
+                         C.c_int, C.c_void_p, C.c_int, C.c_void_p],
     "sp3_upsample2x": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "sp3_head_final": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                        C.c_void_p],

@@ -105,7 +105,7 @@ class SpatialMemory:
         assert M > 0
         Mpad = (M + 7) // 8 * 8
         ld = (self.cap + 7) // 8 * 8
-        qn = eng.ws("mem_qn", (B * P, C))
+        qn = eng.ws("mem_qn", (B * P, C), eng.adt)
         ops.layernorm(feat, w["norm_q.w"], w["norm_q.b"], 1e-5, qn, rows=B * P, C_=C)
         S = eng.ws("mem_S", (B, P, ld))
         Pm = eng.ws("mem_P", (B, P, ld))

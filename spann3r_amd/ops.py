@@ -51,23 +51,35 @@ def set_profiler(p):
     _prof = p
 
 
-_TILE_NAMES = {0: "32x32xk4", 1: "64x64", 2: "64x128"}
+_TILE_NAMES = {0: "32x32xk4", 1: "64x64", 2: "64x128", 3: "64x64xk4"}
 
 
-def pick_tile(M, N, batch=1):
+def pick_tile(M, N, batch=1, splitk=1, conv=False):
     """Mirror of the auto heuristic in csrc/gemm.hip (kept in sync so profiles can be keyed by instantiation)."""
-    t64 = ((M + 63) // 64) * ((N + 63) // 64) * batch
+    t64 = ((M + 63) // 64) * ((N + 63) // 64) * batch * splitk
     t128 = ((M + 63) // 64) * ((N + 127) // 128) * batch
-    if t128 >= 1024 and N % 128 == 0:
-        return 2
-    if t64 >= 512:
-        return 1
-    return 0
+    if conv or M > 2048:
+        if t128 >= 1024 and N % 128 == 0:
+            return 2
+        if t64 >= 512:
+            return 1
+        return 0
+    return 3 if t64 >= 128 else 0
+
+
+def pick_splitk(M, N, K):
+    """How many workgroups share one output tile's K range (PARTIAL epilogue + sp3_reduce_ln): enough 64x64 tiles
+    to cover the 256 CUs, but at least 4 k-blocks of 64 per wave (K / (splitk*4*64) >= 1)."""
+    tiles = ((M + 63) // 64) * ((N + 63) // 64)
+    s = 1
+    while tiles * s < 192 and K // (s * 2) >= 512 and s < 8:
+        s *= 2
+    return s
 
 
 def _gemm_launch(d, what, loader_name):
     if d.tile < 0:
-        d.tile = pick_tile(d.M, d.N, max(d.batch, 1))
+        d.tile = pick_tile(d.M, d.N, max(d.batch, 1), max(d.splitk, 1), d.loader == L.LOAD_CONV3X3)
     if _prof is None:
         L.check(L.load().sp3_gemm(C.byref(d), L.stream_ptr()), what)
         return
@@ -77,7 +89,9 @@ def _gemm_launch(d, what, loader_name):
     wsz = 4 if d.wdtype == F32 else 2
     flops = 2.0 * d.M * d.N * d.K * b
     nbytes = b * (4.0 * d.M * d.K + wsz * d.N * d.K + 4.0 * d.M * d.N)
-    _prof.end("gemm<%s,%s,%s>" % ("f32" if d.wdtype == F32 else "bf16", loader_name, _TILE_NAMES[d.tile]), e0, flops, nbytes)
+    adt = "bf16" if d.a_bf16 else "f32"
+    _prof.end("gemm<A%s,W%s,%s,%s>" % (adt, "f32" if d.wdtype == F32 else "bf16", loader_name, _TILE_NAMES[d.tile]),
+              e0, flops, nbytes)
 
 
 def _timed(key, flops, nbytes, fn, *args):
@@ -102,12 +116,22 @@ def _f32(t, name):
         raise TypeError("%s must be a float32 CUDA(HIP) tensor" % name)
 
 
+def _act(t, name):
+    """GEMM A operands: fp32, or bf16 in bf16 mode.  Returns the a_bf16 flag."""
+    if not t.is_cuda or t.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("%s must be a float32/bfloat16 CUDA(HIP) tensor" % name)
+    return int(t.dtype == torch.bfloat16)
+
+
 def gemm(A, W, out, *, M, N, K, lda, ldc, bias=None, res1=None, ldr1=0, res2=None, ldr2=0, act=ACT_NONE, alpha=1.0,
-         out_bf16=False, relu_in=False, tile=-1, batch=1, strideA=0, strideW=0, strideC=0, ldw=0,
-         A2=None, lda2=0, K1=0):
-    """out[M,N] = act(alpha * A[M,K] @ W[N,K]^T + bias) (+ res1 + res2).  nn.Linear / 1x1 conv / einsum."""
-    _f32(A, "A")
+         relu_in=False, tile=-1, batch=1, strideA=0, strideW=0, strideC=0, ldw=0,
+         A2=None, lda2=0, K1=0, splitk=0):
+    """out[M,N] = act(alpha * A[M,K] @ W[N,K]^T + bias) (+ res1 + res2).  nn.Linear / 1x1 conv / einsum.
+    `out` may be fp32 or bf16.  splitk >= 1 selects the PARTIAL epilogue: out is an fp32 [splitk, M, ldc] workspace
+    that sp3_reduce_ln finishes."""
     d = GemmDesc()
+    d.a_bf16 = _act(A, "A")
+    out_bf16 = out.dtype == torch.bfloat16
     d.A, d.A2, d.W, d.C = A.data_ptr(), L.ptr(A2), W.data_ptr(), out.data_ptr()
     d.bias, d.res1, d.res2 = L.ptr(bias), L.ptr(res1), L.ptr(res2)
     d.M, d.N, d.K, d.batch, d.K1 = M, N, K, batch, K1
@@ -115,17 +139,38 @@ def gemm(A, W, out, *, M, N, K, lda, ldc, bias=None, res1=None, ldr1=0, res2=Non
     d.strideA, d.strideW, d.strideC = strideA, strideW, strideC
     d.alpha, d.wdtype, d.act, d.out_bf16, d.relu_in = alpha, wdtype_of(W), act, int(out_bf16), int(relu_in)
     d.loader, d.epi, d.tile = L.LOAD_PLAIN, L.EPI_PLAIN, tile
+    if splitk >= 1:
+        d.epi, d.splitk = L.EPI_PARTIAL, splitk
     _gemm_launch(d, "sp3_gemm", "plain")
     return out
+
+
+def reduce_ln(partial, splits, rows, C_, *, bias=None, res=None, ldres=0, x_out=None, ldx=0,
+              ln1=None, out1=None, ld1=0, ln2=None, out2=None, ld2=0, eps=1e-6):
+    """Finish a split-K GEMM: x = sum(partials) + bias (+ res); x_out = x; out1/out2 = LayerNorm(x) with (gamma, beta)
+    pairs ln1 / ln2.  One launch replaces `x = x + proj(...)` and the LayerNorm(s) that follow on the stream."""
+    d = L.ReduceLnDesc()
+    d.partial, d.split_stride, d.splits, d.rows, d.C = partial.data_ptr(), rows * C_, splits, rows, C_
+    d.bias, d.res, d.ldres = L.ptr(bias), L.ptr(res), ldres or C_
+    d.x_out, d.ldx = L.ptr(x_out), ldx or C_
+    if out1 is not None:
+        d.g1, d.b1, d.out1, d.ld1, d.out1_bf16 = ln1[0].data_ptr(), ln1[1].data_ptr(), out1.data_ptr(), ld1 or C_, int(out1.dtype == torch.bfloat16)
+    if out2 is not None:
+        d.g2, d.b2, d.out2, d.ld2, d.out2_bf16 = ln2[0].data_ptr(), ln2[1].data_ptr(), out2.data_ptr(), ld2 or C_, int(out2.dtype == torch.bfloat16)
+    d.eps = eps
+    nln = (out1 is not None) + (out2 is not None)
+    _timed("reduce_ln", (splits + 8.0 * nln) * rows * C_, 4.0 * rows * C_ * (splits + 2 + nln),
+           lambda: L.check(L.load().sp3_reduce_ln(C.byref(d), L.stream_ptr()), "sp3_reduce_ln"))
 
 
 def conv3x3(x, Wp, out, *, B, H, W_, Cin, Cout, stride=1, bias=None, res1=None, res2=None, act=ACT_NONE,
             relu_in=False, tile=-1):
     """3x3 Conv2d, padding 1, on an NHWC fp32 map [B,H,W,Cin] -> [B,OH,OW,Cout] (implicit GEMM).
     Wp is the weight packed as [Cout, 9*Cin] with k = (ky*3+kx)*Cin + ci."""
-    _f32(x, "x")
     OH, OW = (H - 1) // stride + 1, (W_ - 1) // stride + 1
     d = GemmDesc()
+    d.a_bf16 = _act(x, "x")
+    d.out_bf16 = int(out.dtype == torch.bfloat16)
     d.A, d.W, d.C = x.data_ptr(), Wp.data_ptr(), out.data_ptr()
     d.bias, d.res1, d.res2 = L.ptr(bias), L.ptr(res1), L.ptr(res2)
     d.M, d.N, d.K, d.batch = B * OH * OW, Cout, 9 * Cin, 1
@@ -140,8 +185,9 @@ def conv3x3(x, Wp, out, *, B, H, W_, Cin, Cout, stride=1, bias=None, res1=None, 
 def conv_transpose_ks(x, Wp, out, *, B, H, W_, Cin, Cout, ks, bias=None, tile=-1):
     """ConvTranspose2d with kernel == stride == ks on NHWC [B,H,W,Cin] -> [B,ks*H,ks*W,Cout].
     Wp is packed [(ky*ks+kx)*Cout + co, ci]."""
-    _f32(x, "x")
     d = GemmDesc()
+    d.a_bf16 = _act(x, "x")
+    d.out_bf16 = int(out.dtype == torch.bfloat16)
     d.A, d.W, d.C, d.bias = x.data_ptr(), Wp.data_ptr(), out.data_ptr(), L.ptr(bias)
     d.M, d.N, d.K, d.batch = B * H * W_, ks * ks * Cout, Cin, 1
     d.lda, d.ldc = Cin, Cout
@@ -155,8 +201,8 @@ def conv_transpose_ks(x, Wp, out, *, B, H, W_, Cin, Cout, ks, bias=None, tile=-1
 def proj_rope_vt(A, W, bias, out_qk, ldc, vt, vt_ld, *, M, N, K, lda, rope_cols, pos, cos, sin, tokens, heads, tile=-1):
     """Fused q/k(/v) projection of an attention layer: bias + 2-D RoPE on columns [0, rope_cols)
     (stored row-major to out_qk) and per-head transposed store of the V columns to vt."""
-    _f32(A, "A")
     d = GemmDesc()
+    d.a_bf16 = _act(A, "A")
     d.A, d.W, d.C, d.bias = A.data_ptr(), W.data_ptr(), L.ptr(out_qk), L.ptr(bias)
     d.M, d.N, d.K, d.batch = M, N, K, 1
     d.lda, d.ldc = lda, ldc
@@ -212,8 +258,8 @@ def attention(q, sq, ldq, k, sk, ldk, vt, vt_ld, out, ldo, *, B, heads, Nq, Nk, 
     _timed("attention<%s>" % ("f32" if es == 4 else "bf16"), 4.0 * B * heads * Nq * Nk * 64,
            B * heads * 64.0 * (es * (Nq + 2 * Nk) + 4 * Nq),
            lambda: L.check(L.load().sp3_attention(q.data_ptr(), sq, ldq, k.data_ptr(), sk, ldk, vt.data_ptr(), vt_ld,
-                                                  out.data_ptr(), ldo, B, heads, Nq, Nk, float(scale), wdtype_of(vt),
-                                                  L.stream_ptr()), "sp3_attention"))
+                                                  out.data_ptr(), ldo, int(out.dtype == torch.bfloat16), B, heads, Nq, Nk,
+                                                  float(scale), wdtype_of(vt), L.stream_ptr()), "sp3_attention"))
     return out
 
 
@@ -257,8 +303,8 @@ def gather_1d(src, dst, sel, n_sel):
 def im2col_patch(img, out, *, B, C_, H, W_, p, strides):
     _f32(img, "img")
     sb, sc, sy, sx = strides
-    L.check(L.load().sp3_im2col_patch(img.data_ptr(), sb, sc, sy, sx, B, C_, H, W_, p, out.data_ptr(), L.stream_ptr()),
-            "sp3_im2col_patch")
+    L.check(L.load().sp3_im2col_patch(img.data_ptr(), sb, sc, sy, sx, B, C_, H, W_, p, out.data_ptr(),
+                                      int(out.dtype == torch.bfloat16), L.stream_ptr()), "sp3_im2col_patch")
     return out
 
 

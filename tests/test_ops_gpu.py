@@ -36,7 +36,7 @@ TOL = {torch.float32: 2e-5, torch.bfloat16: 2e-3}
 @pytest.mark.parametrize("wdt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,N,K", [(196, 1024, 1024), (392, 3072, 1024), (20, 768, 768), (100, 96, 1024),
                                    (196, 588, 1024), (49, 256, 96), (196, 1024, 1736), (7, 32, 8), (300, 160, 200)])
-@pytest.mark.parametrize("tile", [-1, 0, 1, 2])
+@pytest.mark.parametrize("tile", [-1, 0, 1, 2, 3])
 def test_gemm_plain(wdt, M, N, K, tile):
     ops = _ops()
     A, W = rnd(M, K, seed=1), rnd(N, K, seed=2)
@@ -68,8 +68,50 @@ def test_gemm_epilogue_bias_gelu_residuals(wdt):
     ops.gemm(Ad, Wd, x, M=M, N=N, K=K, lda=K, ldc=N, bias=b.to(DEV), res1=x, ldr1=N)
     assert rel_err(x.cpu(), (Ar.double() @ Wr.double().T) + b.double() + r1.double()) < TOL[wdt]
     ob = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
-    ops.gemm(Ad, Wd, ob, M=M, N=N, K=K, lda=K, ldc=N, act=ops.ACT_RELU, out_bf16=True)
+    ops.gemm(Ad, Wd, ob, M=M, N=N, K=K, lda=K, ldc=N, act=ops.ACT_RELU)
     assert rel_err(ob.float().cpu(), F.relu(Ar.double() @ Wr.double().T)) < 5e-3
+
+
+@pytest.mark.parametrize("M,N,K", [(196, 1024, 1024), (196, 768, 3072), (392, 1024, 4096), (20, 768, 776)])
+@pytest.mark.parametrize("tile", [-1, 0, 3])
+def test_gemm_bf16_activations(M, N, K, tile):
+    """bf16 mode keeps GEMM inputs in bf16 (a_bf16): same numerics as converting fp32 on load."""
+    ops = _ops()
+    A, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2) * 0.05, rnd(N, seed=3)
+    Ab = A.to(torch.bfloat16)
+    out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    ops.gemm(Ab.to(DEV), W.to(DEV).to(torch.bfloat16), out, M=M, N=N, K=K, lda=K, ldc=N, bias=b.to(DEV), act=ops.ACT_GELU, tile=tile)
+    ref = F.gelu(Ab.double() @ bf(W).double().T + b.double())
+    assert rel_err(out.float().cpu(), ref) < 6e-3
+    out32 = torch.empty(M, N, device=DEV)
+    ops.gemm(Ab.to(DEV), W.to(DEV).to(torch.bfloat16), out32, M=M, N=N, K=K, lda=K, ldc=N, tile=tile)
+    assert rel_err(out32.cpu(), Ab.double() @ bf(W).double().T) < TOL[torch.bfloat16]
+
+
+@pytest.mark.parametrize("wdt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K,S", [(196, 1024, 4096, 4), (196, 768, 768, 1), (392, 1024, 1024, 2), (20, 768, 3080, 3)])
+def test_splitk_reduce_ln(wdt, M, N, K, S):
+    """Split-K GEMM (PARTIAL epilogue) + sp3_reduce_ln == Linear + residual + two LayerNorms."""
+    ops = _ops()
+    A, W, b, res = rnd(M, K, seed=1), rnd(N, K, seed=2) * 0.05, rnd(N, seed=3), rnd(M, N, seed=4)
+    g1, b1, g2, b2 = rnd(N, seed=5) + 1, rnd(N, seed=6), rnd(N, seed=7) + 1, rnd(N, seed=8)
+    part = torch.full((S, M, N), float("nan"), device=DEV)
+    ops.gemm(A.to(DEV), W.to(DEV).to(wdt), part, M=M, N=N, K=K, lda=K, ldc=N, splitk=S)
+    x = res.clone().to(DEV)
+    o1 = torch.empty(M, N, device=DEV)
+    o2 = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    ops.reduce_ln(part, S, M, N, bias=b.to(DEV), res=x, x_out=x, ln1=(g1.to(DEV), b1.to(DEV)), out1=o1,
+                  ln2=(g2.to(DEV), b2.to(DEV)), out2=o2, eps=1e-6)
+    Ar, Wr = (bf(A), bf(W)) if wdt == torch.bfloat16 else (A, W)
+    xr = Ar.double() @ Wr.double().T + b.double() + res.double()
+    assert rel_err(x.cpu(), xr) < TOL[wdt]
+    assert rel_err(o1.cpu(), F.layer_norm(xr, (N,), g1.double(), b1.double(), 1e-6)) < (1e-4 if wdt == torch.float32 else 5e-3)
+    assert rel_err(o2.float().cpu(), F.layer_norm(xr, (N,), g2.double(), b2.double(), 1e-6)) < 8e-3
+    # no LayerNorm, no residual: plain finish
+    y = torch.empty(M, N, device=DEV)
+    ops.reduce_ln(part, S, M, N, bias=b.to(DEV), x_out=y)
+    assert rel_err(y.cpu(), Ar.double() @ Wr.double().T + b.double()) < TOL[wdt]
+    assert ops.pick_splitk(196, 1024, 4096) == 4 and ops.pick_splitk(196, 4096, 1024) == 1
 
 
 @pytest.mark.parametrize("wdt", [torch.float32, torch.bfloat16])
@@ -200,6 +242,11 @@ def test_attention(wdt, B, heads, Nq, Nk):
     a = torch.softmax(torch.einsum("bqhd,bkhd->bhqk", q.double(), k.double()) * 0.125, -1)
     ref = torch.einsum("bhqk,bkhd->bqhd", a, v.double()).reshape(B * Nq, C)
     assert rel_err(out.cpu(), ref) < (2e-5 if wdt == torch.float32 else 1e-2)
+    if wdt == torch.bfloat16:
+        ob = torch.empty(B * Nq, C, device=DEV, dtype=torch.bfloat16)
+        ops.attention(q.to(DEV).to(wdt), Nq * C, C, k.to(DEV).to(wdt), Nk * C, C, vt.reshape(-1, npad).to(DEV).to(wdt), npad, ob, C,
+                      B=B, heads=heads, Nq=Nq, Nk=Nk, scale=0.125)
+        assert rel_err(ob.float().cpu(), ref) < 1.5e-2
 
 
 # ----------------------------------------------------------------------------- LayerNorm
@@ -307,6 +354,9 @@ def test_im2col_upsample_headfinal():
     ops.im2col_patch(img.to(DEV), col, B=B, C_=3, H=H, W_=W, p=p, strides=img.stride())
     ref = F.unfold(img, p, stride=p).transpose(1, 2).reshape(-1, 3 * p * p)
     assert torch.equal(col.cpu(), ref)
+    colb = torch.empty(B * (H // p) * (W // p), 3 * p * p, device=DEV, dtype=torch.bfloat16)
+    ops.im2col_patch(img.to(DEV), colb, B=B, C_=3, H=H, W_=W, p=p, strides=img.stride())
+    assert torch.equal(colb.cpu(), ref.to(torch.bfloat16))
     nhwc = img.permute(0, 2, 3, 1).contiguous()          # pts3d layout
     sb, sy, sx, sc = nhwc.stride()
     ops.im2col_patch(nhwc.to(DEV), col, B=B, C_=3, H=H, W_=W, p=p, strides=(sb, sc, sy, sx))
