@@ -91,6 +91,11 @@ typedef struct sp3_gemm_desc {
   int32_t tile;           /* -1 auto; 0: 32x32 (K over 4 waves); 1: 64x64; 2: 64x128; 3: 64x64 (K over 4 waves) */
   int32_t a_bf16;
   int32_t splitk;         /* >= 1; > 1 only with SP3_EPI_PARTIAL */
+  int32_t a_packed;       /* A is in MFMA-fragment order [ceil(M/16)][ceil(K/KB)][64 lanes][CH] (see w_packed); written
+                             that way by the producing kernel (out_packed options), plain loader only */
+  int32_t out_packed;     /* plain epilogue: store C in fragment order (it is the next GEMM's packed A; dims M x N) */
+  int32_t w_packed;       /* W is in MFMA-fragment order [ceil(N/16)][ceil(K/KB)][64 lanes][CH], zero padded; KB/CH =
+                             64/16 (bf16) or 32/8 (fp32); lane = 16*g + r holds row 16*nb + r, k = kb*KB + g*CH + e */
 } sp3_gemm_desc;
 int sp3_gemm(const sp3_gemm_desc* desc_host, void* stream);
 
@@ -101,6 +106,9 @@ int sp3_gemm(const sp3_gemm_desc* desc_host, void* stream);
  */
 int sp3_layernorm(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
                   void* out, int64_t ldo, int out_bf16, int rows, int C, void* stream);
+/* Same, output in fragment order (see sp3_gemm_desc.a_packed). */
+int sp3_layernorm_packed(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
+                         void* out, int out_bf16, int rows, int C, void* stream);
 /* Same, but stores the result TRANSPOSED: out[c * ldo + row] (used to append LN_v(value) columns
  * to the [1024, capacity] V^T bank of the spatial memory). */
 int sp3_layernorm_t(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
@@ -125,6 +133,7 @@ typedef struct sp3_reduce_ln_desc {
   const float* g2; const float* b2; void* out2; int64_t ld2; int32_t out2_bf16;
   float eps;
   int32_t splits, rows, C;
+  int32_t out1_packed, out2_packed;   /* store the LayerNorm output in fragment order (GEMM a_packed operand) */
 } sp3_reduce_ln_desc;
 int sp3_reduce_ln(const sp3_reduce_ln_desc* desc_host, void* stream);
 
@@ -146,6 +155,10 @@ int sp3_rope_2d(void* tokens, int dtype, int B, int N, int H, int D, int64_t sB,
 int sp3_attention(const void* q, int64_t sq, int64_t ldq, const void* k, int64_t sk, int64_t ldk,
                   const void* vt, int64_t vt_ld, void* out, int64_t ldo, int out_bf16,
                   int B, int heads, int Nq, int Nk, float scale, int dtype, void* stream);
+/* out_packed != 0: out is stored in fragment order as a [B*Nq, heads*64] GEMM operand (ldo ignored) */
+int sp3_attention_ex(const void* q, int64_t sq, int64_t ldq, const void* k, int64_t sk, int64_t ldk,
+                     const void* vt, int64_t vt_ld, void* out, int64_t ldo, int out_bf16, int out_packed,
+                     int B, int heads, int Nq, int Nk, float scale, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Spatial-memory kernels (spann3r/model.py:97-210).
@@ -187,7 +200,7 @@ int sp3_gather_1d(const float* src, float* dst, const int32_t* sel, int n_sel, v
  *   w fp32 [4, C], b fp32 [4] -> pts [pixels,3], conf [pixels], raw [pixels,4] (optional).
  */
 int sp3_im2col_patch(const float* img, int64_t sb, int64_t sc, int64_t sy, int64_t sx, int B, int C, int H, int W,
-                     int p, void* out, int out_bf16, void* stream);
+                     int p, void* out, int out_bf16, int out_packed, void* stream);
 int sp3_upsample2x(const float* in, float* out, int B, int H, int W, int C, int outH, int outW, void* stream);
 int sp3_head_final(const float* feat, const float* w, const float* b, int64_t pixels, int C, float* pts,
                    float* conf, float* raw, void* stream);

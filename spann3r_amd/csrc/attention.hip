@@ -93,7 +93,8 @@ template <typename T>
 __global__ __launch_bounds__(64) void attention_kernel(const T* __restrict__ Q, int64_t sq, int64_t ldq,
                                                        const T* __restrict__ K, int64_t sk, int64_t ldk,
                                                        const T* __restrict__ VT, int64_t vt_ld, void* __restrict__ O,
-                                                       int64_t ldo, int out_bf16, int heads, int Nq, int Nk, float scale) {
+                                                       int64_t ldo, int out_bf16, int out_packed, int heads, int Nq, int Nk,
+                                                       float scale) {
   using A = AttnT<T>;
   const int lane = threadIdx.x, g = lane >> 4, ql = lane & 15;
   const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
@@ -154,44 +155,48 @@ __global__ __launch_bounds__(64) void attention_kernel(const T* __restrict__ Q, 
   const float inv = 1.0f / l_run;
   // O^T[d = 16*db + 4*g + r][q = lane&15]
   if (q0 + ql < Nq) {
-    const int64_t off = ((int64_t)b * Nq + q0 + ql) * ldo + h * 64;
-    if (out_bf16) {
-      __bf16* orow = reinterpret_cast<__bf16*>(O) + off;
+    const int row = b * Nq + q0 + ql;
 #pragma unroll
-      for (int db = 0; db < 4; ++db) {
+    for (int db = 0; db < 4; ++db) {
+      const int col = h * 64 + db * 16 + 4 * g;
+      const int64_t off = out_packed ? packed_off(row, col, heads * 64, out_bf16 != 0) : (int64_t)row * ldo + col;
+      if (out_bf16) {
         bf16x4 ob;
         ob[0] = (__bf16)(o[db][0] * inv); ob[1] = (__bf16)(o[db][1] * inv); ob[2] = (__bf16)(o[db][2] * inv); ob[3] = (__bf16)(o[db][3] * inv);
-        *reinterpret_cast<bf16x4*>(orow + db * 16 + 4 * g) = ob;
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(O) + off) = ob;
+      } else {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(O) + off) = make_float4(o[db][0] * inv, o[db][1] * inv, o[db][2] * inv, o[db][3] * inv);
       }
-    } else {
-      float* orow = reinterpret_cast<float*>(O) + off;
-#pragma unroll
-      for (int db = 0; db < 4; ++db)
-        *reinterpret_cast<float4*>(orow + db * 16 + 4 * g) = make_float4(o[db][0] * inv, o[db][1] * inv, o[db][2] * inv, o[db][3] * inv);
     }
   }
 }
 
 }  // namespace
 
-extern "C" int sp3_attention(const void* q, int64_t sq, int64_t ldq, const void* k, int64_t sk, int64_t ldk, const void* vt,
-                             int64_t vt_ld, void* out, int64_t ldo, int out_bf16, int B, int heads, int Nq, int Nk, float scale,
-                             int dtype, void* stream) {
+extern "C" int sp3_attention_ex(const void* q, int64_t sq, int64_t ldq, const void* k, int64_t sk, int64_t ldk, const void* vt,
+                                int64_t vt_ld, void* out, int64_t ldo, int out_bf16, int out_packed, int B, int heads, int Nq,
+                                int Nk, float scale, int dtype, void* stream) {
   SP3_CHECK(q && k && vt && out, "sp3_attention: null pointer");
   SP3_CHECK(B > 0 && heads > 0 && Nq > 0 && Nk > 0, "sp3_attention: bad shape");
   SP3_CHECK(vt_ld >= ((Nk + 63) / 64) * 64 && vt_ld % 8 == 0, "sp3_attention: vt_ld=%lld must be >= Nk padded to 64", (long long)vt_ld);
-  SP3_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && ldo % 4 == 0, "sp3_attention: row strides must keep 16-byte alignment");
+  SP3_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && (out_packed || ldo % 4 == 0), "sp3_attention: row strides must keep 16-byte alignment");
   SP3_CHECK(dtype == SP3_F32 || dtype == SP3_BF16, "sp3_attention: bad dtype %d", dtype);
   dim3 grid((Nq + 15) / 16, heads, B);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == SP3_BF16)
     hipLaunchKernelGGL(attention_kernel<__bf16>, grid, dim3(64), 0, st, reinterpret_cast<const __bf16*>(q), sq, ldq,
                        reinterpret_cast<const __bf16*>(k), sk, ldk, reinterpret_cast<const __bf16*>(vt), vt_ld, out, ldo,
-                       out_bf16, heads, Nq, Nk, scale);
+                       out_bf16, out_packed, heads, Nq, Nk, scale);
   else
     hipLaunchKernelGGL(attention_kernel<float>, grid, dim3(64), 0, st, reinterpret_cast<const float*>(q), sq, ldq,
                        reinterpret_cast<const float*>(k), sk, ldk, reinterpret_cast<const float*>(vt), vt_ld, out, ldo, out_bf16,
-                       heads, Nq, Nk, scale);
+                       out_packed, heads, Nq, Nk, scale);
   SP3_LAUNCH_CHECK("sp3_attention");
   return 0;
+}
+
+extern "C" int sp3_attention(const void* q, int64_t sq, int64_t ldq, const void* k, int64_t sk, int64_t ldk, const void* vt,
+                             int64_t vt_ld, void* out, int64_t ldo, int out_bf16, int B, int heads, int Nq, int Nk, float scale,
+                             int dtype, void* stream) {
+  return sp3_attention_ex(q, sq, ldq, k, sk, ldk, vt, vt_ld, out, ldo, out_bf16, 0, B, heads, Nq, Nk, scale, dtype, stream);
 }

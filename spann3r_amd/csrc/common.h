@@ -57,3 +57,14 @@ __device__ __forceinline__ float4 relu4(float4 v) {
 __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
+
+// Fragment-order ("packed") operand layout shared by sp3_gemm's a_packed / w_packed and every producer's
+// out_packed option: [ceil(rows/16)][ceil(K/KB)][4 lane groups g][16 rows r][CH], KB/CH = 64/16 (bf16), 32/8 (fp32).
+// Element (row, k) lives at the offset below; 4 consecutive k (k % 4 == 0) stay contiguous.
+__device__ __forceinline__ int64_t packed_off(int row, int k, int K, bool bf16) {
+  const int lkb = bf16 ? 6 : 5, lch = bf16 ? 4 : 3;
+  const int nkb = (K + (1 << lkb) - 1) >> lkb;
+  const int kb = k >> lkb, kk = k & ((1 << lkb) - 1);
+  const int g = kk >> lch, e = kk & ((1 << lch) - 1);
+  return ((((int64_t)(row >> 4) * nkb + kb) * 4 + g) * 16 + (row & 15)) * (1 << lch) + e;
+}

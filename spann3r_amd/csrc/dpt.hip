@@ -9,7 +9,7 @@ namespace {
 // out[(b*nh*nw + py_*nw + px_), c*p*p + iy*p + ix] = img[b, c, py_*p+iy, px_*p+ix]  (generic strides)
 __global__ __launch_bounds__(256) void im2col_patch_kernel(const float* __restrict__ img, int64_t sb, int64_t sc, int64_t sy,
                                                            int64_t sx, int C, int H, int W, int p, void* __restrict__ out,
-                                                           int out_bf16, int64_t total) {
+                                                           int out_bf16, int out_packed, int64_t total) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= total) return;
   const int K = C * p * p;
@@ -22,8 +22,9 @@ __global__ __launch_bounds__(256) void im2col_patch_kernel(const float* __restri
   const int c = k / (p * p), r2 = k - c * p * p;
   const int iy = r2 / p, ix = r2 - iy * p;
   const float val = img[b * sb + c * sc + (int64_t)(ty * p + iy) * sy + (int64_t)(tx * p + ix) * sx];
-  if (out_bf16) reinterpret_cast<__bf16*>(out)[idx] = (__bf16)val;
-  else reinterpret_cast<float*>(out)[idx] = val;
+  const int64_t o = out_packed ? packed_off((int)row, k, K, out_bf16 != 0) : idx;
+  if (out_bf16) reinterpret_cast<__bf16*>(out)[o] = (__bf16)val;
+  else reinterpret_cast<float*>(out)[o] = val;
 }
 
 // F.interpolate(scale_factor=2, bilinear, align_corners=True) on NHWC; optional crop to [outH,outW].
@@ -106,13 +107,13 @@ __global__ __launch_bounds__(256) void head_final_kernel(const float* __restrict
 #define ST(s) reinterpret_cast<hipStream_t>(s)
 
 extern "C" int sp3_im2col_patch(const float* img, int64_t sb, int64_t sc, int64_t sy, int64_t sx, int B, int C, int H, int W,
-                                int p, void* out, int out_bf16, void* stream) {
+                                int p, void* out, int out_bf16, int out_packed, void* stream) {
   SP3_CHECK(img && out && B > 0 && C > 0 && p > 0, "sp3_im2col_patch: bad arguments");
   // same assertion as dust3r/patch_embed.py:22-23
   SP3_CHECK(H % p == 0 && W % p == 0, "Input image size (%d,%d) is not a multiple of patch size (%d)", H, W, p);
   const int64_t total = (int64_t)B * (H / p) * (W / p) * C * p * p;
   hipLaunchKernelGGL(im2col_patch_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ST(stream), img, sb, sc, sy, sx,
-                     C, H, W, p, out, out_bf16, total);
+                     C, H, W, p, out, out_bf16, out_packed, total);
   SP3_LAUNCH_CHECK("sp3_im2col_patch");
   return 0;
 }

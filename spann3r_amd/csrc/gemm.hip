@@ -25,6 +25,7 @@
 //    with fp32 accumulation; bf16-mode activations are either already bf16 (a_bf16) or fp32 converted
 //    on load (v_cvt_pk_bf16_f32).
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -49,13 +50,35 @@ __device__ __forceinline__ bf16x8 relu8(bf16x8 v) {
   return v;
 }
 
+// Loads are UNCONDITIONAL (addresses are clamped by the caller) and invalid halves are zeroed with a bitwise AND:
+// a `cond ? load : 0` select makes hipcc branch around each load and wait vmcnt(0) per element, which serialises
+// the whole operand stream (cdna_hip_programming.md §5 "three .s-level traps" (c)).
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+__device__ __forceinline__ bf16x8 mask8(bf16x8 v, unsigned m) {
+  u32x4 b = __builtin_bit_cast(u32x4, v);
+  b &= m;
+  return __builtin_bit_cast(bf16x8, b);
+}
+__device__ __forceinline__ float4 mask4(float4 v, unsigned m) {
+  v.x = __uint_as_float(__float_as_uint(v.x) & m);
+  v.y = __uint_as_float(__float_as_uint(v.y) & m);
+  v.z = __uint_as_float(__float_as_uint(v.z) & m);
+  v.w = __uint_as_float(__float_as_uint(v.w) & m);
+  return v;
+}
+
 struct WRegB { bf16x8 v[2]; };
-__device__ __forceinline__ void loadW_b(WRegB& r, const __bf16* p, bool v0, bool v1) {
-  const bf16x8* q = reinterpret_cast<const bf16x8*>(p);
-  r.v[0] = q[0];
-  r.v[1] = v1 ? q[1] : q[0];          // never touch bytes past K
-  if (!v0) r.v[0] = zero8();
-  if (!v1) r.v[1] = zero8();
+// off1: element offset of the second half (CH/2 when it is inside K, 0 otherwise).  Masks (0 or ~0) and the
+// optional ReLU are applied by fix*() right before the MFMAs consume the registers, so the only vmcnt wait of a
+// stage sits at its first use.
+__device__ __forceinline__ void loadW_b(WRegB& r, const __bf16* p, int off1) {
+  r.v[0] = *reinterpret_cast<const bf16x8*>(p);
+  r.v[1] = *reinterpret_cast<const bf16x8*>(p + off1);
+}
+__device__ __forceinline__ void fixW_b(WRegB& r, unsigned m0, unsigned m1) {
+  r.v[0] = mask8(r.v[0], m0);
+  r.v[1] = mask8(r.v[1], m1);
 }
 
 template <> struct MM<float, __bf16> {
@@ -63,16 +86,17 @@ template <> struct MM<float, __bf16> {
   static constexpr int CH = 16;   // k elements per lane per block
   struct AReg { float4 v[4]; };
   using WReg = WRegB;
-  static __device__ __forceinline__ void loadA(AReg& r, const float* p, bool v0, bool v1, bool relu) {
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  static __device__ __forceinline__ void loadA(AReg& r, const float* p, int off1) {
     const float4* q = reinterpret_cast<const float4*>(p);
-    const float4* q1 = v1 ? q + 2 : q;
+    const float4* q1 = reinterpret_cast<const float4*>(p + off1);
     r.v[0] = q[0]; r.v[1] = q[1]; r.v[2] = q1[0]; r.v[3] = q1[1];
-    if (!v0) { r.v[0] = z; r.v[1] = z; }
-    if (!v1) { r.v[2] = z; r.v[3] = z; }
+  }
+  static __device__ __forceinline__ void fixA(AReg& r, unsigned m0, unsigned m1, bool relu) {
+    r.v[0] = mask4(r.v[0], m0); r.v[1] = mask4(r.v[1], m0); r.v[2] = mask4(r.v[2], m1); r.v[3] = mask4(r.v[3], m1);
     if (relu) { r.v[0] = relu4(r.v[0]); r.v[1] = relu4(r.v[1]); r.v[2] = relu4(r.v[2]); r.v[3] = relu4(r.v[3]); }
   }
-  static __device__ __forceinline__ void loadW(WReg& r, const __bf16* p, bool v0, bool v1) { loadW_b(r, p, v0, v1); }
+  static __device__ __forceinline__ void loadW(WReg& r, const __bf16* p, int off1) { loadW_b(r, p, off1); }
+  static __device__ __forceinline__ void fixW(WReg& r, unsigned m0, unsigned m1) { fixW_b(r, m0, m1); }
   template <int MF, int NF>
   static __device__ __forceinline__ void mma(f32x4 (&acc)[MF][NF], const AReg (&a)[MF], const WReg (&w)[NF]) {
 #pragma unroll
@@ -93,15 +117,16 @@ template <> struct MM<__bf16, __bf16> {
   static constexpr int CH = 16;
   struct AReg { bf16x8 v[2]; };
   using WReg = WRegB;
-  static __device__ __forceinline__ void loadA(AReg& r, const __bf16* p, bool v0, bool v1, bool relu) {
-    const bf16x8* q = reinterpret_cast<const bf16x8*>(p);
-    r.v[0] = q[0];
-    r.v[1] = v1 ? q[1] : q[0];
-    if (!v0) r.v[0] = zero8();
-    if (!v1) r.v[1] = zero8();
+  static __device__ __forceinline__ void loadA(AReg& r, const __bf16* p, int off1) {
+    r.v[0] = *reinterpret_cast<const bf16x8*>(p);
+    r.v[1] = *reinterpret_cast<const bf16x8*>(p + off1);
+  }
+  static __device__ __forceinline__ void fixA(AReg& r, unsigned m0, unsigned m1, bool relu) {
+    r.v[0] = mask8(r.v[0], m0); r.v[1] = mask8(r.v[1], m1);
     if (relu) { r.v[0] = relu8(r.v[0]); r.v[1] = relu8(r.v[1]); }
   }
-  static __device__ __forceinline__ void loadW(WReg& r, const __bf16* p, bool v0, bool v1) { loadW_b(r, p, v0, v1); }
+  static __device__ __forceinline__ void loadW(WReg& r, const __bf16* p, int off1) { loadW_b(r, p, off1); }
+  static __device__ __forceinline__ void fixW(WReg& r, unsigned m0, unsigned m1) { fixW_b(r, m0, m1); }
   template <int MF, int NF>
   static __device__ __forceinline__ void mma(f32x4 (&acc)[MF][NF], const AReg (&a)[MF], const WReg (&w)[NF]) {
 #pragma unroll
@@ -119,20 +144,20 @@ template <> struct MM<float, float> {
   static constexpr int CH = 8;
   struct AReg { float4 v[2]; };
   struct WReg { float4 v[2]; };
-  static __device__ __forceinline__ void loadA(AReg& r, const float* p, bool v0, bool v1, bool relu) {
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4* q = reinterpret_cast<const float4*>(p);
-    r.v[0] = q[0]; r.v[1] = v1 ? q[1] : q[0];
-    if (!v0) r.v[0] = z;
-    if (!v1) r.v[1] = z;
+  static __device__ __forceinline__ void loadA(AReg& r, const float* p, int off1) {
+    r.v[0] = *reinterpret_cast<const float4*>(p);
+    r.v[1] = *reinterpret_cast<const float4*>(p + off1);
+  }
+  static __device__ __forceinline__ void fixA(AReg& r, unsigned m0, unsigned m1, bool relu) {
+    r.v[0] = mask4(r.v[0], m0); r.v[1] = mask4(r.v[1], m1);
     if (relu) { r.v[0] = relu4(r.v[0]); r.v[1] = relu4(r.v[1]); }
   }
-  static __device__ __forceinline__ void loadW(WReg& r, const float* p, bool v0, bool v1) {
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4* q = reinterpret_cast<const float4*>(p);
-    r.v[0] = q[0]; r.v[1] = v1 ? q[1] : q[0];
-    if (!v0) r.v[0] = z;
-    if (!v1) r.v[1] = z;
+  static __device__ __forceinline__ void loadW(WReg& r, const float* p, int off1) {
+    r.v[0] = *reinterpret_cast<const float4*>(p);
+    r.v[1] = *reinterpret_cast<const float4*>(p + off1);
+  }
+  static __device__ __forceinline__ void fixW(WReg& r, unsigned m0, unsigned m1) {
+    r.v[0] = mask4(r.v[0], m0); r.v[1] = mask4(r.v[1], m1);
   }
   template <int MF, int NF>
   static __device__ __forceinline__ void mma(f32x4 (&acc)[MF][NF], const AReg (&a)[MF], const WReg (&w)[NF]) {
@@ -160,17 +185,30 @@ template <typename TA, int LOADER, int MF> struct ARows;
 template <typename TA, int MF> struct ARows<TA, SP3_LOAD_PLAIN, MF> {
   const TA* base[MF];
   const TA* base2[MF];
-  __device__ __forceinline__ void init(const sp3_gemm_desc& d, const TA* A, int row0, int lane) {
+  // a_packed: A is in MFMA-fragment order [ceil(M/16)][ceil(K/KB)][64 lanes][CH] (written that way by the producing
+  // kernel), so a wave's operand load is one contiguous run; otherwise row-major [M, lda].
+  __device__ __forceinline__ void init(const sp3_gemm_desc& d, const TA* A, int row0, int lane, int KB, int CH) {
 #pragma unroll
     for (int m = 0; m < MF; ++m) {
-      int r = row0 + m * 16 + (lane & 15);
-      r = r < d.M ? r : d.M - 1;
-      base[m] = A + (int64_t)r * d.lda;
-      base2[m] = d.A2 ? reinterpret_cast<const TA*>(d.A2) + (int64_t)r * d.lda2 - d.K1 : base[m];
+      if (d.a_packed) {
+        int mb = (row0 + m * 16) >> 4;
+        const int mb_max = (d.M + 15) / 16 - 1;
+        mb = mb < mb_max ? mb : mb_max;
+        const int nkb = (d.K + KB - 1) / KB;
+        // ptr() adds k = kb*KB + g*CH; fold "- g*CH" here and scale kb*KB -> kb*64*CH through pk_mul
+        base[m] = A + ((int64_t)mb * nkb * 64 + lane) * CH;
+        base2[m] = base[m];
+      } else {
+        int r = row0 + m * 16 + (lane & 15);
+        r = r < d.M ? r : d.M - 1;
+        base[m] = A + (int64_t)r * d.lda;
+        base2[m] = d.A2 ? reinterpret_cast<const TA*>(d.A2) + (int64_t)r * d.lda2 - d.K1 : base[m];
+      }
     }
   }
-  __device__ __forceinline__ const TA* ptr(const sp3_gemm_desc& d, int m, int k, bool& inb) const {
+  __device__ __forceinline__ const TA* ptr(const sp3_gemm_desc& d, int m, int k, int kb, int CH, bool& inb) const {
     inb = true;
+    if (d.a_packed) return base[m] + (int64_t)kb * 64 * CH;
     return (k < d.K1 ? base[m] : base2[m]) + k;
   }
 };
@@ -179,7 +217,7 @@ template <typename TA, int MF> struct ARows<TA, SP3_LOAD_CONV3X3, MF> {
   const TA* img[MF];
   int iy0[MF], ix0[MF];
   const TA* safe;
-  __device__ __forceinline__ void init(const sp3_gemm_desc& d, const TA* A, int row0, int lane) {
+  __device__ __forceinline__ void init(const sp3_gemm_desc& d, const TA* A, int row0, int lane, int, int) {
     safe = A;
 #pragma unroll
     for (int m = 0; m < MF; ++m) {
@@ -195,7 +233,7 @@ template <typename TA, int MF> struct ARows<TA, SP3_LOAD_CONV3X3, MF> {
       ix0[m] = ox * d.conv_stride - 1;
     }
   }
-  __device__ __forceinline__ const TA* ptr(const sp3_gemm_desc& d, int m, int k, bool& inb) const {
+  __device__ __forceinline__ const TA* ptr(const sp3_gemm_desc& d, int m, int k, int, int, bool& inb) const {
     const int tap = k / d.conv_C;
     const int ci = k - tap * d.conv_C;
     const int dy = tap / 3;
@@ -241,13 +279,30 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_kernel(const GemmArgs 
 
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   ARows<TA, LOADER, MF> arows;
-  arows.init(d, A, m0 + wm * MF * 16, lane);
-  const TW* wrow[NF];
+  arows.init(d, A, m0 + wm * MF * 16, lane, M_::KB, M_::CH);
+  // W operand addressing.  Row-major [N, ldw]: lane (g, r) reads row c at k = kb*KB + g*CH (16 rows per load
+  // instruction -> 4 different cache lines per lane quad).  Packed (w_packed, weights re-ordered once at load time into
+  // MFMA-fragment order [N/16][K/KB][lane][CH]): a wave reads 64*CH contiguous elements per fragment -> fully coalesced.
+  const TW* wbase[NF];
+  int64_t wstep;
+  if (d.w_packed) {
+    const int nkb_pad = (d.K + KB - 1) / KB;
+    wstep = 64 * CH;
 #pragma unroll
-  for (int n = 0; n < NF; ++n) {
-    int c = n0 + wn * NF * 16 + n * 16 + (lane & 15);
-    c = c < d.N ? c : d.N - 1;
-    wrow[n] = W + (int64_t)c * d.ldw;
+    for (int n = 0; n < NF; ++n) {
+      int nb = (n0 + wn * NF * 16 + n * 16) >> 4;
+      const int nb_max = (d.N + 15) / 16 - 1;
+      nb = nb < nb_max ? nb : nb_max;
+      wbase[n] = W + ((int64_t)nb * nkb_pad * 64 + lane) * CH;
+    }
+  } else {
+    wstep = KB;
+#pragma unroll
+    for (int n = 0; n < NF; ++n) {
+      int c = n0 + wn * NF * 16 + n * 16 + (lane & 15);
+      c = c < d.N ? c : d.N - 1;
+      wbase[n] = W + (int64_t)c * d.ldw + g * CH;
+    }
   }
 
   f32x4 acc[MF][NF];
@@ -265,35 +320,85 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_kernel(const GemmArgs 
 
   typename M_::AReg a[STAGES][MF];
   typename M_::WReg w[STAGES][NF];
+  // masks of each stage (0 / ~0): K tail per half, and per A row the conv zero-padding; applied at consume time
+  unsigned am0[STAGES][MF], am1[STAGES][MF], wm0[STAGES], wm1[STAGES];
+  constexpr bool CONV = LOADER == SP3_LOAD_CONV3X3;
 
-  auto load = [&](typename M_::AReg (&ar)[MF], typename M_::WReg (&wr)[NF], int kb) {
+  // FULL = the k-block lies entirely inside K.  Loads are never predicated; addresses are clamped instead.
+  auto load = [&](auto full_tag, int st, int kb) {
+    constexpr bool FULL = decltype(full_tag)::value;
     const int k = kb * KB + g * CH;
-    const bool v0 = k < d.K, v1 = (k + CH / 2) < d.K;
-    const int kc = v0 ? k : 0;              // clamp: always a legal address, zeroed by v0/v1
+    const bool v0 = FULL || k < d.K, v1 = FULL || (k + CH / 2) < d.K;
+    const int kc = v0 ? k : 0;
+    const int off1 = v1 ? CH / 2 : 0;
+    wm0[st] = v0 ? 0xffffffffu : 0u;
+    wm1[st] = v1 ? 0xffffffffu : 0u;
 #pragma unroll
     for (int m = 0; m < MF; ++m) {
       bool inb;
-      const TA* p = arows.ptr(d, m, kc, inb);
-      M_::loadA(ar[m], p, v0 && inb, v1 && inb, relu);
+      const TA* p = arows.ptr(d, m, kc, kb, CH, inb);
+      const unsigned im = inb ? 0xffffffffu : 0u;
+      am0[st][m] = wm0[st] & im;
+      am1[st][m] = wm1[st] & im;
+      M_::loadA(a[st][m], p, d.a_packed ? CH / 2 : off1);
     }
+    // row-major W: same clamp as A (kc - g*CH is the k-block base); packed W is zero-padded to whole k-blocks
+    const int64_t woff = d.w_packed ? (int64_t)kb * wstep : (int64_t)(kc - g * CH);
+    const int woff1 = d.w_packed ? CH / 2 : off1;
 #pragma unroll
-    for (int n = 0; n < NF; ++n) M_::loadW(wr[n], wrow[n] + kc, v0, v1);
+    for (int n = 0; n < NF; ++n) M_::loadW(w[st][n], wbase[n] + woff, woff1);
   };
+  auto consume = [&](auto full_tag, int st) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    if (!FULL || CONV) {
+#pragma unroll
+      for (int m = 0; m < MF; ++m) M_::fixA(a[st][m], am0[st][m], am1[st][m], relu);
+    }
+    if (!FULL) {
+#pragma unroll
+      for (int n = 0; n < NF; ++n) M_::fixW(w[st][n], wm0[st], wm1[st]);
+    }
+    M_::template mma<MF, NF>(acc, a[st], w[st]);
+  };
+  using FullT = std::integral_constant<bool, true>;
+  using TailT = std::integral_constant<bool, false>;
 
-  // STAGES-deep register ring: (STAGES-1) k-blocks of loads in flight per wave
+  // STAGES-deep register ring: (STAGES-1) k-blocks of loads in flight per wave.
+  // prologue (uniform branches), branch-free steady state over full k-blocks, masked drain.
   {
-    const int kb0 = kb_lo + wk;
+    const int kb_full = d.K / KB;                       // k-blocks [0, kb_full) are complete
+    const int kb_hi_full = kb_hi < kb_full ? kb_hi : kb_full;
+    int kb = kb_lo + wk;
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
-      if (kb0 + s * WK < kb_hi) load(a[s], w[s], kb0 + s * WK);
-    for (int kb = kb0; kb < kb_hi; kb += STAGES * WK) {
+      if (kb + s * WK < kb_hi) load(TailT{}, s, kb + s * WK);
+    if (kb + (2 * STAGES - 2) * WK < kb_hi_full) {
+      // the prologue stages are full blocks here, but were loaded through the masked path: consume them masked once
+      do {
+#pragma unroll
+        for (int s = 0; s < STAGES; ++s) {
+          load(FullT{}, (s + STAGES - 1) % STAGES, kb + (s + STAGES - 1) * WK);
+          consume(TailT{}, s);
+        }
+        kb += STAGES * WK;
+      } while (false);
+      while (kb + (2 * STAGES - 2) * WK < kb_hi_full) {
+#pragma unroll
+        for (int s = 0; s < STAGES; ++s) {
+          load(FullT{}, (s + STAGES - 1) % STAGES, kb + (s + STAGES - 1) * WK);
+          consume(FullT{}, s);
+        }
+        kb += STAGES * WK;
+      }
+    }
+    for (; kb < kb_hi; kb += STAGES * WK) {
 #pragma unroll
       for (int s = 0; s < STAGES; ++s) {
         const int kcur = kb + s * WK;
         if (kcur < kb_hi) {
           const int knext = kcur + (STAGES - 1) * WK;
-          if (knext < kb_hi) load(a[(s + STAGES - 1) % STAGES], w[(s + STAGES - 1) % STAGES], knext);
-          M_::template mma<MF, NF>(acc, a[s], w[s]);
+          if (knext < kb_hi) load(TailT{}, (s + STAGES - 1) % STAGES, knext);
+          consume(TailT{}, s);
         }
       }
     }
@@ -402,6 +507,8 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_kernel(const GemmArgs 
       const int b = gm / pp, rem = gm - b * pp;
       const int y = rem / d.ps_W, x = rem - y * d.ps_W;
       off = (((int64_t)b * d.ps_H * d.ps_k + y * d.ps_k + ky) * ((int64_t)d.ps_W * d.ps_k) + x * d.ps_k + kx) * d.ps_C + co;
+    } else if (d.out_packed) {
+      off = packed_off(gm, gn, d.N, d.out_bf16 != 0);      // C is the next GEMM's A operand, fragment order
     } else {
       off = (int64_t)bz * d.strideC + (int64_t)gm * d.ldc + gn;
     }
@@ -488,14 +595,20 @@ extern "C" int sp3_gemm(const sp3_gemm_desc* dp, void* stream_) {
   if (d.batch <= 0) d.batch = 1;
   if (d.splitk <= 0) d.splitk = 1;
   if (d.ldw <= 0) d.ldw = d.K;
+  SP3_CHECK(!d.w_packed || d.batch == 1, "sp3_gemm: packed weights are unbatched");
+  SP3_CHECK(!d.out_packed || (d.epi == SP3_EPI_PLAIN && d.batch == 1 && d.N % 4 == 0), "sp3_gemm: out_packed needs the plain epilogue, batch 1, N %% 4 == 0");
+  SP3_CHECK(!d.a_packed || (d.loader == SP3_LOAD_PLAIN && !d.A2 && d.batch == 1), "sp3_gemm: packed A is plain / unbatched / unsplit");
+  SP3_CHECK(!d.a_packed || ((d.a_bf16 != 0) == (d.wdtype == SP3_BF16)), "sp3_gemm: packed A must have the MFMA dtype (its fragment geometry)");
   if (!d.A2) d.K1 = d.K;
   const int aalign = d.a_bf16 ? 8 : 4;    // elements per 16 bytes
   SP3_CHECK(d.ldw >= d.K && d.ldw % 8 == 0, "sp3_gemm: ldw=%lld must be >= K and a multiple of 8", (long long)d.ldw);
   SP3_CHECK(!d.A2 || (d.loader == SP3_LOAD_PLAIN && d.K1 % 64 == 0 && d.K1 > 0 && d.K1 < d.K && d.lda2 % aalign == 0 && d.batch == 1),
             "sp3_gemm: bad split-A configuration (K1=%d)", d.K1);
   SP3_CHECK(d.splitk == 1 || d.epi == SP3_EPI_PARTIAL, "sp3_gemm: splitk > 1 needs the PARTIAL epilogue");
-  if (d.loader == SP3_LOAD_PLAIN) {
+  if (d.loader == SP3_LOAD_PLAIN && !d.a_packed) {
     SP3_CHECK(d.lda % aalign == 0 && d.lda >= d.K1, "sp3_gemm: lda=%lld must be >= K and keep 16-byte rows", (long long)d.lda);
+  } else if (d.loader == SP3_LOAD_PLAIN) {
+    /* packed A: geometry is implied by M, K */
   } else if (d.loader == SP3_LOAD_CONV3X3) {
     SP3_CHECK(d.conv_C % 16 == 0, "sp3_gemm: conv Cin=%d must be a multiple of 16", d.conv_C);
     SP3_CHECK(d.K == 9 * d.conv_C, "sp3_gemm: conv K=%d != 9*Cin", d.K);
@@ -527,7 +640,10 @@ extern "C" int sp3_gemm(const sp3_gemm_desc* dp, void* stream_) {
       else if (t64 >= 512) tile = 1;
       else tile = 0;
     } else {
-      tile = (t64 >= 128) ? 3 : 0;      // weight-streaming shapes: biggest tile that still fills the CUs
+      // weight-streaming shapes (M ~ 196): measured on MI355X (tools/bench_gemm.py, packed operands) the 32x32 tile
+      // with K split over the 4 waves wins on every hot-path shape: ~3 us fixed cost vs ~5 us for the 64x64 tile
+      tile = 0;
+      (void)t64;
     }
   }
   if (d.wdtype == SP3_BF16) {

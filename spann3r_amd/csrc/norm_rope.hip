@@ -51,7 +51,7 @@ __device__ __forceinline__ void ln_row(const float* __restrict__ xr, int C, cons
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t ldx,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         float eps, void* __restrict__ out, int64_t ldo, int out_bf16,
-                                                        int rows, int C) {
+                                                        int out_packed, int rows, int C) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -63,12 +63,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   for (int i = 0; i < LN_MAX_V4; ++i) {
     const int j = lane + i * 64;
     if (j < c4) {
+      const int64_t off = out_packed ? packed_off(row, 4 * j, C, out_bf16 != 0) : (int64_t)row * ldo + 4 * j;
       if (out_bf16) {
         bf16x4 o;
         o[0] = (__bf16)v[i].x; o[1] = (__bf16)v[i].y; o[2] = (__bf16)v[i].z; o[3] = (__bf16)v[i].w;
-        reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(out) + (int64_t)row * ldo)[j] = o;
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(out) + off) = o;
       } else {
-        reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (int64_t)row * ldo)[j] = v[i];
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + off) = v[i];
       }
     }
   }
@@ -121,13 +122,15 @@ __global__ __launch_bounds__(256) void layernorm_t_kernel(const float* __restric
 // (they share mean / rstd).  Same two-pass fp32 statistics as layernorm_kernel.
 struct ReduceLnArgs { sp3_reduce_ln_desc d; };
 
-__device__ __forceinline__ void store_row4(void* out, int64_t ld, int bf, int row, int j, float4 v) {
+// store 4 consecutive columns (4j .. 4j+3) of `row`; packed != 0 -> fragment order of a [rows, C] GEMM operand
+__device__ __forceinline__ void store_row4(void* out, int64_t ld, int bf, int packed, int C, int row, int j, float4 v) {
+  const int64_t off = packed ? packed_off(row, 4 * j, C, bf != 0) : (int64_t)row * ld + 4 * j;
   if (bf) {
     bf16x4 o;
     o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
-    reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(out) + (int64_t)row * ld)[j] = o;
+    *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(out) + off) = o;
   } else {
-    reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + (int64_t)row * ld)[j] = v;
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + off) = v;
   }
 }
 
@@ -181,11 +184,11 @@ __global__ __launch_bounds__(256) void reduce_ln_kernel(const ReduceLnArgs args)
       n.x = (v[i].x - mean) * rstd; n.y = (v[i].y - mean) * rstd; n.z = (v[i].z - mean) * rstd; n.w = (v[i].w - mean) * rstd;
       if (d.out1) {
         const float4 gm = reinterpret_cast<const float4*>(d.g1)[j], bt = reinterpret_cast<const float4*>(d.b1)[j];
-        store_row4(d.out1, d.ld1, d.out1_bf16, row, j, make_float4(n.x * gm.x + bt.x, n.y * gm.y + bt.y, n.z * gm.z + bt.z, n.w * gm.w + bt.w));
+        store_row4(d.out1, d.ld1, d.out1_bf16, d.out1_packed, C, row, j, make_float4(n.x * gm.x + bt.x, n.y * gm.y + bt.y, n.z * gm.z + bt.z, n.w * gm.w + bt.w));
       }
       if (d.out2) {
         const float4 gm = reinterpret_cast<const float4*>(d.g2)[j], bt = reinterpret_cast<const float4*>(d.b2)[j];
-        store_row4(d.out2, d.ld2, d.out2_bf16, row, j, make_float4(n.x * gm.x + bt.x, n.y * gm.y + bt.y, n.z * gm.z + bt.z, n.w * gm.w + bt.w));
+        store_row4(d.out2, d.ld2, d.out2_bf16, d.out2_packed, C, row, j, make_float4(n.x * gm.x + bt.x, n.y * gm.y + bt.y, n.z * gm.z + bt.z, n.w * gm.w + bt.w));
       }
     }
   }
@@ -234,8 +237,17 @@ extern "C" int sp3_layernorm(const float* x, int64_t ldx, const float* gamma, co
   if (ln_check(x, ldx, gamma, beta, out, rows, C)) return 1;
   SP3_CHECK(ldo % 4 == 0, "sp3_layernorm: ldo must be a multiple of 4");
   hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, ldx,
-                     gamma, beta, eps, out, ldo, out_bf16, rows, C);
+                     gamma, beta, eps, out, ldo, out_bf16, 0, rows, C);
   SP3_LAUNCH_CHECK("sp3_layernorm");
+  return 0;
+}
+
+extern "C" int sp3_layernorm_packed(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, void* out,
+                                    int out_bf16, int rows, int C, void* stream) {
+  if (ln_check(x, ldx, gamma, beta, out, rows, C)) return 1;
+  hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, ldx,
+                     gamma, beta, eps, out, (int64_t)0, out_bf16, 1, rows, C);
+  SP3_LAUNCH_CHECK("sp3_layernorm_packed");
   return 0;
 }
 
@@ -243,8 +255,8 @@ extern "C" int sp3_reduce_ln(const sp3_reduce_ln_desc* dp, void* stream) {
   SP3_CHECK(dp && dp->partial, "sp3_reduce_ln: null descriptor / partial");
   const sp3_reduce_ln_desc& d = *dp;
   SP3_CHECK(d.rows > 0 && d.C > 0 && d.C % 4 == 0 && d.C <= 64 * 4 * LN_MAX_V4 && d.splits >= 1, "sp3_reduce_ln: bad rows=%d C=%d splits=%d", d.rows, d.C, d.splits);
-  SP3_CHECK(!d.out1 || (d.g1 && d.b1 && d.ld1 % 4 == 0), "sp3_reduce_ln: LayerNorm 1 needs gamma/beta");
-  SP3_CHECK(!d.out2 || (d.g2 && d.b2 && d.ld2 % 4 == 0), "sp3_reduce_ln: LayerNorm 2 needs gamma/beta");
+  SP3_CHECK(!d.out1 || (d.g1 && d.b1 && (d.out1_packed || d.ld1 % 4 == 0)), "sp3_reduce_ln: LayerNorm 1 needs gamma/beta");
+  SP3_CHECK(!d.out2 || (d.g2 && d.b2 && (d.out2_packed || d.ld2 % 4 == 0)), "sp3_reduce_ln: LayerNorm 2 needs gamma/beta");
   SP3_CHECK(!d.res || d.ldres % 4 == 0, "sp3_reduce_ln: ldres must be a multiple of 4");
   SP3_CHECK(!d.x_out || d.ldx % 4 == 0, "sp3_reduce_ln: ldx must be a multiple of 4");
   ReduceLnArgs a;

@@ -47,17 +47,17 @@ class Engine:
         cfg, dev, wdt = self.cfg, self.device, self.wdt
         w = self.w
 
-        def mat(t):      # MFMA operand: [N, K] in the compute dtype
-            return t.detach().to(dev, torch.float32).reshape(t.shape[0], -1).to(wdt).contiguous()
+        def mat(t):      # MFMA operand: [N, K] in the compute dtype, re-ordered once into fragment order
+            return ops.PackedWeight(t.detach().to(dev, torch.float32).reshape(t.shape[0], -1).to(wdt).contiguous())
 
         def vec(t):      # biases / LN parameters stay fp32
             return t.detach().to(dev, torch.float32).contiguous()
 
         def conv3(t):    # [Cout,Cin,3,3] -> [Cout, (ky,kx,ci)]
-            return t.detach().to(dev, torch.float32).permute(0, 2, 3, 1).reshape(t.shape[0], -1).to(wdt).contiguous()
+            return ops.PackedWeight(t.detach().to(dev, torch.float32).permute(0, 2, 3, 1).reshape(t.shape[0], -1).to(wdt).contiguous())
 
         def convt(t):    # ConvTranspose2d [Cin,Cout,k,k] -> [(ky,kx,co), ci]
-            return t.detach().to(dev, torch.float32).permute(2, 3, 1, 0).reshape(-1, t.shape[0]).to(wdt).contiguous()
+            return ops.PackedWeight(t.detach().to(dev, torch.float32).permute(2, 3, 1, 0).reshape(-1, t.shape[0]).to(wdt).contiguous())
 
         def block(dst, src):
             for n in ("norm1", "norm2"):
@@ -115,7 +115,16 @@ class Engine:
             w[d_ + "h4.b"] = vec(p[s + "head.4.bias"])
 
     def weight_bytes(self):
-        return sum(t.numel() * t.element_size() for t in self.w.values())
+        return sum((t.data if isinstance(t, ops.PackedWeight) else t).numel() * t.element_size() for t in self.w.values())
+
+    def wsp(self, name, rows, K):
+        """fragment-order activation buffer [rows, K] in the activation dtype (GEMM a_packed operand)"""
+        key = ("packed", name, rows, K, self.adt)
+        t = self._ws.get(key)
+        if t is None:
+            t = ops.PackedAct(rows, K, self.adt, self.device)
+            self._ws[key] = t
+        return t
 
     # ------------------------------------------------------------------ workspace
     def ws(self, name, shape, dtype=torch.float32, zero=False):
@@ -175,13 +184,13 @@ class Engine:
         """Pre-LN ViT block on the fp32 stream x (croco/models/blocks.py:127-130).  `ln_in` = norm1(x) (computed by the
         producer of x); the block's last kernel also emits next_out = LayerNorm(x_new; next_norm)."""
         w = self.w
-        ao = self.ws("attn_out", (R, C), self.adt)
+        ao = self.wsp("attn_out", R, C)
         self._attn_core(ln_in, R, B, P, C, heads, pre, pos32, ao)
-        ln2 = self.ws("ln_b", (R, C), self.adt)
+        ln2 = self.wsp("ln_b", R, C)
         self._linear_reduce(ao, w[pre + "proj.w"], w[pre + "proj.b"], R, C, C, C, res=x, x_out=x,
                             ln1=self._norm(pre + "norm2"), out1=ln2)
         Hd = C * self.cfg.mlp_ratio
-        h = self.ws("mlp_hidden", (R, Hd), self.adt)
+        h = self.wsp("mlp_hidden", R, Hd)
         ops.gemm(ln2, w[pre + "fc1.w"], h, M=R, N=Hd, K=C, lda=C, ldc=Hd, bias=w[pre + "fc1.b"], act=ACT_GELU)
         self._linear_reduce(h, w[pre + "fc2.w"], w[pre + "fc2.b"], R, C, Hd, Hd, res=x, x_out=x if keep_x else None,
                             ln1=self._norm(next_norm), out1=next_out)
@@ -191,9 +200,9 @@ class Engine:
         """patch-embed GEMM + `depth` blocks + final norm; every LayerNorm rides on the producing kernel."""
         cfg, w = self.cfg, self.w
         E = cfg.enc_dim
-        K0 = col.shape[1]
+        K0 = col.K
         x = self.ws("vit_x", (R, E))
-        lnA = self.ws("ln_a", (R, E), self.adt)
+        lnA = self.wsp("ln_a", R, E)
         first = (prefix + "0.norm1") if depth > 0 else final_norm
         self._linear_reduce(col, w[patch_w + ".w"], w[patch_w + ".b"], R, E, K0, K0, x_out=x, ln1=self._norm(first),
                             out1=lnA if depth > 0 else final_out)
@@ -215,7 +224,7 @@ class Engine:
         P, E = nh * nw, cfg.enc_dim
         R = B * P
         pos64, pos32, _ = self.positions(B, nh, nw)
-        col = self.ws("im2col", (R, 3 * p * p), self.adt)
+        col = self.wsp("im2col", R, 3 * p * p)
         ops.im2col_patch(img, col, B=B, C_=3, H=H, W_=W_, p=p, strides=img.stride())
         if out is None:
             out = torch.empty(B, P, E, device=self.device)
@@ -235,8 +244,8 @@ class Engine:
         outs = {1: [f1], 2: [f2]}
         depth = cfg.dec_depth
         # per side, double-buffered by layer parity: ln1 = norm1(own previous layer), yn = norm_y(OTHER side's previous layer)
-        ln1 = {s: [self.ws("dec_ln1_%d_%d" % (s, j), (Rs[s], D), self.adt) for j in (0, 1)] for s in (1, 2)}
-        yn = {s: [self.ws("dec_yn_%d_%d" % (s, j), (Rs[3 - s], D), self.adt) for j in (0, 1)] for s in (1, 2)}
+        ln1 = {s: [self.wsp("dec_ln1_%d_%d" % (s, j), Rs[s], D) for j in (0, 1)] for s in (1, 2)}
+        yn = {s: [self.wsp("dec_yn_%d_%d" % (s, j), Rs[3 - s], D) for j in (0, 1)] for s in (1, 2)}
         prev = {}
         for s in (1, 2):
             o = 3 - s
@@ -255,9 +264,9 @@ class Engine:
                 R, P, Ro, Po = Rs[s], Ps[s], Rs[o], Ps[o]
                 x = self.ws("dec%d_l%d" % (s, i + 1), (R, D))
                 # self attention (croco/models/blocks.py:187)
-                ao = self.ws("attn_out_dec", (Rmax, D), self.adt)
+                ao = self.wsp("attn_out_dec_%d" % R, R, D)
                 self._attn_core(ln1[s][cur], R, B, P, D, Hh, pre, pos[s], ao)
-                ln2 = self.ws("dec_ln_b", (Rmax, D), self.adt)
+                ln2 = self.wsp("dec_ln_b_%d" % R, R, D)
                 self._linear_reduce(ao, w[pre + "proj.w"], w[pre + "proj.b"], R, D, D, D, res=prev[s], x_out=x,
                                     ln1=self._norm(pre + "norm2"), out1=ln2)
                 # cross attention to the other side's previous-layer tokens through norm_y (:188-189)
@@ -270,12 +279,12 @@ class Engine:
                 ops.proj_rope_vt(ln2, w[pre + "cq.w"], w[pre + "cq.b"], qbuf, D, None, 0, M=R, N=D, K=D, lda=D,
                                  rope_cols=D, pos=pos[s], cos=self.cos, sin=self.sin, tokens=P, heads=Hh)
                 ops.attention(qbuf, P * D, D, kbuf, Po * D, D, vt, vt_ld, ao, D, B=B, heads=Hh, Nq=P, Nk=Po, scale=64 ** -0.5)
-                ln3 = self.ws("dec_ln_c", (Rmax, D), self.adt)
+                ln3 = self.wsp("dec_ln_c_%d" % R, R, D)
                 self._linear_reduce(ao, w[pre + "cproj.w"], w[pre + "cproj.b"], R, D, D, D, res=x, x_out=x,
                                     ln1=self._norm(pre + "norm3"), out1=ln3)
                 # MLP (:190); its finishing kernel emits the next layer's norm1 (own side) and norm_y (other side)
                 Hd = D * cfg.mlp_ratio
-                h = self.ws("mlp_hidden_dec", (Rmax, Hd), self.adt)
+                h = self.wsp("mlp_hidden_dec_%d" % R, R, Hd)
                 ops.gemm(ln3, w[pre + "fc1.w"], h, M=R, N=Hd, K=D, lda=D, ldc=Hd, bias=w[pre + "fc1.b"], act=ACT_GELU)
                 if last:
                     normed = self.ws("dec%d_normed" % s, (R, D))
@@ -297,7 +306,7 @@ class Engine:
         the concatenation is never materialised (split-A GEMM)."""
         cfg, w = self.cfg, self.w
         E, D, Kd = cfg.enc_dim, cfg.dec_dim, cfg.key_dim
-        h = self.ws("key_hidden", (R, Kd), self.adt)
+        h = self.wsp("key_hidden", R, Kd)
         pre = "key%d." % num
         ops.gemm(feat, w[pre + "0.w"], h, M=R, N=Kd, K=Kd, lda=E, ldc=Kd, bias=w[pre + "0.b"], act=ACT_GELU,
                  A2=dec_last, lda2=D, K1=E)
@@ -394,11 +403,11 @@ class Engine:
         P = nh * nw
         R = B * P
         _, _, zero_pos = self.positions(B, nh, nw)
-        col = self.ws("im2col", (R, 3 * p * p), self.adt)
+        col = self.wsp("im2col", R, 3 * p * p)
         sb, sy, sx, sc = pts3d.stride()
         ops.im2col_patch(pts3d, col, B=B, C_=3, H=H, W_=W_, p=p, strides=(sb, sc, sy, sx))
         # rope=None in the reference (mem_pos_enc=False): all-zero positions make the fused RoPE the identity
-        vn = self.ws("val_normed", (R, E), self.adt)
+        vn = self.wsp("val_normed", R, E)
         self._vit(col, R, B, P, "pospatch", "val", cfg.val_depth, zero_pos, "value_norm", vn)
         self._linear_reduce(vn, w["value_out.w"], w["value_out.b"], R, E, E, E, res=res, x_out=out)
         return out

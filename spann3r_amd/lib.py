@@ -35,7 +35,7 @@ class GemmDesc(C.Structure):
         ("rope_cols", C.c_int32), ("vt", C.c_void_p), ("tokens", C.c_int32), ("heads", C.c_int32),
         ("vt_ld", C.c_int64),
         ("ps_k", C.c_int32), ("ps_H", C.c_int32), ("ps_W", C.c_int32), ("ps_C", C.c_int32),
-        ("tile", C.c_int32), ("a_bf16", C.c_int32), ("splitk", C.c_int32),
+        ("tile", C.c_int32), ("a_bf16", C.c_int32), ("splitk", C.c_int32), ("a_packed", C.c_int32), ("out_packed", C.c_int32), ("w_packed", C.c_int32),
     ]
 
 
@@ -46,6 +46,7 @@ class ReduceLnDesc(C.Structure):
         ("g1", C.c_void_p), ("b1", C.c_void_p), ("out1", C.c_void_p), ("ld1", C.c_int64), ("out1_bf16", C.c_int32),
         ("g2", C.c_void_p), ("b2", C.c_void_p), ("out2", C.c_void_p), ("ld2", C.c_int64), ("out2_bf16", C.c_int32),
         ("eps", C.c_float), ("splits", C.c_int32), ("rows", C.c_int32), ("C", C.c_int32),
+        ("out1_packed", C.c_int32), ("out2_packed", C.c_int32),
     ]
 
 
@@ -56,6 +57,11 @@ _PROTOS = {
     "sp3_layernorm": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_int,
                       C.c_int, C.c_int, C.c_void_p],
     "sp3_reduce_ln": [C.POINTER(ReduceLnDesc), C.c_void_p],
+    "sp3_layernorm_packed": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int,
+                             C.c_int, C.c_int, C.c_void_p],
+    "sp3_attention_ex": [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
+                         C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
+                         C.c_void_p],
     "sp3_layernorm_t": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_int,
                         C.c_int, C.c_int, C.c_void_p],
     "sp3_rope_2d": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64,
@@ -73,7 +79,7 @@ _PROTOS = {
                         C.c_int, C.c_void_p],
     "sp3_gather_1d": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p],
     "sp3_im2col_patch": [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
-                         C.c_int, C.c_void_p, C.c_int, C.c_void_p],
+                         C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p],
     "sp3_upsample2x": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "sp3_head_final": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                        C.c_void_p],

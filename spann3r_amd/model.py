@@ -80,6 +80,19 @@ class SpatialMemory:
     def bank(self):
         return self._banks[self._cur]
 
+    def reset(self):
+        """Start a new sequence on the same arena (stale rows are never read: every read is bounded by M)."""
+        self._cur, self.M, self.wm, self.lm, self.events = 0, 0, 0, 0, []
+
+    def snapshot(self):
+        """Detached copy of the reference-visible state (what `return_memory=True` hands out)."""
+        snap = MemorySnapshot()
+        for name in ("mem_k", "mem_v", "mem_attn", "mem_count"):
+            t = getattr(self, name)
+            setattr(snap, name, None if t is None else t.clone())
+        snap.wm, snap.lm, snap.M, snap.num_patches, snap.events = self.wm, self.lm, self.M, self.P, list(self.events)
+        return snap
+
     # reference-compatible views (what return_memory=True exposes)
     @property
     def mem_k(self):
@@ -105,7 +118,7 @@ class SpatialMemory:
         assert M > 0
         Mpad = (M + 7) // 8 * 8
         ld = (self.cap + 7) // 8 * 8
-        qn = eng.ws("mem_qn", (B * P, C), eng.adt)
+        qn = eng.ws("mem_qn", (B * P, C), eng.adt)      # row-major: the S GEMM is batched over sequences
         ops.layernorm(feat, w["norm_q.w"], w["norm_q.b"], 1e-5, qn, rows=B * P, C_=C)
         S = eng.ws("mem_S", (B, P, ld))
         Pm = eng.ws("mem_P", (B, P, ld))
@@ -151,18 +164,28 @@ class SpatialMemory:
             ops.cos_sim(feat_k[b], self.bank["k_raw"][b, self.M - n:self.M], self.wm, P, C, self._score[b])
         return self._score[:, :self.wm]
 
-    def check_sim(self, feat_k):
+    def sim_needed(self):
         if self.M == 0 or self.sim_thresh == 1.0 or self.wm == 0:
             return False
         if self.wm * self.P > self.M:
             # the reference reshapes mem_k[:, -wm*P:] and raises here (SURVEY.md §7 quirk ii, 512x512 after a prune)
             raise RuntimeError("working memory (%d tokens) larger than the bank (%d): reference check_sim is undefined"
                                % (self.wm * self.P, self.M))
-        mx = max(self.sim_scores(feat_k).cpu().reshape(-1).tolist())      # host sync, as in the reference (:114)
+        return True
+
+    def sim_verdict(self):
+        """Host side of check_sim: reads the scores the cos_sim kernel left in self._score (host sync, as :114)."""
+        mx = max(self._score[:, :self.wm].cpu().reshape(-1).tolist())
         if mx > self.sim_thresh:
             print("Similarity detected:", mx)
             return True
         return False
+
+    def check_sim(self, feat_k):
+        if not self.sim_needed():
+            return False
+        self.sim_scores(feat_k)
+        return self.sim_verdict()
 
     def add_mem_check(self, feat_k, feat_v):
         """Eval-mode write policy (:120-143)."""
@@ -170,6 +193,18 @@ class SpatialMemory:
             self.events.append("skip")
             return
         self.add_mem(feat_k, feat_v)
+        self._after_write()
+
+    def finish_staged(self, similar):
+        """Second half of add_mem_check when the similarity kernel and the speculative write were already launched
+        (hipGraph path): commit or drop the staged frame, then the working/long-term bookkeeping and prune."""
+        if similar:
+            self.events.append("skip")
+            return
+        self.commit()
+        self._after_write()
+
+    def _after_write(self):
         self.wm += 1
         if self.wm > self.work_mem_size:
             self.wm -= 1
@@ -203,6 +238,108 @@ class SpatialMemory:
         self.events.append("prune %d->%d" % (M, k))
         self._cur = 1 - self._cur
         self.M = k
+
+
+class MemorySnapshot:
+    """What forward(..., return_memory=True) returns: the reference SpatialMemory's visible fields."""
+    mem_k = mem_v = mem_attn = mem_count = None
+    wm = lm = M = 0
+
+
+class _SequenceRunner:
+    """Static-buffer, hipGraph-captured execution of Spann3R.forward for one (batch, H, W, policy) geometry.
+
+    Every per-frame step is a fixed kernel sequence over persistent buffers; the only things that vary between steps
+    of a sequence are the memory fill M, the working-memory count wm and the active bank, so graphs are cached by
+    (M, wm, bank).  A key runs eagerly the first time it is seen (that run also creates every workspace buffer), is
+    captured + replayed the second time, and replayed afterwards.  The host only touches the device between steps to
+    read the similarity score (the reference's own host sync, spann3r/model.py:114) and to clone the outputs.
+    """
+
+    def __init__(self, model, eng, B, H, W, training):
+        cfg = model.cfg
+        self.model, self.eng, self.B, self.H, self.W, self.training = model, eng, B, H, W, training
+        p = cfg.patch
+        self.nh, self.nw = H // p, W // p
+        self.P, self.E = self.nh * self.nw, cfg.enc_dim
+        dev = eng.device
+        self.img_pair = torch.empty(2 * B, 3, H, W, device=dev)
+        self.featpair = torch.empty(2 * B, self.P, self.E, device=dev)
+        self.feat1, self.feat2 = self.featpair[:B], self.featpair[B:]
+        self.fuse = torch.empty(B, self.P, self.E, device=dev)
+        self.k1 = torch.empty(B, self.P, self.E, device=dev)
+        self.k2 = torch.empty(B, self.P, self.E, device=dev)
+        self.v = torch.empty(B, self.P, self.E, device=dev)
+        self.mem = None
+        self.graphs = {}
+        self.seen = set()
+        self.out = None
+
+    def ensure_memory(self, n_frames):
+        need = (n_frames - 1) * self.P if self.training else 4000 + 8 * self.P
+        if self.mem is None or self.mem.cap < need:
+            self.mem = SpatialMemory(self.eng, self.B, self.P, capacity=need, attn_thresh=0.0 if self.training else 5e-4)
+            self.graphs.clear()
+            self.seen.clear()
+        self.mem.reset()
+        return self.mem
+
+    # ---- the kernel sequences (spann3r/model.py:485-531) ----------------------------------------------------
+    def _tail(self, f1):
+        eng, mem, B, P = self.eng, self.mem, self.B, self.P
+        dec1, dec2 = eng.decoder(f1, self.feat2, B, self.nh, self.nw, self.nh, self.nw)
+        eng.encode_feat_key(self.feat1, dec1[-1], B * P, 1, self.k1)
+        eng.encode_feat_key(self.feat2, dec2[-1], B * P, 2, self.k2)
+        pts1, conf1, _ = eng.dpt_head(dec1, B, self.nh, self.nw, 1)
+        pts2, conf2, _ = eng.dpt_head(dec2, B, self.nh, self.nw, 2)
+        # portrait results are handed on axis-swapped (landscape_only wrapper), and the value encoder sees that view
+        eng.encode_cur_value(pts1.swapaxes(1, 2) if self.H > self.W else pts1, self.v, self.k1)   # v = cur_v + feat_k1
+        if not self.training and mem.sim_needed():
+            mem.sim_scores(self.k1)
+        mem.stage_write(self.k1, self.v)
+        self.out = (pts1, conf1, pts2, conf2)
+
+    def _first(self):
+        self.eng.encode_image(self.img_pair, out=self.featpair)
+        self._tail(self.feat1)
+
+    def _step(self):
+        eng, B, P, E = self.eng, self.B, self.P, self.E
+        ops.copy2d(self.feat2, E, self.feat1, E, B * P, E)      # feat1 <- previous feat2 (:294)
+        eng.encode_image(self.img_pair[B:], out=self.feat2)
+        self.mem.memory_read(self.k2, self.fuse)                # reads k2 before _tail overwrites it
+        self._tail(self.fuse)
+
+    def run(self, first, use_graphs):
+        mem = self.mem
+        key = ("first" if first else "step", mem.M, mem.wm, mem._cur)
+        fn = self._first if first else self._step
+        if not use_graphs:
+            fn()
+        elif key in self.graphs:
+            self.graphs[key].replay()
+        elif key in self.seen:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                fn()
+            self.graphs[key] = g
+            g.replay()
+        else:
+            self.seen.add(key)
+            fn()
+        pts1, conf1, pts2, conf2 = self.out
+        res1 = {"pts3d": pts1.clone(), "conf": conf1.clone()}
+        res2 = {"pts3d": pts2.clone(), "conf": conf2.clone()}
+        if self.H > self.W:                                     # landscape_only wrapper (dust3r/utils/misc.py:79-80)
+            res1 = {k: v.swapaxes(1, 2) for k, v in res1.items()}
+            res2 = {k: v.swapaxes(1, 2) for k, v in res2.items()}
+        # memory policy (:518-521): the frame was staged inside the step; commit or drop it here
+        if self.training:
+            mem.commit()
+        else:
+            mem.finish_staged(mem.sim_verdict() if mem.sim_needed() else False)
+        return res1, res2
 
 
 class Spann3R(nn.Module):
@@ -253,6 +390,8 @@ class Spann3R(nn.Module):
         self._engine = None
         self._engine_key = None
         self._pinned = None
+        self._runners = {}
+        self.use_graphs = True       # capture each per-frame step in a hipGraph (False: same kernels, eager launches)
 
     # ------------------------------------------------------------------ engine management
     def set_precision(self, precision):
@@ -275,6 +414,7 @@ class Spann3R(nn.Module):
         if self._engine is None or self._engine_key != key:
             self._engine = Engine(self.cfg, dict(self._params), dev, self.precision)
             self._engine_key = key
+            self._runners = {}
         return self._engine
 
     # ------------------------------------------------------------------ reference-shaped stage methods
@@ -363,6 +503,46 @@ class Spann3R(nn.Module):
         n = len(frames)
         if n < 2:
             raise ValueError("need at least two frames")
+        img0 = frames[0]["img"]
+        B = img0.shape[0]
+        p = self.cfg.patch
+        P = (img0.shape[-2] // p) * (img0.shape[-1] // p)
+        uniform = all(tuple(f["img"].shape) == tuple(img0.shape) and "true_shape" not in f for f in frames)
+        if uniform and img0.shape[-2] % p == 0 and img0.shape[-1] % p == 0:
+            return self._forward_static(eng, frames, return_memory)
+        return self._forward_general(eng, frames, return_memory)
+
+    def _forward_static(self, eng, frames, return_memory):
+        """Same-shape sequences (every caller of the reference: demo/eval/app/training batches): static buffers,
+        one hipGraph per step."""
+        img0 = frames[0]["img"]
+        B, _, H, W = img0.shape
+        key = (B, H, W, bool(self.training))
+        run = self._runners.get(key)
+        if run is None:
+            run = self._runners[key] = _SequenceRunner(self, eng, B, H, W, bool(self.training))
+        mem = run.ensure_memory(len(frames))
+        preds, preds_all = None, []
+        for i in range(len(frames) - 1):
+            if i == 0:
+                run.img_pair[:B].copy_(frames[0]["img"])
+            run.img_pair[B:].copy_(frames[i + 1]["img"])
+            res1, res2 = run.run(i == 0, self.use_graphs)
+            res2["pts3d_in_other_view"] = res2.pop("pts3d")                      # :523
+            if preds is None:
+                preds = [res1]
+            else:
+                res1["pts3d_in_other_view"] = res1.pop("pts3d")
+                preds.append(res1)
+            preds_all.append((res1, res2))
+        preds.append(res2)
+        if return_memory:
+            return preds, preds_all, mem.snapshot()
+        return preds, preds_all
+
+    def _forward_general(self, eng, frames, return_memory):
+        """Reference-shaped loop over the stage methods (mixed shapes / explicit true_shape): same kernels, eager."""
+        n = len(frames)
         img0 = frames[0]["img"]
         B = img0.shape[0]
         p = self.cfg.patch

@@ -64,15 +64,16 @@ def pick_tile(M, N, batch=1, splitk=1, conv=False):
         if t64 >= 512:
             return 1
         return 0
-    return 3 if t64 >= 128 else 0
+    return 0
 
 
 def pick_splitk(M, N, K):
-    """How many workgroups share one output tile's K range (PARTIAL epilogue + sp3_reduce_ln): enough 64x64 tiles
-    to cover the 256 CUs, but at least 4 k-blocks of 64 per wave (K / (splitk*4*64) >= 1)."""
-    tiles = ((M + 63) // 64) * ((N + 63) // 64)
+    """How many workgroups share one output tile's K range (PARTIAL epilogue + sp3_reduce_ln).  With 32x32 tiles the
+    hot-path shapes already launch >= 168 workgroups, and tools/bench_gemm.py shows no gain from splitting further on
+    MI355X, so this only kicks in for very small outputs with a long K."""
+    tiles = ((M + 31) // 32) * ((N + 31) // 32)
     s = 1
-    while tiles * s < 192 and K // (s * 2) >= 512 and s < 8:
+    while tiles * s < 128 and K // (s * 2) >= 1024 and s < 8:
         s *= 2
     return s
 
@@ -103,6 +104,65 @@ def _timed(key, flops, nbytes, fn, *args):
     return r
 
 
+def packed_shape(rows, K, dtype):
+    """shape of a fragment-order operand buffer (include/spann3r_hip.h: a_packed / w_packed)"""
+    KB, CH = (64, 16) if dtype == torch.bfloat16 else (32, 8)
+    return ((rows + 15) // 16, (K + KB - 1) // KB, 4, 16, CH)
+
+
+class PackedAct:
+    """An activation matrix [M, K] in fragment order; produced by kernels with out_packed, consumed as GEMM A."""
+
+    def __init__(self, M, K, dtype, device, data=None):
+        self.M, self.K, self.dtype = M, K, dtype
+        self.data = torch.zeros(packed_shape(M, K, dtype), dtype=dtype, device=device) if data is None else data
+        self.is_cuda = self.data.is_cuda
+
+    @staticmethod
+    def from_dense(x):
+        M, K = x.shape
+        KB, CH = (64, 16) if x.dtype == torch.bfloat16 else (32, 8)
+        nb, nkb = (M + 15) // 16, (K + KB - 1) // KB
+        pad = torch.zeros(nb * 16, nkb * KB, dtype=x.dtype, device=x.device)
+        pad[:M, :K] = x
+        return PackedAct(M, K, x.dtype, x.device, pad.view(nb, 16, nkb, 4, CH).permute(0, 2, 3, 1, 4).contiguous())
+
+    def to_dense(self):
+        nb, nkb, _, _, CH = self.data.shape
+        return self.data.permute(0, 3, 1, 2, 4).reshape(nb * 16, nkb * 4 * CH)[:self.M, :self.K]
+
+    def data_ptr(self):
+        return self.data.data_ptr()
+
+
+class PackedWeight:
+    """A weight matrix [N, K] re-ordered once into MFMA-fragment order (include/spann3r_hip.h: w_packed) so that
+    every operand load of the GEMM is a fully coalesced, contiguous wave read."""
+
+    def __init__(self, w2d):
+        N, K = w2d.shape
+        self.N, self.K, self.dtype = N, K, w2d.dtype
+        KB, CH = (64, 16) if w2d.dtype == torch.bfloat16 else (32, 8)
+        nb, nkb = (N + 15) // 16, (K + KB - 1) // KB
+        pad = torch.zeros(nb * 16, nkb * KB, dtype=w2d.dtype, device=w2d.device)
+        pad[:N, :K] = w2d
+        # [nb, r, kb, g, e] -> [nb, kb, g, r, e]
+        self.data = pad.view(nb, 16, nkb, 4, CH).permute(0, 2, 3, 1, 4).contiguous()
+
+    def data_ptr(self):
+        return self.data.data_ptr()
+
+    def element_size(self):
+        return self.data.element_size()
+
+
+def _w(d, W):
+    """fills the W fields of a GemmDesc from a tensor or a PackedWeight"""
+    d.W = W.data_ptr()
+    d.w_packed = int(isinstance(W, PackedWeight))
+    d.wdtype = wdtype_of(W)
+
+
 def wdtype_of(t):
     if t.dtype == torch.float32:
         return F32
@@ -116,8 +176,12 @@ def _f32(t, name):
         raise TypeError("%s must be a float32 CUDA(HIP) tensor" % name)
 
 
+def _is_packed(t):
+    return int(isinstance(t, PackedAct))
+
+
 def _act(t, name):
-    """GEMM A operands: fp32, or bf16 in bf16 mode.  Returns the a_bf16 flag."""
+    """GEMM A operands: fp32, or bf16 in bf16 mode (dense tensor or PackedAct).  Returns the a_bf16 flag."""
     if not t.is_cuda or t.dtype not in (torch.float32, torch.bfloat16):
         raise TypeError("%s must be a float32/bfloat16 CUDA(HIP) tensor" % name)
     return int(t.dtype == torch.bfloat16)
@@ -131,13 +195,16 @@ def gemm(A, W, out, *, M, N, K, lda, ldc, bias=None, res1=None, ldr1=0, res2=Non
     that sp3_reduce_ln finishes."""
     d = GemmDesc()
     d.a_bf16 = _act(A, "A")
+    d.a_packed = _is_packed(A)
+    d.out_packed = _is_packed(out)
     out_bf16 = out.dtype == torch.bfloat16
-    d.A, d.A2, d.W, d.C = A.data_ptr(), L.ptr(A2), W.data_ptr(), out.data_ptr()
+    _w(d, W)
+    d.A, d.A2, d.C = A.data_ptr(), L.ptr(A2), out.data_ptr()
     d.bias, d.res1, d.res2 = L.ptr(bias), L.ptr(res1), L.ptr(res2)
     d.M, d.N, d.K, d.batch, d.K1 = M, N, K, batch, K1
     d.lda, d.lda2, d.ldw, d.ldc, d.ldr1, d.ldr2 = lda, lda2, ldw, ldc, ldr1, ldr2
     d.strideA, d.strideW, d.strideC = strideA, strideW, strideC
-    d.alpha, d.wdtype, d.act, d.out_bf16, d.relu_in = alpha, wdtype_of(W), act, int(out_bf16), int(relu_in)
+    d.alpha, d.act, d.out_bf16, d.relu_in = alpha, act, int(out_bf16), int(relu_in)
     d.loader, d.epi, d.tile = L.LOAD_PLAIN, L.EPI_PLAIN, tile
     if splitk >= 1:
         d.epi, d.splitk = L.EPI_PARTIAL, splitk
@@ -155,8 +222,10 @@ def reduce_ln(partial, splits, rows, C_, *, bias=None, res=None, ldres=0, x_out=
     d.x_out, d.ldx = L.ptr(x_out), ldx or C_
     if out1 is not None:
         d.g1, d.b1, d.out1, d.ld1, d.out1_bf16 = ln1[0].data_ptr(), ln1[1].data_ptr(), out1.data_ptr(), ld1 or C_, int(out1.dtype == torch.bfloat16)
+        d.out1_packed = _is_packed(out1)
     if out2 is not None:
         d.g2, d.b2, d.out2, d.ld2, d.out2_bf16 = ln2[0].data_ptr(), ln2[1].data_ptr(), out2.data_ptr(), ld2 or C_, int(out2.dtype == torch.bfloat16)
+        d.out2_packed = _is_packed(out2)
     d.eps = eps
     nln = (out1 is not None) + (out2 is not None)
     _timed("reduce_ln", (splits + 8.0 * nln) * rows * C_, 4.0 * rows * C_ * (splits + 2 + nln),
@@ -171,11 +240,12 @@ def conv3x3(x, Wp, out, *, B, H, W_, Cin, Cout, stride=1, bias=None, res1=None, 
     d = GemmDesc()
     d.a_bf16 = _act(x, "x")
     d.out_bf16 = int(out.dtype == torch.bfloat16)
-    d.A, d.W, d.C = x.data_ptr(), Wp.data_ptr(), out.data_ptr()
+    _w(d, Wp)
+    d.A, d.C = x.data_ptr(), out.data_ptr()
     d.bias, d.res1, d.res2 = L.ptr(bias), L.ptr(res1), L.ptr(res2)
     d.M, d.N, d.K, d.batch = B * OH * OW, Cout, 9 * Cin, 1
     d.lda, d.ldc, d.ldr1, d.ldr2 = Cin, Cout, Cout, Cout
-    d.alpha, d.wdtype, d.act, d.relu_in = 1.0, wdtype_of(Wp), act, int(relu_in)
+    d.alpha, d.act, d.relu_in = 1.0, act, int(relu_in)
     d.loader, d.epi, d.tile = L.LOAD_CONV3X3, L.EPI_PLAIN, tile
     d.conv_H, d.conv_W, d.conv_C, d.conv_OH, d.conv_OW, d.conv_stride = H, W_, Cin, OH, OW, stride
     _gemm_launch(d, "sp3_gemm(conv3x3)", "conv3x3")
@@ -188,10 +258,11 @@ def conv_transpose_ks(x, Wp, out, *, B, H, W_, Cin, Cout, ks, bias=None, tile=-1
     d = GemmDesc()
     d.a_bf16 = _act(x, "x")
     d.out_bf16 = int(out.dtype == torch.bfloat16)
-    d.A, d.W, d.C, d.bias = x.data_ptr(), Wp.data_ptr(), out.data_ptr(), L.ptr(bias)
+    _w(d, Wp)
+    d.A, d.C, d.bias = x.data_ptr(), out.data_ptr(), L.ptr(bias)
     d.M, d.N, d.K, d.batch = B * H * W_, ks * ks * Cout, Cin, 1
     d.lda, d.ldc = Cin, Cout
-    d.alpha, d.wdtype = 1.0, wdtype_of(Wp)
+    d.alpha = 1.0
     d.loader, d.epi, d.tile = L.LOAD_PLAIN, L.EPI_PIXSHUF, tile
     d.ps_k, d.ps_H, d.ps_W, d.ps_C = ks, H, W_, Cout
     _gemm_launch(d, "sp3_gemm(conv_transpose)", "plain")
@@ -203,10 +274,12 @@ def proj_rope_vt(A, W, bias, out_qk, ldc, vt, vt_ld, *, M, N, K, lda, rope_cols,
     (stored row-major to out_qk) and per-head transposed store of the V columns to vt."""
     d = GemmDesc()
     d.a_bf16 = _act(A, "A")
-    d.A, d.W, d.C, d.bias = A.data_ptr(), W.data_ptr(), L.ptr(out_qk), L.ptr(bias)
+    d.a_packed = _is_packed(A)
+    _w(d, W)
+    d.A, d.C, d.bias = A.data_ptr(), L.ptr(out_qk), L.ptr(bias)
     d.M, d.N, d.K, d.batch = M, N, K, 1
     d.lda, d.ldc = lda, ldc
-    d.alpha, d.wdtype = 1.0, wdtype_of(W)
+    d.alpha = 1.0
     d.loader, d.epi, d.tile = L.LOAD_PLAIN, L.EPI_ROPE_VT, tile
     d.rope_cos, d.rope_sin, d.pos, d.rope_cols = cos.data_ptr(), sin.data_ptr(), pos.data_ptr(), rope_cols
     d.vt, d.vt_ld, d.tokens, d.heads = L.ptr(vt), vt_ld, tokens, heads
@@ -219,6 +292,12 @@ def layernorm(x, gamma, beta, eps, out, *, rows, C_, ldx=None, ldo=None, transpo
     _f32(x, "x")
     ldx = C_ if ldx is None else ldx
     ldo = C_ if ldo is None else ldo
+    if _is_packed(out):
+        _timed("layernorm", 8.0 * rows * C_, rows * C_ * 6.0,
+               lambda: L.check(L.load().sp3_layernorm_packed(x.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(), eps,
+                                                             out.data_ptr(), int(out.dtype == torch.bfloat16), rows, C_,
+                                                             L.stream_ptr()), "sp3_layernorm_packed"))
+        return out
     fn = L.load().sp3_layernorm_t if transposed else L.load().sp3_layernorm
     _timed("layernorm_t" if transposed else "layernorm", 8.0 * rows * C_, rows * C_ * (4.0 + out.element_size()),
            lambda: L.check(fn(x.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(), eps, out.data_ptr(), ldo,
@@ -257,9 +336,10 @@ def attention(q, sq, ldq, k, sk, ldk, vt, vt_ld, out, ldo, *, B, heads, Nq, Nk, 
     es = vt.element_size()
     _timed("attention<%s>" % ("f32" if es == 4 else "bf16"), 4.0 * B * heads * Nq * Nk * 64,
            B * heads * 64.0 * (es * (Nq + 2 * Nk) + 4 * Nq),
-           lambda: L.check(L.load().sp3_attention(q.data_ptr(), sq, ldq, k.data_ptr(), sk, ldk, vt.data_ptr(), vt_ld,
-                                                  out.data_ptr(), ldo, int(out.dtype == torch.bfloat16), B, heads, Nq, Nk,
-                                                  float(scale), wdtype_of(vt), L.stream_ptr()), "sp3_attention"))
+           lambda: L.check(L.load().sp3_attention_ex(q.data_ptr(), sq, ldq, k.data_ptr(), sk, ldk, vt.data_ptr(), vt_ld,
+                                                     out.data_ptr(), ldo, int(out.dtype == torch.bfloat16), _is_packed(out),
+                                                     B, heads, Nq, Nk, float(scale), wdtype_of(vt), L.stream_ptr()),
+                           "sp3_attention"))
     return out
 
 
@@ -304,7 +384,7 @@ def im2col_patch(img, out, *, B, C_, H, W_, p, strides):
     _f32(img, "img")
     sb, sc, sy, sx = strides
     L.check(L.load().sp3_im2col_patch(img.data_ptr(), sb, sc, sy, sx, B, C_, H, W_, p, out.data_ptr(),
-                                      int(out.dtype == torch.bfloat16), L.stream_ptr()), "sp3_im2col_patch")
+                                      int(out.dtype == torch.bfloat16), _is_packed(out), L.stream_ptr()), "sp3_im2col_patch")
     return out
 
 

@@ -102,6 +102,30 @@ def test_tiny_forward_vs_golden(tiny_model, precision, tol):
         assert [mem.wm, mem.lm] == list(g["mem_wm_lm"])
 
 
+def test_graph_replay_equals_eager(tiny_model):
+    """1st call of a geometry runs eagerly, 2nd captures + replays hipGraphs, 3rd replays: all bit-identical,
+    and identical to use_graphs=False (same kernels, same order)."""
+    from spann3r_amd.weights import synth_frames
+    m = tiny_model
+    frames = to_dev(synth_frames(5, 48, 64, seed=5))
+    outs = [m(frames, return_memory=True) for _ in range(3)]
+    run = [r for k, r in m._runners.items() if k[:3] == (1, 48, 64)][0]
+    assert len(run.graphs) == 4                      # one per step of the 5-frame sequence
+    m.use_graphs = False
+    try:
+        outs.append(m(frames, return_memory=True))
+    finally:
+        m.use_graphs = True
+    for o in outs[1:]:
+        for a, b in zip(outs[0][0], o[0]):
+            for k in a:
+                assert torch.equal(a[k], b[k]), k
+        assert torch.equal(outs[0][2].mem_k, o[2].mem_k) and torch.equal(outs[0][2].mem_attn, o[2].mem_attn)
+    # a different sequence through the captured graphs must differ (inputs are copied into the static buffers)
+    other, _ = m(to_dev(synth_frames(5, 48, 64, seed=6)))
+    assert not torch.equal(other[0]["pts3d"], outs[0][0][0]["pts3d"])
+
+
 def test_tiny_training_policy(tiny_model):
     """Growing bank: train-mode memory policy with dropout disabled (the oracle for BASELINE config 3)."""
     from spann3r_amd.weights import synth_frames

@@ -37,13 +37,19 @@ TOL = {torch.float32: 2e-5, torch.bfloat16: 2e-3}
 @pytest.mark.parametrize("M,N,K", [(196, 1024, 1024), (392, 3072, 1024), (20, 768, 768), (100, 96, 1024),
                                    (196, 588, 1024), (49, 256, 96), (196, 1024, 1736), (7, 32, 8), (300, 160, 200)])
 @pytest.mark.parametrize("tile", [-1, 0, 1, 2, 3])
-def test_gemm_plain(wdt, M, N, K, tile):
+@pytest.mark.parametrize("packed", [0, 1, 2])
+def test_gemm_plain(wdt, M, N, K, tile, packed):
     ops = _ops()
     A, W = rnd(M, K, seed=1), rnd(N, K, seed=2)
     # asymmetric content so a transposed write cannot pass
     A[:, 0] += torch.arange(M) * 0.01
     W[:, 1] += torch.arange(N) * 0.02
     Ad, Wd = A.to(DEV), W.to(DEV).to(wdt)
+    if packed:
+        Wd = ops.PackedWeight(Wd)
+    if packed == 2:        # A in fragment order too (as the producing kernels write it); bf16 A in bf16 mode
+        Ad = ops.PackedAct.from_dense(Ad.to(wdt))
+        assert torch.equal(Ad.to_dense(), A.to(DEV).to(wdt))
     out = torch.full((M, N), float("nan"), device=DEV)
     ops.gemm(Ad, Wd, out, M=M, N=N, K=K, lda=K, ldc=N, tile=tile)
     ref = (bf(A) if wdt == torch.bfloat16 else A).double() @ (bf(W) if wdt == torch.bfloat16 else W).double().T
@@ -111,7 +117,7 @@ def test_splitk_reduce_ln(wdt, M, N, K, S):
     y = torch.empty(M, N, device=DEV)
     ops.reduce_ln(part, S, M, N, bias=b.to(DEV), x_out=y)
     assert rel_err(y.cpu(), Ar.double() @ Wr.double().T + b.double()) < TOL[wdt]
-    assert ops.pick_splitk(196, 1024, 4096) == 4 and ops.pick_splitk(196, 4096, 1024) == 1
+    assert ops.pick_splitk(196, 1024, 4096) == 1 and ops.pick_splitk(16, 64, 8192) > 1
 
 
 @pytest.mark.parametrize("wdt", [torch.float32, torch.bfloat16])
@@ -168,6 +174,49 @@ def test_conv_transpose(wdt, ks, C):
     xr, wr = (bf(x), bf(w)) if wdt == torch.bfloat16 else (x, w)
     ref = F.conv_transpose2d(xr.double(), wr.double(), b.double(), stride=ks)
     assert rel_err(out.cpu(), ref.permute(0, 2, 3, 1)) < TOL[wdt]
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_packed_producers(dt):
+    """Every producer's fragment-order output (out_packed) holds exactly what its row-major output holds."""
+    ops = _ops()
+    rows, C = 197, 1024
+    x, g, b = rnd(rows, C, seed=1) * 2, rnd(C, seed=2) + 1, rnd(C, seed=3)
+    xd, gd, bd = x.to(DEV), g.to(DEV), b.to(DEV)
+    dense = torch.empty(rows, C, device=DEV, dtype=dt)
+    pk = ops.PackedAct(rows, C, dt, DEV)
+    ops.layernorm(xd, gd, bd, 1e-6, dense, rows=rows, C_=C)
+    ops.layernorm(xd, gd, bd, 1e-6, pk, rows=rows, C_=C)
+    assert torch.equal(pk.to_dense(), dense)
+    # reduce_ln: one packed and one dense LayerNorm output
+    part = rnd(2, rows, C, seed=4).to(DEV)
+    pk2 = ops.PackedAct(rows, C, dt, DEV)
+    d2 = torch.empty(rows, C, device=DEV, dtype=dt)
+    ops.reduce_ln(part, 2, rows, C, bias=bd, ln1=(gd, bd), out1=pk2, ln2=(gd, bd), out2=d2)
+    assert torch.equal(pk2.to_dense(), d2)
+    # GEMM epilogue (bias + GELU) into a packed buffer
+    M, N, K = 196, 768, 256
+    A, W = rnd(M, K, seed=5).to(DEV), (rnd(N, K, seed=6) * 0.1).to(DEV).to(dt)
+    od, op = torch.empty(M, N, device=DEV, dtype=dt), ops.PackedAct(M, N, dt, DEV)
+    ops.gemm(A, W, od, M=M, N=N, K=K, lda=K, ldc=N, bias=rnd(N, seed=7).to(DEV), act=ops.ACT_GELU)
+    ops.gemm(A, W, op, M=M, N=N, K=K, lda=K, ldc=N, bias=rnd(N, seed=7).to(DEV), act=ops.ACT_GELU)
+    assert torch.equal(op.to_dense(), od)
+    # attention output
+    B, heads, Nq = 2, 3, 37
+    Cc = heads * 64
+    q, k = rnd(B, Nq, heads, 64, seed=8).to(DEV).to(dt), rnd(B, Nq, heads, 64, seed=9).to(DEV).to(dt)
+    vt = torch.zeros(B * heads * 64, 64, device=DEV, dtype=dt)
+    vt[:, :Nq] = rnd(B * heads * 64, Nq, seed=10).to(DEV).to(dt)
+    ad, apk = torch.empty(B * Nq, Cc, device=DEV, dtype=dt), ops.PackedAct(B * Nq, Cc, dt, DEV)
+    for o in (ad, apk):
+        ops.attention(q, Nq * Cc, Cc, k, Nq * Cc, Cc, vt, 64, o, Cc, B=B, heads=heads, Nq=Nq, Nk=Nq, scale=0.125)
+    assert torch.equal(apk.to_dense(), ad)
+    # im2col
+    img = rnd(2, 3, 32, 48, seed=11).to(DEV)
+    cd, cp = torch.empty(12, 768, device=DEV, dtype=dt), ops.PackedAct(12, 768, dt, DEV)
+    for o in (cd, cp):
+        ops.im2col_patch(img, o, B=2, C_=3, H=32, W_=48, p=16, strides=img.stride())
+    assert torch.equal(cp.to_dense(), cd)
 
 
 # ----------------------------------------------------------------------------- RoPE / projection / attention
