@@ -154,26 +154,24 @@ class Engine:
     # Activations that only feed a GEMM (LayerNorm outputs, attention outputs, GELU outputs) are stored in `adt`
     # (bf16 in bf16 mode: exactly the rounding the MFMA operand conversion would apply on load, at half the traffic);
     # the residual stream, LayerNorm statistics and everything the API returns stay fp32.
-    def _attn_core(self, x, R, B, P, C, heads, pre, pos32, ao):
+    def _attn_core(self, x, R, B, P, C, heads, pre, pos32, ao, tag=""):
         """qkv projection with fused bias + 2-D RoPE + per-head V^T store, then softmax(qk^T/8)v
         (croco/models/blocks.py:94-109).  x [R,C] LayerNormed input -> ao [R,C]."""
         w = self.w
         npad = (P + 63) // 64 * 64
-        qk = self.ws("qk", (R, 2 * C), self.wdt)
-        vt = self.ws("vt", (B * heads * 64, npad), self.wdt, zero=True)
+        qk = self.ws("qk" + tag, (R, 2 * C), self.wdt)
+        vt = self.ws("vt" + tag, (B * heads * 64, npad), self.wdt, zero=True)
         ops.proj_rope_vt(x, w[pre + "qkv.w"], w[pre + "qkv.b"], qk, 2 * C, vt, npad, M=R, N=3 * C, K=C, lda=C,
                          rope_cols=2 * C, pos=pos32, cos=self.cos, sin=self.sin, tokens=P, heads=heads)
         ops.attention(qk, P * 2 * C, 2 * C, qk[:, C:], P * 2 * C, 2 * C, vt, npad, ao, C, B=B, heads=heads, Nq=P, Nk=P,
                       scale=64 ** -0.5)
 
     def _linear_reduce(self, A, W, bias, R, N, K, lda, *, res=None, x_out=None, ln1=None, out1=None, ln2=None, out2=None,
-                       eps=1e-6, A2=None, lda2=0, K1=0):
+                       eps=1e-6, A2=None, lda2=0, K1=0, tag=""):
         """x = A.W^T + bias (+ res) as a split-K GEMM finished by the fused reduce + residual + LayerNorm kernel
         (`x = x + proj(...)` and the norm(s) that follow, croco/models/blocks.py:128-129,187-190)."""
         S = ops.pick_splitk(R, N, K)
-        part = self.ws("splitk_partial", (8 * R * max(N, 1),))
-        if part.numel() < S * R * N:
-            part = self.ws("splitk_partial_%d" % (S * R * N), (S * R * N,))
+        part = self.ws("splitk_partial" + tag, (max(S, 2) * R * N,))
         ops.gemm(A, W, part, M=R, N=N, K=K, lda=lda, ldc=N, splitk=S, A2=A2, lda2=lda2, K1=K1)
         ops.reduce_ln(part, S, R, N, bias=bias, res=res, x_out=x_out, ln1=ln1, out1=out1, ln2=ln2, out2=out2, eps=eps)
 
@@ -231,71 +229,115 @@ class Engine:
         self._vit(col, R, B, P, "patch", "enc", cfg.enc_depth, pos32, "enc_norm", out)
         return out, pos64
 
-    def decoder(self, f1, f2, B, nh1, nw1, nh2, nw2):
+    def side_streams(self):
+        """Two side streams: the two decoder branches of a layer (dust3r/model.py:196-198 reads only the PREVIOUS
+        layer pair) and the two DPT heads are independent, so they run concurrently; under hipGraph capture the
+        fork/join becomes graph edges."""
+        if getattr(self, "_streams", None) is None:
+            self._streams = {1: torch.cuda.Stream(device=self.device), 2: torch.cuda.Stream(device=self.device)}
+        return self._streams
+
+    def fork(self):
+        main = torch.cuda.current_stream()
+        st = self.side_streams()
+        for k in (1, 2):
+            st[k].wait_stream(main)
+        return main, st
+
+    def join(self, main, st):
+        for k in (1, 2):
+            main.wait_stream(st[k])
+
+    def decoder(self, f1, f2, B, nh1, nw1, nh2, nw2, streams=None):
         """dust3r._decoder (dust3r/model.py:186-205).  f1, f2 fp32 [B,P,1024].
-        Returns two lists of dec_depth+1 tensors ([B,P,1024] then [B,P,768] ...), last one dec_norm'ed."""
+        Returns two lists of dec_depth+1 tensors ([B,P,1024] then [B,P,768] ...), last one dec_norm'ed.
+        `streams` = {1: stream, 2: stream}: run the two sides concurrently (caller forks / joins)."""
         cfg, w = self.cfg, self.w
         E, D, Hh = cfg.enc_dim, cfg.dec_dim, cfg.dec_heads
         P1, P2 = nh1 * nw1, nh2 * nw2
         Rs, Ps = {1: B * P1, 2: B * P2}, {1: P1, 2: P2}
-        Rmax, Pmax = max(Rs.values()), max(P1, P2)
+        Pmax = max(P1, P2)
         pos = {1: self.positions(B, nh1, nw1)[1], 2: self.positions(B, nh2, nw2)[1]}
         f = {1: f1, 2: f2}
         outs = {1: [f1], 2: [f2]}
         depth = cfg.dec_depth
+        cur_stream = torch.cuda.current_stream() if self.device.type == "cuda" else None
+        st = streams or {1: cur_stream, 2: cur_stream}
         # per side, double-buffered by layer parity: ln1 = norm1(own previous layer), yn = norm_y(OTHER side's previous layer)
         ln1 = {s: [self.wsp("dec_ln1_%d_%d" % (s, j), Rs[s], D) for j in (0, 1)] for s in (1, 2)}
         yn = {s: [self.wsp("dec_yn_%d_%d" % (s, j), Rs[3 - s], D) for j in (0, 1)] for s in (1, 2)}
         prev = {}
+        # Cross-stream event waits inside a capture crash hipStreamEndCapture on ROCm 7.2 (tools/
+        # probe_multistream_capture.py), plain fork/join does not: so both sides fork from and join to the main stream
+        # once per layer (layer i+1 of either side needs layer i of BOTH sides anyway).
+        main = cur_stream
+
+        def fork_layer():
+            if streams:
+                st[1].wait_stream(main)
+                st[2].wait_stream(main)
+
+        def join_layer():
+            if streams:
+                main.wait_stream(st[1])
+                main.wait_stream(st[2])
+
+        fork_layer()
         for s in (1, 2):
             o = 3 - s
-            prev[s] = self.ws("dec%d_l0" % s, (Rs[s], D))
-            # decoder_embed (dust3r/model.py:190-191); emits norm1 for side s and norm_y for side o's first block
-            self._linear_reduce(f[s], w["dec_embed.w"], w["dec_embed.b"], Rs[s], D, E, E, x_out=prev[s],
-                                ln1=self._norm("dec%d_0.norm1" % s), out1=ln1[s][0],
-                                ln2=self._norm("dec%d_0.norm_y" % o), out2=yn[o][0])
+            with torch.cuda.stream(st[s]):
+                prev[s] = self.ws("dec%d_l0" % s, (Rs[s], D))
+                # decoder_embed (dust3r/model.py:190-191); emits norm1 for side s and norm_y for side o's first block
+                self._linear_reduce(f[s], w["dec_embed.w"], w["dec_embed.b"], Rs[s], D, E, E, x_out=prev[s],
+                                    ln1=self._norm("dec%d_0.norm1" % s), out1=ln1[s][0],
+                                    ln2=self._norm("dec%d_0.norm_y" % o), out2=yn[o][0], tag="_s%d" % s)
+        join_layer()
         for i in range(depth):
             cur, nx = i % 2, (i + 1) % 2
             last = i == depth - 1
             new = {}
+            fork_layer()
             for s in (1, 2):
                 o = 3 - s
+                tag = "_s%d" % s
                 pre = "dec%d_%d." % (s, i)
                 R, P, Ro, Po = Rs[s], Ps[s], Rs[o], Ps[o]
-                x = self.ws("dec%d_l%d" % (s, i + 1), (R, D))
-                # self attention (croco/models/blocks.py:187)
-                ao = self.wsp("attn_out_dec_%d" % R, R, D)
-                self._attn_core(ln1[s][cur], R, B, P, D, Hh, pre, pos[s], ao)
-                ln2 = self.wsp("dec_ln_b_%d" % R, R, D)
-                self._linear_reduce(ao, w[pre + "proj.w"], w[pre + "proj.b"], R, D, D, D, res=prev[s], x_out=x,
-                                    ln1=self._norm(pre + "norm2"), out1=ln2)
-                # cross attention to the other side's previous-layer tokens through norm_y (:188-189)
-                kbuf = self.ws("ck", (Rmax, D), self.wdt)
-                vt = self.ws("cvt", (B * Hh * 64, (Pmax + 63) // 64 * 64), self.wdt, zero=True)
-                vt_ld = vt.shape[1]
-                ops.proj_rope_vt(yn[s][cur], w[pre + "ckv.w"], w[pre + "ckv.b"], kbuf, D, vt, vt_ld, M=Ro, N=2 * D, K=D, lda=D,
-                                 rope_cols=D, pos=pos[o], cos=self.cos, sin=self.sin, tokens=Po, heads=Hh)
-                qbuf = self.ws("cq", (Rmax, D), self.wdt)
-                ops.proj_rope_vt(ln2, w[pre + "cq.w"], w[pre + "cq.b"], qbuf, D, None, 0, M=R, N=D, K=D, lda=D,
-                                 rope_cols=D, pos=pos[s], cos=self.cos, sin=self.sin, tokens=P, heads=Hh)
-                ops.attention(qbuf, P * D, D, kbuf, Po * D, D, vt, vt_ld, ao, D, B=B, heads=Hh, Nq=P, Nk=Po, scale=64 ** -0.5)
-                ln3 = self.wsp("dec_ln_c_%d" % R, R, D)
-                self._linear_reduce(ao, w[pre + "cproj.w"], w[pre + "cproj.b"], R, D, D, D, res=x, x_out=x,
-                                    ln1=self._norm(pre + "norm3"), out1=ln3)
-                # MLP (:190); its finishing kernel emits the next layer's norm1 (own side) and norm_y (other side)
-                Hd = D * cfg.mlp_ratio
-                h = self.wsp("mlp_hidden_dec_%d" % R, R, Hd)
-                ops.gemm(ln3, w[pre + "fc1.w"], h, M=R, N=Hd, K=D, lda=D, ldc=Hd, bias=w[pre + "fc1.b"], act=ACT_GELU)
-                if last:
-                    normed = self.ws("dec%d_normed" % s, (R, D))
-                    self._linear_reduce(h, w[pre + "fc2.w"], w[pre + "fc2.b"], R, D, Hd, Hd, res=x, x_out=None,
-                                        ln1=self._norm("dec_norm"), out1=normed)
-                    new[s] = normed
-                else:
-                    self._linear_reduce(h, w[pre + "fc2.w"], w[pre + "fc2.b"], R, D, Hd, Hd, res=x, x_out=x,
-                                        ln1=self._norm("dec%d_%d.norm1" % (s, i + 1)), out1=ln1[s][nx],
-                                        ln2=self._norm("dec%d_%d.norm_y" % (o, i + 1)), out2=yn[o][nx])
-                    new[s] = x
+                with torch.cuda.stream(st[s]):
+                    x = self.ws("dec%d_l%d" % (s, i + 1), (R, D))
+                    # self attention (croco/models/blocks.py:187)
+                    ao = self.wsp("attn_out_dec" + tag, R, D)
+                    self._attn_core(ln1[s][cur], R, B, P, D, Hh, pre, pos[s], ao, tag=tag)
+                    ln2 = self.wsp("dec_ln_b" + tag, R, D)
+                    self._linear_reduce(ao, w[pre + "proj.w"], w[pre + "proj.b"], R, D, D, D, res=prev[s], x_out=x,
+                                        ln1=self._norm(pre + "norm2"), out1=ln2, tag=tag)
+                    # cross attention to the other side's previous-layer tokens through norm_y (:188-189)
+                    kbuf = self.ws("ck" + tag, (Ro, D), self.wdt)
+                    vt = self.ws("cvt" + tag, (B * Hh * 64, (Pmax + 63) // 64 * 64), self.wdt, zero=True)
+                    vt_ld = vt.shape[1]
+                    ops.proj_rope_vt(yn[s][cur], w[pre + "ckv.w"], w[pre + "ckv.b"], kbuf, D, vt, vt_ld, M=Ro, N=2 * D, K=D, lda=D,
+                                     rope_cols=D, pos=pos[o], cos=self.cos, sin=self.sin, tokens=Po, heads=Hh)
+                    qbuf = self.ws("cq" + tag, (R, D), self.wdt)
+                    ops.proj_rope_vt(ln2, w[pre + "cq.w"], w[pre + "cq.b"], qbuf, D, None, 0, M=R, N=D, K=D, lda=D,
+                                     rope_cols=D, pos=pos[s], cos=self.cos, sin=self.sin, tokens=P, heads=Hh)
+                    ops.attention(qbuf, P * D, D, kbuf, Po * D, D, vt, vt_ld, ao, D, B=B, heads=Hh, Nq=P, Nk=Po, scale=64 ** -0.5)
+                    ln3 = self.wsp("dec_ln_c" + tag, R, D)
+                    self._linear_reduce(ao, w[pre + "cproj.w"], w[pre + "cproj.b"], R, D, D, D, res=x, x_out=x,
+                                        ln1=self._norm(pre + "norm3"), out1=ln3, tag=tag)
+                    # MLP (:190); its finishing kernel emits the next layer's norm1 (own side) and norm_y (other side)
+                    Hd = D * cfg.mlp_ratio
+                    h = self.wsp("mlp_hidden_dec" + tag, R, Hd)
+                    ops.gemm(ln3, w[pre + "fc1.w"], h, M=R, N=Hd, K=D, lda=D, ldc=Hd, bias=w[pre + "fc1.b"], act=ACT_GELU)
+                    if last:
+                        normed = self.ws("dec%d_normed" % s, (R, D))
+                        self._linear_reduce(h, w[pre + "fc2.w"], w[pre + "fc2.b"], R, D, Hd, Hd, res=x, x_out=None,
+                                            ln1=self._norm("dec_norm"), out1=normed, tag=tag)
+                        new[s] = normed
+                    else:
+                        self._linear_reduce(h, w[pre + "fc2.w"], w[pre + "fc2.b"], R, D, Hd, Hd, res=x, x_out=x,
+                                            ln1=self._norm("dec%d_%d.norm1" % (s, i + 1)), out1=ln1[s][nx],
+                                            ln2=self._norm("dec%d_%d.norm_y" % (o, i + 1)), out2=yn[o][nx], tag=tag)
+                        new[s] = x
+            join_layer()
             for s in (1, 2):
                 prev[s] = new[s]
                 outs[s].append(new[s].view(B, Ps[s], D))
@@ -306,17 +348,17 @@ class Engine:
         the concatenation is never materialised (split-A GEMM)."""
         cfg, w = self.cfg, self.w
         E, D, Kd = cfg.enc_dim, cfg.dec_dim, cfg.key_dim
-        h = self.wsp("key_hidden", R, Kd)
+        h = self.wsp("key_hidden%d" % num, R, Kd)
         pre = "key%d." % num
         ops.gemm(feat, w[pre + "0.w"], h, M=R, N=Kd, K=Kd, lda=E, ldc=Kd, bias=w[pre + "0.b"], act=ACT_GELU,
                  A2=dec_last, lda2=D, K1=E)
         ops.gemm(h, w[pre + "2.w"], out, M=R, N=E, K=Kd, lda=Kd, ldc=E, bias=w[pre + "2.b"])
         return out
 
-    def _rcu(self, x, pre, B, H, W_, out, extra_res=None):
+    def _rcu(self, x, pre, B, H, W_, out, extra_res=None, tag=""):
         """ResidualConvUnit_custom (croco/models/dpt_block.py:120-142): conv2(relu(conv1(relu(x)))) + x [+ extra]."""
         w, F = self.w, self.cfg.dpt_feat
-        t = self.ws("rcu_tmp", (B * H * W_, F))
+        t = self.ws("rcu_tmp" + tag, (B * H * W_, F))
         ops.conv3x3(x, w[pre + "c1.w"], t, B=B, H=H, W_=W_, Cin=F, Cout=F, bias=w[pre + "c1.b"], relu_in=True, act=ACT_RELU)
         ops.conv3x3(t, w[pre + "c2.w"], out, B=B, H=H, W_=W_, Cin=F, Cout=F, bias=w[pre + "c2.b"], res1=x, res2=extra_res)
         return out
@@ -330,10 +372,10 @@ class Engine:
         cur = x0
         if x1 is not None:
             s = self.ws("fus_sum_" + tag, (M, F))
-            self._rcu(x1, pre + "u1", B, H, W_, s, extra_res=x0)
+            self._rcu(x1, pre + "u1", B, H, W_, s, extra_res=x0, tag=tag)
             cur = s
         r = self.ws("fus_rcu2_" + tag, (M, F))
-        self._rcu(cur, pre + "u2", B, H, W_, r)
+        self._rcu(cur, pre + "u2", B, H, W_, r, tag=tag)
         oc = self.ws("fus_oc_" + tag, (M, F))
         ops.gemm(r, w[pre + "out.w"], oc, M=M, N=F, K=F, lda=F, ldc=F, bias=w[pre + "out.b"])
         OH, OW = (2 * H, 2 * W_) if crop is None else crop
@@ -353,38 +395,38 @@ class Engine:
         ld = (96, 192, 384, 768)
         t = []
         for i in range(4):
-            o = self.ws("dpt_pp%d" % i, (R, ld[i]))
+            o = self.ws("dpt%d_pp%d" % (num, i), (R, ld[i]))
             ops.gemm(dec[hk[i]], w[pre + "pp%d.w" % i], o, M=R, N=ld[i], K=dims[i], lda=dims[i], ldc=ld[i], bias=w[pre + "pp%d.b" % i])
             t.append(o)
         # act_postprocess tails (croco/models/dpt_block.py:356-410)
-        l0 = self.ws("dpt_l0", (B * 16 * nh * nw, ld[0]))
+        l0 = self.ws("dpt%d_l0" % num, (B * 16 * nh * nw, ld[0]))
         ops.conv_transpose_ks(t[0], w[pre + "pp0t.w"], l0, B=B, H=nh, W_=nw, Cin=ld[0], Cout=ld[0], ks=4, bias=w[pre + "pp0t.b"])
-        l1 = self.ws("dpt_l1", (B * 4 * nh * nw, ld[1]))
+        l1 = self.ws("dpt%d_l1" % num, (B * 4 * nh * nw, ld[1]))
         ops.conv_transpose_ks(t[1], w[pre + "pp1t.w"], l1, B=B, H=nh, W_=nw, Cin=ld[1], Cout=ld[1], ks=2, bias=w[pre + "pp1t.b"])
         l2 = t[2]
         h3, w3 = (nh - 1) // 2 + 1, (nw - 1) // 2 + 1
-        l3 = self.ws("dpt_l3", (B * h3 * w3, ld[3]))
+        l3 = self.ws("dpt%d_l3" % num, (B * h3 * w3, ld[3]))
         ops.conv3x3(t[3], w[pre + "pp3c.w"], l3, B=B, H=nh, W_=nw, Cin=ld[3], Cout=ld[3], stride=2, bias=w[pre + "pp3c.b"])
         # scratch.layer_rn (3x3, no bias) -> 256 channels
         geo = ((4 * nh, 4 * nw), (2 * nh, 2 * nw), (nh, nw), (h3, w3))
         rn = []
         for i, src in enumerate((l0, l1, l2, l3)):
             Hh, Ww = geo[i]
-            o = self.ws("dpt_rn%d" % i, (B * Hh * Ww, F))
+            o = self.ws("dpt%d_rn%d" % (num, i), (B * Hh * Ww, F))
             ops.conv3x3(src, w[pre + "rn%d.w" % i], o, B=B, H=Hh, W_=Ww, Cin=ld[i], Cout=F)
             rn.append(o)
         # refinenets; path_4 is cropped to layer 3's size (dust3r/heads/dpt_head.py:57)
-        p4, H4, W4 = self._fusion(pre + "ref4.", B, h3, w3, rn[3], None, "4", crop=(nh, nw))
-        p3, H3, W3 = self._fusion(pre + "ref3.", B, H4, W4, p4, rn[2], "3")
-        p2, H2, W2 = self._fusion(pre + "ref2.", B, H3, W3, p3, rn[1], "2")
-        p1, H1, W1 = self._fusion(pre + "ref1.", B, H2, W2, p2, rn[0], "1")
+        p4, H4, W4 = self._fusion(pre + "ref4.", B, h3, w3, rn[3], None, "%d_4" % num, crop=(nh, nw))
+        p3, H3, W3 = self._fusion(pre + "ref3.", B, H4, W4, p4, rn[2], "%d_3" % num)
+        p2, H2, W2 = self._fusion(pre + "ref2.", B, H3, W3, p3, rn[1], "%d_2" % num)
+        p1, H1, W1 = self._fusion(pre + "ref1.", B, H2, W2, p2, rn[0], "%d_1" % num)
         # head: conv3x3(256->128) -> x2 -> conv3x3(128->128) + ReLU -> 1x1(128->4) + postprocess
-        a = self.ws("dpt_h0", (B * H1 * W1, Lc))
+        a = self.ws("dpt%d_h0" % num, (B * H1 * W1, Lc))
         ops.conv3x3(p1, w[pre + "h0.w"], a, B=B, H=H1, W_=W1, Cin=F, Cout=Lc, bias=w[pre + "h0.b"])
         OH, OW = 2 * H1, 2 * W1
-        u = self.ws("dpt_h0up", (B * OH * OW, Lc))
+        u = self.ws("dpt%d_h0up" % num, (B * OH * OW, Lc))
         ops.upsample2x(a, u, B=B, H=H1, W_=W1, C_=Lc)
-        c = self.ws("dpt_h2", (B * OH * OW, Lc))
+        c = self.ws("dpt%d_h2" % num, (B * OH * OW, Lc))
         ops.conv3x3(u, w[pre + "h2.w"], c, B=B, H=OH, W_=OW, Cin=Lc, Cout=Lc, bias=w[pre + "h2.b"], act=ACT_RELU)
         pts = self.ws("dpt_pts%d" % num, (B, OH, OW, 3))
         conf = self.ws("dpt_conf%d" % num, (B, OH, OW))

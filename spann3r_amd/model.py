@@ -286,17 +286,27 @@ class _SequenceRunner:
 
     # ---- the kernel sequences (spann3r/model.py:485-531) ----------------------------------------------------
     def _tail(self, f1):
+        """decode + key MLPs + DPT heads + value encoder + staged memory write.  The view-1 branch (decoder side 1,
+        key 1, head 1, value encoder, memory write) and the view-2 branch (decoder side 2, key 2, head 2) only meet in
+        the decoder's cross-attention, so they run on two streams."""
         eng, mem, B, P = self.eng, self.mem, self.B, self.P
-        dec1, dec2 = eng.decoder(f1, self.feat2, B, self.nh, self.nw, self.nh, self.nw)
-        eng.encode_feat_key(self.feat1, dec1[-1], B * P, 1, self.k1)
-        eng.encode_feat_key(self.feat2, dec2[-1], B * P, 2, self.k2)
-        pts1, conf1, _ = eng.dpt_head(dec1, B, self.nh, self.nw, 1)
-        pts2, conf2, _ = eng.dpt_head(dec2, B, self.nh, self.nw, 2)
-        # portrait results are handed on axis-swapped (landscape_only wrapper), and the value encoder sees that view
-        eng.encode_cur_value(pts1.swapaxes(1, 2) if self.H > self.W else pts1, self.v, self.k1)   # v = cur_v + feat_k1
-        if not self.training and mem.sim_needed():
-            mem.sim_scores(self.k1)
-        mem.stage_write(self.k1, self.v)
+        st = eng.side_streams()
+        main = torch.cuda.current_stream()
+        dec1, dec2 = eng.decoder(f1, self.feat2, B, self.nh, self.nw, self.nh, self.nw, streams=st)   # joined on return
+        st[1].wait_stream(main)
+        st[2].wait_stream(main)
+        with torch.cuda.stream(st[1]):
+            eng.encode_feat_key(self.feat1, dec1[-1], B * P, 1, self.k1)
+            pts1, conf1, _ = eng.dpt_head(dec1, B, self.nh, self.nw, 1)
+            # portrait results are handed on axis-swapped (landscape_only wrapper); the value encoder sees that view
+            eng.encode_cur_value(pts1.swapaxes(1, 2) if self.H > self.W else pts1, self.v, self.k1)   # v = cur_v + feat_k1
+            if not self.training and mem.sim_needed():
+                mem.sim_scores(self.k1)
+            mem.stage_write(self.k1, self.v)
+        with torch.cuda.stream(st[2]):
+            eng.encode_feat_key(self.feat2, dec2[-1], B * P, 2, self.k2)
+            pts2, conf2, _ = eng.dpt_head(dec2, B, self.nh, self.nw, 2)
+        eng.join(main, st)
         self.out = (pts1, conf1, pts2, conf2)
 
     def _first(self):
