@@ -178,40 +178,40 @@ class Engine:
     def _norm(self, name):
         return (self.w[name + ".w"], self.w[name + ".b"])
 
-    def _block(self, x, ln_in, R, B, P, C, heads, pre, pos32, next_norm, next_out, keep_x=True):
+    def _block(self, x, ln_in, R, B, P, C, heads, pre, pos32, next_norm, next_out, keep_x=True, tag=""):
         """Pre-LN ViT block on the fp32 stream x (croco/models/blocks.py:127-130).  `ln_in` = norm1(x) (computed by the
         producer of x); the block's last kernel also emits next_out = LayerNorm(x_new; next_norm)."""
         w = self.w
-        ao = self.wsp("attn_out", R, C)
-        self._attn_core(ln_in, R, B, P, C, heads, pre, pos32, ao)
-        ln2 = self.wsp("ln_b", R, C)
+        ao = self.wsp("attn_out" + tag, R, C)
+        self._attn_core(ln_in, R, B, P, C, heads, pre, pos32, ao, tag=tag)
+        ln2 = self.wsp("ln_b" + tag, R, C)
         self._linear_reduce(ao, w[pre + "proj.w"], w[pre + "proj.b"], R, C, C, C, res=x, x_out=x,
-                            ln1=self._norm(pre + "norm2"), out1=ln2)
+                            ln1=self._norm(pre + "norm2"), out1=ln2, tag=tag)
         Hd = C * self.cfg.mlp_ratio
-        h = self.wsp("mlp_hidden", R, Hd)
+        h = self.wsp("mlp_hidden" + tag, R, Hd)
         ops.gemm(ln2, w[pre + "fc1.w"], h, M=R, N=Hd, K=C, lda=C, ldc=Hd, bias=w[pre + "fc1.b"], act=ACT_GELU)
         self._linear_reduce(h, w[pre + "fc2.w"], w[pre + "fc2.b"], R, C, Hd, Hd, res=x, x_out=x if keep_x else None,
-                            ln1=self._norm(next_norm), out1=next_out)
+                            ln1=self._norm(next_norm), out1=next_out, tag=tag)
 
     # ------------------------------------------------------------------ stages
-    def _vit(self, col, R, B, P, patch_w, prefix, depth, pos32, final_norm, final_out):
+    def _vit(self, col, R, B, P, patch_w, prefix, depth, pos32, final_norm, final_out, tag=""):
         """patch-embed GEMM + `depth` blocks + final norm; every LayerNorm rides on the producing kernel."""
         cfg, w = self.cfg, self.w
         E = cfg.enc_dim
         K0 = col.K
-        x = self.ws("vit_x", (R, E))
-        lnA = self.wsp("ln_a", R, E)
+        x = self.ws("vit_x" + tag, (R, E))
+        lnA = self.wsp("ln_a" + tag, R, E)
         first = (prefix + "0.norm1") if depth > 0 else final_norm
         self._linear_reduce(col, w[patch_w + ".w"], w[patch_w + ".b"], R, E, K0, K0, x_out=x, ln1=self._norm(first),
-                            out1=lnA if depth > 0 else final_out)
+                            out1=lnA if depth > 0 else final_out, tag=tag)
         for i in range(depth):
             last = i == depth - 1
             nxt = final_norm if last else prefix + "%d.norm1" % (i + 1)
             self._block(x, lnA, R, B, P, E, cfg.enc_heads, prefix + "%d." % i, pos32, nxt, final_out if last else lnA,
-                        keep_x=not last)
+                        keep_x=not last, tag=tag)
         return final_out
 
-    def encode_image(self, img, out=None):
+    def encode_image(self, img, out=None, tag=""):
         """dust3r._encode_image (dust3r/model.py:131-154): patch embed -> enc_depth blocks -> enc_norm.
         img fp32 [B,3,H,W] on device -> feat [B,P,1024] (written to `out` if given), pos int64 [B,P,2]."""
         cfg = self.cfg
@@ -222,11 +222,11 @@ class Engine:
         P, E = nh * nw, cfg.enc_dim
         R = B * P
         pos64, pos32, _ = self.positions(B, nh, nw)
-        col = self.wsp("im2col", R, 3 * p * p)
+        col = self.wsp("im2col" + tag, R, 3 * p * p)
         ops.im2col_patch(img, col, B=B, C_=3, H=H, W_=W_, p=p, strides=img.stride())
         if out is None:
             out = torch.empty(B, P, E, device=self.device)
-        self._vit(col, R, B, P, "patch", "enc", cfg.enc_depth, pos32, "enc_norm", out)
+        self._vit(col, R, B, P, "patch", "enc", cfg.enc_depth, pos32, "enc_norm", out, tag=tag)
         return out, pos64
 
     def side_streams(self):
@@ -234,7 +234,7 @@ class Engine:
         layer pair) and the two DPT heads are independent, so they run concurrently; under hipGraph capture the
         fork/join becomes graph edges."""
         if getattr(self, "_streams", None) is None:
-            self._streams = {1: torch.cuda.Stream(device=self.device), 2: torch.cuda.Stream(device=self.device)}
+            self._streams = {k: torch.cuda.Stream(device=self.device) for k in (1, 2, 3)}
         return self._streams
 
     def fork(self):
@@ -445,11 +445,11 @@ class Engine:
         P = nh * nw
         R = B * P
         _, _, zero_pos = self.positions(B, nh, nw)
-        col = self.wsp("im2col", R, 3 * p * p)
+        col = self.wsp("im2col_val", R, 3 * p * p)
         sb, sy, sx, sc = pts3d.stride()
         ops.im2col_patch(pts3d, col, B=B, C_=3, H=H, W_=W_, p=p, strides=(sb, sc, sy, sx))
         # rope=None in the reference (mem_pos_enc=False): all-zero positions make the fused RoPE the identity
         vn = self.wsp("val_normed", R, E)
-        self._vit(col, R, B, P, "pospatch", "val", cfg.val_depth, zero_pos, "value_norm", vn)
-        self._linear_reduce(vn, w["value_out.w"], w["value_out.b"], R, E, E, E, res=res, x_out=out)
+        self._vit(col, R, B, P, "pospatch", "val", cfg.val_depth, zero_pos, "value_norm", vn, tag="_val")
+        self._linear_reduce(vn, w["value_out.w"], w["value_out.b"], R, E, E, E, res=res, x_out=out, tag="_val")
         return out

@@ -264,6 +264,8 @@ class _SequenceRunner:
         self.P, self.E = self.nh * self.nw, cfg.enc_dim
         dev = eng.device
         self.img_pair = torch.empty(2 * B, 3, H, W, device=dev)
+        self.img_next = torch.empty(B, 3, H, W, device=dev)          # frame i+2, encoded one step ahead
+        self.feat_pre = torch.empty(B, self.P, self.E, device=dev)
         self.featpair = torch.empty(2 * B, self.P, self.E, device=dev)
         self.feat1, self.feat2 = self.featpair[:B], self.featpair[B:]
         self.fuse = torch.empty(B, self.P, self.E, device=dev)
@@ -285,13 +287,18 @@ class _SequenceRunner:
         return self.mem
 
     # ---- the kernel sequences (spann3r/model.py:485-531) ----------------------------------------------------
-    def _tail(self, f1):
+    def _tail(self, f1, has_next):
         """decode + key MLPs + DPT heads + value encoder + staged memory write.  The view-1 branch (decoder side 1,
         key 1, head 1, value encoder, memory write) and the view-2 branch (decoder side 2, key 2, head 2) only meet in
-        the decoder's cross-attention, so they run on two streams."""
+        the decoder's cross-attention, so they run on two streams; a third stream encodes the NEXT frame (each frame
+        is still encoded exactly once, spann3r/model.py:293-295 -- one step earlier than the reference does it)."""
         eng, mem, B, P = self.eng, self.mem, self.B, self.P
         st = eng.side_streams()
         main = torch.cuda.current_stream()
+        if has_next:
+            st[3].wait_stream(main)
+            with torch.cuda.stream(st[3]):
+                eng.encode_image(self.img_next, out=self.feat_pre, tag="_pre")
         dec1, dec2 = eng.decoder(f1, self.feat2, B, self.nh, self.nw, self.nh, self.nw, streams=st)   # joined on return
         st[1].wait_stream(main)
         st[2].wait_stream(main)
@@ -306,24 +313,27 @@ class _SequenceRunner:
         with torch.cuda.stream(st[2]):
             eng.encode_feat_key(self.feat2, dec2[-1], B * P, 2, self.k2)
             pts2, conf2, _ = eng.dpt_head(dec2, B, self.nh, self.nw, 2)
-        eng.join(main, st)
+        main.wait_stream(st[1])
+        main.wait_stream(st[2])
+        if has_next:
+            main.wait_stream(st[3])
         self.out = (pts1, conf1, pts2, conf2)
 
-    def _first(self):
+    def _first(self, has_next):
         self.eng.encode_image(self.img_pair, out=self.featpair)
-        self._tail(self.feat1)
+        self._tail(self.feat1, has_next)
 
-    def _step(self):
+    def _step(self, has_next):
         eng, B, P, E = self.eng, self.B, self.P, self.E
         ops.copy2d(self.feat2, E, self.feat1, E, B * P, E)      # feat1 <- previous feat2 (:294)
-        eng.encode_image(self.img_pair[B:], out=self.feat2)
+        ops.copy2d(self.feat_pre, E, self.feat2, E, B * P, E)   # feat2 <- the frame encoded during the previous step
         self.mem.memory_read(self.k2, self.fuse)                # reads k2 before _tail overwrites it
-        self._tail(self.fuse)
+        self._tail(self.fuse, has_next)
 
-    def run(self, first, use_graphs):
+    def run(self, first, has_next, use_graphs):
         mem = self.mem
-        key = ("first" if first else "step", mem.M, mem.wm, mem._cur)
-        fn = self._first if first else self._step
+        key = ("first" if first else "step", mem.M, mem.wm, mem._cur, has_next)
+        fn = (lambda: self._first(has_next)) if first else (lambda: self._step(has_next))
         if not use_graphs:
             fn()
         elif key in self.graphs:
@@ -533,11 +543,15 @@ class Spann3R(nn.Module):
             run = self._runners[key] = _SequenceRunner(self, eng, B, H, W, bool(self.training))
         mem = run.ensure_memory(len(frames))
         preds, preds_all = None, []
-        for i in range(len(frames) - 1):
+        n = len(frames)
+        for i in range(n - 1):
             if i == 0:
                 run.img_pair[:B].copy_(frames[0]["img"])
-            run.img_pair[B:].copy_(frames[i + 1]["img"])
-            res1, res2 = run.run(i == 0, self.use_graphs)
+                run.img_pair[B:].copy_(frames[1]["img"])
+            has_next = i + 2 < n
+            if has_next:
+                run.img_next.copy_(frames[i + 2]["img"])
+            res1, res2 = run.run(i == 0, has_next, self.use_graphs)
             res2["pts3d_in_other_view"] = res2.pop("pts3d")                      # :523
             if preds is None:
                 preds = [res1]
