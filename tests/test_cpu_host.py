@@ -1,0 +1,165 @@
+"""Host-side logic that needs no GPU: the C-ABI surface, the drop-in boundary (constructor, state dict, error
+behaviour) and the multi-process sequence sharding (gloo, world size 2)."""
+import argparse
+import ctypes
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import pytest
+import torch
+
+from conftest import REPO
+
+
+# ----------------------------------------------------------------------------- C-ABI
+def _header():
+    return open(os.path.join(REPO, "include", "spann3r_hip.h")).read()
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as g
+    from spann3r_amd import lib
+    if not os.path.exists(lib.LIB_PATH):
+        g.build()
+    l = lib.load()
+    declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(sp3_\w+)\s*\(", _header(), flags=re.M))
+    assert len(declared) >= 24
+    for name in declared:
+        assert hasattr(l, name), "missing export " + name
+    assert declared == set(lib.EXPORTS), declared ^ set(lib.EXPORTS)
+    assert l.sp3_version() >= 1
+
+
+def test_ctypes_structs_match_the_header():
+    """sizeof / offsetof of the two descriptor structs, as gcc sees include/spann3r_hip.h, equal the ctypes mirror."""
+    from spann3r_amd import lib
+    fields_g = [f[0] for f in lib.GemmDesc._fields_]
+    fields_r = [f[0] for f in lib.ReduceLnDesc._fields_]
+    src = '#include "%s"\n#include <stdio.h>\n#include <stddef.h>\nint main(){\n' % os.path.join(REPO, "include", "spann3r_hip.h")
+    src += 'printf("%zu\\n", sizeof(sp3_gemm_desc));\n'
+    src += "".join('printf("%%zu\\n", offsetof(sp3_gemm_desc, %s));\n' % f for f in fields_g)
+    src += 'printf("%zu\\n", sizeof(sp3_reduce_ln_desc));\n'
+    src += "".join('printf("%%zu\\n", offsetof(sp3_reduce_ln_desc, %s));\n' % f for f in fields_r)
+    src += "return 0;}\n"
+    with tempfile.TemporaryDirectory() as d:
+        c, exe = os.path.join(d, "p.c"), os.path.join(d, "p")
+        open(c, "w").write(src)
+        subprocess.check_call(["gcc", c, "-o", exe])
+        vals = [int(x) for x in subprocess.check_output([exe]).split()]
+    exp = [ctypes.sizeof(lib.GemmDesc)] + [getattr(lib.GemmDesc, f).offset for f in fields_g]
+    exp += [ctypes.sizeof(lib.ReduceLnDesc)] + [getattr(lib.ReduceLnDesc, f).offset for f in fields_r]
+    assert vals == exp
+
+
+def test_argument_validation_reports_errors_without_a_gpu():
+    """Every entry point validates before it launches; failures come back as rc != 0 + sp3_last_error()."""
+    from spann3r_amd import lib
+    l = lib.load()
+    d = lib.GemmDesc()
+    assert l.sp3_gemm(ctypes.byref(d), None) != 0
+    assert b"null A/W/C" in l.sp3_last_error()
+    with pytest.raises(RuntimeError, match="sp3_layernorm"):
+        lib.check(l.sp3_layernorm(None, 0, None, None, 1e-6, None, 0, 0, 4, 1024, None), "sp3_layernorm")
+    assert l.sp3_rope_2d(1, 0, 1, 1, 1, 6, 0, 0, 0, 1, 100.0, 1.0, None) != 0      # D % 4 != 0, curope.cpp's check
+    assert b"multiple of 4" in l.sp3_last_error()
+
+
+# ----------------------------------------------------------------------------- drop-in boundary
+def test_state_dict_contract():
+    """1101 keys (8 aliases), 658.69 M parameters, same key order as the reference."""
+    from spann3r_amd.config import FULL
+    from spann3r_amd.weights import param_spec, alias_of
+    spec = param_spec(FULL)
+    assert len(spec) == 1101
+    aliases = [k for k in spec if alias_of(k)]
+    assert len(aliases) == 8
+    n = sum(int(torch.tensor(s).prod()) for k, s in spec.items() if not alias_of(k))
+    assert abs(n / 1e6 - 658.69) < 0.01
+    assert spec["dust3r.enc_blocks.23.attn.qkv.weight"] == (3072, 1024)
+    assert spec["dust3r.downstream_head1.dpt.act_postprocess.0.1.weight"] == (96, 96, 4, 4)
+    assert spec["attn_head_2.0.weight"] == (1792, 1792)
+
+
+def test_constructor_from_reference_checkpoint(tiny_sd):
+    """Spann3R(dus3r_name=<file>) reads the DUSt3R checkpoint the way dust3r/model.py:27-51,94-101 does: geometry from
+    the constructor string, dec_blocks duplicated into dec_blocks2 when absent, pos_patch_embed cloned from patch_embed."""
+    from spann3r_amd import Spann3R, TINY
+    from spann3r_amd.config import Spann3RConfig
+    dust3r = {k[len("dust3r."):]: v for k, v in tiny_sd.items() if k.startswith("dust3r.") and "dec_blocks2" not in k}
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "dust3r.pth")
+        torch.save({"args": argparse.Namespace(model=TINY.ctor_string()), "model": dust3r}, path)
+        m = Spann3R(dus3r_name=path, use_feat=False, init_weights=False)
+    assert m.cfg == TINY and hasattr(m, "dust3r") and not m.training is False
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(tiny_sd.keys())
+    assert torch.equal(sd["dust3r.dec_blocks2.3.mlp.fc1.weight"], tiny_sd["dust3r.dec_blocks.3.mlp.fc1.weight"])
+    assert torch.equal(sd["pos_patch_embed.proj.weight"], tiny_sd["dust3r.patch_embed.proj.weight"])
+    assert sd["dust3r.downstream_head1.dpt.scratch.layer_rn.2.weight"].data_ptr() == \
+        sd["dust3r.downstream_head1.dpt.scratch.layer3_rn.weight"].data_ptr()
+    assert Spann3RConfig.from_ctor_string(TINY.ctor_string("PatchEmbedDust3R")) == TINY
+    with pytest.raises(ValueError):
+        Spann3RConfig.from_ctor_string("AsymmetricCroCo3DStereo(enc_embed_dim=768, dec_depth=12)")
+    with pytest.raises(NotImplementedError):
+        Spann3R(dus3r_name=None, use_feat=True)
+
+
+def test_no_cpu_fallback(tiny_sd):
+    from spann3r_amd import Spann3R, TINY
+    m = Spann3R(dus3r_name=None, cfg=TINY, init_weights=False).eval()
+    m.load_state_dict(tiny_sd)
+    frames = [{"img": torch.zeros(1, 3, 32, 32)}] * 2
+    with pytest.raises(RuntimeError, match="MI355X"):
+        m(frames)
+    m.train()
+    with pytest.raises(NotImplementedError, match="dropout"):
+        m(frames)
+
+
+def test_bench_flop_model():
+    sys.path.insert(0, REPO)
+    import bench
+    assert abs(bench.flops_per_sequence(10, 224) / 1e9 - 3260.5) < 1.0
+    assert abs(bench.flops_per_sequence(50, 512) / 1e9 - 1.061e5) / 1.061e5 < 0.01
+
+
+# ----------------------------------------------------------------------------- multi-process sharding (gloo, world 2)
+WORKER = r'''
+import os, sys
+sys.path.insert(0, %(repo)r)
+import torch, torch.distributed as dist
+from spann3r_amd.runner import shard, gather_stats, aggregate, run_sequences, make_sequence
+dist.init_process_group(backend="gloo", init_method="env://")
+rank, world = dist.get_rank(), dist.get_world_size()
+ids = shard(6, rank, world)
+seqs = [make_sequence(s, 3, 32, 48) for s in ids]
+def fwd(seq):                                   # stand-in for model.forward: the sharding/timing/gather path is what is tested
+    return float(sum(f["img"].sum() for f in seq))
+frames, seconds, last = run_sequences(fwd, seqs)
+dist.barrier()
+stats = gather_stats(frames, seconds, extra=[float(sum(ids))])
+fps, tot, mx = aggregate(stats)
+if rank == 0:
+    assert stats.shape == (2, 3), stats.shape
+    assert tot == 18 and sorted(stats[:, 2].tolist()) == [6.0, 9.0], stats
+    assert mx == float(stats[:, 1].max()) and fps == tot / mx
+    print("OK", tot)
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_sharding_and_stats_gather():
+    with tempfile.TemporaryDirectory() as d:
+        script = os.path.join(d, "w.py")
+        open(script, "w").write(WORKER % {"repo": REPO})
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", WORLD_SIZE="2")
+        procs = [subprocess.Popen([sys.executable, script], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                                  stderr=subprocess.STDOUT) for r in range(2)]
+        outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+        assert all(p.returncode == 0 for p in procs), outs
+        assert "OK 18" in outs[0]
+    from spann3r_amd.runner import shard
+    assert shard(8, 3, 8) == [3] and shard(10, 1, 4) == [1, 5, 9]
