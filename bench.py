@@ -157,9 +157,14 @@ def main():
                                     "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else None}
                                    for k, v in top[:8]]
         out["profiled_sequence_kernel_ms"] = total_ms
-        mr = getattr(model, "last_memread", None)
-        if mr:
-            out["memread"] = mr
+        reads = [r for r in prof.region_summary() if r["key"] == "memread"]
+        if reads:
+            big = max(reads, key=lambda r: r["info"]["M"])
+            gbs = big["bytes"] / (big["ms"] * 1e-3) / 1e9
+            out["memread"] = {"what": "spatial-memory read (LN_q, S = q.K_hat^T/32, softmax+threshold, P.V_hat + q, colsum)",
+                              "bank_tokens": big["info"]["M"], "algorithmic_bytes": big["bytes"], "us": 1e3 * big["ms"],
+                              "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                              "reads_per_sequence": len(reads), "all_reads_us": [round(1e3 * r["ms"], 2) for r in reads]}
 
     # ---- CPU baseline: the oracle (port of the reference algorithm) on this box's host cores, bounded sample
     if not args.no_cpu_baseline:

@@ -1,0 +1,44 @@
+#!/usr/bin/env python
+"""The timed region of the reference's demo.py (lines 81-132) on synthetic frames: build the model, load a state dict,
+move only view['img'] to the device, time model.forward(batch), report FPS = len(batch) / seconds (with the device sync the
+reference omits).  The real demo.py cannot be imported in this image (cv2 / open3d / torchvision are not installed)."""
+import argparse
+import time
+
+import torch
+
+from spann3r_amd import Spann3R, FULL, TINY
+from spann3r_amd.weights import synth_state_dict, synth_frames
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=10)
+    ap.add_argument("--size", type=int, default=224)
+    ap.add_argument("--tiny", action="store_true", help="2-layer encoder / 10-layer decoder geometry (quick look)")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--repeat", type=int, default=3)
+    args = ap.parse_args()
+    cfg = TINY if args.tiny else FULL
+    device = "cuda"
+    model = Spann3R(dus3r_name=None, cfg=cfg, init_weights=False).to(device)      # demo.py:81-82
+    model.load_state_dict(synth_state_dict(0, cfg))                               # demo.py:84 (no checkpoint ships)
+    model.eval().set_precision(args.precision)
+    batch = synth_frames(args.frames, args.size, args.size)
+    for view in batch:                                                            # demo.py:94-95
+        view["img"] = view["img"].to(device, non_blocking=True)
+    for it in range(args.repeat):
+        torch.cuda.synchronize()
+        start = time.time()
+        preds, preds_all = model.forward(batch)                                   # demo.py:125
+        torch.cuda.synchronize()
+        end = time.time()
+        print("Time: %.4f s, FPS: %.1f  (%d frames, call %d: %s)" %
+              (end - start, len(batch) / (end - start), len(batch), it,
+               ["eager warm-up", "hipGraph capture", "hipGraph replay"][min(it, 2)]))
+    pts = preds[-1]["pts3d_in_other_view"]
+    print("last frame: pts3d_in_other_view", tuple(pts.shape), "conf mean %.3f" % float(preds[-1]["conf"].mean()))
+
+
+if __name__ == "__main__":
+    main()

@@ -116,6 +116,8 @@ class SpatialMemory:
         eng, bk, w = self.eng, self.bank, self.eng.w
         B, P, C, M = self.B, self.P, self.C, self.M
         assert M > 0
+        prof = ops._prof
+        e0 = prof.region_begin() if prof is not None else None
         Mpad = (M + 7) // 8 * 8
         ld = (self.cap + 7) // 8 * 8
         qn = eng.ws("mem_qn", (B * P, C), eng.adt)      # row-major: the S GEMM is batched over sequences
@@ -129,6 +131,10 @@ class SpatialMemory:
                  strideA=P * ld, strideW=C * self.cap, strideC=P * C)
         for b in range(B):
             ops.colsum_accum(Pm[b], ld, P, M, bk["attn"][b])
+        if prof is not None:
+            es = bk["k_hat"].element_size()
+            # algorithmic bytes of one read: K_hat + V_hat once, plus the query in and the fused features out
+            prof.region_end("memread", e0, B * (2.0 * M * C * es + 2.0 * P * C * 4), info={"M": M, "tokens_per_frame": P})
         return out
 
     # ------------------------------------------------------------------ write (:80-95)
@@ -335,6 +341,8 @@ class _SequenceRunner:
         key = ("first" if first else "step", mem.M, mem.wm, mem._cur, has_next)
         fn = (lambda: self._first(has_next)) if first else (lambda: self._step(has_next))
         if not use_graphs:
+            if ops._prof is not None:
+                ops._prof.step_begin()
             fn()
         elif key in self.graphs:
             self.graphs[key].replay()

@@ -21,8 +21,27 @@ class Profiler:
     """Brackets every launch with HIP events on the launch stream (torch's current stream) and books the
     ALGORITHMIC flops / bytes of the launch (bench.py's `roofline` object is computed from this)."""
 
-    def __init__(self):
+    def __init__(self, blocker_ms=12.0):
         self.rec = []
+        self.regions = []
+        self.blocker_cycles = int(blocker_ms * 2.4e6)
+
+    def step_begin(self):
+        """Park the GPU on a spin kernel while the host enqueues the whole step, so that the event brackets below
+        measure back-to-back kernel execution instead of host launch gaps (eager launches are host-bound)."""
+        torch.cuda._sleep(self.blocker_cycles)
+
+    def region_begin(self):
+        return self.begin()
+
+    def region_end(self, key, e0, nbytes, info=None):
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.regions.append((key, e0, e1, float(nbytes), info))
+
+    def region_summary(self):
+        torch.cuda.synchronize()
+        return [dict(key=k, ms=e0.elapsed_time(e1), bytes=b, info=i) for k, e0, e1, b, i in self.regions]
 
     def begin(self):
         e = torch.cuda.Event(enable_timing=True)
