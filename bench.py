@@ -131,6 +131,7 @@ def main():
             model.use_graphs = False
         fwd(seqs[0])
         prof = ops.Profiler()
+        out["event_bracket_overhead_us"] = 1e3 * prof.calibrate()
         ops.set_profiler(prof)
         fwd(seqs[0])
         ops.set_profiler(None)

@@ -53,13 +53,31 @@ class Profiler:
         e1.record()
         self.rec.append((key, e0, e1, float(flops), float(nbytes)))
 
+    def calibrate(self, n=200):
+        """Cost of an EMPTY event bracket on a busy stream (the event packets themselves take a few us on the GPU);
+        summary() subtracts it from every bracket."""
+        torch.cuda.synchronize()
+        self.step_begin()
+        ev = []
+        for _ in range(n):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            e1.record()
+            ev.append((e0, e1))
+        torch.cuda.synchronize()
+        t = sorted(a.elapsed_time(b) for a, b in ev)
+        self.bracket_ms = t[len(t) // 2]
+        return self.bracket_ms
+
     def summary(self):
         torch.cuda.synchronize()
         agg = {}
+        ov = getattr(self, "bracket_ms", 0.0)
         for key, e0, e1, fl, by in self.rec:
             a = agg.setdefault(key, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
             a["launches"] += 1
-            a["ms"] += e0.elapsed_time(e1)
+            a["ms"] += max(e0.elapsed_time(e1) - ov, 1e-4)
             a["flops"] += fl
             a["bytes"] += by
         return agg

@@ -91,3 +91,23 @@ def test_hip_rope_equals_c_restatement():
     t = tok.clone().cuda()
     ops.rope_2d(t.transpose(1, 2), pos.cuda(), 100.0, 1.0)
     assert rel_err(t.cpu(), bnhd.transpose(1, 2)) < 1e-5
+
+
+@pytest.mark.gpu
+def test_curope_dropin_module():
+    """spann3r_amd.curope.cuRoPE2D has the reference module's semantics (curope2d.py:32-40): [B,H,N,D] in, in place,
+    and the autograd function's backward undoes the forward rotation."""
+    from spann3r_amd.curope import cuRoPE2D, cuRoPE2D_func
+    tok, pos = _case()
+    rope = cuRoPE2D(freq=100.0)
+    t = tok.clone().cuda()
+    out = rope(t, pos.cuda())
+    assert out.data_ptr() == t.data_ptr()
+    assert rel_err(out.cpu(), O.rope2d(tok, pos, 100.0, 1.0)) < 1e-5
+    x = tok.clone().cuda().transpose(1, 2).contiguous().requires_grad_(True)
+    y = cuRoPE2D_func.apply(x.clone(), pos.cuda(), 100.0, 1.0)
+    g = torch.ones_like(y)
+    y.backward(g.clone())
+    # d/dx sum(rope(x)) = rope^-1 applied to ones
+    ones = torch.ones_like(tok)
+    assert rel_err(x.grad.cpu().transpose(1, 2), O.rope2d(ones, pos, 100.0, -1.0)) < 1e-5
