@@ -93,6 +93,8 @@ typedef struct sp3_gemm_desc {
   int32_t splitk;         /* >= 1; > 1 only with SP3_EPI_PARTIAL */
   int32_t a_packed;       /* A is in MFMA-fragment order [ceil(M/16)][ceil(K/KB)][64 lanes][CH] (see w_packed); written
                              that way by the producing kernel (out_packed options), plain loader only */
+  int32_t qkv_packed;     /* ROPE_VT epilogue, bf16: q/k stored in fragment order (rows = b*vt_ld + n, K-dim = rope_cols) and
+                             V in PV-operand order [(b,h)][vt_ld/32][4][64][8] -- the layouts sp3_attention_packed reads */
   int32_t out_packed;     /* plain epilogue: store C in fragment order (it is the next GEMM's packed A; dims M x N) */
   int32_t w_packed;       /* W is in MFMA-fragment order [ceil(N/16)][ceil(K/KB)][64 lanes][CH], zero padded; KB/CH =
                              64/16 (bf16) or 32/8 (fp32); lane = 16*g + r holds row 16*nb + r, k = kb*KB + g*CH + e */
@@ -159,6 +161,14 @@ int sp3_attention(const void* q, int64_t sq, int64_t ldq, const void* k, int64_t
 int sp3_attention_ex(const void* q, int64_t sq, int64_t ldq, const void* k, int64_t sk, int64_t ldk,
                      const void* vt, int64_t vt_ld, void* out, int64_t ldo, int out_bf16, int out_packed,
                      int B, int heads, int Nq, int Nk, float scale, int dtype, void* stream);
+
+/* bf16 attention on the fragment-order q/k and PV-order V written by the qkv_packed ROPE_VT epilogue: every operand load
+ * is one contiguous wave read, the next key tile is prefetched during the softmax.  qp/kp: packed [B*npad_q|npad_k, q_cols|k_cols]
+ * matrices, head h of q at columns q_col0 + 64h (k: k_col0 + 64h); vtp as described at qkv_packed (vt_ld = npad_k).
+ * out: fp32/bf16 row-major [B*Nq, ldo] or fragment order (out_packed). */
+int sp3_attention_packed(const void* qp, int q_cols, int q_col0, int npad_q, const void* kp, int k_cols, int k_col0, int npad_k,
+                         const void* vtp, void* out, int64_t ldo, int out_bf16, int out_packed,
+                         int B, int heads, int Nq, int Nk, float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Spatial-memory kernels (spann3r/model.py:97-210).

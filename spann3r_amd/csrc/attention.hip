@@ -171,6 +171,147 @@ __global__ __launch_bounds__(64) void attention_kernel(const T* __restrict__ Q, 
   }
 }
 
+
+// ------------------------------------------------------------------ bf16, fragment-order operands, prefetching
+struct KFrag { bf16x8 v[2]; };
+
+__device__ __forceinline__ KFrag load_frag(const __bf16* base, int row, int col, int K) {
+  // lane (g, r) of a 16-row block reads its 16 contiguous elements (d = 16g .. 16g+15 of the head at `col`)
+  const __bf16* p = base + packed_off(row, col, K, true);
+  KFrag f;
+  f.v[0] = *reinterpret_cast<const bf16x8*>(p);
+  f.v[1] = *reinterpret_cast<const bf16x8*>(p + 8);
+  return f;
+}
+
+// One workgroup = 16 query rows of one head; its 4 waves split the key tiles (tile t goes to wave t & 3), each running
+// an independent online softmax; the four partial (m, l, O^T) states are merged through LDS (wave w merges d-block w).
+// At N = 196 (4 tiles) every wave handles ONE tile: the dependent chain is 1 tile instead of 4.
+__global__ __launch_bounds__(256) void attention_packed_kernel(const __bf16* __restrict__ QP, int q_cols, int q_col0, int npad_q,
+                                                               const __bf16* __restrict__ KP, int k_cols, int k_col0, int npad_k,
+                                                               const __bf16* __restrict__ VTP, void* __restrict__ O, int64_t ldo,
+                                                               int out_bf16, int out_packed, int heads, int Nq, int Nk, float scale) {
+  __shared__ float sh_o[4][4][64][4];   // [wave][db][lane][r]
+  __shared__ float sh_m[4][64], sh_l[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, ql = lane & 15;
+  const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int q0 = qt * 16;
+  const KFrag qf = load_frag(QP, b * npad_q + q0 + ql, q_col0 + h * 64 + 16 * g, q_cols);
+  const int krow0 = b * npad_k;
+  const int kcol = k_col0 + h * 64 + 16 * g;
+  const int64_t nU = npad_k >> 5;
+  const __bf16* vbase = VTP + ((int64_t)(b * heads + h) * nU * 4 * 64 + lane) * 8;
+  const int ntiles = (Nk + 63) >> 6;
+  const float sl2 = scale * 1.4426950408889634f;     // softmax in base 2: exp(x) = exp2(x * log2 e), v_exp_f32
+
+  f32x4 o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+
+  if (wave < ntiles) {
+    KFrag kc[4], kn[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) kc[t] = load_frag(KP, krow0 + (wave << 6) + 16 * t + ql, kcol, k_cols);
+    for (int tile = wave; tile < ntiles; tile += 4) {
+      const int kb = tile << 6;
+      // V of this tile and K of this wave's next tile are requested before any arithmetic (unconditional loads: the
+      // last iteration re-reads its own tile)
+      bf16x8 vv[2][4];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+          vv[u][db] = *reinterpret_cast<const bf16x8*>(vbase + (((int64_t)(2 * tile + u)) * 4 + db) * 64 * 8);
+      const int nkb = (tile + 4 < ntiles ? tile + 4 : tile) << 6;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) kn[t] = load_frag(KP, krow0 + nkb + 16 * t + ql, kcol, k_cols);
+
+      f32x4 s[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc[t].v[0], qf.v[0], s[t], 0, 0, 0);
+        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc[t].v[1], qf.v[1], s[t], 0, 0, 0);
+      }
+      float mx = -INFINITY;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kb + 16 * t + 4 * g + r;
+          const float v = key < Nk ? s[t][r] * sl2 : -INFINITY;
+          s[t][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = exp2f(m_run - m_new);
+      float ps = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = exp2f(s[t][r] - m_new);
+          s[t][r] = e;
+          ps += e;
+        }
+      l_run = l_run * alpha + ps;
+      m_run = m_new;
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[db][r] *= alpha;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        bf16x8 pb;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pb[j] = (__bf16)s[2 * u + (j >> 2)][j & 3];
+#pragma unroll
+        for (int db = 0; db < 4; ++db) o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vv[u][db], pb, o[db], 0, 0, 0);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) kc[t] = kn[t];
+    }
+    l_run += __shfl_xor(l_run, 16);
+    l_run += __shfl_xor(l_run, 32);
+  }
+  // ---- merge the four per-wave states (base-2 running max m, sum l, O^T)
+  sh_m[wave][lane] = m_run;
+  sh_l[wave][lane] = l_run;
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+    *reinterpret_cast<float4*>(&sh_o[wave][db][lane][0]) = make_float4(o[db][0], o[db][1], o[db][2], o[db][3]);
+  __syncthreads();
+  float M = sh_m[0][lane];
+#pragma unroll
+  for (int w = 1; w < 4; ++w) M = fmaxf(M, sh_m[w][lane]);
+  float L = 0.f;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int db = wave;                       // this wave merges d-block `wave`
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const float sc = exp2f(sh_m[w][lane] - M);            // 0 for a wave that saw no tile (m = -inf)
+    L += sh_l[w][lane] * sc;
+    const float4 ow = *reinterpret_cast<const float4*>(&sh_o[w][db][lane][0]);
+    acc.x += ow.x * sc; acc.y += ow.y * sc; acc.z += ow.z * sc; acc.w += ow.w * sc;
+  }
+  const float inv = 1.0f / L;
+  if (q0 + ql < Nq) {
+    const int row = b * Nq + q0 + ql;
+    const int col = h * 64 + db * 16 + 4 * g;
+    const int64_t off = out_packed ? packed_off(row, col, heads * 64, out_bf16 != 0) : (int64_t)row * ldo + col;
+    if (out_bf16) {
+      bf16x4 ob;
+      ob[0] = (__bf16)(acc.x * inv); ob[1] = (__bf16)(acc.y * inv); ob[2] = (__bf16)(acc.z * inv); ob[3] = (__bf16)(acc.w * inv);
+      *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(O) + off) = ob;
+    } else {
+      *reinterpret_cast<float4*>(reinterpret_cast<float*>(O) + off) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int sp3_attention_ex(const void* q, int64_t sq, int64_t ldq, const void* k, int64_t sk, int64_t ldk, const void* vt,
@@ -199,4 +340,20 @@ extern "C" int sp3_attention(const void* q, int64_t sq, int64_t ldq, const void*
                              int64_t vt_ld, void* out, int64_t ldo, int out_bf16, int B, int heads, int Nq, int Nk, float scale,
                              int dtype, void* stream) {
   return sp3_attention_ex(q, sq, ldq, k, sk, ldk, vt, vt_ld, out, ldo, out_bf16, 0, B, heads, Nq, Nk, scale, dtype, stream);
+}
+
+extern "C" int sp3_attention_packed(const void* qp, int q_cols, int q_col0, int npad_q, const void* kp, int k_cols, int k_col0,
+                                    int npad_k, const void* vtp, void* out, int64_t ldo, int out_bf16, int out_packed, int B,
+                                    int heads, int Nq, int Nk, float scale, void* stream) {
+  SP3_CHECK(qp && kp && vtp && out, "sp3_attention_packed: null pointer");
+  SP3_CHECK(B > 0 && heads > 0 && Nq > 0 && Nk > 0, "sp3_attention_packed: bad shape");
+  SP3_CHECK(npad_q % 16 == 0 && npad_q >= ((Nq + 15) / 16) * 16 && npad_k % 64 == 0 && npad_k >= ((Nk + 63) / 64) * 64,
+            "sp3_attention_packed: npad_q=%d / npad_k=%d do not cover Nq=%d / Nk=%d", npad_q, npad_k, Nq, Nk);
+  SP3_CHECK(q_cols % 64 == 0 && k_cols % 64 == 0 && q_col0 % 64 == 0 && k_col0 % 64 == 0, "sp3_attention_packed: column geometry");
+  SP3_CHECK(out_packed || ldo % 4 == 0, "sp3_attention_packed: ldo");
+  hipLaunchKernelGGL(attention_packed_kernel, dim3((Nq + 15) / 16, heads, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const __bf16*>(qp), q_cols, q_col0, npad_q, reinterpret_cast<const __bf16*>(kp), k_cols, k_col0,
+                     npad_k, reinterpret_cast<const __bf16*>(vtp), out, ldo, out_bf16, out_packed, heads, Nq, Nk, scale);
+  SP3_LAUNCH_CHECK("sp3_attention_packed");
+  return 0;
 }

@@ -446,7 +446,16 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_kernel(const GemmArgs 
       const int vc = gn - d.rope_cols;
       const int h = vc >> 6, dd = vc & 63;
       const int b = gm / d.tokens, n = gm - b * d.tokens;
-      vt[((int64_t)(b * d.heads + h) * 64 + dd) * d.vt_ld + n] = (TW)v;
+      if (d.qkv_packed) {
+        // PV-operand order [(b,h)][key/32][d/16][lane = 16*g + d%16][8]: the 8 keys a lane feeds to one
+        // v_mfma_f32_16x16x32 (keys 32u + 16*(e>>2) + 4g + (e&3)) are contiguous -> 1 KB contiguous per wave load
+        const int u = n >> 5, kk = n & 31, w16 = kk & 15;
+        const int e = (w16 & 3) + 4 * (kk >> 4), lane_ = (w16 >> 2) * 16 + (dd & 15);
+        const int64_t nU = d.vt_ld >> 5;
+        vt[((((int64_t)(b * d.heads + h) * nU + u) * 4 + (dd >> 4)) * 64 + lane_) * 8 + e] = (TW)v;
+      } else {
+        vt[((int64_t)(b * d.heads + h) * 64 + dd) * d.vt_ld + n] = (TW)v;
+      }
     }
     return;
   }
@@ -474,7 +483,13 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_kernel(const GemmArgs 
       const int hc = gn & 63;
       const int axis = hc >> 5, is_v = (hc >> 4) & 1, i0 = hc & 15;
       const int pos = d.pos[(int64_t)gm * 2 + axis];
-      TW* out = reinterpret_cast<TW*>(d.C) + (int64_t)bz * d.strideC + (int64_t)gm * d.ldc + gn;
+      TW* out;
+      if (d.qkv_packed) {      // fragment order, rows padded per image to vt_ld (a multiple of 64) tokens
+        const int b = gm / d.tokens, n = gm - b * d.tokens;
+        out = reinterpret_cast<TW*>(d.C) + packed_off(b * (int)d.vt_ld + n, gn, d.rope_cols, true);
+      } else {
+        out = reinterpret_cast<TW*>(d.C) + (int64_t)bz * d.strideC + (int64_t)gm * d.ldc + gn;
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float self = v[e] + (d.bias ? d.bias[gn + e] : 0.f);
@@ -622,6 +637,8 @@ extern "C" int sp3_gemm(const sp3_gemm_desc* dp, void* stream_) {
     SP3_CHECK(d.rope_cols == 0 || (d.rope_cos && d.rope_sin && d.pos), "sp3_gemm: ROPE_VT needs tables and positions");
     SP3_CHECK(d.rope_cols == d.N || (d.vt && d.tokens > 0 && d.heads > 0 && d.vt_ld >= d.tokens), "sp3_gemm: ROPE_VT needs vt/tokens/heads");
     SP3_CHECK(d.batch == 1, "sp3_gemm: ROPE_VT is unbatched (rows carry the batch)");
+    SP3_CHECK(!d.qkv_packed || (d.wdtype == SP3_BF16 && d.tokens > 0 && d.vt_ld % 64 == 0 && d.vt_ld >= d.tokens),
+              "sp3_gemm: qkv_packed needs bf16, tokens and vt_ld (padded tokens per image, multiple of 64)");
   } else if (d.epi == SP3_EPI_PIXSHUF) {
     SP3_CHECK(d.ps_k > 0 && d.ps_C > 0 && d.ps_C % 4 == 0 && d.N == d.ps_k * d.ps_k * d.ps_C && d.M % (d.ps_H * d.ps_W) == 0,
               "sp3_gemm: bad PIXSHUF geometry");

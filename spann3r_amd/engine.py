@@ -159,6 +159,15 @@ class Engine:
         (croco/models/blocks.py:94-109).  x [R,C] LayerNormed input -> ao [R,C]."""
         w = self.w
         npad = (P + 63) // 64 * 64
+        if self.precision == "bf16":
+            # fragment-order q/k (+ PV-order V) straight from the projection epilogue; zero pad rows are never written
+            qkp = self.ws("qkp" + tag, ops.packed_shape(B * npad, 2 * C, self.wdt), self.wdt, zero=True)
+            vtp = self.ws("vtp" + tag, (B * heads * npad * 64,), self.wdt, zero=True)
+            ops.proj_rope_vt(x, w[pre + "qkv.w"], w[pre + "qkv.b"], qkp, 0, vtp, npad, M=R, N=3 * C, K=C, lda=C,
+                             rope_cols=2 * C, pos=pos32, cos=self.cos, sin=self.sin, tokens=P, heads=heads, qkv_packed=True)
+            ops.attention_packed(qkp, 2 * C, 0, npad, qkp, 2 * C, C, npad, vtp, ao, C, B=B, heads=heads, Nq=P, Nk=P,
+                                 scale=64 ** -0.5)
+            return
         qk = self.ws("qk" + tag, (R, 2 * C), self.wdt)
         vt = self.ws("vt" + tag, (B * heads * 64, npad), self.wdt, zero=True)
         ops.proj_rope_vt(x, w[pre + "qkv.w"], w[pre + "qkv.b"], qk, 2 * C, vt, npad, M=R, N=3 * C, K=C, lda=C,
@@ -311,15 +320,30 @@ class Engine:
                     self._linear_reduce(ao, w[pre + "proj.w"], w[pre + "proj.b"], R, D, D, D, res=prev[s], x_out=x,
                                         ln1=self._norm(pre + "norm2"), out1=ln2, tag=tag)
                     # cross attention to the other side's previous-layer tokens through norm_y (:188-189)
-                    kbuf = self.ws("ck" + tag, (Ro, D), self.wdt)
-                    vt = self.ws("cvt" + tag, (B * Hh * 64, (Pmax + 63) // 64 * 64), self.wdt, zero=True)
-                    vt_ld = vt.shape[1]
-                    ops.proj_rope_vt(yn[s][cur], w[pre + "ckv.w"], w[pre + "ckv.b"], kbuf, D, vt, vt_ld, M=Ro, N=2 * D, K=D, lda=D,
-                                     rope_cols=D, pos=pos[o], cos=self.cos, sin=self.sin, tokens=Po, heads=Hh)
-                    qbuf = self.ws("cq" + tag, (R, D), self.wdt)
-                    ops.proj_rope_vt(ln2, w[pre + "cq.w"], w[pre + "cq.b"], qbuf, D, None, 0, M=R, N=D, K=D, lda=D,
-                                     rope_cols=D, pos=pos[s], cos=self.cos, sin=self.sin, tokens=P, heads=Hh)
-                    ops.attention(qbuf, P * D, D, kbuf, Po * D, D, vt, vt_ld, ao, D, B=B, heads=Hh, Nq=P, Nk=Po, scale=64 ** -0.5)
+                    if self.precision == "bf16":
+                        npq, npk = (P + 63) // 64 * 64, (Po + 63) // 64 * 64
+                        kbuf = self.ws("ckp" + tag, ops.packed_shape(B * npk, D, self.wdt), self.wdt, zero=True)
+                        vt = self.ws("cvtp" + tag, (B * Hh * npk * 64,), self.wdt, zero=True)
+                        ops.proj_rope_vt(yn[s][cur], w[pre + "ckv.w"], w[pre + "ckv.b"], kbuf, 0, vt, npk, M=Ro, N=2 * D, K=D,
+                                         lda=D, rope_cols=D, pos=pos[o], cos=self.cos, sin=self.sin, tokens=Po, heads=Hh,
+                                         qkv_packed=True)
+                        qbuf = self.ws("cqp" + tag, ops.packed_shape(B * npq, D, self.wdt), self.wdt, zero=True)
+                        ops.proj_rope_vt(ln2, w[pre + "cq.w"], w[pre + "cq.b"], qbuf, 0, None, npq, M=R, N=D, K=D, lda=D,
+                                         rope_cols=D, pos=pos[s], cos=self.cos, sin=self.sin, tokens=P, heads=Hh,
+                                         qkv_packed=True)
+                        ops.attention_packed(qbuf, D, 0, npq, kbuf, D, 0, npk, vt, ao, D, B=B, heads=Hh, Nq=P, Nk=Po,
+                                             scale=64 ** -0.5)
+                    else:
+                        kbuf = self.ws("ck" + tag, (Ro, D), self.wdt)
+                        vt = self.ws("cvt" + tag, (B * Hh * 64, (Pmax + 63) // 64 * 64), self.wdt, zero=True)
+                        vt_ld = vt.shape[1]
+                        ops.proj_rope_vt(yn[s][cur], w[pre + "ckv.w"], w[pre + "ckv.b"], kbuf, D, vt, vt_ld, M=Ro, N=2 * D, K=D,
+                                         lda=D, rope_cols=D, pos=pos[o], cos=self.cos, sin=self.sin, tokens=Po, heads=Hh)
+                        qbuf = self.ws("cq" + tag, (R, D), self.wdt)
+                        ops.proj_rope_vt(ln2, w[pre + "cq.w"], w[pre + "cq.b"], qbuf, D, None, 0, M=R, N=D, K=D, lda=D,
+                                         rope_cols=D, pos=pos[s], cos=self.cos, sin=self.sin, tokens=P, heads=Hh)
+                        ops.attention(qbuf, P * D, D, kbuf, Po * D, D, vt, vt_ld, ao, D, B=B, heads=Hh, Nq=P, Nk=Po,
+                                      scale=64 ** -0.5)
                     ln3 = self.wsp("dec_ln_c" + tag, R, D)
                     self._linear_reduce(ao, w[pre + "cproj.w"], w[pre + "cproj.b"], R, D, D, D, res=x, x_out=x,
                                         ln1=self._norm(pre + "norm3"), out1=ln3, tag=tag)

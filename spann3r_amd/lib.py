@@ -35,7 +35,7 @@ class GemmDesc(C.Structure):
         ("rope_cols", C.c_int32), ("vt", C.c_void_p), ("tokens", C.c_int32), ("heads", C.c_int32),
         ("vt_ld", C.c_int64),
         ("ps_k", C.c_int32), ("ps_H", C.c_int32), ("ps_W", C.c_int32), ("ps_C", C.c_int32),
-        ("tile", C.c_int32), ("a_bf16", C.c_int32), ("splitk", C.c_int32), ("a_packed", C.c_int32), ("out_packed", C.c_int32), ("w_packed", C.c_int32),
+        ("tile", C.c_int32), ("a_bf16", C.c_int32), ("splitk", C.c_int32), ("a_packed", C.c_int32), ("qkv_packed", C.c_int32), ("out_packed", C.c_int32), ("w_packed", C.c_int32),
     ]
 
 
@@ -68,6 +68,8 @@ _PROTOS = {
                     C.c_void_p, C.c_float, C.c_float, C.c_void_p],
     "sp3_attention": [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
                       C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p],
+    "sp3_attention_packed": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                             C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p],
     "sp3_softmax_thresh": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float,
                            C.c_int, C.c_void_p],
     "sp3_colsum_accum": [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p],

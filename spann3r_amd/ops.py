@@ -306,7 +306,8 @@ def conv_transpose_ks(x, Wp, out, *, B, H, W_, Cin, Cout, ks, bias=None, tile=-1
     return out
 
 
-def proj_rope_vt(A, W, bias, out_qk, ldc, vt, vt_ld, *, M, N, K, lda, rope_cols, pos, cos, sin, tokens, heads, tile=-1):
+def proj_rope_vt(A, W, bias, out_qk, ldc, vt, vt_ld, *, M, N, K, lda, rope_cols, pos, cos, sin, tokens, heads, tile=-1,
+                 qkv_packed=False):
     """Fused q/k(/v) projection of an attention layer: bias + 2-D RoPE on columns [0, rope_cols)
     (stored row-major to out_qk) and per-head transposed store of the V columns to vt."""
     d = GemmDesc()
@@ -320,6 +321,7 @@ def proj_rope_vt(A, W, bias, out_qk, ldc, vt, vt_ld, *, M, N, K, lda, rope_cols,
     d.loader, d.epi, d.tile = L.LOAD_PLAIN, L.EPI_ROPE_VT, tile
     d.rope_cos, d.rope_sin, d.pos, d.rope_cols = cos.data_ptr(), sin.data_ptr(), pos.data_ptr(), rope_cols
     d.vt, d.vt_ld, d.tokens, d.heads = L.ptr(vt), vt_ld, tokens, heads
+    d.qkv_packed = int(qkv_packed)
     if out_qk is None:
         d.C = vt.data_ptr()           # unused by the kernel when rope_cols == 0, but must be non-null
     _gemm_launch(d, "sp3_gemm(rope_vt)", "plain")
@@ -377,6 +379,16 @@ def attention(q, sq, ldq, k, sk, ldk, vt, vt_ld, out, ldo, *, B, heads, Nq, Nk, 
                                                      out.data_ptr(), ldo, int(out.dtype == torch.bfloat16), _is_packed(out),
                                                      B, heads, Nq, Nk, float(scale), wdtype_of(vt), L.stream_ptr()),
                            "sp3_attention"))
+    return out
+
+
+def attention_packed(qp, q_cols, q_col0, npad_q, kp, k_cols, k_col0, npad_k, vtp, out, ldo, *, B, heads, Nq, Nk, scale):
+    """bf16 attention on the fragment-order q/k and PV-order V written by proj_rope_vt(qkv_packed=True)."""
+    _timed("attention_packed<bf16>", 4.0 * B * heads * Nq * Nk * 64, B * heads * 64.0 * (2 * (Nq + 2 * Nk) + 4 * Nq),
+           lambda: L.check(L.load().sp3_attention_packed(qp.data_ptr(), q_cols, q_col0, npad_q, kp.data_ptr(), k_cols, k_col0,
+                                                         npad_k, vtp.data_ptr(), out.data_ptr(), ldo,
+                                                         int(out.dtype == torch.bfloat16), _is_packed(out), B, heads, Nq, Nk,
+                                                         float(scale), L.stream_ptr()), "sp3_attention_packed"))
     return out
 
 

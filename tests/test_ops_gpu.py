@@ -298,6 +298,68 @@ def test_attention(wdt, B, heads, Nq, Nk):
         assert rel_err(ob.float().cpu(), ref) < 1.5e-2
 
 
+def _pack_v_for_pv(v, npad):
+    """host mirror of the PV-operand order written by the qkv_packed epilogue: v [B,N,H,64] -> [(b,h)][npad/32][4][64][8]"""
+    B, N, H, _ = v.shape
+    out = torch.zeros(B, H, npad // 32, 4, 64, 8, dtype=v.dtype)
+    for n in range(N):
+        u, kk = n // 32, n % 32
+        w16 = kk % 16
+        e, g = (w16 % 4) + 4 * (kk // 16), w16 // 4
+        for db in range(4):
+            out[:, :, u, db, g * 16:(g + 1) * 16, e] = v[:, n, :, db * 16:(db + 1) * 16]
+    return out
+
+
+@pytest.mark.parametrize("B,heads,Nq,Nk", [(1, 16, 196, 196), (2, 12, 20, 20), (1, 12, 50, 300), (2, 3, 17, 65)])
+def test_attention_packed(B, heads, Nq, Nk):
+    """bf16 attention on fragment-order q/k + PV-order V == softmax(qk^T/8)v on the bf16-rounded operands."""
+    ops = _ops()
+    C = heads * 64
+    q, k, v = rnd(B, Nq, heads, 64, seed=1) * 2, rnd(B, Nk, heads, 64, seed=2), rnd(B, Nk, heads, 64, seed=3)
+    qb, kb_, vb = q.to(torch.bfloat16), k.to(torch.bfloat16), v.to(torch.bfloat16)
+    npq, npk = (Nq + 63) // 64 * 64, (Nk + 63) // 64 * 64
+    qd = torch.zeros(B, npq, C, dtype=torch.bfloat16); qd[:, :Nq] = qb.reshape(B, Nq, C)
+    kd = torch.zeros(B, npk, C, dtype=torch.bfloat16); kd[:, :Nk] = kb_.reshape(B, Nk, C)
+    qp = ops.PackedAct.from_dense(qd.reshape(B * npq, C).to(DEV))
+    kp = ops.PackedAct.from_dense(kd.reshape(B * npk, C).to(DEV))
+    vp = _pack_v_for_pv(vb, npk).to(DEV)
+    a = torch.softmax(torch.einsum("bqhd,bkhd->bhqk", qb.double(), kb_.double()) * 0.125, -1)
+    ref = torch.einsum("bhqk,bkhd->bqhd", a, vb.double()).reshape(B * Nq, C)
+    out = torch.empty(B * Nq, C, device=DEV)
+    ops.attention_packed(qp, C, 0, npq, kp, C, 0, npk, vp, out, C, B=B, heads=heads, Nq=Nq, Nk=Nk, scale=0.125)
+    assert rel_err(out.cpu(), ref) < 1e-2
+    outp = ops.PackedAct(B * Nq, C, torch.bfloat16, DEV)
+    ops.attention_packed(qp, C, 0, npq, kp, C, 0, npk, vp, outp, C, B=B, heads=heads, Nq=Nq, Nk=Nk, scale=0.125)
+    assert rel_err(outp.to_dense().float().cpu(), ref) < 1.5e-2
+
+
+def test_proj_rope_vt_packed():
+    """The qkv_packed epilogue writes the same numbers as the row-major one, in the layouts attention_packed reads."""
+    from oracle import spann3r_oracle as O
+    from spann3r_amd.engine import _rope_tables
+    ops = _ops()
+    B, nh, nw, C, heads = 2, 4, 5, 768, 12
+    P, R, npad = nh * nw, 2 * nh * nw, 64
+    x, W, b = rnd(R, C, seed=1), rnd(3 * C, C, seed=2) * 0.05, rnd(3 * C, seed=3)
+    pos = _pos(B, nh, nw)
+    cos, sin = _rope_tables(64, 100.0, DEV)
+    args = dict(M=R, N=3 * C, K=C, lda=C, rope_cols=2 * C, pos=pos.reshape(-1, 2).to(torch.int32).to(DEV), cos=cos, sin=sin,
+                tokens=P, heads=heads)
+    Wd = W.to(DEV).to(torch.bfloat16)
+    qk = torch.zeros(R, 2 * C, device=DEV, dtype=torch.bfloat16)
+    vt = torch.zeros(B * heads * 64, npad, device=DEV, dtype=torch.bfloat16)
+    ops.proj_rope_vt(x.to(DEV), Wd, b.to(DEV), qk, 2 * C, vt, npad, **args)
+    qkp = ops.PackedAct(B * npad, 2 * C, torch.bfloat16, DEV)
+    vtp = torch.zeros(B * heads * (npad // 32) * 4 * 64 * 8, device=DEV, dtype=torch.bfloat16)
+    ops.proj_rope_vt(x.to(DEV), Wd, b.to(DEV), qkp.data, 0, vtp, npad, qkv_packed=True, **args)
+    dense = qkp.to_dense().reshape(B, npad, 2 * C)
+    assert torch.equal(dense[:, :P].reshape(R, 2 * C), qk)
+    assert float(dense[:, P:].abs().max()) == 0.0
+    v_row = vt.reshape(B, heads, 64, npad)[..., :P].permute(0, 3, 1, 2).contiguous()       # [B,P,H,64]
+    assert torch.equal(vtp.reshape(B, heads, npad // 32, 4, 64, 8).cpu(), _pack_v_for_pv(v_row.cpu(), npad))
+
+
 # ----------------------------------------------------------------------------- LayerNorm
 @pytest.mark.parametrize("C", [768, 1024, 1792, 96])
 def test_layernorm(C):
