@@ -93,6 +93,21 @@ typedef struct sp3_gemm_desc {
   int32_t splitk;         /* >= 1; > 1 only with SP3_EPI_PARTIAL */
   int32_t a_packed;       /* A is in MFMA-fragment order [ceil(M/16)][ceil(K/KB)][64 lanes][CH] (see w_packed); written
                              that way by the producing kernel (out_packed options), plain loader only */
+  /* --- LayerNorm folded into the GEMM (DESIGN.md "LN fold"): for y = LayerNorm(x; gamma, beta) . W^T + b,
+   *   y = rstd * (x . (gamma (.) W)^T) - rstd * mean * s + (b + beta . W^T),  s_n = sum_k (gamma (.) W)_nk.
+   * CONSUMER side: A is the raw stream x (packed), W is gamma (.) W, bias is the folded bias, ln_s = s, and the row
+   * statistics come from ln_stats[M][ln_nt][2] = per-32-column partial (sum, sum of squares) of x written by the
+   * PRODUCER of x; mean/rstd are finished per output tile.  PRODUCER side (plain epilogue): stats_out receives those
+   * partials of the rows this launch finalises (N % 32 == 0) and c2 a second, fragment-order copy of C in the MFMA
+   * dtype (the consumers' A operand).  Replaces the norm1/norm2/norm3/norm_y/value_norm launches
+   * (croco/models/blocks.py:128-129,187-190, spann3r/model.py:308). */
+  const float* ln_stats;
+  const float* ln_s;
+  int32_t ln_nt;          /* number of 32-column groups of x = C_x / 32 */
+  int32_t ln_C;           /* C_x */
+  float ln_eps;
+  float* stats_out;       /* [M][N/32][2] or null */
+  void* c2;               /* packed copy of C (dims M x N) in the MFMA dtype, or null */
   int32_t qkv_packed;     /* ROPE_VT epilogue, bf16: q/k stored in fragment order (rows = b*vt_ld + n, K-dim = rope_cols) and
                              V in PV-operand order [(b,h)][vt_ld/32][4][64][8] -- the layouts sp3_attention_packed reads */
   int32_t out_packed;     /* plain epilogue: store C in fragment order (it is the next GEMM's packed A; dims M x N) */

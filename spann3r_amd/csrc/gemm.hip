@@ -420,6 +420,31 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_kernel(const GemmArgs 
   }
   __syncthreads();
 
+  // folded LayerNorm: finish mean / rstd of this tile's rows from the producer's per-32-column partial sums
+  float* rowstat = smem + (size_t)WK * BM * LDS_LD;     // [BM][2]
+  if (d.ln_stats) {
+    for (int r = tid; r < BM; r += NT) {
+      const int gm = m0 + r;
+      float mean = 0.f, rstd = 0.f;
+      if (gm < d.M) {
+        const float2* ps = reinterpret_cast<const float2*>(d.ln_stats) + (int64_t)gm * d.ln_nt;
+        float s1 = 0.f, s2 = 0.f;
+        for (int t = 0; t < d.ln_nt; ++t) { const float2 v = ps[t]; s1 += v.x; s2 += v.y; }
+        mean = s1 / (float)d.ln_C;
+        const float var = fmaxf(s2 / (float)d.ln_C - mean * mean, 0.f);
+        rstd = 1.0f / sqrtf(var + d.ln_eps);
+      }
+      rowstat[2 * r] = mean;
+      rowstat[2 * r + 1] = rstd;
+    }
+    __syncthreads();
+  }
+  // y = rstd * acc - rstd * mean * s[n]   (bias, already folded with beta . W^T, is added by the epilogues below)
+  auto ln_fold = [&](float acc, int row, int gn) -> float {
+    const float mean = rowstat[2 * row], rstd = rowstat[2 * row + 1];
+    return rstd * acc - rstd * mean * d.ln_s[gn];
+  };
+
   auto lds_sum4 = [&](int row, int c4) -> float4 {
     float4 v = *reinterpret_cast<const float4*>(smem + row * LDS_LD + c4);
 #pragma unroll
@@ -442,7 +467,9 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_kernel(const GemmArgs 
       float v = smem[row * LDS_LD + col];
 #pragma unroll
       for (int s = 1; s < WK; ++s) v += smem[(size_t)s * BM * LDS_LD + row * LDS_LD + col];
-      v = v * alpha + (d.bias ? d.bias[gn] : 0.f);
+      v = v * alpha;
+      if (d.ln_stats) v = ln_fold(v, row, gn);
+      v += (d.bias ? d.bias[gn] : 0.f);
       const int vc = gn - d.rope_cols;
       const int h = vc >> 6, dd = vc & 63;
       const int b = gm / d.tokens, n = gm - b * d.tokens;
@@ -492,8 +519,10 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_kernel(const GemmArgs 
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float self = v[e] + (d.bias ? d.bias[gn + e] : 0.f);
-        const float other = pv[e] + (d.bias ? d.bias[(gn + e) ^ 16] : 0.f);
+        float self = v[e], other = pv[e];
+        if (d.ln_stats) { self = ln_fold(self, row, gn + e); other = ln_fold(other, row, (gn + e) ^ 16); }
+        self += (d.bias ? d.bias[gn + e] : 0.f);
+        other += (d.bias ? d.bias[(gn + e) ^ 16] : 0.f);
         const float cs = d.rope_cos[pos * 16 + i0 + e], sn = d.rope_sin[pos * 16 + i0 + e];
         const float o = is_v ? (self * cs + other * sn) : (self * cs - other * sn);
         out[e] = (TW)o;
@@ -506,6 +535,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_kernel(const GemmArgs 
     for (int e = 0; e < 4; ++e) {
       if (e < nvalid) {
         float x = v[e];
+        if (d.ln_stats) x = ln_fold(x, row, gn + e);
         if (d.epi == SP3_EPI_PIXSHUF) x += d.bias ? d.bias[(gn + e) % d.ps_C] : 0.f;
         else x += d.bias ? d.bias[gn + e] : 0.f;
         if (d.act == SP3_ACT_GELU) x = gelu_erf(x);
@@ -537,6 +567,26 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_kernel(const GemmArgs 
 #pragma unroll
       for (int e = 0; e < 4; ++e) if (e < nvalid) v[e] += r[e];
     }
+    if (d.stats_out) {
+      // per-32-column partial (sum, sum of squares) of the finished rows: 8 consecutive lanes share a row group
+      float s1 = (v[0] + v[1]) + (v[2] + v[3]);
+      float s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+#pragma unroll
+      for (int o_ = 1; o_ < 8; o_ <<= 1) { s1 += __shfl_xor(s1, o_); s2 += __shfl_xor(s2, o_); }
+      if (((gn >> 2) & 7) == 0)
+        reinterpret_cast<float2*>(d.stats_out)[(int64_t)gm * (d.N >> 5) + (gn >> 5)] = make_float2(s1, s2);
+    }
+    if (d.c2) {
+      const bool cb = d.wdtype == SP3_BF16;
+      const int64_t o2 = packed_off(gm, gn, d.N, cb);
+      if (cb) {
+        bf16x4 ob;
+        ob[0] = (__bf16)v[0]; ob[1] = (__bf16)v[1]; ob[2] = (__bf16)v[2]; ob[3] = (__bf16)v[3];
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(d.c2) + o2) = ob;
+      } else {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(d.c2) + o2) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
     if (d.out_bf16) {
       __bf16* o = reinterpret_cast<__bf16*>(d.C) + off;
       if (nvalid == 4 && ((off & 3) == 0)) {
@@ -566,7 +616,7 @@ int launch(const sp3_gemm_desc& d, hipStream_t stream) {
   int blocks;
   if (mt >= nt) blocks = ((mt + 7) / 8) * 8 * nt;
   else blocks = ((nt + 7) / 8) * 8 * mt;
-  const size_t lds = (size_t)WK * BM * (BN + 4) * sizeof(float);
+  const size_t lds = ((size_t)WK * BM * (BN + 4) + 2 * BM) * sizeof(float);
   auto kern = gemm_kernel<TA, TW, LOADER, MF, NF, WM, WN, WK, STAGES>;
   if (lds > 64 * 1024) {
     static bool raised = false;     // one-time opt-in to > 64 KiB of dynamic LDS for this instantiation
@@ -611,6 +661,10 @@ extern "C" int sp3_gemm(const sp3_gemm_desc* dp, void* stream_) {
   if (d.splitk <= 0) d.splitk = 1;
   if (d.ldw <= 0) d.ldw = d.K;
   SP3_CHECK(!d.w_packed || d.batch == 1, "sp3_gemm: packed weights are unbatched");
+  SP3_CHECK(!d.ln_stats || (d.ln_s && d.ln_nt > 0 && d.ln_C == 32 * d.ln_nt && d.batch == 1 && d.epi != SP3_EPI_PARTIAL),
+            "sp3_gemm: folded LayerNorm needs ln_s, ln_nt, ln_C = 32*ln_nt, batch 1");
+  SP3_CHECK((!d.stats_out && !d.c2) || (d.epi == SP3_EPI_PLAIN && d.batch == 1 && d.N % 32 == 0 && !d.out_packed),
+            "sp3_gemm: stats_out / c2 need the plain epilogue, batch 1, N %% 32 == 0");
   SP3_CHECK(!d.out_packed || (d.epi == SP3_EPI_PLAIN && d.batch == 1 && d.N % 4 == 0), "sp3_gemm: out_packed needs the plain epilogue, batch 1, N %% 4 == 0");
   SP3_CHECK(!d.a_packed || (d.loader == SP3_LOAD_PLAIN && !d.A2 && d.batch == 1), "sp3_gemm: packed A is plain / unbatched / unsplit");
   SP3_CHECK(!d.a_packed || ((d.a_bf16 != 0) == (d.wdtype == SP3_BF16)), "sp3_gemm: packed A must have the MFMA dtype (its fragment geometry)");

@@ -35,6 +35,8 @@ class Engine:
         self.precision = precision
         self.wdt = torch.float32 if precision == "fp32" else torch.bfloat16
         self.adt = self.wdt          # dtype of activations that only feed GEMMs
+        import os
+        self.packed_attn = precision == "bf16" and not os.environ.get("SP3_NO_PACKED_ATTN")
         self._ws = {}
         self._pos_cache = {}
         self.max_pos = 0
@@ -59,36 +61,48 @@ class Engine:
         def convt(t):    # ConvTranspose2d [Cin,Cout,k,k] -> [(ky,kx,co), ci]
             return ops.PackedWeight(t.detach().to(dev, torch.float32).permute(2, 3, 1, 0).reshape(-1, t.shape[0]).to(wdt).contiguous())
 
+        def fold(dst, weight, bias, norm):
+            """LayerNorm folded into the consuming Linear (DESIGN.md "LN fold"): W' = gamma (.) W in the MFMA dtype,
+            s_n = sum_k W'_nk taken from the ROUNDED W' (the identity (x-mu).W' = x.W' - mu.s must hold for the operand
+            the MFMA really multiplies), b' = b + W . beta."""
+            W = weight.detach().to(dev, torch.float32)
+            g = p[norm + ".weight"].detach().to(dev, torch.float32)
+            beta = p[norm + ".bias"].detach().to(dev, torch.float32)
+            Wf = (W * g[None, :]).to(wdt)
+            w[dst + ".w"] = ops.PackedWeight(Wf.contiguous())
+            w[dst + ".s"] = Wf.float().sum(1).contiguous()
+            w[dst + ".b"] = (bias.detach().to(dev, torch.float32) + W @ beta).contiguous()
+
         def block(dst, src):
-            for n in ("norm1", "norm2"):
-                w[dst + n + ".w"], w[dst + n + ".b"] = vec(p[src + n + ".weight"]), vec(p[src + n + ".bias"])
-            w[dst + "qkv.w"], w[dst + "qkv.b"] = mat(p[src + "attn.qkv.weight"]), vec(p[src + "attn.qkv.bias"])
+            fold(dst + "qkv", p[src + "attn.qkv.weight"], p[src + "attn.qkv.bias"], src + "norm1")
             w[dst + "proj.w"], w[dst + "proj.b"] = mat(p[src + "attn.proj.weight"]), vec(p[src + "attn.proj.bias"])
-            w[dst + "fc1.w"], w[dst + "fc1.b"] = mat(p[src + "mlp.fc1.weight"]), vec(p[src + "mlp.fc1.bias"])
             w[dst + "fc2.w"], w[dst + "fc2.b"] = mat(p[src + "mlp.fc2.weight"]), vec(p[src + "mlp.fc2.bias"])
 
         w["patch.w"], w["patch.b"] = mat(p["dust3r.patch_embed.proj.weight"]), vec(p["dust3r.patch_embed.proj.bias"])
         w["pospatch.w"], w["pospatch.b"] = mat(p["pos_patch_embed.proj.weight"]), vec(p["pos_patch_embed.proj.bias"])
         for i in range(cfg.enc_depth):
             block("enc%d." % i, "dust3r.enc_blocks.%d." % i)
+            fold("enc%d.fc1" % i, p["dust3r.enc_blocks.%d.mlp.fc1.weight" % i], p["dust3r.enc_blocks.%d.mlp.fc1.bias" % i],
+                 "dust3r.enc_blocks.%d.norm2" % i)
         for i in range(cfg.val_depth):
             block("val%d." % i, "value_encoder.%d." % i)
-        for n, s in (("enc_norm", "dust3r.enc_norm"), ("dec_norm", "dust3r.dec_norm"), ("value_norm", "value_norm"),
+            fold("val%d.fc1" % i, p["value_encoder.%d.mlp.fc1.weight" % i], p["value_encoder.%d.mlp.fc1.bias" % i],
+                 "value_encoder.%d.norm2" % i)
+        for n, s in (("enc_norm", "dust3r.enc_norm"), ("dec_norm", "dust3r.dec_norm"),
                      ("norm_q", "norm_q"), ("norm_k", "norm_k"), ("norm_v", "norm_v")):
             w[n + ".w"], w[n + ".b"] = vec(p[s + ".weight"]), vec(p[s + ".bias"])
         w["dec_embed.w"], w["dec_embed.b"] = mat(p["dust3r.decoder_embed.weight"]), vec(p["dust3r.decoder_embed.bias"])
-        w["value_out.w"], w["value_out.b"] = mat(p["value_out.weight"]), vec(p["value_out.bias"])
+        fold("value_out", p["value_out.weight"], p["value_out.bias"], "value_norm")
         for side, name in ((1, "dec_blocks"), (2, "dec_blocks2")):
             for i in range(cfg.dec_depth):
                 src, dst = "dust3r.%s.%d." % (name, i), "dec%d_%d." % (side, i)
                 block(dst, src)
-                for n in ("norm3", "norm_y"):
-                    w[dst + n + ".w"], w[dst + n + ".b"] = vec(p[src + n + ".weight"]), vec(p[src + n + ".bias"])
+                fold(dst + "fc1", p[src + "mlp.fc1.weight"], p[src + "mlp.fc1.bias"], src + "norm3")
                 ca = src + "cross_attn."
-                w[dst + "cq.w"], w[dst + "cq.b"] = mat(p[ca + "projq.weight"]), vec(p[ca + "projq.bias"])
+                fold(dst + "cq", p[ca + "projq.weight"], p[ca + "projq.bias"], src + "norm2")
                 # projk and projv read the same input (norm_y of the other side): one GEMM, N = 2*768
-                w[dst + "ckv.w"] = mat(torch.cat((p[ca + "projk.weight"].detach(), p[ca + "projv.weight"].detach()), 0))
-                w[dst + "ckv.b"] = vec(torch.cat((p[ca + "projk.bias"].detach(), p[ca + "projv.bias"].detach()), 0))
+                fold(dst + "ckv", torch.cat((p[ca + "projk.weight"].detach(), p[ca + "projv.weight"].detach()), 0),
+                     torch.cat((p[ca + "projk.bias"].detach(), p[ca + "projv.bias"].detach()), 0), src + "norm_y")
                 w[dst + "cproj.w"], w[dst + "cproj.b"] = mat(p[ca + "proj.weight"]), vec(p[ca + "proj.bias"])
         for h in (1, 2):
             s, d_ = "attn_head_%d." % h, "key%d." % h
@@ -154,31 +168,33 @@ class Engine:
     # Activations that only feed a GEMM (LayerNorm outputs, attention outputs, GELU outputs) are stored in `adt`
     # (bf16 in bf16 mode: exactly the rounding the MFMA operand conversion would apply on load, at half the traffic);
     # the residual stream, LayerNorm statistics and everything the API returns stay fp32.
-    def _attn_core(self, x, R, B, P, C, heads, pre, pos32, ao, tag=""):
-        """qkv projection with fused bias + 2-D RoPE + per-head V^T store, then softmax(qk^T/8)v
-        (croco/models/blocks.py:94-109).  x [R,C] LayerNormed input -> ao [R,C]."""
+    def _attn_core(self, xp, st, R, B, P, C, heads, pre, pos32, ao, tag=""):
+        """norm1 (folded) + qkv projection with fused bias + 2-D RoPE + per-head V^T store, then softmax(qk^T/8)v
+        (croco/models/blocks.py:94-109, 128).  xp/st: fragment-order copy and row-statistics partials of the stream x."""
         w = self.w
         npad = (P + 63) // 64 * 64
-        if self.precision == "bf16":
+        ln = ops.LnFold(st, C, w[pre + "qkv.s"], 1e-6)
+        if self.packed_attn:
             # fragment-order q/k (+ PV-order V) straight from the projection epilogue; zero pad rows are never written
             qkp = self.ws("qkp" + tag, ops.packed_shape(B * npad, 2 * C, self.wdt), self.wdt, zero=True)
             vtp = self.ws("vtp" + tag, (B * heads * npad * 64,), self.wdt, zero=True)
-            ops.proj_rope_vt(x, w[pre + "qkv.w"], w[pre + "qkv.b"], qkp, 0, vtp, npad, M=R, N=3 * C, K=C, lda=C,
-                             rope_cols=2 * C, pos=pos32, cos=self.cos, sin=self.sin, tokens=P, heads=heads, qkv_packed=True)
+            ops.proj_rope_vt(xp, w[pre + "qkv.w"], w[pre + "qkv.b"], qkp, 0, vtp, npad, M=R, N=3 * C, K=C, lda=C,
+                             rope_cols=2 * C, pos=pos32, cos=self.cos, sin=self.sin, tokens=P, heads=heads, qkv_packed=True,
+                             ln=ln)
             ops.attention_packed(qkp, 2 * C, 0, npad, qkp, 2 * C, C, npad, vtp, ao, C, B=B, heads=heads, Nq=P, Nk=P,
                                  scale=64 ** -0.5)
             return
         qk = self.ws("qk" + tag, (R, 2 * C), self.wdt)
         vt = self.ws("vt" + tag, (B * heads * 64, npad), self.wdt, zero=True)
-        ops.proj_rope_vt(x, w[pre + "qkv.w"], w[pre + "qkv.b"], qk, 2 * C, vt, npad, M=R, N=3 * C, K=C, lda=C,
-                         rope_cols=2 * C, pos=pos32, cos=self.cos, sin=self.sin, tokens=P, heads=heads)
+        ops.proj_rope_vt(xp, w[pre + "qkv.w"], w[pre + "qkv.b"], qk, 2 * C, vt, npad, M=R, N=3 * C, K=C, lda=C,
+                         rope_cols=2 * C, pos=pos32, cos=self.cos, sin=self.sin, tokens=P, heads=heads, ln=ln)
         ops.attention(qk, P * 2 * C, 2 * C, qk[:, C:], P * 2 * C, 2 * C, vt, npad, ao, C, B=B, heads=heads, Nq=P, Nk=P,
                       scale=64 ** -0.5)
 
     def _linear_reduce(self, A, W, bias, R, N, K, lda, *, res=None, x_out=None, ln1=None, out1=None, ln2=None, out2=None,
                        eps=1e-6, A2=None, lda2=0, K1=0, tag=""):
-        """x = A.W^T + bias (+ res) as a split-K GEMM finished by the fused reduce + residual + LayerNorm kernel
-        (`x = x + proj(...)` and the norm(s) that follow, croco/models/blocks.py:128-129,187-190)."""
+        """x = A.W^T + bias (+ res) as a split-K GEMM finished by the fused reduce + residual + LayerNorm kernel (kept for
+        very small outputs with a long K; the blocks themselves use the folded-LayerNorm GEMMs below)."""
         S = ops.pick_splitk(R, N, K)
         part = self.ws("splitk_partial" + tag, (max(S, 2) * R * N,))
         ops.gemm(A, W, part, M=R, N=N, K=K, lda=lda, ldc=N, splitk=S, A2=A2, lda2=lda2, K1=K1)
@@ -187,43 +203,53 @@ class Engine:
     def _norm(self, name):
         return (self.w[name + ".w"], self.w[name + ".b"])
 
-    def _block(self, x, ln_in, R, B, P, C, heads, pre, pos32, next_norm, next_out, keep_x=True, tag=""):
-        """Pre-LN ViT block on the fp32 stream x (croco/models/blocks.py:127-130).  `ln_in` = norm1(x) (computed by the
-        producer of x); the block's last kernel also emits next_out = LayerNorm(x_new; next_norm)."""
+    def stats(self, name, R, C):
+        """row-statistics partials [R, C/32, 2] of a stream tensor (written by its producer GEMM)"""
+        return self.ws(name, (R, C // 32, 2))
+
+    def _update(self, A, pre, R, C, K, x_in, x_out, xp, st):
+        """x_out = x_in + A . W^T + b  (attention / MLP output projection, croco/models/blocks.py:110,128-129) with the
+        producer-side halves of the next folded LayerNorm: fragment-order copy xp and statistics partials st."""
         w = self.w
+        ops.gemm(A, w[pre + ".w"], x_out, M=R, N=C, K=K, lda=K, ldc=C, bias=w[pre + ".b"], res1=x_in, ldr1=C,
+                 stats_out=st, c2=xp)
+
+    def _mlp_fc1(self, xp, st, R, C, pre, h):
+        """norm (folded) + fc1 + exact-erf GELU (croco/models/blocks.py:74-75), output in fragment order for fc2"""
+        w = self.w
+        Hd = C * self.cfg.mlp_ratio
+        ops.gemm(xp, w[pre + "fc1.w"], h, M=R, N=Hd, K=C, lda=C, ldc=Hd, bias=w[pre + "fc1.b"], act=ACT_GELU,
+                 ln=ops.LnFold(st, C, w[pre + "fc1.s"], 1e-6))
+
+    def _block(self, x, xpA, stA, xpB, stB, R, B, P, C, heads, pre, pos32, tag="", last=False):
+        """Pre-LN ViT block on the fp32 stream x (croco/models/blocks.py:127-130): 5 launches, no LayerNorm kernel.
+        (xpA, stA) describe x on entry and on exit (unless `last`); (xpB, stB) are scratch for the mid-block state."""
         ao = self.wsp("attn_out" + tag, R, C)
-        self._attn_core(ln_in, R, B, P, C, heads, pre, pos32, ao, tag=tag)
-        ln2 = self.wsp("ln_b" + tag, R, C)
-        self._linear_reduce(ao, w[pre + "proj.w"], w[pre + "proj.b"], R, C, C, C, res=x, x_out=x,
-                            ln1=self._norm(pre + "norm2"), out1=ln2, tag=tag)
+        self._attn_core(xpA, stA, R, B, P, C, heads, pre, pos32, ao, tag=tag)
+        self._update(ao, pre + "proj", R, C, C, x, x, xpB, stB)
         Hd = C * self.cfg.mlp_ratio
         h = self.wsp("mlp_hidden" + tag, R, Hd)
-        ops.gemm(ln2, w[pre + "fc1.w"], h, M=R, N=Hd, K=C, lda=C, ldc=Hd, bias=w[pre + "fc1.b"], act=ACT_GELU)
-        self._linear_reduce(h, w[pre + "fc2.w"], w[pre + "fc2.b"], R, C, Hd, Hd, res=x, x_out=x if keep_x else None,
-                            ln1=self._norm(next_norm), out1=next_out, tag=tag)
+        self._mlp_fc1(xpB, stB, R, C, pre, h)
+        self._update(h, pre + "fc2", R, C, Hd, x, x, xpA, stA)
 
     # ------------------------------------------------------------------ stages
-    def _vit(self, col, R, B, P, patch_w, prefix, depth, pos32, final_norm, final_out, tag=""):
-        """patch-embed GEMM + `depth` blocks + final norm; every LayerNorm rides on the producing kernel."""
+    def _vit(self, col, R, B, P, patch_w, prefix, depth, pos32, tag=""):
+        """patch-embed GEMM + `depth` blocks.  Returns (x fp32, fragment-order copy, statistics) of the final stream."""
         cfg, w = self.cfg, self.w
         E = cfg.enc_dim
         K0 = col.K
         x = self.ws("vit_x" + tag, (R, E))
-        lnA = self.wsp("ln_a" + tag, R, E)
-        first = (prefix + "0.norm1") if depth > 0 else final_norm
-        self._linear_reduce(col, w[patch_w + ".w"], w[patch_w + ".b"], R, E, K0, K0, x_out=x, ln1=self._norm(first),
-                            out1=lnA if depth > 0 else final_out, tag=tag)
+        xpA, xpB = self.wsp("vit_xpA" + tag, R, E), self.wsp("vit_xpB" + tag, R, E)
+        stA, stB = self.stats("vit_stA" + tag, R, E), self.stats("vit_stB" + tag, R, E)
+        ops.gemm(col, w[patch_w + ".w"], x, M=R, N=E, K=K0, lda=K0, ldc=E, bias=w[patch_w + ".b"], stats_out=stA, c2=xpA)
         for i in range(depth):
-            last = i == depth - 1
-            nxt = final_norm if last else prefix + "%d.norm1" % (i + 1)
-            self._block(x, lnA, R, B, P, E, cfg.enc_heads, prefix + "%d." % i, pos32, nxt, final_out if last else lnA,
-                        keep_x=not last, tag=tag)
-        return final_out
+            self._block(x, xpA, stA, xpB, stB, R, B, P, E, cfg.enc_heads, prefix + "%d." % i, pos32, tag=tag)
+        return x, xpA, stA
 
     def encode_image(self, img, out=None, tag=""):
         """dust3r._encode_image (dust3r/model.py:131-154): patch embed -> enc_depth blocks -> enc_norm.
         img fp32 [B,3,H,W] on device -> feat [B,P,1024] (written to `out` if given), pos int64 [B,P,2]."""
-        cfg = self.cfg
+        cfg, w = self.cfg, self.w
         B, Cin, H, W_ = img.shape
         p = cfg.patch
         assert Cin == 3 and H % p == 0 and W_ % p == 0, "Input image size is not a multiple of patch size"
@@ -235,7 +261,8 @@ class Engine:
         ops.im2col_patch(img, col, B=B, C_=3, H=H, W_=W_, p=p, strides=img.stride())
         if out is None:
             out = torch.empty(B, P, E, device=self.device)
-        self._vit(col, R, B, P, "patch", "enc", cfg.enc_depth, pos32, "enc_norm", out, tag=tag)
+        x, _, _ = self._vit(col, R, B, P, "patch", "enc", cfg.enc_depth, pos32, tag=tag)
+        ops.layernorm(x, w["enc_norm.w"], w["enc_norm.b"], 1e-6, out, rows=R, C_=E)     # API-visible: stays a kernel
         return out, pos64
 
     def side_streams(self):
@@ -272,9 +299,9 @@ class Engine:
         depth = cfg.dec_depth
         cur_stream = torch.cuda.current_stream() if self.device.type == "cuda" else None
         st = streams or {1: cur_stream, 2: cur_stream}
-        # per side, double-buffered by layer parity: ln1 = norm1(own previous layer), yn = norm_y(OTHER side's previous layer)
-        ln1 = {s: [self.wsp("dec_ln1_%d_%d" % (s, j), Rs[s], D) for j in (0, 1)] for s in (1, 2)}
-        yn = {s: [self.wsp("dec_yn_%d_%d" % (s, j), Rs[3 - s], D) for j in (0, 1)] for s in (1, 2)}
+        # per side, double-buffered by layer parity: fragment-order copy + statistics of the layer output
+        xp = {s: [self.wsp("dec_xp_%d_%d" % (s, j), Rs[s], D) for j in (0, 1)] for s in (1, 2)}
+        st_ = {s: [self.stats("dec_st_%d_%d" % (s, j), Rs[s], D) for j in (0, 1)] for s in (1, 2)}
         prev = {}
         # Cross-stream event waits inside a capture crash hipStreamEndCapture on ROCm 7.2 (tools/
         # probe_multistream_capture.py), plain fork/join does not: so both sides fork from and join to the main stream
@@ -286,20 +313,28 @@ class Engine:
                 st[1].wait_stream(main)
                 st[2].wait_stream(main)
 
+        import os
+        dbg_sync = os.environ.get("SP3_DEC_SYNC")
+
         def join_layer():
             if streams:
                 main.wait_stream(st[1])
                 main.wait_stream(st[2])
+                # A join that is followed directly by a fork leaves `main` with nothing but event waits between them; on
+                # ROCm 7.2 the next fork's event then does NOT order the side streams behind both joins (measured:
+                # run-to-run different decoder outputs, gone with a host sync here).  One trivial kernel on `main`
+                # makes the join a real node of the stream / graph.
+                ops.fill(self.ws("join_token", (64,)), 0.0)
+                if dbg_sync:
+                    torch.cuda.synchronize()
 
         fork_layer()
         for s in (1, 2):
-            o = 3 - s
             with torch.cuda.stream(st[s]):
                 prev[s] = self.ws("dec%d_l0" % s, (Rs[s], D))
-                # decoder_embed (dust3r/model.py:190-191); emits norm1 for side s and norm_y for side o's first block
-                self._linear_reduce(f[s], w["dec_embed.w"], w["dec_embed.b"], Rs[s], D, E, E, x_out=prev[s],
-                                    ln1=self._norm("dec%d_0.norm1" % s), out1=ln1[s][0],
-                                    ln2=self._norm("dec%d_0.norm_y" % o), out2=yn[o][0], tag="_s%d" % s)
+                # decoder_embed (dust3r/model.py:190-191)
+                ops.gemm(f[s], w["dec_embed.w"], prev[s], M=Rs[s], N=D, K=E, lda=E, ldc=D, bias=w["dec_embed.b"],
+                         stats_out=st_[s][0], c2=xp[s][0])
         join_layer()
         for i in range(depth):
             cur, nx = i % 2, (i + 1) % 2
@@ -313,53 +348,51 @@ class Engine:
                 R, P, Ro, Po = Rs[s], Ps[s], Rs[o], Ps[o]
                 with torch.cuda.stream(st[s]):
                     x = self.ws("dec%d_l%d" % (s, i + 1), (R, D))
-                    # self attention (croco/models/blocks.py:187)
+                    xq, stq = self.wsp("dec_xq" + tag, R, D), self.stats("dec_stq" + tag, R, D)
+                    # self attention (croco/models/blocks.py:187), norm1 folded into the qkv GEMM
                     ao = self.wsp("attn_out_dec" + tag, R, D)
-                    self._attn_core(ln1[s][cur], R, B, P, D, Hh, pre, pos[s], ao, tag=tag)
-                    ln2 = self.wsp("dec_ln_b" + tag, R, D)
-                    self._linear_reduce(ao, w[pre + "proj.w"], w[pre + "proj.b"], R, D, D, D, res=prev[s], x_out=x,
-                                        ln1=self._norm(pre + "norm2"), out1=ln2, tag=tag)
-                    # cross attention to the other side's previous-layer tokens through norm_y (:188-189)
-                    if self.precision == "bf16":
+                    self._attn_core(xp[s][cur], st_[s][cur], R, B, P, D, Hh, pre, pos[s], ao, tag=tag)
+                    self._update(ao, pre + "proj", R, D, D, prev[s], x, xq, stq)
+                    # cross attention to the other side's previous-layer tokens (:188-189): norm_y folded into the k/v
+                    # projection, norm2 into the q projection
+                    lnk = ops.LnFold(st_[o][cur], D, w[pre + "ckv.s"], 1e-6)
+                    lnq = ops.LnFold(stq, D, w[pre + "cq.s"], 1e-6)
+                    if self.packed_attn:
                         npq, npk = (P + 63) // 64 * 64, (Po + 63) // 64 * 64
                         kbuf = self.ws("ckp" + tag, ops.packed_shape(B * npk, D, self.wdt), self.wdt, zero=True)
                         vt = self.ws("cvtp" + tag, (B * Hh * npk * 64,), self.wdt, zero=True)
-                        ops.proj_rope_vt(yn[s][cur], w[pre + "ckv.w"], w[pre + "ckv.b"], kbuf, 0, vt, npk, M=Ro, N=2 * D, K=D,
+                        ops.proj_rope_vt(xp[o][cur], w[pre + "ckv.w"], w[pre + "ckv.b"], kbuf, 0, vt, npk, M=Ro, N=2 * D, K=D,
                                          lda=D, rope_cols=D, pos=pos[o], cos=self.cos, sin=self.sin, tokens=Po, heads=Hh,
-                                         qkv_packed=True)
+                                         qkv_packed=True, ln=lnk)
                         qbuf = self.ws("cqp" + tag, ops.packed_shape(B * npq, D, self.wdt), self.wdt, zero=True)
-                        ops.proj_rope_vt(ln2, w[pre + "cq.w"], w[pre + "cq.b"], qbuf, 0, None, npq, M=R, N=D, K=D, lda=D,
+                        ops.proj_rope_vt(xq, w[pre + "cq.w"], w[pre + "cq.b"], qbuf, 0, None, npq, M=R, N=D, K=D, lda=D,
                                          rope_cols=D, pos=pos[s], cos=self.cos, sin=self.sin, tokens=P, heads=Hh,
-                                         qkv_packed=True)
+                                         qkv_packed=True, ln=lnq)
                         ops.attention_packed(qbuf, D, 0, npq, kbuf, D, 0, npk, vt, ao, D, B=B, heads=Hh, Nq=P, Nk=Po,
                                              scale=64 ** -0.5)
                     else:
                         kbuf = self.ws("ck" + tag, (Ro, D), self.wdt)
                         vt = self.ws("cvt" + tag, (B * Hh * 64, (Pmax + 63) // 64 * 64), self.wdt, zero=True)
                         vt_ld = vt.shape[1]
-                        ops.proj_rope_vt(yn[s][cur], w[pre + "ckv.w"], w[pre + "ckv.b"], kbuf, D, vt, vt_ld, M=Ro, N=2 * D, K=D,
-                                         lda=D, rope_cols=D, pos=pos[o], cos=self.cos, sin=self.sin, tokens=Po, heads=Hh)
+                        ops.proj_rope_vt(xp[o][cur], w[pre + "ckv.w"], w[pre + "ckv.b"], kbuf, D, vt, vt_ld, M=Ro, N=2 * D, K=D,
+                                         lda=D, rope_cols=D, pos=pos[o], cos=self.cos, sin=self.sin, tokens=Po, heads=Hh, ln=lnk)
                         qbuf = self.ws("cq" + tag, (R, D), self.wdt)
-                        ops.proj_rope_vt(ln2, w[pre + "cq.w"], w[pre + "cq.b"], qbuf, D, None, 0, M=R, N=D, K=D, lda=D,
-                                         rope_cols=D, pos=pos[s], cos=self.cos, sin=self.sin, tokens=P, heads=Hh)
+                        ops.proj_rope_vt(xq, w[pre + "cq.w"], w[pre + "cq.b"], qbuf, D, None, 0, M=R, N=D, K=D, lda=D,
+                                         rope_cols=D, pos=pos[s], cos=self.cos, sin=self.sin, tokens=P, heads=Hh, ln=lnq)
                         ops.attention(qbuf, P * D, D, kbuf, Po * D, D, vt, vt_ld, ao, D, B=B, heads=Hh, Nq=P, Nk=Po,
                                       scale=64 ** -0.5)
-                    ln3 = self.wsp("dec_ln_c" + tag, R, D)
-                    self._linear_reduce(ao, w[pre + "cproj.w"], w[pre + "cproj.b"], R, D, D, D, res=x, x_out=x,
-                                        ln1=self._norm(pre + "norm3"), out1=ln3, tag=tag)
-                    # MLP (:190); its finishing kernel emits the next layer's norm1 (own side) and norm_y (other side)
+                    self._update(ao, pre + "cproj", R, D, D, x, x, xq, stq)
+                    # MLP (:190), norm3 folded into fc1; fc2 emits the copy + statistics the next layer's GEMMs consume
                     Hd = D * cfg.mlp_ratio
                     h = self.wsp("mlp_hidden_dec" + tag, R, Hd)
-                    ops.gemm(ln3, w[pre + "fc1.w"], h, M=R, N=Hd, K=D, lda=D, ldc=Hd, bias=w[pre + "fc1.b"], act=ACT_GELU)
+                    self._mlp_fc1(xq, stq, R, D, pre, h)
                     if last:
+                        self._update(h, pre + "fc2", R, D, Hd, x, x, None, None)
                         normed = self.ws("dec%d_normed" % s, (R, D))
-                        self._linear_reduce(h, w[pre + "fc2.w"], w[pre + "fc2.b"], R, D, Hd, Hd, res=x, x_out=None,
-                                            ln1=self._norm("dec_norm"), out1=normed, tag=tag)
+                        ops.layernorm(x, w["dec_norm.w"], w["dec_norm.b"], 1e-6, normed, rows=R, C_=D)   # API-visible
                         new[s] = normed
                     else:
-                        self._linear_reduce(h, w[pre + "fc2.w"], w[pre + "fc2.b"], R, D, Hd, Hd, res=x, x_out=x,
-                                            ln1=self._norm("dec%d_%d.norm1" % (s, i + 1)), out1=ln1[s][nx],
-                                            ln2=self._norm("dec%d_%d.norm_y" % (o, i + 1)), out2=yn[o][nx], tag=tag)
+                        self._update(h, pre + "fc2", R, D, Hd, x, x, xp[s][nx], st_[s][nx])
                         new[s] = x
             join_layer()
             for s in (1, 2):
@@ -473,7 +506,8 @@ class Engine:
         sb, sy, sx, sc = pts3d.stride()
         ops.im2col_patch(pts3d, col, B=B, C_=3, H=H, W_=W_, p=p, strides=(sb, sc, sy, sx))
         # rope=None in the reference (mem_pos_enc=False): all-zero positions make the fused RoPE the identity
-        vn = self.wsp("val_normed", R, E)
-        self._vit(col, R, B, P, "pospatch", "val", cfg.val_depth, zero_pos, "value_norm", vn, tag="_val")
-        self._linear_reduce(vn, w["value_out.w"], w["value_out.b"], R, E, E, E, res=res, x_out=out, tag="_val")
+        x, xp, st = self._vit(col, R, B, P, "pospatch", "val", cfg.val_depth, zero_pos, tag="_val")
+        # value_norm folded into value_out; + feat_k1 in the epilogue
+        ops.gemm(xp, w["value_out.w"], out, M=R, N=E, K=E, lda=E, ldc=E, bias=w["value_out.b"], res1=res, ldr1=E,
+                 ln=ops.LnFold(st, E, w["value_out.s"], 1e-6))
         return out

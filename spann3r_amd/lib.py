@@ -35,7 +35,9 @@ class GemmDesc(C.Structure):
         ("rope_cols", C.c_int32), ("vt", C.c_void_p), ("tokens", C.c_int32), ("heads", C.c_int32),
         ("vt_ld", C.c_int64),
         ("ps_k", C.c_int32), ("ps_H", C.c_int32), ("ps_W", C.c_int32), ("ps_C", C.c_int32),
-        ("tile", C.c_int32), ("a_bf16", C.c_int32), ("splitk", C.c_int32), ("a_packed", C.c_int32), ("qkv_packed", C.c_int32), ("out_packed", C.c_int32), ("w_packed", C.c_int32),
+        ("tile", C.c_int32), ("a_bf16", C.c_int32), ("splitk", C.c_int32), ("a_packed", C.c_int32),
+        ("ln_stats", C.c_void_p), ("ln_s", C.c_void_p), ("ln_nt", C.c_int32), ("ln_C", C.c_int32), ("ln_eps", C.c_float),
+        ("stats_out", C.c_void_p), ("c2", C.c_void_p), ("qkv_packed", C.c_int32), ("out_packed", C.c_int32), ("w_packed", C.c_int32),
     ]
 
 

@@ -200,6 +200,18 @@ def _w(d, W):
     d.wdtype = wdtype_of(W)
 
 
+class LnFold:
+    """Consumer-side arguments of a folded LayerNorm: statistics partials of x [M, C/32, 2], s_n = sum_k (gamma*W)_nk."""
+
+    def __init__(self, stats, C_, s, eps=1e-6):
+        self.stats, self.C, self.s, self.eps = stats, C_, s, eps
+
+
+def _ln(d, ln):
+    if ln is not None:
+        d.ln_stats, d.ln_s, d.ln_nt, d.ln_C, d.ln_eps = ln.stats.data_ptr(), ln.s.data_ptr(), ln.C // 32, ln.C, ln.eps
+
+
 def wdtype_of(t):
     if t.dtype == torch.float32:
         return F32
@@ -226,7 +238,7 @@ def _act(t, name):
 
 def gemm(A, W, out, *, M, N, K, lda, ldc, bias=None, res1=None, ldr1=0, res2=None, ldr2=0, act=ACT_NONE, alpha=1.0,
          relu_in=False, tile=-1, batch=1, strideA=0, strideW=0, strideC=0, ldw=0,
-         A2=None, lda2=0, K1=0, splitk=0):
+         A2=None, lda2=0, K1=0, splitk=0, ln=None, stats_out=None, c2=None):
     """out[M,N] = act(alpha * A[M,K] @ W[N,K]^T + bias) (+ res1 + res2).  nn.Linear / 1x1 conv / einsum.
     `out` may be fp32 or bf16.  splitk >= 1 selects the PARTIAL epilogue: out is an fp32 [splitk, M, ldc] workspace
     that sp3_reduce_ln finishes."""
@@ -245,6 +257,8 @@ def gemm(A, W, out, *, M, N, K, lda, ldc, bias=None, res1=None, ldr1=0, res2=Non
     d.loader, d.epi, d.tile = L.LOAD_PLAIN, L.EPI_PLAIN, tile
     if splitk >= 1:
         d.epi, d.splitk = L.EPI_PARTIAL, splitk
+    _ln(d, ln)
+    d.stats_out, d.c2 = L.ptr(stats_out), L.ptr(c2)
     _gemm_launch(d, "sp3_gemm", "plain")
     return out
 
@@ -307,7 +321,7 @@ def conv_transpose_ks(x, Wp, out, *, B, H, W_, Cin, Cout, ks, bias=None, tile=-1
 
 
 def proj_rope_vt(A, W, bias, out_qk, ldc, vt, vt_ld, *, M, N, K, lda, rope_cols, pos, cos, sin, tokens, heads, tile=-1,
-                 qkv_packed=False):
+                 qkv_packed=False, ln=None):
     """Fused q/k(/v) projection of an attention layer: bias + 2-D RoPE on columns [0, rope_cols)
     (stored row-major to out_qk) and per-head transposed store of the V columns to vt."""
     d = GemmDesc()
@@ -322,6 +336,7 @@ def proj_rope_vt(A, W, bias, out_qk, ldc, vt, vt_ld, *, M, N, K, lda, rope_cols,
     d.rope_cos, d.rope_sin, d.pos, d.rope_cols = cos.data_ptr(), sin.data_ptr(), pos.data_ptr(), rope_cols
     d.vt, d.vt_ld, d.tokens, d.heads = L.ptr(vt), vt_ld, tokens, heads
     d.qkv_packed = int(qkv_packed)
+    _ln(d, ln)
     if out_qk is None:
         d.C = vt.data_ptr()           # unused by the kernel when rope_cols == 0, but must be non-null
     _gemm_launch(d, "sp3_gemm(rope_vt)", "plain")

@@ -121,6 +121,38 @@ def test_splitk_reduce_ln(wdt, M, N, K, S):
 
 
 @pytest.mark.parametrize("wdt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,C,N", [(196, 1024, 3072), (392, 768, 768), (20, 1024, 4096)])
+def test_layernorm_folded_into_gemm(wdt, M, C, N):
+    """Producer GEMM emits x (fp32), a fragment-order copy and per-32-column (sum, sumsq) partials; the consumer GEMM
+    computes LayerNorm(x) @ W^T + b as rstd*(x @ (g*W)^T) - rstd*mean*s + (b + W @ beta) without an LN launch."""
+    ops = _ops()
+    K0 = 256
+    A0, W0, b0, res = rnd(M, K0, seed=1), rnd(C, K0, seed=2) * 0.2, rnd(C, seed=3), rnd(M, C, seed=4) * 2 + 0.3
+    g, beta = rnd(C, seed=5) * 0.3 + 1, rnd(C, seed=6) * 0.2
+    W, b = rnd(N, C, seed=7) * 0.05, rnd(N, seed=8)
+    x = res.clone().to(DEV)
+    xp = ops.PackedAct(M, C, wdt, DEV)
+    stats = torch.full((M, C // 32, 2), float("nan"), device=DEV)
+    ops.gemm(A0.to(DEV), W0.to(DEV).to(wdt), x, M=M, N=C, K=K0, lda=K0, ldc=C, bias=b0.to(DEV), res1=x, ldr1=C,
+             stats_out=stats, c2=xp)
+    A0r, W0r = (bf(A0), bf(W0)) if wdt == torch.bfloat16 else (A0, W0)
+    xr = A0r.double() @ W0r.double().T + b0.double() + res.double()
+    assert rel_err(x.cpu(), xr) < TOL[wdt]
+    assert torch.equal(xp.to_dense(), x.to(wdt))
+    st = stats.cpu().double()
+    assert rel_err(st[..., 0].sum(1), xr.sum(1)) < 1e-4 and rel_err(st[..., 1].sum(1), (xr * xr).sum(1)) < 1e-4
+    # consumer
+    Wf = (W * g[None, :]).to(wdt)
+    s_n = Wf.float().sum(1)
+    bfold = b + W @ beta
+    y = torch.empty(M, N, device=DEV)
+    ops.gemm(xp, ops.PackedWeight(Wf.to(DEV)), y, M=M, N=N, K=C, lda=C, ldc=N, bias=bfold.to(DEV),
+             ln=ops.LnFold(stats, C, s_n.to(DEV), 1e-6))
+    ref = F.layer_norm(xr, (C,), g.double(), beta.double(), 1e-6) @ W.double().T + b.double()
+    assert rel_err(y.cpu(), ref) < (2e-4 if wdt == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize("wdt", [torch.float32, torch.bfloat16])
 def test_gemm_split_a_ldw_batch(wdt):
     ops = _ops()
     # split-A (cat along K without the copy), as used by encode_feat_key

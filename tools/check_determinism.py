@@ -1,0 +1,16 @@
+import sys; sys.path.insert(0, '/root/repo')
+import torch
+from spann3r_amd import Spann3R, TINY, FULL
+from spann3r_amd.weights import synth_state_dict, synth_frames
+cfg = FULL if len(sys.argv) > 1 and sys.argv[1] == "full" else TINY
+m = Spann3R(dus3r_name=None, cfg=cfg, init_weights=False); m.load_state_dict(synth_state_dict(0, cfg)); m = m.cuda().eval()
+S = 224 if cfg is FULL else 64
+frames = [{"img": f["img"].cuda()} for f in synth_frames(5, S, S)]
+for prec in ("fp32", "bf16"):
+    m.set_precision(prec)
+    for graphs in (False, True):
+        m.use_graphs = graphs
+        outs = [m(frames)[0] for _ in range(4)]
+        for j in range(1, 4):
+            d = max(float((a["conf"] - b["conf"]).abs().max()) for a, b in zip(outs[0], outs[j]))
+            print(prec, "graphs" if graphs else "eager", "run", j, "max |dconf| vs run 0:", d)
