@@ -36,7 +36,7 @@ class Engine:
         self.wdt = torch.float32 if precision == "fp32" else torch.bfloat16
         self.adt = self.wdt          # dtype of activations that only feed GEMMs
         import os
-        self.packed_attn = precision == "bf16" and not os.environ.get("SP3_NO_PACKED_ATTN")
+        self.packed_attn = precision == "bf16"      # fragment-order q/k/v + wave-split attention kernel
         self._ws = {}
         self._pos_cache = {}
         self.max_pos = 0
@@ -313,20 +313,10 @@ class Engine:
                 st[1].wait_stream(main)
                 st[2].wait_stream(main)
 
-        import os
-        dbg_sync = os.environ.get("SP3_DEC_SYNC")
-
         def join_layer():
             if streams:
                 main.wait_stream(st[1])
                 main.wait_stream(st[2])
-                # A join that is followed directly by a fork leaves `main` with nothing but event waits between them; on
-                # ROCm 7.2 the next fork's event then does NOT order the side streams behind both joins (measured:
-                # run-to-run different decoder outputs, gone with a host sync here).  One trivial kernel on `main`
-                # makes the join a real node of the stream / graph.
-                ops.fill(self.ws("join_token", (64,)), 0.0)
-                if dbg_sync:
-                    torch.cuda.synchronize()
 
         fork_layer()
         for s in (1, 2):

@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libspann3r_hip.so")
+LIB_PATH = os.environ.get("SP3_LIB_PATH") or os.path.join(_HERE, "libspann3r_hip.so")   # override: kernel-variant experiments
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2

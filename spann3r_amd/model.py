@@ -301,20 +301,11 @@ class _SequenceRunner:
         eng, mem, B, P = self.eng, self.mem, self.B, self.P
         main = torch.cuda.current_stream()
         st = eng.side_streams()
-        dbg = os.environ.get("SP3_STREAMS", "3")        # debugging aid: "1" = everything on one stream, "2" = no prefetch stream
-        if dbg == "1":
-            st = {1: main, 2: main, 3: main}
-        elif dbg == "2":
-            st = {1: st[1], 2: st[2], 3: main}
         if has_next:
             st[3].wait_stream(main)
             with torch.cuda.stream(st[3]):
                 eng.encode_image(self.img_next, out=self.feat_pre, tag="_pre")
-        dec1, dec2 = eng.decoder(f1, self.feat2, B, self.nh, self.nw, self.nh, self.nw,
-                                 streams=None if dbg == "1" else st)                                 # joined on return
-        if os.environ.get("SP3_TAIL_SERIAL"):
-            st = {1: main, 2: main, 3: st[3]}
-        ops.fill(eng.ws("join_token", (64,)), 0.0)      # see Engine.decoder: keep a kernel between a join and a fork
+        dec1, dec2 = eng.decoder(f1, self.feat2, B, self.nh, self.nw, self.nh, self.nw, streams=st)   # joined on return
         st[1].wait_stream(main)
         st[2].wait_stream(main)
         with torch.cuda.stream(st[1]):
