@@ -311,6 +311,24 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_kernel(const GemmArgs 
 #pragma unroll
     for (int n = 0; n < NF; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // Folded LayerNorm: the producer's per-32-column (sum, sum of squares) partials of this tile's rows are requested
+  // BEFORE the K loop (TPR threads per row, 4 partials each in flight) and reduced after it: their latency hides
+  // behind the GEMM instead of sitting between two barriers.
+  constexpr int TPR = NT / BM;                      // threads per tile row (8 or 4): a power of two, lane-aligned
+  const int srow = tid / TPR, sj = tid % TPR;
+  float2 sp[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+  const float2* sps = nullptr;
+  constexpr bool LNF = LOADER == SP3_LOAD_PLAIN;    // the conv loader never folds a LayerNorm (keeps its registers)
+  if (LNF && d.ln_stats) {
+    const int sgm = (m0 + srow) < d.M ? (m0 + srow) : d.M - 1;
+    sps = reinterpret_cast<const float2*>(d.ln_stats) + (int64_t)sgm * d.ln_nt;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int t = sj + q * TPR;
+      sp[q] = sps[t < d.ln_nt ? t : d.ln_nt - 1];     // unconditional load, clamped; masked when summed
+    }
+  }
+
   // k-blocks of this workgroup's K slice (split-K over grid.z), interleaved over the WK waves
   const int nkb_all = (d.K + KB - 1) / KB;
   const int per = (nkb_all + d.splitk - 1) / d.splitk;
@@ -418,31 +436,41 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_kernel(const GemmArgs 
           slab[row * LDS_LD + col] = acc[m][n][r];
         }
   }
+  // folded LayerNorm: finish mean / rstd of this tile's rows (rowstat does not alias the slabs: one barrier covers both)
+  float* rowstat = smem + (size_t)WK * BM * LDS_LD;     // [BM][2]
+  if (LNF && d.ln_stats) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (sj + q * TPR < d.ln_nt) { s1 += sp[q].x; s2 += sp[q].y; }
+    for (int t = sj + 4 * TPR; t < d.ln_nt; t += TPR) { const float2 v = sps[t]; s1 += v.x; s2 += v.y; }
+#pragma unroll
+    for (int o_ = 1; o_ < TPR; o_ <<= 1) { s1 += __shfl_xor(s1, o_); s2 += __shfl_xor(s2, o_); }
+    if (sj == 0) {
+      const float mean = s1 / (float)d.ln_C;
+      const float var = fmaxf(s2 / (float)d.ln_C - mean * mean, 0.f);
+      rowstat[2 * srow] = mean;
+      rowstat[2 * srow + 1] = 1.0f / sqrtf(var + d.ln_eps);
+    }
+  }
   __syncthreads();
 
-  // folded LayerNorm: finish mean / rstd of this tile's rows from the producer's per-32-column partial sums
-  float* rowstat = smem + (size_t)WK * BM * LDS_LD;     // [BM][2]
-  if (d.ln_stats) {
-    for (int r = tid; r < BM; r += NT) {
-      const int gm = m0 + r;
-      float mean = 0.f, rstd = 0.f;
-      if (gm < d.M) {
-        const float2* ps = reinterpret_cast<const float2*>(d.ln_stats) + (int64_t)gm * d.ln_nt;
-        float s1 = 0.f, s2 = 0.f;
-        for (int t = 0; t < d.ln_nt; ++t) { const float2 v = ps[t]; s1 += v.x; s2 += v.y; }
-        mean = s1 / (float)d.ln_C;
-        const float var = fmaxf(s2 / (float)d.ln_C - mean * mean, 0.f);
-        rstd = 1.0f / sqrtf(var + d.ln_eps);
-      }
-      rowstat[2 * r] = mean;
-      rowstat[2 * r + 1] = rstd;
-    }
-    __syncthreads();
-  }
   // y = rstd * acc - rstd * mean * s[n]   (bias, already folded with beta . W^T, is added by the epilogues below)
   auto ln_fold = [&](float acc, int row, int gn) -> float {
     const float mean = rowstat[2 * row], rstd = rowstat[2 * row + 1];
     return rstd * acc - rstd * mean * d.ln_s[gn];
+  };
+  // the same for 4 consecutive columns gn..gn+3 (gn % 4 == 0, all inside N)
+  auto ln_fold4 = [&](float (&x)[4], int row, int gn) {
+    const float mean = rowstat[2 * row], rstd = rowstat[2 * row + 1];
+    const float4 s4 = *reinterpret_cast<const float4*>(d.ln_s + gn);
+    const float rm = rstd * mean;
+    x[0] = rstd * x[0] - rm * s4.x; x[1] = rstd * x[1] - rm * s4.y;
+    x[2] = rstd * x[2] - rm * s4.z; x[3] = rstd * x[3] - rm * s4.w;
+  };
+  auto add4 = [&](float (&x)[4], const float* p) {
+    const float4 b4 = *reinterpret_cast<const float4*>(p);
+    x[0] += b4.x; x[1] += b4.y; x[2] += b4.z; x[3] += b4.w;
   };
 
   auto lds_sum4 = [&](int row, int c4) -> float4 {
@@ -460,6 +488,49 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_kernel(const GemmArgs 
   if (d.epi == SP3_EPI_ROPE_VT && n0 >= d.rope_cols) {
     // ---------------- V part: store transposed per head, vt[((b*heads+h)*64+dd)*vt_ld + n]
     TW* vt = reinterpret_cast<TW*>(d.vt);
+    if ((d.tokens & 3) == 0) {
+      // 4 consecutive tokens of one column per thread: they are contiguous in both V layouts (8- or 16-byte store)
+      for (int idx = tid; idx < (BM / 4) * BN; idx += NT) {
+        const int rq = idx % (BM / 4), col = idx / (BM / 4);
+        const int gm = m0 + 4 * rq, gn = n0 + col;
+        if (gm >= d.M || gn >= d.N) continue;                       // M % 4 == 0 here (M = B * tokens)
+        const float bias = d.bias ? d.bias[gn] : 0.f;
+        const float sn_ = d.ln_stats ? d.ln_s[gn] : 0.f;
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = 4 * rq + i;
+          float x = smem[row * LDS_LD + col];
+#pragma unroll
+          for (int s_ = 1; s_ < WK; ++s_) x += smem[(size_t)s_ * BM * LDS_LD + row * LDS_LD + col];
+          x *= alpha;
+          if (d.ln_stats) { const float mean = rowstat[2 * row], rstd = rowstat[2 * row + 1]; x = rstd * x - rstd * mean * sn_; }
+          v[i] = x + bias;
+        }
+        const int vc = gn - d.rope_cols;
+        const int h = vc >> 6, dd = vc & 63;
+        const int b = gm / d.tokens, n = gm - b * d.tokens;
+        int64_t off;
+        if (d.qkv_packed) {
+          // PV-operand order [(b,h)][key/32][d/16][lane = 16*g + d%16][8]: the 8 keys a lane feeds to one
+          // v_mfma_f32_16x16x32 (keys 32u + 16*(e>>2) + 4g + (e&3)) are contiguous -> 1 KB contiguous per wave load
+          const int u = n >> 5, kk = n & 31, w16 = kk & 15;
+          const int e = 4 * (kk >> 4), lane_ = (w16 >> 2) * 16 + (dd & 15);
+          const int64_t nU = d.vt_ld >> 5;
+          off = ((((int64_t)(b * d.heads + h) * nU + u) * 4 + (dd >> 4)) * 64 + lane_) * 8 + e;
+        } else {
+          off = ((int64_t)(b * d.heads + h) * 64 + dd) * d.vt_ld + n;
+        }
+        if constexpr (sizeof(TW) == 2) {
+          bf16x4 ob;
+          ob[0] = (__bf16)v[0]; ob[1] = (__bf16)v[1]; ob[2] = (__bf16)v[2]; ob[3] = (__bf16)v[3];
+          *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(vt) + off) = ob;
+        } else {
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(vt) + off) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+      return;
+    }
     for (int idx = tid; idx < BM * BN; idx += NT) {
       const int row = idx % BM, col = idx / BM;
       const int gm = m0 + row, gn = n0 + col;
@@ -474,8 +545,6 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_kernel(const GemmArgs 
       const int h = vc >> 6, dd = vc & 63;
       const int b = gm / d.tokens, n = gm - b * d.tokens;
       if (d.qkv_packed) {
-        // PV-operand order [(b,h)][key/32][d/16][lane = 16*g + d%16][8]: the 8 keys a lane feeds to one
-        // v_mfma_f32_16x16x32 (keys 32u + 16*(e>>2) + 4g + (e&3)) are contiguous -> 1 KB contiguous per wave load
         const int u = n >> 5, kk = n & 31, w16 = kk & 15;
         const int e = (w16 & 3) + 4 * (kk >> 4), lane_ = (w16 >> 2) * 16 + (dd & 15);
         const int64_t nU = d.vt_ld >> 5;
@@ -504,12 +573,21 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_kernel(const GemmArgs 
     }
 
     if (d.epi == SP3_EPI_ROPE_VT) {
-      // bias, then RoPE with the partner column (col ^ 16 inside the 64-wide head)
+      // bias, then RoPE with the partner column (col ^ 16 inside the 64-wide head); everything in groups of 4 columns
+      // (rope_cols % 64 == 0, so the group and its partner group lie inside N and are 16-byte aligned)
       float4 part4 = lds_sum4(row, c4 ^ 16);
       float pv[4] = {part4.x * alpha, part4.y * alpha, part4.z * alpha, part4.w * alpha};
       const int hc = gn & 63;
       const int axis = hc >> 5, is_v = (hc >> 4) & 1, i0 = hc & 15;
       const int pos = d.pos[(int64_t)gm * 2 + axis];
+      if (d.ln_stats) { ln_fold4(v, row, gn); ln_fold4(pv, row, gn ^ 16); }
+      if (d.bias) { add4(v, d.bias + gn); add4(pv, d.bias + (gn ^ 16)); }
+      const float4 cs4 = *reinterpret_cast<const float4*>(d.rope_cos + pos * 16 + i0);
+      const float4 sn4 = *reinterpret_cast<const float4*>(d.rope_sin + pos * 16 + i0);
+      const float cs[4] = {cs4.x, cs4.y, cs4.z, cs4.w}, sn[4] = {sn4.x, sn4.y, sn4.z, sn4.w};
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = is_v ? (v[e] * cs[e] + pv[e] * sn[e]) : (v[e] * cs[e] - pv[e] * sn[e]);
       TW* out;
       if (d.qkv_packed) {      // fragment order, rows padded per image to vt_ld (a multiple of 64) tokens
         const int b = gm / d.tokens, n = gm - b * d.tokens;
@@ -517,31 +595,40 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_kernel(const GemmArgs 
       } else {
         out = reinterpret_cast<TW*>(d.C) + (int64_t)bz * d.strideC + (int64_t)gm * d.ldc + gn;
       }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float self = v[e], other = pv[e];
-        if (d.ln_stats) { self = ln_fold(self, row, gn + e); other = ln_fold(other, row, (gn + e) ^ 16); }
-        self += (d.bias ? d.bias[gn + e] : 0.f);
-        other += (d.bias ? d.bias[(gn + e) ^ 16] : 0.f);
-        const float cs = d.rope_cos[pos * 16 + i0 + e], sn = d.rope_sin[pos * 16 + i0 + e];
-        const float o = is_v ? (self * cs + other * sn) : (self * cs - other * sn);
-        out[e] = (TW)o;
+      if constexpr (sizeof(TW) == 2) {
+        bf16x4 ob;
+        ob[0] = (__bf16)o[0]; ob[1] = (__bf16)o[1]; ob[2] = (__bf16)o[2]; ob[3] = (__bf16)o[3];
+        if ((reinterpret_cast<uintptr_t>(out) & 7) == 0) *reinterpret_cast<bf16x4*>(out) = ob;
+        else { out[0] = ob[0]; out[1] = ob[1]; out[2] = ob[2]; out[3] = ob[3]; }
+      } else {
+        if ((reinterpret_cast<uintptr_t>(out) & 15) == 0) *reinterpret_cast<float4*>(out) = make_float4(o[0], o[1], o[2], o[3]);
+        else { out[0] = o[0]; out[1] = o[1]; out[2] = o[2]; out[3] = o[3]; }
       }
       continue;
     }
 
     // bias + activation
+    if (nvalid == 4 && d.epi != SP3_EPI_PIXSHUF) {
+      if (d.ln_stats) ln_fold4(v, row, gn);
+      if (d.bias) add4(v, d.bias + gn);
+    } else {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      if (e < nvalid) {
-        float x = v[e];
-        if (d.ln_stats) x = ln_fold(x, row, gn + e);
-        if (d.epi == SP3_EPI_PIXSHUF) x += d.bias ? d.bias[(gn + e) % d.ps_C] : 0.f;
-        else x += d.bias ? d.bias[gn + e] : 0.f;
-        if (d.act == SP3_ACT_GELU) x = gelu_erf(x);
-        else if (d.act == SP3_ACT_RELU) x = fmaxf(x, 0.f);
-        v[e] = x;
+      for (int e = 0; e < 4; ++e) {
+        if (e < nvalid) {
+          float x = v[e];
+          if (d.ln_stats) x = ln_fold(x, row, gn + e);
+          if (d.epi == SP3_EPI_PIXSHUF) x += d.bias ? d.bias[(gn + e) % d.ps_C] : 0.f;
+          else x += d.bias ? d.bias[gn + e] : 0.f;
+          v[e] = x;
+        }
       }
+    }
+    if (d.act == SP3_ACT_GELU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+    } else if (d.act == SP3_ACT_RELU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
     }
 
     int64_t off;
@@ -657,12 +744,16 @@ extern "C" int sp3_gemm(const sp3_gemm_desc* dp, void* stream_) {
   SP3_CHECK(!d.a_bf16 || d.wdtype == SP3_BF16, "sp3_gemm: a_bf16 needs wdtype bf16");
   SP3_CHECK((reinterpret_cast<uintptr_t>(d.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(d.W) & 15) == 0,
             "sp3_gemm: A and W must be 16-byte aligned");
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  SP3_CHECK(al16(d.bias) && al16(d.ln_s) && al16(d.ln_stats) && al16(d.rope_cos) && al16(d.rope_sin),
+            "sp3_gemm: bias / ln_s / ln_stats / rope tables must be 16-byte aligned (vector loads in the epilogue)");
   if (d.batch <= 0) d.batch = 1;
   if (d.splitk <= 0) d.splitk = 1;
   if (d.ldw <= 0) d.ldw = d.K;
   SP3_CHECK(!d.w_packed || d.batch == 1, "sp3_gemm: packed weights are unbatched");
-  SP3_CHECK(!d.ln_stats || (d.ln_s && d.ln_nt > 0 && d.ln_C == 32 * d.ln_nt && d.batch == 1 && d.epi != SP3_EPI_PARTIAL),
-            "sp3_gemm: folded LayerNorm needs ln_s, ln_nt, ln_C = 32*ln_nt, batch 1");
+  SP3_CHECK(!d.ln_stats || (d.ln_s && d.ln_nt > 0 && d.ln_C == 32 * d.ln_nt && d.batch == 1 && d.epi != SP3_EPI_PARTIAL &&
+                            d.loader == SP3_LOAD_PLAIN && d.N % 4 == 0),
+            "sp3_gemm: folded LayerNorm needs ln_s, ln_nt, ln_C = 32*ln_nt, batch 1, the plain loader, N %% 4 == 0");
   SP3_CHECK((!d.stats_out && !d.c2) || (d.epi == SP3_EPI_PLAIN && d.batch == 1 && d.N % 32 == 0 && !d.out_packed),
             "sp3_gemm: stats_out / c2 need the plain epilogue, batch 1, N %% 32 == 0");
   SP3_CHECK(!d.out_packed || (d.epi == SP3_EPI_PLAIN && d.batch == 1 && d.N % 4 == 0), "sp3_gemm: out_packed needs the plain epilogue, batch 1, N %% 4 == 0");
