@@ -224,6 +224,16 @@ int sp3_gather_1d(const float* src, float* dst, const int32_t* sel, int n_sel, v
  *   pts3d = xyz/max(|xyz|,1e-8) * expm1(|xyz|), conf = 1 + exp(c).  feat [pixels, C] fp32,
  *   w fp32 [4, C], b fp32 [4] -> pts [pixels,3], conf [pixels], raw [pixels,4] (optional).
  */
+/* sp3_conv3x3_tile : Conv2d(3x3, stride 1, padding 1) on an NHWC map [B,H,W,Cin] -> [B,H,W,Cout] as an LDS-tiled
+ *   implicit GEMM (bf16 MFMA, fp32 accumulation): out = act(conv(relu_in ? relu(x) : x) + bias) + res1 + res2.
+ *   x fp32 or bf16 (in_bf16); w_packed = the [Cout, 9*Cin] weight (k = (ky*3+kx)*Cin + ci) as bf16 in sp3_gemm's
+ *   w_packed fragment order; bias fp32[Cout] / res1 / res2 fp32 NHWC maps of the output shape, all optional;
+ *   out fp32 or bf16 (out_bf16).  Cin, Cout multiples of 64; act is SP3_ACT_NONE or SP3_ACT_RELU.
+ *   Replaces the Conv2d calls of ResidualConvUnit_custom (croco/models/dpt_block.py:120-142), scratch.layer_rn
+ *   (:180-188) and the head convs (:318-324) in bf16 mode; fp32 mode and stride 2 use sp3_gemm's LOAD_CONV3X3. */
+int sp3_conv3x3_tile(const void* x, int in_bf16, const void* w_packed, const float* bias, const float* res1,
+                     const float* res2, void* out, int out_bf16, int B, int H, int W, int Cin, int Cout,
+                     int relu_in, int act, void* stream);
 int sp3_im2col_patch(const float* img, int64_t sb, int64_t sc, int64_t sy, int64_t sx, int B, int C, int H, int W,
                      int p, void* out, int out_bf16, int out_packed, void* stream);
 int sp3_upsample2x(const float* in, float* out, int B, int H, int W, int C, int outH, int outW, void* stream);

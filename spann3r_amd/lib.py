@@ -84,6 +84,8 @@ _PROTOS = {
     "sp3_gather_1d": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p],
     "sp3_im2col_patch": [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int,
                          C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p],
+    "sp3_conv3x3_tile": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "sp3_upsample2x": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "sp3_head_final": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                        C.c_void_p],

@@ -284,10 +284,21 @@ def reduce_ln(partial, splits, rows, C_, *, bias=None, res=None, ldres=0, x_out=
 
 
 def conv3x3(x, Wp, out, *, B, H, W_, Cin, Cout, stride=1, bias=None, res1=None, res2=None, act=ACT_NONE,
-            relu_in=False, tile=-1):
+            relu_in=False, tile=-1, force_tile_kernel=False):
     """3x3 Conv2d, padding 1, on an NHWC fp32 map [B,H,W,Cin] -> [B,OH,OW,Cout] (implicit GEMM).
     Wp is the weight packed as [Cout, 9*Cin] with k = (ky*3+kx)*Cin + ci."""
     OH, OW = (H - 1) // stride + 1, (W_ - 1) // stride + 1
+    if (tile < 0 and stride == 1 and isinstance(Wp, PackedWeight) and Wp.dtype == torch.bfloat16
+            and Cin % 64 == 0 and Cout % 64 == 0 and Cin <= 768 and (force_tile_kernel or H * W_ >= 2048)):
+        # bf16 weights, stride 1: the LDS-tiled kernel (input halo tile staged once, 9 taps read it from LDS)
+        _act(x, "x")
+        _timed("conv3x3_tile", 2.0 * B * H * W_ * Cout * 9 * Cin,
+               B * H * W_ * (x.element_size() * Cin + out.element_size() * Cout) + 2.0 * 9 * Cin * Cout,
+               lambda: L.check(L.load().sp3_conv3x3_tile(
+                   x.data_ptr(), int(x.dtype == torch.bfloat16), Wp.data_ptr(), L.ptr(bias), L.ptr(res1), L.ptr(res2),
+                   out.data_ptr(), int(out.dtype == torch.bfloat16), B, H, W_, Cin, Cout, int(relu_in), act,
+                   L.stream_ptr()), "sp3_conv3x3_tile"))
+        return out
     d = GemmDesc()
     d.a_bf16 = _act(x, "x")
     d.out_bf16 = int(out.dtype == torch.bfloat16)

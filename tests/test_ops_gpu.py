@@ -193,6 +193,39 @@ def test_conv3x3(wdt, B, H, W, Cin, Cout, stride):
     assert rel_err(out.cpu(), nhwc(ref)) < TOL[wdt]
 
 
+@pytest.mark.parametrize("in_dt,out_dt", [(torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16), (torch.float32, torch.bfloat16)])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(1, 56, 56, 256, 256), (2, 13, 9, 128, 128), (1, 8, 8, 64, 192), (1, 20, 28, 256, 128),
+                                            (1, 3, 5, 384, 64)])
+@pytest.mark.parametrize("variant", ["rcu1", "rcu2", "plain"])
+def test_conv3x3_tile(in_dt, out_dt, B, H, W, Cin, Cout, variant):
+    """sp3_conv3x3_tile (LDS halo tile, packed bf16 weights) vs F.conv2d on the bf16-rounded operands; ragged tiles,
+    input ReLU, bias / ReLU / two residuals, fp32 and bf16 maps."""
+    ops = _ops()
+    x, w, b = rnd(B, Cin, H, W, seed=1), rnd(Cout, Cin, 3, 3, seed=2) * 0.05, rnd(Cout, seed=3)
+    r1, r2 = rnd(B, Cout, H, W, seed=4), rnd(B, Cout, H, W, seed=5)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous()
+    wp = ops.PackedWeight(w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to(DEV).to(torch.bfloat16))
+    out = torch.full((B, H, W, Cout), float("nan"), device=DEV, dtype=out_dt)
+    xin = nhwc(x).to(DEV).to(in_dt)
+    relu_in = variant in ("rcu1", "rcu2")
+    kw = dict(B=B, H=H, W_=W, Cin=Cin, Cout=Cout, relu_in=relu_in, force_tile_kernel=True)
+    if variant == "rcu1":
+        ops.conv3x3(xin, wp, out, bias=b.to(DEV), act=ops.ACT_RELU, **kw)
+    elif variant == "rcu2":
+        ops.conv3x3(xin, wp, out, bias=b.to(DEV), res1=nhwc(r1).to(DEV), res2=nhwc(r2).to(DEV), **kw)
+    else:
+        ops.conv3x3(xin, wp, out, **kw)
+    xr = bf(x)
+    xr = F.relu(xr) if relu_in else xr
+    ref = F.conv2d(xr.double(), bf(w).double(), None if variant == "plain" else b.double(), padding=1)
+    if variant == "rcu1":
+        ref = F.relu(ref)
+    elif variant == "rcu2":
+        ref = ref + r1.double() + r2.double()
+    tol = 2e-5 if out_dt == torch.float32 else 6e-3
+    assert rel_err(out.float().cpu(), nhwc(ref)) < tol
+
+
 @pytest.mark.parametrize("wdt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("ks,C", [(4, 96), (2, 192)])
 def test_conv_transpose(wdt, ks, C):
