@@ -797,7 +797,9 @@ extern "C" int sp3_gemm(const sp3_gemm_desc* dp, void* stream_) {
     const long sk = d.splitk;
     const long t64 = (long)((d.M + 63) / 64) * ((d.N + 63) / 64) * d.batch * sk;
     const long t128 = (long)((d.M + 63) / 64) * ((d.N + 127) / 128) * d.batch;
-    if (d.loader == SP3_LOAD_CONV3X3 || d.M > 2048) {
+    if (d.loader != SP3_LOAD_CONV3X3 && d.M >= 1024 && sk == 1) {
+      tile = (d.K >= 2048 && d.N % 128 == 0) ? 2 : 1;     // many rows: 64-row tiles (tools/bench_gemm.py --M 1960)
+    } else if (d.loader == SP3_LOAD_CONV3X3 || d.M > 2048) {
       if (t128 >= 1024 && d.N % 128 == 0) tile = 2;
       else if (t64 >= 512) tile = 1;
       else tile = 0;

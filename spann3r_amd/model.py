@@ -282,6 +282,8 @@ class _SequenceRunner:
         self.graphs = {}
         self.seen = set()
         self.out = None
+        self.batched = False          # True: the frames of the sequence were encoded up front (encode_sequence)
+        self.img_all = self.feats = None
 
     def ensure_memory(self, n_frames):
         need = (n_frames - 1) * self.P if self.training else 4000 + 8 * self.P
@@ -291,6 +293,51 @@ class _SequenceRunner:
             self.seen.clear()
         self.mem.reset()
         return self.mem
+
+    # ---- whole-sequence encoder -------------------------------------------------------------------------------
+    ENC_CHUNK_ROWS = 16          # images per encoder launch group (bounds the workspace for long sequences)
+
+    def encode_sequence(self, frames, use_graphs):
+        """The ViT-L encoder sees each frame exactly once and does not depend on the memory (spann3r/model.py:293-295),
+        so for a sequence that is handed over as a whole all frames go through it together: M = n*B*P rows per GEMM
+        instead of B*P, i.e. 64-row tiles and 5-10x fewer weight passes.  feats[i] is what the reference calls feat of
+        frame i."""
+        B, n = self.B, len(frames)
+        if self.feats is None or self.feats.shape[0] < n * B:
+            self.img_all = torch.empty(n * B, 3, self.H, self.W, device=self.eng.device)
+            self.feats = torch.empty(n * B, self.P, self.E, device=self.eng.device)
+            self.graphs = {k: g for k, g in self.graphs.items() if k[0] != "enc"}
+            self.seen = {k for k in self.seen if k[0] != "enc"}
+        for i, f in enumerate(frames):
+            self.img_all[i * B:(i + 1) * B].copy_(f["img"])
+        per = max(1, self.ENC_CHUNK_ROWS // B)
+        for c0 in range(0, n, per):
+            c1 = min(n, c0 + per)
+            img, out = self.img_all[c0 * B:c1 * B], self.feats[c0 * B:c1 * B]
+            self._graphed(("enc", c0, c1), lambda: self.eng.encode_image(img, out=out, tag="_seq"), use_graphs)
+        self.batched = True
+
+    def load_pair(self, i):
+        """featpair <- (feat of frame i, feat of frame i+1): two adjacent slabs of the sequence buffer, one copy"""
+        B, P, E = self.B, self.P, self.E
+        ops.copy2d(self.feats[i * B:(i + 2) * B], E, self.featpair, E, 2 * B * P, E)
+
+    def _graphed(self, key, fn, use_graphs):
+        """eager the first time a key is seen (creates the workspaces), captured the second time, replayed afterwards"""
+        if not use_graphs:
+            fn()
+        elif key in self.graphs:
+            self.graphs[key].replay()
+        elif key in self.seen:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                fn()
+            self.graphs[key] = g
+            g.replay()
+        else:
+            self.seen.add(key)
+            fn()
 
     # ---- the kernel sequences (spann3r/model.py:485-531) ----------------------------------------------------
     def _tail(self, f1, has_next):
@@ -326,36 +373,26 @@ class _SequenceRunner:
         self.out = (pts1, conf1, pts2, conf2)
 
     def _first(self, has_next):
-        self.eng.encode_image(self.img_pair, out=self.featpair)
+        if not self.batched:
+            self.eng.encode_image(self.img_pair, out=self.featpair)
         self._tail(self.feat1, has_next)
 
     def _step(self, has_next):
         eng, B, P, E = self.eng, self.B, self.P, self.E
-        ops.copy2d(self.feat2, E, self.feat1, E, B * P, E)      # feat1 <- previous feat2 (:294)
-        ops.copy2d(self.feat_pre, E, self.feat2, E, B * P, E)   # feat2 <- the frame encoded during the previous step
+        if not self.batched:
+            ops.copy2d(self.feat2, E, self.feat1, E, B * P, E)      # feat1 <- previous feat2 (:294)
+            ops.copy2d(self.feat_pre, E, self.feat2, E, B * P, E)   # feat2 <- the frame encoded during the previous step
         self.mem.memory_read(self.k2, self.fuse)                # reads k2 before _tail overwrites it
         self._tail(self.fuse, has_next)
 
     def run(self, first, has_next, use_graphs):
         mem = self.mem
-        key = ("first" if first else "step", mem.M, mem.wm, mem._cur, has_next)
+        has_next = has_next and not self.batched                # nothing to prefetch: the sequence is already encoded
+        key = ("first" if first else "step", mem.M, mem.wm, mem._cur, has_next, self.batched)
         fn = (lambda: self._first(has_next)) if first else (lambda: self._step(has_next))
-        if not use_graphs:
-            if ops._prof is not None:
-                ops._prof.step_begin()
-            fn()
-        elif key in self.graphs:
-            self.graphs[key].replay()
-        elif key in self.seen:
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                fn()
-            self.graphs[key] = g
-            g.replay()
-        else:
-            self.seen.add(key)
-            fn()
+        if not use_graphs and ops._prof is not None:
+            ops._prof.step_begin()
+        self._graphed(key, fn, use_graphs)
         pts1, conf1, pts2, conf2 = self.out
         res1 = {"pts3d": pts1.clone(), "conf": conf1.clone()}
         res2 = {"pts3d": pts2.clone(), "conf": conf2.clone()}
@@ -420,6 +457,7 @@ class Spann3R(nn.Module):
         self._pinned = None
         self._runners = {}
         self.use_graphs = True       # capture each per-frame step in a hipGraph (False: same kernels, eager launches)
+        self.batch_encode = True     # forward(): encode all frames of the sequence together (False: frame by frame)
 
     # ------------------------------------------------------------------ engine management
     def set_precision(self, precision):
@@ -552,13 +590,20 @@ class Spann3R(nn.Module):
         mem = run.ensure_memory(len(frames))
         preds, preds_all = None, []
         n = len(frames)
+        if self.batch_encode and n > 2:
+            run.encode_sequence(frames, self.use_graphs)
+        else:
+            run.batched = False
         for i in range(n - 1):
-            if i == 0:
-                run.img_pair[:B].copy_(frames[0]["img"])
-                run.img_pair[B:].copy_(frames[1]["img"])
+            if run.batched:
+                run.load_pair(i)
+            else:
+                if i == 0:
+                    run.img_pair[:B].copy_(frames[0]["img"])
+                    run.img_pair[B:].copy_(frames[1]["img"])
+                if i + 2 < n:
+                    run.img_next.copy_(frames[i + 2]["img"])
             has_next = i + 2 < n
-            if has_next:
-                run.img_next.copy_(frames[i + 2]["img"])
             res1, res2 = run.run(i == 0, has_next, self.use_graphs)
             res2["pts3d_in_other_view"] = res2.pop("pts3d")                      # :523
             if preds is None:

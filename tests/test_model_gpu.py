@@ -110,7 +110,8 @@ def test_graph_replay_equals_eager(tiny_model):
     frames = to_dev(synth_frames(5, 48, 64, seed=5))
     outs = [m(frames, return_memory=True) for _ in range(3)]
     run = [r for k, r in m._runners.items() if k[:3] == (1, 48, 64)][0]
-    assert len(run.graphs) == 4                      # one per step of the 5-frame sequence
+    assert sum(k[0] in ("first", "step") for k in run.graphs) == 4      # one per step of the 5-frame sequence
+    assert ("enc", 0, 5) in run.graphs                                   # + the whole-sequence encoder
     m.use_graphs = False
     try:
         outs.append(m(frames, return_memory=True))
@@ -124,6 +125,24 @@ def test_graph_replay_equals_eager(tiny_model):
     # a different sequence through the captured graphs must differ (inputs are copied into the static buffers)
     other, _ = m(to_dev(synth_frames(5, 48, 64, seed=6)))
     assert not torch.equal(other[0]["pts3d"], outs[0][0][0]["pts3d"])
+
+
+def test_batched_encoder_equals_per_frame(tiny_model):
+    """forward() encodes the whole sequence in one batch; the frame-by-frame schedule (prefetch stream) computes the
+    same features with other GEMM tiles: results agree to fp32 rounding, memory decisions are identical."""
+    from spann3r_amd.weights import synth_frames
+    m = tiny_model
+    frames = to_dev(synth_frames(6, 48, 64, seed=7))
+    a = m(frames, return_memory=True)
+    m.batch_encode = False
+    try:
+        b = m(frames, return_memory=True)
+    finally:
+        m.batch_encode = True
+    for x, y in zip(a[0], b[0]):
+        for k in x:
+            assert rel_err(x[k].cpu(), y[k].cpu()) < 2e-5, k
+    assert a[2].M == b[2].M and a[2].wm == b[2].wm
 
 
 def test_tiny_training_policy(tiny_model):

@@ -15,6 +15,7 @@ ap.add_argument("--adt", default="bf16")
 ap.add_argument("--wdt", default="bf16")
 ap.add_argument("--iters", type=int, default=50)
 ap.add_argument("--packed", type=int, default=1)
+ap.add_argument("--M", type=int, default=0, help="only the encoder shapes at this M")
 args = ap.parse_args()
 DT = {"bf16": torch.bfloat16, "f32": torch.float32}
 dev = "cuda"
@@ -24,6 +25,8 @@ shapes = [  # M, N, K, splitk list
 ]
 
 
+if args.M:
+    shapes = [(args.M, 3072, 1024, [0]), (args.M, 4096, 1024, [0]), (args.M, 1024, 4096, [0]), (args.M, 1024, 1024, [0])]
 from tools.timing import timeit  # noqa: E402
 
 
