@@ -192,7 +192,8 @@ int sp3_attention_packed(const void* qp, int q_cols, int q_col0, int npad_q, con
  *   written as 0 so that P can be the A operand of the P.V GEMM.  batch in grid.y via strideS.
  * sp3_colsum_accum : mem_attn[j] += sum_r P[r, j]  (:180-181).
  * sp3_cos_sim      : score[t] = mean_p cos(k[p,:], wm[t,p,:]) for t < T (:102-112); k fp32 [P,C],
- *   wm fp32 [T,P,C] contiguous. Deterministic reduction order.
+ *   wm fp32 [T,P,C] contiguous; scratch fp32 [T*P] holds the per-patch cosines (one wave per (t,p) pair, then one
+ *   block per t averages them). Deterministic reduction order.
  * sp3_mem_append   : count[0..M) += 1; count[M..M+P) = 0; attn[M..M+P) = 0  (:84-90).
  * sp3_prune_select : w = attn/count, w[count < protect] = 1e8; sel[0..top_k) = indices of the top_k
  *   weights, sorted by weight descending, ties by index ascending (:187-193). M <= 8192.
@@ -203,7 +204,7 @@ int sp3_attention_packed(const void* qp, int q_cols, int q_col0, int npad_q, con
 int sp3_softmax_thresh(const float* S, float* P, int64_t ld, int64_t strideS, int rows, int M, int Mpad,
                        float thresh, int batch, void* stream);
 int sp3_colsum_accum(const float* P, int64_t ld, int rows, int M, float* mem_attn, void* stream);
-int sp3_cos_sim(const float* k, const float* wm, int T, int P, int C, float* score, void* stream);
+int sp3_cos_sim(const float* k, const float* wm, int T, int P, int C, float* scratch, float* score, void* stream);
 int sp3_mem_append(float* count, float* attn, int M, int P, void* stream);
 int sp3_prune_select(const float* attn, const float* count, int M, float protect, int top_k,
                      int32_t* sel, void* stream);

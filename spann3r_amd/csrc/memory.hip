@@ -75,27 +75,33 @@ __global__ __launch_bounds__(256) void colsum_accum_kernel(const float* __restri
   mem_attn[j] += s;
 }
 
-// One block per stored frame t: mean over patches of cos(k[p], wm[t,p]); fixed reduction order.
-__global__ __launch_bounds__(256) void cos_sim_kernel(const float* __restrict__ k, const float* __restrict__ wm, int P, int C,
-                                                      float* __restrict__ score) {
+// cos_sim, stage 1: one wave per (stored frame t, patch p) pair -> cosv[t*P + p] = cos(k[p], wm[t,p]).
+__global__ __launch_bounds__(256) void cos_pair_kernel(const float* __restrict__ k, const float* __restrict__ wm, int TP, int P, int C,
+                                                       float* __restrict__ cosv) {
+  const int lane = threadIdx.x & 63, j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= TP) return;
+  const float* a = k + (int64_t)(j % P) * C;
+  const float* b = wm + (int64_t)j * C;
+  float dot = 0.f, na = 0.f, nb = 0.f;
+  for (int c = lane * 4; c < C; c += 256) {
+    const float4 x = *reinterpret_cast<const float4*>(a + c);
+    const float4 y = *reinterpret_cast<const float4*>(b + c);
+    dot += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
+    na += (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
+    nb += (y.x * y.x + y.y * y.y) + (y.z * y.z + y.w * y.w);
+  }
+  dot = wave_sum(dot); na = wave_sum(na); nb = wave_sum(nb);
+  // F.normalize(p=2, eps=1e-12): x / max(||x||, eps)
+  if (lane == 0) cosv[j] = dot / (fmaxf(sqrtf(na), 1e-12f) * fmaxf(sqrtf(nb), 1e-12f));
+}
+
+// cos_sim, stage 2: one block per stored frame t: mean over patches, fixed reduction order.
+__global__ __launch_bounds__(256) void cos_mean_kernel(const float* __restrict__ cosv, int P, float* __restrict__ score) {
   __shared__ float sh[4];
   const int t = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   float acc = 0.f;
-  for (int p = w; p < P; p += 4) {
-    const float* a = k + (int64_t)p * C;
-    const float* b = wm + ((int64_t)t * P + p) * C;
-    float dot = 0.f, na = 0.f, nb = 0.f;
-    for (int c = lane * 4; c < C; c += 256) {
-      const float4 x = *reinterpret_cast<const float4*>(a + c);
-      const float4 y = *reinterpret_cast<const float4*>(b + c);
-      dot += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
-      na += (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w);
-      nb += (y.x * y.x + y.y * y.y) + (y.z * y.z + y.w * y.w);
-    }
-    dot = wave_sum(dot); na = wave_sum(na); nb = wave_sum(nb);
-    // F.normalize(p=2, eps=1e-12): x / max(||x||, eps)
-    acc += dot / (fmaxf(sqrtf(na), 1e-12f) * fmaxf(sqrtf(nb), 1e-12f));
-  }
+  for (int p = threadIdx.x; p < P; p += 256) acc += cosv[(int64_t)t * P + p];
+  acc = wave_sum(acc);
   if (lane == 0) sh[w] = acc;
   __syncthreads();
   if (threadIdx.x == 0) score[t] = ((sh[0] + sh[1]) + (sh[2] + sh[3])) / (float)P;
@@ -209,9 +215,10 @@ extern "C" int sp3_colsum_accum(const float* P, int64_t ld, int rows, int M, flo
   return 0;
 }
 
-extern "C" int sp3_cos_sim(const float* k, const float* wm, int T, int P, int C, float* score, void* stream) {
-  SP3_CHECK(k && wm && score && T > 0 && P > 0 && C > 0 && C % 4 == 0, "sp3_cos_sim: bad arguments");
-  hipLaunchKernelGGL(cos_sim_kernel, dim3(T), dim3(256), 0, ST(stream), k, wm, P, C, score);
+extern "C" int sp3_cos_sim(const float* k, const float* wm, int T, int P, int C, float* scratch, float* score, void* stream) {
+  SP3_CHECK(k && wm && scratch && score && T > 0 && P > 0 && C > 0 && C % 4 == 0, "sp3_cos_sim: bad arguments");
+  hipLaunchKernelGGL(cos_pair_kernel, dim3((T * P + 3) / 4), dim3(256), 0, ST(stream), k, wm, T * P, P, C, scratch);
+  hipLaunchKernelGGL(cos_mean_kernel, dim3(T), dim3(256), 0, ST(stream), scratch, P, score);
   SP3_LAUNCH_CHECK("sp3_cos_sim");
   return 0;
 }

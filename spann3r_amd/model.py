@@ -68,6 +68,7 @@ class SpatialMemory:
         self.lm = 0
         self.events = []
         self._score = torch.zeros(batch, max(work_mem_size, 1), device=dev)
+        self._cos_scratch = torch.empty(max(work_mem_size, 1) * num_patches, device=dev)
         self._sel = torch.zeros(batch, max(long_mem_size, 1), dtype=torch.int32, device=dev)
 
     def _alloc(self, dev, wdt):
@@ -167,7 +168,7 @@ class SpatialMemory:
         B, P, C = self.B, self.P, self.C
         n = self.wm * P
         for b in range(B):
-            ops.cos_sim(feat_k[b], self.bank["k_raw"][b, self.M - n:self.M], self.wm, P, C, self._score[b])
+            ops.cos_sim(feat_k[b], self.bank["k_raw"][b, self.M - n:self.M], self.wm, P, C, self._score[b], self._cos_scratch)
         return self._score[:, :self.wm]
 
     def sim_needed(self):

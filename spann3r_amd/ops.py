@@ -431,8 +431,11 @@ def colsum_accum(P, ld, rows, M, mem_attn):
     L.check(L.load().sp3_colsum_accum(P.data_ptr(), ld, rows, M, mem_attn.data_ptr(), L.stream_ptr()), "sp3_colsum_accum")
 
 
-def cos_sim(k, wm, T, P, C_, score):
-    L.check(L.load().sp3_cos_sim(k.data_ptr(), wm.data_ptr(), T, P, C_, score.data_ptr(), L.stream_ptr()), "sp3_cos_sim")
+def cos_sim(k, wm, T, P, C_, score, scratch):
+    """score[t] = mean_p cos(k[p], wm[t, p]); scratch: fp32 [>= T*P]"""
+    assert scratch.numel() >= T * P and scratch.dtype == torch.float32
+    L.check(L.load().sp3_cos_sim(k.data_ptr(), wm.data_ptr(), T, P, C_, scratch.data_ptr(), score.data_ptr(), L.stream_ptr()),
+            "sp3_cos_sim")
 
 
 def mem_append(count, attn, M, P):

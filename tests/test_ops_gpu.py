@@ -481,7 +481,7 @@ def test_cos_sim_append_prune_gather():
     k, wm = rnd(P, C, seed=1), rnd(T, P, C, seed=2)
     wm[1] = k * 1.7 + 0.01 * wm[1]
     score = torch.zeros(T, device=DEV)
-    ops.cos_sim(k.to(DEV), wm.to(DEV), T, P, C, score)
+    ops.cos_sim(k.to(DEV), wm.to(DEV), T, P, C, score, torch.empty(T * P, device=DEV))
     ref = torch.einsum("pc,tpc->tp", F.normalize(k.double(), dim=-1), F.normalize(wm.double(), dim=-1)).mean(-1)
     assert rel_err(score.cpu(), ref) < 1e-5 and float(score[1]) > 0.95
     # append bookkeeping
