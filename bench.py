@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--train-policy", action="store_true", help="growing bank (train-mode memory policy, dropout off)")
+    ap.add_argument("--schedule", default="", help="comma list of schedule switches to turn OFF: batch_encode, defer_head2, "
+                                                   "grouped_decoder (debugging / A-B runs; default = the shipped schedule)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -82,6 +84,9 @@ def main():
         model.mem_dropout.eval()
     if hasattr(model, "use_graphs"):
         model.use_graphs = not args.no_graphs
+    for off in filter(None, args.schedule.split(",")):
+        assert hasattr(model, off), off
+        setattr(model, off, False)
 
     # rank r owns sequences {s : s mod world == r}; a handful of distinct sequences, cycled
     n_distinct = 4

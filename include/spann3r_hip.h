@@ -113,6 +113,13 @@ typedef struct sp3_gemm_desc {
   int32_t out_packed;     /* plain epilogue: store C in fragment order (it is the next GEMM's packed A; dims M x N) */
   int32_t w_packed;       /* W is in MFMA-fragment order [ceil(N/16)][ceil(K/KB)][64 lanes][CH], zero padded; KB/CH =
                              64/16 (bf16) or 32/8 (fp32); lane = 16*g + r holds row 16*nb + r, k = kb*KB + g*CH + e */
+  /* --- grouped launches (batch > 1, grid.y): `batch` independent problems of one shape in one launch, e.g. the two
+   *   sides of a DUSt3R decoder layer (different weights, dust3r/model.py:196-198).  A / W / C advance by strideA /
+   *   strideW / strideC ELEMENTS per batch index (C in its own dtype, any epilogue, also the packed layouts), res1 /
+   *   res2 are [batch][M][ld], and the operands below advance by these BYTE offsets.  Offsets may be negative (the
+   *   cross-attention k/v projection of side z reads the tokens and statistics of side 1-z).  rope tables / pos are
+   *   shared. */
+  int64_t sb_A2, sb_bias, sb_ln_stats, sb_ln_s, sb_stats_out, sb_c2, sb_vt;
 } sp3_gemm_desc;
 int sp3_gemm(const sp3_gemm_desc* desc_host, void* stream);
 
@@ -151,6 +158,9 @@ typedef struct sp3_reduce_ln_desc {
   float eps;
   int32_t splits, rows, C;
   int32_t out1_packed, out2_packed;   /* store the LayerNorm output in fragment order (GEMM a_packed operand) */
+  int32_t act;            /* SP3_ACT_NONE | SP3_ACT_RELU, applied to sum + bias BEFORE the residuals (sp3_gemm's order) */
+  const float* res2;      /* second residual [rows, ldres2] or null: x = act(sum + bias) + res + res2 */
+  int64_t ldres2;
 } sp3_reduce_ln_desc;
 int sp3_reduce_ln(const sp3_reduce_ln_desc* desc_host, void* stream);
 
@@ -180,10 +190,12 @@ int sp3_attention_ex(const void* q, int64_t sq, int64_t ldq, const void* k, int6
 /* bf16 attention on the fragment-order q/k and PV-order V written by the qkv_packed ROPE_VT epilogue: every operand load
  * is one contiguous wave read, the next key tile is prefetched during the softmax.  qp/kp: packed [B*npad_q|npad_k, q_cols|k_cols]
  * matrices, head h of q at columns q_col0 + 64h (k: k_col0 + 64h); vtp as described at qkv_packed (vt_ld = npad_k).
- * out: fp32/bf16 row-major [B*Nq, ldo] or fragment order (out_packed). */
+ * out: fp32/bf16 row-major [B*Nq, ldo] or fragment order (out_packed).  o_group > 0: every o_group consecutive images form
+ * one problem of a grouped launch whose output rows start at a multiple of o_group_rows (image b -> row
+ * (b / o_group) * o_group_rows + (b % o_group) * Nq), so each problem's packed rows stay 16-aligned; 0: rows b * Nq. */
 int sp3_attention_packed(const void* qp, int q_cols, int q_col0, int npad_q, const void* kp, int k_cols, int k_col0, int npad_k,
                          const void* vtp, void* out, int64_t ldo, int out_bf16, int out_packed,
-                         int B, int heads, int Nq, int Nk, float scale, void* stream);
+                         int B, int heads, int Nq, int Nk, float scale, int o_group, int o_group_rows, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Spatial-memory kernels (spann3r/model.py:97-210).

@@ -190,7 +190,8 @@ __device__ __forceinline__ KFrag load_frag(const __bf16* base, int row, int col,
 __global__ __launch_bounds__(256) void attention_packed_kernel(const __bf16* __restrict__ QP, int q_cols, int q_col0, int npad_q,
                                                                const __bf16* __restrict__ KP, int k_cols, int k_col0, int npad_k,
                                                                const __bf16* __restrict__ VTP, void* __restrict__ O, int64_t ldo,
-                                                               int out_bf16, int out_packed, int heads, int Nq, int Nk, float scale) {
+                                                               int out_bf16, int out_packed, int heads, int Nq, int Nk, float scale,
+                                                               int o_group, int o_group_rows) {
   __shared__ float sh_o[4][4][64][4];   // [wave][db][lane][r]
   __shared__ float sh_m[4][64], sh_l[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, ql = lane & 15;
@@ -299,7 +300,9 @@ __global__ __launch_bounds__(256) void attention_packed_kernel(const __bf16* __r
   }
   const float inv = 1.0f / L;
   if (q0 + ql < Nq) {
-    const int row = b * Nq + q0 + ql;
+    // output row: images are consecutive, except that every o_group of them may start at a multiple of o_group_rows
+    // (grouped launches keep each problem's packed rows 16-aligned)
+    const int row = o_group > 0 ? (b / o_group) * o_group_rows + (b % o_group) * Nq + q0 + ql : b * Nq + q0 + ql;
     const int col = h * 64 + db * 16 + 4 * g;
     const int64_t off = out_packed ? packed_off(row, col, heads * 64, out_bf16 != 0) : (int64_t)row * ldo + col;
     if (out_bf16) {
@@ -344,16 +347,18 @@ extern "C" int sp3_attention(const void* q, int64_t sq, int64_t ldq, const void*
 
 extern "C" int sp3_attention_packed(const void* qp, int q_cols, int q_col0, int npad_q, const void* kp, int k_cols, int k_col0,
                                     int npad_k, const void* vtp, void* out, int64_t ldo, int out_bf16, int out_packed, int B,
-                                    int heads, int Nq, int Nk, float scale, void* stream) {
+                                    int heads, int Nq, int Nk, float scale, int o_group, int o_group_rows, void* stream) {
   SP3_CHECK(qp && kp && vtp && out, "sp3_attention_packed: null pointer");
   SP3_CHECK(B > 0 && heads > 0 && Nq > 0 && Nk > 0, "sp3_attention_packed: bad shape");
   SP3_CHECK(npad_q % 16 == 0 && npad_q >= ((Nq + 15) / 16) * 16 && npad_k % 64 == 0 && npad_k >= ((Nk + 63) / 64) * 64,
             "sp3_attention_packed: npad_q=%d / npad_k=%d do not cover Nq=%d / Nk=%d", npad_q, npad_k, Nq, Nk);
   SP3_CHECK(q_cols % 64 == 0 && k_cols % 64 == 0 && q_col0 % 64 == 0 && k_col0 % 64 == 0, "sp3_attention_packed: column geometry");
   SP3_CHECK(out_packed || ldo % 4 == 0, "sp3_attention_packed: ldo");
+  SP3_CHECK(o_group == 0 || (o_group > 0 && B % o_group == 0 && o_group_rows >= o_group * Nq), "sp3_attention_packed: output grouping");
   hipLaunchKernelGGL(attention_packed_kernel, dim3((Nq + 15) / 16, heads, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      reinterpret_cast<const __bf16*>(qp), q_cols, q_col0, npad_q, reinterpret_cast<const __bf16*>(kp), k_cols, k_col0,
-                     npad_k, reinterpret_cast<const __bf16*>(vtp), out, ldo, out_bf16, out_packed, heads, Nq, Nk, scale);
+                     npad_k, reinterpret_cast<const __bf16*>(vtp), out, ldo, out_bf16, out_packed, heads, Nq, Nk, scale, o_group,
+                     o_group_rows);
   SP3_LAUNCH_CHECK("sp3_attention_packed");
   return 0;
 }

@@ -247,7 +247,7 @@ template <typename TA, int MF> struct ARows<TA, SP3_LOAD_CONV3X3, MF> {
 // ------------------------------------------------------------------ the kernel
 template <typename TA, typename TW, int LOADER, int MF, int NF, int WM, int WN, int WK, int STAGES>
 __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_kernel(const GemmArgs args) {
-  const sp3_gemm_desc& d = args.d;
+  sp3_gemm_desc d = args.d;                  // local copy: grouped launches shift the per-problem pointers below
   using M_ = MM<TA, TW>;
   constexpr int BM = MF * 16 * WM, BN = NF * 16 * WN, NT = 64 * WM * WN * WK;
   constexpr int KB = M_::KB, CH = M_::CH;
@@ -274,6 +274,17 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_kernel(const GemmArgs 
   const int g = lane >> 4;
   const int bz = blockIdx.y;
   const int kz = blockIdx.z;
+  if (d.batch > 1) {                         // grouped launch: problem bz (wave-uniform pointer arithmetic)
+    auto shift = [&](auto*& p, int64_t bytes) {
+      using P = std::remove_reference_t<decltype(p)>;
+      if (p) p = reinterpret_cast<P>(reinterpret_cast<uintptr_t>(p) + (uintptr_t)(bz * bytes));
+    };
+    shift(d.A2, d.sb_A2); shift(d.bias, d.sb_bias); shift(d.ln_stats, d.sb_ln_stats); shift(d.ln_s, d.sb_ln_s);
+    shift(d.stats_out, d.sb_stats_out); shift(d.c2, d.sb_c2); shift(d.vt, d.sb_vt);
+    const int64_t csz = d.epi == SP3_EPI_ROPE_VT ? (int64_t)sizeof(TW) : (d.out_bf16 ? 2 : 4);
+    shift(d.C, d.strideC * csz);
+    d.strideC = 0;
+  }
   const TA* A = reinterpret_cast<const TA*>(d.A) + (int64_t)bz * d.strideA;
   const TW* W = reinterpret_cast<const TW*>(d.W) + (int64_t)bz * d.strideW;
 
@@ -750,19 +761,20 @@ extern "C" int sp3_gemm(const sp3_gemm_desc* dp, void* stream_) {
   if (d.batch <= 0) d.batch = 1;
   if (d.splitk <= 0) d.splitk = 1;
   if (d.ldw <= 0) d.ldw = d.K;
-  SP3_CHECK(!d.w_packed || d.batch == 1, "sp3_gemm: packed weights are unbatched");
-  SP3_CHECK(!d.ln_stats || (d.ln_s && d.ln_nt > 0 && d.ln_C == 32 * d.ln_nt && d.batch == 1 && d.epi != SP3_EPI_PARTIAL &&
+  SP3_CHECK(!d.ln_stats || (d.ln_s && d.ln_nt > 0 && d.ln_C == 32 * d.ln_nt && d.epi != SP3_EPI_PARTIAL &&
                             d.loader == SP3_LOAD_PLAIN && d.N % 4 == 0),
-            "sp3_gemm: folded LayerNorm needs ln_s, ln_nt, ln_C = 32*ln_nt, batch 1, the plain loader, N %% 4 == 0");
-  SP3_CHECK((!d.stats_out && !d.c2) || (d.epi == SP3_EPI_PLAIN && d.batch == 1 && d.N % 32 == 0 && !d.out_packed),
-            "sp3_gemm: stats_out / c2 need the plain epilogue, batch 1, N %% 32 == 0");
-  SP3_CHECK(!d.out_packed || (d.epi == SP3_EPI_PLAIN && d.batch == 1 && d.N % 4 == 0), "sp3_gemm: out_packed needs the plain epilogue, batch 1, N %% 4 == 0");
-  SP3_CHECK(!d.a_packed || (d.loader == SP3_LOAD_PLAIN && !d.A2 && d.batch == 1), "sp3_gemm: packed A is plain / unbatched / unsplit");
+            "sp3_gemm: folded LayerNorm needs ln_s, ln_nt, ln_C = 32*ln_nt, the plain loader, N %% 4 == 0");
+  SP3_CHECK((!d.stats_out && !d.c2) || (d.epi == SP3_EPI_PLAIN && d.N % 32 == 0 && !d.out_packed),
+            "sp3_gemm: stats_out / c2 need the plain epilogue, N %% 32 == 0");
+  SP3_CHECK(!d.out_packed || (d.epi == SP3_EPI_PLAIN && d.N % 4 == 0), "sp3_gemm: out_packed needs the plain epilogue, N %% 4 == 0");
+  SP3_CHECK(!d.a_packed || (d.loader == SP3_LOAD_PLAIN && !d.A2), "sp3_gemm: packed A is plain / unsplit");
+  SP3_CHECK(d.batch == 1 || ((d.sb_bias | d.sb_ln_stats | d.sb_ln_s | d.sb_stats_out | d.sb_c2 | d.sb_vt | d.sb_A2) & 15) == 0,
+            "sp3_gemm: per-batch byte offsets must keep 16-byte alignment");
   SP3_CHECK(!d.a_packed || ((d.a_bf16 != 0) == (d.wdtype == SP3_BF16)), "sp3_gemm: packed A must have the MFMA dtype (its fragment geometry)");
   if (!d.A2) d.K1 = d.K;
   const int aalign = d.a_bf16 ? 8 : 4;    // elements per 16 bytes
   SP3_CHECK(d.ldw >= d.K && d.ldw % 8 == 0, "sp3_gemm: ldw=%lld must be >= K and a multiple of 8", (long long)d.ldw);
-  SP3_CHECK(!d.A2 || (d.loader == SP3_LOAD_PLAIN && d.K1 % 64 == 0 && d.K1 > 0 && d.K1 < d.K && d.lda2 % aalign == 0 && d.batch == 1),
+  SP3_CHECK(!d.A2 || (d.loader == SP3_LOAD_PLAIN && d.K1 % 64 == 0 && d.K1 > 0 && d.K1 < d.K && d.lda2 % aalign == 0),
             "sp3_gemm: bad split-A configuration (K1=%d)", d.K1);
   SP3_CHECK(d.splitk == 1 || d.epi == SP3_EPI_PARTIAL, "sp3_gemm: splitk > 1 needs the PARTIAL epilogue");
   if (d.loader == SP3_LOAD_PLAIN && !d.a_packed) {
@@ -781,7 +793,6 @@ extern "C" int sp3_gemm(const sp3_gemm_desc* dp, void* stream_) {
     SP3_CHECK(d.rope_cols % 64 == 0 && d.N % 64 == 0, "sp3_gemm: ROPE_VT needs 64-wide heads (N=%d rope_cols=%d)", d.N, d.rope_cols);
     SP3_CHECK(d.rope_cols == 0 || (d.rope_cos && d.rope_sin && d.pos), "sp3_gemm: ROPE_VT needs tables and positions");
     SP3_CHECK(d.rope_cols == d.N || (d.vt && d.tokens > 0 && d.heads > 0 && d.vt_ld >= d.tokens), "sp3_gemm: ROPE_VT needs vt/tokens/heads");
-    SP3_CHECK(d.batch == 1, "sp3_gemm: ROPE_VT is unbatched (rows carry the batch)");
     SP3_CHECK(!d.qkv_packed || (d.wdtype == SP3_BF16 && d.tokens > 0 && d.vt_ld % 64 == 0 && d.vt_ld >= d.tokens),
               "sp3_gemm: qkv_packed needs bf16, tokens and vt_ld (padded tokens per image, multiple of 64)");
   } else if (d.epi == SP3_EPI_PIXSHUF) {

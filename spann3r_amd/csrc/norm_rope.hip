@@ -155,8 +155,13 @@ __global__ __launch_bounds__(256) void reduce_ln_kernel(const ReduceLnArgs args)
         const float4 b = reinterpret_cast<const float4*>(d.bias)[j];
         x.x += b.x; x.y += b.y; x.z += b.z; x.w += b.w;
       }
+      if (d.act == SP3_ACT_RELU) x = relu4(x);
       if (d.res) {
         const float4 r = reinterpret_cast<const float4*>(d.res + (int64_t)row * d.ldres)[j];
+        x.x += r.x; x.y += r.y; x.z += r.z; x.w += r.w;
+      }
+      if (d.res2) {
+        const float4 r = reinterpret_cast<const float4*>(d.res2 + (int64_t)row * d.ldres2)[j];
         x.x += r.x; x.y += r.y; x.z += r.z; x.w += r.w;
       }
       if (d.x_out) reinterpret_cast<float4*>(d.x_out + (int64_t)row * d.ldx)[j] = x;

@@ -128,6 +128,18 @@ class Engine:
             w[d_ + "h4.w"] = p[s + "head.4.weight"].detach().to(dev, torch.float32).reshape(4, -1).contiguous()
             w[d_ + "h4.b"] = vec(p[s + "head.4.bias"])
 
+        if self.packed_attn:
+            # grouped launches: the two decoder sides (and the two key MLPs) run as problems 0 / 1 of ONE launch per op
+            def stack(dst, a, b, names):
+                for nm in names:
+                    x, y = w[a + nm], w[b + nm]
+                    w[dst + nm] = ops.PackedWeightGroup([x, y]) if isinstance(x, ops.PackedWeight) else torch.stack((x, y)).contiguous()
+            for i in range(cfg.dec_depth):
+                stack("decg_%d." % i, "dec1_%d." % i, "dec2_%d." % i,
+                      ["qkv.w", "qkv.b", "qkv.s", "proj.w", "proj.b", "cq.w", "cq.b", "cq.s", "ckv.w", "ckv.b", "ckv.s",
+                       "cproj.w", "cproj.b", "fc1.w", "fc1.b", "fc1.s", "fc2.w", "fc2.b"])
+            stack("keyg.", "key1.", "key2.", ["0.w", "0.b", "2.w", "2.b"])
+
     def weight_bytes(self):
         return sum((t.data if isinstance(t, ops.PackedWeight) else t).numel() * t.element_size() for t in self.w.values())
 
@@ -390,6 +402,107 @@ class Engine:
                 outs[s].append(new[s].view(B, Ps[s], D))
         return outs[1], outs[2]
 
+    # ------------------------------------------------------------------ grouped decoder (bf16 mode)
+    def wspg(self, name, R, K):
+        key = ("packed2", name, R, K, self.adt)
+        t = self._ws.get(key)
+        if t is None:
+            t = self._ws[key] = ops.PackedAct.group(2, R, K, self.adt, self.device)
+        return t
+
+    def decoder_grouped(self, f1, f2, B, nh, nw):
+        """dust3r._decoder (dust3r/model.py:186-205) with both sides as problems 0 / 1 of one grouped launch per op:
+        10 launches per layer on ONE stream instead of 2 x 10 on two streams with a fork/join per layer (the cross-stream
+        dependencies cost ~8 us of idle GPU each).  Same kernels, same arithmetic per side as `decoder`."""
+        cfg, w = self.cfg, self.w
+        E, D, Hh = cfg.enc_dim, cfg.dec_dim, cfg.dec_heads
+        P = nh * nw
+        R = B * P
+        npad = (P + 63) // 64 * 64
+        nt = D // 32
+        pos = self.positions(B, nh, nw)[1]
+        depth = cfg.dec_depth
+        es = 2 if self.adt == torch.bfloat16 else 4
+        x = [self.ws("decg_x%d" % l, (2, R, D)) for l in range(depth + 1)]
+        xp = [self.wspg("decg_xp%d" % j, R, D) for j in (0, 1)]
+        st = [self.ws("decg_st%d" % j, (2, R, nt, 2)) for j in (0, 1)]
+        xq, stq = self.wspg("decg_xq", R, D), self.ws("decg_stq", (2, R, nt, 2))
+        ao, h = self.wspg("decg_ao", R, D), self.wspg("decg_h", R, D * cfg.mlp_ratio)
+        qkp = self.ws("decg_qkp", ops.packed_shape(2 * B * npad, 2 * D, self.wdt), self.wdt, zero=True)
+        vtp = self.ws("decg_vtp", (2 * B * Hh * npad * 64,), self.wdt, zero=True)
+        cqp = self.ws("decg_cqp", ops.packed_shape(2 * B * npad, D, self.wdt), self.wdt, zero=True)
+        ckp = self.ws("decg_ckp", ops.packed_shape(2 * B * npad, D, self.wdt), self.wdt, zero=True)
+        cvtp = self.ws("decg_cvtp", (2 * B * Hh * npad * 64,), self.wdt, zero=True)
+        sb_st, sb_vt = R * nt * 8, B * Hh * npad * 64 * 2
+        Rp = xp[0].rows_pad
+        # decoder_embed (dust3r/model.py:190-191): one weight, two inputs that live in different buffers
+        dA = f2.data_ptr() - f1.data_ptr()
+        assert dA % 16 == 0 and f1.dtype == f2.dtype == torch.float32
+        ops.gemm(f1, w["dec_embed.w"], x[0], M=R, N=D, K=E, lda=E, ldc=D, bias=w["dec_embed.b"], stats_out=st[0], c2=xp[0],
+                 batch=2, strideA=dA // 4, strideC=R * D, sb={"stats_out": sb_st, "c2": xp[0].stride * es})
+        rope = dict(pos=pos, cos=self.cos, sin=self.sin, tokens=P, heads=Hh, qkv_packed=True, batch=2)
+        for i in range(depth):
+            cur, nx = i % 2, (i + 1) % 2
+            g = "decg_%d." % i
+            last = i == depth - 1
+            xi, xo = x[i], x[i + 1]
+
+            def upd(A, K, pre, res, stats, c2):
+                sb = {"bias": D * 4}
+                if stats is not None:
+                    sb["stats_out"], sb["c2"] = sb_st, c2.stride * es
+                ops.gemm(A, w[g + pre + ".w"], xo, M=R, N=D, K=K, lda=K, ldc=D, bias=w[g + pre + ".b"], res1=res, ldr1=D,
+                         stats_out=stats, c2=c2, batch=2, strideA=A.stride, strideW=w[g + pre + ".w"].stride, strideC=R * D, sb=sb)
+
+            # self attention (croco/models/blocks.py:187), norm1 folded into the qkv GEMM
+            ops.proj_rope_vt(xp[cur], w[g + "qkv.w"], w[g + "qkv.b"], qkp, 0, vtp, npad, M=R, N=3 * D, K=D, lda=D, rope_cols=2 * D,
+                             ln=ops.LnFold(st[cur], D, w[g + "qkv.s"], 1e-6, sb_stats=sb_st, sb_s=3 * D * 4),
+                             strideA=xp[cur].stride, strideW=w[g + "qkv.w"].stride, strideC=B * npad * 2 * D,
+                             sb={"bias": 3 * D * 4, "vt": sb_vt}, **rope)
+            ops.attention_packed(qkp, 2 * D, 0, npad, qkp, 2 * D, D, npad, vtp, ao, D, B=2 * B, heads=Hh, Nq=P, Nk=P,
+                                 scale=64 ** -0.5, o_group=B, o_group_rows=Rp)
+            upd(ao, D, "proj", xi, stq, xq)
+            # cross attention (:188-189): q from this side (norm2), k/v from the OTHER side's previous layer (norm_y):
+            # problem z reads side 1-z -> start at side 1 and step backwards
+            ops.proj_rope_vt(xq, w[g + "cq.w"], w[g + "cq.b"], cqp, 0, None, npad, M=R, N=D, K=D, lda=D, rope_cols=D,
+                             ln=ops.LnFold(stq, D, w[g + "cq.s"], 1e-6, sb_stats=sb_st, sb_s=D * 4),
+                             strideA=xq.stride, strideW=w[g + "cq.w"].stride, strideC=B * npad * D, sb={"bias": D * 4}, **rope)
+            ops.proj_rope_vt(xp[cur].at(1), w[g + "ckv.w"], w[g + "ckv.b"], ckp, 0, cvtp, npad, M=R, N=2 * D, K=D, lda=D, rope_cols=D,
+                             ln=ops.LnFold(st[cur][1], D, w[g + "ckv.s"], 1e-6, sb_stats=-sb_st, sb_s=2 * D * 4),
+                             strideA=-xp[cur].stride, strideW=w[g + "ckv.w"].stride, strideC=B * npad * D,
+                             sb={"bias": 2 * D * 4, "vt": sb_vt}, **rope)
+            ops.attention_packed(cqp, D, 0, npad, ckp, D, 0, npad, cvtp, ao, D, B=2 * B, heads=Hh, Nq=P, Nk=P,
+                                 scale=64 ** -0.5, o_group=B, o_group_rows=Rp)
+            upd(ao, D, "cproj", xo, stq, xq)
+            # MLP (:190), norm3 folded into fc1
+            Hd = D * cfg.mlp_ratio
+            ops.gemm(xq, w[g + "fc1.w"], h, M=R, N=Hd, K=D, lda=D, ldc=Hd, bias=w[g + "fc1.b"], act=ACT_GELU,
+                     ln=ops.LnFold(stq, D, w[g + "fc1.s"], 1e-6, sb_stats=sb_st, sb_s=Hd * 4),
+                     batch=2, strideA=xq.stride, strideW=w[g + "fc1.w"].stride, strideC=h.stride, sb={"bias": Hd * 4})
+            if last:
+                upd(h, Hd, "fc2", xo, None, None)
+            else:
+                upd(h, Hd, "fc2", xo, st[nx], xp[nx])
+        normed = self.ws("decg_normed", (2, R, D))
+        ops.layernorm(x[depth], w["dec_norm.w"], w["dec_norm.b"], 1e-6, normed, rows=2 * R, C_=D)       # API-visible
+        outs = {}
+        for s_ in (0, 1):
+            outs[s_] = [(f1, f2)[s_]] + [x[l][s_].view(B, P, D) for l in range(1, depth)] + [normed[s_].view(B, P, D)]
+        return outs[0], outs[1]
+
+    def encode_feat_keys_grouped(self, feat1, feat2, normed1, normed2, R, out1, out2):
+        """both key MLPs (spann3r/model.py:299-303) as one grouped launch per layer; normed1/2 = the decoders' last outputs"""
+        cfg, w = self.cfg, self.w
+        E, D, Kd = cfg.enc_dim, cfg.dec_dim, cfg.key_dim
+        dF, dN, dO = feat2.data_ptr() - feat1.data_ptr(), normed2.data_ptr() - normed1.data_ptr(), out2.data_ptr() - out1.data_ptr()
+        assert dF % 16 == 0 and dN % 16 == 0 and dO % 16 == 0
+        es = 2 if self.adt == torch.bfloat16 else 4
+        h = self.wspg("keyg_hidden", R, Kd)
+        ops.gemm(feat1, w["keyg.0.w"], h, M=R, N=Kd, K=Kd, lda=E, ldc=Kd, bias=w["keyg.0.b"], act=ACT_GELU, A2=normed1, lda2=D, K1=E,
+                 batch=2, strideA=dF // 4, strideW=w["keyg.0.w"].stride, strideC=h.stride, sb={"bias": Kd * 4, "A2": dN})
+        ops.gemm(h, w["keyg.2.w"], out1, M=R, N=E, K=Kd, lda=Kd, ldc=E, bias=w["keyg.2.b"],
+                 batch=2, strideA=h.stride, strideW=w["keyg.2.w"].stride, strideC=dO // 4, sb={"bias": E * 4})
+
     def encode_feat_key(self, feat, dec_last, R, num, out):
         """spann3r/model.py:299-303: Linear(1792,1792) -> GELU -> Linear(1792,1024) on cat(feat, dec[-1]);
         the concatenation is never materialised (split-A GEMM)."""
@@ -402,12 +515,20 @@ class Engine:
         ops.gemm(h, w[pre + "2.w"], out, M=R, N=E, K=Kd, lda=Kd, ldc=E, bias=w[pre + "2.b"])
         return out
 
+    def _conv_ws(self, head):
+        """split-K scratch of one DPT head's small-map convolutions (one per head: the heads may run concurrently);
+        sized for the largest map that is ever split: 8 partial copies of <= 256 x 768 or 2 of 1024 x 256 outputs per image"""
+        return self.ws("conv_splitk_ws" + str(head), (1 << 23,))
+
     def _rcu(self, x, pre, B, H, W_, out, extra_res=None, tag=""):
         """ResidualConvUnit_custom (croco/models/dpt_block.py:120-142): conv2(relu(conv1(relu(x)))) + x [+ extra]."""
         w, F = self.w, self.cfg.dpt_feat
         t = self.ws("rcu_tmp" + tag, (B * H * W_, F))
-        ops.conv3x3(x, w[pre + "c1.w"], t, B=B, H=H, W_=W_, Cin=F, Cout=F, bias=w[pre + "c1.b"], relu_in=True, act=ACT_RELU)
-        ops.conv3x3(t, w[pre + "c2.w"], out, B=B, H=H, W_=W_, Cin=F, Cout=F, bias=w[pre + "c2.b"], res1=x, res2=extra_res)
+        sk = self._conv_ws(tag[:1])
+        ops.conv3x3(x, w[pre + "c1.w"], t, B=B, H=H, W_=W_, Cin=F, Cout=F, bias=w[pre + "c1.b"], relu_in=True, act=ACT_RELU,
+                    splitk_ws=sk)
+        ops.conv3x3(t, w[pre + "c2.w"], out, B=B, H=H, W_=W_, Cin=F, Cout=F, bias=w[pre + "c2.b"], res1=x, res2=extra_res,
+                    splitk_ws=sk)
         return out
 
     def _fusion(self, pre, B, H, W_, x0, x1, tag, crop=None):
@@ -453,14 +574,16 @@ class Engine:
         l2 = t[2]
         h3, w3 = (nh - 1) // 2 + 1, (nw - 1) // 2 + 1
         l3 = self.ws("dpt%d_l3" % num, (B * h3 * w3, ld[3]))
-        ops.conv3x3(t[3], w[pre + "pp3c.w"], l3, B=B, H=nh, W_=nw, Cin=ld[3], Cout=ld[3], stride=2, bias=w[pre + "pp3c.b"])
+        sk = self._conv_ws(num)
+        ops.conv3x3(t[3], w[pre + "pp3c.w"], l3, B=B, H=nh, W_=nw, Cin=ld[3], Cout=ld[3], stride=2, bias=w[pre + "pp3c.b"],
+                    splitk_ws=sk)
         # scratch.layer_rn (3x3, no bias) -> 256 channels
         geo = ((4 * nh, 4 * nw), (2 * nh, 2 * nw), (nh, nw), (h3, w3))
         rn = []
         for i, src in enumerate((l0, l1, l2, l3)):
             Hh, Ww = geo[i]
             o = self.ws("dpt%d_rn%d" % (num, i), (B * Hh * Ww, F))
-            ops.conv3x3(src, w[pre + "rn%d.w" % i], o, B=B, H=Hh, W_=Ww, Cin=ld[i], Cout=F)
+            ops.conv3x3(src, w[pre + "rn%d.w" % i], o, B=B, H=Hh, W_=Ww, Cin=ld[i], Cout=F, splitk_ws=sk)
             rn.append(o)
         # refinenets; path_4 is cropped to layer 3's size (dust3r/heads/dpt_head.py:57)
         p4, H4, W4 = self._fusion(pre + "ref4.", B, h3, w3, rn[3], None, "%d_4" % num, crop=(nh, nw))

@@ -38,6 +38,8 @@ class GemmDesc(C.Structure):
         ("tile", C.c_int32), ("a_bf16", C.c_int32), ("splitk", C.c_int32), ("a_packed", C.c_int32),
         ("ln_stats", C.c_void_p), ("ln_s", C.c_void_p), ("ln_nt", C.c_int32), ("ln_C", C.c_int32), ("ln_eps", C.c_float),
         ("stats_out", C.c_void_p), ("c2", C.c_void_p), ("qkv_packed", C.c_int32), ("out_packed", C.c_int32), ("w_packed", C.c_int32),
+        ("sb_A2", C.c_int64), ("sb_bias", C.c_int64), ("sb_ln_stats", C.c_int64), ("sb_ln_s", C.c_int64),
+        ("sb_stats_out", C.c_int64), ("sb_c2", C.c_int64), ("sb_vt", C.c_int64),
     ]
 
 
@@ -49,6 +51,7 @@ class ReduceLnDesc(C.Structure):
         ("g2", C.c_void_p), ("b2", C.c_void_p), ("out2", C.c_void_p), ("ld2", C.c_int64), ("out2_bf16", C.c_int32),
         ("eps", C.c_float), ("splits", C.c_int32), ("rows", C.c_int32), ("C", C.c_int32),
         ("out1_packed", C.c_int32), ("out2_packed", C.c_int32),
+            ("act", C.c_int32), ("res2", C.c_void_p), ("ldres2", C.c_int64),
     ]
 
 
@@ -71,7 +74,8 @@ _PROTOS = {
     "sp3_attention": [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
                       C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p],
     "sp3_attention_packed": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
-                             C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p],
+                             C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
+                             C.c_void_p],
     "sp3_softmax_thresh": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float,
                            C.c_int, C.c_void_p],
     "sp3_colsum_accum": [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p],

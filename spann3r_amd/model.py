@@ -68,6 +68,7 @@ class SpatialMemory:
         self.lm = 0
         self.events = []
         self._score = torch.zeros(batch, max(work_mem_size, 1), device=dev)
+        self._score_host, self._score_event, self._score_pending = None, None, False
         self._cos_scratch = torch.empty(max(work_mem_size, 1) * num_patches, device=dev)
         self._sel = torch.zeros(batch, max(long_mem_size, 1), dtype=torch.int32, device=dev)
 
@@ -180,9 +181,23 @@ class SpatialMemory:
                                % (self.wm * self.P, self.M))
         return True
 
+    def fetch_scores_async(self):
+        """queue the device->host copy of the scores behind the kernels launched so far; sim_verdict() waits for it only"""
+        if self._score_host is None:
+            self._score_host = torch.empty(self._score.shape, dtype=torch.float32).pin_memory()
+            self._score_event = torch.cuda.Event()
+        self._score_host.copy_(self._score, non_blocking=True)
+        self._score_event.record()
+        self._score_pending = True
+
     def sim_verdict(self):
-        """Host side of check_sim: reads the scores the cos_sim kernel left in self._score (host sync, as :114)."""
-        mx = max(self._score[:, :self.wm].cpu().reshape(-1).tolist())
+        """Host side of check_sim: reads the scores the cos_sim kernels left in self._score (host sync, as :114)."""
+        if self._score_pending:
+            self._score_event.synchronize()
+            self._score_pending = False
+            mx = max(self._score_host[:, :self.wm].reshape(-1).tolist())
+        else:
+            mx = max(self._score[:, :self.wm].cpu().reshape(-1).tolist())
         if mx > self.sim_thresh:
             print("Similarity detected:", mx)
             return True
@@ -285,6 +300,10 @@ class _SequenceRunner:
         self.out = None
         self.batched = False          # True: the frames of the sequence were encoded up front (encode_sequence)
         self.img_all = self.feats = None
+        self.defer2 = False           # True: the view-2 DPT head runs once for all steps after the loop (finish_head2)
+        self.seq_dec2 = None          # per hook: [steps*B*P, D] copies of the side-2 decoder tokens of every step
+        self.dec2_hooks = None
+        self.head2_out = {}
 
     def ensure_memory(self, n_frames):
         need = (n_frames - 1) * self.P if self.training else 4000 + 8 * self.P
@@ -318,6 +337,51 @@ class _SequenceRunner:
             self._graphed(("enc", c0, c1), lambda: self.eng.encode_image(img, out=out, tag="_seq"), use_graphs)
         self.batched = True
 
+    # ---- deferred view-2 head --------------------------------------------------------------------------------
+    HEAD_CHUNK = 16              # images per deferred head launch group
+
+    def enable_deferred_head2(self, n_frames):
+        """The view-2 pointmap/confidence of a step is an output only (nothing of the recurrence reads it: the memory is
+        written from view 1, spann3r/model.py:505-521), so the per-step DPT head 2 is replaced by ONE pass over all
+        steps after the loop: B*(n-1) images per convolution instead of B."""
+        rows = (n_frames - 1) * self.B * self.P
+        D = self.model.cfg.dec_dim
+        if self.seq_dec2 is None or self.seq_dec2[0].shape[0] < rows:
+            self.seq_dec2 = [torch.empty(rows, D, device=self.eng.device) for _ in range(3)]
+            self.graphs = {k: g for k, g in self.graphs.items() if k[0] != "head2"}
+            self.seen = {k for k in self.seen if k[0] != "head2"}
+        self.defer2 = True
+
+    def save_dec2(self, i):
+        """after step i: keep the three decoder hook outputs of side 2 (hook 0 is the encoder feature, already in feats)"""
+        BP, D = self.B * self.P, self.model.cfg.dec_dim
+        for src, dst in zip(self.dec2_hooks, self.seq_dec2):
+            ops.copy2d(src, D, dst[i * BP:(i + 1) * BP], D, BP, D)
+
+    def finish_head2(self, n_frames, use_graphs):
+        """-> list of (pts2, conf2) per step, fresh tensors"""
+        B, P, hk = self.B, self.P, self.model.cfg.hooks
+        steps = n_frames - 1
+        per = max(1, self.HEAD_CHUNK // B)
+        outs = []
+        for c0 in range(0, steps, per):
+            c1 = min(steps, c0 + per)
+            dec = [None] * (hk[-1] + 1)
+            dec[hk[0]] = self.feats[(c0 + 1) * B:(c1 + 1) * B]                   # frames c0+1 .. c1 are the view-2 frames
+            for j, t in enumerate(self.seq_dec2):
+                dec[hk[j + 1]] = t[c0 * B * P:c1 * B * P]
+            key = ("head2", c0, c1)
+
+            def fn(dec=dec, key=key, nb=(c1 - c0) * B):
+                pts, conf, _ = self.eng.dpt_head(dec, nb, self.nh, self.nw, 2)
+                self.head2_out[key] = (pts, conf)
+            self._graphed(key, fn, use_graphs)
+            pts, conf = self.head2_out[key]
+            pts, conf = pts.clone(), conf.clone()
+            for j in range(c1 - c0):
+                outs.append((pts[j * B:(j + 1) * B], conf[j * B:(j + 1) * B]))
+        return outs
+
     def load_pair(self, i):
         """featpair <- (feat of frame i, feat of frame i+1): two adjacent slabs of the sequence buffer, one copy"""
         B, P, E = self.B, self.P, self.E
@@ -341,62 +405,82 @@ class _SequenceRunner:
             fn()
 
     # ---- the kernel sequences (spann3r/model.py:485-531) ----------------------------------------------------
-    def _tail(self, f1, has_next):
-        """decode + key MLPs + DPT heads + value encoder + staged memory write.  The view-1 branch (decoder side 1,
-        key 1, head 1, value encoder, memory write) and the view-2 branch (decoder side 2, key 2, head 2) only meet in
-        the decoder's cross-attention, so they run on two streams; a third stream encodes the NEXT frame (each frame
-        is still encoded exactly once, spann3r/model.py:293-295 -- one step earlier than the reference does it)."""
-        eng, mem, B, P = self.eng, self.mem, self.B, self.P
+    def _part1(self, first, has_next):
+        """Everything up to the similarity scores: (memory read) + decoder + key MLPs + check_sim's cosine scores.
+        The two decoder sides run on two streams (or as grouped launches); a third stream encodes the NEXT frame in
+        the frame-by-frame mode (each frame is encoded exactly once, spann3r/model.py:293-295)."""
+        eng, mem, B, P, E = self.eng, self.mem, self.B, self.P, self.E
         main = torch.cuda.current_stream()
         st = eng.side_streams()
+        if first:
+            if not self.batched:
+                eng.encode_image(self.img_pair, out=self.featpair)
+            f1 = self.feat1
+        else:
+            if not self.batched:
+                ops.copy2d(self.feat2, E, self.feat1, E, B * P, E)      # feat1 <- previous feat2 (:294)
+                ops.copy2d(self.feat_pre, E, self.feat2, E, B * P, E)   # feat2 <- the frame encoded during the previous step
+            mem.memory_read(self.k2, self.fuse)                         # reads k2 before the key MLP overwrites it
+            f1 = self.fuse
         if has_next:
             st[3].wait_stream(main)
             with torch.cuda.stream(st[3]):
                 eng.encode_image(self.img_next, out=self.feat_pre, tag="_pre")
-        dec1, dec2 = eng.decoder(f1, self.feat2, B, self.nh, self.nw, self.nh, self.nw, streams=st)   # joined on return
-        st[1].wait_stream(main)
-        st[2].wait_stream(main)
-        with torch.cuda.stream(st[1]):
+        if eng.packed_attn and self.model.grouped_decoder:
+            # both decoder sides and both key MLPs as grouped launches on the main stream: no per-layer fork/join
+            dec1, dec2 = eng.decoder_grouped(f1, self.feat2, B, self.nh, self.nw)
+            eng.encode_feat_keys_grouped(self.feat1, self.feat2, dec1[-1], dec2[-1], B * P, self.k1, self.k2)
+        else:
+            dec1, dec2 = eng.decoder(f1, self.feat2, B, self.nh, self.nw, self.nh, self.nw, streams=st)   # joined on return
+            st[2].wait_stream(main)
+            with torch.cuda.stream(st[2]):
+                eng.encode_feat_key(self.feat2, dec2[-1], B * P, 2, self.k2)
             eng.encode_feat_key(self.feat1, dec1[-1], B * P, 1, self.k1)
-            pts1, conf1, _ = eng.dpt_head(dec1, B, self.nh, self.nw, 1)
-            # portrait results are handed on axis-swapped (landscape_only wrapper); the value encoder sees that view
-            eng.encode_cur_value(pts1.swapaxes(1, 2) if self.H > self.W else pts1, self.v, self.k1)   # v = cur_v + feat_k1
-            if not self.training and mem.sim_needed():
-                mem.sim_scores(self.k1)
-            mem.stage_write(self.k1, self.v)
-        with torch.cuda.stream(st[2]):
-            eng.encode_feat_key(self.feat2, dec2[-1], B * P, 2, self.k2)
-            pts2, conf2, _ = eng.dpt_head(dec2, B, self.nh, self.nw, 2)
-        main.wait_stream(st[1])
-        main.wait_stream(st[2])
+            main.wait_stream(st[2])
+        if not self.training and mem.sim_needed():
+            mem.sim_scores(self.k1)
         if has_next:
             main.wait_stream(st[3])
+        self.dec = (dec1, dec2)
+        self.dec2_hooks = [dec2[h] for h in self.model.cfg.hooks[1:]]
+
+    def _part2(self):
+        """DPT head(s) + value encoder + staged memory write (spann3r/model.py:505-521).  Nothing in here feeds the
+        similarity gate, so the host reads the scores of _part1 while this part runs."""
+        eng, mem, B = self.eng, self.mem, self.B
+        dec1, dec2 = self.dec
+        main = torch.cuda.current_stream()
+        st = eng.side_streams()
+        pts2 = conf2 = None
+        if not self.defer2:
+            st[2].wait_stream(main)
+            with torch.cuda.stream(st[2]):
+                pts2, conf2, _ = eng.dpt_head(dec2, B, self.nh, self.nw, 2)
+        pts1, conf1, _ = eng.dpt_head(dec1, B, self.nh, self.nw, 1)
+        # portrait results are handed on axis-swapped (landscape_only wrapper); the value encoder sees that view
+        eng.encode_cur_value(pts1.swapaxes(1, 2) if self.H > self.W else pts1, self.v, self.k1)   # v = cur_v + feat_k1
+        mem.stage_write(self.k1, self.v)
+        if not self.defer2:
+            main.wait_stream(st[2])
         self.out = (pts1, conf1, pts2, conf2)
-
-    def _first(self, has_next):
-        if not self.batched:
-            self.eng.encode_image(self.img_pair, out=self.featpair)
-        self._tail(self.feat1, has_next)
-
-    def _step(self, has_next):
-        eng, B, P, E = self.eng, self.B, self.P, self.E
-        if not self.batched:
-            ops.copy2d(self.feat2, E, self.feat1, E, B * P, E)      # feat1 <- previous feat2 (:294)
-            ops.copy2d(self.feat_pre, E, self.feat2, E, B * P, E)   # feat2 <- the frame encoded during the previous step
-        self.mem.memory_read(self.k2, self.fuse)                # reads k2 before _tail overwrites it
-        self._tail(self.fuse, has_next)
 
     def run(self, first, has_next, use_graphs):
         mem = self.mem
         has_next = has_next and not self.batched                # nothing to prefetch: the sequence is already encoded
-        key = ("first" if first else "step", mem.M, mem.wm, mem._cur, has_next, self.batched)
-        fn = (lambda: self._first(has_next)) if first else (lambda: self._step(has_next))
+        key = (mem.M, mem.wm, mem._cur, has_next, self.batched, self.defer2, self.model.grouped_decoder)
         if not use_graphs and ops._prof is not None:
             ops._prof.step_begin()
-        self._graphed(key, fn, use_graphs)
+        # two graphs per step: the host fetches the similarity scores (async copy + event) as soon as the first one is
+        # done and takes the memory decision while the second one (head, value encoder) still runs -> the next step's
+        # launches are queued before the GPU runs dry.  The reference syncs at the same point of the data flow (:114).
+        self._graphed(("first" if first else "step",) + key, lambda: self._part1(first, has_next), use_graphs)
+        need_sim = not self.training and mem.sim_needed()
+        if need_sim:
+            mem.fetch_scores_async()
+        self._graphed(("tail",) + key, self._part2, use_graphs)
         pts1, conf1, pts2, conf2 = self.out
         res1 = {"pts3d": pts1.clone(), "conf": conf1.clone()}
-        res2 = {"pts3d": pts2.clone(), "conf": conf2.clone()}
+        res2 = {} if pts2 is None else {"pts3d": pts2.clone(), "conf": conf2.clone()}      # {}: filled by finish_head2
         if self.H > self.W:                                     # landscape_only wrapper (dust3r/utils/misc.py:79-80)
             res1 = {k: v.swapaxes(1, 2) for k, v in res1.items()}
             res2 = {k: v.swapaxes(1, 2) for k, v in res2.items()}
@@ -404,7 +488,7 @@ class _SequenceRunner:
         if self.training:
             mem.commit()
         else:
-            mem.finish_staged(mem.sim_verdict() if mem.sim_needed() else False)
+            mem.finish_staged(mem.sim_verdict() if need_sim else False)
         return res1, res2
 
 
@@ -459,6 +543,8 @@ class Spann3R(nn.Module):
         self._runners = {}
         self.use_graphs = True       # capture each per-frame step in a hipGraph (False: same kernels, eager launches)
         self.batch_encode = True     # forward(): encode all frames of the sequence together (False: frame by frame)
+        self.defer_head2 = True      # with batch_encode: run the view-2 DPT head once for all steps after the loop
+        self.grouped_decoder = True  # bf16: the two decoder sides as grouped launches on one stream (False: two streams)
 
     # ------------------------------------------------------------------ engine management
     def set_precision(self, precision):
@@ -593,8 +679,12 @@ class Spann3R(nn.Module):
         n = len(frames)
         if self.batch_encode and n > 2:
             run.encode_sequence(frames, self.use_graphs)
+            if self.defer_head2:
+                run.enable_deferred_head2(n)
+            else:
+                run.defer2 = False
         else:
-            run.batched = False
+            run.batched = run.defer2 = False
         for i in range(n - 1):
             if run.batched:
                 run.load_pair(i)
@@ -606,13 +696,21 @@ class Spann3R(nn.Module):
                     run.img_next.copy_(frames[i + 2]["img"])
             has_next = i + 2 < n
             res1, res2 = run.run(i == 0, has_next, self.use_graphs)
-            res2["pts3d_in_other_view"] = res2.pop("pts3d")                      # :523
+            if run.defer2:
+                run.save_dec2(i)
+            else:
+                res2["pts3d_in_other_view"] = res2.pop("pts3d")                  # :523
             if preds is None:
                 preds = [res1]
             else:
                 res1["pts3d_in_other_view"] = res1.pop("pts3d")
                 preds.append(res1)
             preds_all.append((res1, res2))
+        if run.defer2:
+            for (_, r2), (pts2, conf2) in zip(preds_all, run.finish_head2(n, self.use_graphs)):
+                if H > W:                                       # landscape_only wrapper, as in _SequenceRunner.run
+                    pts2, conf2 = pts2.swapaxes(1, 2), conf2.swapaxes(1, 2)
+                r2["pts3d_in_other_view"], r2["conf"] = pts2, conf2
         preds.append(res2)
         if return_memory:
             return preds, preds_all, mem.snapshot()

@@ -174,6 +174,22 @@ class PackedAct:
     def data_ptr(self):
         return self.data.data_ptr()
 
+    @staticmethod
+    def group(G, M, K, dtype, device):
+        """G fragment-order [M, K] matrices in one allocation, each starting on a 16-row boundary (grouped launches):
+        .stride = elements between consecutive problems, .rows_pad = padded rows per problem."""
+        KB = 64 if dtype == torch.bfloat16 else 32
+        Mp, Kp = (M + 15) // 16 * 16, (K + KB - 1) // KB * KB
+        t = PackedAct(G * Mp, K, dtype, device)
+        t.M, t.G, t.rows_pad, t.stride = M, G, Mp, Mp * Kp
+        return t
+
+    def at(self, g):
+        """problem g of a group as a PackedAct of its own (for launches that start at another problem)"""
+        v = PackedAct(self.M, self.K, self.dtype, self.data.device, data=self.data.view(-1)[g * self.stride:])
+        v.stride = self.stride
+        return v
+
 
 class PackedWeight:
     """A weight matrix [N, K] re-ordered once into MFMA-fragment order (include/spann3r_hip.h: w_packed) so that
@@ -196,6 +212,15 @@ class PackedWeight:
         return self.data.element_size()
 
 
+class PackedWeightGroup(PackedWeight):
+    """Several equally shaped PackedWeights in one allocation (grouped launches); .stride = elements per problem"""
+
+    def __init__(self, items):
+        self.N, self.K, self.dtype = items[0].N, items[0].K, items[0].dtype
+        self.data = torch.stack([w.data for w in items]).contiguous()
+        self.stride = items[0].data.numel()
+
+
 def _w(d, W):
     """fills the W fields of a GemmDesc from a tensor or a PackedWeight"""
     d.W = W.data_ptr()
@@ -206,13 +231,22 @@ def _w(d, W):
 class LnFold:
     """Consumer-side arguments of a folded LayerNorm: statistics partials of x [M, C/32, 2], s_n = sum_k (gamma*W)_nk."""
 
-    def __init__(self, stats, C_, s, eps=1e-6):
+    def __init__(self, stats, C_, s, eps=1e-6, sb_stats=0, sb_s=0):
         self.stats, self.C, self.s, self.eps = stats, C_, s, eps
+        self.sb_stats, self.sb_s = sb_stats, sb_s        # grouped launches: byte offsets per problem
 
 
 def _ln(d, ln):
     if ln is not None:
-        d.ln_stats, d.ln_s, d.ln_nt, d.ln_C, d.ln_eps = ln.stats.data_ptr(), ln.s.data_ptr(), ln.C // 32, ln.C, ln.eps
+        d.ln_stats, d.ln_s, d.ln_nt, d.ln_C, d.ln_eps = L.ptr(ln.stats), ln.s.data_ptr(), ln.C // 32, ln.C, ln.eps
+        d.sb_ln_stats, d.sb_ln_s = ln.sb_stats, ln.sb_s
+
+
+def _group(d, batch, strideA, strideW, strideC, sb):
+    """grouped launch (include/spann3r_hip.h "grouped launches"): element strides of A / W / C and byte offsets of the rest"""
+    d.batch, d.strideA, d.strideW, d.strideC = batch, strideA, strideW, strideC
+    for k, v in (sb or {}).items():
+        setattr(d, "sb_" + k, v)
 
 
 def wdtype_of(t):
@@ -241,7 +275,7 @@ def _act(t, name):
 
 def gemm(A, W, out, *, M, N, K, lda, ldc, bias=None, res1=None, ldr1=0, res2=None, ldr2=0, act=ACT_NONE, alpha=1.0,
          relu_in=False, tile=-1, batch=1, strideA=0, strideW=0, strideC=0, ldw=0,
-         A2=None, lda2=0, K1=0, splitk=0, ln=None, stats_out=None, c2=None):
+         A2=None, lda2=0, K1=0, splitk=0, ln=None, stats_out=None, c2=None, sb=None):
     """out[M,N] = act(alpha * A[M,K] @ W[N,K]^T + bias) (+ res1 + res2).  nn.Linear / 1x1 conv / einsum.
     `out` may be fp32 or bf16.  splitk >= 1 selects the PARTIAL epilogue: out is an fp32 [splitk, M, ldc] workspace
     that sp3_reduce_ln finishes."""
@@ -262,18 +296,21 @@ def gemm(A, W, out, *, M, N, K, lda, ldc, bias=None, res1=None, ldr1=0, res2=Non
         d.epi, d.splitk = L.EPI_PARTIAL, splitk
     _ln(d, ln)
     d.stats_out, d.c2 = L.ptr(stats_out), L.ptr(c2)
+    if sb:
+        _group(d, batch, strideA, strideW, strideC, sb)
     _gemm_launch(d, "sp3_gemm", "plain")
     return out
 
 
 def reduce_ln(partial, splits, rows, C_, *, bias=None, res=None, ldres=0, x_out=None, ldx=0,
-              ln1=None, out1=None, ld1=0, ln2=None, out2=None, ld2=0, eps=1e-6):
+              ln1=None, out1=None, ld1=0, ln2=None, out2=None, ld2=0, eps=1e-6, act=ACT_NONE, res2=None, ldres2=0):
     """Finish a split-K GEMM: x = sum(partials) + bias (+ res); x_out = x; out1/out2 = LayerNorm(x) with (gamma, beta)
     pairs ln1 / ln2.  One launch replaces `x = x + proj(...)` and the LayerNorm(s) that follow on the stream."""
     d = L.ReduceLnDesc()
     d.partial, d.split_stride, d.splits, d.rows, d.C = partial.data_ptr(), rows * C_, splits, rows, C_
     d.bias, d.res, d.ldres = L.ptr(bias), L.ptr(res), ldres or C_
     d.x_out, d.ldx = L.ptr(x_out), ldx or C_
+    d.act, d.res2, d.ldres2 = act, L.ptr(res2), ldres2 or C_
     if out1 is not None:
         d.g1, d.b1, d.out1, d.ld1, d.out1_bf16 = ln1[0].data_ptr(), ln1[1].data_ptr(), out1.data_ptr(), ld1 or C_, int(out1.dtype == torch.bfloat16)
         d.out1_packed = _is_packed(out1)
@@ -287,7 +324,7 @@ def reduce_ln(partial, splits, rows, C_, *, bias=None, res=None, ldres=0, x_out=
 
 
 def conv3x3(x, Wp, out, *, B, H, W_, Cin, Cout, stride=1, bias=None, res1=None, res2=None, act=ACT_NONE,
-            relu_in=False, tile=-1, force_tile_kernel=False):
+            relu_in=False, tile=-1, force_tile_kernel=False, splitk_ws=None):
     """3x3 Conv2d, padding 1, on an NHWC fp32 map [B,H,W,Cin] -> [B,OH,OW,Cout] (implicit GEMM).
     Wp is the weight packed as [Cout, 9*Cin] with k = (ky*3+kx)*Cin + ci."""
     OH, OW = (H - 1) // stride + 1, (W_ - 1) // stride + 1
@@ -306,15 +343,34 @@ def conv3x3(x, Wp, out, *, B, H, W_, Cin, Cout, stride=1, bias=None, res1=None, 
     d.a_bf16 = _act(x, "x")
     d.out_bf16 = int(out.dtype == torch.bfloat16)
     _w(d, Wp)
-    d.A, d.C = x.data_ptr(), out.data_ptr()
-    d.bias, d.res1, d.res2 = L.ptr(bias), L.ptr(res1), L.ptr(res2)
-    d.M, d.N, d.K, d.batch = B * OH * OW, Cout, 9 * Cin, 1
+    M = B * OH * OW
+    S = conv_splitk(M, Cout, 9 * Cin, Wp.dtype) if (splitk_ws is not None and tile < 0 and out.dtype == torch.float32) else 1
+    if S > 1 and splitk_ws.numel() < S * M * Cout:
+        raise ValueError("conv3x3: splitk_ws holds %d floats, needs %d" % (splitk_ws.numel(), S * M * Cout))
+    d.A, d.C = x.data_ptr(), (splitk_ws if S > 1 else out).data_ptr()
+    if S == 1:
+        d.bias, d.res1, d.res2 = L.ptr(bias), L.ptr(res1), L.ptr(res2)
+    d.M, d.N, d.K, d.batch = M, Cout, 9 * Cin, 1
     d.lda, d.ldc, d.ldr1, d.ldr2 = Cin, Cout, Cout, Cout
-    d.alpha, d.act, d.relu_in = 1.0, act, int(relu_in)
-    d.loader, d.epi, d.tile = L.LOAD_CONV3X3, L.EPI_PLAIN, tile
+    d.alpha, d.act, d.relu_in = 1.0, (act if S == 1 else ACT_NONE), int(relu_in)
+    d.loader, d.epi, d.tile = L.LOAD_CONV3X3, (L.EPI_PLAIN if S == 1 else L.EPI_PARTIAL), (tile if S == 1 else 0)
+    d.splitk = S if S > 1 else 0
     d.conv_H, d.conv_W, d.conv_C, d.conv_OH, d.conv_OW, d.conv_stride = H, W_, Cin, OH, OW, stride
     _gemm_launch(d, "sp3_gemm(conv3x3)", "conv3x3")
+    if S > 1:
+        # few output tiles, long K (small maps): K split over S workgroups per tile, finished by one reduce launch
+        reduce_ln(splitk_ws, S, M, Cout, bias=bias, res=res1, ldres=Cout, x_out=out, ldx=Cout, act=act, res2=res2, ldres2=Cout)
     return out
+
+
+def conv_splitk(M, N, K, wdtype):
+    """K split of the implicit-GEMM convolution: only when the 32x32 tiles alone leave most CUs idle"""
+    tiles = ((M + 31) // 32) * ((N + 31) // 32)
+    nkb = K // (64 if wdtype == torch.bfloat16 else 32)
+    s = 1
+    while tiles * s * 2 <= 512 and nkb // (s * 2) >= 4 and s < 8:
+        s *= 2
+    return s
 
 
 def conv_transpose_ks(x, Wp, out, *, B, H, W_, Cin, Cout, ks, bias=None, tile=-1):
@@ -335,7 +391,7 @@ def conv_transpose_ks(x, Wp, out, *, B, H, W_, Cin, Cout, ks, bias=None, tile=-1
 
 
 def proj_rope_vt(A, W, bias, out_qk, ldc, vt, vt_ld, *, M, N, K, lda, rope_cols, pos, cos, sin, tokens, heads, tile=-1,
-                 qkv_packed=False, ln=None):
+                 qkv_packed=False, ln=None, batch=1, strideA=0, strideW=0, strideC=0, sb=None):
     """Fused q/k(/v) projection of an attention layer: bias + 2-D RoPE on columns [0, rope_cols)
     (stored row-major to out_qk) and per-head transposed store of the V columns to vt."""
     d = GemmDesc()
@@ -353,6 +409,8 @@ def proj_rope_vt(A, W, bias, out_qk, ldc, vt, vt_ld, *, M, N, K, lda, rope_cols,
     _ln(d, ln)
     if out_qk is None:
         d.C = vt.data_ptr()           # unused by the kernel when rope_cols == 0, but must be non-null
+    if batch > 1:
+        _group(d, batch, strideA, strideW, strideC, sb)
     _gemm_launch(d, "sp3_gemm(rope_vt)", "plain")
 
 
@@ -411,13 +469,15 @@ def attention(q, sq, ldq, k, sk, ldk, vt, vt_ld, out, ldo, *, B, heads, Nq, Nk, 
     return out
 
 
-def attention_packed(qp, q_cols, q_col0, npad_q, kp, k_cols, k_col0, npad_k, vtp, out, ldo, *, B, heads, Nq, Nk, scale):
+def attention_packed(qp, q_cols, q_col0, npad_q, kp, k_cols, k_col0, npad_k, vtp, out, ldo, *, B, heads, Nq, Nk, scale,
+                     o_group=0, o_group_rows=0):
     """bf16 attention on the fragment-order q/k and PV-order V written by proj_rope_vt(qkv_packed=True)."""
     _timed("attention_packed<bf16>", 4.0 * B * heads * Nq * Nk * 64, B * heads * 64.0 * (2 * (Nq + 2 * Nk) + 4 * Nq),
            lambda: L.check(L.load().sp3_attention_packed(qp.data_ptr(), q_cols, q_col0, npad_q, kp.data_ptr(), k_cols, k_col0,
                                                          npad_k, vtp.data_ptr(), out.data_ptr(), ldo,
                                                          int(out.dtype == torch.bfloat16), _is_packed(out), B, heads, Nq, Nk,
-                                                         float(scale), L.stream_ptr()), "sp3_attention_packed"))
+                                                         float(scale), o_group, o_group_rows, L.stream_ptr()),
+                           "sp3_attention_packed"))
     return out
 
 

@@ -145,6 +145,27 @@ def test_batched_encoder_equals_per_frame(tiny_model):
     assert a[2].M == b[2].M and a[2].wm == b[2].wm
 
 
+def test_grouped_decoder_equals_two_stream_decoder(tiny_model):
+    """bf16: the decoder as grouped launches (both sides = problems 0/1 of one launch per op, one stream) runs the same
+    kernels on the same operands as the two-stream decoder: bit-identical outputs."""
+    from spann3r_amd.weights import synth_frames
+    m = tiny_model.set_precision("bf16")
+    try:
+        frames = to_dev(synth_frames(5, 48, 64, seed=9))
+        a = m(frames, return_memory=True)
+        m.grouped_decoder = False
+        try:
+            b = m(frames, return_memory=True)
+        finally:
+            m.grouped_decoder = True
+    finally:
+        m.set_precision("fp32")
+    for x, y in zip(a[0], b[0]):
+        for k in x:
+            assert torch.equal(x[k], y[k]), k
+    assert torch.equal(a[2].mem_k, b[2].mem_k) and torch.equal(a[2].mem_v, b[2].mem_v)
+
+
 def test_tiny_training_policy(tiny_model):
     """Growing bank: train-mode memory policy with dropout disabled (the oracle for BASELINE config 3)."""
     from spann3r_amd.weights import synth_frames

@@ -193,6 +193,26 @@ def test_conv3x3(wdt, B, H, W, Cin, Cout, stride):
     assert rel_err(out.cpu(), nhwc(ref)) < TOL[wdt]
 
 
+@pytest.mark.parametrize("wdt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride", [(1, 14, 14, 256, 256, 1), (1, 14, 14, 768, 768, 2), (1, 7, 7, 768, 256, 1), (2, 28, 28, 256, 256, 1)])
+def test_conv3x3_splitk(wdt, B, H, W, Cin, Cout, stride):
+    """small maps: K split over several workgroups per output tile (PARTIAL epilogue) + sp3_reduce_ln with the conv's
+    bias / ReLU / two residuals"""
+    ops = _ops()
+    x, w, b = rnd(B, Cin, H, W, seed=1), rnd(Cout, Cin, 3, 3, seed=2) * 0.05, rnd(Cout, seed=3)
+    OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
+    assert ops.conv_splitk(B * OH * OW, Cout, 9 * Cin, wdt) > 1 or B > 1
+    r1, r2 = rnd(B, Cout, OH, OW, seed=4), rnd(B, Cout, OH, OW, seed=5)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous()
+    wp = ops.PackedWeight(w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to(DEV).to(wdt))
+    out = torch.empty(B, OH, OW, Cout, device=DEV)
+    ops.conv3x3(nhwc(x).to(DEV), wp, out, B=B, H=H, W_=W, Cin=Cin, Cout=Cout, stride=stride, bias=b.to(DEV), res1=nhwc(r1).to(DEV),
+                res2=nhwc(r2).to(DEV), relu_in=True, act=ops.ACT_RELU, splitk_ws=torch.empty(1 << 21, device=DEV))
+    xr, wr = (bf(F.relu(x)), bf(w)) if wdt == torch.bfloat16 else (F.relu(x), w)
+    ref = F.relu(F.conv2d(xr.double(), wr.double(), b.double(), stride=stride, padding=1)) + r1.double() + r2.double()
+    assert rel_err(out.cpu(), nhwc(ref)) < TOL[wdt]
+
+
 @pytest.mark.parametrize("in_dt,out_dt", [(torch.float32, torch.float32), (torch.bfloat16, torch.bfloat16), (torch.float32, torch.bfloat16)])
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(1, 56, 56, 256, 256), (2, 13, 9, 128, 128), (1, 8, 8, 64, 192), (1, 20, 28, 256, 128),
                                             (1, 3, 5, 384, 64)])
