@@ -146,19 +146,18 @@ def main():
         total_ms = sum(a["ms"] for a in agg.values())
         top = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])
         key, a = top[0]
-        is_gemm = key.startswith("gemm") or key.startswith("attention")
-        if is_gemm:
-            ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
-            out["roofline"] = {"kernel": key, "bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[args.precision],
-                               "unit": "TFLOP/s", "frac": ach / PEAK_TFLOPS[args.precision], "traffic": None,
-                               "launches": a["launches"], "avg_us": 1e3 * a["ms"] / a["launches"],
-                               "avg_gflop_per_launch": a["flops"] / a["launches"] / 1e9,
-                               "share_of_gpu_time": a["ms"] / total_ms}
+        # the roof that binds the dominant kernel: the larger of (algorithmic FLOPs / dense MFMA peak) and
+        # (algorithmic bytes / HBM peak); frac = that lower bound on the launch time / the measured launch time
+        t_ms = a["ms"] * 1e-3
+        ach_fl, ach_by = a["flops"] / t_ms / 1e12, a["bytes"] / t_ms / 1e9
+        fr_fl, fr_by = ach_fl / PEAK_TFLOPS[args.precision], ach_by / PEAK_HBM_GBS
+        common = {"kernel": key, "traffic": None, "launches": a["launches"], "avg_us": 1e3 * a["ms"] / a["launches"],
+                  "avg_gflop_per_launch": a["flops"] / a["launches"] / 1e9, "avg_mbyte_per_launch": a["bytes"] / a["launches"] / 1e6,
+                  "share_of_gpu_time": a["ms"] / total_ms, "mfma_frac": fr_fl, "hbm_frac": fr_by}
+        if fr_fl >= fr_by:
+            out["roofline"] = dict(bound="mfma", achieved=ach_fl, peak=PEAK_TFLOPS[args.precision], unit="TFLOP/s", frac=fr_fl, **common)
         else:
-            ach = a["bytes"] / (a["ms"] * 1e-3) / 1e9
-            out["roofline"] = {"kernel": key, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                               "frac": ach / PEAK_HBM_GBS, "traffic": None, "launches": a["launches"],
-                               "avg_us": 1e3 * a["ms"] / a["launches"], "share_of_gpu_time": a["ms"] / total_ms}
+            out["roofline"] = dict(bound="hbm", achieved=ach_by, peak=PEAK_HBM_GBS, unit="GB/s", frac=fr_by, **common)
         out["kernel_breakdown"] = [{"kernel": k, "launches": v["launches"], "ms": round(v["ms"], 4),
                                     "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else None}
                                    for k, v in top[:8]]

@@ -66,13 +66,22 @@ __global__ __launch_bounds__(256) void softmax_thresh_kernel(const float* __rest
   for (int j = M + threadIdx.x; j < Mpad; j += 256) p[j] = 0.f;
 }
 
+// mem_attn[j] += sum_r P[r, j]: one workgroup per 64 columns, its 4 waves take the rows r = w, w+4, ... (coalesced 256-byte
+// row segments), partial sums meet in LDS in a fixed order.
 __global__ __launch_bounds__(256) void colsum_accum_kernel(const float* __restrict__ P, int64_t ld, int rows, int M,
                                                            float* __restrict__ mem_attn) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= M) return;
-  float s = 0.f;
-  for (int r = 0; r < rows; ++r) s += P[(int64_t)r * ld + j];
-  mem_attn[j] += s;
+  __shared__ float sh[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + lane;
+  float s0 = 0.f, s1 = 0.f;
+  if (j < M) {
+    int r = w;
+    for (; r + 4 < rows; r += 8) { s0 += P[(int64_t)r * ld + j]; s1 += P[(int64_t)(r + 4) * ld + j]; }
+    if (r < rows) s0 += P[(int64_t)r * ld + j];
+  }
+  sh[w][lane] = s0 + s1;
+  __syncthreads();
+  if (w == 0 && j < M) mem_attn[j] += (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
 }
 
 // cos_sim, stage 1: one wave per (stored frame t, patch p) pair -> cosv[t*P + p] = cos(k[p], wm[t,p]).
@@ -210,7 +219,7 @@ extern "C" int sp3_softmax_thresh(const float* S, float* P, int64_t ld, int64_t 
 
 extern "C" int sp3_colsum_accum(const float* P, int64_t ld, int rows, int M, float* mem_attn, void* stream) {
   SP3_CHECK(P && mem_attn && rows > 0 && M > 0, "sp3_colsum_accum: bad arguments");
-  hipLaunchKernelGGL(colsum_accum_kernel, dim3((M + 255) / 256), dim3(256), 0, ST(stream), P, ld, rows, M, mem_attn);
+  hipLaunchKernelGGL(colsum_accum_kernel, dim3((M + 63) / 64), dim3(256), 0, ST(stream), P, ld, rows, M, mem_attn);
   SP3_LAUNCH_CHECK("sp3_colsum_accum");
   return 0;
 }

@@ -129,7 +129,9 @@ def _gemm_launch(d, what, loader_name):
     b = max(d.batch, 1)
     wsz = 4 if d.wdtype == F32 else 2
     flops = 2.0 * d.M * d.N * d.K * b
-    nbytes = b * (4.0 * d.M * d.K + wsz * d.N * d.K + 4.0 * d.M * d.N)
+    asz, csz = (2 if d.a_bf16 else 4), (2 if d.out_bf16 else 4)
+    a_elems = d.M * d.K if d.loader != L.LOAD_CONV3X3 else d.M * d.conv_stride * d.conv_stride * d.conv_C   # conv: the map, once
+    nbytes = b * (asz * a_elems + wsz * d.N * d.K + csz * d.M * d.N)      # algorithmic: every operand once
     adt = "bf16" if d.a_bf16 else "f32"
     _prof.end("gemm<A%s,W%s,%s,%s>" % (adt, "f32" if d.wdtype == F32 else "bf16", loader_name, _TILE_NAMES[d.tile]),
               e0, flops, nbytes)
