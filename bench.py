@@ -154,6 +154,16 @@ def main():
         common = {"kernel": key, "traffic": None, "launches": a["launches"], "avg_us": 1e3 * a["ms"] / a["launches"],
                   "avg_gflop_per_launch": a["flops"] / a["launches"] / 1e9, "avg_mbyte_per_launch": a["bytes"] / a["launches"] / 1e6,
                   "share_of_gpu_time": a["ms"] / total_ms, "mfma_frac": fr_fl, "hbm_frac": fr_by}
+        # HBM traffic of that kernel from the PMC passes committed under profiles/ (rocprofv3 cannot run inside this
+        # process): bytes per launch, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_f_pmc_hbm_traffic.json")))["kernels"].get(key)
+            if pm and args.precision == "bf16" and args.size == 224:
+                common["traffic"] = pm["traffic_bytes"]
+                common["traffic_note"] = ("HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), "
+                                          "profiles/r01_f_pmc_hbm_traffic.json; algorithmic bytes per launch = %d" % round(a["bytes"] / a["launches"]))
+        except (OSError, ValueError, KeyError):
+            pass
         if fr_fl >= fr_by:
             out["roofline"] = dict(bound="mfma", achieved=ach_fl, peak=PEAK_TFLOPS[args.precision], unit="TFLOP/s", frac=fr_fl, **common)
         else:
