@@ -202,6 +202,8 @@ int sp3_attention_packed(const void* qp, int q_cols, int q_col0, int npad_q, con
  * sp3_softmax_thresh: rows of S fp32 [rows, ld] -> P fp32 [rows, ld]: softmax over the first M
  *   columns; if thresh > 0, p < thresh -> 0 and renormalise (:160,170-172); columns [M, Mpad) are
  *   written as 0 so that P can be the A operand of the P.V GEMM.  batch in grid.y via strideS.
+ *   P_packed (optional): a second, bf16 copy of P in sp3_gemm's a_packed fragment order with K = M rounded up to 64
+ *   (zero filled), stride_packed elements per batch entry -- the coalesced A operand of the P.V GEMM.
  * sp3_colsum_accum : mem_attn[j] += sum_r P[r, j]  (:180-181).
  * sp3_cos_sim      : score[t] = mean_p cos(k[p,:], wm[t,p,:]) for t < T (:102-112); k fp32 [P,C],
  *   wm fp32 [T,P,C] contiguous; scratch fp32 [T*P] holds the per-patch cosines (one wave per (t,p) pair, then one
@@ -214,7 +216,7 @@ int sp3_attention_packed(const void* qp, int q_cols, int q_col0, int npad_q, con
  * sp3_gather_1d    : dst[i] = src[sel[i]] fp32.
  */
 int sp3_softmax_thresh(const float* S, float* P, int64_t ld, int64_t strideS, int rows, int M, int Mpad,
-                       float thresh, int batch, void* stream);
+                       float thresh, int batch, void* P_packed, int64_t stride_packed, void* stream);
 int sp3_colsum_accum(const float* P, int64_t ld, int rows, int M, float* mem_attn, void* stream);
 int sp3_cos_sim(const float* k, const float* wm, int T, int P, int C, float* scratch, float* score, void* stream);
 int sp3_mem_append(float* count, float* attn, int M, int P, void* stream);

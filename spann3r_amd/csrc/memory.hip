@@ -36,7 +36,8 @@ __device__ __forceinline__ float block_reduce_sum(float v, float* sh) {
 
 // One block per row.  softmax over [0,M); optional threshold + renormalise; zero-fill [M,Mpad).
 __global__ __launch_bounds__(256) void softmax_thresh_kernel(const float* __restrict__ S, float* __restrict__ P, int64_t ld,
-                                                             int64_t strideS, int M, int Mpad, float thresh) {
+                                                             int64_t strideS, int M, int Mpad, float thresh,
+                                                             __bf16* __restrict__ Pk, int Kp, int64_t stridePk) {
   __shared__ float sh[8];
   const float* s = S + (int64_t)blockIdx.y * strideS + (int64_t)blockIdx.x * ld;
   float* p = P + (int64_t)blockIdx.y * strideS + (int64_t)blockIdx.x * ld;
@@ -64,6 +65,19 @@ __global__ __launch_bounds__(256) void softmax_thresh_kernel(const float* __rest
     for (int j = threadIdx.x; j < M; j += 256) p[j] = expf(s[j] - mx) * inv;
   }
   for (int j = M + threadIdx.x; j < Mpad; j += 256) p[j] = 0.f;
+  if (Pk) {
+    // second copy for the P.V GEMM: bf16, fragment order [rows, Kp] (Kp = M rounded up to 64, zero filled): 8 consecutive
+    // probabilities = one 16-byte store.  Reads back this block's own fp32 row (visible after the barrier).
+    __syncthreads();
+    __bf16* pk = Pk + (int64_t)blockIdx.y * stridePk;
+    const int row = blockIdx.x;
+    for (int j8 = threadIdx.x * 8; j8 < Kp; j8 += 256 * 8) {
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (__bf16)((j8 + e) < M ? p[j8 + e] : 0.f);
+      *reinterpret_cast<bf16x8*>(pk + packed_off(row, j8, Kp, true)) = o;
+    }
+  }
 }
 
 // mem_attn[j] += sum_r P[r, j]: one workgroup per 64 columns, its 4 waves take the rows r = w, w+4, ... (coalesced 256-byte
@@ -209,10 +223,11 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
 #define ST(s) reinterpret_cast<hipStream_t>(s)
 
 extern "C" int sp3_softmax_thresh(const float* S, float* P, int64_t ld, int64_t strideS, int rows, int M, int Mpad,
-                                  float thresh, int batch, void* stream) {
+                                  float thresh, int batch, void* P_packed, int64_t stride_packed, void* stream) {
   SP3_CHECK(S && P && rows > 0 && M > 0 && Mpad >= M && ld >= Mpad, "sp3_softmax_thresh: bad arguments");
+  const int Kp = (M + 63) / 64 * 64;
   hipLaunchKernelGGL(softmax_thresh_kernel, dim3(rows, batch > 0 ? batch : 1), dim3(256), 0, ST(stream), S, P, ld, strideS, M,
-                     Mpad, thresh);
+                     Mpad, thresh, reinterpret_cast<__bf16*>(P_packed), Kp, stride_packed);
   SP3_LAUNCH_CHECK("sp3_softmax_thresh");
   return 0;
 }

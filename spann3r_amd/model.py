@@ -128,9 +128,29 @@ class SpatialMemory:
         Pm = eng.ws("mem_P", (B, P, ld))
         ops.gemm(qn, bk["k_hat"], S, M=P, N=M, K=C, lda=C, ldc=ld, alpha=1.0 / (C ** 0.5), batch=B,
                  strideA=P * C, strideW=self.cap * C, strideC=P * ld)
-        ops.softmax_thresh(S, Pm, ld=ld, rows=P, M=M, Mpad=Mpad, thresh=self.attn_thresh, batch=B, strideS=P * ld)
-        ops.gemm(Pm, bk["v_hat_t"], out, M=P, N=C, K=Mpad, lda=ld, ldc=C, ldw=self.cap, res1=feat, ldr1=C, batch=B,
-                 strideA=P * ld, strideW=C * self.cap, strideC=P * C)
+        if eng.adt == torch.bfloat16:
+            # bf16: the probabilities reach the P.V GEMM as a fragment-order bf16 operand (coalesced, half the bytes);
+            # long banks split K over several workgroups per output tile (64 tiles otherwise) and one reduce launch adds q
+            Kp = (M + 63) // 64 * 64
+            Pp = 16 * ((P + 15) // 16)
+            pk = eng.ws("mem_P_packed", (B, Pp * ((self.cap + 63) // 64 * 64)), torch.bfloat16, zero=True)
+            ops.softmax_thresh(S, Pm, ld=ld, rows=P, M=M, Mpad=Mpad, thresh=self.attn_thresh, batch=B, strideS=P * ld,
+                               packed=pk, stride_packed=pk.shape[1])
+            S_k = 1
+            while Kp // (2 * S_k) >= 2048 and S_k < 16:
+                S_k *= 2
+            for b in range(B):
+                A = ops.PackedAct(P, Kp, torch.bfloat16, eng.device, data=pk[b])
+                if S_k == 1:
+                    ops.gemm(A, bk["v_hat_t"][b], out[b], M=P, N=C, K=Kp, lda=Kp, ldc=C, ldw=self.cap, res1=feat[b], ldr1=C)
+                else:
+                    part = eng.ws("mem_pv_partial", (S_k * P * C,))
+                    ops.gemm(A, bk["v_hat_t"][b], part, M=P, N=C, K=Kp, lda=Kp, ldc=C, ldw=self.cap, splitk=S_k)
+                    ops.reduce_ln(part, S_k, P, C, res=feat[b], ldres=C, x_out=out[b], ldx=C)
+        else:
+            ops.softmax_thresh(S, Pm, ld=ld, rows=P, M=M, Mpad=Mpad, thresh=self.attn_thresh, batch=B, strideS=P * ld)
+            ops.gemm(Pm, bk["v_hat_t"], out, M=P, N=C, K=Mpad, lda=ld, ldc=C, ldw=self.cap, res1=feat, ldr1=C, batch=B,
+                     strideA=P * ld, strideW=C * self.cap, strideC=P * C)
         for b in range(B):
             ops.colsum_accum(Pm[b], ld, P, M, bk["attn"][b])
         if prof is not None:

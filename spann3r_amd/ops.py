@@ -483,10 +483,11 @@ def attention_packed(qp, q_cols, q_col0, npad_q, kp, k_cols, k_col0, npad_k, vtp
     return out
 
 
-def softmax_thresh(S, P, *, ld, rows, M, Mpad, thresh, batch=1, strideS=0):
+def softmax_thresh(S, P, *, ld, rows, M, Mpad, thresh, batch=1, strideS=0, packed=None, stride_packed=0):
+    """packed: optional bf16 buffer that receives P in fragment order [rows, ceil64(M)] (the P.V GEMM's packed A)"""
     _timed("softmax_thresh", 8.0 * batch * rows * M, 8.0 * batch * rows * M,
            lambda: L.check(L.load().sp3_softmax_thresh(S.data_ptr(), P.data_ptr(), ld, strideS, rows, M, Mpad, float(thresh),
-                                                       batch, L.stream_ptr()), "sp3_softmax_thresh"))
+                                                       batch, L.ptr(packed), stride_packed, L.stream_ptr()), "sp3_softmax_thresh"))
 
 
 def colsum_accum(P, ld, rows, M, mem_attn):

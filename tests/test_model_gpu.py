@@ -259,3 +259,37 @@ def test_full224_vs_golden(full_sd):
     # size-independent properties at full size: determinism and independence of calls (a new memory per forward)
     preds2, _ = m(to_dev(synth_frames(int(g["meta_frames"]), 224, 224)))
     assert all(torch.equal(a["conf"], b["conf"]) for a, b in zip(preds_b, preds2))
+
+
+def test_full512_growing_bank(full_sd):
+    """BASELINE config 3 geometry: 512x512 frames (P = 1024 tokens), growing memory bank (train-mode policy, dropout off).
+    (a) two steps in fp32 against the CPU oracle run live on the same seeded frames (1e-3 bar); (b) at a longer sequence
+    in bf16 the size-independent properties: finite outputs, graph replay == eager, calls independent, bank size."""
+    from oracle import spann3r_oracle as O
+    from spann3r_amd import Spann3R, FULL
+    from spann3r_amd.weights import synth_frames
+    m = Spann3R(dus3r_name=None, cfg=FULL, init_weights=False)
+    m.load_state_dict(full_sd, strict=True)
+    m = m.to(DEV).train()
+    m.mem_dropout.eval()
+    frames = synth_frames(3, 512, 512, seed=11)
+    ref = O.forward(frames, full_sd, FULL, training_policy=True)[0]
+    preds, _, mem = m(to_dev(frames), return_memory=True)
+    worst = 0.0
+    for j, (p, r) in enumerate(zip(preds, ref)):
+        key = "pts3d" if j == 0 else "pts3d_in_other_view"
+        worst = max(worst, rel_err(p[key].cpu(), r[key]), rel_err(p["conf"].cpu(), r["conf"]))
+    print("full512 fp32 (3 frames, growing bank): worst rel err %.3e" % worst)
+    assert worst < TOL_FP32 and mem.M == 2 * 1024
+    m.set_precision("bf16")
+    seq = to_dev(synth_frames(12, 512, 512, seed=12))
+    outs = [m(seq, return_memory=True) for _ in range(3)]           # eager, captured, replayed
+    m.use_graphs = False
+    outs.append(m(seq, return_memory=True))
+    m.use_graphs = True
+    assert outs[0][2].M == 11 * 1024
+    for o in outs:
+        assert all(torch.isfinite(p["conf"]).all() and torch.isfinite(p[k]).all() for p in o[0] for k in p)
+    for o in outs[1:]:
+        for a, b in zip(outs[0][0], o[0]):
+            assert all(torch.equal(a[k], b[k]) for k in a)

@@ -479,7 +479,14 @@ def test_softmax_thresh_and_colsum(thresh):
     S = rnd(B, rows, ld, seed=1) * 4
     Pm = torch.full((B, rows, ld), float("nan"), device=DEV)
     Mpad = (M + 7) // 8 * 8
-    ops.softmax_thresh(S.to(DEV), Pm, ld=ld, rows=rows, M=M, Mpad=Mpad, thresh=thresh, batch=B, strideS=rows * ld)
+    Kp, rp = (M + 63) // 64 * 64, (rows + 15) // 16 * 16
+    pk = torch.full((B, rp * Kp), float("nan"), device=DEV, dtype=torch.bfloat16)
+    ops.softmax_thresh(S.to(DEV), Pm, ld=ld, rows=rows, M=M, Mpad=Mpad, thresh=thresh, batch=B, strideS=rows * ld,
+                       packed=pk, stride_packed=rp * Kp)
+    # the fragment-order bf16 copy holds exactly the rounded probabilities, zero filled up to Kp
+    for b_ in range(B):
+        dense = ops.PackedAct(rows, Kp, torch.bfloat16, DEV, data=pk[b_].view(ops.packed_shape(rows, Kp, torch.bfloat16))).to_dense()
+        assert torch.equal(dense[:, :M], Pm[b_, :, :M].to(torch.bfloat16)) and float(dense[:, M:].float().abs().max()) == 0.0
     a = torch.softmax(S[..., :M].double(), -1)
     if thresh > 0:
         a32 = torch.softmax(S[..., :M], -1)
