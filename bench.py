@@ -178,6 +178,7 @@ def main():
             gbs = big["bytes"] / (big["ms"] * 1e-3) / 1e9
             out["memread"] = {"what": "spatial-memory read (LN_q, S = q.K_hat^T/32, softmax+threshold, P.V_hat + q, colsum)",
                               "bank_tokens": big["info"]["M"], "algorithmic_bytes": big["bytes"], "us": 1e3 * big["ms"],
+                              "launches": big["launches"], "us_uncorrected": 1e3 * big["raw_ms"],
                               "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
                               "reads_per_sequence": len(reads), "all_reads_us": [round(1e3 * r["ms"], 2) for r in reads]}
 

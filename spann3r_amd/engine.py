@@ -203,15 +203,6 @@ class Engine:
         ops.attention(qk, P * 2 * C, 2 * C, qk[:, C:], P * 2 * C, 2 * C, vt, npad, ao, C, B=B, heads=heads, Nq=P, Nk=P,
                       scale=64 ** -0.5)
 
-    def _linear_reduce(self, A, W, bias, R, N, K, lda, *, res=None, x_out=None, ln1=None, out1=None, ln2=None, out2=None,
-                       eps=1e-6, A2=None, lda2=0, K1=0, tag=""):
-        """x = A.W^T + bias (+ res) as a split-K GEMM finished by the fused reduce + residual + LayerNorm kernel (kept for
-        very small outputs with a long K; the blocks themselves use the folded-LayerNorm GEMMs below)."""
-        S = ops.pick_splitk(R, N, K)
-        part = self.ws("splitk_partial" + tag, (max(S, 2) * R * N,))
-        ops.gemm(A, W, part, M=R, N=N, K=K, lda=lda, ldc=N, splitk=S, A2=A2, lda2=lda2, K1=K1)
-        ops.reduce_ln(part, S, R, N, bias=bias, res=res, x_out=x_out, ln1=ln1, out1=out1, ln2=ln2, out2=out2, eps=eps)
-
     def _norm(self, name):
         return (self.w[name + ".w"], self.w[name + ".b"])
 

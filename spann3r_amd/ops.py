@@ -32,16 +32,24 @@ class Profiler:
         torch.cuda._sleep(self.blocker_cycles)
 
     def region_begin(self):
-        return self.begin()
+        return (self.begin(), len(self.rec))
 
     def region_end(self, key, e0, nbytes, info=None):
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        self.regions.append((key, e0, e1, float(nbytes), info))
+        e0, n0 = e0
+        self.regions.append((key, e0, e1, float(nbytes), info, len(self.rec) - n0))
 
     def region_summary(self):
+        """a region spans several bracketed launches: its own bracket and every inner one cost `bracket_ms` of GPU time
+        each (calibrate()), which is subtracted; `raw_ms` keeps the uncorrected span"""
         torch.cuda.synchronize()
-        return [dict(key=k, ms=e0.elapsed_time(e1), bytes=b, info=i) for k, e0, e1, b, i in self.regions]
+        ov = getattr(self, "bracket_ms", 0.0)
+        out = []
+        for k, e0, e1, b, i, inner in self.regions:
+            raw = e0.elapsed_time(e1)
+            out.append(dict(key=k, ms=max(raw - ov * (inner + 1), 1e-4), raw_ms=raw, launches=inner, bytes=b, info=i))
+        return out
 
     def begin(self):
         e = torch.cuda.Event(enable_timing=True)
@@ -105,17 +113,6 @@ def pick_tile(M, N, batch=1, splitk=1, conv=False, K=0):
             return 1
         return 0
     return 0
-
-
-def pick_splitk(M, N, K):
-    """How many workgroups share one output tile's K range (PARTIAL epilogue + sp3_reduce_ln).  With 32x32 tiles the
-    hot-path shapes already launch >= 168 workgroups, and tools/bench_gemm.py shows no gain from splitting further on
-    MI355X, so this only kicks in for very small outputs with a long K."""
-    tiles = ((M + 31) // 32) * ((N + 31) // 32)
-    s = 1
-    while tiles * s < 128 and K // (s * 2) >= 1024 and s < 8:
-        s *= 2
-    return s
 
 
 def _gemm_launch(d, what, loader_name):

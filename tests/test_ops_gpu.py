@@ -117,7 +117,7 @@ def test_splitk_reduce_ln(wdt, M, N, K, S):
     y = torch.empty(M, N, device=DEV)
     ops.reduce_ln(part, S, M, N, bias=b.to(DEV), x_out=y)
     assert rel_err(y.cpu(), Ar.double() @ Wr.double().T + b.double()) < TOL[wdt]
-    assert ops.pick_splitk(196, 1024, 4096) == 1 and ops.pick_splitk(16, 64, 8192) > 1
+    assert ops.conv_splitk(196, 256, 2304, torch.bfloat16) > 1 and ops.conv_splitk(3136, 256, 2304, torch.bfloat16) == 1
 
 
 @pytest.mark.parametrize("wdt", [torch.float32, torch.bfloat16])
