@@ -245,8 +245,28 @@ template <typename TA, int MF> struct ARows<TA, SP3_LOAD_CONV3X3, MF> {
 };
 
 // ------------------------------------------------------------------ the kernel
-template <typename TA, typename TW, int LOADER, int MF, int NF, int WM, int WN, int WK, int STAGES>
-__global__ __launch_bounds__(64 * WM * WN * WK) void gemm_kernel(const GemmArgs args) {
+// 16 bytes per lane, global -> LDS without passing through registers (global_load_lds_dwordx4): lane l's bytes land at
+// the wave-uniform `lds` + 16 l.
+__device__ __forceinline__ void glds16(const char* gsrc, char* lds) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+#else
+  (void)gsrc; (void)lds;
+#endif
+}
+
+// LDSK = true selects the LDS-staged K loop (bf16 fragment-order A and W, 2 stages, one barrier per k-block): both
+// operand tiles arrive once per workgroup by global_load_lds and every wave reads its fragments from LDS.  For tiles wide
+// enough that the per-wave register ring cannot hold the operands (128 x 128), i.e. the many-row GEMMs of the
+// whole-sequence encoder.  The epilogues are shared.
+// The hot 32x32 bf16 tile sits at the edge of 3 waves per SIMD (512 / 3 = 170 registers); small edits used to tip it
+// over to 2, which costs 10-25 % on the wide-N launches (tools/bench_block.py), so its register budget is pinned.
+template <typename TA, int LOADER, int MF, int NF, int WK>
+constexpr int gemm_min_waves() { return (sizeof(TA) == 2 && LOADER == SP3_LOAD_PLAIN && MF == 2 && NF == 2 && WK == 4) ? 3 : 1; }
+
+template <typename TA, typename TW, int LOADER, int MF, int NF, int WM, int WN, int WK, int STAGES, bool LDSK = false>
+__global__ __launch_bounds__(64 * WM * WN * WK, (gemm_min_waves<TA, LOADER, MF, NF, WK>())) void gemm_kernel(const GemmArgs args) {
   sp3_gemm_desc d = args.d;                  // local copy: grouped launches shift the per-problem pointers below
   using M_ = MM<TA, TW>;
   constexpr int BM = MF * 16 * WM, BN = NF * 16 * WN, NT = 64 * WM * WN * WK;
@@ -392,6 +412,63 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_kernel(const GemmArgs 
   using FullT = std::integral_constant<bool, true>;
   using TailT = std::integral_constant<bool, false>;
 
+  if constexpr (LDSK) {
+    // ---- LDS-staged K loop.  Stage = BM/16 A blocks + BN/16 W blocks of 2 KB (one fragment block = 64 lanes x 32 B, the
+    // same bytes in HBM and in LDS, so the DMA's "wave-uniform base + lane * 16" destination needs no address math).
+    static_assert(WK == 1 && std::is_same<TA, __bf16>::value && std::is_same<TW, __bf16>::value, "LDS-staged loop: bf16, WK = 1");
+    constexpr int NBLK = BM / 16 + BN / 16, STAGE_BYTES = NBLK * 2048, PER_WAVE = NBLK / (NT / 64);
+    static_assert(NBLK % (NT / 64) == 0, "blocks must divide over the waves");
+    char* lds_b = reinterpret_cast<char*>(smem);
+    const int nkb_pad = (d.K + KB - 1) / KB;
+    const int rb_max = (d.M + 15) / 16 - 1, nb_max = (d.N + 15) / 16 - 1;
+    const char* src[PER_WAVE];
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+      const int blk = wave * PER_WAVE + i;              // 0 .. NBLK-1: A row blocks first, then W column blocks
+      if (blk < BM / 16) {
+        int rb = (m0 >> 4) + blk;
+        rb = rb < rb_max ? rb : rb_max;                 // rows past M: re-read the last block (masked at the store)
+        src[i] = reinterpret_cast<const char*>(A + (int64_t)rb * nkb_pad * 1024) + lane * 16;
+      } else {
+        int nb = (n0 >> 4) + blk - BM / 16;
+        nb = nb < nb_max ? nb : nb_max;
+        src[i] = reinterpret_cast<const char*>(W + (int64_t)nb * nkb_pad * 1024) + lane * 16;
+      }
+    }
+    auto issue = [&](int stage, int kb) {
+#pragma unroll
+      for (int i = 0; i < PER_WAVE; ++i) {
+        const char* g0 = src[i] + (int64_t)kb * 2048;
+        char* l0 = lds_b + stage * STAGE_BYTES + (wave * PER_WAVE + i) * 2048;
+        glds16(g0, l0);
+        glds16(g0 + 1024, l0 + 1024);
+      }
+    };
+    issue(0, kb_lo);
+    for (int kb = kb_lo; kb < kb_hi; ++kb) {
+      const int stage = (kb - kb_lo) & 1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of stage `stage` has landed ...
+      __syncthreads();                                   // ... and so has everyone's; nobody still reads the other stage
+      if (kb + 1 < kb_hi) issue(stage ^ 1, kb + 1);
+      const char* st = lds_b + stage * STAGE_BYTES + lane * 32;
+      typename M_::AReg af[MF];
+      typename M_::WReg wf[NF];
+#pragma unroll
+      for (int m = 0; m < MF; ++m) {
+        const char* q = st + (wm * MF + m) * 2048;
+        af[m].v[0] = *reinterpret_cast<const bf16x8*>(q);
+        af[m].v[1] = *reinterpret_cast<const bf16x8*>(q + 16);
+      }
+#pragma unroll
+      for (int n = 0; n < NF; ++n) {
+        const char* q = st + (BM / 16 + wn * NF + n) * 2048;
+        wf[n].v[0] = *reinterpret_cast<const bf16x8*>(q);
+        wf[n].v[1] = *reinterpret_cast<const bf16x8*>(q + 16);
+      }
+      M_::template mma<MF, NF>(acc, af, wf);
+    }
+    __syncthreads();                                     // the stages are dead: the epilogue slab re-uses their bytes
+  } else
   // STAGES-deep register ring: (STAGES-1) k-blocks of loads in flight per wave.
   // prologue (uniform branches), branch-free steady state over full k-blocks, masked drain.
   {
@@ -707,15 +784,19 @@ __global__ __launch_bounds__(64 * WM * WN * WK) void gemm_kernel(const GemmArgs 
   }
 }
 
-template <typename TA, typename TW, int LOADER, int MF, int NF, int WM, int WN, int WK, int STAGES>
+template <typename TA, typename TW, int LOADER, int MF, int NF, int WM, int WN, int WK, int STAGES, bool LDSK = false>
 int launch(const sp3_gemm_desc& d, hipStream_t stream) {
   constexpr int BM = MF * 16 * WM, BN = NF * 16 * WN, NT = 64 * WM * WN * WK;
   const int mt = (d.M + BM - 1) / BM, nt = (d.N + BN - 1) / BN;
   int blocks;
   if (mt >= nt) blocks = ((mt + 7) / 8) * 8 * nt;
   else blocks = ((nt + 7) / 8) * 8 * mt;
-  const size_t lds = ((size_t)WK * BM * (BN + 4) + 2 * BM) * sizeof(float);
-  auto kern = gemm_kernel<TA, TW, LOADER, MF, NF, WM, WN, WK, STAGES>;
+  size_t lds = ((size_t)WK * BM * (BN + 4) + 2 * BM) * sizeof(float);
+  if (LDSK) {
+    const size_t stages = (size_t)2 * (BM / 16 + BN / 16) * 2048;      // the epilogue slab aliases the two stages
+    lds = lds > stages ? lds : stages;
+  }
+  auto kern = gemm_kernel<TA, TW, LOADER, MF, NF, WM, WN, WK, STAGES, LDSK>;
   if (lds > 64 * 1024) {
     static bool raised = false;     // one-time opt-in to > 64 KiB of dynamic LDS for this instantiation
     if (!raised) {
@@ -738,6 +819,13 @@ int dispatch_tile(const sp3_gemm_desc& d, int tile, hipStream_t stream) {
     case 1: return launch<TA, TW, LOADER, 2, 2, 2, 2, 1, 2>(d, stream);   // 64x64, wave tile 32x32
     case 2: return launch<TA, TW, LOADER, 2, 4, 2, 2, 1, 2>(d, stream);   // 64x128, wave tile 32x64
     case 3: return launch<TA, TW, LOADER, 4, 4, 1, 1, 4, 3>(d, stream);   // 64x64, K over 4 waves
+    case 5:                                                                // 128x128, LDS-staged operands (2x2 waves of 64x64)
+      if constexpr (std::is_same<TA, __bf16>::value && std::is_same<TW, __bf16>::value && LOADER == SP3_LOAD_PLAIN) {
+        if (d.a_packed && d.w_packed && !d.A2 && d.splitk == 1 && d.K % 64 == 0)
+          return launch<TA, TW, LOADER, 4, 4, 2, 2, 1, 2, true>(d, stream);
+      }
+      sp3_set_error("sp3_gemm: tile 5 (128x128, LDS-staged) needs bf16 fragment-order A and W, K %% 64 == 0, no split");
+      return 1;
     default: sp3_set_error("sp3_gemm: bad tile %d", tile); return 1;
   }
 }
@@ -808,7 +896,10 @@ extern "C" int sp3_gemm(const sp3_gemm_desc* dp, void* stream_) {
     const long sk = d.splitk;
     const long t64 = (long)((d.M + 63) / 64) * ((d.N + 63) / 64) * d.batch * sk;
     const long t128 = (long)((d.M + 63) / 64) * ((d.N + 127) / 128) * d.batch;
-    if (d.loader != SP3_LOAD_CONV3X3 && d.M >= 1024 && sk == 1) {
+    if (d.loader != SP3_LOAD_CONV3X3 && d.M >= 1024 && sk == 1 && d.a_packed && d.w_packed && d.a_bf16 && !d.A2 &&
+        d.epi != SP3_EPI_PARTIAL && d.N >= 3072 && d.N % 128 == 0 && d.K % 64 == 0 && d.batch == 1) {
+      tile = 5;                                            // 128x128, LDS-staged operands
+    } else if (d.loader != SP3_LOAD_CONV3X3 && d.M >= 1024 && sk == 1) {
       tile = (d.K >= 2048 && d.N % 128 == 0) ? 2 : 1;     // many rows: 64-row tiles (tools/bench_gemm.py --M 1960)
     } else if (d.loader == SP3_LOAD_CONV3X3 || d.M > 2048) {
       if (t128 >= 1024 && d.N % 128 == 0) tile = 2;

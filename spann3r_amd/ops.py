@@ -96,13 +96,15 @@ def set_profiler(p):
     _prof = p
 
 
-_TILE_NAMES = {0: "32x32xk4", 1: "64x64", 2: "64x128", 3: "64x64xk4"}
+_TILE_NAMES = {0: "32x32xk4", 1: "64x64", 2: "64x128", 3: "64x64xk4", 5: "128x128lds"}
 
 
-def pick_tile(M, N, batch=1, splitk=1, conv=False, K=0):
+def pick_tile(M, N, batch=1, splitk=1, conv=False, K=0, packed_bf16=False):
     """Mirror of the auto heuristic in csrc/gemm.hip (kept in sync so profiles can be keyed by instantiation)."""
     t64 = ((M + 63) // 64) * ((N + 63) // 64) * batch * splitk
     t128 = ((M + 63) // 64) * ((N + 127) // 128) * batch
+    if not conv and M >= 1024 and splitk == 1 and packed_bf16 and N >= 3072 and N % 128 == 0 and K % 64 == 0 and batch == 1:
+        return 5        # 128x128, operands staged through LDS: 335-430 TFLOP/s vs 300-340 for the 64-row register tiles
     if not conv and M >= 1024 and splitk == 1:
         # many rows (a whole sequence of frames through the encoder): 64-row tiles; tools/bench_gemm.py --M 1960
         return 2 if (K >= 2048 and N % 128 == 0) else 1
@@ -117,7 +119,8 @@ def pick_tile(M, N, batch=1, splitk=1, conv=False, K=0):
 
 def _gemm_launch(d, what, loader_name):
     if d.tile < 0:
-        d.tile = pick_tile(d.M, d.N, max(d.batch, 1), max(d.splitk, 1), d.loader == L.LOAD_CONV3X3, d.K)
+        d.tile = pick_tile(d.M, d.N, max(d.batch, 1), max(d.splitk, 1), d.loader == L.LOAD_CONV3X3, d.K,
+                           bool(d.a_packed and d.w_packed and d.a_bf16 and not d.A2 and d.epi != L.EPI_PARTIAL))
     if _prof is None:
         L.check(L.load().sp3_gemm(C.byref(d), L.stream_ptr()), what)
         return

@@ -57,6 +57,50 @@ def test_gemm_plain(wdt, M, N, K, tile, packed):
     assert rel_err(out.cpu(), ref) < TOL[wdt], (M, N, K, tile)
 
 
+@pytest.mark.parametrize("M,N,K", [(1960, 3072, 1024), (300, 256, 192), (129, 384, 64), (1100, 1024, 4096)])
+def test_gemm_lds_staged_tile(M, N, K):
+    """tile 5: 128x128, both operands staged through LDS by global_load_lds (bf16 fragment-order A and W); ragged M / N
+    tiles, K down to one k-block; epilogues: bias + GELU -> packed bf16, residual + row statistics + packed copy, folded
+    LayerNorm."""
+    ops = _ops()
+    A, W, b, r1 = rnd(M, K, seed=1), rnd(N, K, seed=2) * 0.05, rnd(N, seed=3), rnd(M, N, seed=4)
+    A[:, 0] += torch.arange(M) * 0.01
+    W[:, 1] += torch.arange(N) * 0.02
+    Ap = ops.PackedAct.from_dense(A.to(DEV).to(torch.bfloat16))
+    Wp = ops.PackedWeight(W.to(DEV).to(torch.bfloat16))
+    ref = bf(A).double() @ bf(W).double().T
+    out = torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm(Ap, Wp, out, M=M, N=N, K=K, lda=K, ldc=N, tile=5)
+    assert rel_err(out.cpu(), ref) < TOL[torch.bfloat16]
+    # the same launch must agree with the register-ring tiles to fp32 summation order
+    out1 = torch.empty(M, N, device=DEV)
+    ops.gemm(Ap, Wp, out1, M=M, N=N, K=K, lda=K, ldc=N, tile=1)
+    assert rel_err(out.cpu(), out1.cpu()) < 1e-5
+    if N % 32 == 0:
+        # producer epilogue: bias + residual, row statistics, packed copy
+        st = torch.zeros(M, N // 32, 2, device=DEV)
+        c2 = ops.PackedAct(M, N, torch.bfloat16, DEV)
+        x = torch.empty(M, N, device=DEV)
+        ops.gemm(Ap, Wp, x, M=M, N=N, K=K, lda=K, ldc=N, bias=b.to(DEV), res1=r1.to(DEV), ldr1=N, stats_out=st, c2=c2, tile=5)
+        xr = ref + b.double() + r1.double()
+        assert rel_err(x.cpu(), xr) < TOL[torch.bfloat16]
+        assert rel_err(st[..., 0].sum(1).cpu(), x.cpu().double().sum(1)) < 1e-5
+        assert torch.equal(c2.to_dense(), x.to(torch.bfloat16))
+        # consumer epilogue: LayerNorm of x folded into the next GEMM + GELU -> packed bf16
+        g, beta = rnd(N, seed=5) + 1, rnd(N, seed=6)
+        W2 = rnd(256, N, seed=7) * 0.05
+        Wf = (W2 * g[None]).to(torch.bfloat16)
+        s_n = Wf.float().sum(1).to(DEV)
+        b2 = (rnd(256, seed=8) + W2 @ beta).to(DEV)
+        h = ops.PackedAct(M, 256, torch.bfloat16, DEV)
+        ops.gemm(c2, ops.PackedWeight(Wf.to(DEV)), h, M=M, N=256, K=N, lda=N, ldc=256, bias=b2, act=ops.ACT_GELU,
+                 ln=ops.LnFold(st, N, s_n, 1e-6), tile=5)
+        xf = x.cpu().double()
+        mu, var = xf.mean(1, keepdim=True), xf.var(1, unbiased=False, keepdim=True)
+        y = ((bf(x.cpu()).double() @ Wf.double().T) - mu * Wf.double().sum(1)[None]) / torch.sqrt(var + 1e-6) + b2.cpu().double()
+        assert rel_err(h.to_dense().float().cpu(), F.gelu(y)) < 8e-3
+
+
 @pytest.mark.parametrize("wdt", [torch.float32, torch.bfloat16])
 def test_gemm_epilogue_bias_gelu_residuals(wdt):
     ops = _ops()
