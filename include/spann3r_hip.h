@@ -89,7 +89,8 @@ typedef struct sp3_gemm_desc {
   int64_t vt_ld;
   int32_t ps_k, ps_H, ps_W, ps_C;
   int32_t tile;           /* -1 auto; 0: 32x32 (K over 4 waves); 1: 64x64; 2: 64x128; 3: 64x64 (K over 4 waves);
-                             5: 128x128 with both operands staged through LDS (bf16 fragment-order A and W, K % 64 == 0) */
+                             5 / 6: 128x128 / 128x64 with both operands staged through LDS (bf16 fragment-order A and W,
+                             K % 64 == 0) */
   int32_t a_bf16;
   int32_t splitk;         /* >= 1; > 1 only with SP3_EPI_PARTIAL */
   int32_t a_packed;       /* A is in MFMA-fragment order [ceil(M/16)][ceil(K/KB)][64 lanes][CH] (see w_packed); written

@@ -826,6 +826,13 @@ int dispatch_tile(const sp3_gemm_desc& d, int tile, hipStream_t stream) {
       }
       sp3_set_error("sp3_gemm: tile 5 (128x128, LDS-staged) needs bf16 fragment-order A and W, K %% 64 == 0, no split");
       return 1;
+    case 6:                                                                // 128x64, LDS-staged operands (2x2 waves of 64x32)
+      if constexpr (std::is_same<TA, __bf16>::value && std::is_same<TW, __bf16>::value && LOADER == SP3_LOAD_PLAIN) {
+        if (d.a_packed && d.w_packed && !d.A2 && d.splitk == 1 && d.K % 64 == 0)
+          return launch<TA, TW, LOADER, 4, 2, 2, 2, 1, 2, true>(d, stream);
+      }
+      sp3_set_error("sp3_gemm: tile 6 (128x64, LDS-staged) needs bf16 fragment-order A and W, K %% 64 == 0, no split");
+      return 1;
     default: sp3_set_error("sp3_gemm: bad tile %d", tile); return 1;
   }
 }
@@ -898,7 +905,8 @@ extern "C" int sp3_gemm(const sp3_gemm_desc* dp, void* stream_) {
     const long t128 = (long)((d.M + 63) / 64) * ((d.N + 127) / 128) * d.batch;
     if (d.loader != SP3_LOAD_CONV3X3 && d.M >= 1024 && sk == 1 && d.a_packed && d.w_packed && d.a_bf16 && !d.A2 &&
         d.epi != SP3_EPI_PARTIAL && d.N >= 3072 && d.N % 128 == 0 && d.K % 64 == 0 && d.batch == 1) {
-      tile = 5;                                            // 128x128, LDS-staged operands
+      // LDS-staged operands: 128x128 for large grids / N multiple of 4096, else 128x64 (tools/bench_gemm.py --M 1960)
+      tile = (d.N % 4096 == 0 || (long)((d.M + 127) / 128) * (d.N / 128) >= 1024) ? 5 : 6;
     } else if (d.loader != SP3_LOAD_CONV3X3 && d.M >= 1024 && sk == 1) {
       tile = (d.K >= 2048 && d.N % 128 == 0) ? 2 : 1;     // many rows: 64-row tiles (tools/bench_gemm.py --M 1960)
     } else if (d.loader == SP3_LOAD_CONV3X3 || d.M > 2048) {

@@ -96,7 +96,7 @@ def set_profiler(p):
     _prof = p
 
 
-_TILE_NAMES = {0: "32x32xk4", 1: "64x64", 2: "64x128", 3: "64x64xk4", 5: "128x128lds"}
+_TILE_NAMES = {0: "32x32xk4", 1: "64x64", 2: "64x128", 3: "64x64xk4", 5: "128x128lds", 6: "128x64lds"}
 
 
 def pick_tile(M, N, batch=1, splitk=1, conv=False, K=0, packed_bf16=False):
@@ -104,7 +104,10 @@ def pick_tile(M, N, batch=1, splitk=1, conv=False, K=0, packed_bf16=False):
     t64 = ((M + 63) // 64) * ((N + 63) // 64) * batch * splitk
     t128 = ((M + 63) // 64) * ((N + 127) // 128) * batch
     if not conv and M >= 1024 and splitk == 1 and packed_bf16 and N >= 3072 and N % 128 == 0 and K % 64 == 0 and batch == 1:
-        return 5        # 128x128, operands staged through LDS: 335-430 TFLOP/s vs 300-340 for the 64-row register tiles
+        # operands staged through LDS (tools/bench_gemm.py --M 1960 --packed 2): 128x128 when the grid is large or N is a
+        # multiple of 4096 (438 TFLOP/s at N=4096), else 128x64 (438 TFLOP/s at N=3072, where 128x128 quantises badly)
+        wg5 = ((M + 127) // 128) * (N // 128)
+        return 5 if (N % 4096 == 0 or wg5 >= 1024) else 6
     if not conv and M >= 1024 and splitk == 1:
         # many rows (a whole sequence of frames through the encoder): 64-row tiles; tools/bench_gemm.py --M 1960
         return 2 if (K >= 2048 and N % 128 == 0) else 1

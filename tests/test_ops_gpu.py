@@ -70,6 +70,9 @@ def test_gemm_lds_staged_tile(M, N, K):
     Wp = ops.PackedWeight(W.to(DEV).to(torch.bfloat16))
     ref = bf(A).double() @ bf(W).double().T
     out = torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm(Ap, Wp, out, M=M, N=N, K=K, lda=K, ldc=N, tile=6)          # the 128x64 variant of the same loop
+    assert rel_err(out.cpu(), ref) < TOL[torch.bfloat16]
+    out.fill_(float("nan"))
     ops.gemm(Ap, Wp, out, M=M, N=N, K=K, lda=K, ldc=N, tile=5)
     assert rel_err(out.cpu(), ref) < TOL[torch.bfloat16]
     # the same launch must agree with the register-ring tiles to fp32 summation order

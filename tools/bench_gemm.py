@@ -41,7 +41,7 @@ for M, N, K, sks in shapes:
         A = ops.PackedAct.from_dense(A)
     bias = torch.randn(N, device=dev)
     for sk in sks:
-        for tile in ((0, 3, 1, 2, 5) if (args.packed == 2 and args.adt == 'bf16' and K % 64 == 0) else (0, 3, 1, 2)):
+        for tile in ((0, 3, 1, 2, 5, 6) if (args.packed == 2 and args.adt == 'bf16' and K % 64 == 0) else (0, 3, 1, 2)):
             if sk == 0:
                 out = torch.empty(M, N, device=dev, dtype=DT[args.adt])
                 fn = lambda: ops.gemm(A, W, out, M=M, N=N, K=K, lda=K, ldc=N, bias=bias, act=ops.ACT_GELU, tile=tile)
