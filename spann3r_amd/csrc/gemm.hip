@@ -256,8 +256,13 @@ __device__ __forceinline__ void glds16(const char* gsrc, char* lds) {
 #endif
 }
 
+// Stages of the LDS-staged loop.  Measured (tools/bench_gemm.py --M 1960, 128x64 tile, N = 3072): 2 stages (48 KB, three
+// workgroups per CU) 28 us, 3 stages (72 KB, two per CU) 39 us -- residency beats prefetch depth here, so 2 everywhere.
+template <int BM, int BN> struct LDSK_STAGES { static constexpr int value = 2; };
+
 // LDSK = true selects the LDS-staged K loop (bf16 fragment-order A and W, 2 stages, one barrier per k-block): both
-// operand tiles arrive once per workgroup by global_load_lds and every wave reads its fragments from LDS.  For tiles wide
+// operand tiles arrive once per workgroup by global_load_lds (2 or 3 stages, one barrier per k-block) and every wave reads
+// its fragments from LDS.  For tiles wide
 // enough that the per-wave register ring cannot hold the operands (128 x 128), i.e. the many-row GEMMs of the
 // whole-sequence encoder.  The epilogues are shared.
 // The hot 32x32 bf16 tile sits at the edge of 3 waves per SIMD (512 / 3 = 170 registers); small edits used to tip it
@@ -444,12 +449,20 @@ __global__ __launch_bounds__(64 * WM * WN * WK, (gemm_min_waves<TA, LOADER, MF, 
         glds16(g0 + 1024, l0 + 1024);
       }
     };
-    issue(0, kb_lo);
+    // NST stages: k-blocks kb .. kb+NST-2 are in flight while kb is multiplied.  Waits are counted by hand (hipcc cannot see what a DMA wrote): this wave's loads
+    // retire in order, so "all but the newest stage's 2*PER_WAVE loads" means stage kb has landed; the barrier then makes
+    // every wave's share visible and proves nobody still reads the stage that is refilled next.
+    constexpr int NST = LDSK_STAGES<BM, BN>::value, LOADS = 2 * PER_WAVE;
+#pragma unroll
+    for (int s_ = 0; s_ < NST - 1; ++s_)
+      if (kb_lo + s_ < kb_hi) issue(s_, kb_lo + s_);
     for (int kb = kb_lo; kb < kb_hi; ++kb) {
-      const int stage = (kb - kb_lo) & 1;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of stage `stage` has landed ...
-      __syncthreads();                                   // ... and so has everyone's; nobody still reads the other stage
-      if (kb + 1 < kb_hi) issue(stage ^ 1, kb + 1);
+      const int i = kb - kb_lo;
+      const int stage = i % NST;
+      if (NST == 3 && kb + 1 < kb_hi) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (kb + NST - 1 < kb_hi) issue((i + NST - 1) % NST, kb + NST - 1);
       const char* st = lds_b + stage * STAGE_BYTES + lane * 32;
       typename M_::AReg af[MF];
       typename M_::WReg wf[NF];
@@ -793,7 +806,7 @@ int launch(const sp3_gemm_desc& d, hipStream_t stream) {
   else blocks = ((nt + 7) / 8) * 8 * mt;
   size_t lds = ((size_t)WK * BM * (BN + 4) + 2 * BM) * sizeof(float);
   if (LDSK) {
-    const size_t stages = (size_t)2 * (BM / 16 + BN / 16) * 2048;      // the epilogue slab aliases the two stages
+    const size_t stages = (size_t)LDSK_STAGES<BM, BN>::value * (BM / 16 + BN / 16) * 2048;      // the epilogue slab aliases the stages
     lds = lds > stages ? lds : stages;
   }
   auto kern = gemm_kernel<TA, TW, LOADER, MF, NF, WM, WN, WK, STAGES, LDSK>;
