@@ -293,3 +293,24 @@ def test_full512_growing_bank(full_sd):
     for o in outs[1:]:
         for a, b in zip(outs[0][0], o[0]):
             assert all(torch.equal(a[k], b[k]) for k in a)
+
+
+def test_encoder_whole_sequence_bf16_lds_tiles(full_sd):
+    """bf16, 10 frames of 224x224 through the encoder at once (M = 1960 rows: the qkv / fc1 GEMMs run on the LDS-staged
+    128-row tiles, incl. the RoPE + V-store epilogue and the folded LayerNorm) against the same frames encoded one by
+    one (32x32 register tiles): same bf16 operands, different fp32 summation order only."""
+    from spann3r_amd import Spann3R, FULL, ops
+    from spann3r_amd.weights import synth_frames
+    m = Spann3R(dus3r_name=None, cfg=FULL, init_weights=False)
+    m.load_state_dict(full_sd, strict=True)
+    m = m.to(DEV).eval().set_precision("bf16")
+    eng = m.engine
+    imgs = torch.cat([f["img"] for f in synth_frames(10, 224, 224, seed=21)]).to(DEV)
+    assert ops.pick_tile(10 * 196, 3072, K=1024, packed_bf16=True) in (5, 6) and ops.pick_tile(10 * 196, 4096, K=1024, packed_bf16=True) == 5
+    together, _ = eng.encode_image(imgs, tag="_t")
+    together = together.clone()
+    for i in range(10):
+        one, _ = eng.encode_image(imgs[i:i + 1], tag="_o")
+        err = rel_err(together[i].cpu(), one[0].cpu())
+        assert err < 2e-2, (i, err)
+    print("whole-sequence encoder vs per-frame (bf16): last rel err %.2e" % err)

@@ -5,7 +5,8 @@ from spann3r_amd.weights import synth_state_dict, synth_frames
 cfg = FULL if len(sys.argv) > 1 and sys.argv[1] == "full" else TINY
 m = Spann3R(dus3r_name=None, cfg=cfg, init_weights=False); m.load_state_dict(synth_state_dict(0, cfg)); m = m.cuda().eval()
 S = 224 if cfg is FULL else 64
-frames = [{"img": f["img"].cuda()} for f in synth_frames(5, S, S)]
+NF = int(sys.argv[3]) if len(sys.argv) > 3 else 5      # >= 6 frames at 224: the encoder's LDS-staged tiles (M >= 1024)
+frames = [{"img": f["img"].cuda()} for f in synth_frames(NF, S, S)]
 for prec in ("fp32", "bf16"):
     m.set_precision(prec)
     for graphs in (False, True):
