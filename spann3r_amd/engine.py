@@ -39,8 +39,9 @@ class Engine:
         self.packed_attn = precision == "bf16"      # fragment-order q/k/v + wave-split attention kernel
         self._ws = {}
         self._pos_cache = {}
-        self.max_pos = 0
-        self.cos = self.sin = None
+        # RoPE tables for every grid the build supports, allocated ONCE: captured graphs hold their addresses
+        self.max_pos = 256
+        self.cos, self.sin = _rope_tables(self.max_pos, cfg.rope_base, self.device)
         self.w = {}
         self._pack(params)
 
@@ -168,10 +169,8 @@ class Engine:
         if key not in self._pos_cache:
             ys, xs = torch.meshgrid(torch.arange(nh), torch.arange(nw), indexing="ij")
             pos = torch.stack((ys.reshape(-1), xs.reshape(-1)), -1)[None].expand(B, -1, -1).contiguous()
-            need = max(nh, nw)
-            if need > self.max_pos:
-                self.max_pos = max(need, 64)
-                self.cos, self.sin = _rope_tables(self.max_pos, self.cfg.rope_base, self.device)
+            if max(nh, nw) > self.max_pos:
+                raise ValueError("token grid %dx%d exceeds the %d positions of the RoPE tables" % (nh, nw, self.max_pos))
             self._pos_cache[key] = (pos.to(self.device), pos.reshape(-1, 2).to(torch.int32).to(self.device).contiguous(),
                                     torch.zeros(B * nh * nw, 2, dtype=torch.int32, device=self.device))
         return self._pos_cache[key]

@@ -298,11 +298,16 @@ class _SequenceRunner:
     read the similarity score (the reference's own host sync, spann3r/model.py:114) and to clone the outputs.
     """
 
-    def __init__(self, model, eng, B, H, W, training):
+    def __init__(self, model, eng, B, H, W, training, true_hw=None):
         cfg = model.cfg
         self.model, self.eng, self.B, self.H, self.W, self.training = model, eng, B, H, W, training
         p = cfg.patch
-        self.nh, self.nw = H // p, W // p
+        self.nh, self.nw = H // p, W // p                 # token raster of the image (PatchEmbedDust3R ignores true_shape)
+        # The heads see the tokens as a (true_h/p, true_w/p) grid and portrait results come back axis-swapped
+        # (transpose_to_landscape wrapper, dust3r/utils/misc.py:54-96 with landscape_only=True, spann3r/model.py:222).
+        th, tw = true_hw or (H, W)
+        self.hh, self.hw = th // p, tw // p
+        self.swap = th > tw
         self.P, self.E = self.nh * self.nw, cfg.enc_dim
         dev = eng.device
         self.img_pair = torch.empty(2 * B, 3, H, W, device=dev)
@@ -346,8 +351,9 @@ class _SequenceRunner:
         if self.feats is None or self.feats.shape[0] < n * B:
             self.img_all = torch.empty(n * B, 3, self.H, self.W, device=self.eng.device)
             self.feats = torch.empty(n * B, self.P, self.E, device=self.eng.device)
-            self.graphs = {k: g for k, g in self.graphs.items() if k[0] != "enc"}
-            self.seen = {k for k in self.seen if k[0] != "enc"}
+            # every graph that baked in the old buffers dies with them: the encoder's AND the deferred head's (reads feats)
+            self.graphs = {k: g for k, g in self.graphs.items() if k[0] not in ("enc", "head2")}
+            self.seen = {k for k in self.seen if k[0] not in ("enc", "head2")}
         for i, f in enumerate(frames):
             self.img_all[i * B:(i + 1) * B].copy_(f["img"])
         per = max(1, self.ENC_CHUNK_ROWS // B)
@@ -393,7 +399,7 @@ class _SequenceRunner:
             key = ("head2", c0, c1)
 
             def fn(dec=dec, key=key, nb=(c1 - c0) * B):
-                pts, conf, _ = self.eng.dpt_head(dec, nb, self.nh, self.nw, 2)
+                pts, conf, _ = self.eng.dpt_head(dec, nb, self.hh, self.hw, 2)
                 self.head2_out[key] = (pts, conf)
             self._graphed(key, fn, use_graphs)
             pts, conf = self.head2_out[key]
@@ -475,10 +481,10 @@ class _SequenceRunner:
         if not self.defer2:
             st[2].wait_stream(main)
             with torch.cuda.stream(st[2]):
-                pts2, conf2, _ = eng.dpt_head(dec2, B, self.nh, self.nw, 2)
-        pts1, conf1, _ = eng.dpt_head(dec1, B, self.nh, self.nw, 1)
+                pts2, conf2, _ = eng.dpt_head(dec2, B, self.hh, self.hw, 2)
+        pts1, conf1, _ = eng.dpt_head(dec1, B, self.hh, self.hw, 1)
         # portrait results are handed on axis-swapped (landscape_only wrapper); the value encoder sees that view
-        eng.encode_cur_value(pts1.swapaxes(1, 2) if self.H > self.W else pts1, self.v, self.k1)   # v = cur_v + feat_k1
+        eng.encode_cur_value(pts1.swapaxes(1, 2) if self.swap else pts1, self.v, self.k1)   # v = cur_v + feat_k1
         mem.stage_write(self.k1, self.v)
         if not self.defer2:
             main.wait_stream(st[2])
@@ -501,7 +507,7 @@ class _SequenceRunner:
         pts1, conf1, pts2, conf2 = self.out
         res1 = {"pts3d": pts1.clone(), "conf": conf1.clone()}
         res2 = {} if pts2 is None else {"pts3d": pts2.clone(), "conf": conf2.clone()}      # {}: filled by finish_head2
-        if self.H > self.W:                                     # landscape_only wrapper (dust3r/utils/misc.py:79-80)
+        if self.swap:                                           # landscape_only wrapper (dust3r/utils/misc.py:79-80)
             res1 = {k: v.swapaxes(1, 2) for k, v in res1.items()}
             res2 = {k: v.swapaxes(1, 2) for k, v in res2.items()}
         # memory policy (:518-521): the frame was staged inside the step; commit or drop it here
@@ -529,7 +535,11 @@ class Spann3R(nn.Module):
         # spann3r/model.py:248: only its .training flag and p matter for the forward-only build
         self.mem_dropout = nn.Dropout(memory_dropout)
         ckpt = None
-        if dus3r_name is not None and os.path.isfile(dus3r_name):
+        if dus3r_name is not None and not os.path.isfile(dus3r_name):
+            # the reference fails here too (load_model / hub download, dust3r/model.py:83-90); dus3r_name=None is the
+            # explicit "no checkpoint" switch (seeded synthetic weights if init_weights, else uninitialised for load_state_dict)
+            raise FileNotFoundError("DUSt3R checkpoint %r not found (pass dus3r_name=None to build without one)" % dus3r_name)
+        if dus3r_name is not None:
             # dust3r/model.py:27-51: the checkpoint carries its own constructor string
             torch.serialization.add_safe_globals([argparse.Namespace])
             ckpt = torch.load(dus3r_name, map_location="cpu", weights_only=True)
@@ -549,6 +559,10 @@ class Spann3R(nn.Module):
                     if k.startswith("dust3r.dec_blocks."):
                         sd[k.replace("dust3r.dec_blocks.", "dust3r.dec_blocks2.")] = v
             own = self.state_dict()
+            # dust3r/model.py:47-49 prints the strict=False result; same report here
+            missing = [k for k in own if k.startswith("dust3r.") and k not in sd and alias_of(k) is None]
+            unexpected = [k for k in sd if k not in own]
+            print("<checkpoint %s: missing keys %s, unexpected keys %s>" % (dus3r_name, missing, unexpected))
             with torch.no_grad():
                 for k, v in sd.items():
                     if k in own:
@@ -565,6 +579,8 @@ class Spann3R(nn.Module):
         self.batch_encode = True     # forward(): encode all frames of the sequence together (False: frame by frame)
         self.defer_head2 = True      # with batch_encode: run the view-2 DPT head once for all steps after the loop
         self.grouped_decoder = True  # bf16: the two decoder sides as grouped launches on one stream (False: two streams)
+        self.force_general = False   # True: always take the reference-shaped eager loop (_forward_general; tests)
+        self.max_runners = 4         # geometries (batch, H, W, policy, true_shape) kept with their buffers and graphs
 
     # ------------------------------------------------------------------ engine management
     def set_precision(self, precision):
@@ -590,23 +606,39 @@ class Spann3R(nn.Module):
             self._runners = {}
         return self._engine
 
+    def _runner(self, key, make):
+        """LRU over geometries: a runner owns the static buffers, the memory arena and the hipGraphs of one geometry."""
+        run = self._runners.pop(key, None)
+        if run is None:
+            run = make()
+            while len(self._runners) >= self.max_runners:
+                self._runners.pop(next(iter(self._runners)))
+        self._runners[key] = run
+        return run
+
     # ------------------------------------------------------------------ reference-shaped stage methods
     @staticmethod
     def _true_shape(view):
         img = view["img"]
         return view.get("true_shape", torch.tensor(img.shape[-2:])[None].repeat(img.shape[0], 1))
 
+    def _tag_grid(self, pos, img):
+        """remember the token raster a position tensor was built for (saves decode() a device read of pos.max())"""
+        pos._sp3_grid = (img.shape[-2] // self.cfg.patch, img.shape[-1] // self.cfg.patch)
+        return pos
+
     def encode_image(self, view):                                           # spann3r/model.py:263-270
         img = view["img"]
         feat, pos = self.engine.encode_image(img.float())
-        return feat, pos, self._true_shape(view)
+        return feat, self._tag_grid(pos[:], img), self._true_shape(view)
 
     def encode_image_pairs(self, view1, view2):                             # :272-287
         img = torch.cat((view1["img"], view2["img"]), dim=0).float()
         feat, pos = self.engine.encode_image(img)
         f1, f2 = feat.chunk(2, dim=0)
         p1, p2 = pos.chunk(2, dim=0)
-        return f1.contiguous(), f2.contiguous(), p1, p2, self._true_shape(view1), self._true_shape(view2)
+        return (f1.contiguous(), f2.contiguous(), self._tag_grid(p1, img), self._tag_grid(p2, img),
+                self._true_shape(view1), self._true_shape(view2))
 
     def encode_frames(self, view1, view2, feat1, feat2, pos1, pos2, shape1, shape2):   # :289-297
         if feat1 is None:
@@ -615,20 +647,17 @@ class Spann3R(nn.Module):
         feat2, pos2, shape2 = self.encode_image(view2)
         return feat1, feat2, pos1, pos2, shape1, shape2
 
-    @staticmethod
-    def _grid(shape, patch):
-        """token grid (nh, nw) the encoder produced for images of `true_shape` (PatchEmbedDust3R keeps raster order)."""
-        h, w = int(shape[0, 0]), int(shape[0, 1])
-        return h // patch, w // patch
-
-    def decode(self, feat1, pos1, feat2, pos2, shape1=None, shape2=None):   # :322-325
-        B, P1 = feat1.shape[:2]
-        g1 = self._grid(shape1, self.cfg.patch) if shape1 is not None else self._grid_from_pos(pos1)
-        g2 = self._grid(shape2, self.cfg.patch) if shape2 is not None else self._grid_from_pos(pos2)
+    def decode(self, feat1, pos1, feat2, pos2):                             # :322-325
+        """RoPE positions are the token raster of the IMAGE (pos comes from the patch embed, which ignores true_shape)."""
+        B = feat1.shape[0]
+        g1, g2 = self._grid_from_pos(pos1), self._grid_from_pos(pos2)
         return self.engine.decoder(feat1, feat2, B, g1[0], g1[1], g2[0], g2[1])
 
     @staticmethod
     def _grid_from_pos(pos):
+        g = getattr(pos, "_sp3_grid", None)
+        if g is not None:
+            return g
         return int(pos[0, :, 0].max()) + 1, int(pos[0, :, 1].max()) + 1
 
     def encode_feat_key(self, feat1, feat2, num=1):                         # :299-303
@@ -672,28 +701,50 @@ class Spann3R(nn.Module):
         finally:
             self._pinned = None
 
+    def _uniform_true_hw(self, frames):
+        """(true_h, true_w) if every frame carries the same image shape and the same true_shape for the whole batch
+        (absent = the image shape, spann3r/model.py:266), else None.  Every reference caller supplies `true_shape`
+        (dust3r/datasets/base/base_stereo_view_dataset.py:89, demo.py:109, eval.py:101), normally as a CPU int32
+        tensor equal to the image shape, or its transpose for portrait images the dataset rotated to landscape (:215-220)."""
+        img0 = frames[0]["img"]
+        H, W = int(img0.shape[-2]), int(img0.shape[-1])
+        p = self.cfg.patch
+        if H % p or W % p or any(tuple(f["img"].shape) != tuple(img0.shape) for f in frames):
+            return None
+        ts = [f["true_shape"] for f in frames if f.get("true_shape") is not None]
+        if not ts:
+            return H, W
+        try:
+            t = torch.stack([torch.as_tensor(x).reshape(-1, 2) for x in ts])            # [n, B, 2]
+        except RuntimeError:
+            return None
+        if t.is_cuda:
+            t = t.cpu()                                      # one host read per forward; the callers keep it on the CPU
+        th, tw = int(t[0, 0, 0]), int(t[0, 0, 1])
+        if not bool((t == t[0, 0]).all()) or t.shape[1] not in (1, img0.shape[0]):
+            return None
+        if len(ts) != len(frames) and (th, tw) != (H, W):
+            return None                                      # frames without the key default to the image shape
+        if (th, tw) not in ((H, W), (W, H)):
+            return None
+        return th, tw
+
     def _forward(self, eng, frames, return_memory):
         n = len(frames)
         if n < 2:
             raise ValueError("need at least two frames")
-        img0 = frames[0]["img"]
-        B = img0.shape[0]
-        p = self.cfg.patch
-        P = (img0.shape[-2] // p) * (img0.shape[-1] // p)
-        uniform = all(tuple(f["img"].shape) == tuple(img0.shape) and "true_shape" not in f for f in frames)
-        if uniform and img0.shape[-2] % p == 0 and img0.shape[-1] % p == 0:
-            return self._forward_static(eng, frames, return_memory)
+        hw = None if self.force_general else self._uniform_true_hw(frames)
+        if hw is not None:
+            return self._forward_static(eng, frames, return_memory, hw)
         return self._forward_general(eng, frames, return_memory)
 
-    def _forward_static(self, eng, frames, return_memory):
-        """Same-shape sequences (every caller of the reference: demo/eval/app/training batches): static buffers,
-        one hipGraph per step."""
+    def _forward_static(self, eng, frames, return_memory, true_hw):
+        """Same-shape sequences with one true_shape (what demo / eval / app / training batches are): static buffers,
+        whole-sequence encoder, two hipGraphs per step."""
         img0 = frames[0]["img"]
         B, _, H, W = img0.shape
-        key = (B, H, W, bool(self.training))
-        run = self._runners.get(key)
-        if run is None:
-            run = self._runners[key] = _SequenceRunner(self, eng, B, H, W, bool(self.training))
+        key = (B, H, W, bool(self.training), true_hw)
+        run = self._runner(key, lambda: _SequenceRunner(self, eng, B, H, W, bool(self.training), true_hw))
         mem = run.ensure_memory(len(frames))
         preds, preds_all = None, []
         n = len(frames)
@@ -728,7 +779,7 @@ class Spann3R(nn.Module):
             preds_all.append((res1, res2))
         if run.defer2:
             for (_, r2), (pts2, conf2) in zip(preds_all, run.finish_head2(n, self.use_graphs)):
-                if H > W:                                       # landscape_only wrapper, as in _SequenceRunner.run
+                if run.swap:                                    # landscape_only wrapper, as in _SequenceRunner.run
                     pts2, conf2 = pts2.swapaxes(1, 2), conf2.swapaxes(1, 2)
                 r2["pts3d_in_other_view"], r2["conf"] = pts2, conf2
         preds.append(res2)
@@ -758,7 +809,7 @@ class Spann3R(nn.Module):
                 feat_fuse = sp_mem.memory_read(feat_k2, torch.empty_like(feat1))
             else:
                 feat_fuse = feat1
-            dec1, dec2 = self.decode(feat_fuse, pos1, feat2, pos2, shape1, shape2)
+            dec1, dec2 = self.decode(feat_fuse, pos1, feat2, pos2)
             feat_k1 = self.encode_feat_key(feat1, dec1[-1], 1)
             feat_k2 = self.encode_feat_key(feat2, dec2[-1], 2)
             res1 = self.downstream_head(dec1, shape1, 1)

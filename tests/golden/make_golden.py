@@ -10,6 +10,11 @@ What is dumped (SURVEY.md §8c "recommended dumps"):
   spann3r_full224.npz 24/12 model, 5 frames of 224x224 (BASELINE config 1), outputs subsampled
   memory_bank.npz     reference SpatialMemory driven stand-alone for 32 frames of P=196:
                       similarity skip, working->long-term hand-over and one prune (5096->4000)
+  spann3r_trueshape.npz  tiny model, batch 2, 4 frames of 48x80 WITH `true_shape` (landscape, and dataset-rotated portrait)
+  spann3r_cfg2_224x10.npz  24/12 model, 10 frames of 224x224, eval policy (BASELINE config 2 = the bench workload):
+                      subsampled outputs, per-step feat_fuse / feat_k / cur_v, final mem_attn / mem_count
+  spann3r_cfg3_512x13.npz  24/12 model, 13 frames of 512x512, train memory policy with dropout off (BASELINE config 3,
+                      growing bank: 11 reads, bank up to 11264 tokens), same dumps
 """
 import argparse
 import os
@@ -188,6 +193,65 @@ def make_full():
     print("full224: %d arrays" % len(out))
 
 
+def make_sequence_fixture(name, H, W, NF, train_policy, S):
+    """A whole benched configuration: outputs subsampled by S pixels, token tensors by (7, 16)."""
+    cfg = FULL
+    sd = synth_state_dict(0, cfg)
+    m = build_reference(cfg, sd, name)
+    if train_policy:                      # SURVEY.md Appendix A.6: growing bank, deterministic
+        m.train()
+        m.mem_dropout.eval()
+    frames = synth_frames(NF, H, W)
+    t = time.time()
+    preds, preds_all, sp, steps = run_with_taps(m, frames)
+    dt = time.time() - t
+    print("%s: reference forward %.2f s (%.2f frames/s, %d threads)" % (name, dt, NF / dt, torch.get_num_threads()))
+    out = {"meta_hw": np.array([H, W]), "meta_frames": np.array(NF), "meta_seed": np.array(0), "meta_sub": np.array(S),
+           "meta_train_policy": np.array(int(train_policy)), "fingerprint": np.array(state_dict_fingerprint(sd)),
+           "ref_seconds": np.array(dt), "ref_threads": np.array(torch.get_num_threads())}
+    for j, p in enumerate(preds):
+        pts = p["pts3d" if j == 0 else "pts3d_in_other_view"]
+        out["pred%d_pts_sub" % j] = npf(pts[:, ::S, ::S])
+        out["pred%d_conf_sub" % j] = npf(p["conf"][:, ::S, ::S])
+        out["pred%d_stats" % j] = np.array([float(pts.double().mean()), float(pts.double().abs().mean()),
+                                            float(p["conf"].double().mean())])
+    for i, (r1, r2) in enumerate(preds_all):      # the view-2 result of every step (only the last one is in preds)
+        out["step%d_pts2_sub" % i] = npf(r2["pts3d_in_other_view"][:, ::S, ::S])
+        out["step%d_conf2_sub" % i] = npf(r2["conf"][:, ::S, ::S])
+    for i, s in enumerate(steps):
+        for k in ("feat_fuse", "feat_k1", "feat_k2", "cur_v"):
+            out["s%d_%s_sub" % (i, k)] = npf(s[k][:, ::7, ::16])
+    out["mem_k_sub"], out["mem_v_sub"] = npf(sp.mem_k[:, ::7, ::16]), npf(sp.mem_v[:, ::7, ::16])
+    out["mem_count"], out["mem_attn"] = npf(sp.mem_count), npf(sp.mem_attn)
+    out["mem_wm_lm"] = np.array([sp.wm, sp.lm])
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("%s: %d arrays" % (name, len(out)))
+
+
+def make_trueshape():
+    """What real callers send (dust3r/datasets/base/base_stereo_view_dataset.py:89,215-220; demo.py:109): every view carries
+    `true_shape` as a CPU int32 tensor.  Case L: landscape image, true_shape = image shape.  Case P: a portrait image the
+    dataset rotated to landscape, true_shape = (W_img, H_img): the patch embed ignores it, the heads regroup the tokens."""
+    cfg, H, W, NF = TINY, 48, 80, 4
+    sd = synth_state_dict(0, cfg)
+    frames = synth_frames(NF, H, W, batch=2, seed=31)
+    out = {"meta_hw": np.array([H, W]), "meta_frames": np.array(NF), "meta_seed": np.array(31), "meta_batch": np.array(2),
+           "fingerprint": np.array(state_dict_fingerprint(sd))}
+    for tag, ts in (("L", (H, W)), ("P", (W, H))):
+        m = build_reference(cfg, sd, "ts" + tag)
+        fr = [dict(f, true_shape=torch.tensor([ts, ts], dtype=torch.int32)) for f in frames]
+        with torch.no_grad():
+            preds, preds_all, sp = m(fr, return_memory=True)
+        for j, p in enumerate(preds):
+            out["%s_pred%d_pts" % (tag, j)] = npf(p["pts3d" if j == 0 else "pts3d_in_other_view"])
+            out["%s_pred%d_conf" % (tag, j)] = npf(p["conf"])
+        for i, (r1, r2) in enumerate(preds_all):
+            out["%s_step%d_conf2" % (tag, i)] = npf(r2["conf"])
+        out["%s_mem_attn" % tag] = npf(sp.mem_attn)
+    np.savez_compressed(os.path.join(HERE, "spann3r_trueshape.npz"), **out)
+    print("trueshape: %d arrays" % len(out))
+
+
 from memory_inputs import memory_inputs  # noqa: E402  (shared with the tests)
 
 
@@ -229,3 +293,9 @@ if __name__ == "__main__":
         make_memory()
     if "full" in what:
         make_full()
+    if "trueshape" in what:
+        make_trueshape()
+    if "cfg2" in what:
+        make_sequence_fixture("spann3r_cfg2_224x10", 224, 224, 10, False, 4)
+    if "cfg3" in what:
+        make_sequence_fixture("spann3r_cfg3_512x13", 512, 512, 13, True, 8)

@@ -105,6 +105,29 @@ def test_constructor_from_reference_checkpoint(tiny_sd):
         Spann3RConfig.from_ctor_string("AsymmetricCroCo3DStereo(enc_embed_dim=768, dec_depth=12)")
     with pytest.raises(NotImplementedError):
         Spann3R(dus3r_name=None, use_feat=True)
+    with pytest.raises(FileNotFoundError):                    # a mistyped path must not silently build synthetic weights
+        Spann3R(dus3r_name="/nonexistent/DUSt3R.pth")
+
+
+def test_true_shape_routing():
+    """Host logic of Spann3R._forward: which frame lists take the static (hipGraph) path.  Every reference caller sends
+    `true_shape` (CPU int32, = image shape, or its transpose for dataset-rotated portraits)."""
+    from spann3r_amd import Spann3R, TINY
+    m = Spann3R(dus3r_name=None, cfg=TINY, init_weights=False)
+    img = torch.zeros(2, 3, 48, 80)
+    ts = lambda h, w: torch.tensor([[h, w]] * 2, dtype=torch.int32)
+    assert m._uniform_true_hw([{"img": img}] * 3) == (48, 80)
+    assert m._uniform_true_hw([{"img": img, "true_shape": ts(48, 80)}] * 3) == (48, 80)
+    assert m._uniform_true_hw([{"img": img, "true_shape": ts(80, 48)}] * 3) == (80, 48)         # rotated portrait
+    assert m._uniform_true_hw([{"img": img, "true_shape": torch.tensor([[48, 80]])}] * 2) == (48, 80)   # demo.py:109
+    assert m._uniform_true_hw([{"img": img, "true_shape": ts(48, 80)}, {"img": img}]) == (48, 80)
+    # -> general path: shapes that change inside the sequence or the batch, or that do not match the image
+    assert m._uniform_true_hw([{"img": img, "true_shape": ts(48, 80)}, {"img": img, "true_shape": ts(80, 48)}]) is None
+    assert m._uniform_true_hw([{"img": img, "true_shape": torch.tensor([[48, 80], [80, 48]])}] * 2) is None
+    assert m._uniform_true_hw([{"img": img, "true_shape": ts(80, 48)}, {"img": img}]) is None
+    assert m._uniform_true_hw([{"img": img, "true_shape": ts(32, 120)}] * 2) is None
+    assert m._uniform_true_hw([{"img": img}, {"img": torch.zeros(2, 3, 80, 48)}]) is None
+    assert m._uniform_true_hw([{"img": torch.zeros(1, 3, 50, 80)}] * 2) is None                 # not a multiple of the patch
 
 
 def test_no_cpu_fallback(tiny_sd):

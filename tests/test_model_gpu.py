@@ -12,8 +12,8 @@ from conftest import load_golden, rel_err
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-TOL_FP32 = 1e-3          # north_star tolerance; measured errors are ~1e-5 and are printed
-TOL_BF16 = 6e-2          # bf16 operands, fp32 accumulate: reported, not the parity claim
+TOL_FP32 = 1e-3          # north_star tolerance; measured errors are ~1e-5 and are printed.  fp32 mode carries the parity claim.
+TOL_BF16 = 3e-2          # bf16 operands, fp32 accumulate (the bench mode): measured 1.2e-2 worst, bound = ~2x that; reported
 
 
 @pytest.fixture(scope="module")
@@ -51,7 +51,7 @@ def test_tiny_stages_vs_golden(tiny_model):
     errs["enc_feat2"] = rel_err(f2.cpu(), g["s0_feat2"])
     # a7: decoder on the reference's inputs
     gf = lambda k: torch.from_numpy(g[k]).to(DEV)
-    dec1, dec2 = m.decode(gf("s0_feat_fuse"), p1, gf("s0_feat2"), p2, s1, s2)
+    dec1, dec2 = m.decode(gf("s0_feat_fuse"), p1, gf("s0_feat2"), p2)
     for h in TINY.hooks[1:]:
         errs["dec1_%d" % h] = rel_err(dec1[h].reshape(g["s0_dec1_%d" % h].shape).cpu(), g["s0_dec1_%d" % h])
         errs["dec2_%d" % h] = rel_err(dec2[h].reshape(g["s0_dec2_%d" % h].shape).cpu(), g["s0_dec2_%d" % h])
@@ -314,3 +314,132 @@ def test_encoder_whole_sequence_bf16_lds_tiles(full_sd):
         err = rel_err(together[i].cpu(), one[0].cpu())
         assert err < 2e-2, (i, err)
     print("whole-sequence encoder vs per-frame (bf16): last rel err %.2e" % err)
+
+
+# ----------------------------------------------------------------------------- what real callers send: true_shape
+def _with_true_shape(frames, ts, device=None):
+    """dust3r/datasets/base/base_stereo_view_dataset.py:89 + default collate: int32 [B, 2], left on the CPU by demo.py:94-95"""
+    B = frames[0]["img"].shape[0]
+    t = torch.tensor([ts] * B, dtype=torch.int32)
+    return [dict(f, true_shape=t.to(device) if device else t.clone()) for f in frames]
+
+
+@pytest.mark.parametrize("tag", ["L", "P"])
+def test_true_shape_takes_graph_path_and_matches_reference(tiny_model, tag):
+    """A Demo-/dataset-shaped batch (every view carries `true_shape`) must hit the static hipGraph path and match the
+    reference dump: L = landscape, P = portrait rotated to landscape by the dataset (true_shape = transposed image shape)."""
+    from spann3r_amd.weights import synth_frames
+    g = load_golden("spann3r_trueshape.npz")
+    H, W = map(int, g["meta_hw"])
+    ts = (H, W) if tag == "L" else (W, H)
+    m = tiny_model
+    frames = _with_true_shape(to_dev(synth_frames(int(g["meta_frames"]), H, W, batch=int(g["meta_batch"]), seed=int(g["meta_seed"]))), ts)
+    assert not frames[0]["true_shape"].is_cuda
+    for rep in range(3):                                 # eager, capture, replay
+        preds, preds_all, mem = m(frames, return_memory=True)
+        for j, p in enumerate(preds):
+            key = "pts3d" if j == 0 else "pts3d_in_other_view"
+            assert tuple(p[key].shape) == tuple(g["%s_pred%d_pts" % (tag, j)].shape)
+            assert rel_err(p[key].cpu(), g["%s_pred%d_pts" % (tag, j)]) < TOL_FP32, (rep, j)
+            assert rel_err(p["conf"].cpu(), g["%s_pred%d_conf" % (tag, j)]) < TOL_FP32, (rep, j)
+        for i, (_, r2) in enumerate(preds_all):
+            assert rel_err(r2["conf"].cpu(), g["%s_step%d_conf2" % (tag, i)]) < TOL_FP32
+        assert rel_err(mem.mem_attn.cpu(), g["%s_mem_attn" % tag]) < TOL_FP32
+    run = m._runners[(int(g["meta_batch"]), H, W, False, ts)]
+    assert any(k[0] == "step" for k in run.graphs) and any(k[0] == "tail" for k in run.graphs)
+    # a device-resident true_shape and the key-less form give the same thing (landscape only for the latter)
+    p_dev, _ = m(_with_true_shape(frames, ts, DEV))
+    assert all(torch.equal(a[k], b[k]) for a, b in zip(preds, p_dev) for k in a)
+    if tag == "L":
+        p_none, _ = m([{"img": f["img"]} for f in frames])
+        assert all(torch.equal(a[k], b[k]) for a, b in zip(preds, p_none) for k in a)
+
+
+@pytest.mark.parametrize("tag", ["L", "P"])
+def test_general_path_matches_reference(tiny_model, tag):
+    """_forward_general (the reference-shaped eager loop over the stage methods, taken for sequences whose true_shape
+    changes between frames) pinned on its own against the same reference dump."""
+    from spann3r_amd.weights import synth_frames
+    g = load_golden("spann3r_trueshape.npz")
+    H, W = map(int, g["meta_hw"])
+    ts = (H, W) if tag == "L" else (W, H)
+    m = tiny_model
+    frames = _with_true_shape(to_dev(synth_frames(int(g["meta_frames"]), H, W, batch=int(g["meta_batch"]), seed=int(g["meta_seed"]))), ts)
+    m.force_general = True
+    try:
+        preds, preds_all, mem = m(frames, return_memory=True)
+    finally:
+        m.force_general = False
+    for j, p in enumerate(preds):
+        key = "pts3d" if j == 0 else "pts3d_in_other_view"
+        assert rel_err(p[key].cpu(), g["%s_pred%d_pts" % (tag, j)]) < TOL_FP32, j
+        assert rel_err(p["conf"].cpu(), g["%s_pred%d_conf" % (tag, j)]) < TOL_FP32, j
+    assert rel_err(mem.mem_attn.cpu(), g["%s_mem_attn" % tag]) < TOL_FP32
+    # a sequence that really needs it: landscape views followed by rotated-portrait views of the same image size
+    mixed = _with_true_shape(frames[:2], (H, W)) + _with_true_shape(frames[2:], (W, H))
+    assert m._uniform_true_hw(mixed) is None
+    pm, _ = m(mixed)
+    assert all(torch.isfinite(v).all() for p in pm for v in p.values())
+
+
+# ----------------------------------------------------------------------------- the benched configurations, at their lengths
+def _run_sequence_fixture(name, full_sd, precision):
+    from spann3r_amd import Spann3R, FULL
+    from spann3r_amd.weights import synth_frames, state_dict_fingerprint
+    g = load_golden(name)
+    assert state_dict_fingerprint(full_sd) == float(g["fingerprint"])
+    H, W = map(int, g["meta_hw"])
+    S, n = int(g["meta_sub"]), int(g["meta_frames"])
+    m = Spann3R(dus3r_name=None, cfg=FULL, init_weights=False)
+    m.load_state_dict(full_sd, strict=True)
+    m = m.to(DEV).eval().set_precision(precision)
+    if bool(g["meta_train_policy"]):
+        m.train()
+        m.mem_dropout.eval()
+    frames = _with_true_shape(to_dev(synth_frames(n, H, W)), (H, W))
+    taps = []
+    from spann3r_amd.model import _SequenceRunner
+    orig = _SequenceRunner.run
+
+    def run(self, *a):                      # per-step state straight from the runner's static buffers
+        r = orig(self, *a)
+        taps.append({k: getattr(self, k)[:, ::7, ::16].cpu() for k in ("fuse", "k1", "k2", "v")})
+        return r
+    _SequenceRunner.run = run
+    try:
+        preds, preds_all, mem = m(frames, return_memory=True)
+    finally:
+        _SequenceRunner.run = orig
+    err = {"pts": 0.0, "conf": 0.0, "pts2": 0.0, "fuse": 0.0, "k": 0.0}
+    for j, p in enumerate(preds):
+        pts = p["pts3d" if j == 0 else "pts3d_in_other_view"]
+        err["pts"] = max(err["pts"], rel_err(pts[:, ::S, ::S].cpu(), g["pred%d_pts_sub" % j]))
+        err["conf"] = max(err["conf"], rel_err(p["conf"][:, ::S, ::S].cpu(), g["pred%d_conf_sub" % j]))
+    for i, (_, r2) in enumerate(preds_all):
+        err["pts2"] = max(err["pts2"], rel_err(r2["pts3d_in_other_view"][:, ::S, ::S].cpu(), g["step%d_pts2_sub" % i]),
+                          rel_err(r2["conf"][:, ::S, ::S].cpu(), g["step%d_conf2_sub" % i]))
+    for i, t in enumerate(taps):
+        if i > 0:                            # step 0 has no memory read (feat_fuse = feat1)
+            err["fuse"] = max(err["fuse"], rel_err(t["fuse"], g["s%d_feat_fuse_sub" % i]))
+        err["k"] = max(err["k"], rel_err(t["k1"], g["s%d_feat_k1_sub" % i]), rel_err(t["k2"], g["s%d_feat_k2_sub" % i]))
+    err["mem_attn"] = rel_err(mem.mem_attn.cpu(), g["mem_attn"])
+    assert np.array_equal(mem.mem_count.cpu().numpy(), g["mem_count"])
+    assert [mem.wm, mem.lm] == list(g["mem_wm_lm"])
+    print("%s %s: %s" % (name, precision, {k: "%.2e" % v for k, v in err.items()}))
+    return err
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", TOL_FP32), ("bf16", TOL_BF16)])
+def test_cfg2_224x10_vs_reference(full_sd, precision, tol):
+    """BASELINE config 2 = the bench workload at its benched length (10 frames of 224x224, eval policy, batch 1): outputs,
+    every view-2 result, every memory read (feat_fuse), the keys and the final mem_attn against the reference dump."""
+    err = _run_sequence_fixture("spann3r_cfg2_224x10.npz", full_sd, precision)
+    assert max(err.values()) < tol, err
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", TOL_FP32), ("bf16", TOL_BF16)])
+def test_cfg3_512x13_vs_reference(full_sd, precision, tol):
+    """BASELINE config 3: 512x512, growing bank (train policy, dropout off), 13 frames = 11 memory reads over up to
+    11264 bank tokens, against the reference dump."""
+    err = _run_sequence_fixture("spann3r_cfg3_512x13.npz", full_sd, precision)
+    assert max(err.values()) < tol, err

@@ -92,3 +92,53 @@ def test_full224(full_sd):
         assert rel_err(pts[:, ::4, ::4], g["pred%d_pts_sub" % j]) < 1e-4
         assert rel_err(p["conf"][:, ::4, ::4], g["pred%d_conf_sub" % j]) < 1e-4
     assert rel_err(mem.mem_k[:, ::7, ::16], g["mem_k_sub"]) < 1e-4
+
+
+def test_true_shape_views(tiny_sd):
+    """Views WITH `true_shape` (what every reference caller sends): landscape, and a portrait the dataset rotated to
+    landscape (true_shape = transposed image shape: the heads regroup the tokens, the patch embed does not)."""
+    g = load_golden("spann3r_trueshape.npz")
+    H, W = map(int, g["meta_hw"])
+    frames = synth_frames(int(g["meta_frames"]), H, W, batch=int(g["meta_batch"]), seed=int(g["meta_seed"]))
+    for tag, ts in (("L", (H, W)), ("P", (W, H))):
+        fr = [dict(f, true_shape=torch.tensor([ts, ts], dtype=torch.int32)) for f in frames]
+        preds, preds_all, mem = O.forward(fr, tiny_sd, TINY, return_memory=True)
+        for j, p in enumerate(preds):
+            assert rel_err(p["pts3d" if j == 0 else "pts3d_in_other_view"], g["%s_pred%d_pts" % (tag, j)]) < TOL
+            assert rel_err(p["conf"], g["%s_pred%d_conf" % (tag, j)]) < TOL
+        for i, (_, r2) in enumerate(preds_all):
+            assert rel_err(r2["conf"], g["%s_step%d_conf2" % (tag, i)]) < TOL
+        assert rel_err(mem.mem_attn, g["%s_mem_attn" % tag]) < 1e-4
+
+
+def _check_sequence_fixture(name, full_sd, tol=1e-4):
+    g = load_golden(name)
+    assert state_dict_fingerprint(full_sd) == float(g["fingerprint"])
+    H, W = map(int, g["meta_hw"])
+    S = int(g["meta_sub"])
+    frames = synth_frames(int(g["meta_frames"]), H, W)
+    taps = {}
+    preds, preds_all, mem = O.forward(frames, full_sd, FULL, training_policy=bool(g["meta_train_policy"]),
+                                      return_memory=True, taps=taps)
+    for j, p in enumerate(preds):
+        pts = p["pts3d" if j == 0 else "pts3d_in_other_view"]
+        assert rel_err(pts[:, ::S, ::S], g["pred%d_pts_sub" % j]) < tol
+        assert rel_err(p["conf"][:, ::S, ::S], g["pred%d_conf_sub" % j]) < tol
+    for i, s in enumerate(taps["steps"]):
+        for k in ("feat_fuse", "feat_k1", "feat_k2", "cur_v"):
+            assert rel_err(s[k][:, ::7, ::16], g["s%d_%s_sub" % (i, k)]) < tol, (i, k)
+    assert np.array_equal(mem.mem_count.numpy(), g["mem_count"])
+    assert rel_err(mem.mem_attn, g["mem_attn"]) < tol
+    assert [mem.wm, mem.lm] == list(g["mem_wm_lm"])
+
+
+@pytest.mark.slow
+def test_cfg2_224x10(full_sd):
+    """BASELINE config 2 (the bench workload): 10 frames of 224x224, eval policy."""
+    _check_sequence_fixture("spann3r_cfg2_224x10.npz", full_sd)
+
+
+@pytest.mark.slow
+def test_cfg3_512x13(full_sd):
+    """BASELINE config 3: 13 frames of 512x512, growing bank (train policy, dropout off): 11 reads, up to 11264 tokens."""
+    _check_sequence_fixture("spann3r_cfg3_512x13.npz", full_sd)
