@@ -5,25 +5,29 @@ A "step" is one pass of the hot path over one synthetic sequence: Spann3R.forwar
 batch 1, bf16 MFMA (BASELINE.json configs[1]).  value = whole-job frames/s with inputs resident in HBM.
 
   python bench.py --gpus N --steps K --warmup W
+      N > 1 without a launcher: this process spawns N ranks itself (one per GPU, pinned to a slice of the host cores,
+      RCCL rendezvous on 127.0.0.1) and prints rank 0's line; it exits non-zero instead of silently running fewer ranks.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+      the launcher's RANK / LOCAL_RANK / WORLD_SIZE are used as they are.
 
 One process per GPU; independent sequences are sharded across ranks (no data-path collective); the only collective is
-one RCCL all_gather of {frames, seconds} per rank.  Rank 0 prints ONE JSON line with the extra objects
-  roofline     : dominant kernel (by GPU time) -- algorithmic FLOPs / HIP-event time vs the dense MFMA peak
-  memread      : spatial-memory read (S = q.K^T, softmax/threshold, P.V) algorithmic bytes / HIP-event time vs HBM peak
-  cpu_baseline : the CPU oracle (a port of the reference algorithm, oracle/) timed on this box's host cores
+one RCCL all_gather of {frames, seconds} per rank, on the device.  Rank 0 prints ONE JSON line with the extra objects
+  roofline     : dominant kernel (by GPU time): algorithmic bytes / FLOPs per launch over its average launch duration,
+                 measured live with HIP events on the launch stream (event cost calibrated against a spin kernel)
+  memread      : the spatial-memory read region (all its launches): algorithmic bytes / HIP-event time vs the HBM peak
+  fp32, config3: (N = 1 only) the parity mode on the same workload, and BASELINE config 3 (512x512, 50 frames, growing bank)
+  cpu_baseline : (N = 1 only) the CPU oracle (a port of the reference algorithm, oracle/) on this box's host cores
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
 
 METRIC = "frames/sec/GPU (224px, 10-frame seq) + mem-bank cross-attn HBM GB/s"
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}       # dense MFMA peaks, MI355X_MICROARCH.md
@@ -42,7 +46,7 @@ def flops_per_sequence(n_frames, size):
     return n_frames * enc + (n_frames - 1) * step + read * sum(range(1, n_frames - 1))
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -52,61 +56,216 @@ def main():
     ap.add_argument("--size", type=int, default=224)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the fp32 and config-3 secondary measurements")
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--train-policy", action="store_true", help="growing bank (train-mode memory policy, dropout off)")
     ap.add_argument("--schedule", default="", help="comma list of schedule switches to turn OFF: batch_encode, defer_head2, "
                                                    "grouped_decoder (debugging / A-B runs; default = the shipped schedule)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+# ----------------------------------------------------------------------------- self-spawn (no launcher)
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n, argv):
+    """Start n ranks of this script (one per GPU), CPU cores split evenly, and relay rank 0's JSON line.
+    Returns the exit code: non-zero if any rank fails or the box has fewer than n GPUs."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < n:
+        print("bench.py: --gpus %d requested but only %d GPU(s) visible; refusing to run a smaller job" % (n, have), file=sys.stderr)
+        return 2
+    port = _free_port()
+    cores = sorted(os.sched_getaffinity(0))
+    per = max(1, len(cores) // n)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+                   SP3_BENCH_CORES=",".join(map(str, cores[r * per:(r + 1) * per])), OMP_NUM_THREADS=str(per))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    if any(rcs):
+        print("bench.py: rank exit codes %s" % rcs, file=sys.stderr)
+        return 1
+    sys.stdout.write(out0)
+    return 0
+
+
+# ----------------------------------------------------------------------------- measurement pieces
+def build_model(precision, dev, train_policy=False, schedule_off=(), graphs=True):
+    from spann3r_amd import Spann3R, FULL
+    from spann3r_amd.weights import synth_state_dict
+    sd = synth_state_dict(0, FULL)                      # seeded synthetic weights of the named architecture
+    model = Spann3R(dus3r_name=None, cfg=FULL, init_weights=False)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).eval().set_precision(precision)
+    if train_policy:
+        model.train()
+        model.mem_dropout.eval()
+    model.use_graphs = graphs
+    for off in schedule_off:
+        assert hasattr(model, off), off
+        setattr(model, off, False)
+    return model, sd
+
+
+def time_sequences(model, seqs, steps, warmup, world=1):
+    import torch
+    import torch.distributed as dist
+    from spann3r_amd.runner import run_sequences
+    sync = torch.cuda.synchronize
+    for i in range(warmup):
+        model(seqs[i % len(seqs)])
+    sync()
+    if world > 1:
+        dist.barrier()
+    sync()
+    frames, seconds, _ = run_sequences(model, [seqs[i % len(seqs)] for i in range(steps)], sync=sync)
+    if world > 1:
+        dist.barrier()
+    return frames, seconds
+
+
+def kernel_profile(model, seq, precision):
+    """One more sequence with eager launches (same kernels, same stream, same order) and every launch timed with HIP
+    events on the launch stream.  Returns (roofline dict, breakdown list, total kernel ms, memread dict or None)."""
+    from spann3r_amd import ops
+    graphs = model.use_graphs
+    model.use_graphs = False
+    try:
+        model(seq)
+        prof = ops.Profiler()
+        cal = prof.calibrate()
+        ops.set_profiler(prof)
+        model(seq)
+    finally:
+        ops.set_profiler(None)
+        model.use_graphs = graphs
+    agg = prof.summary()
+    total_ms = sum(a["ms"] for a in agg.values())
+    top = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])
+    key, a = top[0]
+    # the roof that binds the dominant kernel: the larger of (algorithmic FLOPs / dense MFMA peak) and
+    # (algorithmic bytes / HBM peak); frac = that lower bound on the launch time / the measured launch time
+    t_s = a["ms"] * 1e-3
+    ach_fl, ach_by = a["flops"] / t_s / 1e12, a["bytes"] / t_s / 1e9
+    fr_fl, fr_by = ach_fl / PEAK_TFLOPS[precision], ach_by / PEAK_HBM_GBS
+    common = {"kernel": key, "traffic": None, "launches": a["launches"], "avg_us": 1e3 * a["ms"] / a["launches"],
+              "avg_gflop_per_launch": a["flops"] / a["launches"] / 1e9, "avg_mbyte_per_launch": a["bytes"] / a["launches"] / 1e6,
+              "share_of_gpu_time": a["ms"] / total_ms, "mfma_frac": fr_fl, "hbm_frac": fr_by,
+              "timing": "HIP events on the launch stream, one bracket per launch, minus the event cost measured around a spin "
+                        "kernel of known length (%.2f us); compare profiles/ rocprofv3 --kernel-trace of the same build" % (1e3 * cal)}
+    # HBM traffic of that kernel from PMC passes (rocprofv3 cannot run inside this process): bytes per launch, FETCH_SIZE
+    # doubled as MI355X_MICROARCH.md prescribes for gfx950.  Only reported when the committed file names THIS kernel.
+    try:
+        pm_all = json.load(open(os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")))
+        pm = pm_all["kernels"].get(key)
+        if pm and precision == "bf16":
+            common["traffic"] = pm["traffic_bytes"]
+            common["traffic_build"] = pm_all.get("build", "unknown")
+            common["traffic_note"] = ("HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of build '%s' "
+                                      "(profiles/pmc_hbm_traffic.json), not of this process" % pm_all.get("build", "unknown"))
+    except (OSError, ValueError, KeyError):
+        pass
+    if fr_fl >= fr_by:
+        roof = dict(bound="mfma", achieved=ach_fl, peak=PEAK_TFLOPS[precision], unit="TFLOP/s", frac=fr_fl, **common)
+    else:
+        roof = dict(bound="hbm", achieved=ach_by, peak=PEAK_HBM_GBS, unit="GB/s", frac=fr_by, **common)
+    breakdown = [{"kernel": k, "launches": v["launches"], "ms": round(v["ms"], 4), "avg_us": round(1e3 * v["ms"] / v["launches"], 2),
+                  "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else None,
+                  "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else None}
+                 for k, v in top[:8]]
+    memread = None
+    reads = [r for r in prof.region_summary() if r["key"] == "memread"]
+    if reads:
+        big = max(reads, key=lambda r: r["info"]["M"])
+        gbs = big["bytes"] / (big["ms"] * 1e-3) / 1e9
+        memread = {"what": "spatial-memory read (LN_q folded, S = q.K_hat^T/32, softmax+threshold, P.V_hat + q, column sums)",
+                   "bank_tokens": big["info"]["M"], "queries": big["info"]["tokens_per_frame"], "algorithmic_bytes": big["bytes"],
+                   "us": 1e3 * big["ms"], "launches": big["launches"], "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                   "frac": gbs / PEAK_HBM_GBS, "gflop": big["info"].get("flops", 0.0) / 1e9,
+                   "tflops": big["info"].get("flops", 0.0) / (big["ms"] * 1e-3) / 1e12,
+                   "reads_per_sequence": len(reads), "all_reads_us": [round(1e3 * r["ms"], 2) for r in reads]}
+    return roof, breakdown, total_ms, memread
+
+
+def cpu_baseline(sd, size, train_policy):
+    """The CPU oracle on this box's host cores: warm-up, a thread-count sweep on a short sequence, then the median of 3
+    runs of the bounded sample at the best count."""
+    import torch
+    from oracle import spann3r_oracle as O
+    from spann3r_amd import FULL
+    from spann3r_amd.runner import make_sequence
+    cores = len(os.sched_getaffinity(0))
+    nfr = 3 if size > 224 else 5
+    short = make_sequence(0, 3, size, size)
+    sample = make_sequence(0, nfr, size, size)
+
+    def run(frames):
+        t0 = time.perf_counter()
+        O.forward(frames, sd, FULL, training_policy=train_policy)
+        return time.perf_counter() - t0
+    run(short)                                                   # warm-up (allocator, oneDNN primitive caches)
+    sweep = {}
+    for nt in sorted({min(cores, c) for c in (8, 16, 32, 64, 128)}):
+        torch.set_num_threads(nt)
+        sweep[nt] = len(short) / run(short)
+    best = max(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    ts = sorted(run(sample) for _ in range(3))
+    model_name = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model_name = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": nfr / ts[1], "unit": "frames/s", "cores": best, "kind": "port", "cpu": model_name, "host_cores": cores,
+            "thread_sweep_frames_per_s": {str(k): round(v, 3) for k, v in sweep.items()},
+            "sample": "median of 3 runs of one %d-frame %dx%d sequence, fp32, torch-CPU oracle (oracle/spann3r_oracle.py) after a "
+                      "warm-up, at the best thread count of the sweep; %.1f s per run" % (nfr, size, size, ts[1])}
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+
+    import torch
+    import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE %d; refusing to report a job of a different size" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
+    if os.environ.get("SP3_BENCH_CORES"):
+        os.sched_setaffinity(0, {int(c) for c in os.environ["SP3_BENCH_CORES"].split(",")})
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", init_method="env://")   # 'nccl' IS RCCL on ROCm
-    if args.gpus != world and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    from spann3r_amd import Spann3R, FULL
-    from spann3r_amd import ops
-    from spann3r_amd.runner import make_sequence, run_sequences, gather_stats, aggregate, shard
-    from spann3r_amd.weights import synth_state_dict
+    from spann3r_amd.runner import make_sequence, gather_stats, aggregate, shard
 
-    sd = synth_state_dict(0, FULL)                      # seeded synthetic weights of the named architecture
-    model = Spann3R(dus3r_name=None, cfg=FULL, init_weights=False)
-    model.load_state_dict(sd, strict=True)
-    model = model.to(dev).eval().set_precision(args.precision)
-    if args.train_policy:
-        model.train()
-        model.mem_dropout.eval()
-    if hasattr(model, "use_graphs"):
-        model.use_graphs = not args.no_graphs
-    for off in filter(None, args.schedule.split(",")):
-        assert hasattr(model, off), off
-        setattr(model, off, False)
-
+    model, sd = build_model(args.precision, dev, args.train_policy, tuple(filter(None, args.schedule.split(","))), not args.no_graphs)
     # rank r owns sequences {s : s mod world == r}; a handful of distinct sequences, cycled
     n_distinct = 4
     my_ids = shard(n_distinct * world, rank, world)
     seqs = [make_sequence(s, args.frames, args.size, args.size, device=dev) for s in my_ids]
-
-    def fwd(seq):
-        return model(seq)
-
-    sync = torch.cuda.synchronize
-    for i in range(args.warmup):
-        fwd(seqs[i % len(seqs)])
-    sync()
-    if world > 1:
-        dist.barrier()
-    sync()
-    frames, seconds, _ = run_sequences(fwd, [seqs[i % len(seqs)] for i in range(args.steps)], sync=sync)
-    if world > 1:
-        dist.barrier()
-    stats = gather_stats(frames, seconds, device=dev)
+    frames, seconds = time_sequences(model, seqs, args.steps, args.warmup, world)
+    stats = gather_stats(frames, seconds, device=dev)           # RCCL all_gather on the device when world > 1
     fps, tot_frames, max_seconds = aggregate(stats)
 
     if rank != 0:
@@ -121,8 +280,9 @@ def main():
         "config": {"workload": "Spann3R.forward, %d-frame %dx%d sequence, batch 1, ViT-L enc / ViT-B dec / DPT heads, %s memory policy"
                                % (args.frames, args.size, args.size, "train (growing bank)" if args.train_policy else "eval"),
                    "frames_per_step": args.frames, "parallelism": "sequences sharded 1/GPU x%d" % world,
-                   "hip_graphs": bool(getattr(model, "use_graphs", False))},
+                   "hip_graphs": bool(model.use_graphs)},
         "per_gpu_frames_per_s": fps / world,
+        "per_rank_seconds": [round(float(s), 6) for s in stats[:, 1]],
     }
     fl = flops_per_sequence(args.frames, args.size)
     out["end_to_end"] = {"algorithmic_gflop_per_step": fl / 1e9,
@@ -131,68 +291,41 @@ def main():
 
     # ---- per-kernel HIP-event timing over one more sequence (eager launches, same kernels, same stream)
     if not args.no_profile:
-        graphs = getattr(model, "use_graphs", False)
-        if graphs:
-            model.use_graphs = False
-        fwd(seqs[0])
-        prof = ops.Profiler()
-        out["event_bracket_overhead_us"] = 1e3 * prof.calibrate()
-        ops.set_profiler(prof)
-        fwd(seqs[0])
-        ops.set_profiler(None)
-        if graphs:
-            model.use_graphs = True
-        agg = prof.summary()
-        total_ms = sum(a["ms"] for a in agg.values())
-        top = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])
-        key, a = top[0]
-        # the roof that binds the dominant kernel: the larger of (algorithmic FLOPs / dense MFMA peak) and
-        # (algorithmic bytes / HBM peak); frac = that lower bound on the launch time / the measured launch time
-        t_ms = a["ms"] * 1e-3
-        ach_fl, ach_by = a["flops"] / t_ms / 1e12, a["bytes"] / t_ms / 1e9
-        fr_fl, fr_by = ach_fl / PEAK_TFLOPS[args.precision], ach_by / PEAK_HBM_GBS
-        common = {"kernel": key, "traffic": None, "launches": a["launches"], "avg_us": 1e3 * a["ms"] / a["launches"],
-                  "avg_gflop_per_launch": a["flops"] / a["launches"] / 1e9, "avg_mbyte_per_launch": a["bytes"] / a["launches"] / 1e6,
-                  "share_of_gpu_time": a["ms"] / total_ms, "mfma_frac": fr_fl, "hbm_frac": fr_by}
-        # HBM traffic of that kernel from the PMC passes committed under profiles/ (rocprofv3 cannot run inside this
-        # process): bytes per launch, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_f_pmc_hbm_traffic.json")))["kernels"].get(key)
-            if pm and args.precision == "bf16" and args.size == 224:
-                common["traffic"] = pm["traffic_bytes"]
-                common["traffic_note"] = ("HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), "
-                                          "profiles/r01_f_pmc_hbm_traffic.json; algorithmic bytes per launch = %d" % round(a["bytes"] / a["launches"]))
-        except (OSError, ValueError, KeyError):
-            pass
-        if fr_fl >= fr_by:
-            out["roofline"] = dict(bound="mfma", achieved=ach_fl, peak=PEAK_TFLOPS[args.precision], unit="TFLOP/s", frac=fr_fl, **common)
-        else:
-            out["roofline"] = dict(bound="hbm", achieved=ach_by, peak=PEAK_HBM_GBS, unit="GB/s", frac=fr_by, **common)
-        out["kernel_breakdown"] = [{"kernel": k, "launches": v["launches"], "ms": round(v["ms"], 4),
-                                    "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else None}
-                                   for k, v in top[:8]]
-        out["profiled_sequence_kernel_ms"] = total_ms
-        reads = [r for r in prof.region_summary() if r["key"] == "memread"]
-        if reads:
-            big = max(reads, key=lambda r: r["info"]["M"])
-            gbs = big["bytes"] / (big["ms"] * 1e-3) / 1e9
-            out["memread"] = {"what": "spatial-memory read (LN_q, S = q.K_hat^T/32, softmax+threshold, P.V_hat + q, colsum)",
-                              "bank_tokens": big["info"]["M"], "algorithmic_bytes": big["bytes"], "us": 1e3 * big["ms"],
-                              "launches": big["launches"], "us_uncorrected": 1e3 * big["raw_ms"],
-                              "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
-                              "reads_per_sequence": len(reads), "all_reads_us": [round(1e3 * r["ms"], 2) for r in reads]}
+        roof, breakdown, total_ms, memread = kernel_profile(model, seqs[0], args.precision)
+        out["roofline"], out["kernel_breakdown"], out["profiled_sequence_kernel_ms"] = roof, breakdown, total_ms
+        if memread:
+            out["memread"] = memread
+
+    # ---- secondary measurements on this GPU (N = 1 only): the fp32 parity mode, and BASELINE config 3
+    if world == 1 and not args.no_extras and (args.size, args.frames, args.precision, args.train_policy) == (224, 10, "bf16", False):
+        model.set_precision("fp32")
+        f32_frames, f32_s = time_sequences(model, seqs, 6, 3)
+        out["fp32"] = {"value": f32_frames / f32_s, "unit": "frames/s", "what": "same workload in the fp32 MFMA parity mode "
+                       "(<=1e-3 vs the reference, tests/test_model_gpu.py)", "steps": 6,
+                       "frac_of_mfma_peak": fl * 6 / f32_s / 1e12 / PEAK_TFLOPS["fp32"]}
+        model.set_precision("bf16")
+        del model
+        torch.cuda.empty_cache()
+        m3, _ = build_model("bf16", dev, train_policy=True)
+        seq3 = [make_sequence(100, 50, 512, 512, device=dev)]
+        c3_frames, c3_s = time_sequences(m3, seq3, 3, 3)
+        fl3 = flops_per_sequence(50, 512)
+        c3 = {"workload": "Spann3R.forward, 50-frame 512x512 sequence, batch 1, growing bank (train memory policy, dropout off), bf16",
+              "value": c3_frames / c3_s, "unit": "frames/s", "steps": 3, "ms_per_sequence": 1e3 * c3_s / 3,
+              "frac_of_mfma_peak": fl3 * 3 / c3_s / 1e12 / PEAK_TFLOPS["bf16"]}
+        if not args.no_profile:
+            roof3, breakdown3, _, memread3 = kernel_profile(m3, seq3[0], "bf16")
+            c3["dominant_kernel"] = {k: roof3[k] for k in ("kernel", "avg_us", "launches", "share_of_gpu_time", "mfma_frac", "hbm_frac")}
+            c3["kernel_breakdown"] = breakdown3[:5]
+            if memread3:
+                c3["memread"] = memread3
+        out["config3"] = c3
+        del m3
+        torch.cuda.empty_cache()
 
     # ---- CPU baseline: the oracle (port of the reference algorithm) on this box's host cores, bounded sample
-    if not args.no_cpu_baseline:
-        from oracle import spann3r_oracle as O
-        nfr = 3 if args.size > 224 else 5
-        cpu_frames = make_sequence(0, nfr, args.size, args.size)
-        t0 = time.perf_counter()
-        O.forward(cpu_frames, sd, FULL, training_policy=args.train_policy)
-        dt = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": nfr / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-                               "sample": "one %d-frame %dx%d sequence, fp32, torch-CPU oracle (oracle/spann3r_oracle.py), %.1f s"
-                                         % (nfr, args.size, args.size, dt)}
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(sd, args.size, args.train_policy)
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

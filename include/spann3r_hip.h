@@ -93,7 +93,7 @@ typedef struct sp3_gemm_desc {
                              K % 64 == 0) */
   int32_t a_bf16;
   int32_t splitk;         /* >= 1; > 1 only with SP3_EPI_PARTIAL */
-  int32_t a_packed;       /* A is in MFMA-fragment order [ceil(M/16)][ceil(K/KB)][64 lanes][CH] (see w_packed); written
+  int32_t a_packed;       /* A is in MFMA-fragment order [ceil(M/16)][ceil(K/KB)][2 halves][64 lanes][CH/2] (see w_packed); written
                              that way by the producing kernel (out_packed options), plain loader only */
   /* --- LayerNorm folded into the GEMM (DESIGN.md "LN fold"): for y = LayerNorm(x; gamma, beta) . W^T + b,
    *   y = rstd * (x . (gamma (.) W)^T) - rstd * mean * s + (b + beta . W^T),  s_n = sum_k (gamma (.) W)_nk.
@@ -113,8 +113,9 @@ typedef struct sp3_gemm_desc {
   int32_t qkv_packed;     /* ROPE_VT epilogue, bf16: q/k stored in fragment order (rows = b*vt_ld + n, K-dim = rope_cols) and
                              V in PV-operand order [(b,h)][vt_ld/32][4][64][8] -- the layouts sp3_attention_packed reads */
   int32_t out_packed;     /* plain epilogue: store C in fragment order (it is the next GEMM's packed A; dims M x N) */
-  int32_t w_packed;       /* W is in MFMA-fragment order [ceil(N/16)][ceil(K/KB)][64 lanes][CH], zero padded; KB/CH =
-                             64/16 (bf16) or 32/8 (fp32); lane = 16*g + r holds row 16*nb + r, k = kb*KB + g*CH + e */
+  int32_t w_packed;       /* W is in MFMA-fragment order [ceil(N/16)][ceil(K/KB)][2 halves][64 lanes][CH/2], zero padded; KB/CH =
+                             64/16 (bf16) or 32/8 (fp32); lane = 16*g + r holds row 16*nb + r, k = kb*KB + g*CH + e: e < CH/2 in the first 1 KB
+                             half of the 2 KB block, the rest in the second (every wave access is one contiguous KB) */
   /* --- grouped launches (batch > 1, grid.y): `batch` independent problems of one shape in one launch, e.g. the two
    *   sides of a DUSt3R decoder layer (different weights, dust3r/model.py:196-198).  A / W / C advance by strideA /
    *   strideW / strideC ELEMENTS per batch index (C in its own dtype, any epilogue, also the packed layouts), res1 /
@@ -122,6 +123,10 @@ typedef struct sp3_gemm_desc {
    *   cross-attention k/v projection of side z reads the tokens and statistics of side 1-z).  rope tables / pos are
    *   shared. */
   int64_t sb_A2, sb_bias, sb_ln_stats, sb_ln_s, sb_stats_out, sb_c2, sb_vt;
+  /* --- diagnostics: if non-null, the first 8 workgroups of a role-loop launch (tiles 13-15) store shader-clock stamps of
+   *   their own timeline: trace[wg*64 + 0] = entry, [1] = loop done, [2] = epilogue done, [8 + i/4] = loader passed the
+   *   barrier of k-block i (i % 4 == 0), [32 + i/4] = consumer wave 0 finished k-block i.  tools/trace_gemm.py prints it. */
+  int64_t* trace;
 } sp3_gemm_desc;
 int sp3_gemm(const sp3_gemm_desc* desc_host, void* stream);
 
@@ -261,6 +266,9 @@ int sp3_head_final(const float* feat, const float* w, const float* b, int64_t pi
 int sp3_copy2d_f32(const float* src, int64_t lds, float* dst, int64_t ldd, int rows, int cols, void* stream);
 int sp3_fill_f32(float* p, float v, int64_t n, void* stream);
 int sp3_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+/* Measurement aid (bench.py): a one-wave kernel that spins `cycles` shader clocks and stores its own duration in ticks of
+ * the constant 100 MHz counter: a kernel of known length to calibrate the cost of a HIP-event bracket against. */
+int sp3_spin(int64_t cycles, int64_t* ticks_100mhz, void* stream);
 
 #ifdef __cplusplus
 }

@@ -176,11 +176,12 @@ __global__ __launch_bounds__(64) void attention_kernel(const T* __restrict__ Q, 
 struct KFrag { bf16x8 v[2]; };
 
 __device__ __forceinline__ KFrag load_frag(const __bf16* base, int row, int col, int K) {
-  // lane (g, r) of a 16-row block reads its 16 contiguous elements (d = 16g .. 16g+15 of the head at `col`)
+  // lane (g, r) of a 16-row block reads its 16 elements (d = 16g .. 16g+15 of the head at `col`): two 16-byte halves,
+  // one in each 1 KB piece of the fragment block
   const __bf16* p = base + packed_off(row, col, K, true);
   KFrag f;
   f.v[0] = *reinterpret_cast<const bf16x8*>(p);
-  f.v[1] = *reinterpret_cast<const bf16x8*>(p + 8);
+  f.v[1] = *reinterpret_cast<const bf16x8*>(p + 64 * 8);
   return f;
 }
 

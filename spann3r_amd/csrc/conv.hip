@@ -44,18 +44,18 @@ __global__ __launch_bounds__(256) void conv3x3_tile_kernel(const ConvArgs a) {
   const int b = t / a.tiles_y;
   const int y0 = ty * TH, x0 = tx * TW, n0 = blockIdx.y * BN;
 
-  // ---- W stream set-up: unit u = (tap, 32-channel group); fragment-order weight [Cout/16][K/64][64 lanes][16]
+  // ---- W stream set-up: unit u = (tap, 32-channel group); fragment-order weight [Cout/16][K/64][2 halves][64 lanes][8]
   const int upt = Cin >> 5;                   // units per tap
   const int U = 9 * upt;
   const int nkb = (9 * Cin) >> 6;
   const __bf16* wb[NF];
 #pragma unroll
-  for (int n = 0; n < NF; ++n) wb[n] = a.w + ((int64_t)((n0 >> 4) + n) * nkb * 64 + lane) * 16;
+  for (int n = 0; n < NF; ++n) wb[n] = a.w + ((int64_t)((n0 >> 4) + n) * nkb * 128 + lane) * 8;
   const int nu = (U - wave + 3) >> 2;         // units of this wave: wave, wave + 4, ...
   auto w_off = [&](int i) -> int64_t {        // element offset of unit #i of this wave inside a 16-row fragment panel
     int u = wave + 4 * i;
     u = u < U ? u : U - 1;                    // clamped: the tail re-loads the last unit instead of branching
-    return (int64_t)(u >> 1) * (64 * 16) + (u & 1) * 8;     // K-block (u >> 1) [u counts 32-deep halves], half u & 1
+    return (int64_t)(u >> 1) * (64 * 16) + (u & 1) * (64 * 8);     // K-block (u >> 1) [u counts 32-deep halves], 1 KB half u & 1
   };
   bf16x8 wq[DEPTH][NF];
 #pragma unroll

@@ -110,6 +110,8 @@ template <> struct MM<float, __bf16> {
       }
     }
   }
+  template <int MF, int NF>
+  static __device__ __forceinline__ void mma_half(f32x4 (&)[MF][NF], const AReg (&)[MF], const WReg (&)[NF]) {}
 };
 
 template <> struct MM<__bf16, __bf16> {
@@ -136,6 +138,15 @@ template <> struct MM<__bf16, __bf16> {
         acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m].v[0], w[n].v[0], acc[m][n], 0, 0, 0);
         acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m].v[1], w[n].v[1], acc[m][n], 0, 0, 0);
       }
+  }
+  // one 16-byte half of the k-block (v[0] only): the LDS-staged loop with the contraction split over a wave pair
+  template <int MF, int NF>
+  static __device__ __forceinline__ void mma_half(f32x4 (&acc)[MF][NF], const AReg (&a)[MF], const WReg (&w)[NF]) {
+#pragma unroll
+    for (int m = 0; m < MF; ++m)
+#pragma unroll
+      for (int n = 0; n < NF; ++n)
+        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m].v[0], w[n].v[0], acc[m][n], 0, 0, 0);
   }
 };
 
@@ -175,6 +186,18 @@ template <> struct MM<float, float> {
       }
     }
   }
+  template <int MF, int NF>
+  static __device__ __forceinline__ void mma_half(f32x4 (&acc)[MF][NF], const AReg (&a)[MF], const WReg (&w)[NF]) {
+#pragma unroll
+    for (int m = 0; m < MF; ++m)
+#pragma unroll
+      for (int n = 0; n < NF; ++n) {
+        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].v[0].x, w[n].v[0].x, acc[m][n], 0, 0, 0);
+        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].v[0].y, w[n].v[0].y, acc[m][n], 0, 0, 0);
+        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].v[0].z, w[n].v[0].z, acc[m][n], 0, 0, 0);
+        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].v[0].w, w[n].v[0].w, acc[m][n], 0, 0, 0);
+      }
+  }
 };
 
 // ------------------------------------------------------------------ A-row addressing
@@ -196,7 +219,7 @@ template <typename TA, int MF> struct ARows<TA, SP3_LOAD_PLAIN, MF> {
         mb = mb < mb_max ? mb : mb_max;
         const int nkb = (d.K + KB - 1) / KB;
         // ptr() adds k = kb*KB + g*CH; fold "- g*CH" here and scale kb*KB -> kb*64*CH through pk_mul
-        base[m] = A + ((int64_t)mb * nkb * 64 + lane) * CH;
+        base[m] = A + ((int64_t)mb * nkb * 128 + lane) * (CH / 2);      // first 1 KB half of the block; + 64*CH/2 = second
         base2[m] = base[m];
       } else {
         int r = row0 + m * 16 + (lane & 15);
@@ -256,25 +279,45 @@ __device__ __forceinline__ void glds16(const char* gsrc, char* lds) {
 #endif
 }
 
-// Stages of the LDS-staged loop.  Measured (tools/bench_gemm.py --M 1960, 128x64 tile, N = 3072): 2 stages (48 KB, three
-// workgroups per CU) 28 us, 3 stages (72 KB, two per CU) 39 us -- residency beats prefetch depth here, so 2 everywhere.
-template <int BM, int BN> struct LDSK_STAGES { static constexpr int value = 2; };
-
-// LDSK = true selects the LDS-staged K loop (bf16 fragment-order A and W, 2 stages, one barrier per k-block): both
-// operand tiles arrive once per workgroup by global_load_lds (2 or 3 stages, one barrier per k-block) and every wave reads
-// its fragments from LDS.  For tiles wide
-// enough that the per-wave register ring cannot hold the operands (128 x 128), i.e. the many-row GEMMs of the
-// whole-sequence encoder.  The epilogues are shared.
+// LDSK = true selects the LDS-staged K loop (fragment-order A and W in the MFMA dtype, STAGES = 2..4 ring slots, one
+// barrier per k-block): both operand tiles arrive once per workgroup by global_load_lds and every wave reads its fragments
+// from LDS.  Two uses: (a) tiles too wide for the per-wave register ring (128 x 128: the many-row GEMMs of the
+// whole-sequence encoder; 2 slots measured best there, three workgroups per CU beat a deeper ring); (b) the 196-row
+// weight-streaming GEMMs of the per-frame step: 112- or 208-row tiles read each weight panel once or twice instead of
+// seven times (32-row tiles), which is what bounds those launches (L2 -> CU bytes), with a 3-4 slot ring because only
+// one workgroup fits a CU.  The epilogues are shared.
 // The hot 32x32 bf16 tile sits at the edge of 3 waves per SIMD (512 / 3 = 170 registers); small edits used to tip it
 // over to 2, which costs 10-25 % on the wide-N launches (tools/bench_block.py), so its register budget is pinned.
 template <typename TA, int LOADER, int MF, int NF, int WK>
 constexpr int gemm_min_waves() { return (sizeof(TA) == 2 && LOADER == SP3_LOAD_PLAIN && MF == 2 && NF == 2 && WK == 4) ? 3 : 1; }
 
-template <typename TA, typename TW, int LOADER, int MF, int NF, int WM, int WN, int WK, int STAGES, bool LDSK = false>
-__global__ __launch_bounds__(64 * WM * WN * WK, (gemm_min_waves<TA, LOADER, MF, NF, WK>())) void gemm_kernel(const GemmArgs args) {
+// LOOP: 0 = register ring, 1 = both operands through LDS (above), >= 2 = weight streaming with roles (below) and
+// LOOP loader waves.
+// LOOP >= 2 (the per-frame step's 196-row GEMMs with HBM-cold weights).  Measured on MI355X (tools/ubench/stream.hip, tools/
+// bench_gemm2.py): a CU pulls 40-50 B/clk of L2-hot data but every cold weight byte is ~3000 clk away, so a loop that
+// keeps its weights and activations in ONE in-order vmcnt queue runs at latency / ring depth per k-block.  Here the
+// queues are split by wave role: WM*WN*WK consumer waves keep their own weight fragments in a 12-k-block REGISTER ring
+// (plain loads, refilled right after use: 12 k-blocks of prefetch distance, compiler-counted waits), and NLOAD loader
+// waves do nothing but DMA the shared activation tile (BM x 64 per k-block) into a STAGES-slot LDS ring.
+// compile-time loop with early exit: f(integral_constant<int, I>) -> keep going?
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    if (f(std::integral_constant<int, I>{})) static_for<I + 1, N>(f);
+  }
+}
+
+constexpr int kWRing = 12;
+constexpr int kMaxKb = 64;                 // k-blocks per K slice the role loop is unrolled for (K / splitk <= 4096 in bf16)
+
+template <typename TA, typename TW, int LOADER, int MF, int NF, int WM, int WN, int WK, int STAGES, int LOOP = 0>
+__global__ __launch_bounds__(64 * (WM * WN * WK + (LOOP >= 2 ? LOOP : 0)), (gemm_min_waves<TA, LOADER, MF, NF, WK>()))
+void gemm_kernel(const GemmArgs args) {
   sp3_gemm_desc d = args.d;                  // local copy: grouped launches shift the per-problem pointers below
   using M_ = MM<TA, TW>;
-  constexpr int BM = MF * 16 * WM, BN = NF * 16 * WN, NT = 64 * WM * WN * WK;
+  constexpr bool LDSK = LOOP != 0;
+  constexpr int NCW = WM * WN * WK;          // consumer (MFMA) waves
+  constexpr int BM = MF * 16 * WM, BN = NF * 16 * WN, NT = 64 * (NCW + (LOOP >= 2 ? LOOP : 0));
   constexpr int KB = M_::KB, CH = M_::CH;
   constexpr int LDS_LD = BN + 4;
   extern __shared__ __attribute__((aligned(16))) float smem[];   // [WK][BM][LDS_LD]
@@ -329,7 +372,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, (gemm_min_waves<TA, LOADER, MF, 
       int nb = (n0 + wn * NF * 16 + n * 16) >> 4;
       const int nb_max = (d.N + 15) / 16 - 1;
       nb = nb < nb_max ? nb : nb_max;
-      wbase[n] = W + ((int64_t)nb * nkb_pad * 64 + lane) * CH;
+      wbase[n] = W + ((int64_t)nb * nkb_pad * 128 + lane) * (CH / 2);
     }
   } else {
     wstep = KB;
@@ -347,19 +390,38 @@ __global__ __launch_bounds__(64 * WM * WN * WK, (gemm_min_waves<TA, LOADER, MF, 
 #pragma unroll
     for (int n = 0; n < NF; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // Epilogue operands that depend on the column only (bias, LayerNorm column sums): NT is a multiple of BN/4, so a thread
+  // keeps one 4-column group through the whole epilogue -> request them NOW.  Every launch has its own vectors, cold in
+  // HBM: loaded in the epilogue they cost each workgroup a ~3000-clk round trip after its last MFMA.
+  static_assert(NT % (BN / 4) == 0, "epilogue column group must be fixed per thread");
+  const int ec4 = (tid % (BN / 4)) * 4;
+  const bool epre = (n0 + ec4 + 4) <= d.N && (d.N & 3) == 0 && d.epi != SP3_EPI_PIXSHUF;
+  float4 pre_b4 = make_float4(0.f, 0.f, 0.f, 0.f), pre_s4 = pre_b4;
+  if (epre) {
+    if (d.bias) pre_b4 = *reinterpret_cast<const float4*>(d.bias + n0 + ec4);
+    if (d.ln_stats) pre_s4 = *reinterpret_cast<const float4*>(d.ln_s + n0 + ec4);
+  }
+
   // Folded LayerNorm: the producer's per-32-column (sum, sum of squares) partials of this tile's rows are requested
   // BEFORE the K loop (TPR threads per row, 4 partials each in flight) and reduced after it: their latency hides
   // behind the GEMM instead of sitting between two barriers.
-  constexpr int TPR = NT / BM;                      // threads per tile row (8 or 4): a power of two, lane-aligned
+  // threads per tile row: the largest power of two (lane-aligned groups) with TPR * BM <= NT; spare threads idle here
+  constexpr int TPR = NT >= 8 * BM ? 8 : NT >= 4 * BM ? 4 : NT >= 2 * BM ? 2 : 1;
+  // partials requested up front per thread: 4 where registers are short (the register-ring tiles, the 128-row LDS tiles
+  // that live on three workgroups per CU); the weight-streaming LDS tiles take all of a 1024-wide row (32 groups)
+  constexpr int NPRE = (LDSK && STAGES >= 3) ? 32 / TPR : 4;
   const int srow = tid / TPR, sj = tid % TPR;
-  float2 sp[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+  float2 sp[NPRE];
+#pragma unroll
+  for (int q = 0; q < NPRE; ++q) sp[q] = make_float2(0.f, 0.f);
   const float2* sps = nullptr;
-  constexpr bool LNF = LOADER == SP3_LOAD_PLAIN;    // the conv loader never folds a LayerNorm (keeps its registers)
-  if (LNF && d.ln_stats) {
+  // the conv loader never folds a LayerNorm (keeps its registers); in the role loop the loader waves own the statistics
+  constexpr bool LNF = LOADER == SP3_LOAD_PLAIN && LOOP < 2;
+  if (LNF && d.ln_stats && srow < BM) {
     const int sgm = (m0 + srow) < d.M ? (m0 + srow) : d.M - 1;
     sps = reinterpret_cast<const float2*>(d.ln_stats) + (int64_t)sgm * d.ln_nt;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NPRE; ++q) {
       const int t = sj + q * TPR;
       sp[q] = sps[t < d.ln_nt ? t : d.ln_nt - 1];     // unconditional load, clamped; masked when summed
     }
@@ -394,11 +456,11 @@ __global__ __launch_bounds__(64 * WM * WN * WK, (gemm_min_waves<TA, LOADER, MF, 
       const unsigned im = inb ? 0xffffffffu : 0u;
       am0[st][m] = wm0[st] & im;
       am1[st][m] = wm1[st] & im;
-      M_::loadA(a[st][m], p, d.a_packed ? CH / 2 : off1);
+      M_::loadA(a[st][m], p, d.a_packed ? 64 * CH / 2 : off1);
     }
     // row-major W: same clamp as A (kc - g*CH is the k-block base); packed W is zero-padded to whole k-blocks
     const int64_t woff = d.w_packed ? (int64_t)kb * wstep : (int64_t)(kc - g * CH);
-    const int woff1 = d.w_packed ? CH / 2 : off1;
+    const int woff1 = d.w_packed ? 64 * CH / 2 : off1;
 #pragma unroll
     for (int n = 0; n < NF; ++n) M_::loadW(w[st][n], wbase[n] + woff, woff1);
   };
@@ -417,68 +479,245 @@ __global__ __launch_bounds__(64 * WM * WN * WK, (gemm_min_waves<TA, LOADER, MF, 
   using FullT = std::integral_constant<bool, true>;
   using TailT = std::integral_constant<bool, false>;
 
+  if constexpr (LOOP >= 2) {
+    constexpr int kLoaderWaves = LOOP;
+    static_assert(sizeof(TA) == sizeof(TW) && WK <= 2 && NF == 1 && WM == 1, "role loop: fragment-order operands, one column block per wave");
+    constexpr int MBLK = BM / 16, STAGE_BYTES = MBLK * 2048, NINSTR = 2 * MBLK;
+    constexpr int PER = (NINSTR + kLoaderWaves - 1) / kLoaderWaves, NST = STAGES;
+    static_assert(NST >= 2 && NST <= 4 && PER * (NST - 1) < 64, "activation ring: 2..4 slots");
+    char* lds_b = reinterpret_cast<char*>(smem);
+    const int nkb_a = (d.K + KB - 1) / KB;
+    const int nk = kb_hi - kb_lo;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    int64_t* tr = (d.trace && blockIdx.x < 8 && blockIdx.y == 0 && blockIdx.z == 0) ? d.trace + blockIdx.x * 64 : nullptr;
+    if (tr && tid == 0) { tr[0] = clock64(); tr[3] = wall_clock64(); }
+    if (wave_u >= NCW) {
+      // ---------------- loader waves: the activation tile, k-block by k-block, into the LDS ring
+      const int lw = wave_u - NCW;
+      const int rb_max = (d.M + 15) / 16 - 1;
+      const char* src[PER];
+      int dst[PER];
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        int j = lw + i * kLoaderWaves;
+        j = j < NINSTR ? j : NINSTR - 1;                  // surplus slot: repeats the last piece
+        int rb = (m0 >> 4) + (j >> 1);
+        rb = rb < rb_max ? rb : rb_max;                   // rows past M: re-read the last block (masked at the store)
+        src[i] = reinterpret_cast<const char*>(A + (int64_t)rb * nkb_a * (2048 / sizeof(TA))) + (j & 1) * 1024 + lane * 16;
+        dst[i] = j * 1024;
+      }
+      auto issue = [&](int slot, int kb) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) glds16(src[i] + (int64_t)kb * 2048, lds_b + slot * STAGE_BYTES + dst[i]);
+      };
+      if (tr && wave_u == NCW && lane == 0) tr[5] = clock64();
+#pragma unroll
+      for (int s_ = 0; s_ < NST - 1; ++s_)
+        if (s_ < nk) issue(s_, kb_lo + s_);
+      asm volatile("s_barrier" ::: "memory");             // the first activation stages are queued ahead of the weight flood
+      // folded LayerNorm: the loader waves own the row statistics (their registers are free; the consumers' hold the
+      // weight ring): one thread per row requests all per-32-column partials of the producer now, sums them after the loop
+      constexpr int RPT = (BM + 64 * kLoaderWaves - 1) / (64 * kLoaderWaves);
+      float2 lnp[RPT][32];
+      if (d.ln_stats) {
+#pragma unroll
+        for (int rr = 0; rr < RPT; ++rr) {
+          const int row = tid - 64 * NCW + rr * 64 * kLoaderWaves;
+          const int gm = (m0 + row) < d.M ? (m0 + row) : d.M - 1;          // clamped, unconditional loads
+          const float2* ps = reinterpret_cast<const float2*>(d.ln_stats) + (int64_t)gm * d.ln_nt;
+#pragma unroll
+          for (int q = 0; q < 32; ++q) lnp[rr][q] = ps[q < d.ln_nt ? q : d.ln_nt - 1];
+        }
+      }
+      int fill = NST - 1;
+      for (int i = 0; i < nk; ++i) {
+        const int ahead = nk - 1 - i;
+        const int pending = ahead < NST - 2 ? ahead : NST - 2;
+        if (pending >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+        else if (pending == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (tr && wave_u == NCW && lane == 0 && i == 0) tr[6] = clock64();
+        asm volatile("s_barrier" ::: "memory");           // stage i visible to the consumers; slot of stage i-1 is free
+        if (tr && wave_u == NCW && lane == 0 && (i & 3) == 0 && i < 96) tr[8 + (i >> 2)] = clock64();
+        if (i + NST - 1 < nk) issue(fill, kb_lo + i + NST - 1);
+        fill = fill + 1 == NST ? 0 : fill + 1;
+      }
+      // folded LayerNorm: finish mean / rstd of the tile's rows (partials requested before the DMA loop).  rowstat sits
+      // behind the epilogue slabs, beyond the ring, so writing it while the consumers still multiply is safe.
+      if (d.ln_stats) {
+        float* rs = smem + (size_t)WK * BM * LDS_LD;
+#pragma unroll
+        for (int rr = 0; rr < RPT; ++rr) {
+          const int row = tid - 64 * NCW + rr * 64 * kLoaderWaves;
+          if (row < BM) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int q = 0; q < 32; ++q)
+              if (q < d.ln_nt) { s1 += lnp[rr][q].x; s2 += lnp[rr][q].y; }
+            const float mean = s1 / (float)d.ln_C;
+            const float var = fmaxf(s2 / (float)d.ln_C - mean * mean, 0.f);
+            rs[2 * row] = mean;
+            rs[2 * row + 1] = 1.0f / sqrtf(var + d.ln_eps);
+          }
+        }
+      }
+    } else {
+      // ---------------- consumer waves: own weight fragments in registers, activations from the LDS ring
+      using W16 = std::remove_reference_t<decltype(((typename M_::WReg*)nullptr)->v[0])>;
+      using V16 = std::remove_reference_t<decltype(((typename M_::AReg*)nullptr)->v[0])>;
+      static_assert(sizeof(W16) == 16 && sizeof(V16) == 16, "fragment halves are 16 bytes");
+      const int nkb_w = (d.K + KB - 1) / KB;
+      int nb = (n0 >> 4) + wn;
+      const int nb_max = (d.N + 15) / 16 - 1;
+      nb = nb < nb_max ? nb : nb_max;
+      // WK = 2: the pair splits every k-block by its two 1 KB halves
+      const int hoff = WK == 2 ? wk * 1024 : 0;
+      const char* wsrc = reinterpret_cast<const char*>(W + (int64_t)nb * nkb_w * (2048 / sizeof(TW))) + lane * 16;
+      W16 wr[kWRing][WK == 2 ? 1 : 2];
+      auto loadw = [&](int slot, int kb) {                // kb clamped by the caller
+        const char* q = wsrc + (int64_t)kb * 2048;
+        wr[slot][0] = *reinterpret_cast<const W16*>(q + hoff);
+        if constexpr (WK == 1) wr[slot][1] = *reinterpret_cast<const W16*>(q + 1024);
+      };
+      const int kb_last = kb_hi - 1;
+      // the first kWHead k-blocks of weights go out at once; the rest of the ring waits until the loaders have queued their
+      // first activation stages (the memory pipe of a CU is first come, first served: behind 128 KB of cold weight
+      // requests the first activation stage used to land ~6000 clk late)
+      constexpr int kWHead = 4;
+#pragma unroll
+      for (int s_ = 0; s_ < kWHead; ++s_) { const int kb = kb_lo + s_; loadw(s_, kb < kb_last ? kb : kb_last); }
+      asm volatile("s_barrier" ::: "memory");
+#pragma unroll
+      for (int s_ = kWHead; s_ < kWRing; ++s_) { const int kb = kb_lo + s_; loadw(s_, kb < kb_last ? kb : kb_last); }
+      if (tr && tid == 0) tr[7] = clock64();
+      // Fully unrolled over the k-blocks of the slice (<= kMaxKb; uniform early exit): straight-line code lets hipcc count
+      // the register loads exactly -- inside a real loop its waitcnt pass drains the whole ring at every back edge.
+      // Software-pipelined over the LDS ring: step i first passes the barrier of stage i+1 and requests ITS activation
+      // fragments, then multiplies stage i from the registers filled one step earlier (ds_read latency hides under MFMAs).
+      // The lgkmcnt(0) in front of each barrier retires the reads of the stage whose slot the loaders refill next.
+      typename M_::AReg af[2][MF];
+      auto read_a = [&](int buf, int stage) {
+        const char* st = lds_b + (stage % NST) * STAGE_BYTES + lane * 16;
+#pragma unroll
+        for (int m = 0; m < MF; ++m) {
+          af[buf][m].v[0] = *reinterpret_cast<const V16*>(st + m * 2048 + hoff);
+          if constexpr (WK == 1) af[buf][m].v[1] = *reinterpret_cast<const V16*>(st + m * 2048 + 1024);
+        }
+      };
+      asm volatile("s_barrier" ::: "memory");             // stage 0 landed
+      read_a(0, 0);
+      static_for<0, kMaxKb>([&](auto ic) -> bool {
+        constexpr int i = decltype(ic)::value;
+        if (i >= nk) return false;                        // wave-uniform
+        if (i + 1 < nk) {
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          read_a((i + 1) & 1, i + 1);
+        }
+        typename M_::WReg wf[1];
+        wf[0].v[0] = wr[i % kWRing][0];
+        if constexpr (WK == 1) { wf[0].v[1] = wr[i % kWRing][1]; M_::template mma<MF, 1>(acc, af[i & 1], wf); }
+        else M_::template mma_half<MF, 1>(acc, af[i & 1], wf);
+        if (i + kWRing < kMaxKb) {                        // refill this register slot kWRing k-blocks ahead: unconditional
+          const int kn = kb_lo + i + kWRing;              // (clamped) -- a predicated load would drain the queue
+          loadw(i % kWRing, kn < kb_last ? kn : kb_last);
+        }
+        if constexpr ((i & 3) == 0) {
+          if (tr && tid == 0) { asm volatile("" ::"v"(acc[0][0][0])); tr[32 + (i >> 2)] = clock64(); }
+        }
+        return true;
+      });
+    }
+    if (tr && tid == 0) tr[1] = clock64();
+    __syncthreads();                                     // the ring is dead: the epilogue slab re-uses its bytes
+  } else
   if constexpr (LDSK) {
     // ---- LDS-staged K loop.  Stage = BM/16 A blocks + BN/16 W blocks of 2 KB (one fragment block = 64 lanes x 32 B, the
     // same bytes in HBM and in LDS, so the DMA's "wave-uniform base + lane * 16" destination needs no address math).
-    static_assert(WK == 1 && std::is_same<TA, __bf16>::value && std::is_same<TW, __bf16>::value, "LDS-staged loop: bf16, WK = 1");
-    constexpr int NBLK = BM / 16 + BN / 16, STAGE_BYTES = NBLK * 2048, PER_WAVE = NBLK / (NT / 64);
-    static_assert(NBLK % (NT / 64) == 0, "blocks must divide over the waves");
+    // A stage is moved by 2*NBLK DMA instructions of 1 KB, dealt round-robin to the waves; when they do not divide evenly
+    // the surplus slots repeat the last piece (same bytes to the same place), so every wave issues exactly PER
+    // instructions per stage and the hand-counted vmcnt below is the same constant for all of them.
+    static_assert(sizeof(TA) == sizeof(TW), "LDS-staged loop: A and W in the MFMA dtype (fragment order)");
+    constexpr int NW = NT / 64;
+    constexpr int NBLK = BM / 16 + BN / 16, STAGE_BYTES = NBLK * 2048, NINSTR = 2 * NBLK, PER = (NINSTR + NW - 1) / NW;
+    constexpr int NST = STAGES;
+    static_assert(NST >= 2 && NST <= 4 && PER * (NST - 1) < 64, "stage ring: 2..4 stages, vmcnt is a 6-bit count");
     char* lds_b = reinterpret_cast<char*>(smem);
     const int nkb_pad = (d.K + KB - 1) / KB;
     const int rb_max = (d.M + 15) / 16 - 1, nb_max = (d.N + 15) / 16 - 1;
-    const char* src[PER_WAVE];
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const char* src[PER];
+    int dst[PER];
 #pragma unroll
-    for (int i = 0; i < PER_WAVE; ++i) {
-      const int blk = wave * PER_WAVE + i;              // 0 .. NBLK-1: A row blocks first, then W column blocks
+    for (int i = 0; i < PER; ++i) {
+      int j = wave_u + i * NW;                            // piece 0 .. NINSTR-1: A row blocks first, then W column blocks
+      j = j < NINSTR ? j : NINSTR - 1;
+      const int blk = j >> 1;
+      const char* base;
       if (blk < BM / 16) {
         int rb = (m0 >> 4) + blk;
-        rb = rb < rb_max ? rb : rb_max;                 // rows past M: re-read the last block (masked at the store)
-        src[i] = reinterpret_cast<const char*>(A + (int64_t)rb * nkb_pad * 1024) + lane * 16;
+        rb = rb < rb_max ? rb : rb_max;                   // rows past M: re-read the last block (masked at the store)
+        base = reinterpret_cast<const char*>(A + (int64_t)rb * nkb_pad * (2048 / sizeof(TA)));
       } else {
         int nb = (n0 >> 4) + blk - BM / 16;
         nb = nb < nb_max ? nb : nb_max;
-        src[i] = reinterpret_cast<const char*>(W + (int64_t)nb * nkb_pad * 1024) + lane * 16;
+        base = reinterpret_cast<const char*>(W + (int64_t)nb * nkb_pad * (2048 / sizeof(TW)));
       }
+      src[i] = base + (j & 1) * 1024 + lane * 16;
+      dst[i] = j * 1024;
     }
-    auto issue = [&](int stage, int kb) {
+    auto issue = [&](int slot, int kb) {
 #pragma unroll
-      for (int i = 0; i < PER_WAVE; ++i) {
-        const char* g0 = src[i] + (int64_t)kb * 2048;
-        char* l0 = lds_b + stage * STAGE_BYTES + (wave * PER_WAVE + i) * 2048;
-        glds16(g0, l0);
-        glds16(g0 + 1024, l0 + 1024);
-      }
+      for (int i = 0; i < PER; ++i) glds16(src[i] + (int64_t)kb * 2048, lds_b + slot * STAGE_BYTES + dst[i]);
     };
-    // NST stages: k-blocks kb .. kb+NST-2 are in flight while kb is multiplied.  Waits are counted by hand (hipcc cannot see what a DMA wrote): this wave's loads
-    // retire in order, so "all but the newest stage's 2*PER_WAVE loads" means stage kb has landed; the barrier then makes
-    // every wave's share visible and proves nobody still reads the stage that is refilled next.
-    constexpr int NST = LDSK_STAGES<BM, BN>::value, LOADS = 2 * PER_WAVE;
+    // NST stages: while k-block i is multiplied, i+1 .. i+NST-2 are in flight and i+NST-1 is issued.  Waits are counted by
+    // hand (hipcc cannot see what a DMA wrote): this wave's loads retire in order, so "at most `pending` stages' worth
+    // outstanding" means stage i has landed; the barrier then makes every wave's share visible and proves nobody still
+    // reads the slot that is refilled next (it was multiplied in iteration i-1).
+    const int nk = kb_hi - kb_lo;
 #pragma unroll
     for (int s_ = 0; s_ < NST - 1; ++s_)
-      if (kb_lo + s_ < kb_hi) issue(s_, kb_lo + s_);
-    for (int kb = kb_lo; kb < kb_hi; ++kb) {
-      const int i = kb - kb_lo;
-      const int stage = i % NST;
-      if (NST == 3 && kb + 1 < kb_hi) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+      if (s_ < nk) issue(s_, kb_lo + s_);
+    int slot = 0, fill = NST - 1;
+    for (int i = 0; i < nk; ++i) {
+      const int ahead = nk - 1 - i;
+      const int pending = ahead < NST - 2 ? ahead : NST - 2;
+      if (pending >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+      else if (pending == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      if (kb + NST - 1 < kb_hi) issue((i + NST - 1) % NST, kb + NST - 1);
-      const char* st = lds_b + stage * STAGE_BYTES + lane * 32;
+      if (i + NST - 1 < nk) issue(fill, kb_lo + i + NST - 1);
+      const char* st = lds_b + slot * STAGE_BYTES + lane * 16;
       typename M_::AReg af[MF];
       typename M_::WReg wf[NF];
+      using V16 = std::remove_reference_t<decltype(af[0].v[0])>;
+      using W16 = std::remove_reference_t<decltype(wf[0].v[0])>;
+      static_assert(sizeof(V16) == 16 && sizeof(W16) == 16, "fragment halves are 16 bytes");
+      if constexpr (WK == 1) {
 #pragma unroll
-      for (int m = 0; m < MF; ++m) {
-        const char* q = st + (wm * MF + m) * 2048;
-        af[m].v[0] = *reinterpret_cast<const bf16x8*>(q);
-        af[m].v[1] = *reinterpret_cast<const bf16x8*>(q + 16);
-      }
+        for (int m = 0; m < MF; ++m) {
+          const char* q = st + (wm * MF + m) * 2048;
+          af[m].v[0] = *reinterpret_cast<const V16*>(q);
+          af[m].v[1] = *reinterpret_cast<const V16*>(q + 1024);
+        }
 #pragma unroll
-      for (int n = 0; n < NF; ++n) {
-        const char* q = st + (BM / 16 + wn * NF + n) * 2048;
-        wf[n].v[0] = *reinterpret_cast<const bf16x8*>(q);
-        wf[n].v[1] = *reinterpret_cast<const bf16x8*>(q + 16);
+        for (int n = 0; n < NF; ++n) {
+          const char* q = st + (BM / 16 + wn * NF + n) * 2048;
+          wf[n].v[0] = *reinterpret_cast<const W16*>(q);
+          wf[n].v[1] = *reinterpret_cast<const W16*>(q + 1024);
+        }
+        M_::template mma<MF, NF>(acc, af, wf);
+      } else {
+        // WK = 2: the two waves of a pair split the contraction inside the k-block (one 1 KB half each)
+        static_assert(WK <= 2, "LDS-staged loop: K over at most 2 waves");
+        const int hoff = wk * 1024;
+#pragma unroll
+        for (int m = 0; m < MF; ++m) af[m].v[0] = *reinterpret_cast<const V16*>(st + (wm * MF + m) * 2048 + hoff);
+#pragma unroll
+        for (int n = 0; n < NF; ++n) wf[n].v[0] = *reinterpret_cast<const W16*>(st + (BM / 16 + wn * NF + n) * 2048 + hoff);
+        M_::template mma_half<MF, NF>(acc, af, wf);
       }
-      M_::template mma<MF, NF>(acc, af, wf);
+      slot = slot + 1 == NST ? 0 : slot + 1;
+      fill = fill + 1 == NST ? 0 : fill + 1;
     }
     __syncthreads();                                     // the stages are dead: the epilogue slab re-uses their bytes
   } else
@@ -524,7 +763,7 @@ __global__ __launch_bounds__(64 * WM * WN * WK, (gemm_min_waves<TA, LOADER, MF, 
   }
 
   // ---- accumulators -> LDS (C layout: col = lane&15, row = 4*(lane>>4) + reg)
-  {
+  if (LOOP < 2 || wave < NCW) {
     float* slab = smem + (size_t)wk * BM * LDS_LD;
 #pragma unroll
     for (int m = 0; m < MF; ++m)
@@ -539,12 +778,12 @@ __global__ __launch_bounds__(64 * WM * WN * WK, (gemm_min_waves<TA, LOADER, MF, 
   }
   // folded LayerNorm: finish mean / rstd of this tile's rows (rowstat does not alias the slabs: one barrier covers both)
   float* rowstat = smem + (size_t)WK * BM * LDS_LD;     // [BM][2]
-  if (LNF && d.ln_stats) {
+  if (LNF && d.ln_stats && srow < BM) {
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < NPRE; ++q)
       if (sj + q * TPR < d.ln_nt) { s1 += sp[q].x; s2 += sp[q].y; }
-    for (int t = sj + 4 * TPR; t < d.ln_nt; t += TPR) { const float2 v = sps[t]; s1 += v.x; s2 += v.y; }
+    for (int t = sj + NPRE * TPR; t < d.ln_nt; t += TPR) { const float2 v = sps[t]; s1 += v.x; s2 += v.y; }
 #pragma unroll
     for (int o_ = 1; o_ < TPR; o_ <<= 1) { s1 += __shfl_xor(s1, o_); s2 += __shfl_xor(s2, o_); }
     if (sj == 0) {
@@ -555,6 +794,9 @@ __global__ __launch_bounds__(64 * WM * WN * WK, (gemm_min_waves<TA, LOADER, MF, 
     }
   }
   __syncthreads();
+  if constexpr (LOOP >= 2) {
+    if (d.trace && blockIdx.x < 8 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) d.trace[blockIdx.x * 64 + 48] = clock64();
+  }
 
   // y = rstd * acc - rstd * mean * s[n]   (bias, already folded with beta . W^T, is added by the epilogues below)
   auto ln_fold = [&](float acc, int row, int gn) -> float {
@@ -657,7 +899,105 @@ __global__ __launch_bounds__(64 * WM * WN * WK, (gemm_min_waves<TA, LOADER, MF, 
     return;
   }
 
+  // ---------------- plain epilogue of the LDS-staged / role tiles: a thread keeps ONE column group (NT is a multiple of
+  // BN/4) and walks the rows, so bias and the LayerNorm column sums are loaded once, and the residual rows of all its
+  // iterations are requested up front (in the generic loop below every iteration is a dependent L2 round trip: loads of
+  // iteration i+1 cannot be hoisted above the stores of iteration i)
+  if constexpr (LDSK && (NT % (BN / 4)) == 0) {
+    constexpr int CG = BN / 4, RSTEP = NT / CG, ITER = (BM + RSTEP - 1) / RSTEP;
+    if (d.epi == SP3_EPI_PLAIN && (d.N & 3) == 0 && ITER <= 4) {
+      const int c4 = ec4, gn = n0 + c4, row0 = tid / CG;
+      if (gn < d.N) {
+        const float4 b4 = pre_b4, s4 = pre_s4;            // (N % 4 == 0: the group is whole, epre held)
+        float4 r1[ITER], r2[ITER];
+        int gmc[ITER];
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+          const int gm = m0 + row0 + it * RSTEP;
+          gmc[it] = gm < d.M ? gm : d.M - 1;              // clamped: unconditional loads
+          r1[it] = r2[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (d.res1) {
+#pragma unroll
+          for (int it = 0; it < ITER; ++it) r1[it] = *reinterpret_cast<const float4*>(d.res1 + ((int64_t)bz * d.M + gmc[it]) * d.ldr1 + gn);
+        }
+        if (d.res2) {
+#pragma unroll
+          for (int it = 0; it < ITER; ++it) r2[it] = *reinterpret_cast<const float4*>(d.res2 + ((int64_t)bz * d.M + gmc[it]) * d.ldr2 + gn);
+        }
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+          const int row = row0 + it * RSTEP, gm = m0 + row;
+          if (row < BM && gm < d.M) {
+            const float4 a4 = lds_sum4(row, c4);
+            float v[4] = {a4.x * alpha, a4.y * alpha, a4.z * alpha, a4.w * alpha};
+            if (d.ln_stats) {
+              const float mean = rowstat[2 * row], rstd = rowstat[2 * row + 1], rm = rstd * mean;
+              v[0] = rstd * v[0] - rm * s4.x; v[1] = rstd * v[1] - rm * s4.y;
+              v[2] = rstd * v[2] - rm * s4.z; v[3] = rstd * v[3] - rm * s4.w;
+            }
+            v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+            if (d.act == SP3_ACT_GELU) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+            } else if (d.act == SP3_ACT_RELU) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            v[0] += r1[it].x + r2[it].x; v[1] += r1[it].y + r2[it].y; v[2] += r1[it].z + r2[it].z; v[3] += r1[it].w + r2[it].w;
+            if (d.stats_out) {
+              float s1 = (v[0] + v[1]) + (v[2] + v[3]);
+              float s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+#pragma unroll
+              for (int o_ = 1; o_ < 8; o_ <<= 1) { s1 += __shfl_xor(s1, o_); s2 += __shfl_xor(s2, o_); }
+              if (((gn >> 2) & 7) == 0)
+                reinterpret_cast<float2*>(d.stats_out)[(int64_t)gm * (d.N >> 5) + (gn >> 5)] = make_float2(s1, s2);
+            }
+            if (d.c2) {
+              const bool cb = d.wdtype == SP3_BF16;
+              const int64_t o2 = packed_off(gm, gn, d.N, cb);
+              if (cb) {
+                bf16x4 ob;
+                ob[0] = (__bf16)v[0]; ob[1] = (__bf16)v[1]; ob[2] = (__bf16)v[2]; ob[3] = (__bf16)v[3];
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(d.c2) + o2) = ob;
+              } else {
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(d.c2) + o2) = make_float4(v[0], v[1], v[2], v[3]);
+              }
+            }
+            const int64_t off = d.out_packed ? packed_off(gm, gn, d.N, d.out_bf16 != 0) : (int64_t)bz * d.strideC + (int64_t)gm * d.ldc + gn;
+            if (d.out_bf16) {
+              __bf16* o = reinterpret_cast<__bf16*>(d.C) + off;
+              bf16x4 ob;
+              ob[0] = (__bf16)v[0]; ob[1] = (__bf16)v[1]; ob[2] = (__bf16)v[2]; ob[3] = (__bf16)v[3];
+              if ((off & 3) == 0) *reinterpret_cast<bf16x4*>(o) = ob;
+              else { o[0] = ob[0]; o[1] = ob[1]; o[2] = ob[2]; o[3] = ob[3]; }
+            } else {
+              float* o = reinterpret_cast<float*>(d.C) + off;
+              if ((off & 3) == 0) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+              else { o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3]; }
+            }
+          }
+        }
+      }
+      if constexpr (LOOP >= 2) {
+        if (d.trace && blockIdx.x < 8 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) {
+          d.trace[blockIdx.x * 64 + 2] = clock64();
+          d.trace[blockIdx.x * 64 + 4] = wall_clock64();
+        }
+      }
+      return;
+    }
+  }
+
+  const bool rope_epi = d.epi == SP3_EPI_ROPE_VT;
   for (int idx = tid; idx < BM * (BN / 4); idx += NT) {
+    // RoPE pairs column c with c ^ 16: the partner group's bias / column sums sit 4 lanes away (whole waves enter an
+    // iteration together: BM * BN / 4 is a multiple of 64), so they are fetched by shuffle instead of a second cold load
+    float4 pb4 = pre_b4, ps4 = pre_s4;
+    if (rope_epi) {
+      pb4 = make_float4(__shfl_xor(pre_b4.x, 4), __shfl_xor(pre_b4.y, 4), __shfl_xor(pre_b4.z, 4), __shfl_xor(pre_b4.w, 4));
+      ps4 = make_float4(__shfl_xor(pre_s4.x, 4), __shfl_xor(pre_s4.y, 4), __shfl_xor(pre_s4.z, 4), __shfl_xor(pre_s4.w, 4));
+    }
     const int row = idx / (BN / 4), c4 = (idx % (BN / 4)) * 4;
     const int gm = m0 + row, gn = n0 + c4;
     if (gm >= d.M || gn >= d.N) continue;
@@ -681,8 +1021,20 @@ __global__ __launch_bounds__(64 * WM * WN * WK, (gemm_min_waves<TA, LOADER, MF, 
       const int hc = gn & 63;
       const int axis = hc >> 5, is_v = (hc >> 4) & 1, i0 = hc & 15;
       const int pos = d.pos[(int64_t)gm * 2 + axis];
-      if (d.ln_stats) { ln_fold4(v, row, gn); ln_fold4(pv, row, gn ^ 16); }
-      if (d.bias) { add4(v, d.bias + gn); add4(pv, d.bias + (gn ^ 16)); }
+      if (epre) {
+        if (d.ln_stats) {
+          const float mean = rowstat[2 * row], rstd = rowstat[2 * row + 1], rm = rstd * mean;
+          v[0] = rstd * v[0] - rm * pre_s4.x; v[1] = rstd * v[1] - rm * pre_s4.y;
+          v[2] = rstd * v[2] - rm * pre_s4.z; v[3] = rstd * v[3] - rm * pre_s4.w;
+          pv[0] = rstd * pv[0] - rm * ps4.x; pv[1] = rstd * pv[1] - rm * ps4.y;
+          pv[2] = rstd * pv[2] - rm * ps4.z; pv[3] = rstd * pv[3] - rm * ps4.w;
+        }
+        v[0] += pre_b4.x; v[1] += pre_b4.y; v[2] += pre_b4.z; v[3] += pre_b4.w;
+        pv[0] += pb4.x; pv[1] += pb4.y; pv[2] += pb4.z; pv[3] += pb4.w;
+      } else {
+        if (d.ln_stats) { ln_fold4(v, row, gn); ln_fold4(pv, row, gn ^ 16); }
+        if (d.bias) { add4(v, d.bias + gn); add4(pv, d.bias + (gn ^ 16)); }
+      }
       const float4 cs4 = *reinterpret_cast<const float4*>(d.rope_cos + pos * 16 + i0);
       const float4 sn4 = *reinterpret_cast<const float4*>(d.rope_sin + pos * 16 + i0);
       const float cs[4] = {cs4.x, cs4.y, cs4.z, cs4.w}, sn[4] = {sn4.x, sn4.y, sn4.z, sn4.w};
@@ -709,7 +1061,14 @@ __global__ __launch_bounds__(64 * WM * WN * WK, (gemm_min_waves<TA, LOADER, MF, 
     }
 
     // bias + activation
-    if (nvalid == 4 && d.epi != SP3_EPI_PIXSHUF) {
+    if (epre) {                                           // c4 == ec4 for every iteration of this thread
+      if (d.ln_stats) {
+        const float mean = rowstat[2 * row], rstd = rowstat[2 * row + 1], rm = rstd * mean;
+        v[0] = rstd * v[0] - rm * pre_s4.x; v[1] = rstd * v[1] - rm * pre_s4.y;
+        v[2] = rstd * v[2] - rm * pre_s4.z; v[3] = rstd * v[3] - rm * pre_s4.w;
+      }
+      v[0] += pre_b4.x; v[1] += pre_b4.y; v[2] += pre_b4.z; v[3] += pre_b4.w;
+    } else if (nvalid == 4 && d.epi != SP3_EPI_PIXSHUF) {
       if (d.ln_stats) ln_fold4(v, row, gn);
       if (d.bias) add4(v, d.bias + gn);
     } else {
@@ -795,21 +1154,28 @@ __global__ __launch_bounds__(64 * WM * WN * WK, (gemm_min_waves<TA, LOADER, MF, 
       }
     }
   }
+  if constexpr (LOOP >= 2) {
+    if (d.trace && blockIdx.x < 8 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) {
+      d.trace[blockIdx.x * 64 + 2] = clock64();
+      d.trace[blockIdx.x * 64 + 4] = wall_clock64();
+    }
+  }
 }
 
-template <typename TA, typename TW, int LOADER, int MF, int NF, int WM, int WN, int WK, int STAGES, bool LDSK = false>
+template <typename TA, typename TW, int LOADER, int MF, int NF, int WM, int WN, int WK, int STAGES, int LOOP = 0>
 int launch(const sp3_gemm_desc& d, hipStream_t stream) {
-  constexpr int BM = MF * 16 * WM, BN = NF * 16 * WN, NT = 64 * WM * WN * WK;
+  constexpr bool LDSK = LOOP != 0;
+  constexpr int BM = MF * 16 * WM, BN = NF * 16 * WN, NT = 64 * (WM * WN * WK + (LOOP >= 2 ? LOOP : 0));
   const int mt = (d.M + BM - 1) / BM, nt = (d.N + BN - 1) / BN;
   int blocks;
   if (mt >= nt) blocks = ((mt + 7) / 8) * 8 * nt;
   else blocks = ((nt + 7) / 8) * 8 * mt;
   size_t lds = ((size_t)WK * BM * (BN + 4) + 2 * BM) * sizeof(float);
   if (LDSK) {
-    const size_t stages = (size_t)LDSK_STAGES<BM, BN>::value * (BM / 16 + BN / 16) * 2048;      // the epilogue slab aliases the stages
+    const size_t stages = (size_t)STAGES * (BM / 16 + (LOOP >= 2 ? 0 : BN / 16)) * 2048;      // the epilogue slab aliases the ring
     lds = lds > stages ? lds : stages;
   }
-  auto kern = gemm_kernel<TA, TW, LOADER, MF, NF, WM, WN, WK, STAGES, LDSK>;
+  auto kern = gemm_kernel<TA, TW, LOADER, MF, NF, WM, WN, WK, STAGES, LOOP>;
   if (lds > 64 * 1024) {
     static bool raised = false;     // one-time opt-in to > 64 KiB of dynamic LDS for this instantiation
     if (!raised) {
@@ -832,19 +1198,40 @@ int dispatch_tile(const sp3_gemm_desc& d, int tile, hipStream_t stream) {
     case 1: return launch<TA, TW, LOADER, 2, 2, 2, 2, 1, 2>(d, stream);   // 64x64, wave tile 32x32
     case 2: return launch<TA, TW, LOADER, 2, 4, 2, 2, 1, 2>(d, stream);   // 64x128, wave tile 32x64
     case 3: return launch<TA, TW, LOADER, 4, 4, 1, 1, 4, 3>(d, stream);   // 64x64, K over 4 waves
-    case 5:                                                                // 128x128, LDS-staged operands (2x2 waves of 64x64)
-      if constexpr (std::is_same<TA, __bf16>::value && std::is_same<TW, __bf16>::value && LOADER == SP3_LOAD_PLAIN) {
-        if (d.a_packed && d.w_packed && !d.A2 && d.splitk == 1 && d.K % 64 == 0)
-          return launch<TA, TW, LOADER, 4, 4, 2, 2, 1, 2, true>(d, stream);
+    case 5: case 6: case 7: case 8: case 9: case 10: case 11: case 12: case 13: case 14: case 15: case 16: case 17:     // LDS-staged operands
+      if constexpr (sizeof(TA) == sizeof(TW) && LOADER == SP3_LOAD_PLAIN) {
+        if (d.a_packed && d.w_packed && !d.A2 && d.K % MM<TA, TW>::KB == 0) {
+          switch (tile) {
+            case 5: return launch<TA, TW, LOADER, 4, 4, 2, 2, 1, 2, 1>(d, stream);    // 128x128, 2x2 waves of 64x64
+            case 6: return launch<TA, TW, LOADER, 4, 2, 2, 2, 1, 2, 1>(d, stream);    // 128x64,  2x2 waves of 64x32
+            case 7: return launch<TA, TW, LOADER, 7, 1, 1, 4, 1, 4, 1>(d, stream);    // 112x64,  4 waves of 112x16, 4 slots
+            case 8: return launch<TA, TW, LOADER, 13, 1, 1, 4, 1, 3, 1>(d, stream);   // 208x64,  4 waves of 208x16, 3 slots
+            case 9: return launch<TA, TW, LOADER, 7, 1, 1, 2, 1, 4, 1>(d, stream);    // 112x32,  2 waves of 112x16, 4 slots
+            case 10: return launch<TA, TW, LOADER, 7, 2, 1, 2, 1, 4, 1>(d, stream);   // 112x64,  2 waves of 112x32, 4 slots
+            case 11: return launch<TA, TW, LOADER, 7, 1, 1, 4, 2, 4, 1>(d, stream);   // 112x64,  4x2 waves (K halves), 4 slots
+            case 12: return launch<TA, TW, LOADER, 13, 1, 1, 4, 2, 3, 1>(d, stream);  // 208x64,  4x2 waves (K halves), 3 slots
+            // weight streaming with roles: consumers keep their weights in a register ring, 2 loader waves DMA the activations
+            default: break;
+          }
+          const int nkb_slice = ((d.K / MM<TA, TW>::KB) + d.splitk - 1) / d.splitk;
+          if (d.ln_stats && d.ln_nt > 32) {
+            sp3_set_error("sp3_gemm: tile %d folds a LayerNorm over at most 1024 columns (ln_C=%d)", tile, d.ln_C);
+            return 1;
+          }
+          if (nkb_slice > kMaxKb) {
+            sp3_set_error("sp3_gemm: tile %d streams at most %d k-blocks per K slice (K=%d, splitk=%d)", tile, kMaxKb, d.K, d.splitk);
+            return 1;
+          }
+          if constexpr (sizeof(TA) == 2) switch (tile) {      // bf16 only (the fp32 mode is MFMA-bound, not weight-bound)
+            case 13: return launch<TA, TW, LOADER, 7, 1, 1, 4, 2, 4, 2>(d, stream);   // 112x64,  4x2 consumer waves + 2 loaders
+            case 14: return launch<TA, TW, LOADER, 7, 1, 1, 4, 1, 4, 2>(d, stream);   // 112x64,  4 consumer waves + 2 loaders
+            case 15: return launch<TA, TW, LOADER, 13, 1, 1, 4, 2, 3, 2>(d, stream);  // 208x64,  4x2 consumer waves + 2 loaders
+            case 16: return launch<TA, TW, LOADER, 7, 1, 1, 4, 1, 4, 6>(d, stream);   // 112x64,  4 consumer waves + 6 loaders
+            case 17: return launch<TA, TW, LOADER, 7, 1, 1, 4, 2, 4, 4>(d, stream);   // 112x64,  4x2 consumer waves + 4 loaders
+          }
+        }
       }
-      sp3_set_error("sp3_gemm: tile 5 (128x128, LDS-staged) needs bf16 fragment-order A and W, K %% 64 == 0, no split");
-      return 1;
-    case 6:                                                                // 128x64, LDS-staged operands (2x2 waves of 64x32)
-      if constexpr (std::is_same<TA, __bf16>::value && std::is_same<TW, __bf16>::value && LOADER == SP3_LOAD_PLAIN) {
-        if (d.a_packed && d.w_packed && !d.A2 && d.splitk == 1 && d.K % 64 == 0)
-          return launch<TA, TW, LOADER, 4, 2, 2, 2, 1, 2, true>(d, stream);
-      }
-      sp3_set_error("sp3_gemm: tile 6 (128x64, LDS-staged) needs bf16 fragment-order A and W, K %% 64 == 0, no split");
+      sp3_set_error("sp3_gemm: tile %d (LDS-staged) needs fragment-order A and W in the MFMA dtype, whole k-blocks, no split A", tile);
       return 1;
     default: sp3_set_error("sp3_gemm: bad tile %d", tile); return 1;
   }
@@ -916,12 +1303,19 @@ extern "C" int sp3_gemm(const sp3_gemm_desc* dp, void* stream_) {
     const long sk = d.splitk;
     const long t64 = (long)((d.M + 63) / 64) * ((d.N + 63) / 64) * d.batch * sk;
     const long t128 = (long)((d.M + 63) / 64) * ((d.N + 127) / 128) * d.batch;
-    if (d.loader != SP3_LOAD_CONV3X3 && d.M >= 1024 && sk == 1 && d.a_packed && d.w_packed && d.a_bf16 && !d.A2 &&
-        d.epi != SP3_EPI_PARTIAL && d.N >= 3072 && d.N % 128 == 0 && d.K % 64 == 0 && d.batch == 1) {
-      // LDS-staged operands: 128x128 for large grids / N multiple of 4096, else 128x64 (tools/bench_gemm.py --M 1960)
-      tile = (d.N % 4096 == 0 || (long)((d.M + 127) / 128) * (d.N / 128) >= 1024) ? 5 : 6;
+    const bool lds_ok = d.loader != SP3_LOAD_CONV3X3 && sk == 1 && d.a_packed && d.w_packed && d.a_bf16 && !d.A2 &&
+                        d.epi != SP3_EPI_PARTIAL && d.K % 64 == 0;
+    if (lds_ok && d.M >= 1024 && d.N >= 2304 && d.N % 128 == 0) {
+      // LDS-staged operands (tools/bench_gemm2.py --big, HBM-cold weights, also grouped launches): 128x128 for large grids
+      // / N multiple of 4096, else 128x64
+      tile = (d.N % 4096 == 0 || (long)((d.M + 127) / 128) * (d.N / 128) * d.batch >= 1024) ? 5 : 6;
     } else if (d.loader != SP3_LOAD_CONV3X3 && d.M >= 1024 && sk == 1) {
-      tile = (d.K >= 2048 && d.N % 128 == 0) ? 2 : 1;     // many rows: 64-row tiles (tools/bench_gemm.py --M 1960)
+      tile = 1;                                           // many rows, narrow N: 64x64 register tiles
+    } else if (lds_ok && d.M <= 224 && d.M > 112 && d.epi == SP3_EPI_PLAIN && d.N >= 3072 && d.K <= 1024 &&
+               (!d.ln_stats || d.ln_nt <= 32)) {
+      // the widest 196-row GEMMs (fc1 of the decoder pair and of the value encoder): 112x64 role tile -- consumers keep
+      // their weights in a register ring, loader waves DMA the activations (10.6 vs 14.1 us, 11.4 vs 12.0 us cold)
+      tile = 13;
     } else if (d.loader == SP3_LOAD_CONV3X3 || d.M > 2048) {
       if (t128 >= 1024 && d.N % 128 == 0) tile = 2;
       else if (t64 >= 512) tile = 1;

@@ -295,6 +295,22 @@ extern "C" int sp3_gather_1d(const float* src, float* dst, const int32_t* sel, i
   return 0;
 }
 
+// A kernel of known length for calibrating host-side timers: spins `cycles` shader clocks and reports its own duration
+// (first to last instruction) in ticks of the constant 100 MHz counter (s_memrealtime).
+__global__ void spin_kernel(int64_t cycles, int64_t* ticks) {
+  const int64_t t0 = wall_clock64();
+  const int64_t c0 = clock64();
+  while (clock64() - c0 < cycles) __builtin_amdgcn_s_sleep(2);
+  if (threadIdx.x == 0) ticks[0] = wall_clock64() - t0;
+}
+
+extern "C" int sp3_spin(int64_t cycles, int64_t* ticks_100mhz, void* stream) {
+  SP3_CHECK(ticks_100mhz && cycles >= 0, "sp3_spin: bad arguments");
+  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, ST(stream), cycles, ticks_100mhz);
+  SP3_LAUNCH_CHECK("sp3_spin");
+  return 0;
+}
+
 extern "C" int sp3_fill_f32(float* p, float v, int64_t n, void* stream) {
   SP3_CHECK(p && n > 0, "sp3_fill_f32: bad arguments");
   hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ST(stream), p, v, n);

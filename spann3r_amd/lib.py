@@ -40,6 +40,7 @@ class GemmDesc(C.Structure):
         ("stats_out", C.c_void_p), ("c2", C.c_void_p), ("qkv_packed", C.c_int32), ("out_packed", C.c_int32), ("w_packed", C.c_int32),
         ("sb_A2", C.c_int64), ("sb_bias", C.c_int64), ("sb_ln_stats", C.c_int64), ("sb_ln_s", C.c_int64),
         ("sb_stats_out", C.c_int64), ("sb_c2", C.c_int64), ("sb_vt", C.c_int64),
+        ("trace", C.c_void_p),
     ]
 
 
@@ -96,6 +97,7 @@ _PROTOS = {
     "sp3_fill_f32": [C.c_void_p, C.c_float, C.c_int64, C.c_void_p],
     "sp3_cast_f32_to_bf16": [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
     "sp3_copy2d_f32": [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p],
+    "sp3_spin": [C.c_int64, C.c_void_p, C.c_void_p],
 }
 EXPORTS = sorted(list(_PROTOS) + ["sp3_last_error", "sp3_version"])
 

@@ -156,7 +156,8 @@ class SpatialMemory:
         if prof is not None:
             es = bk["k_hat"].element_size()
             # algorithmic bytes of one read: K_hat + V_hat once, plus the query in and the fused features out
-            prof.region_end("memread", e0, B * (2.0 * M * C * es + 2.0 * P * C * 4), info={"M": M, "tokens_per_frame": P})
+            prof.region_end("memread", e0, B * (2.0 * M * C * es + 2.0 * P * C * 4),
+                            info={"M": M, "tokens_per_frame": P, "flops": 4.0 * B * P * M * C})
         return out
 
     # ------------------------------------------------------------------ write (:80-95)

@@ -61,21 +61,26 @@ class Profiler:
         e1.record()
         self.rec.append((key, e0, e1, float(flops), float(nbytes)))
 
-    def calibrate(self, n=200):
-        """Cost of an EMPTY event bracket on a busy stream (the event packets themselves take a few us on the GPU);
-        summary() subtracts it from every bracket."""
+    def calibrate(self, n=40):
+        """Cost of one event bracket AROUND A RUNNING KERNEL: brackets a spin kernel that reports its own duration
+        (sp3_spin, 100 MHz device counter); cost = elapsed(bracket) - kernel duration, median over n launches.  (An EMPTY
+        bracket overstates it -- two back-to-back event packets serialise -- which made round 1's per-kernel times ~2 us
+        too short against rocprofv3.)  summary() subtracts it from every bracket."""
+        ticks = torch.zeros(n, dtype=torch.int64, device="cuda")
         torch.cuda.synchronize()
         self.step_begin()
         ev = []
-        for _ in range(n):
+        for i in range(n):
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
+            L.check(L.load().sp3_spin(12000, ticks[i:].data_ptr(), L.stream_ptr()), "sp3_spin")
             e1.record()
             ev.append((e0, e1))
         torch.cuda.synchronize()
-        t = sorted(a.elapsed_time(b) for a, b in ev)
-        self.bracket_ms = t[len(t) // 2]
+        dur_ms = (ticks.cpu().double() * 1e-5).tolist()            # 10 ns ticks -> ms
+        t = sorted(a.elapsed_time(b) - d for (a, b), d in zip(ev, dur_ms))
+        self.bracket_ms = max(t[len(t) // 2], 0.0)
         return self.bracket_ms
 
     def summary(self):
@@ -96,21 +101,22 @@ def set_profiler(p):
     _prof = p
 
 
-_TILE_NAMES = {0: "32x32xk4", 1: "64x64", 2: "64x128", 3: "64x64xk4", 5: "128x128lds", 6: "128x64lds"}
+_TILE_NAMES = {0: "32x32xk4", 1: "64x64", 2: "64x128", 3: "64x64xk4", 5: "128x128lds", 6: "128x64lds", 7: "112x64lds",
+               8: "208x64lds", 9: "112x32lds", 10: "112x64lds2w", 11: "112x64lds8w", 12: "208x64lds8w", 13: "112x64wreg8",
+               14: "112x64wreg4", 15: "208x64wreg8", 16: "112x64wreg4l6", 17: "112x64wreg8l4"}
 
 
-def pick_tile(M, N, batch=1, splitk=1, conv=False, K=0, packed_bf16=False):
+def pick_tile(M, N, batch=1, splitk=1, conv=False, K=0, packed_bf16=False, plain=False, ln_nt=0):
     """Mirror of the auto heuristic in csrc/gemm.hip (kept in sync so profiles can be keyed by instantiation)."""
     t64 = ((M + 63) // 64) * ((N + 63) // 64) * batch * splitk
     t128 = ((M + 63) // 64) * ((N + 127) // 128) * batch
-    if not conv and M >= 1024 and splitk == 1 and packed_bf16 and N >= 3072 and N % 128 == 0 and K % 64 == 0 and batch == 1:
-        # operands staged through LDS (tools/bench_gemm.py --M 1960 --packed 2): 128x128 when the grid is large or N is a
-        # multiple of 4096 (438 TFLOP/s at N=4096), else 128x64 (438 TFLOP/s at N=3072, where 128x128 quantises badly)
-        wg5 = ((M + 127) // 128) * (N // 128)
-        return 5 if (N % 4096 == 0 or wg5 >= 1024) else 6
+    lds_ok = not conv and splitk == 1 and packed_bf16 and K % 64 == 0
+    if lds_ok and M >= 1024 and N >= 2304 and N % 128 == 0:
+        return 5 if (N % 4096 == 0 or ((M + 127) // 128) * (N // 128) * batch >= 1024) else 6
     if not conv and M >= 1024 and splitk == 1:
-        # many rows (a whole sequence of frames through the encoder): 64-row tiles; tools/bench_gemm.py --M 1960
-        return 2 if (K >= 2048 and N % 128 == 0) else 1
+        return 1
+    if lds_ok and 112 < M <= 224 and plain and N >= 3072 and K <= 1024 and ln_nt <= 32:
+        return 13
     if conv or M > 2048:
         if t128 >= 1024 and N % 128 == 0:
             return 2
@@ -123,7 +129,8 @@ def pick_tile(M, N, batch=1, splitk=1, conv=False, K=0, packed_bf16=False):
 def _gemm_launch(d, what, loader_name):
     if d.tile < 0:
         d.tile = pick_tile(d.M, d.N, max(d.batch, 1), max(d.splitk, 1), d.loader == L.LOAD_CONV3X3, d.K,
-                           bool(d.a_packed and d.w_packed and d.a_bf16 and not d.A2 and d.epi != L.EPI_PARTIAL))
+                           bool(d.a_packed and d.w_packed and d.a_bf16 and not d.A2 and d.epi != L.EPI_PARTIAL),
+                           d.epi == L.EPI_PLAIN, d.ln_nt if d.ln_stats else 0)
     if _prof is None:
         L.check(L.load().sp3_gemm(C.byref(d), L.stream_ptr()), what)
         return
@@ -152,7 +159,7 @@ def _timed(key, flops, nbytes, fn, *args):
 def packed_shape(rows, K, dtype):
     """shape of a fragment-order operand buffer (include/spann3r_hip.h: a_packed / w_packed)"""
     KB, CH = (64, 16) if dtype == torch.bfloat16 else (32, 8)
-    return ((rows + 15) // 16, (K + KB - 1) // KB, 4, 16, CH)
+    return ((rows + 15) // 16, (K + KB - 1) // KB, 2, 4, 16, CH // 2)
 
 
 class PackedAct:
@@ -170,11 +177,12 @@ class PackedAct:
         nb, nkb = (M + 15) // 16, (K + KB - 1) // KB
         pad = torch.zeros(nb * 16, nkb * KB, dtype=x.dtype, device=x.device)
         pad[:M, :K] = x
-        return PackedAct(M, K, x.dtype, x.device, pad.view(nb, 16, nkb, 4, CH).permute(0, 2, 3, 1, 4).contiguous())
+        # [nb, r, kb, g, h, e] -> [nb, kb, h, g, r, e]
+        return PackedAct(M, K, x.dtype, x.device, pad.view(nb, 16, nkb, 4, 2, CH // 2).permute(0, 2, 4, 3, 1, 5).contiguous())
 
     def to_dense(self):
-        nb, nkb, _, _, CH = self.data.shape
-        return self.data.permute(0, 3, 1, 2, 4).reshape(nb * 16, nkb * 4 * CH)[:self.M, :self.K]
+        nb, nkb, _, _, _, ch2 = self.data.shape
+        return self.data.permute(0, 4, 1, 3, 2, 5).reshape(nb * 16, nkb * 8 * ch2)[:self.M, :self.K]
 
     def data_ptr(self):
         return self.data.data_ptr()
@@ -207,8 +215,8 @@ class PackedWeight:
         nb, nkb = (N + 15) // 16, (K + KB - 1) // KB
         pad = torch.zeros(nb * 16, nkb * KB, dtype=w2d.dtype, device=w2d.device)
         pad[:N, :K] = w2d
-        # [nb, r, kb, g, e] -> [nb, kb, g, r, e]
-        self.data = pad.view(nb, 16, nkb, 4, CH).permute(0, 2, 3, 1, 4).contiguous()
+        # [nb, r, kb, g, h, e] -> [nb, kb, h, g, r, e]
+        self.data = pad.view(nb, 16, nkb, 4, 2, CH // 2).permute(0, 2, 4, 3, 1, 5).contiguous()
 
     def data_ptr(self):
         return self.data.data_ptr()
@@ -280,7 +288,7 @@ def _act(t, name):
 
 def gemm(A, W, out, *, M, N, K, lda, ldc, bias=None, res1=None, ldr1=0, res2=None, ldr2=0, act=ACT_NONE, alpha=1.0,
          relu_in=False, tile=-1, batch=1, strideA=0, strideW=0, strideC=0, ldw=0,
-         A2=None, lda2=0, K1=0, splitk=0, ln=None, stats_out=None, c2=None, sb=None):
+         A2=None, lda2=0, K1=0, splitk=0, ln=None, stats_out=None, c2=None, sb=None, trace=None):
     """out[M,N] = act(alpha * A[M,K] @ W[N,K]^T + bias) (+ res1 + res2).  nn.Linear / 1x1 conv / einsum.
     `out` may be fp32 or bf16.  splitk >= 1 selects the PARTIAL epilogue: out is an fp32 [splitk, M, ldc] workspace
     that sp3_reduce_ln finishes."""
@@ -301,6 +309,7 @@ def gemm(A, W, out, *, M, N, K, lda, ldc, bias=None, res1=None, ldr1=0, res2=Non
         d.epi, d.splitk = L.EPI_PARTIAL, splitk
     _ln(d, ln)
     d.stats_out, d.c2 = L.ptr(stats_out), L.ptr(c2)
+    d.trace = L.ptr(trace)
     if sb:
         _group(d, batch, strideA, strideW, strideC, sb)
     _gemm_launch(d, "sp3_gemm", "plain")

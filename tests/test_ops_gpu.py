@@ -57,51 +57,73 @@ def test_gemm_plain(wdt, M, N, K, tile, packed):
     assert rel_err(out.cpu(), ref) < TOL[wdt], (M, N, K, tile)
 
 
-@pytest.mark.parametrize("M,N,K", [(1960, 3072, 1024), (300, 256, 192), (129, 384, 64), (1100, 1024, 4096)])
-def test_gemm_lds_staged_tile(M, N, K):
-    """tile 5: 128x128, both operands staged through LDS by global_load_lds (bf16 fragment-order A and W); ragged M / N
-    tiles, K down to one k-block; epilogues: bias + GELU -> packed bf16, residual + row statistics + packed copy, folded
-    LayerNorm."""
+LDS_TILES = [5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15]          # 13-15: bf16 only, at most 64 k-blocks per K slice
+
+
+@pytest.mark.parametrize("wdt", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("M,N,K", [(1960, 3072, 1024), (300, 256, 192), (129, 384, 64), (1100, 1024, 4096), (196, 768, 768),
+                                   (196, 2304, 768), (196, 1024, 4096), (98, 96, 128)])
+def test_gemm_lds_staged_tile(M, N, K, wdt):
+    """tiles 5-12: both operands staged through LDS by global_load_lds (fragment-order A and W in the MFMA dtype): the
+    128-row tiles of the whole-sequence encoder and the 112- / 208-row weight-streaming tiles (2-4 ring slots, pieces dealt
+    unevenly over the waves, K halves over wave pairs); ragged M / N tiles, K down to one k-block; epilogues: bias + GELU
+    -> packed, residual + row statistics + packed copy, folded LayerNorm, split-K partials."""
     ops = _ops()
+    KB = 64 if wdt == torch.bfloat16 else 32
+    if K % KB:
+        pytest.skip("whole k-blocks only")
+    if wdt == torch.float32 and M * N * K > 2e9:
+        pytest.skip("fp32 case kept small")
+    cast = bf if wdt == torch.bfloat16 else (lambda t: t)
+    tol = TOL[wdt]
     A, W, b, r1 = rnd(M, K, seed=1), rnd(N, K, seed=2) * 0.05, rnd(N, seed=3), rnd(M, N, seed=4)
     A[:, 0] += torch.arange(M) * 0.01
     W[:, 1] += torch.arange(N) * 0.02
-    Ap = ops.PackedAct.from_dense(A.to(DEV).to(torch.bfloat16))
-    Wp = ops.PackedWeight(W.to(DEV).to(torch.bfloat16))
-    ref = bf(A).double() @ bf(W).double().T
-    out = torch.full((M, N), float("nan"), device=DEV)
-    ops.gemm(Ap, Wp, out, M=M, N=N, K=K, lda=K, ldc=N, tile=6)          # the 128x64 variant of the same loop
-    assert rel_err(out.cpu(), ref) < TOL[torch.bfloat16]
-    out.fill_(float("nan"))
-    ops.gemm(Ap, Wp, out, M=M, N=N, K=K, lda=K, ldc=N, tile=5)
-    assert rel_err(out.cpu(), ref) < TOL[torch.bfloat16]
-    # the same launch must agree with the register-ring tiles to fp32 summation order
+    Ap = ops.PackedAct.from_dense(A.to(DEV).to(wdt))
+    Wp = ops.PackedWeight(W.to(DEV).to(wdt))
+    ref = cast(A).double() @ cast(W).double().T
     out1 = torch.empty(M, N, device=DEV)
-    ops.gemm(Ap, Wp, out1, M=M, N=N, K=K, lda=K, ldc=N, tile=1)
-    assert rel_err(out.cpu(), out1.cpu()) < 1e-5
+    ops.gemm(Ap, Wp, out1, M=M, N=N, K=K, lda=K, ldc=N, tile=1)          # a register-ring tile
+    tiles = [t for t in LDS_TILES if t < 13 or wdt == torch.bfloat16]
+    for tile in tiles:
+        out = torch.full((M, N), float("nan"), device=DEV)
+        ops.gemm(Ap, Wp, out, M=M, N=N, K=K, lda=K, ldc=N, tile=tile)
+        assert rel_err(out.cpu(), ref) < tol, tile
+        # the same launch must agree with the register-ring tiles to fp32 summation order
+        assert rel_err(out.cpu(), out1.cpu()) < 1e-5, tile
+    nkb = K // KB
+    for tile, S in ((7, 2), (8, 3), (11, 4), (13, 2), (14, 3)):
+        if nkb >= S and tile in tiles:                                                     # split-K partials of the streaming tiles
+            part = torch.full((S, M, N), float("nan"), device=DEV)
+            ops.gemm(Ap, Wp, part, M=M, N=N, K=K, lda=K, ldc=N, splitk=S, tile=tile)
+            assert rel_err(part.sum(0).cpu(), ref) < tol, (tile, S)
     if N % 32 == 0:
-        # producer epilogue: bias + residual, row statistics, packed copy
-        st = torch.zeros(M, N // 32, 2, device=DEV)
-        c2 = ops.PackedAct(M, N, torch.bfloat16, DEV)
-        x = torch.empty(M, N, device=DEV)
-        ops.gemm(Ap, Wp, x, M=M, N=N, K=K, lda=K, ldc=N, bias=b.to(DEV), res1=r1.to(DEV), ldr1=N, stats_out=st, c2=c2, tile=5)
-        xr = ref + b.double() + r1.double()
-        assert rel_err(x.cpu(), xr) < TOL[torch.bfloat16]
-        assert rel_err(st[..., 0].sum(1).cpu(), x.cpu().double().sum(1)) < 1e-5
-        assert torch.equal(c2.to_dense(), x.to(torch.bfloat16))
-        # consumer epilogue: LayerNorm of x folded into the next GEMM + GELU -> packed bf16
-        g, beta = rnd(N, seed=5) + 1, rnd(N, seed=6)
-        W2 = rnd(256, N, seed=7) * 0.05
-        Wf = (W2 * g[None]).to(torch.bfloat16)
-        s_n = Wf.float().sum(1).to(DEV)
-        b2 = (rnd(256, seed=8) + W2 @ beta).to(DEV)
-        h = ops.PackedAct(M, 256, torch.bfloat16, DEV)
-        ops.gemm(c2, ops.PackedWeight(Wf.to(DEV)), h, M=M, N=256, K=N, lda=N, ldc=256, bias=b2, act=ops.ACT_GELU,
-                 ln=ops.LnFold(st, N, s_n, 1e-6), tile=5)
-        xf = x.cpu().double()
-        mu, var = xf.mean(1, keepdim=True), xf.var(1, unbiased=False, keepdim=True)
-        y = ((bf(x.cpu()).double() @ Wf.double().T) - mu * Wf.double().sum(1)[None]) / torch.sqrt(var + 1e-6) + b2.cpu().double()
-        assert rel_err(h.to_dense().float().cpu(), F.gelu(y)) < 8e-3
+        for tile in (5, 7, 8, 11, 13, 14):
+            if tile not in tiles:
+                continue
+            # producer epilogue: bias + residual, row statistics, packed copy
+            st = torch.zeros(M, N // 32, 2, device=DEV)
+            c2 = ops.PackedAct(M, N, wdt, DEV)
+            x = torch.empty(M, N, device=DEV)
+            ops.gemm(Ap, Wp, x, M=M, N=N, K=K, lda=K, ldc=N, bias=b.to(DEV), res1=r1.to(DEV), ldr1=N, stats_out=st, c2=c2, tile=tile)
+            xr = ref + b.double() + r1.double()
+            assert rel_err(x.cpu(), xr) < tol
+            assert rel_err(st[..., 0].sum(1).cpu(), x.cpu().double().sum(1)) < 1e-5
+            assert torch.equal(c2.to_dense(), x.to(wdt))
+            # consumer epilogue: LayerNorm of x folded into the next GEMM + GELU -> packed
+            g, beta = rnd(N, seed=5) + 1, rnd(N, seed=6)
+            W2 = rnd(256, N, seed=7) * 0.05
+            Wf = (W2 * g[None]).to(wdt)
+            s_n = Wf.float().sum(1).to(DEV)
+            b2 = (rnd(256, seed=8) + W2 @ beta).to(DEV)
+            h = ops.PackedAct(M, 256, wdt, DEV)
+            if N % KB == 0 and (tile < 13 or N <= 1024):          # the role tiles fold a LayerNorm of at most 1024 columns
+                ops.gemm(c2, ops.PackedWeight(Wf.to(DEV)), h, M=M, N=256, K=N, lda=N, ldc=256, bias=b2, act=ops.ACT_GELU,
+                         ln=ops.LnFold(st, N, s_n, 1e-6), tile=tile)
+                xf = x.cpu().double()
+                mu, var = xf.mean(1, keepdim=True), xf.var(1, unbiased=False, keepdim=True)
+                y = ((cast(x.cpu()).double() @ Wf.double().T) - mu * Wf.double().sum(1)[None]) / torch.sqrt(var + 1e-6) + b2.cpu().double()
+                assert rel_err(h.to_dense().float().cpu(), F.gelu(y)) < (8e-3 if wdt == torch.bfloat16 else 1e-4), tile
 
 
 @pytest.mark.parametrize("wdt", [torch.float32, torch.bfloat16])
