@@ -206,25 +206,55 @@ int sp3_attention_packed(const void* qp, int q_cols, int q_col0, int npad_q, con
 
 /* ------------------------------------------------------------------------------------------
  * Spatial-memory kernels (spann3r/model.py:97-210).
- * sp3_softmax_thresh: rows of S fp32 [rows, ld] -> P fp32 [rows, ld]: softmax over the first M
- *   columns; if thresh > 0, p < thresh -> 0 and renormalise (:160,170-172); columns [M, Mpad) are
- *   written as 0 so that P can be the A operand of the P.V GEMM.  batch in grid.y via strideS.
- *   P_packed (optional): a second, bf16 copy of P in sp3_gemm's a_packed fragment order with K = M rounded up to 64
- *   (zero filled), stride_packed elements per batch entry -- the coalesced A operand of the P.V GEMM.
- * sp3_colsum_accum : mem_attn[j] += sum_r P[r, j]  (:180-181).
+ * The bank (spann3r_amd/model.py SpatialMemory) keeps, next to the reference's mem_k / mem_v / mem_attn / mem_count, the
+ * two operands of a read already normalised and in sp3_gemm's fragment order (w_packed): K' = gamma_q (.) LN_k(mem_k)
+ * [cap, 1024] and LN_v(mem_v)^T [1024, cap], plus s_bank / b_bank [cap] that fold LN_q into the S GEMM.
+ * sp3_bank_write   : one launch per stored frame (:80-95 plus the bank-side LayerNorms of :154,174): raw copies, K', V^T,
+ *   s_bank[t] = alpha * sum_c K'[t,c] (of the rounded operand), b_bank[t] = alpha * sum_c beta_q[c] LN_k(k)[t,c].
+ * sp3_softmax_thresh: rows of S fp32 [rows, ld]: softmax over the first M columns; if thresh > 0, p < thresh -> 0 and
+ *   renormalise (:160,170-172).  Outputs (either may be null): P fp32 [rows, ld] (columns [M, Mpad) written as 0) and
+ *   P_packed = the probabilities as sp3_gemm's a_packed operand [rows, K] with K = M rounded up to one k-block (64 bf16 /
+ *   32 fp32, zero filled), stride_packed elements per batch entry.  batch in grid.y via strideS.
+ * sp3_colsum_accum : mem_attn[j] += sum_r P[r, j]  (:180-181) from the row-major fp32 P;
+ * sp3_colsum_packed: the same from the fragment-order copy (one writer per column, fixed order: deterministic).
+ * sp3_pack_stats   : fragment-order copy + per-32-column (sum, sum of squares) partials of a row-major fp32 matrix (what
+ *   a producer GEMM's c2 / stats_out write), for callers that hand memory_read a plain tensor.
  * sp3_cos_sim      : score[t] = mean_p cos(k[p,:], wm[t,p,:]) for t < T (:102-112); k fp32 [P,C],
  *   wm fp32 [T,P,C] contiguous; scratch fp32 [T*P] holds the per-patch cosines (one wave per (t,p) pair, then one
  *   block per t averages them). Deterministic reduction order.
  * sp3_mem_append   : count[0..M) += 1; count[M..M+P) = 0; attn[M..M+P) = 0  (:84-90).
  * sp3_prune_select : w = attn/count, w[count < protect] = 1e8; sel[0..top_k) = indices of the top_k
- *   weights, sorted by weight descending, ties by index ascending (:187-193). M <= 8192.
+ *   weights, sorted by weight descending, ties by index ascending (:187-193). M <= 16384.
  * sp3_gather_rows  : dst[i, :] = src[sel[i], :] (row gather of a [*, C] matrix, elem_size bytes/elem).
- * sp3_gather_cols  : dst[c, i] = src[c, sel[i]] for c < C (the V^T bank), zero-fills [n_sel, n_fill).
+ * sp3_gather_cols  : dst[c, i] = src[c, sel[i]] for c < C (a row-major V^T), zero-fills [n_sel, n_fill).
+ * sp3_gather_packed_rows / _cols : the same two gathers on fragment-order matrices ([*, C] rows = tokens; [C, cap] with
+ *   k = token; the column gather zero-fills tokens [n_sel, n_fill)).
  * sp3_gather_1d    : dst[i] = src[sel[i]] fp32.
  */
+typedef struct sp3_bank_write_desc {
+  const float* feat_k;    /* [P, C] fp32: the frame's memory key   (feat_k1) */
+  const float* feat_v;    /* [P, C] fp32: the frame's memory value (cur_v + feat_k1) */
+  float* k_raw;           /* [cap, C] fp32 = reference mem_k; rows [M, M+P) are written */
+  float* v_raw;           /* [cap, C] fp32 = reference mem_v */
+  void* k_hat;            /* fragment-order [cap, C] in wdtype: gamma_q (.) LN_k(mem_k) */
+  void* v_hat_t;          /* fragment-order [C, cap] in wdtype: LN_v(mem_v)^T */
+  float* s_bank;          /* [cap] */
+  float* b_bank;          /* [cap] */
+  const float *gamma_k, *beta_k, *gamma_v, *beta_v, *gamma_q, *beta_q;   /* norm_k / norm_v / norm_q, fp32 [C] */
+  float eps;              /* 1e-5 (spann3r/model.py:245-247) */
+  float alpha;            /* 1 / sqrt(C): the S GEMM's scale, folded into s_bank / b_bank */
+  int32_t M, P, C, cap;   /* cap % 64 == 0, C % 256 == 0 */
+  int32_t wdtype;         /* SP3_F32 | SP3_BF16 */
+} sp3_bank_write_desc;
+int sp3_bank_write(const sp3_bank_write_desc* desc_host, void* stream);
 int sp3_softmax_thresh(const float* S, float* P, int64_t ld, int64_t strideS, int rows, int M, int Mpad,
-                       float thresh, int batch, void* P_packed, int64_t stride_packed, void* stream);
+                       float thresh, int batch, void* P_packed, int64_t stride_packed, int packed_bf16, void* stream);
 int sp3_colsum_accum(const float* P, int64_t ld, int rows, int M, float* mem_attn, void* stream);
+int sp3_colsum_packed(const void* P_packed, int packed_bf16, int rows, int M, float* mem_attn, void* stream);
+int sp3_pack_stats(const float* x, int64_t ldx, int rows, int C, void* packed, int packed_bf16, float* stats, void* stream);
+int sp3_gather_packed_rows(const void* src, void* dst, const int32_t* sel, int n_sel, int C, int elem_size, void* stream);
+int sp3_gather_packed_cols(const void* src, void* dst, const int32_t* sel, int n_sel, int n_fill, int C, int cap,
+                           int elem_size, void* stream);
 int sp3_cos_sim(const float* k, const float* wm, int T, int P, int C, float* scratch, float* score, void* stream);
 int sp3_mem_append(float* count, float* attn, int M, int P, void* stream);
 int sp3_prune_select(const float* attn, const float* count, int M, float protect, int top_k,

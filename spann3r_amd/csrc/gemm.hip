@@ -365,7 +365,7 @@ void gemm_kernel(const GemmArgs args) {
   const TW* wbase[NF];
   int64_t wstep;
   if (d.w_packed) {
-    const int nkb_pad = (d.K + KB - 1) / KB;
+    const int nkb_pad = (int)((d.ldw + KB - 1) / KB);      // k-blocks ALLOCATED per row panel (ldw >= K: a bank that grows along K)
     wstep = 64 * CH;
 #pragma unroll
     for (int n = 0; n < NF; ++n) {
@@ -566,7 +566,7 @@ void gemm_kernel(const GemmArgs args) {
       using W16 = std::remove_reference_t<decltype(((typename M_::WReg*)nullptr)->v[0])>;
       using V16 = std::remove_reference_t<decltype(((typename M_::AReg*)nullptr)->v[0])>;
       static_assert(sizeof(W16) == 16 && sizeof(V16) == 16, "fragment halves are 16 bytes");
-      const int nkb_w = (d.K + KB - 1) / KB;
+      const int nkb_w = (int)((d.ldw + KB - 1) / KB);
       int nb = (n0 >> 4) + wn;
       const int nb_max = (d.N + 15) / 16 - 1;
       nb = nb < nb_max ? nb : nb_max;
@@ -660,7 +660,7 @@ void gemm_kernel(const GemmArgs args) {
       } else {
         int nb = (n0 >> 4) + blk - BM / 16;
         nb = nb < nb_max ? nb : nb_max;
-        base = reinterpret_cast<const char*>(W + (int64_t)nb * nkb_pad * (2048 / sizeof(TW)));
+        base = reinterpret_cast<const char*>(W + (int64_t)nb * (int)((d.ldw + KB - 1) / KB) * (2048 / sizeof(TW)));
       }
       src[i] = base + (j & 1) * 1024 + lane * 16;
       dst[i] = j * 1024;
@@ -1257,8 +1257,8 @@ extern "C" int sp3_gemm(const sp3_gemm_desc* dp, void* stream_) {
   if (d.splitk <= 0) d.splitk = 1;
   if (d.ldw <= 0) d.ldw = d.K;
   SP3_CHECK(!d.ln_stats || (d.ln_s && d.ln_nt > 0 && d.ln_C == 32 * d.ln_nt && d.epi != SP3_EPI_PARTIAL &&
-                            d.loader == SP3_LOAD_PLAIN && d.N % 4 == 0),
-            "sp3_gemm: folded LayerNorm needs ln_s, ln_nt, ln_C = 32*ln_nt, the plain loader, N %% 4 == 0");
+                            d.loader == SP3_LOAD_PLAIN),
+            "sp3_gemm: folded LayerNorm needs ln_s, ln_nt, ln_C = 32*ln_nt, the plain loader");
   SP3_CHECK((!d.stats_out && !d.c2) || (d.epi == SP3_EPI_PLAIN && d.N % 32 == 0 && !d.out_packed),
             "sp3_gemm: stats_out / c2 need the plain epilogue, N %% 32 == 0");
   SP3_CHECK(!d.out_packed || (d.epi == SP3_EPI_PLAIN && d.N % 4 == 0), "sp3_gemm: out_packed needs the plain epilogue, N %% 4 == 0");
@@ -1309,8 +1309,8 @@ extern "C" int sp3_gemm(const sp3_gemm_desc* dp, void* stream_) {
       // LDS-staged operands (tools/bench_gemm2.py --big, HBM-cold weights, also grouped launches): 128x128 for large grids
       // / N multiple of 4096, else 128x64
       tile = (d.N % 4096 == 0 || (long)((d.M + 127) / 128) * (d.N / 128) * d.batch >= 1024) ? 5 : 6;
-    } else if (d.loader != SP3_LOAD_CONV3X3 && d.M >= 1024 && sk == 1) {
-      tile = 1;                                           // many rows, narrow N: 64x64 register tiles
+    } else if (d.loader != SP3_LOAD_CONV3X3 && d.M >= 1024) {
+      tile = 1;                                           // many rows, narrow N (also split-K partials): 64x64 register tiles
     } else if (lds_ok && d.M <= 224 && d.M > 112 && d.epi == SP3_EPI_PLAIN && d.N >= 3072 && d.K <= 1024 &&
                (!d.ln_stats || d.ln_nt <= 32)) {
       // the widest 196-row GEMMs (fc1 of the decoder pair and of the value encoder): 112x64 role tile -- consumers keep

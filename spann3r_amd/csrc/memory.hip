@@ -2,12 +2,14 @@
 //
 // The bank is a static-capacity arena owned by the host side (spann3r_amd/model.py):
 //   K_raw [cap,1024] fp32, V_raw [cap,1024] fp32 (what the reference calls mem_k / mem_v),
-//   K_hat [cap,1024] = LN_k(K_raw) and V_hat^T [1024,cap] = LN_v(V_raw)^T in the MFMA dtype,
-//   mem_attn [cap], mem_count [cap] fp32.
-// LayerNorm is row-wise, so normalising ONCE at write time is exactly what the reference recomputes
-// over the whole bank at every read (model.py:154,174).  A read is then
-//   S = LN_q(q) . K_hat^T / 32   (sp3_gemm, alpha)      -> sp3_softmax_thresh -> P
-//   out = P . V_hat + q          (sp3_gemm, residual)   ;  mem_attn += colsum(P)  (sp3_colsum_accum)
+//   K_hat' = gamma_q (.) LN_k(K_raw) as a FRAGMENT-ORDER [cap, 1024] matrix (the W operand of the S GEMM) and
+//   V_hat^T = LN_v(V_raw)^T as a fragment-order [1024, cap] matrix (the W operand of the P.V GEMM), in the MFMA dtype,
+//   s_bank / b_bank [cap] fp32: the per-token constants that fold LN_q into the S GEMM, mem_attn / mem_count [cap] fp32.
+// LayerNorm is row-wise, so normalising ONCE at write time (sp3_bank_write, one launch per stored frame) is exactly what
+// the reference recomputes over the whole bank at every read (model.py:154,174).  A read is then
+//   S = LN_q(q) . K_hat^T / 32   (sp3_gemm: raw q in fragment order, LN_q folded through s_bank / b_bank, alpha)
+//   P = softmax / threshold / renormalise   (sp3_softmax_thresh: fragment-order copy for the next GEMM)
+//   out = P . V_hat + q          (sp3_gemm, residual)   ;  mem_attn += colsum(P)  (sp3_colsum_accum / _packed)
 #include "common.h"
 #include <math.h>
 
@@ -34,20 +36,27 @@ __device__ __forceinline__ float block_reduce_sum(float v, float* sh) {
   return r;
 }
 
-// One block per row.  softmax over [0,M); optional threshold + renormalise; zero-fill [M,Mpad).
+// One block per row.  softmax over [0,M); optional threshold + renormalise.  Outputs, both optional: P fp32 row-major
+// (zero-filled over [M,Mpad)) and Pk = the same probabilities as a fragment-order operand [rows, Kp] (Kp = M rounded up to
+// 64, zero filled) in bf16 or fp32: 8 (4) consecutive probabilities = one 16-byte store.
+template <typename TP>
 __global__ __launch_bounds__(256) void softmax_thresh_kernel(const float* __restrict__ S, float* __restrict__ P, int64_t ld,
                                                              int64_t strideS, int M, int Mpad, float thresh,
-                                                             __bf16* __restrict__ Pk, int Kp, int64_t stridePk) {
+                                                             TP* __restrict__ Pk, int Kp, int64_t stridePk) {
   __shared__ float sh[8];
   const float* s = S + (int64_t)blockIdx.y * strideS + (int64_t)blockIdx.x * ld;
-  float* p = P + (int64_t)blockIdx.y * strideS + (int64_t)blockIdx.x * ld;
-  float mx = -INFINITY;
-  for (int j = threadIdx.x; j < M; j += 256) mx = fmaxf(mx, s[j]);
-  mx = block_reduce_max(mx, sh);
-  float sum = 0.f;
-  for (int j = threadIdx.x; j < M; j += 256) sum += expf(s[j] - mx);
-  sum = block_reduce_sum(sum, sh);
-  const float inv = 1.0f / sum;
+  // one pass for max and sum (online softmax per thread, merged across the block): a long bank row (196 KB at 49152
+  // tokens) does not stay in cache between passes
+  float mx = -INFINITY, sum = 0.f;
+  for (int j = threadIdx.x; j < M; j += 256) {
+    const float v = s[j];
+    if (v > mx) { sum = sum * expf(mx - v) + 1.0f; mx = v; }
+    else sum += expf(v - mx);
+  }
+  const float gmx = block_reduce_max(mx, sh);
+  sum = block_reduce_sum(mx == -INFINITY ? 0.f : sum * expf(mx - gmx), sh);
+  mx = gmx;
+  float inv = 1.0f / sum, rk = 1.0f;
   if (thresh > 0.f) {
     float kept = 0.f;
     for (int j = threadIdx.x; j < M; j += 256) {
@@ -55,28 +64,66 @@ __global__ __launch_bounds__(256) void softmax_thresh_kernel(const float* __rest
       v = v < thresh ? 0.f : v;
       kept += v;
     }
-    kept = block_reduce_sum(kept, sh);
-    for (int j = threadIdx.x; j < M; j += 256) {
-      float v = expf(s[j] - mx) * inv;
-      v = v < thresh ? 0.f : v;
-      p[j] = v / kept;
-    }
-  } else {
-    for (int j = threadIdx.x; j < M; j += 256) p[j] = expf(s[j] - mx) * inv;
+    rk = block_reduce_sum(kept, sh);
   }
-  for (int j = M + threadIdx.x; j < Mpad; j += 256) p[j] = 0.f;
+  auto prob = [&](int j) -> float {
+    float v = expf(s[j] - mx) * inv;
+    if (thresh > 0.f) v = (v < thresh ? 0.f : v) / rk;
+    return v;
+  };
+  if (P) {
+    float* p = P + (int64_t)blockIdx.y * strideS + (int64_t)blockIdx.x * ld;
+    for (int j = threadIdx.x; j < M; j += 256) p[j] = prob(j);
+    for (int j = M + threadIdx.x; j < Mpad; j += 256) p[j] = 0.f;
+  }
   if (Pk) {
-    // second copy for the P.V GEMM: bf16, fragment order [rows, Kp] (Kp = M rounded up to 64, zero filled): 8 consecutive
-    // probabilities = one 16-byte store.  Reads back this block's own fp32 row (visible after the barrier).
-    __syncthreads();
-    __bf16* pk = Pk + (int64_t)blockIdx.y * stridePk;
+    constexpr int E = 16 / (int)sizeof(TP);               // elements per 16-byte store
+    TP* pk = Pk + (int64_t)blockIdx.y * stridePk;
     const int row = blockIdx.x;
-    for (int j8 = threadIdx.x * 8; j8 < Kp; j8 += 256 * 8) {
-      bf16x8 o;
+    for (int j0 = threadIdx.x * E; j0 < Kp; j0 += 256 * E) {
+      TP o[E];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = (__bf16)((j8 + e) < M ? p[j8 + e] : 0.f);
-      *reinterpret_cast<bf16x8*>(pk + packed_off(row, j8, Kp, true)) = o;
+      for (int e = 0; e < E; ++e) o[e] = (TP)((j0 + e) < M ? prob(j0 + e) : 0.f);
+      typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+      *reinterpret_cast<u4*>(pk + packed_off(row, j0, Kp, sizeof(TP) == 2)) = *reinterpret_cast<const u4*>(o);
     }
+  }
+}
+
+// mem_attn[j] += sum_r P[r, j] from the fragment-order probabilities [rows, Kp]: one workgroup per 64-column k-block
+// walks the row blocks (2 KB each, contiguous), every thread keeps the partial sums of its 16 bytes, the 16 rows x 2
+// halves of a column meet in LDS in a fixed order (one writer per column: deterministic, no atomics).
+template <typename TP>
+__global__ __launch_bounds__(256) void colsum_packed_kernel(const TP* __restrict__ Pk, int rows, int M, int Kp,
+                                                            float* __restrict__ mem_attn) {
+  constexpr int E = 16 / (int)sizeof(TP), KB = 8 * E, TPB = 2048 / 16;      // 128 threads cover one 2 KB block
+  __shared__ float sh[2][KB][17];
+  const int kb = blockIdx.x, nkb = Kp / KB, nrb = (rows + 15) / 16;
+  const int t = threadIdx.x & (TPB - 1), half_wg = threadIdx.x / TPB;       // two row blocks in flight per iteration
+  // thread t of a block holds 16 bytes: piece h = t / 64, lane l = t % 64 -> g = l / 16, r = l % 16, k = g*2E + h*E + e
+  const int h = t >> 6, l = t & 63, g = l >> 4, r = l & 15;
+  float acc[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) acc[e] = 0.f;
+  for (int rb = half_wg; rb < nrb; rb += 2) {
+    typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+    const u4 raw = *reinterpret_cast<const u4*>(reinterpret_cast<const char*>(Pk) + ((int64_t)rb * nkb + kb) * 2048 + t * 16);
+    const TP* v = reinterpret_cast<const TP*>(&raw);
+    const bool ok = rb * 16 + r < rows;
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] += ok ? (float)v[e] : 0.f;
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) sh[half_wg][g * 2 * E + h * E + e][r] = acc[e];
+  __syncthreads();
+  if (threadIdx.x < KB) {
+    const int j = kb * KB + threadIdx.x;
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) sum += sh[q][threadIdx.x][rr];
+    if (j < M) mem_attn[j] += sum;
   }
 }
 
@@ -137,7 +184,7 @@ __global__ __launch_bounds__(256) void mem_append_kernel(float* __restrict__ cou
 }
 
 // Single-block bitonic sort of (weight, index): weight descending, index ascending on ties.
-constexpr int PRUNE_MAX = 8192;
+constexpr int PRUNE_MAX = 16384;      // 4000 + 8 * P tokens for P up to 1536 (512x768); 128 KB of LDS
 __global__ __launch_bounds__(1024) void prune_select_kernel(const float* __restrict__ attn, const float* __restrict__ count,
                                                             int M, float protect, int top_k, int32_t* __restrict__ sel) {
   extern __shared__ __attribute__((aligned(16))) unsigned char raw[];
@@ -218,17 +265,241 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
   if (i < n) d[i] = (__bf16)s[i];
 }
 
+
+// ------------------------------------------------------------------ memory write (spann3r/model.py:80-95 + the LayerNorms of :154,174)
+// One launch per stored frame.  A workgroup owns TG consecutive bank tokens (TG = 8 bf16 / 4 fp32 = the tokens that share
+// a 16-byte piece of the fragment-order V^T), aligned to the absolute token index; its 4 waves take the tokens in turn:
+//   k row: raw copy; k_hat = LN_k(k); K' = k_hat (.) gamma_q stored in fragment order (row = token);
+//          s = alpha * sum_c K'_c (of the ROUNDED operand), b = alpha * sum_c beta_q,c k_hat_c  -> fold LN_q into the S GEMM
+//   v row: raw copy; v_hat = LN_v(v) staged in LDS, then written TRANSPOSED in fragment order (row = channel, k = token):
+//          the TG tokens of a channel are one 16-byte store.
+struct BankWriteArgs {
+  const float *fk, *fv;
+  float *k_raw, *v_raw;
+  void *k_hat, *v_hat_t;
+  float *s_bank, *b_bank;
+  const float *gk, *bk, *gv, *bv, *gq, *bq;
+  float eps, alpha;
+  int M, P, C, cap;
+};
+
+template <typename TW>
+__global__ __launch_bounds__(256) void bank_write_kernel(const BankWriteArgs a) {
+  constexpr int TG = 16 / (int)sizeof(TW);
+  constexpr bool BF = sizeof(TW) == 2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char raw_[];
+  TW* stage = reinterpret_cast<TW*>(raw_);                 // [TG][C]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t0 = (a.M / TG + blockIdx.x) * TG;             // first token of this group (absolute bank row)
+  const int C = a.C;
+  for (int j = wave; j < TG; j += 4) {
+    const int t = t0 + j;
+    if (t < a.M || t >= a.M + a.P) continue;               // wave-uniform
+    const int pr = t - a.M;
+    // ---- key row
+    {
+      const float* x = a.fk + (int64_t)pr * C;
+      float s1 = 0.f, s2 = 0.f;
+      for (int c = lane * 4; c < C; c += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(x + c);
+        *reinterpret_cast<float4*>(a.k_raw + (int64_t)t * C + c) = v;
+        s1 += (v.x + v.y) + (v.z + v.w);
+        s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      }
+      s1 = wave_sum(s1); s2 = wave_sum(s2);
+      const float mean = s1 / (float)C;
+      const float rstd = 1.0f / sqrtf(fmaxf(s2 / (float)C - mean * mean, 0.f) + a.eps);
+      float ss = 0.f, sb = 0.f;
+      for (int c = lane * 4; c < C; c += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(x + c);
+        const float4 g = *reinterpret_cast<const float4*>(a.gk + c), be = *reinterpret_cast<const float4*>(a.bk + c);
+        const float4 gq = *reinterpret_cast<const float4*>(a.gq + c), bq = *reinterpret_cast<const float4*>(a.bq + c);
+        const float kh[4] = {(v.x - mean) * rstd * g.x + be.x, (v.y - mean) * rstd * g.y + be.y,
+                             (v.z - mean) * rstd * g.z + be.z, (v.w - mean) * rstd * g.w + be.w};
+        const float gqa[4] = {gq.x, gq.y, gq.z, gq.w}, bqa[4] = {bq.x, bq.y, bq.z, bq.w};
+        TW w[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          w[e] = (TW)(kh[e] * gqa[e]);
+          ss += (float)w[e];
+          sb += bqa[e] * kh[e];
+        }
+        TW* dst = reinterpret_cast<TW*>(a.k_hat) + packed_off(t, c, C, BF);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[e] = w[e];
+      }
+      ss = wave_sum(ss); sb = wave_sum(sb);
+      if (lane == 0) { a.s_bank[t] = a.alpha * ss; a.b_bank[t] = a.alpha * sb; }
+    }
+    // ---- value row
+    {
+      const float* x = a.fv + (int64_t)pr * C;
+      float s1 = 0.f, s2 = 0.f;
+      for (int c = lane * 4; c < C; c += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(x + c);
+        *reinterpret_cast<float4*>(a.v_raw + (int64_t)t * C + c) = v;
+        s1 += (v.x + v.y) + (v.z + v.w);
+        s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      }
+      s1 = wave_sum(s1); s2 = wave_sum(s2);
+      const float mean = s1 / (float)C;
+      const float rstd = 1.0f / sqrtf(fmaxf(s2 / (float)C - mean * mean, 0.f) + a.eps);
+      for (int c = lane * 4; c < C; c += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(x + c);
+        const float4 g = *reinterpret_cast<const float4*>(a.gv + c), be = *reinterpret_cast<const float4*>(a.bv + c);
+        TW* d = stage + j * C + c;
+        d[0] = (TW)((v.x - mean) * rstd * g.x + be.x); d[1] = (TW)((v.y - mean) * rstd * g.y + be.y);
+        d[2] = (TW)((v.z - mean) * rstd * g.z + be.z); d[3] = (TW)((v.w - mean) * rstd * g.w + be.w);
+      }
+    }
+  }
+  __syncthreads();
+  // ---- transposed store of the staged value rows: channel c, tokens t0 .. t0+TG-1 = one 16-byte piece
+  const bool whole = t0 >= a.M && t0 + TG <= a.M + a.P;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    TW* dst = reinterpret_cast<TW*>(a.v_hat_t) + packed_off(c, t0, a.cap, BF);
+    if (whole) {
+      TW o[TG];
+#pragma unroll
+      for (int j = 0; j < TG; ++j) o[j] = stage[j * C + c];
+      typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+      *reinterpret_cast<u4*>(dst) = *reinterpret_cast<const u4*>(o);
+    } else {
+#pragma unroll
+      for (int j = 0; j < TG; ++j)
+        if (t0 + j >= a.M && t0 + j < a.M + a.P) dst[j] = stage[j * C + c];
+    }
+  }
+}
+
+// Fragment-order copy + per-32-column (sum, sum of squares) partials of a row-major fp32 matrix: what a producer GEMM's
+// stats_out / c2 options write, as a stand-alone launch (the reference-shaped eager path hands memory_read a plain tensor).
+template <typename TW>
+__global__ __launch_bounds__(256) void pack_stats_kernel(const float* __restrict__ x, int64_t ldx, int rows, int C,
+                                                         TW* __restrict__ packed, float* __restrict__ stats) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  for (int c = lane * 4; c < C; c += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(x + (int64_t)row * ldx + c);
+    TW* d = packed + packed_off(row, c, C, sizeof(TW) == 2);
+    d[0] = (TW)v.x; d[1] = (TW)v.y; d[2] = (TW)v.z; d[3] = (TW)v.w;
+    float s1 = (v.x + v.y) + (v.z + v.w), s2 = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+#pragma unroll
+    for (int o_ = 1; o_ < 8; o_ <<= 1) { s1 += __shfl_xor(s1, o_); s2 += __shfl_xor(s2, o_); }
+    if ((lane & 7) == 0) reinterpret_cast<float2*>(stats)[(int64_t)row * (C >> 5) + (c >> 5)] = make_float2(s1, s2);
+  }
+}
+
+// prune (spann3r/model.py:195-201) on the fragment-order banks.  Rows of K' (row = token): 16-byte pieces move whole.
+__global__ __launch_bounds__(256) void gather_packed_rows_kernel(const char* __restrict__ src, char* __restrict__ dst,
+                                                                 const int32_t* __restrict__ sel, int C, int esz) {
+  const int i = blockIdx.x, si = sel[i];
+  const int per = 16 / esz;                                // elements per 16-byte piece
+  const bool bf = esz == 2;
+  for (int c = threadIdx.x * per; c < C; c += 256 * per) {
+    typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+    *reinterpret_cast<u4*>(dst + packed_off(i, c, C, bf) * esz) = *reinterpret_cast<const u4*>(src + packed_off(si, c, C, bf) * esz);
+  }
+}
+
+// Columns of V^T (k = token): destination piece (channel c, tokens 8q..8q+7) gathers its elements one by one.
+template <typename TW>
+__global__ __launch_bounds__(256) void gather_packed_cols_kernel(const TW* __restrict__ src, TW* __restrict__ dst,
+                                                                 const int32_t* __restrict__ sel, int n_sel, int n_fill, int cap) {
+  constexpr int TG = 16 / (int)sizeof(TW);
+  const int c = blockIdx.y;
+  const int q = blockIdx.x * 256 + threadIdx.x;            // piece index along the token axis
+  if (q * TG >= n_fill) return;
+  TW o[TG];
+#pragma unroll
+  for (int j = 0; j < TG; ++j) {
+    const int i = q * TG + j;
+    o[j] = i < n_sel ? src[packed_off(c, sel[i], cap, sizeof(TW) == 2)] : (TW)0.f;
+  }
+  typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+  *reinterpret_cast<u4*>(dst + packed_off(c, q * TG, cap, sizeof(TW) == 2)) = *reinterpret_cast<const u4*>(o);
+}
+
 }  // namespace
 
 #define ST(s) reinterpret_cast<hipStream_t>(s)
 
 extern "C" int sp3_softmax_thresh(const float* S, float* P, int64_t ld, int64_t strideS, int rows, int M, int Mpad,
-                                  float thresh, int batch, void* P_packed, int64_t stride_packed, void* stream) {
-  SP3_CHECK(S && P && rows > 0 && M > 0 && Mpad >= M && ld >= Mpad, "sp3_softmax_thresh: bad arguments");
-  const int Kp = (M + 63) / 64 * 64;
-  hipLaunchKernelGGL(softmax_thresh_kernel, dim3(rows, batch > 0 ? batch : 1), dim3(256), 0, ST(stream), S, P, ld, strideS, M,
-                     Mpad, thresh, reinterpret_cast<__bf16*>(P_packed), Kp, stride_packed);
+                                  float thresh, int batch, void* P_packed, int64_t stride_packed, int packed_bf16, void* stream) {
+  SP3_CHECK(S && (P || P_packed) && rows > 0 && M > 0 && Mpad >= M && ld >= Mpad, "sp3_softmax_thresh: bad arguments");
+  const dim3 grid(rows, batch > 0 ? batch : 1);
+  if (packed_bf16) {
+    const int Kp = (M + 63) / 64 * 64;
+    hipLaunchKernelGGL(softmax_thresh_kernel<__bf16>, grid, dim3(256), 0, ST(stream), S, P, ld, strideS, M, Mpad, thresh,
+                       reinterpret_cast<__bf16*>(P_packed), Kp, stride_packed);
+  } else {
+    const int Kp = (M + 31) / 32 * 32;
+    hipLaunchKernelGGL(softmax_thresh_kernel<float>, grid, dim3(256), 0, ST(stream), S, P, ld, strideS, M, Mpad, thresh,
+                       reinterpret_cast<float*>(P_packed), Kp, stride_packed);
+  }
   SP3_LAUNCH_CHECK("sp3_softmax_thresh");
+  return 0;
+}
+
+extern "C" int sp3_colsum_packed(const void* P_packed, int packed_bf16, int rows, int M, float* mem_attn, void* stream) {
+  SP3_CHECK(P_packed && mem_attn && rows > 0 && M > 0, "sp3_colsum_packed: bad arguments");
+  if (packed_bf16) {
+    const int Kp = (M + 63) / 64 * 64;
+    hipLaunchKernelGGL(colsum_packed_kernel<__bf16>, dim3(Kp / 64), dim3(256), 0, ST(stream), (const __bf16*)P_packed, rows, M, Kp, mem_attn);
+  } else {
+    const int Kp = (M + 31) / 32 * 32;
+    hipLaunchKernelGGL(colsum_packed_kernel<float>, dim3(Kp / 32), dim3(256), 0, ST(stream), (const float*)P_packed, rows, M, Kp, mem_attn);
+  }
+  SP3_LAUNCH_CHECK("sp3_colsum_packed");
+  return 0;
+}
+
+extern "C" int sp3_bank_write(const sp3_bank_write_desc* dp, void* stream) {
+  SP3_CHECK(dp != nullptr, "sp3_bank_write: null descriptor");
+  const sp3_bank_write_desc& d = *dp;
+  SP3_CHECK(d.feat_k && d.feat_v && d.k_raw && d.v_raw && d.k_hat && d.v_hat_t && d.s_bank && d.b_bank, "sp3_bank_write: null pointer");
+  SP3_CHECK(d.gamma_k && d.beta_k && d.gamma_v && d.beta_v && d.gamma_q && d.beta_q, "sp3_bank_write: null LayerNorm parameter");
+  SP3_CHECK(d.P > 0 && d.M >= 0 && d.C > 0 && d.C % 256 == 0 && d.cap % 64 == 0 && d.M + d.P <= d.cap,
+            "sp3_bank_write: bad geometry M=%d P=%d C=%d cap=%d", d.M, d.P, d.C, d.cap);
+  SP3_CHECK(d.wdtype == SP3_F32 || d.wdtype == SP3_BF16, "sp3_bank_write: bad wdtype %d", d.wdtype);
+  BankWriteArgs a{d.feat_k, d.feat_v, d.k_raw, d.v_raw, d.k_hat, d.v_hat_t, d.s_bank, d.b_bank, d.gamma_k, d.beta_k,
+                  d.gamma_v, d.beta_v, d.gamma_q, d.beta_q, d.eps, d.alpha, d.M, d.P, d.C, d.cap};
+  const int TG = d.wdtype == SP3_BF16 ? 8 : 4;
+  const int groups = (d.M + d.P + TG - 1) / TG - d.M / TG;
+  const size_t lds = (size_t)TG * d.C * (d.wdtype == SP3_BF16 ? 2 : 4);
+  if (d.wdtype == SP3_BF16) hipLaunchKernelGGL(bank_write_kernel<__bf16>, dim3(groups), dim3(256), lds, ST(stream), a);
+  else hipLaunchKernelGGL(bank_write_kernel<float>, dim3(groups), dim3(256), lds, ST(stream), a);
+  SP3_LAUNCH_CHECK("sp3_bank_write");
+  return 0;
+}
+
+extern "C" int sp3_pack_stats(const float* x, int64_t ldx, int rows, int C, void* packed, int packed_bf16, float* stats, void* stream) {
+  SP3_CHECK(x && packed && stats && rows > 0 && C > 0 && C % 256 == 0 && ldx % 4 == 0, "sp3_pack_stats: bad arguments");
+  if (packed_bf16) hipLaunchKernelGGL(pack_stats_kernel<__bf16>, dim3((rows + 3) / 4), dim3(256), 0, ST(stream), x, ldx, rows, C, (__bf16*)packed, stats);
+  else hipLaunchKernelGGL(pack_stats_kernel<float>, dim3((rows + 3) / 4), dim3(256), 0, ST(stream), x, ldx, rows, C, (float*)packed, stats);
+  SP3_LAUNCH_CHECK("sp3_pack_stats");
+  return 0;
+}
+
+extern "C" int sp3_gather_packed_rows(const void* src, void* dst, const int32_t* sel, int n_sel, int C, int elem_size, void* stream) {
+  SP3_CHECK(src && dst && sel && n_sel > 0 && C > 0 && C % 64 == 0 && (elem_size == 2 || elem_size == 4), "sp3_gather_packed_rows: bad arguments");
+  hipLaunchKernelGGL(gather_packed_rows_kernel, dim3(n_sel), dim3(256), 0, ST(stream), (const char*)src, (char*)dst, sel, C, elem_size);
+  SP3_LAUNCH_CHECK("sp3_gather_packed_rows");
+  return 0;
+}
+
+extern "C" int sp3_gather_packed_cols(const void* src, void* dst, const int32_t* sel, int n_sel, int n_fill, int C, int cap,
+                                      int elem_size, void* stream) {
+  SP3_CHECK(src && dst && sel && n_sel > 0 && C > 0 && C % 16 == 0 && cap % 64 == 0 && n_fill <= cap && n_sel <= n_fill,
+            "sp3_gather_packed_cols: bad arguments");
+  const int TG = 16 / elem_size;
+  dim3 grid((n_fill / TG + 255) / 256, C);
+  if (elem_size == 2)
+    hipLaunchKernelGGL(gather_packed_cols_kernel<__bf16>, grid, dim3(256), 0, ST(stream), (const __bf16*)src, (__bf16*)dst, sel, n_sel, n_fill, cap);
+  else if (elem_size == 4)
+    hipLaunchKernelGGL(gather_packed_cols_kernel<float>, grid, dim3(256), 0, ST(stream), (const float*)src, (float*)dst, sel, n_sel, n_fill, cap);
+  else SP3_CHECK(false, "sp3_gather_packed_cols: elem_size %d", elem_size);
+  SP3_LAUNCH_CHECK("sp3_gather_packed_cols");
   return 0;
 }
 
@@ -258,6 +529,12 @@ extern "C" int sp3_prune_select(const float* attn, const float* count, int M, fl
                                 void* stream) {
   SP3_CHECK(attn && count && sel, "sp3_prune_select: null pointer");
   SP3_CHECK(M > 0 && M <= PRUNE_MAX && top_k > 0 && top_k <= M, "sp3_prune_select: M=%d top_k=%d (M <= %d)", M, top_k, PRUNE_MAX);
+  static bool raised = false;         // one-time opt-in to > 64 KiB of dynamic LDS
+  if (!raised) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(prune_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PRUNE_MAX * 8);
+    SP3_CHECK(e == hipSuccess, "sp3_prune_select: cannot raise dynamic LDS: %s", hipGetErrorString(e));
+    raised = true;
+  }
   hipLaunchKernelGGL(prune_select_kernel, dim3(1), dim3(1024), PRUNE_MAX * 8, ST(stream), attn, count, M, protect, top_k, sel);
   SP3_LAUNCH_CHECK("sp3_prune_select");
   return 0;

@@ -480,6 +480,12 @@ class Engine:
             outs[s_] = [(f1, f2)[s_]] + [x[l][s_].view(B, P, D) for l in range(1, depth)] + [normed[s_].view(B, P, D)]
         return outs[0], outs[1]
 
+    def key_aux(self, R):
+        """fragment-order copy + row-statistics partials of the keys, written by the key MLP's last GEMM: the next
+        memory read consumes feat_k2 as a GEMM operand with LN_q folded (problem 1 of the pair)"""
+        E = self.cfg.enc_dim
+        return self.wspg("keyg_packed", R, E), self.ws("keyg_stats", (2, R, E // 32, 2))
+
     def encode_feat_keys_grouped(self, feat1, feat2, normed1, normed2, R, out1, out2):
         """both key MLPs (spann3r/model.py:299-303) as one grouped launch per layer; normed1/2 = the decoders' last outputs"""
         cfg, w = self.cfg, self.w
@@ -490,18 +496,27 @@ class Engine:
         h = self.wspg("keyg_hidden", R, Kd)
         ops.gemm(feat1, w["keyg.0.w"], h, M=R, N=Kd, K=Kd, lda=E, ldc=Kd, bias=w["keyg.0.b"], act=ACT_GELU, A2=normed1, lda2=D, K1=E,
                  batch=2, strideA=dF // 4, strideW=w["keyg.0.w"].stride, strideC=h.stride, sb={"bias": Kd * 4, "A2": dN})
-        ops.gemm(h, w["keyg.2.w"], out1, M=R, N=E, K=Kd, lda=Kd, ldc=E, bias=w["keyg.2.b"],
-                 batch=2, strideA=h.stride, strideW=w["keyg.2.w"].stride, strideC=dO // 4, sb={"bias": E * 4})
+        kp, kst = self.key_aux(R)
+        ops.gemm(h, w["keyg.2.w"], out1, M=R, N=E, K=Kd, lda=Kd, ldc=E, bias=w["keyg.2.b"], stats_out=kst, c2=kp,
+                 batch=2, strideA=h.stride, strideW=w["keyg.2.w"].stride, strideC=dO // 4,
+                 sb={"bias": E * 4, "stats_out": R * (E // 32) * 8, "c2": kp.stride * es})
+        return kp.at(1), kst[1]
 
-    def encode_feat_key(self, feat, dec_last, R, num, out):
+    def encode_feat_key(self, feat, dec_last, R, num, out, aux=False):
         """spann3r/model.py:299-303: Linear(1792,1792) -> GELU -> Linear(1792,1024) on cat(feat, dec[-1]);
-        the concatenation is never materialised (split-A GEMM)."""
+        the concatenation is never materialised (split-A GEMM).  aux: also write the fragment-order copy and the
+        row-statistics partials of the key (returned; see key_aux)."""
         cfg, w = self.cfg, self.w
         E, D, Kd = cfg.enc_dim, cfg.dec_dim, cfg.key_dim
         h = self.wsp("key_hidden%d" % num, R, Kd)
         pre = "key%d." % num
         ops.gemm(feat, w[pre + "0.w"], h, M=R, N=Kd, K=Kd, lda=E, ldc=Kd, bias=w[pre + "0.b"], act=ACT_GELU,
                  A2=dec_last, lda2=D, K1=E)
+        if aux:
+            kp, kst = self.key_aux(R)
+            ops.gemm(h, w[pre + "2.w"], out, M=R, N=E, K=Kd, lda=Kd, ldc=E, bias=w[pre + "2.b"], stats_out=kst[num - 1],
+                     c2=kp.at(num - 1))
+            return kp.at(num - 1), kst[num - 1]
         ops.gemm(h, w[pre + "2.w"], out, M=R, N=E, K=Kd, lda=Kd, ldc=E, bias=w[pre + "2.b"])
         return out
 

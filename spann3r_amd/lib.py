@@ -56,6 +56,17 @@ class ReduceLnDesc(C.Structure):
     ]
 
 
+class BankWriteDesc(C.Structure):
+    _fields_ = [
+        ("feat_k", C.c_void_p), ("feat_v", C.c_void_p), ("k_raw", C.c_void_p), ("v_raw", C.c_void_p),
+        ("k_hat", C.c_void_p), ("v_hat_t", C.c_void_p), ("s_bank", C.c_void_p), ("b_bank", C.c_void_p),
+        ("gamma_k", C.c_void_p), ("beta_k", C.c_void_p), ("gamma_v", C.c_void_p), ("beta_v", C.c_void_p),
+        ("gamma_q", C.c_void_p), ("beta_q", C.c_void_p),
+        ("eps", C.c_float), ("alpha", C.c_float),
+        ("M", C.c_int32), ("P", C.c_int32), ("C", C.c_int32), ("cap", C.c_int32), ("wdtype", C.c_int32),
+    ]
+
+
 _lib = None
 
 _PROTOS = {
@@ -78,7 +89,12 @@ _PROTOS = {
                              C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
                              C.c_void_p],
     "sp3_softmax_thresh": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float,
-                           C.c_int, C.c_void_p, C.c_int64, C.c_void_p],
+                           C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p],
+    "sp3_colsum_packed": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
+    "sp3_bank_write": [C.POINTER(BankWriteDesc), C.c_void_p],
+    "sp3_pack_stats": [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p],
+    "sp3_gather_packed_rows": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "sp3_gather_packed_cols": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "sp3_colsum_accum": [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
     "sp3_cos_sim": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
     "sp3_mem_append": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p],

@@ -43,10 +43,12 @@ def _build_param_tree(root: nn.Module, spec):
 class SpatialMemory:
     """Device-resident spatial memory (reference: spann3r/model.py:11-210).
 
-    Bank layout per batch element (capacity `cap` rows, fixed for the sequence):
-      mem_k_raw [cap,1024] fp32  = reference mem_k          mem_v_raw [cap,1024] fp32 = reference mem_v
-      k_hat     [cap,1024] wdt   = LN_k(mem_k)              v_hat_t   [1024,cap] wdt  = LN_v(mem_v)^T
-      mem_attn  [cap] fp32, mem_count [cap] fp32
+    Bank layout per batch element (capacity `cap` rows, a multiple of 64, fixed for the sequence):
+      k_raw [cap,1024] fp32 = reference mem_k            v_raw [cap,1024] fp32 = reference mem_v
+      k_hat  fragment-order [cap,1024] wdt = gamma_q (.) LN_k(mem_k)   (W operand of the S GEMM; LN_q is folded into it)
+      v_hat_t fragment-order [1024,cap] wdt = LN_v(mem_v)^T             (W operand of the P.V GEMM)
+      s_bank, b_bank [cap] fp32 (fold constants of LN_q), mem_attn [cap] fp32, mem_count [cap] fp32
+    One launch writes a frame (sp3_bank_write); a read is S GEMM -> softmax/threshold -> P.V GEMM (+ column sums).
     """
 
     def __init__(self, engine: Engine, batch, num_patches, capacity, attn_thresh=5e-4, long_mem_size=4000,
@@ -61,6 +63,7 @@ class SpatialMemory:
         self.num_patches = num_patches
         self.cap = (capacity + 63) // 64 * 64
         dev, wdt = engine.device, engine.wdt
+        self.kb = 64 if wdt == torch.bfloat16 else 32           # k-block of the MFMA dtype
         self._banks = [self._alloc(dev, wdt), None]   # second bank allocated on first prune
         self._cur = 0
         self.M = 0
@@ -71,16 +74,26 @@ class SpatialMemory:
         self._score_host, self._score_event, self._score_pending = None, None, False
         self._cos_scratch = torch.empty(max(work_mem_size, 1) * num_patches, device=dev)
         self._sel = torch.zeros(batch, max(long_mem_size, 1), dtype=torch.int32, device=dev)
+        w = engine.w
+        self._norms = (w["norm_k.w"], w["norm_k.b"], w["norm_v.w"], w["norm_v.b"], w["norm_q.w"], w["norm_q.b"])
 
     def _alloc(self, dev, wdt):
         B, cap, C = self.B, self.cap, self.C
         return dict(k_raw=torch.zeros(B, cap, C, device=dev), v_raw=torch.zeros(B, cap, C, device=dev),
-                    k_hat=torch.zeros(B, cap, C, dtype=wdt, device=dev), v_hat_t=torch.zeros(B, C, cap, dtype=wdt, device=dev),
+                    k_hat=torch.zeros((B,) + ops.packed_shape(cap, C, wdt), dtype=wdt, device=dev),
+                    v_hat_t=torch.zeros((B,) + ops.packed_shape(C, cap, wdt), dtype=wdt, device=dev),
+                    s_bank=torch.zeros(B, cap, device=dev), b_bank=torch.zeros(B, cap, device=dev),
                     attn=torch.zeros(B, cap, device=dev), count=torch.zeros(B, cap, device=dev))
+
+    def bank_bytes(self):
+        return sum(sum(t.numel() * t.element_size() for t in bk.values()) for bk in self._banks if bk is not None)
 
     @property
     def bank(self):
         return self._banks[self._cur]
+
+    def _bank_of(self, bk, b):
+        return {k: v[b] for k, v in bk.items()}
 
     def reset(self):
         """Start a new sequence on the same arena (stale rows are never read: every read is bounded by M)."""
@@ -113,46 +126,48 @@ class SpatialMemory:
         return None if self.M == 0 else self.bank["count"][:, :self.M, None]
 
     # ------------------------------------------------------------------ read (:145-183)
-    def memory_read(self, feat, out):
-        """feat fp32 [B,P,1024] (the query, feat_k2) -> out = attn . LN_v(mem_v) + feat ; mem_attn += colsum(attn)."""
-        eng, bk, w = self.eng, self.bank, self.eng.w
-        B, P, C, M = self.B, self.P, self.C, self.M
+    def memory_read(self, feat, out, feat_packed=None, feat_stats=None):
+        """feat fp32 [B,P,1024] (the query, feat_k2) -> out = attn . LN_v(mem_v) + feat ; mem_attn += colsum(attn).
+        feat_packed / feat_stats: fragment-order copy and row-statistics partials of `feat` when its producer already
+        wrote them (B == 1: the key-MLP GEMM's c2 / stats_out); otherwise one sp3_pack_stats launch makes them."""
+        eng, bk = self.eng, self.bank
+        B, P, C, M, kb = self.B, self.P, self.C, self.M, self.kb
         assert M > 0
         prof = ops._prof
         e0 = prof.region_begin() if prof is not None else None
-        Mpad = (M + 7) // 8 * 8
-        ld = (self.cap + 7) // 8 * 8
-        qn = eng.ws("mem_qn", (B * P, C), eng.adt)      # row-major: the S GEMM is batched over sequences
-        ops.layernorm(feat, w["norm_q.w"], w["norm_q.b"], 1e-5, qn, rows=B * P, C_=C)
+        Kp = (M + kb - 1) // kb * kb
+        ld = self.cap
+        Pp = (P + 15) // 16 * 16
         S = eng.ws("mem_S", (B, P, ld))
-        Pm = eng.ws("mem_P", (B, P, ld))
-        ops.gemm(qn, bk["k_hat"], S, M=P, N=M, K=C, lda=C, ldc=ld, alpha=1.0 / (C ** 0.5), batch=B,
-                 strideA=P * C, strideW=self.cap * C, strideC=P * ld)
-        if eng.adt == torch.bfloat16:
-            # bf16: the probabilities reach the P.V GEMM as a fragment-order bf16 operand (coalesced, half the bytes);
-            # long banks split K over several workgroups per output tile (64 tiles otherwise) and one reduce launch adds q
-            Kp = (M + 63) // 64 * 64
-            Pp = 16 * ((P + 15) // 16)
-            pk = eng.ws("mem_P_packed", (B, Pp * ((self.cap + 63) // 64 * 64)), torch.bfloat16, zero=True)
-            ops.softmax_thresh(S, Pm, ld=ld, rows=P, M=M, Mpad=Mpad, thresh=self.attn_thresh, batch=B, strideS=P * ld,
-                               packed=pk, stride_packed=pk.shape[1])
-            S_k = 1
-            while Kp // (2 * S_k) >= 2048 and S_k < 16:
-                S_k *= 2
+        pk = eng.ws("mem_P_packed", (B, Pp * self.cap), eng.adt, zero=True)
+        if feat_packed is None or B > 1:
+            qp = [eng.wsp("mem_q_packed%d" % b, P, C) for b in range(B)]
+            qs = eng.ws("mem_q_stats", (B, P, C // 32, 2))
             for b in range(B):
-                A = ops.PackedAct(P, Kp, torch.bfloat16, eng.device, data=pk[b])
-                if S_k == 1:
-                    ops.gemm(A, bk["v_hat_t"][b], out[b], M=P, N=C, K=Kp, lda=Kp, ldc=C, ldw=self.cap, res1=feat[b], ldr1=C)
-                else:
-                    part = eng.ws("mem_pv_partial", (S_k * P * C,))
-                    ops.gemm(A, bk["v_hat_t"][b], part, M=P, N=C, K=Kp, lda=Kp, ldc=C, ldw=self.cap, splitk=S_k)
-                    ops.reduce_ln(part, S_k, P, C, res=feat[b], ldres=C, x_out=out[b], ldx=C)
+                ops.pack_stats(feat[b], qp[b], qs[b], rows=P, C_=C)
         else:
-            ops.softmax_thresh(S, Pm, ld=ld, rows=P, M=M, Mpad=Mpad, thresh=self.attn_thresh, batch=B, strideS=P * ld)
-            ops.gemm(Pm, bk["v_hat_t"], out, M=P, N=C, K=Mpad, lda=ld, ldc=C, ldw=self.cap, res1=feat, ldr1=C, batch=B,
-                     strideA=P * ld, strideW=C * self.cap, strideC=P * C)
+            qp, qs = [feat_packed], feat_stats.view(1, P, C // 32, 2)
+        alpha = 1.0 / (C ** 0.5)
         for b in range(B):
-            ops.colsum_accum(Pm[b], ld, P, M, bk["attn"][b])
+            # S = LN_q(q) . K_hat^T / 32: raw q (fragment order) x (gamma_q (.) K_hat), LN_q folded through s_bank / b_bank
+            ops.gemm(qp[b], ops.PackedWeight.wrap(bk["k_hat"][b], M, C), S[b], M=P, N=M, K=C, lda=C, ldc=ld, alpha=alpha,
+                     bias=bk["b_bank"][b], ln=ops.LnFold(qs[b], C, bk["s_bank"][b], 1e-5))
+        ops.softmax_thresh(S, None, ld=ld, rows=P, M=M, Mpad=M, thresh=self.attn_thresh, batch=B, strideS=P * ld,
+                           packed=pk, stride_packed=pk.shape[1])
+        # long banks: K split over several workgroups per output tile (64 tiles otherwise), one reduce launch adds q
+        S_k = 1
+        while Kp // (2 * S_k) >= 2048 and S_k < 16:
+            S_k *= 2
+        for b in range(B):
+            A = ops.PackedAct(P, Kp, eng.adt, eng.device, data=pk[b])
+            Wv = ops.PackedWeight.wrap(bk["v_hat_t"][b], C, self.cap)
+            if S_k == 1:
+                ops.gemm(A, Wv, out[b], M=P, N=C, K=Kp, lda=Kp, ldc=C, ldw=self.cap, res1=feat[b], ldr1=C)
+            else:
+                part = eng.ws("mem_pv_partial", (S_k * P * C,))
+                ops.gemm(A, Wv, part, M=P, N=C, K=Kp, lda=Kp, ldc=C, ldw=self.cap, splitk=S_k)
+                ops.reduce_ln(part, S_k, P, C, res=feat[b], ldres=C, x_out=out[b], ldx=C)
+            ops.colsum_packed(pk[b], P, M, bk["attn"][b])
         if prof is not None:
             es = bk["k_hat"].element_size()
             # algorithmic bytes of one read (SURVEY.md §8d): K_hat + V_hat once, plus the query in and the fused features out
@@ -164,15 +179,11 @@ class SpatialMemory:
     def stage_write(self, feat_k, feat_v):
         """Speculatively writes frame (k, v) into rows [M, M+P) of the bank; `commit()` makes it visible.
         (A skipped frame simply never advances M, so the slot is overwritten by the next write.)"""
-        eng, bk, w = self.eng, self.bank, self.eng.w
+        bk = self.bank
         B, P, C, M = self.B, self.P, self.C, self.M
         assert M + P <= self.cap, "spatial memory capacity exceeded"
         for b in range(B):
-            ops.copy2d(feat_k[b], C, bk["k_raw"][b, M:], C, P, C)
-            ops.copy2d(feat_v[b], C, bk["v_raw"][b, M:], C, P, C)
-            ops.layernorm(feat_k[b], w["norm_k.w"], w["norm_k.b"], 1e-5, bk["k_hat"][b, M:], rows=P, C_=C)
-            ops.layernorm(feat_v[b], w["norm_v.w"], w["norm_v.b"], 1e-5, bk["v_hat_t"][b, :, M:], rows=P, C_=C,
-                          ldo=self.cap, transposed=True)
+            ops.bank_write(feat_k[b], feat_v[b], self._bank_of(bk, b), M, P, C, self.cap, self._norms, 1.0 / (C ** 0.5))
 
     def commit(self):
         bk = self.bank
@@ -273,10 +284,10 @@ class SpatialMemory:
             sel = self._sel[b]
             ops.gather_rows(src["k_raw"][b], dst["k_raw"][b], sel, k, C)
             ops.gather_rows(src["v_raw"][b], dst["v_raw"][b], sel, k, C)
-            ops.gather_rows(src["k_hat"][b], dst["k_hat"][b], sel, k, C)
-            ops.gather_cols(src["v_hat_t"][b], self.cap, dst["v_hat_t"][b], self.cap, sel, k, self.cap, C)
-            ops.gather_1d(src["attn"][b], dst["attn"][b], sel, k)
-            ops.gather_1d(src["count"][b], dst["count"][b], sel, k)
+            ops.gather_packed_rows(src["k_hat"][b], dst["k_hat"][b], sel, k, C)
+            ops.gather_packed_cols(src["v_hat_t"][b], dst["v_hat_t"][b], sel, k, self.cap, C, self.cap)
+            for name in ("s_bank", "b_bank", "attn", "count"):
+                ops.gather_1d(src[name][b], dst[name][b], sel, k)
         print("Memory pruned:", M, "->", k)
         self.events.append("prune %d->%d" % (M, k))
         self._cur = 1 - self._cur
@@ -321,6 +332,7 @@ class _SequenceRunner:
         self.k2 = torch.empty(B, self.P, self.E, device=dev)
         self.v = torch.empty(B, self.P, self.E, device=dev)
         self.mem = None
+        self.k2_aux = (None, None)
         self.graphs = {}
         self.seen = set()
         self.out = None
@@ -447,7 +459,8 @@ class _SequenceRunner:
             if not self.batched:
                 ops.copy2d(self.feat2, E, self.feat1, E, B * P, E)      # feat1 <- previous feat2 (:294)
                 ops.copy2d(self.feat_pre, E, self.feat2, E, B * P, E)   # feat2 <- the frame encoded during the previous step
-            mem.memory_read(self.k2, self.fuse)                         # reads k2 before the key MLP overwrites it
+            # reads k2 (and its fragment-order copy / statistics) before the key MLP of this step overwrites them
+            mem.memory_read(self.k2, self.fuse, *(self.k2_aux if B == 1 else (None, None)))
             f1 = self.fuse
         if has_next:
             st[3].wait_stream(main)
@@ -456,12 +469,12 @@ class _SequenceRunner:
         if eng.packed_attn and self.model.grouped_decoder:
             # both decoder sides and both key MLPs as grouped launches on the main stream: no per-layer fork/join
             dec1, dec2 = eng.decoder_grouped(f1, self.feat2, B, self.nh, self.nw)
-            eng.encode_feat_keys_grouped(self.feat1, self.feat2, dec1[-1], dec2[-1], B * P, self.k1, self.k2)
+            self.k2_aux = eng.encode_feat_keys_grouped(self.feat1, self.feat2, dec1[-1], dec2[-1], B * P, self.k1, self.k2)
         else:
             dec1, dec2 = eng.decoder(f1, self.feat2, B, self.nh, self.nw, self.nh, self.nw, streams=st)   # joined on return
             st[2].wait_stream(main)
             with torch.cuda.stream(st[2]):
-                eng.encode_feat_key(self.feat2, dec2[-1], B * P, 2, self.k2)
+                self.k2_aux = eng.encode_feat_key(self.feat2, dec2[-1], B * P, 2, self.k2, aux=True)
             eng.encode_feat_key(self.feat1, dec1[-1], B * P, 1, self.k1)
             main.wait_stream(st[2])
         if not self.training and mem.sim_needed():

@@ -113,7 +113,7 @@ def pick_tile(M, N, batch=1, splitk=1, conv=False, K=0, packed_bf16=False, plain
     lds_ok = not conv and splitk == 1 and packed_bf16 and K % 64 == 0
     if lds_ok and M >= 1024 and N >= 2304 and N % 128 == 0:
         return 5 if (N % 4096 == 0 or ((M + 127) // 128) * (N // 128) * batch >= 1024) else 6
-    if not conv and M >= 1024 and splitk == 1:
+    if not conv and M >= 1024:
         return 1
     if lds_ok and 112 < M <= 224 and plain and N >= 3072 and K <= 1024 and ln_nt <= 32:
         return 13
@@ -217,6 +217,13 @@ class PackedWeight:
         pad[:N, :K] = w2d
         # [nb, r, kb, g, h, e] -> [nb, kb, h, g, r, e]
         self.data = pad.view(nb, 16, nkb, 4, 2, CH // 2).permute(0, 2, 4, 3, 1, 5).contiguous()
+
+    @classmethod
+    def wrap(cls, data, N, K):
+        """a fragment-order [N, K] operand that already lives in `data` (e.g. a spatial-memory bank written by sp3_bank_write)"""
+        w = object.__new__(cls)
+        w.N, w.K, w.dtype, w.data = N, K, data.dtype, data
+        return w
 
     def data_ptr(self):
         return self.data.data_ptr()
@@ -496,14 +503,51 @@ def attention_packed(qp, q_cols, q_col0, npad_q, kp, k_cols, k_col0, npad_k, vtp
 
 
 def softmax_thresh(S, P, *, ld, rows, M, Mpad, thresh, batch=1, strideS=0, packed=None, stride_packed=0):
-    """packed: optional bf16 buffer that receives P in fragment order [rows, ceil64(M)] (the P.V GEMM's packed A)"""
-    _timed("softmax_thresh", 8.0 * batch * rows * M, 8.0 * batch * rows * M,
-           lambda: L.check(L.load().sp3_softmax_thresh(S.data_ptr(), P.data_ptr(), ld, strideS, rows, M, Mpad, float(thresh),
-                                                       batch, L.ptr(packed), stride_packed, L.stream_ptr()), "sp3_softmax_thresh"))
+    """P: optional fp32 row-major output; packed: optional bf16 / fp32 buffer that receives the probabilities in fragment
+    order [rows, M rounded up to a k-block] (the P.V GEMM's packed A)"""
+    pbf = packed is not None and packed.dtype == torch.bfloat16
+    _timed("softmax_thresh", 8.0 * batch * rows * M, (4.0 + (0.0 if P is None else 4.0) + (0.0 if packed is None else packed.element_size())) * batch * rows * M,
+           lambda: L.check(L.load().sp3_softmax_thresh(S.data_ptr(), L.ptr(P), ld, strideS, rows, M, Mpad, float(thresh),
+                                                       batch, L.ptr(packed), stride_packed, int(pbf), L.stream_ptr()), "sp3_softmax_thresh"))
 
 
 def colsum_accum(P, ld, rows, M, mem_attn):
     L.check(L.load().sp3_colsum_accum(P.data_ptr(), ld, rows, M, mem_attn.data_ptr(), L.stream_ptr()), "sp3_colsum_accum")
+
+
+def colsum_packed(packed, rows, M, mem_attn):
+    _timed("colsum_packed", 1.0 * rows * M, 1.0 * packed.element_size() * rows * M,
+           lambda: L.check(L.load().sp3_colsum_packed(packed.data_ptr(), int(packed.dtype == torch.bfloat16), rows, M, mem_attn.data_ptr(),
+                                                      L.stream_ptr()), "sp3_colsum_packed"))
+
+
+def bank_write(feat_k, feat_v, bank, M, P, C_, cap, norms, alpha, eps=1e-5):
+    """bank: dict with k_raw, v_raw, k_hat, v_hat_t, s_bank, b_bank (one batch element); norms: (gk, bk, gv, bv, gq, bq)"""
+    d = L.BankWriteDesc()
+    d.feat_k, d.feat_v = feat_k.data_ptr(), feat_v.data_ptr()
+    d.k_raw, d.v_raw, d.k_hat, d.v_hat_t = bank["k_raw"].data_ptr(), bank["v_raw"].data_ptr(), bank["k_hat"].data_ptr(), bank["v_hat_t"].data_ptr()
+    d.s_bank, d.b_bank = bank["s_bank"].data_ptr(), bank["b_bank"].data_ptr()
+    d.gamma_k, d.beta_k, d.gamma_v, d.beta_v, d.gamma_q, d.beta_q = [t.data_ptr() for t in norms]
+    d.eps, d.alpha, d.M, d.P, d.C, d.cap, d.wdtype = eps, alpha, M, P, C_, cap, wdtype_of(bank["k_hat"])
+    es = bank["k_hat"].element_size()
+    _timed("bank_write", 20.0 * P * C_, P * C_ * (16.0 + 2 * es),
+           lambda: L.check(L.load().sp3_bank_write(C.byref(d), L.stream_ptr()), "sp3_bank_write"))
+
+
+def pack_stats(x, packed, stats, *, rows, C_, ldx=None):
+    _f32(x, "x")
+    L.check(L.load().sp3_pack_stats(x.data_ptr(), C_ if ldx is None else ldx, rows, C_, packed.data_ptr(),
+                                    int(packed.dtype == torch.bfloat16), stats.data_ptr(), L.stream_ptr()), "sp3_pack_stats")
+
+
+def gather_packed_rows(src, dst, sel, n_sel, C_):
+    L.check(L.load().sp3_gather_packed_rows(src.data_ptr(), dst.data_ptr(), sel.data_ptr(), n_sel, C_, src.element_size(),
+                                            L.stream_ptr()), "sp3_gather_packed_rows")
+
+
+def gather_packed_cols(src, dst, sel, n_sel, n_fill, C_, cap):
+    L.check(L.load().sp3_gather_packed_cols(src.data_ptr(), dst.data_ptr(), sel.data_ptr(), n_sel, n_fill, C_, cap, src.element_size(),
+                                            L.stream_ptr()), "sp3_gather_packed_cols")
 
 
 def cos_sim(k, wm, T, P, C_, score, scratch):

@@ -44,7 +44,7 @@ def gather_stats(frames, seconds, extra=(), device="cpu"):
     """all_gather of [frames, seconds, *extra] (float64) -> tensor [world, 2+len(extra)].
     Works without an initialised process group (world 1)."""
     rec = torch.tensor([float(frames), float(seconds)] + [float(x) for x in extra], dtype=torch.float64, device=device)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return rec[None].cpu()
     outs = [torch.empty_like(rec) for _ in range(dist.get_world_size())]
     dist.all_gather(outs, rec)

@@ -159,9 +159,18 @@ dist.init_process_group(backend="gloo", init_method="env://")
 rank, world = dist.get_rank(), dist.get_world_size()
 ids = shard(6, rank, world)
 seqs = [make_sequence(s, 3, 32, 48) for s in ids]
-def fwd(seq):                                   # stand-in for model.forward: the sharding/timing/gather path is what is tested
-    return float(sum(f["img"].sum() for f in seq))
+# a real forward-shaped callable on the CPU: frames -> (preds, preds_all), the oracle's port of Spann3R.forward on the
+# tiny geometry (the HIP model needs a GPU; the sharding / timing / gather path around it is the same)
+from oracle import spann3r_oracle as O
+from spann3r_amd.config import TINY
+from spann3r_amd.weights import synth_state_dict
+sd = synth_state_dict(0, TINY)
+def fwd(seq):
+    preds, preds_all = O.forward(seq, sd, TINY)
+    assert len(preds) == len(seq) and len(preds_all) == len(seq) - 1 and tuple(preds[0]["pts3d"].shape) == (1, 32, 48, 3)
+    return preds, preds_all
 frames, seconds, last = run_sequences(fwd, seqs)
+assert torch.isfinite(last[0][-1]["conf"]).all()
 dist.barrier()
 stats = gather_stats(frames, seconds, extra=[float(sum(ids))])
 fps, tot, mx = aggregate(stats)
@@ -169,6 +178,7 @@ if rank == 0:
     assert stats.shape == (2, 3), stats.shape
     assert tot == 18 and sorted(stats[:, 2].tolist()) == [6.0, 9.0], stats
     assert mx == float(stats[:, 1].max()) and fps == tot / mx
+    # different ranks ran different sequences (seeded per sequence id)
     print("OK", tot)
 dist.destroy_process_group()
 '''
@@ -181,8 +191,33 @@ def test_two_rank_sharding_and_stats_gather():
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", WORLD_SIZE="2")
         procs = [subprocess.Popen([sys.executable, script], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
                                   stderr=subprocess.STDOUT) for r in range(2)]
-        outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+        outs = [p.communicate(timeout=600)[0].decode() for p in procs]
         assert all(p.returncode == 0 for p in procs), outs
         assert "OK 18" in outs[0]
     from spann3r_amd.runner import shard
     assert shard(8, 3, 8) == [3] and shard(10, 1, 4) == [1, 5, 9]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/croco/models"), reason="needs the reference checkout (build container only)")
+def test_curope_shim_is_selected_by_unmodified_reference():
+    """shims/curope satisfies the reference's only native FFI: with it on sys.path the UNMODIFIED
+    croco/models/pos_embed.py:106-110 picks cuRoPE2D (curope2d.py:6-9 `import curope`) instead of the torch fallback,
+    and the module it binds is ours."""
+    code = (
+        "import sys; sys.dont_write_bytecode = True\n"
+        "sys.path[:0] = [%r, %r, '/root/reference']\n"
+        "import dust3r.utils.path_to_croco\n"
+        "import models.pos_embed as pe, models.curope.curope2d as c2d, curope\n"
+        "assert pe.RoPE2D is c2d.cuRoPE2D, pe.RoPE2D\n"
+        "assert c2d._kernels is curope and curope.__file__.startswith(%r), curope.__file__\n"
+        "import torch\n"
+        "try:\n"
+        "    curope.rope_2d(torch.zeros(1, 4, 2, 64), torch.zeros(1, 4, 2, dtype=torch.int64), 100.0, 1.0)\n"
+        "except RuntimeError as e:\n"
+        "    assert 'GPU' in str(e), e\n"
+        "else:\n"
+        "    raise SystemExit('CPU tensors must be refused')\n"
+        "print('shim ok')\n" % (os.path.join(REPO, "shims"), REPO, os.path.join(REPO, "shims")))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "shim ok" in out.stdout, out.stdout + out.stderr
+    assert "slow pytorch version" not in out.stdout

@@ -443,3 +443,23 @@ def test_cfg3_512x13_vs_reference(full_sd, precision, tol):
     11264 bank tokens, against the reference dump."""
     err = _run_sequence_fixture("spann3r_cfg3_512x13.npz", full_sd, precision)
     assert max(err.values()) < tol, err
+
+
+def test_stats_gather_through_rccl_world1():
+    """runner.gather_stats on the DEVICE through the nccl (= RCCL) backend: a one-rank process group exercises the same
+    all_gather call the 8-GPU job issues (bench.py: one record per rank, gathered on the GPU, max over ranks)."""
+    import socket
+    import torch.distributed as dist
+    from spann3r_amd.runner import gather_stats, aggregate
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        stats = gather_stats(20, 0.05, extra=[3.0], device=torch.device("cuda", 0))
+        assert tuple(stats.shape) == (1, 3) and stats.dtype == torch.float64 and not stats.is_cuda
+        fps, frames, seconds = aggregate(stats)
+        assert frames == 20 and seconds == 0.05 and abs(fps - 400.0) < 1e-9
+    finally:
+        dist.destroy_process_group()

@@ -541,21 +541,30 @@ def test_layernorm(C):
 
 
 # ----------------------------------------------------------------------------- spatial-memory kernels
+@pytest.mark.parametrize("pdt", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("thresh", [0.0, 5e-4])
-def test_softmax_thresh_and_colsum(thresh):
+def test_softmax_thresh_and_colsum(thresh, pdt):
     ops = _ops()
     B, rows, M, ld = 2, 37, 1765, 1792
     S = rnd(B, rows, ld, seed=1) * 4
     Pm = torch.full((B, rows, ld), float("nan"), device=DEV)
     Mpad = (M + 7) // 8 * 8
-    Kp, rp = (M + 63) // 64 * 64, (rows + 15) // 16 * 16
-    pk = torch.full((B, rp * Kp), float("nan"), device=DEV, dtype=torch.bfloat16)
+    kb = 64 if pdt == torch.bfloat16 else 32
+    Kp, rp = (M + kb - 1) // kb * kb, (rows + 15) // 16 * 16
+    pk = torch.full((B, rp * Kp), float("nan"), device=DEV, dtype=pdt)
     ops.softmax_thresh(S.to(DEV), Pm, ld=ld, rows=rows, M=M, Mpad=Mpad, thresh=thresh, batch=B, strideS=rows * ld,
                        packed=pk, stride_packed=rp * Kp)
-    # the fragment-order bf16 copy holds exactly the rounded probabilities, zero filled up to Kp
+    # the fragment-order copy holds exactly the (rounded) probabilities, zero filled up to Kp
+    dense = []
     for b_ in range(B):
-        dense = ops.PackedAct(rows, Kp, torch.bfloat16, DEV, data=pk[b_].view(ops.packed_shape(rows, Kp, torch.bfloat16))).to_dense()
-        assert torch.equal(dense[:, :M], Pm[b_, :, :M].to(torch.bfloat16)) and float(dense[:, M:].float().abs().max()) == 0.0
+        dense.append(ops.PackedAct(rows, Kp, pdt, DEV, data=pk[b_].view(ops.packed_shape(rows, Kp, pdt))).to_dense())
+        assert torch.equal(dense[b_][:, :M], Pm[b_, :, :M].to(pdt)) and float(dense[b_][:, M:].float().abs().max()) == 0.0
+    # packed-only call (what memory_read issues): same fragment-order bytes for the valid rows
+    pk2 = torch.full((B, rp * Kp), float("nan"), device=DEV, dtype=pdt)
+    ops.softmax_thresh(S.to(DEV), None, ld=ld, rows=rows, M=M, Mpad=M, thresh=thresh, batch=B, strideS=rows * ld,
+                       packed=pk2, stride_packed=rp * Kp)
+    d2 = ops.PackedAct(rows, Kp, pdt, DEV, data=pk2[0].view(ops.packed_shape(rows, Kp, pdt))).to_dense()
+    assert torch.equal(d2, dense[0])
     a = torch.softmax(S[..., :M].double(), -1)
     if thresh > 0:
         a32 = torch.softmax(S[..., :M], -1)
@@ -569,6 +578,83 @@ def test_softmax_thresh_and_colsum(thresh):
     before = attn.clone()
     ops.colsum_accum(Pm[0], ld, rows, M, attn)
     assert rel_err((attn - before).cpu(), got[0, :, :M].double().sum(0)) < 1e-5
+    # column sums straight from the fragment-order copy: exactly the sums of the stored (rounded) probabilities
+    attn2 = before.clone()
+    pk[:, :] = torch.where(torch.isnan(pk), torch.zeros_like(pk), pk)      # pad rows of the test buffer were never written
+    ops.colsum_packed(pk[0], rows, M, attn2)
+    assert rel_err((attn2 - before).cpu(), dense[0][:, :M].double().sum(0).cpu()) < 1e-5
+
+
+@pytest.mark.parametrize("wdt", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("M0", [0, 196, 588])
+def test_bank_write_pack_stats_packed_gathers(wdt, M0):
+    """sp3_bank_write (one launch per stored frame): raw copies, gamma_q (.) LN_k(k) and LN_v(v)^T in fragment order, the
+    LN_q fold constants; then a read's S GEMM with LN_q folded against torch; then the prune gathers on the packed banks."""
+    ops = _ops()
+    P, C, cap = 196, 1024, 1024
+    kb = 64 if wdt == torch.bfloat16 else 32
+    cast = bf if wdt == torch.bfloat16 else (lambda t: t)
+    names = ("gk", "bk", "gv", "bv", "gq", "bq")
+    nrm = {n: (rnd(C, seed=20 + i) * 0.2 + (1.0 if n[0] == "g" else 0.0)) for i, n in enumerate(names)}
+    bank = dict(k_raw=torch.zeros(cap, C, device=DEV), v_raw=torch.zeros(cap, C, device=DEV),
+                k_hat=torch.zeros(ops.packed_shape(cap, C, wdt), dtype=wdt, device=DEV),
+                v_hat_t=torch.zeros(ops.packed_shape(C, cap, wdt), dtype=wdt, device=DEV),
+                s_bank=torch.zeros(cap, device=DEV), b_bank=torch.zeros(cap, device=DEV))
+    norms = tuple(nrm[n].to(DEV) for n in names)
+    alpha = 1.0 / 32.0
+    ks, vs, M = [], [], M0
+    if M0:                                               # earlier frames first: the new frame must not disturb them
+        k0, v0 = rnd(M0, C, seed=1) * 2, rnd(M0, C, seed=2) * 2
+        for f in range(M0 // P):
+            ops.bank_write(k0[f * P:(f + 1) * P].to(DEV), v0[f * P:(f + 1) * P].to(DEV), bank, f * P, P, C, cap, norms, alpha)
+        ks.append(k0); vs.append(v0)
+    k1, v1 = rnd(P, C, seed=3) * 2 + 0.3, rnd(P, C, seed=4) * 2 - 0.1
+    ops.bank_write(k1.to(DEV), v1.to(DEV), bank, M, P, C, cap, norms, alpha)
+    ks.append(k1); vs.append(v1)
+    K, V = torch.cat(ks), torch.cat(vs)
+    M = M0 + P
+    assert torch.equal(bank["k_raw"][:M].cpu(), K) and torch.equal(bank["v_raw"][:M].cpu(), V)
+    khat = F.layer_norm(K.double(), (C,), nrm["gk"].double(), nrm["bk"].double(), 1e-5)
+    vhat = F.layer_norm(V.double(), (C,), nrm["gv"].double(), nrm["bv"].double(), 1e-5)
+    kp = ops.PackedAct(cap, C, wdt, DEV, data=bank["k_hat"]).to_dense()[:M].float().cpu()
+    tol = 6e-3 if wdt == torch.bfloat16 else 2e-5
+    assert rel_err(kp, khat * nrm["gq"].double()) < tol
+    vt = ops.PackedAct(C, cap, wdt, DEV, data=bank["v_hat_t"]).to_dense().float().cpu()
+    assert rel_err(vt[:, :M], vhat.T) < tol and float(vt[:, M:].abs().max()) == 0.0
+    assert rel_err(bank["s_bank"][:M].cpu(), alpha * kp.double().sum(1)) < 1e-5
+    assert rel_err(bank["b_bank"][:M].cpu(), alpha * (khat * nrm["bq"].double()).sum(1)) < 1e-5
+    # the read's S GEMM: raw q in fragment order, LN_q folded
+    q = rnd(P, C, seed=5) * 1.5 + 0.2
+    qp = ops.PackedAct(P, C, wdt, DEV)
+    qs = torch.zeros(P, C // 32, 2, device=DEV)
+    ops.pack_stats(q.to(DEV), qp, qs, rows=P, C_=C)
+    assert torch.equal(qp.to_dense().cpu(), q.to(wdt)) and rel_err(qs[..., 1].sum(1).cpu(), (q.double() ** 2).sum(1)) < 1e-5
+    S = torch.full((P, cap), float("nan"), device=DEV)
+    ops.gemm(qp, ops.PackedWeight.wrap(bank["k_hat"], M, C), S, M=P, N=M, K=C, lda=C, ldc=cap, alpha=alpha, bias=bank["b_bank"],
+             ln=ops.LnFold(qs, C, bank["s_bank"], 1e-5))
+    qn = F.layer_norm(q.double(), (C,), nrm["gq"].double(), nrm["bq"].double(), 1e-5)
+    assert rel_err(S[:, :M].cpu(), qn @ khat.T * alpha) < (2e-2 if wdt == torch.bfloat16 else 5e-5)
+    # P.V GEMM against the fragment-order V^T with the bank's k-extent (ldw = cap)
+    Kp = (M + kb - 1) // kb * kb
+    pr = torch.softmax(rnd(P, M, seed=6) * 3, -1)
+    Pp = torch.zeros(P, Kp)
+    Pp[:, :M] = pr
+    A = ops.PackedAct.from_dense(Pp.to(DEV).to(wdt))
+    out = torch.empty(P, C, device=DEV)
+    ops.gemm(A, ops.PackedWeight.wrap(bank["v_hat_t"], C, cap), out, M=P, N=C, K=Kp, lda=Kp, ldc=C, ldw=cap, res1=q.to(DEV), ldr1=C)
+    assert rel_err(out.cpu(), cast(pr).double() @ cast(vhat.float()).double() + q.double()) < (1e-2 if wdt == torch.bfloat16 else 5e-5)
+    # prune gathers on the packed banks
+    g = torch.Generator().manual_seed(7)
+    n_sel = M - 40
+    sel_h = torch.randperm(M, generator=g)[:n_sel]
+    sel = sel_h.to(torch.int32).to(DEV)
+    kd = torch.zeros_like(bank["k_hat"])
+    vd = torch.full_like(bank["v_hat_t"], 7.0)
+    ops.gather_packed_rows(bank["k_hat"], kd, sel, n_sel, C)
+    ops.gather_packed_cols(bank["v_hat_t"], vd, sel, n_sel, cap, C, cap)
+    assert torch.equal(ops.PackedAct(cap, C, wdt, DEV, data=kd).to_dense()[:n_sel].cpu(), ops.PackedAct(cap, C, wdt, DEV, data=bank["k_hat"]).to_dense().cpu()[sel_h])
+    vg = ops.PackedAct(C, cap, wdt, DEV, data=vd).to_dense().cpu()
+    assert torch.equal(vg[:, :n_sel], ops.PackedAct(C, cap, wdt, DEV, data=bank["v_hat_t"]).to_dense().cpu()[:, sel_h]) and float(vg[:, n_sel:].abs().max()) == 0.0
 
 
 def test_cos_sim_append_prune_gather():
@@ -596,6 +682,14 @@ def test_cos_sim_append_prune_gather():
     wgt = torch.where(cnt < 10, torch.full_like(at, 1e8), at / cnt)
     order = sorted(range(M), key=lambda j: (-float(wgt[j]), j))[:top_k]
     assert sel.cpu().tolist() == order
+    # the first eval prune of a 512x384 sequence holds 11 * 768 = 8448 tokens (> 8192)
+    M2 = 8448
+    cnt2 = torch.arange(M2 - 1, -1, -1).float() // 768
+    at2 = rnd(M2, seed=15).abs() * (cnt2 + 1)
+    sel2 = torch.zeros(top_k, dtype=torch.int32, device=DEV)
+    ops.prune_select(at2.to(DEV), cnt2.to(DEV), M2, 10.0, top_k, sel2)
+    w2 = torch.where(cnt2 < 10, torch.full_like(at2, 1e8), at2 / cnt2)
+    assert sel2.cpu().tolist() == sorted(range(M2), key=lambda j: (-float(w2[j]), j))[:top_k]
     # gathers
     src = rnd(M, 64, seed=6)
     dst = torch.zeros(top_k, 64, device=DEV)
