@@ -364,3 +364,81 @@ def forward(frames, sd, cfg, training_policy=False, return_memory=False, taps=No
     if return_memory:
         return preds, preds_all, mem
     return preds, preds_all
+
+
+# ----------------------------------------------------------------------------- offline reconstruction (spann3r/model.py:333-471)
+@torch.no_grad()
+def dust3r_forward(view1, view2, sd, cfg):
+    """AsymmetricCroCo3DStereo.forward (dust3r/model.py:213-227).  The reference encodes only half of a symmetrized batch
+    and interleaves (:176-180); encoding every image gives the same features, which is what this restatement does."""
+    f1, p1 = encode_image(view1["img"], sd, cfg)
+    f2, p2 = encode_image(view2["img"], sd, cfg)
+    s1 = view1.get("true_shape", default_shape(view1["img"]))
+    s2 = view2.get("true_shape", default_shape(view2["img"]))
+    dec1, dec2 = decoder(f1, p1, f2, p2, sd, cfg)
+    res1 = downstream_head(dec1, s1, sd, cfg, 1)
+    res2 = downstream_head(dec2, s2, sd, cfg, 2)
+    res2["pts3d_in_other_view"] = res2.pop("pts3d")
+    return res1, res2
+
+
+def find_initial_pair(graph, n_frames):                               # :333-358
+    conf = torch.zeros(n_frames, n_frames)
+    for i in range(len(graph["view1"]["idx"])):
+        c1, c2 = graph["pred1"]["conf"][i], graph["pred2"]["conf"][i]
+        conf[int(graph["view1"]["idx"][i]), int(graph["view2"]["idx"][i])] = ((c1 - 1) / c1).mean() + ((c2 - 1) / c2).mean()
+    flat = int(conf.argmax())
+    return flat // n_frames, flat % n_frames
+
+
+@torch.no_grad()
+def offline_reconstruction(frames, graph, sd, cfg):
+    """Spann3R.offline_reconstruction (:394-471) with find_next_best_view (:360-392), one candidate at a time as the
+    reference does it."""
+    n = len(frames)
+    todo, used = list(range(n)), []
+    mem = SpatialMemoryOracle(sd)
+    i0, i1 = find_initial_pair(graph, n)
+    for i in (i0, i1):
+        used.append(i)
+        todo.remove(i)
+    f, p = encode_image(torch.cat((frames[i0]["img"], frames[i1]["img"]), 0), sd, cfg)
+    (feat1, feat2), (pos1, pos2) = f.chunk(2, 0), p.chunk(2, 0)
+    shape1 = frames[i0].get("true_shape", default_shape(frames[i0]["img"]))
+    shape2 = frames[i1].get("true_shape", default_shape(frames[i1]["img"]))
+    dec1, dec2 = decoder(feat1, pos1, feat2, pos2, sd, cfg)
+    res1 = downstream_head(dec1, shape1, sd, cfg, 1)
+    res2 = downstream_head(dec2, shape2, sd, cfg, 2)
+    feat_k2, preds, preds_all = None, None, []
+    while True:
+        if feat_k2 is not None:
+            feat1, pos1, shape1 = feat2, pos2, shape2
+            feat_fuse = mem.memory_read(feat_k2)
+            best = None
+            for i in todo:                                            # :360-392
+                fi, pi = encode_image(frames[i]["img"], sd, cfg)
+                si = frames[i].get("true_shape", default_shape(frames[i]["img"]))
+                d1, d2 = decoder(feat_fuse, pos1, fi, pi, sd, cfg)
+                r1 = downstream_head(d1, shape1, sd, cfg, 1)
+                r2 = downstream_head(d2, si, sd, cfg, 2)
+                sc = float(((r1["conf"] - 1) / r1["conf"]).mean() + ((r2["conf"] - 1) / r2["conf"]).mean())
+                if sc > (0.0 if best is None else best[0]):
+                    best = (sc, i, d1, d2, r1, r2, fi, pi, si)
+            _, id_n, dec1, dec2, res1, res2, feat2, pos2, shape2 = best
+            todo.remove(id_n)
+            used.append(id_n)
+        feat_k1 = encode_feat_key(feat1, dec1[-1], sd, 1)
+        feat_k2 = encode_feat_key(feat2, dec2[-1], sd, 2)
+        cur_v = encode_cur_value(res1["pts3d"], sd, cfg)
+        mem.add_mem_check(feat_k1, cur_v + feat_k1)
+        res2["pts3d_in_other_view"] = res2.pop("pts3d")
+        if preds is None:
+            preds = [res1]
+        else:
+            res1["pts3d_in_other_view"] = res1.pop("pts3d")
+            preds.append(res1)
+        preds_all.append((res1, res2))
+        if not todo:
+            break
+    preds.append(res2)
+    return preds, preds_all, used

@@ -8,6 +8,7 @@ All arithmetic runs in the HIP kernels of libspann3r_hip.so; there is no CPU / e
 """
 import argparse
 import os
+import weakref
 
 import torch
 import torch.nn as nn
@@ -38,6 +39,53 @@ def _build_param_tree(root: nn.Module, spec):
         mod.register_parameter(parts[-1], prm)
         made[key] = prm
     return made
+
+
+class _Dust3RFacade(nn.Module):
+    """`model.dust3r` (spann3r/model.py:222): holds the DUSt3R parameters under the reference's names and is callable
+    like AsymmetricCroCo3DStereo.forward(view1, view2) -> (res1, res2) (dust3r/model.py:213-227), which is what
+    dust3r.inference.inference() drives to build the pair graph for offline_reconstruction (demo.py:116-118)."""
+
+    def __init__(self, owner):
+        super().__init__()
+        object.__setattr__(self, "_owner_ref", weakref.ref(owner))      # not a submodule: no registration cycle
+
+    @staticmethod
+    def _is_symmetrized(v1, v2):
+        """dust3r/utils/misc.py:29-37: batch entries (2i, 2i+1) are the two orderings of one pair"""
+        x, y = v1.get("instance"), v2.get("instance")
+        if x is None or y is None or len(x) != len(y) or len(x) == 1 or len(x) % 2:
+            return False
+        return all(x[i] == y[i + 1] and x[i + 1] == y[i] for i in range(0, len(x), 2))
+
+    @torch.no_grad()
+    def forward(self, view1, view2):
+        own = self._owner_ref()
+        eng = own.engine
+        img1, img2 = view1["img"], view2["img"]
+        B = img1.shape[0]
+        shape1, shape2 = own._true_shape(view1), own._true_shape(view2)
+        p = own.cfg.patch
+
+        def enc_pair(a, b):                                  # dust3r/model.py:156-165
+            if a.shape[-2:] == b.shape[-2:]:
+                f, _ = eng.encode_image(torch.cat((a, b), 0).float())
+                fa, fb = f.chunk(2, 0)
+                return fa.contiguous(), fb.contiguous()
+            return eng.encode_image(a.float())[0], eng.encode_image(b.float())[0]
+        if self._is_symmetrized(view1, view2):               # half of the batch is encoded (:176-180), then interleaved
+            fa, fb = enc_pair(img1[::2], img2[::2])
+            feat1 = torch.stack((fa, fb), 1).flatten(0, 1).contiguous()
+            feat2 = torch.stack((fb, fa), 1).flatten(0, 1).contiguous()
+        else:
+            feat1, feat2 = enc_pair(img1, img2)
+        g1 = (img1.shape[-2] // p, img1.shape[-1] // p)
+        g2 = (img2.shape[-2] // p, img2.shape[-1] // p)
+        dec1, dec2 = eng.decoder(feat1, feat2, B, g1[0], g1[1], g2[0], g2[1])
+        res1 = own.downstream_head(dec1, shape1, 1)
+        res2 = own.downstream_head(dec2, shape2, 2)
+        res2["pts3d_in_other_view"] = res2.pop("pts3d")     # :226
+        return res1, res2
 
 
 class SpatialMemory:
@@ -559,6 +607,7 @@ class Spann3R(nn.Module):
             ckpt = torch.load(dus3r_name, map_location="cpu", weights_only=True)
             cfg = Spann3RConfig.from_ctor_string(ckpt["args"].model)
         self.cfg = cfg or FULL
+        self.add_module("dust3r", _Dust3RFacade(self))       # the parameter tree below hangs the DUSt3R weights into it
         self._params = _build_param_tree(self, param_spec(self.cfg))
         # no network: without a checkpoint file the weights are seeded synthetic ones
         if init_weights:
@@ -698,6 +747,119 @@ class Spann3R(nn.Module):
         P = (pts.shape[1] // self.cfg.patch) * (pts.shape[2] // self.cfg.patch)
         out = torch.empty(B, P, self.cfg.enc_dim, device=pts.device)
         return self.engine.encode_cur_value(pts, out, add)
+
+    # ------------------------------------------------------------------ offline reconstruction (:333-471)
+    @staticmethod
+    def find_initial_pair(graph, n_frames):
+        """spann3r/model.py:333-358: the pair of the DUSt3R pair graph with the largest mean sigmoid-confidence."""
+        view1, view2, pred1, pred2 = graph["view1"], graph["view2"], graph["pred1"], graph["pred2"]
+        conf_matrix = torch.zeros(n_frames, n_frames)
+        for i in range(len(view1["idx"])):
+            c1, c2 = pred1["conf"][i].float(), pred2["conf"][i].float()
+            conf_matrix[int(view1["idx"][i]), int(view2["idx"][i])] = float(((c1 - 1) / c1).mean() + ((c2 - 1) / c2).mean())
+        flat = int(conf_matrix.argmax())
+        pair_idx = (flat // n_frames, flat % n_frames)
+        print("init pair:%s, conf: %s" % (pair_idx, float(conf_matrix.max())))
+        return pair_idx
+
+    NBV_CHUNK = 16       # candidate views decoded together per launch group
+
+    def find_next_best_view(self, frames, idx_todo, feat_fuse, pos1, shape1, feats=None):
+        """spann3r/model.py:360-392.  The reference encodes, decodes and regresses every remaining view one by one in
+        every round (O(n^2) encoder passes); here each frame's encoder features are computed once (`feats` cache) and the
+        candidates of a round go through the pair decoder and both heads as ONE batch (side 1 = the fused features
+        repeated).  Returns the reference's tuple for the view with the largest mean sigmoid-confidence."""
+        eng = self.engine
+        feats = {} if feats is None else feats
+        B = feat_fuse.shape[0]
+        best = None
+        todo = list(idx_todo)
+        g1 = self._grid_from_pos(pos1)
+        per = self.NBV_CHUNK if B == 1 else 1
+        for c0 in range(0, len(todo), per):
+            ids = todo[c0:c0 + per]
+            for i in ids:
+                if i not in feats:
+                    f, pos, shp = self.encode_image(frames[i])
+                    feats[i] = (f.clone(), pos, shp)
+            f2 = torch.cat([feats[i][0] for i in ids], 0)
+            f1 = feat_fuse.expand(len(ids), -1, -1).contiguous() if B == 1 else feat_fuse
+            g2 = self._grid_from_pos(feats[ids[0]][1])
+            nb = f2.shape[0]
+            dec1, dec2 = eng.decoder(f1, f2, nb, g1[0], g1[1], g2[0], g2[1])
+            sh1 = shape1.expand(nb, -1) if B == 1 else shape1
+            sh2 = torch.cat([torch.as_tensor(feats[i][2]).reshape(-1, 2) for i in ids], 0)
+            res1 = self.downstream_head(dec1, sh1, 1)
+            res2 = self.downstream_head(dec2, sh2, 2)
+            c1, c2 = res1["conf"], res2["conf"]
+            score = (((c1 - 1) / c1).flatten(1).mean(1) + ((c2 - 1) / c2).flatten(1).mean(1)) if B == 1 else \
+                (((c1 - 1) / c1).mean() + ((c2 - 1) / c2).mean()).reshape(1)
+            score = score.cpu()
+            for j, i in enumerate(ids):
+                sc = float(score[j])
+                if best is None and sc <= 0.0:
+                    continue                                # the reference starts from best_conf = 0.0
+                if best is None or sc > best[0]:
+                    sl = slice(j, j + 1) if B == 1 else slice(None)
+                    best = (sc, i, [d[sl].clone() for d in dec1], [d[sl].clone() for d in dec2],
+                            {k: v[sl].clone() for k, v in res1.items()}, {k: v[sl].clone() for k, v in res2.items()})
+        if best is None:
+            raise RuntimeError("find_next_best_view: no candidate with positive confidence (the reference fails here too)")
+        sc, i, d1, d2, r1, r2 = best
+        return i, d1, d2, r1, r2, feats[i][0], feats[i][1], feats[i][2], sc
+
+    @torch.no_grad()
+    def offline_reconstruction(self, frames, graph):
+        """spann3r/model.py:394-471: start from the most confident pair of the DUSt3R pair graph, then repeatedly read the
+        memory, pick the next best view among the remaining frames, and write it.  Returns (preds, preds_all, idx_used)."""
+        self._pinned = None
+        eng = self.engine
+        self._pinned = eng
+        try:
+            n_frames = len(frames)
+            idx_todo, idx_used = list(range(n_frames)), []
+            img0 = frames[0]["img"]
+            B = img0.shape[0]
+            p = self.cfg.patch
+            P = (img0.shape[-2] // p) * (img0.shape[-1] // p)
+            sp_mem = SpatialMemory(eng, B, P, capacity=4000 + 8 * P)
+            pair_idx = self.find_initial_pair(graph, n_frames)
+            f1, f2 = frames[pair_idx[0]], frames[pair_idx[1]]
+            for i in pair_idx:
+                idx_used.append(i)
+                idx_todo.remove(i)
+            feat1, feat2, pos1, pos2, shape1, shape2 = self.encode_image_pairs(f1, f2)
+            feats = {pair_idx[0]: (feat1, pos1, shape1), pair_idx[1]: (feat2, pos2, shape2)}
+            dec1, dec2 = self.decode(feat1, pos1, feat2, pos2)
+            res1 = self.downstream_head(dec1, shape1, 1)
+            res2 = self.downstream_head(dec2, shape2, 2)
+            feat_k2, preds, preds_all = None, None, []
+            while True:
+                if feat_k2 is not None:
+                    feat1, pos1, shape1 = feat2, pos2, shape2
+                    feat_fuse = sp_mem.memory_read(feat_k2, torch.empty_like(feat1))
+                    id_n, dec1, dec2, res1, res2, feat2, pos2, shape2, best_conf = \
+                        self.find_next_best_view(frames, idx_todo, feat_fuse, pos2, shape2, feats)
+                    idx_todo.remove(id_n)
+                    idx_used.append(id_n)
+                    print("next best view: %d, conf: %s" % (id_n, best_conf))
+                feat_k1 = self.encode_feat_key(feat1, dec1[-1], 1)
+                feat_k2 = self.encode_feat_key(feat2, dec2[-1], 2)
+                cur_v = self.encode_cur_value(res1, dec1, pos1, shape1, add=feat_k1)       # = cur_v + feat_k1
+                sp_mem.add_mem_check(feat_k1, cur_v)
+                res2["pts3d_in_other_view"] = res2.pop("pts3d")
+                if preds is None:
+                    preds = [res1]
+                else:
+                    res1["pts3d_in_other_view"] = res1.pop("pts3d")
+                    preds.append(res1)
+                preds_all.append((res1, res2))
+                if len(idx_todo) == 0:
+                    break
+            preds.append(res2)
+            return preds, preds_all, idx_used
+        finally:
+            self._pinned = None
 
     # ------------------------------------------------------------------ forward (:473-539)
     @torch.no_grad()

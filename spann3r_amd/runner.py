@@ -56,3 +56,42 @@ def aggregate(stats):
     frames = float(stats[:, 0].sum())
     seconds = float(stats[:, 1].max())
     return frames / seconds, frames, seconds
+
+
+def pair_graph(dust3r, frames, batch_size=2, scene_graph="complete"):
+    """The DUSt3R pair graph offline_reconstruction starts from, built the way demo.py:100-117 does it with
+    dust3r.image_pairs.make_pairs(symmetrize=True) + dust3r.inference.inference(): every frame becomes a view dict
+    (img, true_shape, idx, instance), the pair list is symmetrised, and each batch of pairs is run in both orders
+    (inference.py:27-37 make_batch_symmetric), so the result holds 4 entries per unordered pair.  Returns
+    dict(view1, view2, pred1, pred2) with tensors on the CPU, lists chained."""
+    views = [dict(img=f["img"], true_shape=torch.tensor(f["img"].shape[-2:])[None], idx=j, instance=str(j)) for j, f in enumerate(frames)]
+    n = len(views)
+    if scene_graph != "complete":
+        raise NotImplementedError("pair_graph builds the complete graph (demo.py default)")
+    pairs = [(i, j) for i in range(n) for j in range(i)]
+    pairs += [(j, i) for i, j in pairs]
+
+    def batch_of(ids):                                      # collate + interleave the two orders of every pair
+        v1, v2 = [], []
+        for a, b in ids:
+            v1 += [views[a], views[b]]
+            v2 += [views[b], views[a]]
+        pack = lambda vs: dict(img=torch.cat([v["img"] for v in vs]), true_shape=torch.cat([v["true_shape"] for v in vs]),
+                               idx=[v["idx"] for v in vs], instance=[v["instance"] for v in vs])
+        return pack(v1), pack(v2)
+    out = dict(view1=dict(idx=[], instance=[], true_shape=[]), view2=dict(idx=[], instance=[], true_shape=[]), pred1={}, pred2={})
+    for c0 in range(0, len(pairs), batch_size):
+        v1, v2 = batch_of(pairs[c0:c0 + batch_size])
+        p1, p2 = dust3r(v1, v2)
+        for name, v in (("view1", v1), ("view2", v2)):
+            out[name]["idx"] += v["idx"]
+            out[name]["instance"] += v["instance"]
+            out[name]["true_shape"].append(v["true_shape"])
+        for name, p in (("pred1", p1), ("pred2", p2)):
+            for k, t in p.items():
+                out[name].setdefault(k, []).append(t.detach().cpu())
+    for name in ("view1", "view2"):
+        out[name]["true_shape"] = torch.cat(out[name]["true_shape"])
+    for name in ("pred1", "pred2"):
+        out[name] = {k: torch.cat(v) for k, v in out[name].items()}
+    return out

@@ -10,6 +10,8 @@ What is dumped (SURVEY.md §8c "recommended dumps"):
   spann3r_full224.npz 24/12 model, 5 frames of 224x224 (BASELINE config 1), outputs subsampled
   memory_bank.npz     reference SpatialMemory driven stand-alone for 32 frames of P=196:
                       similarity skip, working->long-term hand-over and one prune (5096->4000)
+  spann3r_offline.npz  tiny model, 5 frames of 48x64: DUSt3R pair graph (reference make_pairs + inference) and
+                      Spann3R.offline_reconstruction on it (demo.py offline mode): visiting order, outputs
   spann3r_trueshape.npz  tiny model, batch 2, 4 frames of 48x80 WITH `true_shape` (landscape, and dataset-rotated portrait)
   spann3r_cfg2_224x10.npz  24/12 model, 10 frames of 224x224, eval policy (BASELINE config 2 = the bench workload):
                       subsampled outputs, per-step feat_fuse / feat_k / cur_v, final mem_attn / mem_count
@@ -252,6 +254,35 @@ def make_trueshape():
     print("trueshape: %d arrays" % len(out))
 
 
+def make_offline():
+    """demo.py's offline mode on the tiny model: the DUSt3R pair graph through the reference's own make_pairs / inference
+    (complete graph, symmetrised, batch 2) and Spann3R.offline_reconstruction on it."""
+    from dust3r.inference import inference
+    from dust3r.image_pairs import make_pairs
+    cfg, H, W, NF = TINY, 48, 64, 5
+    sd = synth_state_dict(0, cfg)
+    m = build_reference(cfg, sd, "offline")
+    frames = synth_frames(NF, H, W, seed=41)
+    imgs_all = [dict(img=f["img"], true_shape=torch.tensor(f["img"].shape[2:]).unsqueeze(0), idx=j, instance=str(j))
+                for j, f in enumerate(frames)]                                   # demo.py:100-112
+    pairs = make_pairs(imgs_all, scene_graph="complete", prefilter=None, symmetrize=True)
+    graph = inference(pairs, m.dust3r, "cpu", batch_size=2, verbose=False)
+    with torch.no_grad():
+        preds, preds_all, idx_used = m.offline_reconstruction(frames, graph)
+    out = {"meta_hw": np.array([H, W]), "meta_frames": np.array(NF), "meta_seed": np.array(41),
+           "fingerprint": np.array(state_dict_fingerprint(sd)), "idx_used": np.array(idx_used),
+           "graph_idx1": np.array(graph["view1"]["idx"]), "graph_idx2": np.array(graph["view2"]["idx"]),
+           "graph_conf1": npf(graph["pred1"]["conf"]), "graph_conf2": npf(graph["pred2"]["conf"]),
+           "graph_pts1_sub": npf(graph["pred1"]["pts3d"][:, ::4, ::4]), "graph_pts2_sub": npf(graph["pred2"]["pts3d_in_other_view"][:, ::4, ::4])}
+    for j, p in enumerate(preds):
+        out["pred%d_pts" % j] = npf(p["pts3d" if j == 0 else "pts3d_in_other_view"])
+        out["pred%d_conf" % j] = npf(p["conf"])
+    for i, (r1, r2) in enumerate(preds_all):
+        out["step%d_conf2" % i] = npf(r2["conf"])
+    np.savez_compressed(os.path.join(HERE, "spann3r_offline.npz"), **out)
+    print("offline: idx_used", idx_used, "-", len(out), "arrays")
+
+
 from memory_inputs import memory_inputs  # noqa: E402  (shared with the tests)
 
 
@@ -293,6 +324,8 @@ if __name__ == "__main__":
         make_memory()
     if "full" in what:
         make_full()
+    if "offline" in what:
+        make_offline()
     if "trueshape" in what:
         make_trueshape()
     if "cfg2" in what:

@@ -463,3 +463,37 @@ def test_stats_gather_through_rccl_world1():
         assert frames == 20 and seconds == 0.05 and abs(fps - 400.0) < 1e-9
     finally:
         dist.destroy_process_group()
+
+
+def test_offline_reconstruction_vs_reference(tiny_model):
+    """demo.py's offline mode (spann3r/model.py:333-471): `model.dust3r(view1, view2)` builds the pair graph the way
+    make_pairs + inference do, then offline_reconstruction visits the frames in the reference's order and returns the
+    reference's pointmaps (candidates of a round are decoded as one batch here, one by one there)."""
+    from spann3r_amd.runner import pair_graph
+    from spann3r_amd.weights import synth_frames
+    g = load_golden("spann3r_offline.npz")
+    H, W = map(int, g["meta_hw"])
+    m = tiny_model
+    frames = to_dev(synth_frames(int(g["meta_frames"]), H, W, seed=int(g["meta_seed"])))
+    graph = pair_graph(m.dust3r, frames)
+    assert graph["view1"]["idx"] == g["graph_idx1"].tolist() and graph["view2"]["idx"] == g["graph_idx2"].tolist()
+    assert rel_err(graph["pred1"]["conf"], g["graph_conf1"]) < TOL_FP32 and rel_err(graph["pred2"]["conf"], g["graph_conf2"]) < TOL_FP32
+    assert rel_err(graph["pred1"]["pts3d"][:, ::4, ::4], g["graph_pts1_sub"]) < TOL_FP32
+    assert rel_err(graph["pred2"]["pts3d_in_other_view"][:, ::4, ::4], g["graph_pts2_sub"]) < TOL_FP32
+    preds, preds_all, used = m.offline_reconstruction(frames, graph)
+    assert [int(i) for i in used] == g["idx_used"].tolist()
+    assert len(preds) == len(frames) and len(preds_all) == len(frames) - 1 and preds[0] is preds_all[0][0]
+    for j, p in enumerate(preds):
+        key = "pts3d" if j == 0 else "pts3d_in_other_view"
+        assert set(p.keys()) == {key, "conf"}
+        assert rel_err(p[key].cpu(), g["pred%d_pts" % j]) < TOL_FP32, j
+        assert rel_err(p["conf"].cpu(), g["pred%d_conf" % j]) < TOL_FP32, j
+    for i, (_, r2) in enumerate(preds_all):
+        assert rel_err(r2["conf"].cpu(), g["step%d_conf2" % i]) < TOL_FP32
+    # one candidate per launch group (the reference's schedule) picks the same views
+    m.NBV_CHUNK = 1
+    try:
+        _, _, used1 = m.offline_reconstruction(frames, graph)
+    finally:
+        m.NBV_CHUNK = 16
+    assert [int(i) for i in used1] == g["idx_used"].tolist()

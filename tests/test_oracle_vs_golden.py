@@ -142,3 +142,24 @@ def test_cfg2_224x10(full_sd):
 def test_cfg3_512x13(full_sd):
     """BASELINE config 3: 13 frames of 512x512, growing bank (train policy, dropout off): 11 reads, up to 11264 tokens."""
     _check_sequence_fixture("spann3r_cfg3_512x13.npz", full_sd)
+
+
+def test_offline_reconstruction(tiny_sd):
+    """demo.py's offline mode: the DUSt3R pair graph (pair_graph mirrors make_pairs + inference) and the next-best-view
+    loop, against the dump of the reference's own run."""
+    from spann3r_amd.runner import pair_graph
+    g = load_golden("spann3r_offline.npz")
+    H, W = map(int, g["meta_hw"])
+    frames = synth_frames(int(g["meta_frames"]), H, W, seed=int(g["meta_seed"]))
+    graph = pair_graph(lambda v1, v2: O.dust3r_forward(v1, v2, tiny_sd, TINY), frames)
+    assert graph["view1"]["idx"] == g["graph_idx1"].tolist() and graph["view2"]["idx"] == g["graph_idx2"].tolist()
+    assert rel_err(graph["pred1"]["conf"], g["graph_conf1"]) < TOL and rel_err(graph["pred2"]["conf"], g["graph_conf2"]) < TOL
+    assert rel_err(graph["pred2"]["pts3d_in_other_view"][:, ::4, ::4], g["graph_pts2_sub"]) < TOL
+    assert O.find_initial_pair(graph, len(frames)) == tuple(g["idx_used"][:2].tolist())
+    preds, preds_all, used = O.offline_reconstruction(frames, graph, tiny_sd, TINY)
+    assert used == g["idx_used"].tolist()
+    for j, p in enumerate(preds):
+        assert rel_err(p["pts3d" if j == 0 else "pts3d_in_other_view"], g["pred%d_pts" % j]) < TOL
+        assert rel_err(p["conf"], g["pred%d_conf" % j]) < TOL
+    for i, (_, r2) in enumerate(preds_all):
+        assert rel_err(r2["conf"], g["step%d_conf2" % i]) < TOL
