@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--tiny", action="store_true", help="2-layer encoder / 10-layer decoder geometry (quick look)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--repeat", type=int, default=3)
+    ap.add_argument("--offline", action="store_true", help="demo.py --offline: DUSt3R pair graph + next-best-view order")
     args = ap.parse_args()
     cfg = TINY if args.tiny else FULL
     device = "cuda"
@@ -27,6 +28,17 @@ def main():
     batch = synth_frames(args.frames, args.size, args.size)
     for view in batch:                                                            # demo.py:94-95
         view["img"] = view["img"].to(device, non_blocking=True)
+        view["true_shape"] = torch.tensor(view["img"].shape[2:]).unsqueeze(0)     # demo.py:109 (stays on the CPU)
+    if args.offline:                                                              # demo.py:98-121
+        from spann3r_amd.runner import pair_graph
+        torch.cuda.synchronize()
+        start = time.time()
+        output = pair_graph(model.dust3r, batch)          # = make_pairs(complete, symmetrize) + inference(batch_size=2)
+        preds, preds_all, idx_used = model.offline_reconstruction(batch, output)
+        torch.cuda.synchronize()
+        end = time.time()
+        print("Time: %.4f s, FPS: %.1f  (offline, order %s)" % (end - start, len(batch) / (end - start), idx_used))
+        return
     for it in range(args.repeat):
         torch.cuda.synchronize()
         start = time.time()

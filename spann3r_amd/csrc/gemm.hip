@@ -357,6 +357,8 @@ void gemm_kernel(const GemmArgs args) {
   const TW* W = reinterpret_cast<const TW*>(d.W) + (int64_t)bz * d.strideW;
 
   const int m0 = tile_m * BM, n0 = tile_n * BN;
+  int64_t* tr0 = (LOOP == 0 && args.d.trace && blockIdx.x < 8 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) ? args.d.trace + blockIdx.x * 64 : nullptr;
+  if (tr0) { tr0[0] = clock64(); tr0[3] = wall_clock64(); }
   ARows<TA, LOADER, MF> arows;
   arows.init(d, A, m0 + wm * MF * 16, lane, M_::KB, M_::CH);
   // W operand addressing.  Row-major [N, ldw]: lane (g, r) reads row c at k = kb*KB + g*CH (16 rows per load
@@ -721,9 +723,11 @@ void gemm_kernel(const GemmArgs args) {
     }
     __syncthreads();                                     // the stages are dead: the epilogue slab re-uses their bytes
   } else
+  // (trace: tr0[5] = set-up done)
   // STAGES-deep register ring: (STAGES-1) k-blocks of loads in flight per wave.
   // prologue (uniform branches), branch-free steady state over full k-blocks, masked drain.
   {
+    if (tr0) tr0[5] = clock64();
     const int kb_full = d.K / KB;                       // k-blocks [0, kb_full) are complete
     const int kb_hi_full = kb_hi < kb_full ? kb_hi : kb_full;
     int kb = kb_lo + wk;
@@ -762,6 +766,7 @@ void gemm_kernel(const GemmArgs args) {
     }
   }
 
+  if (tr0) { asm volatile("" ::"v"(acc[0][0][0])); tr0[1] = clock64(); }
   // ---- accumulators -> LDS (C layout: col = lane&15, row = 4*(lane>>4) + reg)
   if (LOOP < 2 || wave < NCW) {
     float* slab = smem + (size_t)wk * BM * LDS_LD;
@@ -797,6 +802,7 @@ void gemm_kernel(const GemmArgs args) {
   if constexpr (LOOP >= 2) {
     if (d.trace && blockIdx.x < 8 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) d.trace[blockIdx.x * 64 + 48] = clock64();
   }
+  if (tr0) tr0[48] = clock64();
 
   // y = rstd * acc - rstd * mean * s[n]   (bias, already folded with beta . W^T, is added by the epilogues below)
   auto ln_fold = [&](float acc, int row, int gn) -> float {
@@ -1160,6 +1166,7 @@ void gemm_kernel(const GemmArgs args) {
       d.trace[blockIdx.x * 64 + 4] = wall_clock64();
     }
   }
+  if (tr0) { tr0[2] = clock64(); tr0[4] = wall_clock64(); }
 }
 
 template <typename TA, typename TW, int LOADER, int MF, int NF, int WM, int WN, int WK, int STAGES, int LOOP = 0>

@@ -32,6 +32,9 @@ for name, M, N, K in (("val proj", 196, 1024, 1024), ("val fc1", 196, 4096, 1024
         nkb = K // 64
         ld = [int(r[8 + i]) - t0 for i in range((nkb + 3) // 4)]
         cs = [int(r[32 + i]) - t0 for i in range((nkb + 3) // 4)]
+        if tile < 13:
+            print("wg %d: setup %5d | loop done %6d | slab+sync %6d | end %6d clk (%.2f us)" % (wg, int(r[5]) - t0, int(r[1]) - t0, int(r[48]) - t0, int(r[2]) - t0, (int(r[4]) - int(r[3])) * 0.01))
+            continue
         print("wg %d: setup %5d  W issued %5d  A0 landed %5d | slab+sync %6d |" % (wg, int(r[5]) - t0, int(r[7]) - t0, int(r[6]) - t0, int(r[48]) - t0), end=" ")
         print("wg %d: loop done %6d  end %6d clk (%.0f clk/us, %.2f us) | loader barrier@kb 0,4,..: %s | consumer done@kb 0,4,..: %s"
               % (wg, int(r[1]) - t0, int(r[2]) - t0, clk_per_us, (int(r[4]) - int(r[3])) * 0.01, ld, cs))
