@@ -346,6 +346,13 @@ def main():
                        "(<=1e-3 vs the reference, tests/test_model_gpu.py)", "steps": 6,
                        "frac_of_mfma_peak": fl * 6 / f32_s / 1e12 / PEAK_TFLOPS["fp32"]}
         model.set_precision("bf16")
+        # how the same GPU fills with more independent work per launch: 4 sequences batched into one forward (B = 4).
+        # NOT the headline configuration (BASELINE config 2 is batch 1): reported next to it.
+        seqs_b4 = [make_sequence(200, args.frames, args.size, args.size, batch=4, device=dev)]
+        b4_frames, b4_s = time_sequences(model, seqs_b4, 6, 3)
+        out["batch4"] = {"value": 4 * b4_frames / b4_s, "unit": "frames/s", "steps": 6,
+                         "what": "same model and sequence length, 4 independent sequences per forward call (batch 4): "
+                                 "every launch carries 4x the rows; not the BASELINE configuration"}
         del model
         torch.cuda.empty_cache()
         m3, _ = build_model("bf16", dev, train_policy=True)

@@ -1,3 +1,3 @@
 mkdir -p gpurun_out/r2g
-(timeout 600 python tools/bench_gemm2.py --tiles 0,18,13 2>&1 | grep -v amdgpu | tail -70) > gpurun_out/r2g/tiles18.log
-(timeout 300 python tools/trace_gemm.py 18 2>&1 | grep "wg\|==" | cut -c1-200) > gpurun_out/r2g/trace18.log
+(echo "== no prefetch"; timeout 600 python tools/bench_gemm2.py --tiles 0,13 2>&1 | grep -v amdgpu | grep -E " 0     0|13    0"; echo "== prefetch next"; timeout 600 python tools/bench_gemm2.py --tiles 0,13 --prefetch 1 2>&1 | grep -v amdgpu | grep -E " 0     0|13    0") > gpurun_out/r2g/prefetch.log
+(timeout 600 python -m pytest tests/test_ops_gpu.py -x -q -k "gemm" 2>&1 | tail -3) >> gpurun_out/r2g/prefetch.log
