@@ -18,6 +18,9 @@ def main():
     ap.add_argument("--tiny", action="store_true", help="2-layer encoder / 10-layer decoder geometry (quick look)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--repeat", type=int, default=3)
+    ap.add_argument("--demo_path", default=None, help="folder of images (demo.py --demo_path): decoded with PIL on the host, "
+                    "then cropped / Lanczos-resized / normalised on the GPU (spann3r_amd.preprocess)")
+    ap.add_argument("--kf_every", type=int, default=10)
     ap.add_argument("--offline", action="store_true", help="demo.py --offline: DUSt3R pair graph + next-best-view order")
     args = ap.parse_args()
     cfg = TINY if args.tiny else FULL
@@ -25,8 +28,17 @@ def main():
     model = Spann3R(dus3r_name=None, cfg=cfg, init_weights=False).to(device)      # demo.py:81-82
     model.load_state_dict(synth_state_dict(0, cfg))                               # demo.py:84 (no checkpoint ships)
     model.eval().set_precision(args.precision)
-    batch = synth_frames(args.frames, args.size, args.size)
-    for view in batch:                                                            # demo.py:94-95
+    if args.demo_path:                                                            # demo.py:86-92 (Demo dataset, full_video)
+        import os
+        import numpy as np
+        from PIL import Image
+        from spann3r_amd.preprocess import frames_from_images
+        names = sorted(n for n in os.listdir(args.demo_path) if n.lower().endswith((".jpg", ".jpeg", ".png")))
+        batch = frames_from_images((np.asarray(Image.open(os.path.join(args.demo_path, n)).convert("RGB")) for n in names),
+                                   resolution=args.size, device=device, kf_every=args.kf_every)
+    else:
+        batch = synth_frames(args.frames, args.size, args.size)
+    for view in batch if not args.demo_path else []:                                                            # demo.py:94-95
         view["img"] = view["img"].to(device, non_blocking=True)
         view["true_shape"] = torch.tensor(view["img"].shape[2:]).unsqueeze(0)     # demo.py:109 (stays on the CPU)
     if args.offline:                                                              # demo.py:98-121

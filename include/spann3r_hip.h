@@ -292,6 +292,20 @@ int sp3_upsample2x(const float* in, float* out, int B, int H, int W, int C, int 
 int sp3_head_final(const float* feat, const float* w, const float* b, int64_t pixels, int C, float* pts,
                    float* conf, float* raw, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Input pipeline: one decoded RGB frame (uint8 HWC, row stride src_row_stride bytes) -> the normalised
+ * float image the model consumes.  Replaces PIL Image.crop + Image.resize(LANCZOS) (dust3r/datasets/utils/cropping.py:54-111),
+ * ImgNorm (dust3r/utils/image.py:23) and transpose_to_landscape (dust3r/datasets/base/base_stereo_view_dataset.py:215-220):
+ *   crop window [crop_t, +H1) x [crop_l, +W1)  ->  Pillow's 8-bit LANCZOS resample to W2 x H2 (horizontal pass into `tmp`
+ *   [H1, W2, 3] uint8, then vertical; bounds [n, 2] = (first tap, taps) and coef [n, ksize] = 22-bit fixed-point weights per
+ *   output index, computed by the host: spann3r_amd/preprocess.py)  ->  crop [crop2_t, +outH) x [crop2_l, +outW)  ->
+ *   (u/255 - 0.5)/0.5  ->  out fp32 [3, outH, outW], or [3, outW, outH] if `transpose` (portrait rectified to landscape).
+ * Bit-exact with Pillow for the uint8 stage. */
+int sp3_preprocess_image(const uint8_t* src, int64_t src_row_stride, int crop_l, int crop_t, int H1, int W1,
+                         const int32_t* hbounds, const int32_t* hcoef, int hksize, int W2,
+                         const int32_t* vbounds, const int32_t* vcoef, int vksize, int H2,
+                         int crop2_l, int crop2_t, int outW, int outH, int transpose, uint8_t* tmp, float* out, void* stream);
+
 /* small utilities */
 int sp3_copy2d_f32(const float* src, int64_t lds, float* dst, int64_t ldd, int rows, int cols, void* stream);
 int sp3_fill_f32(float* p, float v, int64_t n, void* stream);

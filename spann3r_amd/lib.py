@@ -114,6 +114,9 @@ _PROTOS = {
     "sp3_cast_f32_to_bf16": [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
     "sp3_copy2d_f32": [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p],
     "sp3_spin": [C.c_int64, C.c_void_p, C.c_void_p],
+    "sp3_preprocess_image": [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                             C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                             C.c_void_p, C.c_void_p],
 }
 EXPORTS = sorted(list(_PROTOS) + ["sp3_last_error", "sp3_version"])
 

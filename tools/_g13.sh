@@ -1,4 +1,3 @@
-mkdir -p gpurun_out/r2l
-(timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -6) > gpurun_out/r2l/t_all.log
-(timeout 900 python bench.py 2>&1 | tail -2) > gpurun_out/r2l/bench.log
-(timeout 900 python bench.py --gpus 2 2>&1 | tail -3; echo "rc=$?") > gpurun_out/r2l/bench_gpus2.log
+mkdir -p gpurun_out/r2o
+(timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3) > gpurun_out/r2o/t_all.log
+(timeout 900 python bench.py 2>&1 | tail -1) > gpurun_out/r2o/bench.log
