@@ -187,13 +187,29 @@ def kernel_profile(model, seq, precision):
     if reads:
         big = max(reads, key=lambda r: r["info"]["M"])
         gbs = big["bytes"] / (big["ms"] * 1e-3) / 1e9
-        memread = {"what": "spatial-memory read (LN_q folded, S = q.K_hat^T/32, softmax+threshold, P.V_hat + q, column sums)",
+        memread = {"what": "spatial-memory read: score GEMM (LN_q folded, softmax statistics in its epilogue) -> P.V_hat + q with the "
+                           "thresholded probabilities built on load (short banks) or softmax launch + split-K P.V (long banks); column sums",
                    "bank_tokens": big["info"]["M"], "queries": big["info"]["tokens_per_frame"], "algorithmic_bytes": big["bytes"],
                    "us": 1e3 * big["ms"], "launches": big["launches"], "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                    "frac": gbs / PEAK_HBM_GBS, "gflop": big["info"].get("flops", 0.0) / 1e9,
                    "tflops": big["info"].get("flops", 0.0) / (big["ms"] * 1e-3) / 1e12,
                    "reads_per_sequence": len(reads), "all_reads_us": [round(1e3 * r["ms"], 2) for r in reads]}
     return roof, breakdown, total_ms, memread
+
+
+def _promote_replay(memread, rep):
+    """The model runs under hipGraph replay, so the replayed read is the headline number of the object; the per-launch
+    event brackets of the eager profiling pass (event cost inside) stay as `eager_event_brackets`."""
+    if not rep:
+        return
+    memread["eager_event_brackets"] = {k: memread[k] for k in ("bank_tokens", "us", "achieved", "frac", "tflops", "all_reads_us") if k in memread}
+    for k in ("bank_tokens", "queries", "us", "achieved", "frac", "tflops", "algorithmic_bytes"):
+        memread[k] = rep[k]
+    if "critical_path" in rep:
+        memread["critical_path"] = rep["critical_path"]
+        memread["launches"] = 3
+    memread["timing"] = rep["timing"]
+    memread.pop("all_reads_us", None)
 
 
 def memread_replay(model, reps=20):
@@ -208,31 +224,42 @@ def memread_replay(model, reps=20):
     aux = run.k2_aux if run.B == 1 else (None, None)
     keep = mem.bank["attn"].clone()
 
-    def read():
-        mem.memory_read(run.k2, run.fuse, *aux)
-    read()
-    torch.cuda.synchronize()
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        for _ in range(reps):
-            read()
-    g.replay()
-    torch.cuda.synchronize()
-    best = 1e30
-    for _ in range(3):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        g.replay()
-        e1.record()
+    def timed(defer):
+        def read():
+            # defer=False: incl. the column-sum launch (the per-frame step folds it into the launch that commits the frame)
+            mem.memory_read(run.k2, run.fuse, *aux, defer_attn=defer)
+            mem._pending_attn = None
+        read()
         torch.cuda.synchronize()
-        best = min(best, e0.elapsed_time(e1) * 1e3 / reps)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(reps):
+                read()
+        g.replay()
+        torch.cuda.synchronize()
+        t = 1e30
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            g.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            t = min(t, e0.elapsed_time(e1) * 1e3 / reps)
+        return t
+    best = timed(False)
+    crit = timed(True) if mem._read_plan()[1] else None
     mem.bank["attn"].copy_(keep)
     es = mem.bank["k_hat"].element_size()
     nbytes = mem.B * (2.0 * mem.M * mem.C * es + 2.0 * mem.P * mem.C * 4)
     flops = 4.0 * mem.B * mem.P * mem.M * mem.C
-    return {"bank_tokens": mem.M, "queries": mem.P, "us": best, "achieved": nbytes / best / 1e3, "unit": "GB/s", "peak": PEAK_HBM_GBS,
+    extra = {} if crit is None else {"critical_path": {
+        "us": crit, "achieved": nbytes / crit / 1e3, "launches": 2,
+        "what": "score GEMM + P.V GEMM only: what the next frame's decoder waits for; the column sums (mem_attn) ride in the launch "
+                "that commits the frame (the former mem_append launch)"}}
+    return {**extra, "bank_tokens": mem.M, "queries": mem.P, "us": best, "achieved": nbytes / best / 1e3, "unit": "GB/s", "peak": PEAK_HBM_GBS,
             "frac": nbytes / best / 1e3 / PEAK_HBM_GBS, "tflops": flops / best / 1e6, "algorithmic_bytes": nbytes,
-            "timing": "hipGraph of %d back-to-back reads (4-5 launches each), HIP events around the replay" % reps}
+            "timing": "hipGraph of %d back-to-back reads (every launch of the read, column sums included), HIP events around the "
+                      "replay" % reps}
 
 
 def cpu_baseline(sd, size, train_policy):
@@ -335,6 +362,7 @@ def main():
         if memread:
             out["memread"] = memread
             rep = memread_replay(model)
+            _promote_replay(out["memread"], rep)
             if rep:
                 out["memread"]["graph_replay"] = rep
 
@@ -369,6 +397,7 @@ def main():
             if memread3:
                 c3["memread"] = memread3
                 rep3 = memread_replay(m3, reps=5)
+                _promote_replay(c3["memread"], rep3)
                 if rep3:
                     c3["memread"]["graph_replay"] = rep3
         out["config3"] = c3

@@ -33,7 +33,7 @@ extern "C" {
 enum { SP3_F32 = 0, SP3_BF16 = 1 };
 enum { SP3_ACT_NONE = 0, SP3_ACT_GELU = 1, SP3_ACT_RELU = 2 };
 enum { SP3_EPI_PLAIN = 0, SP3_EPI_ROPE_VT = 1, SP3_EPI_PIXSHUF = 2, SP3_EPI_PARTIAL = 3 };
-enum { SP3_LOAD_PLAIN = 0, SP3_LOAD_CONV3X3 = 1 };
+enum { SP3_LOAD_PLAIN = 0, SP3_LOAD_CONV3X3 = 1, SP3_LOAD_SOFTMAX = 2 };
 
 const char* sp3_last_error(void);
 int sp3_version(void);
@@ -127,6 +127,20 @@ typedef struct sp3_gemm_desc {
    *   their own timeline: trace[wg*64 + 0] = entry, [1] = loop done, [2] = epilogue done, [8 + i/4] = loader passed the
    *   barrier of k-block i (i % 4 == 0), [32 + i/4] = consumer wave 0 finished k-block i.  tools/trace_gemm.py prints it. */
   int64_t* trace;
+  /* --- the spatial-memory read as two launches (spann3r/model.py:159-183: softmax over the bank, probabilities below
+   *   attn_thresh dropped, renormalised, times V):
+   *   launch 1, the score GEMM (plain loader/epilogue): sm_stats_out[M][ceil(N/32)][2] receives, per row and 32-column
+   *     group of the finished C, (max, sum exp(x - max)) -- the softmax statistics leave with the scores.
+   *   launch 2, loader SP3_LOAD_SOFTMAX (32x32 tile): A is the fp32 score matrix [M, lda] (K = bank tokens, any multiple
+   *     of 4); each lane merges sm_stats[M][sm_nt][2] of its rows to (m, Z) and turns the scores it loads into
+   *     p = exp(a - m) / Z, p < sm_thresh -> 0, on their way into the MFMA; C = (p . W^T) / sum(kept p) (+ bias, res);
+   *     sm_zout[M][4] receives (sum(kept p), m, 1/Z, -) per row.  No probability matrix exists in memory.
+   *     sp3_colsum_softmax finishes the column sums (mem_attn) from the scores and sm_zout. */
+  float* sm_stats_out;
+  const float* sm_stats;
+  int32_t sm_nt;
+  float sm_thresh;
+  float* sm_zout;
 } sp3_gemm_desc;
 int sp3_gemm(const sp3_gemm_desc* desc_host, void* stream);
 
@@ -251,6 +265,11 @@ int sp3_softmax_thresh(const float* S, float* P, int64_t ld, int64_t strideS, in
                        float thresh, int batch, void* P_packed, int64_t stride_packed, int packed_bf16, void* stream);
 int sp3_colsum_accum(const float* P, int64_t ld, int rows, int M, float* mem_attn, void* stream);
 int sp3_colsum_packed(const void* P_packed, int packed_bf16, int rows, int M, float* mem_attn, void* stream);
+/* the column sums of the two-launch read (sp3_gemm, loader SP3_LOAD_SOFTMAX): mem_attn[j] += sum_r [p >= thresh] p / Z'_r,
+ * p = exp(S[r, j] - m_r) / Z_r with rowz[r] = (Z', m, 1/Z, -) = that launch's sm_zout; fixed summation order.  append_P > 0
+ * also does sp3_mem_append(mem_count, mem_attn, M, append_P) (the frame that was read against is committed in the same launch). */
+int sp3_colsum_softmax(const float* S, int64_t ld, int rows, int M, const float* rowz, float thresh, float* mem_attn,
+                       float* mem_count, int append_P, void* stream);
 int sp3_pack_stats(const float* x, int64_t ldx, int rows, int C, void* packed, int packed_bf16, float* stats, void* stream);
 int sp3_gather_packed_rows(const void* src, void* dst, const int32_t* sel, int n_sel, int C, int elem_size, void* stream);
 int sp3_gather_packed_cols(const void* src, void* dst, const int32_t* sel, int n_sel, int n_fill, int C, int cap,

@@ -236,6 +236,38 @@ template <typename TA, int MF> struct ARows<TA, SP3_LOAD_PLAIN, MF> {
   }
 };
 
+// SOFTMAX: row-major fp32 scores [M, lda]; the values become probabilities at consume time (smx4 below).
+template <typename TA, int MF> struct ARows<TA, SP3_LOAD_SOFTMAX, MF> {
+  const TA* base[MF];
+  __device__ __forceinline__ void init(const sp3_gemm_desc& d, const TA* A, int row0, int lane, int, int) {
+#pragma unroll
+    for (int m = 0; m < MF; ++m) {
+      int r = row0 + m * 16 + (lane & 15);
+      r = r < d.M ? r : d.M - 1;
+      base[m] = A + (int64_t)r * d.lda;
+    }
+  }
+  __device__ __forceinline__ const TA* ptr(const sp3_gemm_desc&, int m, int k, int, int, bool& inb) const {
+    inb = true;
+    return base[m] + k;
+  }
+};
+
+// scores -> thresholded probabilities of 4 consecutive keys: p = exp(s - m) / Z, dropped below thr and past the bank's
+// end (`left` keys remain from this group on); z collects the kept mass of the row (the renormalisation of model.py:170-172)
+// (c = -m log2(e) - log2(Z): one fma and one v_exp_f32 per score)
+__device__ __forceinline__ float4 smx4(float4 s, float c, float thr, int left, float& z) {
+  constexpr float L2E = 1.44269504088896341f;
+  float p[4] = {__builtin_amdgcn_exp2f(fmaf(s.x, L2E, c)), __builtin_amdgcn_exp2f(fmaf(s.y, L2E, c)),
+                __builtin_amdgcn_exp2f(fmaf(s.z, L2E, c)), __builtin_amdgcn_exp2f(fmaf(s.w, L2E, c))};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    p[e] = (p[e] < thr || e >= left) ? 0.f : p[e];
+    z += p[e];
+  }
+  return make_float4(p[0], p[1], p[2], p[3]);
+}
+
 template <typename TA, int MF> struct ARows<TA, SP3_LOAD_CONV3X3, MF> {
   const TA* img[MF];
   int iy0[MF], ix0[MF];
@@ -441,6 +473,13 @@ void gemm_kernel(const GemmArgs args) {
   // masks of each stage (0 / ~0): K tail per half, and per A row the conv zero-padding; applied at consume time
   unsigned am0[STAGES][MF], am1[STAGES][MF], wm0[STAGES], wm1[STAGES];
   constexpr bool CONV = LOADER == SP3_LOAD_CONV3X3;
+  // softmax loader: per lane the (max, 1/Z) of its MF rows, the kept probability mass, and per stage the keys left from
+  // the lane's first element to the end of the bank
+  constexpr bool SMX = LOADER == SP3_LOAD_SOFTMAX;
+  float sm_c[MF], sm_z[MF];
+  int sm_left[STAGES];
+#pragma unroll
+  for (int m = 0; m < MF; ++m) { sm_c[m] = 0.f; sm_z[m] = 0.f; }
 
   // FULL = the k-block lies entirely inside K.  Loads are never predicated; addresses are clamped instead.
   auto load = [&](auto full_tag, int st, int kb) {
@@ -451,6 +490,7 @@ void gemm_kernel(const GemmArgs args) {
     const int off1 = v1 ? CH / 2 : 0;
     wm0[st] = v0 ? 0xffffffffu : 0u;
     wm1[st] = v1 ? 0xffffffffu : 0u;
+    if constexpr (SMX) sm_left[st] = d.K - k;
 #pragma unroll
     for (int m = 0; m < MF; ++m) {
       bool inb;
@@ -468,7 +508,16 @@ void gemm_kernel(const GemmArgs args) {
   };
   auto consume = [&](auto full_tag, int st) {
     constexpr bool FULL = decltype(full_tag)::value;
-    if (!FULL || CONV) {
+    if constexpr (SMX) {
+      if constexpr (sizeof(TA) == 4) {
+        constexpr int NV = sizeof(typename M_::AReg) / 16;       // float4s per fragment: 4 (bf16 MFMA, 16 keys) or 2 (fp32, 8 keys)
+        const int left = FULL ? 64 : sm_left[st];
+#pragma unroll
+        for (int m = 0; m < MF; ++m)
+#pragma unroll
+          for (int q = 0; q < NV; ++q) a[st][m].v[q] = smx4(a[st][m].v[q], sm_c[m], d.sm_thresh, left - 4 * q, sm_z[m]);
+      }
+    } else if (!FULL || CONV) {
 #pragma unroll
       for (int m = 0; m < MF; ++m) M_::fixA(a[st][m], am0[st][m], am1[st][m], relu);
     }
@@ -734,6 +783,56 @@ void gemm_kernel(const GemmArgs args) {
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
       if (kb + s * WK < kb_hi) load(TailT{}, s, kb + s * WK);
+    if constexpr (SMX) {
+      // (max, sum exp) partials of the score GEMM -> (m, 1/Z) of this lane's rows: the 4 lanes that share a row split
+      // the 32-key groups, then merge by shuffle.  Issued behind the first operand loads, 4 groups per row in flight
+      // per round trip (a one-at-a-time loop is nt/4 dependent L2 latencies: 8 us at 1764 keys).
+      constexpr int CHK = 4;
+      const float2* ps[MF];
+      float mx[MF], z[MF];
+#pragma unroll
+      for (int m = 0; m < MF; ++m) {
+        int r = m0 + wm * MF * 16 + m * 16 + (lane & 15);
+        r = r < d.M ? r : d.M - 1;
+        ps[m] = reinterpret_cast<const float2*>(d.sm_stats) + (int64_t)r * d.sm_nt;
+        mx[m] = -INFINITY; z[m] = 0.f;
+      }
+      for (int t0 = g; t0 < d.sm_nt; t0 += 4 * CHK) {
+        float2 v[MF][CHK];
+#pragma unroll
+        for (int m = 0; m < MF; ++m)
+#pragma unroll
+          for (int c = 0; c < CHK; ++c) {
+            const int t = t0 + 4 * c;
+            v[m][c] = ps[m][t < d.sm_nt ? t : d.sm_nt - 1];          // clamped, unconditional
+          }
+#pragma unroll
+        for (int m = 0; m < MF; ++m) {
+          float cm = mx[m];
+#pragma unroll
+          for (int c = 0; c < CHK; ++c) cm = (t0 + 4 * c < d.sm_nt) ? fmaxf(cm, v[m][c].x) : cm;
+          float zc = z[m] * __expf(mx[m] - cm);                       // (first round: 0 * exp(-inf) = 0)
+#pragma unroll
+          for (int c = 0; c < CHK; ++c) zc += (t0 + 4 * c < d.sm_nt) ? v[m][c].y * __expf(v[m][c].x - cm) : 0.f;
+          mx[m] = cm; z[m] = zc;
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < MF; ++m) {
+#pragma unroll
+        for (int o_ = 16; o_ < 64; o_ <<= 1) {
+          const float mo = __shfl_xor(mx[m], o_), zo = __shfl_xor(z[m], o_);
+          const float mn = fmaxf(mx[m], mo);
+          z[m] = (mx[m] == -INFINITY ? 0.f : z[m] * __expf(mx[m] - mn)) + (mo == -INFINITY ? 0.f : zo * __expf(mo - mn));
+          mx[m] = mn;
+        }
+        sm_c[m] = -mx[m] * 1.44269504088896341f - __log2f(z[m]);
+        if (d.sm_zout && tile_n == 0 && wk == 0 && wn == 0 && g == 0) {      // (m, 1/Z) of the row for sp3_colsum_softmax
+          const int r = m0 + wm * MF * 16 + m * 16 + (lane & 15);
+          if (r < d.M) { d.sm_zout[4 * (int64_t)r + 1] = mx[m]; d.sm_zout[4 * (int64_t)r + 2] = 1.0f / z[m]; }
+        }
+      }
+    }
     if (kb + (2 * STAGES - 2) * WK < kb_hi_full) {
       // the prologue stages are full blocks here, but were loaded through the masked path: consume them masked once
       do {
@@ -780,6 +879,15 @@ void gemm_kernel(const GemmArgs args) {
           const int col = wn * NF * 16 + n * 16 + (lane & 15);
           slab[row * LDS_LD + col] = acc[m][n][r];
         }
+    if constexpr (SMX) {        // spare column BN of the slab row: this wave's share of the row's kept probability mass
+#pragma unroll
+      for (int m = 0; m < MF; ++m) {
+        float z = sm_z[m];
+        z += __shfl_xor(z, 16);
+        z += __shfl_xor(z, 32);
+        if (g == 0 && wn == 0) slab[(wm * MF * 16 + m * 16 + (lane & 15)) * LDS_LD + BN] = z;
+      }
+    }
   }
   // folded LayerNorm: finish mean / rstd of this tile's rows (rowstat does not alias the slabs: one barrier covers both)
   float* rowstat = smem + (size_t)WK * BM * LDS_LD;     // [BM][2]
@@ -1006,10 +1114,20 @@ void gemm_kernel(const GemmArgs args) {
     }
     const int row = idx / (BN / 4), c4 = (idx % (BN / 4)) * 4;
     const int gm = m0 + row, gn = n0 + c4;
-    if (gm >= d.M || gn >= d.N) continue;
+    // (softmax statistics: the 8 lanes of a 32-column group stay together through the shuffles, also past N)
+    if (gm >= d.M || (gn >= d.N && !d.sm_stats_out)) continue;
     float4 acc4 = lds_sum4(row, c4);
     float v[4] = {acc4.x * alpha, acc4.y * alpha, acc4.z * alpha, acc4.w * alpha};
     const int nvalid = (d.N - gn) < 4 ? (d.N - gn) : 4;
+    if constexpr (SMX) {
+      // renormalise by the kept probability mass of the row (summed over the K-split waves), hand it to the column sums
+      float zs = smem[row * LDS_LD + BN];
+#pragma unroll
+      for (int s_ = 1; s_ < WK; ++s_) zs += smem[(size_t)s_ * BM * LDS_LD + row * LDS_LD + BN];
+      const float izs = 1.0f / zs;
+      v[0] *= izs; v[1] *= izs; v[2] *= izs; v[3] *= izs;
+      if (gn == 0 && d.sm_zout) d.sm_zout[4 * (int64_t)gm] = zs;
+    }
 
     if (d.epi == SP3_EPI_PARTIAL) {
       float* o = reinterpret_cast<float*>(d.C) + ((int64_t)kz * d.M + gm) * d.ldc + gn;
@@ -1119,6 +1237,22 @@ void gemm_kernel(const GemmArgs args) {
       const float* r = d.res2 + ((int64_t)bz * d.M + gm) * d.ldr2 + gn;
 #pragma unroll
       for (int e = 0; e < 4; ++e) if (e < nvalid) v[e] += r[e];
+    }
+    if (d.sm_stats_out) {
+      // per-32-column (max, sum exp(x - max)) of the finished scores: 8 consecutive lanes share a row group
+      float mx = -INFINITY;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (e < nvalid) mx = fmaxf(mx, v[e]);
+#pragma unroll
+      for (int o_ = 1; o_ < 8; o_ <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o_));
+      float se = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (e < nvalid) se += __expf(v[e] - mx);
+#pragma unroll
+      for (int o_ = 1; o_ < 8; o_ <<= 1) se += __shfl_xor(se, o_);
+      if (((gn >> 2) & 7) == 0)
+        reinterpret_cast<float2*>(d.sm_stats_out)[(int64_t)gm * ((d.N + 31) >> 5) + (gn >> 5)] = make_float2(mx, se);
+      if (nvalid <= 0) continue;
     }
     if (d.stats_out) {
       // per-32-column partial (sum, sum of squares) of the finished rows: 8 consecutive lanes share a row group
@@ -1252,7 +1386,9 @@ extern "C" int sp3_gemm(const sp3_gemm_desc* dp, void* stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   SP3_CHECK(d.A && d.W && d.C, "sp3_gemm: null A/W/C");
   SP3_CHECK(d.M > 0 && d.N > 0 && d.K > 0, "sp3_gemm: bad shape M=%d N=%d K=%d", d.M, d.N, d.K);
-  SP3_CHECK(d.K % 8 == 0, "sp3_gemm: K=%d must be a multiple of 8", d.K);
+  SP3_CHECK(d.K % 8 == 0 || (d.loader == SP3_LOAD_SOFTMAX && d.K % 4 == 0), "sp3_gemm: K=%d must be a multiple of 8", d.K);
+  SP3_CHECK(!d.sm_stats_out || (d.epi == SP3_EPI_PLAIN && d.N % 4 == 0 && !d.out_packed && !d.out_bf16 && d.batch == 1),
+            "sp3_gemm: sm_stats_out needs the plain fp32 epilogue, N %% 4 == 0, one problem");
   SP3_CHECK(d.wdtype == SP3_F32 || d.wdtype == SP3_BF16, "sp3_gemm: bad wdtype %d", d.wdtype);
   SP3_CHECK(!d.a_bf16 || d.wdtype == SP3_BF16, "sp3_gemm: a_bf16 needs wdtype bf16");
   SP3_CHECK((reinterpret_cast<uintptr_t>(d.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(d.W) & 15) == 0,
@@ -1283,6 +1419,13 @@ extern "C" int sp3_gemm(const sp3_gemm_desc* dp, void* stream_) {
     SP3_CHECK(d.lda % aalign == 0 && d.lda >= d.K1, "sp3_gemm: lda=%lld must be >= K and keep 16-byte rows", (long long)d.lda);
   } else if (d.loader == SP3_LOAD_PLAIN) {
     /* packed A: geometry is implied by M, K */
+  } else if (d.loader == SP3_LOAD_SOFTMAX) {
+    SP3_CHECK(!d.a_bf16 && !d.a_packed && !d.A2 && d.epi == SP3_EPI_PLAIN && d.splitk == 1 && d.batch == 1 && !d.ln_stats && !d.relu_in,
+              "sp3_gemm: the softmax loader takes row-major fp32 scores, plain epilogue, one problem, no split-K");
+    SP3_CHECK(d.sm_stats && d.sm_nt == (d.K + 31) / 32 && d.lda % 4 == 0 && d.lda >= (d.K + 15) / 16 * 16 && d.K % 4 == 0,
+              "sp3_gemm: softmax loader needs sm_stats[M][ceil(K/32)][2], K %% 4 == 0 and score rows padded to 16 (lda=%lld K=%d)",
+              (long long)d.lda, d.K);
+    SP3_CHECK(d.tile <= 1, "sp3_gemm: the softmax loader runs on the 16x64 tile (tile <= 0) or the 32x32 one (tile 1)");
   } else if (d.loader == SP3_LOAD_CONV3X3) {
     SP3_CHECK(d.conv_C % 16 == 0, "sp3_gemm: conv Cin=%d must be a multiple of 16", d.conv_C);
     SP3_CHECK(d.K == 9 * d.conv_C, "sp3_gemm: conv K=%d != 9*Cin", d.K);
@@ -1310,12 +1453,14 @@ extern "C" int sp3_gemm(const sp3_gemm_desc* dp, void* stream_) {
     const long sk = d.splitk;
     const long t64 = (long)((d.M + 63) / 64) * ((d.N + 63) / 64) * d.batch * sk;
     const long t128 = (long)((d.M + 63) / 64) * ((d.N + 127) / 128) * d.batch;
-    const bool lds_ok = d.loader != SP3_LOAD_CONV3X3 && sk == 1 && d.a_packed && d.w_packed && d.a_bf16 && !d.A2 &&
+    const bool lds_ok = d.loader == SP3_LOAD_PLAIN && !d.sm_stats_out && sk == 1 && d.a_packed && d.w_packed && d.a_bf16 && !d.A2 &&
                         d.epi != SP3_EPI_PARTIAL && d.K % 64 == 0;
     if (lds_ok && d.M >= 1024 && d.N >= 2304 && d.N % 128 == 0) {
       // LDS-staged operands (tools/bench_gemm2.py --big, HBM-cold weights, also grouped launches): 128x128 for large grids
       // / N multiple of 4096, else 128x64
       tile = (d.N % 4096 == 0 || (long)((d.M + 127) / 128) * (d.N / 128) * d.batch >= 1024) ? 5 : 6;
+    } else if (d.loader == SP3_LOAD_SOFTMAX) {
+      tile = 0;
     } else if (d.loader != SP3_LOAD_CONV3X3 && d.M >= 1024) {
       tile = 1;                                           // many rows, narrow N (also split-K partials): 64x64 register tiles
     } else if (lds_ok && d.M <= 224 && d.M > 112 && d.epi == SP3_EPI_PLAIN && d.N >= 3072 && d.K <= 1024 &&
@@ -1333,6 +1478,17 @@ extern "C" int sp3_gemm(const sp3_gemm_desc* dp, void* stream_) {
       tile = 0;
       (void)t64;
     }
+  }
+  SP3_CHECK(!d.sm_stats_out || tile <= 3, "sp3_gemm: sm_stats_out needs a register-ring tile (0-3)");
+  if (d.loader == SP3_LOAD_SOFTMAX) {
+    // 16 x 64 tile, K over the 4 waves: the probabilities of a row are rebuilt by every column tile, so few wide ones
+    // (32 x 32: 16.6 us at 196 x 1764, half of it exponentials)
+    if (d.tile == 1) {
+      if (d.wdtype == SP3_BF16) return launch<float, __bf16, SP3_LOAD_SOFTMAX, 2, 2, 1, 1, 4, 3>(d, stream);
+      return launch<float, float, SP3_LOAD_SOFTMAX, 2, 2, 1, 1, 4, 3>(d, stream);
+    }
+    if (d.wdtype == SP3_BF16) return launch<float, __bf16, SP3_LOAD_SOFTMAX, 1, 4, 1, 1, 4, 3>(d, stream);
+    return launch<float, float, SP3_LOAD_SOFTMAX, 1, 4, 1, 1, 4, 3>(d, stream);
   }
   if (d.wdtype == SP3_BF16) {
     if (d.a_bf16) {

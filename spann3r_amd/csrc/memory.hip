@@ -127,6 +127,48 @@ __global__ __launch_bounds__(256) void colsum_packed_kernel(const TP* __restrict
   }
 }
 
+// Column sums of the thresholded, renormalised probabilities straight from the scores (the two-launch memory read keeps no
+// probability matrix): mem_attn[j] += sum_r [p >= thr] p / Z'_r with p = exp(S[r,j] - m_r) / Z_r; rowz[r] = (Z', m, 1/Z, -)
+// as the P.V launch left them.  One workgroup per 64 columns, its 16 waves take the rows r = w, w+16, ... with 8 loads in
+// flight each; the sixteen partial sums meet in LDS in a fixed order (deterministic).
+__global__ __launch_bounds__(1024) void colsum_softmax_kernel(const float* __restrict__ S, int64_t ld, int rows, int M,
+                                                              const float4* __restrict__ rowz, float thr, float* __restrict__ mem_attn,
+                                                              float* __restrict__ mem_count, int app_P) {
+  __shared__ float sh[16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + lane;
+  const int jc = j < M ? j : M - 1;
+  float acc = 0.f;
+  for (int r0 = w; r0 < rows && blockIdx.x * 64 < M; r0 += 16 * 8) {
+    float sv[8];
+    float4 rz[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int r = r0 + 16 * c, rc = r < rows ? r : rows - 1;
+      sv[c] = S[(int64_t)rc * ld + jc];
+      rz[c] = rowz[rc];
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float p = __expf(sv[c] - rz[c].y) * rz[c].z;
+      acc += (p < thr || r0 + 16 * c >= rows) ? 0.f : p / rz[c].x;
+    }
+  }
+  sh[w][lane] = acc;
+  __syncthreads();
+  if (w == 0 && j < M) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += sh[q][lane];
+    mem_attn[j] += t;
+  }
+  // the bookkeeping of the append that follows the read (sp3_mem_append), when the caller commits the frame in the same launch
+  if (w == 0 && app_P > 0) {
+    if (j < M) mem_count[j] += 1.0f;
+    else if (j < M + app_P) { mem_count[j] = 0.f; mem_attn[j] = 0.f; }
+  }
+}
+
 // mem_attn[j] += sum_r P[r, j]: one workgroup per 64 columns, its 4 waves take the rows r = w, w+4, ... (coalesced 256-byte
 // row segments), partial sums meet in LDS in a fixed order.
 __global__ __launch_bounds__(256) void colsum_accum_kernel(const float* __restrict__ P, int64_t ld, int rows, int M,
@@ -451,6 +493,17 @@ extern "C" int sp3_colsum_packed(const void* P_packed, int packed_bf16, int rows
     hipLaunchKernelGGL(colsum_packed_kernel<float>, dim3(Kp / 32), dim3(256), 0, ST(stream), (const float*)P_packed, rows, M, Kp, mem_attn);
   }
   SP3_LAUNCH_CHECK("sp3_colsum_packed");
+  return 0;
+}
+
+extern "C" int sp3_colsum_softmax(const float* S, int64_t ld, int rows, int M, const float* rowz, float thresh, float* mem_attn,
+                                  float* mem_count, int append_P, void* stream) {
+  SP3_CHECK(S && rowz && mem_attn && rows > 0 && M > 0 && ld >= M, "sp3_colsum_softmax: bad arguments");
+  SP3_CHECK((reinterpret_cast<uintptr_t>(rowz) & 15) == 0, "sp3_colsum_softmax: rowz must be 16-byte aligned");
+  SP3_CHECK(append_P == 0 || (append_P > 0 && mem_count), "sp3_colsum_softmax: append needs mem_count");
+  hipLaunchKernelGGL(colsum_softmax_kernel, dim3((M + append_P + 63) / 64), dim3(1024), 0, ST(stream), S, ld, rows, M,
+                     reinterpret_cast<const float4*>(rowz), thresh, mem_attn, mem_count, append_P);
+  SP3_LAUNCH_CHECK("sp3_colsum_softmax");
   return 0;
 }
 

@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("SP3_LIB_PATH") or os.path.join(_HERE, "libspann3r_hip
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 EPI_PLAIN, EPI_ROPE_VT, EPI_PIXSHUF, EPI_PARTIAL = 0, 1, 2, 3
-LOAD_PLAIN, LOAD_CONV3X3 = 0, 1
+LOAD_PLAIN, LOAD_CONV3X3, LOAD_SOFTMAX = 0, 1, 2
 
 
 class GemmDesc(C.Structure):
@@ -41,6 +41,7 @@ class GemmDesc(C.Structure):
         ("sb_A2", C.c_int64), ("sb_bias", C.c_int64), ("sb_ln_stats", C.c_int64), ("sb_ln_s", C.c_int64),
         ("sb_stats_out", C.c_int64), ("sb_c2", C.c_int64), ("sb_vt", C.c_int64),
         ("trace", C.c_void_p),
+        ("sm_stats_out", C.c_void_p), ("sm_stats", C.c_void_p), ("sm_nt", C.c_int32), ("sm_thresh", C.c_float), ("sm_zout", C.c_void_p),
     ]
 
 
@@ -91,6 +92,7 @@ _PROTOS = {
     "sp3_softmax_thresh": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float,
                            C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p],
     "sp3_colsum_packed": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
+    "sp3_colsum_softmax": [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p],
     "sp3_bank_write": [C.POINTER(BankWriteDesc), C.c_void_p],
     "sp3_pack_stats": [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p],
     "sp3_gather_packed_rows": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p],

@@ -96,8 +96,11 @@ class SpatialMemory:
       k_hat  fragment-order [cap,1024] wdt = gamma_q (.) LN_k(mem_k)   (W operand of the S GEMM; LN_q is folded into it)
       v_hat_t fragment-order [1024,cap] wdt = LN_v(mem_v)^T             (W operand of the P.V GEMM)
       s_bank, b_bank [cap] fp32 (fold constants of LN_q), mem_attn [cap] fp32, mem_count [cap] fp32
-    One launch writes a frame (sp3_bank_write); a read is S GEMM -> softmax/threshold -> P.V GEMM (+ column sums).
+    One launch writes a frame (sp3_bank_write).  A read is two launches while the score matrix stays cache-sized (score
+    GEMM with the softmax statistics in its epilogue; P.V GEMM that builds the thresholded probabilities on load and
+    renormalises in its epilogue) plus the column sums for mem_attn; long banks materialise P (softmax launch, split-K P.V).
     """
+    FUSED_READ_MAX = 2_000_000        # queries x bank tokens: fp32 scores <= 8 MB (L2 / MALL resident for the 32 column tiles)
 
     def __init__(self, engine: Engine, batch, num_patches, capacity, attn_thresh=5e-4, long_mem_size=4000,
                  work_mem_size=5, sim_thresh=0.95):
@@ -124,6 +127,7 @@ class SpatialMemory:
         self._sel = torch.zeros(batch, max(long_mem_size, 1), dtype=torch.int32, device=dev)
         w = engine.w
         self._norms = (w["norm_k.w"], w["norm_k.b"], w["norm_v.w"], w["norm_v.b"], w["norm_q.w"], w["norm_q.b"])
+        self._pending_attn = None
 
     def _alloc(self, dev, wdt):
         B, cap, C = self.B, self.cap, self.C
@@ -146,9 +150,11 @@ class SpatialMemory:
     def reset(self):
         """Start a new sequence on the same arena (stale rows are never read: every read is bounded by M)."""
         self._cur, self.M, self.wm, self.lm, self.events = 0, 0, 0, 0, []
+        self._pending_attn = None
 
     def snapshot(self):
         """Detached copy of the reference-visible state (what `return_memory=True` hands out)."""
+        self._flush_attn()
         snap = MemorySnapshot()
         for name in ("mem_k", "mem_v", "mem_attn", "mem_count"):
             t = getattr(self, name)
@@ -174,10 +180,14 @@ class SpatialMemory:
         return None if self.M == 0 else self.bank["count"][:, :self.M, None]
 
     # ------------------------------------------------------------------ read (:145-183)
-    def memory_read(self, feat, out, feat_packed=None, feat_stats=None):
+    def memory_read(self, feat, out, feat_packed=None, feat_stats=None, defer_attn=False):
         """feat fp32 [B,P,1024] (the query, feat_k2) -> out = attn . LN_v(mem_v) + feat ; mem_attn += colsum(attn).
         feat_packed / feat_stats: fragment-order copy and row-statistics partials of `feat` when its producer already
-        wrote them (B == 1: the key-MLP GEMM's c2 / stats_out); otherwise one sp3_pack_stats launch makes them."""
+        wrote them (B == 1: the key-MLP GEMM's c2 / stats_out); otherwise one sp3_pack_stats launch makes them.
+        defer_attn: the column sums of the two-launch read (mem_attn += ..., consumed by nothing before the next prune) are
+        not launched here but folded into the launch that commits / drops the staged frame (`commit`, `finish_staged`) --
+        a side stream for them costs more in graph fork/join edges than the launch itself (measured: -8 % frames/s)."""
+        self._flush_attn()
         eng, bk = self.eng, self.bank
         B, P, C, M, kb = self.B, self.P, self.C, self.M, self.kb
         assert M > 0
@@ -187,7 +197,6 @@ class SpatialMemory:
         ld = self.cap
         Pp = (P + 15) // 16 * 16
         S = eng.ws("mem_S", (B, P, ld))
-        pk = eng.ws("mem_P_packed", (B, Pp * self.cap), eng.adt, zero=True)
         if feat_packed is None or B > 1:
             qp = [eng.wsp("mem_q_packed%d" % b, P, C) for b in range(B)]
             qs = eng.ws("mem_q_stats", (B, P, C // 32, 2))
@@ -196,26 +205,38 @@ class SpatialMemory:
         else:
             qp, qs = [feat_packed], feat_stats.view(1, P, C // 32, 2)
         alpha = 1.0 / (C ** 0.5)
+        S_k, fused = self._read_plan()
+        # Two launches while the bank is short (every per-frame read of the 224x224 demo): the score GEMM leaves the softmax
+        # statistics of its 32-key groups behind, the P.V GEMM turns scores into thresholded probabilities as it loads
+        # them and renormalises in its epilogue; the column sums (mem_attn, only read by the next prune) follow.
+        # Long banks (split K; the scores no longer sit in L2 for 32 column tiles to re-read) keep a materialised P.
+        st = eng.ws("mem_sm_stats", (B, P, (self.cap + 31) // 32, 2)) if fused else None
+        zk = eng.ws("mem_sm_rowz", (B, P, 4)) if fused else None
         for b in range(B):
             # S = LN_q(q) . K_hat^T / 32: raw q (fragment order) x (gamma_q (.) K_hat), LN_q folded through s_bank / b_bank
             ops.gemm(qp[b], ops.PackedWeight.wrap(bk["k_hat"][b], M, C), S[b], M=P, N=M, K=C, lda=C, ldc=ld, alpha=alpha,
-                     bias=bk["b_bank"][b], ln=ops.LnFold(qs[b], C, bk["s_bank"][b], 1e-5))
-        ops.softmax_thresh(S, None, ld=ld, rows=P, M=M, Mpad=M, thresh=self.attn_thresh, batch=B, strideS=P * ld,
-                           packed=pk, stride_packed=pk.shape[1])
-        # long banks: K split over several workgroups per output tile (64 tiles otherwise), one reduce launch adds q
-        S_k = 1
-        while Kp // (2 * S_k) >= 2048 and S_k < 16:
-            S_k *= 2
-        for b in range(B):
-            A = ops.PackedAct(P, Kp, eng.adt, eng.device, data=pk[b])
-            Wv = ops.PackedWeight.wrap(bk["v_hat_t"][b], C, self.cap)
-            if S_k == 1:
-                ops.gemm(A, Wv, out[b], M=P, N=C, K=Kp, lda=Kp, ldc=C, ldw=self.cap, res1=feat[b], ldr1=C)
-            else:
-                part = eng.ws("mem_pv_partial", (S_k * P * C,))
-                ops.gemm(A, Wv, part, M=P, N=C, K=Kp, lda=Kp, ldc=C, ldw=self.cap, splitk=S_k)
-                ops.reduce_ln(part, S_k, P, C, res=feat[b], ldres=C, x_out=out[b], ldx=C)
-            ops.colsum_packed(pk[b], P, M, bk["attn"][b])
+                     bias=bk["b_bank"][b], ln=ops.LnFold(qs[b], C, bk["s_bank"][b], 1e-5), sm_stats_out=st[b] if fused else None)
+        if fused:
+            for b in range(B):
+                ops.gemm(S[b], ops.PackedWeight.wrap(bk["v_hat_t"][b], C, self.cap), out[b], M=P, N=C, K=M, lda=ld, ldc=C,
+                         ldw=self.cap, res1=feat[b], ldr1=C, softmax=(st[b], self.attn_thresh, zk[b]))
+            self.note_deferred_read()
+            if not defer_attn:
+                self._flush_attn()
+        else:
+            pk = eng.ws("mem_P_packed", (B, Pp * self.cap), eng.adt, zero=True)
+            ops.softmax_thresh(S, None, ld=ld, rows=P, M=M, Mpad=M, thresh=self.attn_thresh, batch=B, strideS=P * ld,
+                               packed=pk, stride_packed=pk.shape[1])
+            for b in range(B):
+                A = ops.PackedAct(P, Kp, eng.adt, eng.device, data=pk[b])
+                Wv = ops.PackedWeight.wrap(bk["v_hat_t"][b], C, self.cap)
+                if S_k == 1:
+                    ops.gemm(A, Wv, out[b], M=P, N=C, K=Kp, lda=Kp, ldc=C, ldw=self.cap, res1=feat[b], ldr1=C)
+                else:
+                    part = eng.ws("mem_pv_partial", (S_k * P * C,))
+                    ops.gemm(A, Wv, part, M=P, N=C, K=Kp, lda=Kp, ldc=C, ldw=self.cap, splitk=S_k)
+                    ops.reduce_ln(part, S_k, P, C, res=feat[b], ldres=C, x_out=out[b], ldx=C)
+                ops.colsum_packed(pk[b], P, M, bk["attn"][b])
         if prof is not None:
             es = bk["k_hat"].element_size()
             # algorithmic bytes of one read: K_hat + V_hat once, plus the query in and the fused features out
@@ -233,10 +254,41 @@ class SpatialMemory:
         for b in range(B):
             ops.bank_write(feat_k[b], feat_v[b], self._bank_of(bk, b), M, P, C, self.cap, self._norms, 1.0 / (C ** 0.5))
 
+    def _read_plan(self):
+        """(split-K factor of the P.V GEMM, two-launch read?) at the current bank length"""
+        M, kb = self.M, self.kb
+        Kp = (M + kb - 1) // kb * kb
+        # long banks: K split over several workgroups per output tile (64 tiles otherwise), one reduce launch adds q
+        S_k = 1
+        while Kp // (2 * S_k) >= 2048 and S_k < 16:
+            S_k *= 2
+        return S_k, (S_k == 1 and self.P * M <= self.FUSED_READ_MAX and M % 4 == 0)
+
+    def note_deferred_read(self):
+        """A two-launch read of the current bank was issued (directly or by replaying the step's hipGraph, which runs no
+        Python): its column sums are owed to mem_attn -- from the static score / row-statistic workspaces."""
+        if self.M > 0 and self._read_plan()[1]:
+            eng = self.eng
+            self._pending_attn = (eng.ws("mem_S", (self.B, self.P, self.cap)), self.cap, self.M, eng.ws("mem_sm_rowz", (self.B, self.P, 4)))
+
+    def _flush_attn(self, append=False):
+        """launch the pending column sums of the last two-launch read (optionally with the append bookkeeping)"""
+        pend, self._pending_attn = self._pending_attn, None
+        if pend is None:
+            return False
+        S, ld, M, zk = pend
+        bk = self.bank
+        fuse = append and M == self.M
+        for b in range(self.B):
+            ops.colsum_softmax(S[b], ld, self.P, M, zk[b], self.attn_thresh, bk["attn"][b],
+                               bk["count"][b] if fuse else None, self.P if fuse else 0)
+        return fuse
+
     def commit(self):
         bk = self.bank
-        for b in range(self.B):
-            ops.mem_append(bk["count"][b], bk["attn"][b], self.M, self.P)
+        if not self._flush_attn(append=True):
+            for b in range(self.B):
+                ops.mem_append(bk["count"][b], bk["attn"][b], self.M, self.P)
         self.M += self.P
 
     def add_mem(self, feat_k, feat_v):
@@ -302,6 +354,7 @@ class SpatialMemory:
         (hipGraph path): commit or drop the staged frame, then the working/long-term bookkeeping and prune."""
         if similar:
             self.events.append("skip")
+            self._flush_attn()
             return
         self.commit()
         self._after_write()
@@ -322,6 +375,7 @@ class SpatialMemory:
         """Keep the top_k tokens by mem_attn/mem_count (tokens younger than work_mem_size+5 steps protected).
         The kept tokens are stored sorted by weight descending, ties by index ascending (the reference's torch.topk
         leaves the tie order implementation-defined, SURVEY.md §7 quirk i)."""
+        self._flush_attn()
         B, C, M, k = self.B, self.C, self.M, self.top_k
         src = self.bank
         if self._banks[1 - self._cur] is None:
@@ -508,7 +562,7 @@ class _SequenceRunner:
                 ops.copy2d(self.feat2, E, self.feat1, E, B * P, E)      # feat1 <- previous feat2 (:294)
                 ops.copy2d(self.feat_pre, E, self.feat2, E, B * P, E)   # feat2 <- the frame encoded during the previous step
             # reads k2 (and its fragment-order copy / statistics) before the key MLP of this step overwrites them
-            mem.memory_read(self.k2, self.fuse, *(self.k2_aux if B == 1 else (None, None)))
+            mem.memory_read(self.k2, self.fuse, *(self.k2_aux if B == 1 else (None, None)), defer_attn=True)
             f1 = self.fuse
         if has_next:
             st[3].wait_stream(main)
@@ -562,6 +616,8 @@ class _SequenceRunner:
         # done and takes the memory decision while the second one (head, value encoder) still runs -> the next step's
         # launches are queued before the GPU runs dry.  The reference syncs at the same point of the data flow (:114).
         self._graphed(("first" if first else "step",) + key, lambda: self._part1(first, has_next), use_graphs)
+        if not first:
+            mem.note_deferred_read()        # (a replayed graph ran no Python)
         need_sim = not self.training and mem.sim_needed()
         if need_sim:
             mem.fetch_scores_async()

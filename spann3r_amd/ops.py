@@ -127,9 +127,12 @@ def pick_tile(M, N, batch=1, splitk=1, conv=False, K=0, packed_bf16=False, plain
 
 
 def _gemm_launch(d, what, loader_name):
+    if d.loader == L.LOAD_SOFTMAX:
+        d.tile = 1 if d.tile == 1 else 0
     if d.tile < 0:
         d.tile = pick_tile(d.M, d.N, max(d.batch, 1), max(d.splitk, 1), d.loader == L.LOAD_CONV3X3, d.K,
-                           bool(d.a_packed and d.w_packed and d.a_bf16 and not d.A2 and d.epi != L.EPI_PARTIAL),
+                           bool(d.a_packed and d.w_packed and d.a_bf16 and not d.A2 and d.epi != L.EPI_PARTIAL
+                                and not d.sm_stats_out),
                            d.epi == L.EPI_PLAIN, d.ln_nt if d.ln_stats else 0)
     if _prof is None:
         L.check(L.load().sp3_gemm(C.byref(d), L.stream_ptr()), what)
@@ -143,7 +146,8 @@ def _gemm_launch(d, what, loader_name):
     a_elems = d.M * d.K if d.loader != L.LOAD_CONV3X3 else d.M * d.conv_stride * d.conv_stride * d.conv_C   # conv: the map, once
     nbytes = b * (asz * a_elems + wsz * d.N * d.K + csz * d.M * d.N)      # algorithmic: every operand once
     adt = "bf16" if d.a_bf16 else "f32"
-    _prof.end("gemm<A%s,W%s,%s,%s>" % (adt, "f32" if d.wdtype == F32 else "bf16", loader_name, _TILE_NAMES[d.tile]),
+    tname = ("16x64xk4" if d.tile == 0 else "32x32xk4") if d.loader == L.LOAD_SOFTMAX else _TILE_NAMES[d.tile]
+    _prof.end("gemm<A%s,W%s,%s,%s>" % (adt, "f32" if d.wdtype == F32 else "bf16", loader_name, tname),
               e0, flops, nbytes)
 
 
@@ -295,10 +299,14 @@ def _act(t, name):
 
 def gemm(A, W, out, *, M, N, K, lda, ldc, bias=None, res1=None, ldr1=0, res2=None, ldr2=0, act=ACT_NONE, alpha=1.0,
          relu_in=False, tile=-1, batch=1, strideA=0, strideW=0, strideC=0, ldw=0,
-         A2=None, lda2=0, K1=0, splitk=0, ln=None, stats_out=None, c2=None, sb=None, trace=None):
+         A2=None, lda2=0, K1=0, splitk=0, ln=None, stats_out=None, c2=None, sb=None, trace=None,
+         sm_stats_out=None, softmax=None):
     """out[M,N] = act(alpha * A[M,K] @ W[N,K]^T + bias) (+ res1 + res2).  nn.Linear / 1x1 conv / einsum.
     `out` may be fp32 or bf16.  splitk >= 1 selects the PARTIAL epilogue: out is an fp32 [splitk, M, ldc] workspace
-    that sp3_reduce_ln finishes."""
+    that sp3_reduce_ln finishes.
+    sm_stats_out: fp32 [M, ceil(N/32), 2] gets the (max, sum exp) partials of the finished rows (score GEMM of the memory
+    read).  softmax=(stats, thresh, zout): A is an fp32 score matrix whose rows become thresholded probabilities on load
+    (loader SOFTMAX); out = (P @ W^T) / kept mass (+ res), zout[M, 4] = (kept mass, row max, 1/Z, -)."""
     d = GemmDesc()
     d.a_bf16 = _act(A, "A")
     d.a_packed = _is_packed(A)
@@ -317,9 +325,13 @@ def gemm(A, W, out, *, M, N, K, lda, ldc, bias=None, res1=None, ldr1=0, res2=Non
     _ln(d, ln)
     d.stats_out, d.c2 = L.ptr(stats_out), L.ptr(c2)
     d.trace = L.ptr(trace)
+    d.sm_stats_out = L.ptr(sm_stats_out)
+    if softmax is not None:
+        st, thresh, zout = softmax
+        d.loader, d.sm_stats, d.sm_nt, d.sm_thresh, d.sm_zout = L.LOAD_SOFTMAX, st.data_ptr(), (K + 31) // 32, float(thresh), L.ptr(zout)
     if sb:
         _group(d, batch, strideA, strideW, strideC, sb)
-    _gemm_launch(d, "sp3_gemm", "plain")
+    _gemm_launch(d, "sp3_gemm", "softmax" if softmax is not None else "plain")
     return out
 
 
@@ -519,6 +531,15 @@ def colsum_packed(packed, rows, M, mem_attn):
     _timed("colsum_packed", 1.0 * rows * M, 1.0 * packed.element_size() * rows * M,
            lambda: L.check(L.load().sp3_colsum_packed(packed.data_ptr(), int(packed.dtype == torch.bfloat16), rows, M, mem_attn.data_ptr(),
                                                       L.stream_ptr()), "sp3_colsum_packed"))
+
+
+def colsum_softmax(S, ld, rows, M, rowz, thresh, mem_attn, mem_count=None, append_P=0):
+    """mem_attn[j] += column sums of the thresholded, renormalised softmax of S[:rows, :M]; rowz [rows, 4] = the softmax-loader
+    GEMM's zout (kept mass, max, 1/Z, -) (two-launch memory read).  append_P > 0: the same launch also does
+    mem_append(mem_count, mem_attn, M, append_P)."""
+    _timed("colsum_softmax", 4.0 * rows * M, 4.0 * rows * M,
+           lambda: L.check(L.load().sp3_colsum_softmax(S.data_ptr(), ld, rows, M, rowz.data_ptr(), float(thresh), mem_attn.data_ptr(),
+                                                       L.ptr(mem_count), append_P, L.stream_ptr()), "sp3_colsum_softmax"))
 
 
 def bank_write(feat_k, feat_v, bank, M, P, C_, cap, norms, alpha, eps=1e-5):

@@ -657,6 +657,66 @@ def test_bank_write_pack_stats_packed_gathers(wdt, M0):
     assert torch.equal(vg[:, :n_sel], ops.PackedAct(C, cap, wdt, DEV, data=bank["v_hat_t"]).to_dense().cpu()[:, sel_h]) and float(vg[:, n_sel:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("wdt", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("rows,M,thresh", [(196, 1764, 5e-4), (196, 196, 5e-4), (37, 1765 // 4 * 4, 0.0), (50, 6000, 5e-4)])
+def test_two_launch_memory_read(wdt, rows, M, thresh):
+    """Score GEMM that leaves (max, sum exp) partials per 32 keys + P.V GEMM with the softmax loader + column sums, against
+    torch: out = renorm(thresh(softmax(S))) @ V^T + q, mem_attn += column sums (spann3r/model.py:159-183)."""
+    ops = _ops()
+    C = 1024
+    kb = 64 if wdt == torch.bfloat16 else 32
+    cap = (M + 63) // 64 * 64 + 64
+    cast = bf if wdt == torch.bfloat16 else (lambda t: t)
+    q = rnd(rows, C, seed=1)
+    Kh = rnd(M, C, seed=2) * 2.0
+    V = rnd(M, C, seed=3)
+    Khp = torch.zeros(cap, C); Khp[:M] = Kh
+    Vt = torch.zeros(C, cap); Vt[:, :M] = V.T
+    Vt[:, M:] = 3.0                                       # stale columns past the bank's end must not leak
+    A = ops.PackedAct.from_dense(q.to(DEV).to(wdt))
+    Wk = ops.PackedAct.from_dense(Khp.to(DEV).to(wdt))
+    Wv = ops.PackedAct.from_dense(Vt.to(DEV).to(wdt))
+    S = torch.full((rows, cap), float("nan"), device=DEV)
+    nt = (M + 31) // 32
+    st = torch.full((rows, nt, 2), float("nan"), device=DEV)       # compact [rows][ceil(M/32)][2]
+    alpha = 0.25
+    ops.gemm(A, ops.PackedWeight.wrap(Wk.data, M, C), S, M=rows, N=M, K=C, lda=C, ldc=cap, alpha=alpha, sm_stats_out=st)
+    Sref = (cast(q).double() @ cast(Kh).double().T) * alpha
+    assert rel_err(S[:, :M].cpu(), Sref) < (1e-5 if wdt == torch.float32 else 1e-5)
+    # the partials: per 32-key group (max, sum exp(x - max)) of the stored scores
+    Sg = S[:, :M].cpu().double()
+    stv = st.cpu().double()
+    for t in (0, nt // 2, nt - 1):
+        blk = Sg[:, 32 * t:min(32 * t + 32, M)]
+        assert rel_err(stv[:, t, 0], blk.max(1).values) < 1e-6
+        assert rel_err(stv[:, t, 1], torch.exp(blk - blk.max(1, keepdim=True).values).sum(1)) < 1e-5
+    out = torch.full((rows, C), float("nan"), device=DEV)
+    zk = torch.full((rows, 4), float("nan"), device=DEV)
+    S[:, M:] = float("nan")                               # scores past the bank's end are never used
+    ops.gemm(S, ops.PackedWeight.wrap(Wv.data, C, cap), out, M=rows, N=C, K=M, lda=cap, ldc=C, ldw=cap, res1=q.to(DEV), ldr1=C,
+             softmax=(st, thresh, zk))
+    a = torch.softmax(Sg, -1)
+    keep = torch.softmax(S[:, :M].cpu(), -1) >= thresh
+    a = torch.where(keep, a, torch.zeros_like(a))
+    zref = a.sum(-1)
+    an = a / zref[:, None]
+    ref = (cast(an.float()).double() if wdt == torch.bfloat16 else an) @ cast(V).double() + q.double()
+    assert rel_err(zk[:, 0].cpu(), zref) < 2e-3            # entries at the threshold may flip
+    assert rel_err(zk[:, 1].cpu(), Sg.max(1).values) < 1e-6 and rel_err(1.0 / zk[:, 2].cpu().double(), torch.exp(Sg - Sg.max(1, keepdim=True).values).sum(1)) < 1e-5
+    assert rel_err(out.cpu(), ref) < (6e-3 if wdt == torch.bfloat16 else 2e-3)
+    attn = rnd(cap, seed=9).abs().to(DEV)
+    before = attn.clone()
+    ops.colsum_softmax(S, cap, rows, M, zk, thresh, attn)
+    assert rel_err((attn - before)[:M].cpu(), an.sum(0)) < 2e-3 and torch.equal(attn[M:], before[M:])
+    # the same launch with the append bookkeeping of the frame that follows the read (sp3_mem_append semantics)
+    attn2, count = before.clone(), torch.arange(cap, device=DEV).float()
+    Pn = min(64, cap - M)
+    ops.colsum_softmax(S, cap, rows, M, zk, thresh, attn2, count, Pn)
+    assert torch.equal(attn2[:M], attn[:M]) and float(attn2[M:M + Pn].abs().max()) == 0 and torch.equal(attn2[M + Pn:], before[M + Pn:])
+    c = count.cpu()
+    assert torch.equal(c[:M], torch.arange(M).float() + 1) and float(c[M:M + Pn].abs().max()) == 0 and torch.equal(c[M + Pn:], torch.arange(M + Pn, cap).float())
+
+
 def test_cos_sim_append_prune_gather():
     ops = _ops()
     T, P, C = 3, 50, 1024
