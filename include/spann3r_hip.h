@@ -143,6 +143,11 @@ typedef struct sp3_gemm_desc {
   float* sm_zout;
 } sp3_gemm_desc;
 int sp3_gemm(const sp3_gemm_desc* desc_host, void* stream);
+/* Two differently shaped groups of problems in ONE launch (grid.y = a.batch + b.batch), e.g. a decoder layer's self-attention
+ * q/k/v projection (N = 2304) and its cross-attention k/v projection (N = 1536): both read the previous layer's tokens
+ * (dust3r/model.py:196-198, croco/models/blocks.py:187-189), so the second launch boundary buys nothing.  Both descriptors
+ * must resolve to the same kernel instance (dtypes, loader, tile; b.tile < 0 takes a's); no split-K. */
+int sp3_gemm2(const sp3_gemm_desc* a, const sp3_gemm_desc* b, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * sp3_layernorm : nn.LayerNorm over the last dim (croco/models/blocks.py:128-129,187-190 eps 1e-6;

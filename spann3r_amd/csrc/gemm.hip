@@ -29,8 +29,11 @@
 
 namespace {
 
+// d2 / nb1: sp3_gemm2 -- a second, differently shaped group of problems in the same launch: blockIdx.y >= nb1 works on d2
 struct GemmArgs {
   sp3_gemm_desc d;
+  sp3_gemm_desc d2;
+  int nb1;
 };
 
 // ------------------------------------------------------------------ per-dtype operand handling
@@ -345,7 +348,9 @@ constexpr int kMaxKb = 64;                 // k-blocks per K slice the role loop
 template <typename TA, typename TW, int LOADER, int MF, int NF, int WM, int WN, int WK, int STAGES, int LOOP = 0>
 __global__ __launch_bounds__(64 * (WM * WN * WK + (LOOP >= 2 ? LOOP : 0)), (gemm_min_waves<TA, LOADER, MF, NF, WK>()))
 void gemm_kernel(const GemmArgs args) {
-  sp3_gemm_desc d = args.d;                  // local copy: grouped launches shift the per-problem pointers below
+  // local copy: grouped launches shift the per-problem pointers below (kernarg segment, wave-uniform select)
+  const bool second = args.nb1 > 0 && (int)blockIdx.y >= args.nb1;
+  sp3_gemm_desc d = second ? args.d2 : args.d;
   using M_ = MM<TA, TW>;
   constexpr bool LDSK = LOOP != 0;
   constexpr int NCW = WM * WN * WK;          // consumer (MFMA) waves
@@ -372,7 +377,7 @@ void gemm_kernel(const GemmArgs args) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
   const int g = lane >> 4;
-  const int bz = blockIdx.y;
+  const int bz = second ? (int)blockIdx.y - args.nb1 : (int)blockIdx.y;
   const int kz = blockIdx.z;
   if (d.batch > 1) {                         // grouped launch: problem bz (wave-uniform pointer arithmetic)
     auto shift = [&](auto*& p, int64_t bytes) {
@@ -1303,14 +1308,18 @@ void gemm_kernel(const GemmArgs args) {
   if (tr0) { tr0[2] = clock64(); tr0[4] = wall_clock64(); }
 }
 
+// sp3_gemm2: the second group of problems of the launch being dispatched (same kernel instance), or null
+thread_local const sp3_gemm_desc* g_pair = nullptr;
+
 template <typename TA, typename TW, int LOADER, int MF, int NF, int WM, int WN, int WK, int STAGES, int LOOP = 0>
 int launch(const sp3_gemm_desc& d, hipStream_t stream) {
   constexpr bool LDSK = LOOP != 0;
   constexpr int BM = MF * 16 * WM, BN = NF * 16 * WN, NT = 64 * (WM * WN * WK + (LOOP >= 2 ? LOOP : 0));
-  const int mt = (d.M + BM - 1) / BM, nt = (d.N + BN - 1) / BN;
-  int blocks;
-  if (mt >= nt) blocks = ((mt + 7) / 8) * 8 * nt;
-  else blocks = ((nt + 7) / 8) * 8 * mt;
+  auto grid_x = [](const sp3_gemm_desc& q) {
+    const int mt = (q.M + BM - 1) / BM, nt = (q.N + BN - 1) / BN;
+    return mt >= nt ? ((mt + 7) / 8) * 8 * nt : ((nt + 7) / 8) * 8 * mt;
+  };
+  int blocks = grid_x(d);
   size_t lds = ((size_t)WK * BM * (BN + 4) + 2 * BM) * sizeof(float);
   if (LDSK) {
     const size_t stages = (size_t)STAGES * (BM / 16 + (LOOP >= 2 ? 0 : BN / 16)) * 2048;      // the epilogue slab aliases the ring
@@ -1327,7 +1336,18 @@ int launch(const sp3_gemm_desc& d, hipStream_t stream) {
   }
   GemmArgs a;
   a.d = d;
-  hipLaunchKernelGGL(kern, dim3(blocks, d.batch, d.splitk), dim3(NT), lds, stream, a);
+  a.nb1 = 0;
+  int gy = d.batch;
+  if (g_pair) {                      // workgroups past a group's own tile count exit at once
+    a.d2 = *g_pair;
+    a.nb1 = d.batch;
+    gy += g_pair->batch;
+    const int b2 = grid_x(*g_pair);
+    blocks = blocks > b2 ? blocks : b2;
+  } else {
+    a.d2 = d;
+  }
+  hipLaunchKernelGGL(kern, dim3(blocks, gy, d.splitk), dim3(NT), lds, stream, a);
   SP3_LAUNCH_CHECK("sp3_gemm");
   return 0;
 }
@@ -1339,6 +1359,13 @@ int dispatch_tile(const sp3_gemm_desc& d, int tile, hipStream_t stream) {
     case 1: return launch<TA, TW, LOADER, 2, 2, 2, 2, 1, 2>(d, stream);   // 64x64, wave tile 32x32
     case 2: return launch<TA, TW, LOADER, 2, 4, 2, 2, 1, 2>(d, stream);   // 64x128, wave tile 32x64
     case 3: return launch<TA, TW, LOADER, 4, 4, 1, 1, 4, 3>(d, stream);   // 64x64, K over 4 waves
+    case 4: case 18:                                                       // 32x64 / 16x64, K over 4 waves (bf16 operands)
+      if constexpr (sizeof(TA) == 2 && LOADER == SP3_LOAD_PLAIN) {
+        if (tile == 4) return launch<TA, TW, LOADER, 2, 4, 1, 1, 4, 3>(d, stream);
+        return launch<TA, TW, LOADER, 1, 4, 1, 1, 4, 3>(d, stream);
+      }
+      sp3_set_error("sp3_gemm: tile %d needs bf16 A and the plain loader", tile);
+      return 1;
     case 5: case 6: case 7: case 8: case 9: case 10: case 11: case 12: case 13: case 14: case 15: case 16: case 17:     // LDS-staged operands
       if constexpr (sizeof(TA) == sizeof(TW) && LOADER == SP3_LOAD_PLAIN) {
         if (d.a_packed && d.w_packed && !d.A2 && d.K % MM<TA, TW>::KB == 0) {
@@ -1380,10 +1407,8 @@ int dispatch_tile(const sp3_gemm_desc& d, int tile, hipStream_t stream) {
 
 }  // namespace
 
-extern "C" int sp3_gemm(const sp3_gemm_desc* dp, void* stream_) {
-  SP3_CHECK(dp != nullptr, "sp3_gemm: null descriptor");
-  sp3_gemm_desc d = *dp;
-  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+// validation, defaults and tile choice of one descriptor
+static int gemm_prepare(sp3_gemm_desc& d, int& tile_out) {
   SP3_CHECK(d.A && d.W && d.C, "sp3_gemm: null A/W/C");
   SP3_CHECK(d.M > 0 && d.N > 0 && d.K > 0, "sp3_gemm: bad shape M=%d N=%d K=%d", d.M, d.N, d.K);
   SP3_CHECK(d.K % 8 == 0 || (d.loader == SP3_LOAD_SOFTMAX && d.K % 4 == 0), "sp3_gemm: K=%d must be a multiple of 8", d.K);
@@ -1480,6 +1505,11 @@ extern "C" int sp3_gemm(const sp3_gemm_desc* dp, void* stream_) {
     }
   }
   SP3_CHECK(!d.sm_stats_out || tile <= 3, "sp3_gemm: sm_stats_out needs a register-ring tile (0-3)");
+  tile_out = tile;
+  return 0;
+}
+
+static int gemm_dispatch(const sp3_gemm_desc& d, int tile, hipStream_t stream) {
   if (d.loader == SP3_LOAD_SOFTMAX) {
     // 16 x 64 tile, K over the 4 waves: the probabilities of a row are rebuilt by every column tile, so few wide ones
     // (32 x 32: 16.6 us at 196 x 1764, half of it exponentials)
@@ -1501,4 +1531,28 @@ extern "C" int sp3_gemm(const sp3_gemm_desc* dp, void* stream_) {
     if (d.loader == SP3_LOAD_PLAIN) return dispatch_tile<float, float, SP3_LOAD_PLAIN>(d, tile, stream);
     return dispatch_tile<float, float, SP3_LOAD_CONV3X3>(d, tile, stream);
   }
+}
+
+extern "C" int sp3_gemm(const sp3_gemm_desc* dp, void* stream_) {
+  SP3_CHECK(dp != nullptr, "sp3_gemm: null descriptor");
+  sp3_gemm_desc d = *dp;
+  int tile = -1;
+  if (int rc = gemm_prepare(d, tile)) return rc;
+  return gemm_dispatch(d, tile, reinterpret_cast<hipStream_t>(stream_));
+}
+
+extern "C" int sp3_gemm2(const sp3_gemm_desc* ap, const sp3_gemm_desc* bp, void* stream_) {
+  SP3_CHECK(ap != nullptr && bp != nullptr, "sp3_gemm2: null descriptor");
+  sp3_gemm_desc a = *ap, b = *bp;
+  int ta = -1, tb = -1;
+  if (int rc = gemm_prepare(a, ta)) return rc;
+  if (b.tile < 0) b.tile = ta;                   // the second group runs on the first one's kernel instance
+  if (int rc = gemm_prepare(b, tb)) return rc;
+  SP3_CHECK(ta == tb && a.wdtype == b.wdtype && a.a_bf16 == b.a_bf16 && a.loader == b.loader && a.loader != SP3_LOAD_SOFTMAX,
+            "sp3_gemm2: both groups must use one kernel instance (tile %d / %d, same dtypes and loader)", ta, tb);
+  SP3_CHECK(a.splitk == 1 && b.splitk == 1 && !a.trace && !b.trace, "sp3_gemm2: no split-K, no trace");
+  g_pair = &b;
+  const int rc = gemm_dispatch(a, ta, reinterpret_cast<hipStream_t>(stream_));
+  g_pair = nullptr;
+  return rc;
 }

@@ -402,7 +402,7 @@ class Engine:
 
     def decoder_grouped(self, f1, f2, B, nh, nw):
         """dust3r._decoder (dust3r/model.py:186-205) with both sides as problems 0 / 1 of one grouped launch per op:
-        10 launches per layer on ONE stream instead of 2 x 10 on two streams with a fork/join per layer (the cross-stream
+        8 launches per layer on ONE stream instead of 2 x 10 on two streams with a fork/join per layer (the cross-stream
         dependencies cost ~8 us of idle GPU each).  Same kernels, same arithmetic per side as `decoder`."""
         cfg, w = self.cfg, self.w
         E, D, Hh = cfg.enc_dim, cfg.dec_dim, cfg.dec_heads
@@ -444,23 +444,25 @@ class Engine:
                 ops.gemm(A, w[g + pre + ".w"], xo, M=R, N=D, K=K, lda=K, ldc=D, bias=w[g + pre + ".b"], res1=res, ldr1=D,
                          stats_out=stats, c2=c2, batch=2, strideA=A.stride, strideW=w[g + pre + ".w"].stride, strideC=R * D, sb=sb)
 
-            # self attention (croco/models/blocks.py:187), norm1 folded into the qkv GEMM
-            ops.proj_rope_vt(xp[cur], w[g + "qkv.w"], w[g + "qkv.b"], qkp, 0, vtp, npad, M=R, N=3 * D, K=D, lda=D, rope_cols=2 * D,
-                             ln=ops.LnFold(st[cur], D, w[g + "qkv.s"], 1e-6, sb_stats=sb_st, sb_s=3 * D * 4),
-                             strideA=xp[cur].stride, strideW=w[g + "qkv.w"].stride, strideC=B * npad * 2 * D,
-                             sb={"bias": 3 * D * 4, "vt": sb_vt}, **rope)
+            # self attention (croco/models/blocks.py:187), norm1 folded into the qkv GEMM -- and, in the same launch, the
+            # cross attention's k/v projection (:188-189; norm_y folded): both read only the previous layer's tokens.
+            # Problem z of the k/v group reads side 1-z -> start at side 1 and step backwards.
+            with ops.pair():
+                ops.proj_rope_vt(xp[cur], w[g + "qkv.w"], w[g + "qkv.b"], qkp, 0, vtp, npad, M=R, N=3 * D, K=D, lda=D, rope_cols=2 * D,
+                                 ln=ops.LnFold(st[cur], D, w[g + "qkv.s"], 1e-6, sb_stats=sb_st, sb_s=3 * D * 4),
+                                 strideA=xp[cur].stride, strideW=w[g + "qkv.w"].stride, strideC=B * npad * 2 * D,
+                                 sb={"bias": 3 * D * 4, "vt": sb_vt}, **rope)
+                ops.proj_rope_vt(xp[cur].at(1), w[g + "ckv.w"], w[g + "ckv.b"], ckp, 0, cvtp, npad, M=R, N=2 * D, K=D, lda=D, rope_cols=D,
+                                 ln=ops.LnFold(st[cur][1], D, w[g + "ckv.s"], 1e-6, sb_stats=-sb_st, sb_s=2 * D * 4),
+                                 strideA=-xp[cur].stride, strideW=w[g + "ckv.w"].stride, strideC=B * npad * D,
+                                 sb={"bias": 2 * D * 4, "vt": sb_vt}, **rope)
             ops.attention_packed(qkp, 2 * D, 0, npad, qkp, 2 * D, D, npad, vtp, ao, D, B=2 * B, heads=Hh, Nq=P, Nk=P,
                                  scale=64 ** -0.5, o_group=B, o_group_rows=Rp)
             upd(ao, D, "proj", xi, stq, xq)
-            # cross attention (:188-189): q from this side (norm2), k/v from the OTHER side's previous layer (norm_y):
-            # problem z reads side 1-z -> start at side 1 and step backwards
+            # cross attention (:188-189): q from this side (norm2); k/v of the OTHER side's previous layer were projected above
             ops.proj_rope_vt(xq, w[g + "cq.w"], w[g + "cq.b"], cqp, 0, None, npad, M=R, N=D, K=D, lda=D, rope_cols=D,
                              ln=ops.LnFold(stq, D, w[g + "cq.s"], 1e-6, sb_stats=sb_st, sb_s=D * 4),
                              strideA=xq.stride, strideW=w[g + "cq.w"].stride, strideC=B * npad * D, sb={"bias": D * 4}, **rope)
-            ops.proj_rope_vt(xp[cur].at(1), w[g + "ckv.w"], w[g + "ckv.b"], ckp, 0, cvtp, npad, M=R, N=2 * D, K=D, lda=D, rope_cols=D,
-                             ln=ops.LnFold(st[cur][1], D, w[g + "ckv.s"], 1e-6, sb_stats=-sb_st, sb_s=2 * D * 4),
-                             strideA=-xp[cur].stride, strideW=w[g + "ckv.w"].stride, strideC=B * npad * D,
-                             sb={"bias": 2 * D * 4, "vt": sb_vt}, **rope)
             ops.attention_packed(cqp, D, 0, npad, ckp, D, 0, npad, cvtp, ao, D, B=2 * B, heads=Hh, Nq=P, Nk=P,
                                  scale=64 ** -0.5, o_group=B, o_group_rows=Rp)
             upd(ao, D, "cproj", xo, stq, xq)

@@ -101,7 +101,7 @@ def set_profiler(p):
     _prof = p
 
 
-_TILE_NAMES = {0: "32x32xk4", 1: "64x64", 2: "64x128", 3: "64x64xk4", 5: "128x128lds", 6: "128x64lds", 7: "112x64lds",
+_TILE_NAMES = {0: "32x32xk4", 1: "64x64", 2: "64x128", 3: "64x64xk4", 4: "32x64xk4", 18: "16x64xk4", 5: "128x128lds", 6: "128x64lds", 7: "112x64lds",
                8: "208x64lds", 9: "112x32lds", 10: "112x64lds2w", 11: "112x64lds8w", 12: "208x64lds8w", 13: "112x64wreg8",
                14: "112x64wreg4", 15: "208x64wreg8", 16: "112x64wreg4l6", 17: "112x64wreg8l4"}
 
@@ -126,7 +126,63 @@ def pick_tile(M, N, batch=1, splitk=1, conv=False, K=0, packed_bf16=False, plain
     return 0
 
 
+_pair = None
+
+
+class pair:
+    """`with ops.pair():` -- the two GEMM launches issued inside go out as ONE launch (sp3_gemm2: two differently shaped
+    groups of problems that depend on the same inputs; same dtypes / loader; the second runs on the first one's tile)."""
+
+    def __enter__(self):
+        global _pair
+        assert _pair is None
+        _pair = []
+        return self
+
+    def __exit__(self, et, ev, tb):
+        global _pair
+        descs, _pair = _pair, None
+        if et is not None:
+            return False
+        if len(descs) != 2:
+            raise RuntimeError("ops.pair(): expected exactly two GEMM launches, got %d" % len(descs))
+        (a, na), (b, _) = descs
+        if a.tile < 0:
+            _pick(a)
+        if b.tile < 0:
+            b.tile = a.tile
+        if _prof is None:
+            L.check(L.load().sp3_gemm2(C.byref(a), C.byref(b), L.stream_ptr()), "sp3_gemm2")
+            return False
+        e0 = _prof.begin()
+        L.check(L.load().sp3_gemm2(C.byref(a), C.byref(b), L.stream_ptr()), "sp3_gemm2")
+        fl, by = 0.0, 0.0
+        for d in (a, b):
+            f, n = _gemm_cost(d)
+            fl, by = fl + f, by + n
+        _prof.end("gemm2<A%s,W%s,%s,%s>" % ("bf16" if a.a_bf16 else "f32", "f32" if a.wdtype == F32 else "bf16", na, _TILE_NAMES[a.tile]), e0, fl, by)
+        return False
+
+
+def _pick(d):
+    d.tile = pick_tile(d.M, d.N, max(d.batch, 1), max(d.splitk, 1), d.loader == L.LOAD_CONV3X3, d.K,
+                       bool(d.a_packed and d.w_packed and d.a_bf16 and not d.A2 and d.epi != L.EPI_PARTIAL
+                            and not d.sm_stats_out),
+                       d.epi == L.EPI_PLAIN, d.ln_nt if d.ln_stats else 0)
+
+
+def _gemm_cost(d):
+    b = max(d.batch, 1)
+    wsz = 4 if d.wdtype == F32 else 2
+    asz, csz = (2 if d.a_bf16 else 4), (2 if d.out_bf16 else 4)
+    a_elems = d.M * d.K if d.loader != L.LOAD_CONV3X3 else d.M * d.conv_stride * d.conv_stride * d.conv_C   # conv: the map, once
+    return 2.0 * d.M * d.N * d.K * b, b * (asz * a_elems + wsz * d.N * d.K + csz * d.M * d.N)      # algorithmic: every operand once
+
+
 def _gemm_launch(d, what, loader_name):
+    if _pair is not None:
+        _pair.append((d, loader_name))
+        return
     if d.loader == L.LOAD_SOFTMAX:
         d.tile = 1 if d.tile == 1 else 0
     if d.tile < 0:

@@ -717,6 +717,36 @@ def test_two_launch_memory_read(wdt, rows, M, thresh):
     assert torch.equal(c[:M], torch.arange(M).float() + 1) and float(c[M:M + Pn].abs().max()) == 0 and torch.equal(c[M + Pn:], torch.arange(M + Pn, cap).float())
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_paired_launch_equals_two_launches(dt):
+    """sp3_gemm2: two differently shaped groups of problems in one launch == the two launches, bit for bit"""
+    ops = _ops()
+    M, K = 196, 768
+    A = ops.PackedAct.group(2, M, K, dt, DEV)
+    A.data.copy_(rnd(*A.data.shape, seed=1).to(DEV).to(dt))
+    outs = {}
+    for mode in ("two", "pair"):
+        res = []
+        ctx = ops.pair() if mode == "pair" else None
+        if ctx:
+            ctx.__enter__()
+        for j, N in enumerate((2304, 1536)):
+            Ws = ops.PackedWeightGroup([ops.PackedWeight((rnd(N, K, seed=10 * j + z) * 0.05).to(DEV).to(dt)) for z in range(2)])
+            bias = rnd(2, N, seed=5 + j).to(DEV)
+            out = torch.zeros(2, M, N, device=DEV)
+            ops.gemm(A, Ws, out, M=M, N=N, K=K, lda=K, ldc=N, bias=bias, batch=2, strideA=A.stride, strideW=Ws.stride,
+                     strideC=M * N, sb={"bias": N * 4}, act=ops.ACT_GELU if j else ops.ACT_NONE)
+            res.append(out)
+        if ctx:
+            ctx.__exit__(None, None, None)
+        outs[mode] = res
+    for a, b in zip(outs["two"], outs["pair"]):
+        assert torch.equal(a, b) and float(a.abs().max()) > 0
+    with pytest.raises(RuntimeError):
+        with ops.pair():
+            pass
+
+
 def test_cos_sim_append_prune_gather():
     ops = _ops()
     T, P, C = 3, 50, 1024

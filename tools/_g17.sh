@@ -1,11 +1,12 @@
 mkdir -p gpurun_out/r2q
-timeout 600 python -m pytest tests/test_ops_gpu.py -x -q -m gpu -k "two_launch" > gpurun_out/r2q/ops.log 2>&1
+timeout 600 python -m pytest tests/test_ops_gpu.py -x -q -m gpu -k "paired or two_launch" > gpurun_out/r2q/ops.log 2>&1
 tail -5 gpurun_out/r2q/ops.log
 timeout 1500 python -m pytest tests/test_model_gpu.py -x -q -m gpu > gpurun_out/r2q/model.log 2>&1
-tail -8 gpurun_out/r2q/model.log
+tail -4 gpurun_out/r2q/model.log
 timeout 600 python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-extras > gpurun_out/r2q/bench.log 2>&1
 tail -1 gpurun_out/r2q/bench.log | python -c "
 import sys,json
 d=json.loads(sys.stdin.readline())
-print(d['value']); print(json.dumps(d['memread'])[:900])
+print(d['value']); 
+for k in d['kernel_breakdown']: print(k)
 "

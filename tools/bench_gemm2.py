@@ -83,7 +83,7 @@ for name, M, N, K, G in shapes:
     part = torch.empty(8 * G * M * N, device=dev)
     for tile in tiles:
         BN = {0: 32, 9: 32}.get(tile, 64)
-        BM = {0: 32, 8: 208, 12: 208, 15: 208, 5: 128, 6: 128, 1: 64, 2: 64}.get(tile, 112)
+        BM = {0: 32, 4: 32, 18: 16, 8: 208, 12: 208, 15: 208, 5: 128, 6: 128, 1: 64, 2: 64}.get(tile, 112)
         wgs = ((M + BM - 1) // BM) * ((N + BN - 1) // BN) * G
         sks = [0]
         if not args.big and tile != 0 and G == 1:
