@@ -871,6 +871,23 @@ void gemm_kernel(const GemmArgs args) {
   }
 
   if (tr0) { asm volatile("" ::"v"(acc[0][0][0])); tr0[1] = clock64(); }
+  // Residual rows of the generic epilogue's FIRST iteration (the only one of the 32x32 tile: BM * BN / 4 == NT), requested
+  // before the accumulators meet in LDS: the stream x was written launches ago by other XCDs, so loaded inside the
+  // epilogue loop it is an exposed miss (~1400 clk) after the last MFMA.
+  float4 pre_r1 = make_float4(0.f, 0.f, 0.f, 0.f), pre_r2 = pre_r1;
+  bool pre_res = false;
+  if constexpr (!LDSK) {
+    const bool al = ((reinterpret_cast<uintptr_t>(d.res1) | reinterpret_cast<uintptr_t>(d.res2)) & 15) == 0 && ((d.ldr1 | d.ldr2) & 3) == 0;
+    if ((d.res1 || d.res2) && al && d.epi == SP3_EPI_PLAIN && (d.N & 3) == 0 && tid < BM * (BN / 4)) {
+      const int prow = tid / (BN / 4);
+      const int pgm = m0 + prow, pgn = n0 + ec4;
+      if (pgm < d.M && pgn < d.N) {
+        pre_res = true;
+        if (d.res1) pre_r1 = *reinterpret_cast<const float4*>(d.res1 + ((int64_t)bz * d.M + pgm) * d.ldr1 + pgn);
+        if (d.res2) pre_r2 = *reinterpret_cast<const float4*>(d.res2 + ((int64_t)bz * d.M + pgm) * d.ldr2 + pgn);
+      }
+    }
+  }
   // ---- accumulators -> LDS (C layout: col = lane&15, row = 4*(lane>>4) + reg)
   if (LOOP < 2 || wave < NCW) {
     float* slab = smem + (size_t)wk * BM * LDS_LD;
@@ -1233,15 +1250,19 @@ void gemm_kernel(const GemmArgs args) {
     } else {
       off = (int64_t)bz * d.strideC + (int64_t)gm * d.ldc + gn;
     }
-    if (d.res1) {
-      const float* r = d.res1 + ((int64_t)bz * d.M + gm) * d.ldr1 + gn;
+    if (pre_res && idx == tid) {                         // requested before the reduction (same row / column group)
+      v[0] += pre_r1.x + pre_r2.x; v[1] += pre_r1.y + pre_r2.y; v[2] += pre_r1.z + pre_r2.z; v[3] += pre_r1.w + pre_r2.w;
+    } else {
+      if (d.res1) {
+        const float* r = d.res1 + ((int64_t)bz * d.M + gm) * d.ldr1 + gn;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) if (e < nvalid) v[e] += r[e];
-    }
-    if (d.res2) {
-      const float* r = d.res2 + ((int64_t)bz * d.M + gm) * d.ldr2 + gn;
+        for (int e = 0; e < 4; ++e) if (e < nvalid) v[e] += r[e];
+      }
+      if (d.res2) {
+        const float* r = d.res2 + ((int64_t)bz * d.M + gm) * d.ldr2 + gn;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) if (e < nvalid) v[e] += r[e];
+        for (int e = 0; e < 4; ++e) if (e < nvalid) v[e] += r[e];
+      }
     }
     if (d.sm_stats_out) {
       // per-32-column (max, sum exp(x - max)) of the finished scores: 8 consecutive lanes share a row group
