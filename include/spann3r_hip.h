@@ -330,6 +330,22 @@ int sp3_preprocess_image(const uint8_t* src, int64_t src_row_stride, int crop_l,
                          const int32_t* vbounds, const int32_t* vcoef, int vksize, int H2,
                          int crop2_l, int crop2_t, int outW, int outH, int transpose, uint8_t* tmp, float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Training criterion: ConfLoss_t(Regr3D_t(L21, norm_mode='avg_dis', fix_first), alpha).compute_frame_loss
+ * (spann3r/loss.py:20-84,129-285; dust3r/losses.py:52-56) forward and backward on stacked buffers:
+ *   P [E, B, HW, 3] predicted pointmaps and Cf [E, B, HW] confidences, one slab per loss entry in the reference's order
+ *   L0, L1, R1, L2, R2, ..., R_{n-1} (E = 2 (n-1); L_i = preds_all[i][0], R_i = preds_all[i-1][1]);
+ *   G [n, B, HW, 3] ground-truth points (world), V [n, B, HW] validity (bytes), pose0 [B, 16] camera pose of view 1 (affine).
+ * forward: out7 (device) = factor loss, loss, conf_loss_1, conf_loss2, conf_mean, pts3d_1, pts3d_2 (the reference's details);
+ *   ent_out (device, nullable) [E, 2] = (mean error, conf loss) per entry; ws = device scratch of sp3_conf_loss_ws_bytes(n, B)
+ *   bytes that the backward reads.  backward: dP, dC = gradients of grad_scale2[0] * loss + grad_scale2[1] * factor loss
+ *   (grad_scale2: 2 floats on the device).  Sums in double, fixed order: deterministic. */
+int64_t sp3_conf_loss_ws_bytes(int n, int B);
+int sp3_conf_loss_forward(const float* P, const float* Cf, const float* G, const uint8_t* V, const float* pose0, int n, int B, int HW,
+                          float alpha, int fix_first, void* ws, float* out7, float* ent_out, void* stream);
+int sp3_conf_loss_backward(const float* P, const float* Cf, const float* G, const uint8_t* V, const float* pose0, int n, int B, int HW,
+                           float alpha, int fix_first, const void* ws, const float* grad_scale2, float* dP, float* dC, void* stream);
+
 /* small utilities */
 int sp3_copy2d_f32(const float* src, int64_t lds, float* dst, int64_t ldd, int rows, int cols, void* stream);
 int sp3_fill_f32(float* p, float v, int64_t n, void* stream);

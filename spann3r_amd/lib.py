@@ -117,11 +117,15 @@ _PROTOS = {
     "sp3_cast_f32_to_bf16": [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
     "sp3_copy2d_f32": [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p],
     "sp3_spin": [C.c_int64, C.c_void_p, C.c_void_p],
+    "sp3_conf_loss_forward": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
+                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    "sp3_conf_loss_backward": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
+                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "sp3_preprocess_image": [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                              C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                              C.c_void_p, C.c_void_p],
 }
-EXPORTS = sorted(list(_PROTOS) + ["sp3_last_error", "sp3_version"])
+EXPORTS = sorted(list(_PROTOS) + ["sp3_last_error", "sp3_version", "sp3_conf_loss_ws_bytes"])
 
 
 def load():
@@ -136,6 +140,8 @@ def load():
     lib.sp3_last_error.restype = C.c_char_p
     lib.sp3_last_error.argtypes = []
     lib.sp3_version.restype = C.c_int
+    lib.sp3_conf_loss_ws_bytes.restype = C.c_int64
+    lib.sp3_conf_loss_ws_bytes.argtypes = [C.c_int, C.c_int]
     for name, argtypes in _PROTOS.items():
         fn = getattr(lib, name)
         fn.restype = C.c_int

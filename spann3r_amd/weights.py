@@ -240,3 +240,28 @@ def synth_frames(n_frames: int, h: int, w: int, batch: int = 1, seed: int = 1000
         base = 0.9 * sx * (1.0 - sx * sx) * (1.0 - 0.75 * yy * yy) + 0.1 * yy
         frames.append({"img": (0.6 * img + base).clamp(-1, 1).contiguous()})
     return frames
+
+
+def synth_loss_case(seed, n=4, B=2, H=24, W=32):
+    """Seeded inputs of the training criterion: gts (pts3d, valid_mask, camera_pose) and preds_all shaped like
+    Spann3R.forward's (res1 has 'pts3d' for the first pair, 'pts3d_in_other_view' afterwards; res2 always the latter)."""
+    g = torch.Generator().manual_seed(seed)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    gts, preds_all = [], []
+    for i in range(n):
+        A = rn(B, 3, 3)
+        Q, _ = torch.linalg.qr(A)
+        pose = torch.eye(4).repeat(B, 1, 1)
+        pose[:, :3, :3] = Q
+        pose[:, :3, 3] = rn(B, 3) * 0.5
+        pts = rn(B, H, W, 3) * 1.5 + torch.tensor([0.0, 0.0, 3.0])
+        valid = torch.rand(B, H, W, generator=g) < 0.8
+        if i == 1:
+            valid[0, :5] = False
+        gts.append(dict(pts3d=pts, valid_mask=valid, camera_pose=pose))
+    for i in range(n - 1):
+        r1 = {("pts3d" if i == 0 else "pts3d_in_other_view"): rn(B, H, W, 3) * 1.2 + torch.tensor([0.0, 0.0, 2.5]),
+              "conf": 1 + torch.exp(rn(B, H, W) * 0.7)}
+        r2 = {"pts3d_in_other_view": rn(B, H, W, 3) * 1.2 + torch.tensor([0.0, 0.0, 2.5]), "conf": 1 + torch.exp(rn(B, H, W) * 0.7)}
+        preds_all.append((r1, r2))
+    return gts, preds_all

@@ -316,8 +316,44 @@ def make_memory():
     print("memory: events\n", np.array(events))
 
 
+def make_loss():
+    """spann3r/loss.py ConfLoss_t(Regr3D_t(L21, norm_mode='avg_dis', fix_first=...), alpha) on seeded inputs: loss, details,
+    factor loss and the autograd gradients of (loss + factor loss) w.r.t. every predicted pointmap / confidence."""
+    from spann3r.loss import Regr3D_t, ConfLoss_t
+    from dust3r.losses import L21
+    from spann3r_amd.weights import synth_loss_case
+    out = {}
+    for tag, seed, fix_first, alpha, scale in (("a", 11, False, 0.4, 1.0), ("b", 12, True, 1.0, 1.0), ("c", 13, False, 0.4, 3.0)):
+        gts, preds_all = synth_loss_case(seed)
+        leaves = []
+        for r1, r2 in preds_all:
+            for r in (r1, r2):
+                for k in r:
+                    if scale != 1.0 and k != "conf":
+                        r[k] = r[k] * scale                   # predictions larger than the ground truth: factor loss active
+                    r[k].requires_grad_(True)
+                    leaves.append(r[k])
+        crit = ConfLoss_t(Regr3D_t(L21, norm_mode="avg_dis", fix_first=fix_first), alpha=alpha)
+        loss, details, factor = crit.compute_frame_loss(gts, preds_all)
+        total = loss + factor
+        total.backward()
+        out[tag + "_meta"] = np.array([seed, int(fix_first)], np.int64)
+        out[tag + "_alpha"] = np.float32(alpha)
+        out[tag + "_scale"] = np.float32(scale)
+        out[tag + "_loss"] = npf(loss)
+        out[tag + "_factor"] = np.float32(float(factor))
+        for k, v in details.items():
+            out[tag + "_detail_" + k] = np.float32(float(v))
+        for j, t in enumerate(leaves):
+            out[tag + "_grad%d" % j] = npf(t.grad)
+        print("loss", tag, float(loss), float(factor), {k: round(float(v), 5) for k, v in details.items()})
+    np.savez_compressed(os.path.join(HERE, "loss_conf.npz"), **out)
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["tiny", "full", "memory"]
+    if "loss" in what:
+        make_loss()
     if "tiny" in what:
         make_tiny()
     if "memory" in what:
