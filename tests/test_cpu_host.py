@@ -198,6 +198,55 @@ def test_two_rank_sharding_and_stats_gather():
     assert shard(8, 3, 8) == [3] and shard(10, 1, 4) == [1, 5, 9]
 
 
+GRAD_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(repo)r)
+import torch, torch.distributed as dist
+from spann3r_amd.runner import GradReducer
+dist.init_process_group(backend="gloo", init_method="env://")
+rank, world = dist.get_rank(), dist.get_world_size()
+torch.manual_seed(0)
+params = [torch.nn.Parameter(torch.zeros(s)) for s in ((300, 7), (5,), (64, 64), (1000,), (3, 3))]
+frozen = torch.nn.Parameter(torch.zeros(4), requires_grad=False)
+g = torch.Generator().manual_seed(100 + rank)
+for i, p in enumerate(params):
+    if not (rank == 1 and i == 1):                       # an unused parameter on one rank: contributes zeros
+        p.grad = torch.randn(p.shape, generator=g)
+mine = [None if p.grad is None else p.grad.clone() for p in params]
+red = GradReducer(params + [frozen], bucket_mb=0.01)     # ~2600 floats per bucket -> several buckets
+assert len(red.buckets) >= 3 and red.buckets[0][0] is params[-1]
+red.start(); red.finish()
+# reference: gather every rank's gradients and average
+for i, p in enumerate(params):
+    loc = mine[i] if mine[i] is not None else torch.zeros(p.shape)
+    allg = [torch.zeros_like(loc) for _ in range(world)]
+    dist.all_gather(allg, loc)
+    assert torch.allclose(p.grad, sum(allg) / world, atol=1e-7), i
+assert frozen.grad is None
+if rank == 0:
+    print("OK grads")
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_gradient_reducer():
+    """bucketed all-reduce averaging (DDP-equivalent, training.py:322-325) over gloo, world size 2"""
+    with tempfile.TemporaryDirectory() as d:
+        script = os.path.join(d, "g.py")
+        open(script, "w").write(GRAD_WORKER % {"repo": REPO})
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29579", WORLD_SIZE="2")
+        procs = [subprocess.Popen([sys.executable, script], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                                  stderr=subprocess.STDOUT) for r in range(2)]
+        outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+        assert all(p.returncode == 0 for p in procs), outs
+        assert "OK grads" in outs[0]
+    from spann3r_amd.runner import GradReducer
+    p = torch.nn.Parameter(torch.ones(3))
+    p.grad = torch.full((3,), 2.0)
+    GradReducer([p]).reduce()                            # no process group: a no-op
+    assert torch.equal(p.grad, torch.full((3,), 2.0))
+
+
 @pytest.mark.skipif(not os.path.isdir("/root/reference/croco/models"), reason="needs the reference checkout (build container only)")
 def test_curope_shim_is_selected_by_unmodified_reference():
     """shims/curope satisfies the reference's only native FFI: with it on sys.path the UNMODIFIED
