@@ -346,6 +346,22 @@ int sp3_conf_loss_forward(const float* P, const float* Cf, const float* G, const
 int sp3_conf_loss_backward(const float* P, const float* Cf, const float* G, const uint8_t* V, const float* pose0, int n, int B, int HW,
                            float alpha, int fix_first, const void* ws, const float* grad_scale2, float* dP, float* dC, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Pieces of the BACKWARD of the spatial-memory read in its training form (attn_thresh = 0, mem_dropout; forward:
+ * spann3r/model.py:145-183), between the four sp3_gemm launches of spann3r_amd/train.py:
+ * sp3_transpose     : dst[c * ld_dst + r] = src[r * ld_src + c]  (sp3_gemm computes A[M,K] . W[N,K]^T only)
+ * sp3_mul           : out = a (.) b  (the dropout mask on the probabilities, :168)
+ * sp3_softmax_bwd   : dS = alpha * A (.) (dA - rowsum(dA (.) A)), dA = dAd (.) mask (mask nullable), rows x T, row stride ld
+ * sp3_layernorm_bwd : dx = LayerNorm backward of dy w.r.t. x (+ dx_add, nullable: the residual path), dgamma / dbeta [C]
+ *                     (accumulate != 0: added to their current contents); scratch: ceil(rows / 4) * 2 * C floats.  Column sums in a
+ *                     fixed order: deterministic. */
+int sp3_transpose(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int rows, int cols, void* stream);
+int sp3_mul(const float* a, const float* b, float* out, int64_t n, void* stream);
+int sp3_softmax_bwd(const float* A, const float* dAd, const float* mask, float* dS, int64_t ld, int rows, int T, float alpha, void* stream);
+int sp3_layernorm_bwd(const float* x, int64_t ldx, const float* gamma, const float* dy, int64_t ldy, const float* dx_add, int64_t ld_add,
+                      float* dx, int64_t ld_dx, float* dgamma, float* dbeta, int accumulate, float* scratch, int rows, int C, float eps,
+                      void* stream);
+
 /* small utilities */
 int sp3_copy2d_f32(const float* src, int64_t lds, float* dst, int64_t ldd, int rows, int cols, void* stream);
 int sp3_fill_f32(float* p, float v, int64_t n, void* stream);

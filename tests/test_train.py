@@ -1,0 +1,71 @@
+"""Backward through the memory fusion: the HIP forward / backward of the train-mode spatial-memory read
+against the CPU oracle in float64 with autograd; the oracle against the unmodified reference module."""
+import os
+
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import train_oracle as TO
+
+
+def _inputs(B, P, T, C, seed, dtype=torch.float32, device="cpu", p_drop=0.15):
+    g = torch.Generator().manual_seed(seed)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    t = dict(feat=rn(B, P, C), mem_k=rn(B, T, C) * 1.3 + 0.1, mem_v=rn(B, T, C) * 0.8 - 0.2)
+    for n in ("q", "k", "v"):
+        t["g" + n], t["b" + n] = 1.0 + 0.2 * rn(C), 0.1 * rn(C)
+    mask = (torch.rand(B, P, T, generator=g) >= p_drop).float() / (1.0 - p_drop)
+    dout = rn(B, P, C)
+    leaves = {k: v.to(dtype).to(device).requires_grad_(True) for k, v in t.items()}
+    return leaves, mask.to(dtype).to(device), dout.to(dtype).to(device)
+
+
+def _run(fn, leaves, mask, dout):
+    out = fn(leaves["feat"], leaves["mem_k"], leaves["mem_v"], (leaves["gq"], leaves["bq"]), (leaves["gk"], leaves["bk"]),
+             (leaves["gv"], leaves["bv"]), mask)
+    out.backward(dout)
+    return out.detach(), {k: v.grad for k, v in leaves.items()}
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/spann3r"), reason="needs the reference checkout (build container only)")
+def test_oracle_matches_reference_memory_read():
+    import sys
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, "/root/reference")
+    try:
+        from spann3r.model import SpatialMemory
+    finally:
+        sys.path.remove("/root/reference")
+    B, P, T, C = 2, 24, 72, 64
+    leaves, _, dout = _inputs(B, P, T, C, seed=3)
+    norms = [torch.nn.LayerNorm(C, eps=1e-5) for _ in range(3)]
+    for m, n in zip(norms, "qkv"):
+        m.weight.data.copy_(leaves["g" + n].detach()); m.bias.data.copy_(leaves["b" + n].detach())
+    sp = SpatialMemory(*norms, mem_dropout=None, attn_thresh=0)
+    sp.add_mem(leaves["mem_k"].detach()[:, :P], leaves["mem_v"].detach()[:, :P])
+    sp.add_mem(leaves["mem_k"].detach()[:, P:], leaves["mem_v"].detach()[:, P:])
+    ref = sp.memory_read(leaves["feat"].detach(), res=True)
+    got = TO.memory_read_train(leaves["feat"], leaves["mem_k"], leaves["mem_v"], (leaves["gq"], leaves["bq"]), (leaves["gk"], leaves["bk"]),
+                               (leaves["gv"], leaves["bv"]), None)
+    assert rel_err(got.detach(), ref.detach()) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,P,T,C,drop", [(1, 196, 588, 1024, True), (2, 50, 150, 256, True), (1, 37, 111, 128, False)])
+def test_memory_read_train_forward_backward(B, P, T, C, drop):
+    from spann3r_amd.train import memory_read_train
+    leaves, mask, dout = _inputs(B, P, T, C, seed=P, device="cuda")
+    out, grads = _run(memory_read_train, leaves, mask if drop else None, dout)
+    l64, m64, d64 = _inputs(B, P, T, C, seed=P, dtype=torch.float64)
+    ref, gref = _run(TO.memory_read_train, l64, m64 if drop else None, d64)
+    assert rel_err(out.cpu(), ref) < 1e-5
+    for k in grads:
+        if k == "bk":        # softmax is invariant to a shift of every score of a row: d out / d beta_k == 0 exactly
+            assert float(gref[k].abs().max()) < 1e-12 and float(grads[k].abs().max()) < 1e-5 * float(grads["gk"].abs().max())
+            continue
+        assert rel_err(grads[k].cpu(), gref[k]) < 2e-4, (k, rel_err(grads[k].cpu(), gref[k]))
+    # deterministic: a second run gives the same bits
+    leaves2, _, _ = _inputs(B, P, T, C, seed=P, device="cuda")
+    out2, grads2 = _run(memory_read_train, leaves2, mask if drop else None, dout)
+    assert torch.equal(out, out2) and all(torch.equal(grads[k], grads2[k]) for k in grads)
