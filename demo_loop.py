@@ -21,6 +21,9 @@ def main():
     ap.add_argument("--demo_path", default=None, help="folder of images (demo.py --demo_path): decoded with PIL on the host, "
                     "then cropped / Lanczos-resized / normalised on the GPU (spann3r_amd.preprocess)")
     ap.add_argument("--kf_every", type=int, default=10)
+    ap.add_argument("--save_ply", default=None, help="write the confidence-filtered cloud here (demo.py:205-212) and print the "
+                    "estimated focal of the first camera (demo.py:147-151)")
+    ap.add_argument("--conf_thresh", type=float, default=1e-3)
     ap.add_argument("--offline", action="store_true", help="demo.py --offline: DUSt3R pair graph + next-best-view order")
     args = ap.parse_args()
     cfg = TINY if args.tiny else FULL
@@ -60,6 +63,19 @@ def main():
         print("Time: %.4f s, FPS: %.1f  (%d frames, call %d: %s)" %
               (end - start, len(batch) / (end - start), len(batch), it,
                ["eager warm-up", "hipGraph capture", "hipGraph replay"][min(it, 2)]))
+    if args.save_ply:
+        from spann3r_amd.postprocess import estimate_focal_knowing_depth, confident_points, write_ply
+        _, H, W, _ = preds[0]["pts3d"].shape
+        focal = estimate_focal_knowing_depth(preds[0]["pts3d"], torch.tensor((W / 2, H / 2)), focal_mode="weiszfeld")
+        print("Estimated focal of first camera: %.3f (%dx%d)" % (focal.item(), W, H))
+        pts_all = torch.cat([p["pts3d" if j == 0 else "pts3d_in_other_view"] for j, p in enumerate(preds)])
+        conf_all = torch.cat([p["conf"] for p in preds])
+        images_all = (torch.cat([v["img"] for v in batch]).permute(0, 2, 3, 1) + 1.0) / 2.0
+        if images_all.shape[1:3] != pts_all.shape[1:3]:
+            images_all = images_all.swapaxes(1, 2)                                # portrait frames were rectified to landscape
+        points, colours = confident_points(pts_all, conf_all, args.conf_thresh, images_all)
+        write_ply(args.save_ply, points, colours)
+        print("wrote %d of %d points to %s" % (len(points), conf_all.numel(), args.save_ply))
     pts = preds[-1]["pts3d_in_other_view"]
     print("last frame: pts3d_in_other_view", tuple(pts.shape), "conf mean %.3f" % float(preds[-1]["conf"].mean()))
 

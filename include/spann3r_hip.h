@@ -362,6 +362,19 @@ int sp3_layernorm_bwd(const float* x, int64_t ldx, const float* gamma, const flo
                       float* dx, int64_t ld_dx, float* dgamma, float* dbeta, int accumulate, float* scratch, int rows, int C, float eps,
                       void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Post-forward geometry (demo.py:147-215).
+ * sp3_focal_weiszfeld : estimate_focal_knowing_depth(pts3d, pp, focal_mode='weiszfeld') (dust3r/post_process.py:38-60):
+ *   pts3d fp32 [B, H, W, 3], principal point (ppx, ppy); closed-form L2 start, `iters` (reference: 10) rounds of inverse-distance
+ *   re-weighting, clipped to [focal_min, focal_max] (already multiplied by the reference's focal_base); focal [B] on the device.
+ * sp3_conf_filter : the confident part of a cloud, pixel order kept (demo.py:205-211: conf_sig = (conf - 1) / conf > thresh,
+ *   boolean indexing of points and colours): conf [n], pts / rgb [n, 3] (rgb nullable) -> out_pts / out_rgb [total, 3];
+ *   scratch: ceil(n / 1024) ints; total: device int64. */
+int sp3_focal_weiszfeld(const float* pts3d, int B, int H, int W, float ppx, float ppy, int iters, float focal_min, float focal_max,
+                        float* focal, void* stream);
+int sp3_conf_filter(const float* conf, const float* pts, const float* rgb, int64_t n, float thresh, int* scratch, int64_t* total,
+                    float* out_pts, float* out_rgb, void* stream);
+
 /* small utilities */
 int sp3_copy2d_f32(const float* src, int64_t lds, float* dst, int64_t ldd, int rows, int cols, void* stream);
 int sp3_fill_f32(float* p, float v, int64_t n, void* stream);

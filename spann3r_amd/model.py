@@ -573,12 +573,18 @@ class _SequenceRunner:
             dec1, dec2 = eng.decoder_grouped(f1, self.feat2, B, self.nh, self.nw)
             self.k2_aux = eng.encode_feat_keys_grouped(self.feat1, self.feat2, dec1[-1], dec2[-1], B * P, self.k1, self.k2)
         else:
-            dec1, dec2 = eng.decoder(f1, self.feat2, B, self.nh, self.nw, self.nh, self.nw, streams=st)   # joined on return
-            st[2].wait_stream(main)
-            with torch.cuda.stream(st[2]):
+            if self.model.decoder_streams:
+                dec1, dec2 = eng.decoder(f1, self.feat2, B, self.nh, self.nw, self.nh, self.nw, streams=st)   # joined on return
+                st[2].wait_stream(main)
+                with torch.cuda.stream(st[2]):
+                    self.k2_aux = eng.encode_feat_key(self.feat2, dec2[-1], B * P, 2, self.k2, aux=True)
+                eng.encode_feat_key(self.feat1, dec1[-1], B * P, 1, self.k1)
+                main.wait_stream(st[2])
+            else:
+                # one stream, side after side: a graph fork/join pair costs more than the overlap of two 196-row launches buys
+                dec1, dec2 = eng.decoder(f1, self.feat2, B, self.nh, self.nw, self.nh, self.nw, streams=None)
                 self.k2_aux = eng.encode_feat_key(self.feat2, dec2[-1], B * P, 2, self.k2, aux=True)
-            eng.encode_feat_key(self.feat1, dec1[-1], B * P, 1, self.k1)
-            main.wait_stream(st[2])
+                eng.encode_feat_key(self.feat1, dec1[-1], B * P, 1, self.k1)
         if not self.training and mem.sim_needed():
             mem.sim_scores(self.k1)
         if has_next:
@@ -698,6 +704,7 @@ class Spann3R(nn.Module):
         self.batch_encode = True     # forward(): encode all frames of the sequence together (False: frame by frame)
         self.defer_head2 = True      # with batch_encode: run the view-2 DPT head once for all steps after the loop
         self.grouped_decoder = True  # bf16: the two decoder sides as grouped launches on one stream (False: two streams)
+        self.decoder_streams = os.environ.get("SP3_DEC_STREAMS", "1") == "1"   # ungrouped decoder (fp32 mode): two streams with a fork/join per layer, or one stream
         self.force_general = False   # True: always take the reference-shaped eager loop (_forward_general; tests)
         self.max_runners = 4         # geometries (batch, H, W, policy, true_shape) kept with their buffers and graphs
 

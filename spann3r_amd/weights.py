@@ -265,3 +265,16 @@ def synth_loss_case(seed, n=4, B=2, H=24, W=32):
         r2 = {"pts3d_in_other_view": rn(B, H, W, 3) * 1.2 + torch.tensor([0.0, 0.0, 2.5]), "conf": 1 + torch.exp(rn(B, H, W) * 0.7)}
         preds_all.append((r1, r2))
     return gts, preds_all
+
+
+def synth_pointmaps(seed, B=2, H=48, W=64, focal=(55.0, 83.0)):
+    """pointmaps of pinhole cameras with known focals + noise, a few outliers, zeros and negative depths"""
+    g = torch.Generator().manual_seed(seed)
+    z = 1.0 + 3.0 * torch.rand(B, H, W, generator=g)
+    u, v = torch.meshgrid(torch.arange(W).float() - W / 2, torch.arange(H).float() - H / 2, indexing="xy")
+    f = torch.tensor(focal[:B]).view(B, 1, 1)
+    pts = torch.stack((u * z / f, v * z / f, z), -1) + 0.01 * torch.randn(B, H, W, 3, generator=g)
+    pts[0, 3, 5] = 0.0                       # 0/0 -> nan_to_num
+    pts[1, 7, 9, 2] = 0.0                    # x/0 -> inf -> 0
+    pts[:, ::7, ::5] *= torch.tensor([3.0, -2.0, 1.0])       # outliers
+    return pts

@@ -350,8 +350,25 @@ def make_loss():
     np.savez_compressed(os.path.join(HERE, "loss_conf.npz"), **out)
 
 
+def make_postprocess():
+    from dust3r.post_process import estimate_focal_knowing_depth
+    from spann3r_amd.weights import synth_pointmaps
+    out = {}
+    for tag, seed in (("a", 21), ("b", 22)):
+        pts = synth_pointmaps(seed)
+        _, H, W, _ = pts.shape
+        pp = torch.tensor((W / 2, H / 2))
+        out[tag + "_seed"] = np.int64(seed)
+        out[tag + "_focal"] = npf(estimate_focal_knowing_depth(pts, pp, focal_mode="weiszfeld"))
+        out[tag + "_focal_clip"] = npf(estimate_focal_knowing_depth(pts, pp, focal_mode="weiszfeld", min_focal=1.2, max_focal=1.3))
+        print("focal", tag, out[tag + "_focal"], out[tag + "_focal_clip"])
+    np.savez_compressed(os.path.join(HERE, "postprocess.npz"), **out)
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["tiny", "full", "memory"]
+    if "postprocess" in what:
+        make_postprocess()
     if "loss" in what:
         make_loss()
     if "tiny" in what:

@@ -1,0 +1,73 @@
+"""Post-forward geometry: focal estimation and confidence filtering.  CPU: the oracle against the dump of the
+unmodified reference function; GPU: the HIP kernels against the oracle / the dump; host writers round-trip."""
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+from oracle import postprocess_oracle as PO
+from spann3r_amd.weights import synth_pointmaps
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_focal_oracle_matches_reference_dump(tag):
+    g = load_golden("postprocess.npz")
+    pts = synth_pointmaps(int(g[tag + "_seed"])).numpy()
+    _, H, W, _ = pts.shape
+    assert rel_err(PO.focal_weiszfeld(pts, (W / 2, H / 2)), g[tag + "_focal"]) < 2e-5
+    assert rel_err(PO.focal_weiszfeld(pts, (W / 2, H / 2), min_focal=1.2, max_focal=1.3), g[tag + "_focal_clip"]) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_focal_kernel(tag):
+    from spann3r_amd.postprocess import estimate_focal_knowing_depth
+    g = load_golden("postprocess.npz")
+    pts = synth_pointmaps(int(g[tag + "_seed"]))
+    _, H, W, _ = pts.shape
+    pp = torch.tensor((W / 2, H / 2))
+    f = estimate_focal_knowing_depth(pts.cuda(), pp, focal_mode="weiszfeld")
+    assert f.is_cuda and rel_err(f.cpu(), g[tag + "_focal"]) < 2e-5
+    assert rel_err(f.cpu().double(), PO.focal_weiszfeld(pts.numpy(), (W / 2, H / 2))) < 2e-5
+    fc = estimate_focal_knowing_depth(pts.cuda(), pp, focal_mode="weiszfeld", min_focal=1.2, max_focal=1.3)
+    assert rel_err(fc.cpu(), g[tag + "_focal_clip"]) < 1e-6
+    with pytest.raises(NotImplementedError):
+        estimate_focal_knowing_depth(pts.cuda(), pp, focal_mode="median")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_frames,H,W,thresh", [(3, 48, 64, 1e-3), (5, 37, 53, 0.5), (1, 8, 8, 0.999)])
+def test_confident_points_kernel(n_frames, H, W, thresh):
+    from spann3r_amd.postprocess import confident_points
+    g = torch.Generator().manual_seed(H)
+    pts = torch.randn(n_frames, H, W, 3, generator=g)
+    rgb = torch.rand(n_frames, H, W, 3, generator=g)
+    conf = 1 + torch.exp(torch.randn(n_frames, H, W, generator=g) * 2)
+    p, c = confident_points(pts.cuda(), conf.cuda(), thresh, rgb.cuda())
+    rp, rc = PO.confident(pts.numpy(), conf.numpy(), thresh, rgb.numpy())
+    assert np.array_equal(p.cpu().numpy(), rp) and np.array_equal(c.cpu().numpy(), rc)        # same points, same order
+    p2, c2 = confident_points(pts.cuda(), conf.cuda(), thresh)
+    assert c2 is None and torch.equal(p2, p)
+
+
+def test_ply_and_transforms_writers(tmp_path):
+    from spann3r_amd.postprocess import write_ply, transforms_json, save_transforms
+    pts = np.arange(12, dtype=np.float32).reshape(4, 3) * 0.5
+    col = np.linspace(0, 1, 12).reshape(4, 3)
+    path = os.path.join(tmp_path, "c.ply")
+    write_ply(path, torch.from_numpy(pts), col)
+    raw = open(path, "rb").read()
+    head, body = raw.split(b"end_header\n")
+    assert b"element vertex 4" in head and b"property double x" in head and b"property uchar blue" in head and len(body) == 4 * 27
+    x, y, z, r, gg, b = struct.unpack("<dddBBB", body[27:54])
+    assert (x, y, z) == (1.5, 2.0, 2.5) and (r, gg, b) == tuple(int(round(v * 255)) for v in col[1])
+    poses = [np.eye(4), np.arange(16, dtype=np.float64).reshape(4, 4)]
+    d = transforms_json(224, 224, torch.tensor(100.0), poses, "c.ply")
+    assert d["fl_x"] == 100.0 and d["cx"] == 112 and d["frames"][1]["file_path"] == "imgs/img_0001.png"
+    assert d["frames"][1]["transform_matrix"][0] == [0.0, -1.0, -2.0, 3.0] and poses[1][0, 1] == -1.0      # flipped in place, as the reference
+    save_transforms(os.path.join(tmp_path, "transforms.json"), d)
+    assert json.load(open(os.path.join(tmp_path, "transforms.json")))["ply_file_path"] == "c.ply"
