@@ -376,6 +376,9 @@ int sp3_conf_filter(const float* conf, const float* pts, const float* rgb, int64
                     float* out_pts, float* out_rgb, void* stream);
 
 /* small utilities */
+/* n (1..8) contiguous device-to-device copies in one launch; every copy 16-byte aligned and a multiple of 16 bytes.
+ * (The sequence loop's per-frame bookkeeping -- torch .clone() / slice assignments around spann3r/model.py:523-531.) */
+int sp3_copy_multi(int n, const void* const* src, void* const* dst, const int64_t* bytes, void* stream);
 int sp3_copy2d_f32(const float* src, int64_t lds, float* dst, int64_t ldd, int rows, int cols, void* stream);
 int sp3_fill_f32(float* p, float v, int64_t n, void* stream);
 int sp3_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);

@@ -225,6 +225,17 @@ __global__ __launch_bounds__(256) void mem_append_kernel(float* __restrict__ cou
   else if (j < M + P) { count[j] = 0.f; attn[j] = 0.f; }
 }
 
+// up to 8 contiguous device-to-device copies in ONE launch (the per-frame bookkeeping of the sequence loop: decoder hook
+// outputs into their sequence slots, the frame's results into the caller's buffers, the next pair of encoder features)
+struct CopyMultiArgs { const char* src[8]; char* dst[8]; int64_t bytes[8]; };
+__global__ __launch_bounds__(256) void copy_multi_kernel(const CopyMultiArgs a) {
+  const int e = blockIdx.y;
+  const int64_t n16 = a.bytes[e] >> 4;
+  const uint4* s = reinterpret_cast<const uint4*>(a.src[e]);
+  uint4* d = reinterpret_cast<uint4*>(a.dst[e]);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) d[i] = s[i];
+}
+
 // Single-block bitonic sort of (weight, index): weight descending, index ascending on ties.
 constexpr int PRUNE_MAX = 16384;      // 4000 + 8 * P tokens for P up to 1536 (512x768); 128 KB of LDS
 __global__ __launch_bounds__(1024) void prune_select_kernel(const float* __restrict__ attn, const float* __restrict__ count,
@@ -568,6 +579,25 @@ extern "C" int sp3_cos_sim(const float* k, const float* wm, int T, int P, int C,
   hipLaunchKernelGGL(cos_pair_kernel, dim3((T * P + 3) / 4), dim3(256), 0, ST(stream), k, wm, T * P, P, C, scratch);
   hipLaunchKernelGGL(cos_mean_kernel, dim3(T), dim3(256), 0, ST(stream), scratch, P, score);
   SP3_LAUNCH_CHECK("sp3_cos_sim");
+  return 0;
+}
+
+extern "C" int sp3_copy_multi(int n, const void* const* src, void* const* dst, const int64_t* bytes, void* stream) {
+  SP3_CHECK(n >= 1 && n <= 8 && src && dst && bytes, "sp3_copy_multi: 1..8 copies");
+  CopyMultiArgs a;
+  int64_t mx = 0;
+  for (int i = 0; i < 8; ++i) {
+    const int j = i < n ? i : 0;
+    SP3_CHECK(src[j] && dst[j] && bytes[j] > 0 && bytes[j] % 16 == 0 &&
+              ((reinterpret_cast<uintptr_t>(src[j]) | reinterpret_cast<uintptr_t>(dst[j])) & 15) == 0,
+              "sp3_copy_multi: copy %d must be non-empty, 16-byte aligned and a multiple of 16 bytes", j);
+    a.src[i] = reinterpret_cast<const char*>(src[j]); a.dst[i] = reinterpret_cast<char*>(dst[j]); a.bytes[i] = bytes[j];
+    mx = bytes[j] > mx ? bytes[j] : mx;
+  }
+  int64_t bx = (mx / 16 + 256 * 4 - 1) / (256 * 4);           // ~4 vectors per thread for the largest copy
+  bx = bx < 1 ? 1 : (bx > 1024 ? 1024 : bx);
+  hipLaunchKernelGGL(copy_multi_kernel, dim3((unsigned)bx, n), dim3(256), 0, ST(stream), a);
+  SP3_LAUNCH_CHECK("sp3_copy_multi");
   return 0;
 }
 

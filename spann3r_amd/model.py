@@ -493,11 +493,11 @@ class _SequenceRunner:
             self.seen = {k for k in self.seen if k[0] != "head2"}
         self.defer2 = True
 
-    def save_dec2(self, i):
-        """after step i: keep the three decoder hook outputs of side 2 (hook 0 is the encoder feature, already in feats)"""
-        BP, D = self.B * self.P, self.model.cfg.dec_dim
-        for src, dst in zip(self.dec2_hooks, self.seq_dec2):
-            ops.copy2d(src, D, dst[i * BP:(i + 1) * BP], D, BP, D)
+    def dec2_copies(self, i):
+        """after step i: the three decoder hook outputs of side 2 go to their sequence slots (hook 0 is the encoder feature,
+        already in feats) -> (src, dst) pairs for the step's bookkeeping launch"""
+        BP = self.B * self.P
+        return [(src, dst[i * BP:(i + 1) * BP]) for src, dst in zip(self.dec2_hooks, self.seq_dec2)]
 
     def finish_head2(self, n_frames, use_graphs):
         """-> list of (pts2, conf2) per step, fresh tensors"""
@@ -523,10 +523,13 @@ class _SequenceRunner:
                 outs.append((pts[j * B:(j + 1) * B], conf[j * B:(j + 1) * B]))
         return outs
 
-    def load_pair(self, i):
+    def pair_copy(self, i):
         """featpair <- (feat of frame i, feat of frame i+1): two adjacent slabs of the sequence buffer, one copy"""
-        B, P, E = self.B, self.P, self.E
-        ops.copy2d(self.feats[i * B:(i + 2) * B], E, self.featpair, E, 2 * B * P, E)
+        B = self.B
+        return (self.feats[i * B:(i + 2) * B], self.featpair)
+
+    def load_pair(self, i):
+        ops.copy_multi([self.pair_copy(i)])
 
     def _graphed(self, key, fn, use_graphs):
         """eager the first time a key is seen (creates the workspaces), captured the second time, replayed afterwards"""
@@ -612,7 +615,9 @@ class _SequenceRunner:
             main.wait_stream(st[2])
         self.out = (pts1, conf1, pts2, conf2)
 
-    def run(self, first, has_next, use_graphs):
+    def run(self, first, has_next, use_graphs, post_copies=()):
+        """post_copies: (src, dst) pairs issued with the step's own result copies in ONE launch after the second graph
+        (decoder hooks -> sequence slots, the next pair of encoder features): six eager launches per frame became one"""
         mem = self.mem
         has_next = has_next and not self.batched                # nothing to prefetch: the sequence is already encoded
         key = (mem.M, mem.wm, mem._cur, has_next, self.batched, self.defer2, self.model.grouped_decoder)
@@ -629,8 +634,13 @@ class _SequenceRunner:
             mem.fetch_scores_async()
         self._graphed(("tail",) + key, self._part2, use_graphs)
         pts1, conf1, pts2, conf2 = self.out
-        res1 = {"pts3d": pts1.clone(), "conf": conf1.clone()}
-        res2 = {} if pts2 is None else {"pts3d": pts2.clone(), "conf": conf2.clone()}      # {}: filled by finish_head2
+        outs = [torch.empty_like(t) for t in (pts1, conf1) + (() if pts2 is None else (pts2, conf2))]
+        copies = list(zip((pts1, conf1) + (() if pts2 is None else (pts2, conf2)), outs))
+        copies += list(post_copies() if callable(post_copies) else post_copies)     # (callable: the hook buffers exist only now)
+        for c0 in range(0, len(copies), 8):
+            ops.copy_multi(copies[c0:c0 + 8])
+        res1 = {"pts3d": outs[0], "conf": outs[1]}
+        res2 = {} if pts2 is None else {"pts3d": outs[2], "conf": outs[3]}                 # {}: filled by finish_head2
         if self.swap:                                           # landscape_only wrapper (dust3r/utils/misc.py:79-80)
             res1 = {k: v.swapaxes(1, 2) for k, v in res1.items()}
             res2 = {k: v.swapaxes(1, 2) for k, v in res2.items()}
@@ -997,7 +1007,8 @@ class Spann3R(nn.Module):
             run.batched = run.defer2 = False
         for i in range(n - 1):
             if run.batched:
-                run.load_pair(i)
+                if i == 0:
+                    run.load_pair(0)
             else:
                 if i == 0:
                     run.img_pair[:B].copy_(frames[0]["img"])
@@ -1005,10 +1016,12 @@ class Spann3R(nn.Module):
                 if i + 2 < n:
                     run.img_next.copy_(frames[i + 2]["img"])
             has_next = i + 2 < n
-            res1, res2 = run.run(i == 0, has_next, self.use_graphs)
-            if run.defer2:
-                run.save_dec2(i)
-            else:
+            def post(i=i):
+                # after this step's kernels: the next step's pair of encoder features, side 2's hook outputs to their slots
+                nxt = [run.pair_copy(i + 1)] if (run.batched and i + 1 < n - 1) else []
+                return nxt + (run.dec2_copies(i) if run.defer2 else [])
+            res1, res2 = run.run(i == 0, has_next, self.use_graphs, post)
+            if not run.defer2:
                 res2["pts3d_in_other_view"] = res2.pop("pts3d")                  # :523
             if preds is None:
                 preds = [res1]

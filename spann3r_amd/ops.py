@@ -589,6 +589,20 @@ def colsum_packed(packed, rows, M, mem_attn):
                                                       L.stream_ptr()), "sp3_colsum_packed"))
 
 
+def copy_multi(pairs):
+    """[(src, dst), ...] (up to 8, contiguous device tensors of equal byte size per pair) copied in one launch"""
+    n = len(pairs)
+    if not 1 <= n <= 8:
+        raise ValueError("copy_multi: 1..8 copies")
+    S, D, Bt = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_int64 * n)()
+    for i, (s_, d_) in enumerate(pairs):
+        nb = s_.numel() * s_.element_size()
+        if not (s_.is_contiguous() and d_.is_contiguous()) or nb != d_.numel() * d_.element_size():
+            raise ValueError("copy_multi: pair %d must be contiguous and of equal size" % i)
+        S[i], D[i], Bt[i] = s_.data_ptr(), d_.data_ptr(), nb
+    _timed("copy_multi", 0.0, 2.0 * sum(Bt), lambda: L.check(L.load().sp3_copy_multi(n, S, D, Bt, L.stream_ptr()), "sp3_copy_multi"))
+
+
 def colsum_softmax(S, ld, rows, M, rowz, thresh, mem_attn, mem_count=None, append_P=0):
     """mem_attn[j] += column sums of the thresholded, renormalised softmax of S[:rows, :M]; rowz [rows, 4] = the softmax-loader
     GEMM's zout (kept mass, max, 1/Z, -) (two-launch memory read).  append_P > 0: the same launch also does
