@@ -64,7 +64,8 @@ def main():
               (end - start, len(batch) / (end - start), len(batch), it,
                ["eager warm-up", "hipGraph capture", "hipGraph replay"][min(it, 2)]))
     if args.save_ply:
-        from spann3r_amd.postprocess import estimate_focal_knowing_depth, confident_points, write_ply
+        from spann3r_amd.postprocess import (estimate_focal_knowing_depth, confident_points, write_ply, estimate_poses,
+                                             transforms_json, save_transforms)
         _, H, W, _ = preds[0]["pts3d"].shape
         focal = estimate_focal_knowing_depth(preds[0]["pts3d"], torch.tensor((W / 2, H / 2)), focal_mode="weiszfeld")
         print("Estimated focal of first camera: %.3f (%dx%d)" % (focal.item(), W, H))
@@ -76,6 +77,11 @@ def main():
         points, colours = confident_points(pts_all, conf_all, args.conf_thresh, images_all)
         write_ply(args.save_ply, points, colours)
         print("wrote %d of %d points to %s" % (len(points), conf_all.numel(), args.save_ply))
+        poses_all, inliers = estimate_poses(pts_all, focal, (W / 2, H / 2))     # demo.py:170-186 (PnP-RANSAC per frame)
+        import os
+        tj = os.path.join(os.path.dirname(os.path.abspath(args.save_ply)), "transforms.json")
+        save_transforms(tj, transforms_json(H, W, focal, list(poses_all), os.path.basename(args.save_ply)))
+        print("wrote %d camera poses to %s (inlier fractions %.2f..%.2f)" % (len(poses_all), tj, inliers.min(), inliers.max()))
     pts = preds[-1]["pts3d_in_other_view"]
     print("last frame: pts3d_in_other_view", tuple(pts.shape), "conf mean %.3f" % float(preds[-1]["conf"].mean()))
 

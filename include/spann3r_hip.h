@@ -375,6 +375,23 @@ int sp3_focal_weiszfeld(const float* pts3d, int B, int H, int W, float ppx, floa
 int sp3_conf_filter(const float* conf, const float* pts, const float* rgb, int64_t n, float thresh, int* scratch, int64_t* total,
                     float* out_pts, float* out_rgb, void* stream);
 
+/* Camera poses from pointmaps (demo.py:170-186 calls cv2.solvePnPRansac per frame; OpenCV is not available in this image, so
+ * this is an independent calibrated PnP, checked on synthetic scenes, NOT pinned against OpenCV -- see spann3r_amd/postprocess.py).
+ * The O(H*W) reductions run here, one workgroup per frame, double-precision sums in a fixed order; the host solves the small systems.
+ * sp3_pnp_dlt_accum: out41[F][41] = the four symmetric 4x4 blocks (10 unique entries each: S, Sx, Sy, Sr) of the calibrated DLT
+ *   normal matrix over the finite points (Rt == null) or over the points whose reprojection error under Rt[F][12] (row-major R | t)
+ *   is below thresh pixels, and the number of points used; norm4[F][4] = Hartley centroid (3) and scale of each frame's points.
+ * sp3_pnp_gn_accum : out29[F][29] = Gauss-Newton normal equations of the reprojection error over the inliers of Rt: H (21 unique,
+ *   row-major upper triangle, parameters (omega, delta) of Xc' = Xc + omega x Xc + delta), g (6), squared error, inlier count. */
+int sp3_pnp_dlt_accum(const float* pts, int F, int H, int W, float focal, float cx, float cy, const float* norm4, const float* Rt,
+                      float thresh, double* out41, void* stream);
+int sp3_pnp_gn_accum(const float* pts, int F, int H, int W, float focal, float cx, float cy, const float* Rt, float thresh, double* out29,
+                     void* stream);
+/* consensus of pose hypotheses: counts[F][n_hyp] = number of finite points of frame f whose reprojection error under
+ * Rt[F][n_hyp][12] is below thresh pixels (the scoring step of the RANSAC; hypotheses come from 8-point DLTs on the host). */
+int sp3_pnp_score(const float* pts, int F, int H, int W, float focal, float cx, float cy, const float* Rt, int n_hyp, float thresh,
+                  int* counts, void* stream);
+
 /* small utilities */
 /* n (1..8) contiguous device-to-device copies in one launch; every copy 16-byte aligned and a multiple of 16 bytes.
  * (The sequence loop's per-frame bookkeeping -- torch .clone() / slice assignments around spann3r/model.py:523-531.) */

@@ -149,3 +149,151 @@ extern "C" int sp3_conf_filter(const float* conf, const float* pts, const float*
   SP3_LAUNCH_CHECK("sp3_conf_filter");
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Camera pose of a frame from its pointmap (demo.py:170-186 calls cv2.solvePnPRansac with all H*W pixel <-> point pairs).
+// The device does the O(H*W) part of a calibrated PnP as fixed-order double-precision reductions, one workgroup per frame;
+// the host solves the 12x12 / 6x6 systems (spann3r_amd/postprocess.py):
+//   pnp_dlt_accum: the normal matrix of the calibrated DLT  [X~ 0 -x X~; 0 X~ -y X~] p = 0  over the (inlier) points, as the
+//     four symmetric 4x4 blocks S = sum w X~X~^T, Sx = sum w x X~X~^T, Sy, Sr = sum w (x^2 + y^2) X~X~^T (X~ = Hartley-
+//     normalised homogeneous point, (x, y) = normalised pixel) -> 40 doubles + the inlier count;
+//   pnp_gn_accum: Gauss-Newton normal equations of the reprojection error in pixels over the inliers (error < thr):
+//     H (21 unique), g (6), cost, count -> 29 doubles.
+namespace {
+
+__device__ __forceinline__ void block_sum_n(double* v, int n, double* sh, double* out) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int k = 0; k < n; ++k) {
+    double x = v[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    if (lane == 0) sh[w * 48 + k] = x;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < n) {
+    double r = 0.0;
+    for (int i = 0; i < 16; ++i) r += sh[i * 48 + threadIdx.x];
+    out[threadIdx.x] = r;
+  }
+}
+
+// reprojection error (pixels) of point X under pose Rt (row-major R | t), or a large value for points behind the camera
+__device__ __forceinline__ float reproj_err(const float* Rt, float X, float Y, float Z, float f, float u, float v, float cx, float cy,
+                                            float& xc, float& yc, float& zc) {
+  xc = Rt[0] * X + Rt[1] * Y + Rt[2] * Z + Rt[9];
+  yc = Rt[3] * X + Rt[4] * Y + Rt[5] * Z + Rt[10];
+  zc = Rt[6] * X + Rt[7] * Y + Rt[8] * Z + Rt[11];
+  if (!(zc > 1e-9f)) return 1e30f;
+  const float du = f * xc / zc + cx - u, dv = f * yc / zc + cy - v;
+  return sqrtf(du * du + dv * dv);
+}
+
+__global__ __launch_bounds__(1024) void pnp_dlt_accum_kernel(const float* __restrict__ pts, int HW, int W, float f, float cx, float cy,
+                                                             const float* __restrict__ norm4, const float* __restrict__ Rt_all, float thr,
+                                                             double* __restrict__ out) {
+  __shared__ double sh[16 * 48];
+  const float* p = pts + (int64_t)blockIdx.x * HW * 3;
+  const float* nm = norm4 + blockIdx.x * 4;                 // centroid (3), scale
+  const float* Rt = Rt_all ? Rt_all + blockIdx.x * 12 : nullptr;
+  double a[41];
+  for (int k = 0; k < 41; ++k) a[k] = 0.0;
+  for (int i = threadIdx.x; i < HW; i += 1024) {
+    const float X = p[3 * i], Y = p[3 * i + 1], Z = p[3 * i + 2];
+    if (!(isfinite(X) && isfinite(Y) && isfinite(Z))) continue;
+    const float u = (float)(i % W), v = (float)(i / W);
+    if (Rt) { float xc, yc, zc; if (reproj_err(Rt, X, Y, Z, f, u, v, cx, cy, xc, yc, zc) >= thr) continue; }
+    const double x = (double)(u - cx) / f, y = (double)(v - cy) / f;
+    const double h[4] = {(double)(X - nm[0]) * nm[3], (double)(Y - nm[1]) * nm[3], (double)(Z - nm[2]) * nm[3], 1.0};
+    const double rr = x * x + y * y;
+    int k = 0;
+    for (int r = 0; r < 4; ++r)
+      for (int c = r; c < 4; ++c, ++k) {
+        const double hh = h[r] * h[c];
+        a[k] += hh; a[10 + k] += x * hh; a[20 + k] += y * hh; a[30 + k] += rr * hh;
+      }
+    a[40] += 1.0;
+  }
+  block_sum_n(a, 41, sh, out + (int64_t)blockIdx.x * 41);
+}
+
+__global__ __launch_bounds__(1024) void pnp_gn_accum_kernel(const float* __restrict__ pts, int HW, int W, float f, float cx, float cy,
+                                                            const float* __restrict__ Rt_all, float thr, double* __restrict__ out) {
+  __shared__ double sh[16 * 48];
+  const float* p = pts + (int64_t)blockIdx.x * HW * 3;
+  const float* Rt = Rt_all + blockIdx.x * 12;
+  double a[29];
+  for (int k = 0; k < 29; ++k) a[k] = 0.0;
+  for (int i = threadIdx.x; i < HW; i += 1024) {
+    const float X = p[3 * i], Y = p[3 * i + 1], Z = p[3 * i + 2];
+    if (!(isfinite(X) && isfinite(Y) && isfinite(Z))) continue;
+    const float u = (float)(i % W), v = (float)(i / W);
+    float xc, yc, zc;
+    if (reproj_err(Rt, X, Y, Z, f, u, v, cx, cy, xc, yc, zc) >= thr) continue;
+    const double iz = 1.0 / zc, xn = xc * iz, yn = yc * iz;
+    const double ru = f * xn + cx - u, rv = f * yn + cy - v;
+    // d(residual) / d(omega, delta) for Xc' = Xc + omega x Xc + delta
+    const double fz = f * iz;
+    const double Ju[6] = {fz * (-xn * yc), fz * (zc + xn * xc), fz * (-yc), fz, 0.0, -fz * xn};
+    const double Jv[6] = {fz * (-zc - yn * yc), fz * (yn * xc), fz * xc, 0.0, fz, -fz * yn};
+    int k = 0;
+    for (int r = 0; r < 6; ++r)
+      for (int c = r; c < 6; ++c, ++k) a[k] += Ju[r] * Ju[c] + Jv[r] * Jv[c];
+    for (int r = 0; r < 6; ++r) a[21 + r] += Ju[r] * ru + Jv[r] * rv;
+    a[27] += ru * ru + rv * rv;
+    a[28] += 1.0;
+  }
+  block_sum_n(a, 29, sh, out + (int64_t)blockIdx.x * 29);
+}
+
+}  // namespace
+
+extern "C" int sp3_pnp_dlt_accum(const float* pts, int F, int H, int W, float focal, float cx, float cy, const float* norm4,
+                                 const float* Rt, float thresh, double* out41, void* stream) {
+  SP3_CHECK(pts && norm4 && out41 && F > 0 && H > 0 && W > 0 && focal > 0.f, "sp3_pnp_dlt_accum: bad arguments");
+  hipLaunchKernelGGL(pnp_dlt_accum_kernel, dim3(F), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), pts, H * W, W, focal, cx, cy, norm4,
+                     Rt, thresh, out41);
+  SP3_LAUNCH_CHECK("sp3_pnp_dlt_accum");
+  return 0;
+}
+
+extern "C" int sp3_pnp_gn_accum(const float* pts, int F, int H, int W, float focal, float cx, float cy, const float* Rt, float thresh,
+                                double* out29, void* stream) {
+  SP3_CHECK(pts && Rt && out29 && F > 0 && H > 0 && W > 0 && focal > 0.f, "sp3_pnp_gn_accum: bad arguments");
+  hipLaunchKernelGGL(pnp_gn_accum_kernel, dim3(F), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), pts, H * W, W, focal, cx, cy, Rt,
+                     thresh, out29);
+  SP3_LAUNCH_CHECK("sp3_pnp_gn_accum");
+  return 0;
+}
+
+// number of points whose reprojection error under hypothesis h of frame f is below thr: counts[f][h]; grid (hyps, frames)
+namespace {
+__global__ __launch_bounds__(256) void pnp_score_kernel(const float* __restrict__ pts, int HW, int W, float f, float cx, float cy,
+                                                        const float* __restrict__ Rt_all, int nh, float thr, int* __restrict__ counts) {
+  __shared__ int sh[4];
+  const float* p = pts + (int64_t)blockIdx.y * HW * 3;
+  const float* Rt = Rt_all + ((int64_t)blockIdx.y * nh + blockIdx.x) * 12;
+  float r[12];
+  for (int k = 0; k < 12; ++k) r[k] = Rt[k];
+  int c = 0;
+  for (int i = threadIdx.x; i < HW; i += 256) {
+    const float X = p[3 * i], Y = p[3 * i + 1], Z = p[3 * i + 2];
+    if (!(isfinite(X) && isfinite(Y) && isfinite(Z))) continue;
+    float xc, yc, zc;
+    c += reproj_err(r, X, Y, Z, f, (float)(i % W), (float)(i / W), cx, cy, xc, yc, zc) < thr;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) counts[blockIdx.y * nh + blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+}  // namespace
+
+extern "C" int sp3_pnp_score(const float* pts, int F, int H, int W, float focal, float cx, float cy, const float* Rt, int n_hyp, float thresh,
+                             int* counts, void* stream) {
+  SP3_CHECK(pts && Rt && counts && F > 0 && H > 0 && W > 0 && n_hyp > 0 && focal > 0.f, "sp3_pnp_score: bad arguments");
+  hipLaunchKernelGGL(pnp_score_kernel, dim3(n_hyp, F), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pts, H * W, W, focal, cx, cy, Rt,
+                     n_hyp, thresh, counts);
+  SP3_LAUNCH_CHECK("sp3_pnp_score");
+  return 0;
+}
