@@ -77,11 +77,14 @@ def main():
         points, colours = confident_points(pts_all, conf_all, args.conf_thresh, images_all)
         write_ply(args.save_ply, points, colours)
         print("wrote %d of %d points to %s" % (len(points), conf_all.numel(), args.save_ply))
-        poses_all, inliers = estimate_poses(pts_all, focal, (W / 2, H / 2))     # demo.py:170-186 (PnP-RANSAC per frame)
-        import os
-        tj = os.path.join(os.path.dirname(os.path.abspath(args.save_ply)), "transforms.json")
-        save_transforms(tj, transforms_json(H, W, focal, list(poses_all), os.path.basename(args.save_ply)))
-        print("wrote %d camera poses to %s (inlier fractions %.2f..%.2f)" % (len(poses_all), tj, inliers.min(), inliers.max()))
+        if focal.item() > 1e-3:                                                 # (seeded random weights give no geometry at all)
+            poses_all, inliers = estimate_poses(pts_all, focal, (W / 2, H / 2))     # demo.py:170-186 (PnP-RANSAC per frame)
+            import os
+            tj = os.path.join(os.path.dirname(os.path.abspath(args.save_ply)), "transforms.json")
+            save_transforms(tj, transforms_json(H, W, focal, list(poses_all), os.path.basename(args.save_ply)))
+            print("wrote %d camera poses to %s (inlier fractions %.2f..%.2f)" % (len(poses_all), tj, inliers.min(), inliers.max()))
+        else:
+            print("degenerate pointmaps (no checkpoint loaded): poses / transforms.json skipped")
     pts = preds[-1]["pts3d_in_other_view"]
     print("last frame: pts3d_in_other_view", tuple(pts.shape), "conf mean %.3f" % float(preds[-1]["conf"].mean()))
 

@@ -109,6 +109,8 @@ def estimate_poses(pts_all, focal, pp, reproj_thresh=8.0, gn_iters=10, n_hyp=96,
     dev = pts.device
     f = float(focal.item() if hasattr(focal, "item") else focal)
     cx, cy = (float(v) for v in (pp.tolist() if hasattr(pp, "tolist") else pp))
+    if not (f > 0 and math.isfinite(f)):
+        raise ValueError("estimate_poses: focal must be positive and finite, got %r" % f)
     lib = L.load()
     flat = pts.reshape(F, -1, 3)
     fin = torch.isfinite(flat).all(-1, keepdim=True)

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     if not os.path.exists(lib.LIB_PATH):
         g.build()
     l = lib.load()
-    declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(sp3_\w+)\s*\(", _header(), flags=re.M))
+    declared = set(re.findall(r"^\s*(?:int|int64_t|const char\*)\s+(sp3_\w+)\s*\(", _header(), flags=re.M))
     assert len(declared) >= 24
     for name in declared:
         assert hasattr(l, name), "missing export " + name
