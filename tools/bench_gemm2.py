@@ -50,7 +50,8 @@ if args.big:
     # (name, M, N, K, batch)
     shapes = [("enc qkv", 1960, 3072, 1024, 1), ("enc fc1", 1960, 4096, 1024, 1), ("enc fc2", 1960, 1024, 4096, 1),
               ("enc proj", 1960, 1024, 1024, 1), ("c3 dec qkv", 1024, 2304, 768, 2), ("c3 dec fc1", 1024, 3072, 768, 2),
-              ("c3 dec fc2", 1024, 768, 3072, 2), ("c3 dec proj", 1024, 768, 768, 2), ("c3 val fc1", 1024, 4096, 1024, 1)]
+              ("c3 dec fc2", 1024, 768, 3072, 2), ("c3 dec proj", 1024, 768, 768, 2), ("c3 val fc1", 1024, 4096, 1024, 1),
+              ("c3 val proj", 1024, 1024, 1024, 1), ("c3 val fc2", 1024, 1024, 4096, 1), ("c3 key 2", 1024, 1024, 1792, 2)]
     tiles = [1, 2, 5, 6]
 else:
     M = args.M
@@ -83,7 +84,7 @@ for name, M, N, K, G in shapes:
     part = torch.empty(8 * G * M * N, device=dev)
     for tile in tiles:
         BN = {0: 32, 9: 32}.get(tile, 64)
-        BM = {0: 32, 4: 32, 18: 16, 8: 208, 12: 208, 15: 208, 5: 128, 6: 128, 1: 64, 2: 64}.get(tile, 112)
+        BM = {0: 32, 4: 32, 18: 16, 20: 64, 21: 64, 8: 208, 12: 208, 15: 208, 5: 128, 6: 128, 1: 64, 2: 64}.get(tile, 112)
         wgs = ((M + BM - 1) // BM) * ((N + BN - 1) // BN) * G
         sks = [0]
         if not args.big and tile != 0 and G == 1:
