@@ -356,6 +356,11 @@ int sp3_conf_loss_backward(const float* P, const float* Cf, const float* G, cons
  *                     (accumulate != 0: added to their current contents); scratch: ceil(rows / 4) * 2 * C floats.  Column sums in a
  *                     fixed order: deterministic. */
 int sp3_transpose(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int rows, int cols, void* stream);
+int sp3_transpose_batched(const float* src, int64_t ld_src, int64_t stride_src, float* dst, int64_t ld_dst, int64_t stride_dst, int rows,
+                          int cols, int batch, void* stream);       /* `batch` matrices, element strides between them */
+/* exact-erf GELU (nn.GELU, croco/models/blocks.py:73-79) of the train-mode blocks and its backward dx = dy * gelu'(x) */
+int sp3_gelu(const float* x, float* y, int64_t n, void* stream);
+int sp3_gelu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream);
 int sp3_mul(const float* a, const float* b, float* out, int64_t n, void* stream);
 int sp3_softmax_bwd(const float* A, const float* dAd, const float* mask, float* dS, int64_t ld, int rows, int T, float alpha, void* stream);
 int sp3_layernorm_bwd(const float* x, int64_t ldx, const float* gamma, const float* dy, int64_t ldy, const float* dx_add, int64_t ld_add,

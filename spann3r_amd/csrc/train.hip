@@ -10,8 +10,10 @@ namespace {
 
 // dst[c * ldd + r] = src[r * lds + c], 32 x 32 tiles through LDS; columns [rows, ldd) of dst are left untouched
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, int64_t lds_, float* __restrict__ dst, int64_t ldd,
-                                                        int rows, int cols) {
+                                                        int rows, int cols, int64_t bs_src, int64_t bs_dst) {
   __shared__ float t[32][33];
+  src += (int64_t)blockIdx.z * bs_src;
+  dst += (int64_t)blockIdx.z * bs_dst;
   const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
 #pragma unroll
   for (int k = 0; k < 32; k += 8) {
@@ -23,6 +25,21 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
   for (int k = 0; k < 32; k += 8) {
     const int c = c0 + ty + k, r = r0 + tx;
     if (c < cols && r < rows) dst[(int64_t)c * ldd + r] = t[tx][ty + k];
+  }
+}
+
+// exact-erf GELU (nn.GELU default, croco/models/blocks.py:73-79) and its derivative: Phi(x) + x phi(x)
+__global__ __launch_bounds__(256) void gelu_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) { const float v = x[i]; y[i] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
+}
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    const float v = x[i];
+    const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752f));
+    const float pdf = 0.39894228040143268f * __expf(-0.5f * v * v);
+    dx[i] = dy[i] * (cdf + v * pdf);
   }
 }
 
@@ -108,8 +125,32 @@ __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __res
 
 extern "C" int sp3_transpose(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int rows, int cols, void* stream) {
   SP3_CHECK(src && dst && rows > 0 && cols > 0 && ld_src >= cols && ld_dst >= rows, "sp3_transpose: bad arguments");
-  hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, ST(stream), src, ld_src, dst, ld_dst, rows, cols);
+  hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32, 1), dim3(256), 0, ST(stream), src, ld_src, dst, ld_dst, rows,
+                     cols, (int64_t)0, (int64_t)0);
   SP3_LAUNCH_CHECK("sp3_transpose");
+  return 0;
+}
+
+extern "C" int sp3_transpose_batched(const float* src, int64_t ld_src, int64_t stride_src, float* dst, int64_t ld_dst, int64_t stride_dst,
+                                     int rows, int cols, int batch, void* stream) {
+  SP3_CHECK(src && dst && rows > 0 && cols > 0 && batch > 0 && batch <= 65535 && ld_src >= cols && ld_dst >= rows, "sp3_transpose_batched: bad arguments");
+  hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32, batch), dim3(256), 0, ST(stream), src, ld_src, dst, ld_dst, rows,
+                     cols, stride_src, stride_dst);
+  SP3_LAUNCH_CHECK("sp3_transpose_batched");
+  return 0;
+}
+
+extern "C" int sp3_gelu(const float* x, float* y, int64_t n, void* stream) {
+  SP3_CHECK(x && y && n > 0, "sp3_gelu: bad arguments");
+  hipLaunchKernelGGL(gelu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ST(stream), x, y, n);
+  SP3_LAUNCH_CHECK("sp3_gelu");
+  return 0;
+}
+
+extern "C" int sp3_gelu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream) {
+  SP3_CHECK(x && dy && dx && n > 0, "sp3_gelu_bwd: bad arguments");
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ST(stream), x, dy, dx, n);
+  SP3_LAUNCH_CHECK("sp3_gelu_bwd");
   return 0;
 }
 

@@ -122,6 +122,9 @@ _PROTOS = {
     "sp3_conf_loss_backward": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "sp3_transpose": [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p],
+    "sp3_transpose_batched": [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "sp3_gelu": [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
+    "sp3_gelu_bwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
     "sp3_mul": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
     "sp3_softmax_bwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_void_p],
     "sp3_layernorm_bwd": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,

@@ -120,3 +120,216 @@ def memory_read_train(feat, mem_k, mem_v, norm_q, norm_k, norm_v, mask=None, eps
                                            norm_q[0], norm_q[1], norm_k[0], norm_k[1], norm_v[0], norm_v[1],
                                            None if mask is None else mask[b].contiguous(), eps))
     return torch.stack(outs)
+
+
+# =====================================================================================================================
+# Train-mode building blocks with HIP forward AND backward (fp32 MFMA): every matrix product of a backward pass is an
+# sp3_gemm launch (C = A . B^T only, so the other operand orders go through sp3_transpose / sp3_transpose_batched with the
+# contraction extent zero-padded to 8), the elementwise pieces are the kernels of csrc/train.hip.  torch is the autograd
+# tape, the reshapes between [B, N, C] and per-head layouts, and the accumulation of gradients at fan-outs.
+# Reference modules: croco/models/blocks.py:73-79 (Mlp), :94-112 (Attention), :127-130 (Block), :149-169 (CrossAttention),
+# :186-191 (DecoderBlock).
+def _nt(A, Bm, M, N, K, lda, ldb, out, ldc, bias=None, res=None, alpha=1.0, batch=1, sA=0, sB=0, sC=0):
+    """out[M, N] (row stride ldc) = alpha * A[M, K] . Bm[N, K]^T (+ bias) (+ res); K % 8 == 0 (operands zero-padded)"""
+    ops.gemm(A, Bm, out, M=M, N=N, K=K, lda=lda, ldc=ldc, ldw=ldb, bias=bias, res1=res, ldr1=ldc, alpha=alpha,
+             batch=batch, strideA=sA, strideW=sB, strideC=sC)
+    return out
+
+
+def _tb(src, rows, cols, ld_src, batch=1, stride_src=0):
+    """batched transpose with the new row length padded to 8 (zeros): [batch, rows, cols] -> [batch, cols, r8(rows)]"""
+    ldd = _r8(rows)
+    dst = torch.zeros(batch, cols, ldd, device=src.device)
+    L.check(L.load().sp3_transpose_batched(src.data_ptr(), ld_src, stride_src, dst.data_ptr(), ldd, cols * ldd, rows, cols, batch,
+                                           L.stream_ptr()), "sp3_transpose_batched")
+    return dst
+
+
+def _pad8(x):
+    """[R, N] -> contiguous [R, r8(N)] with zero columns (no copy when N % 8 == 0)"""
+    R, N = x.shape
+    if N % 8 == 0 and x.is_contiguous():
+        return x
+    y = torch.zeros(R, _r8(N), device=x.device)
+    y[:, :N] = x
+    return y
+
+
+class _Linear(torch.autograd.Function):
+    """y = x W^T + b (+ res); x [R, K], W [N, K]"""
+
+    @staticmethod
+    def forward(ctx, x, W, b, res):
+        R, K = x.shape
+        N = W.shape[0]
+        y = torch.empty(R, N, device=x.device)
+        xp, Wp = _pad8(x), _pad8(W)
+        _nt(xp, Wp, R, N, xp.shape[1], xp.shape[1], Wp.shape[1], y, N, bias=b, res=res)
+        ctx.save_for_backward(x, W)
+        ctx.has = (b is not None, res is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        R, K = x.shape
+        N = W.shape[0]
+        dy = dy.contiguous()
+        dev = x.device
+        dx = dW = db = None
+        if ctx.needs_input_grad[0]:
+            WT = _tb(W, N, K, K)[0]                                      # [K, r8(N)]
+            dyp = _pad8(dy)
+            dx = _nt(dyp, WT, R, K, dyp.shape[1], dyp.shape[1], WT.shape[1], torch.empty(R, K, device=dev), K)
+        if ctx.needs_input_grad[1]:
+            dyT, xT = _tb(dy, R, N, N)[0], _tb(x, R, K, K)[0]            # [N, r8(R)], [K, r8(R)]
+            dW = _nt(dyT, xT, N, K, dyT.shape[1], dyT.shape[1], xT.shape[1], torch.empty(N, K, device=dev), K)
+        if ctx.has[0] and ctx.needs_input_grad[2]:
+            db = torch.zeros(N, device=dev)
+            ops.colsum_accum(dy, N, R, N, db)
+        return dx, dW, db, (dy if ctx.has[1] else None)
+
+
+def linear(x, W, b=None, res=None):
+    sh = x.shape
+    y = _Linear.apply(x.reshape(-1, sh[-1]).contiguous(), W, b, None if res is None else res.reshape(-1, W.shape[0]).contiguous())
+    return y.reshape(*sh[:-1], W.shape[0])
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, g, b, eps):
+        R, C_ = x.shape
+        y = torch.empty_like(x)
+        ops.layernorm(x, g, b, eps, y, rows=R, C_=C_)
+        ctx.save_for_backward(x, g)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g = ctx.saved_tensors
+        dx, dg, db = _ln_bwd(x, g, dy.contiguous(), None, ctx.eps)
+        return dx, dg, db, None
+
+
+def layer_norm(x, g, b, eps):
+    sh = x.shape
+    return _LayerNorm.apply(x.reshape(-1, sh[-1]).contiguous(), g, b, eps).reshape(sh)
+
+
+class _Gelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        L.check(L.load().sp3_gelu(x.data_ptr(), y.data_ptr(), x.numel(), L.stream_ptr()), "sp3_gelu")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        L.check(L.load().sp3_gelu_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), L.stream_ptr()), "sp3_gelu_bwd")
+        return dx
+
+
+class _Attention(torch.autograd.Function):
+    """softmax(q k^T * scale) v on [BH, Nq, D] x [BH, Nk, D] (D % 8 == 0), heads as the batch of grouped GEMM launches"""
+
+    @staticmethod
+    def forward(ctx, q, k, v, scale):
+        BH, Nq, D = q.shape
+        Nk = k.shape[1]
+        Nkp = _r8(Nk)
+        dev = q.device
+        S = torch.zeros(BH, Nq, Nkp, device=dev)
+        _nt(q, k, Nq, Nk, D, D, D, S, Nkp, alpha=scale, batch=BH, sA=Nq * D, sB=Nk * D, sC=Nq * Nkp)
+        P = torch.empty_like(S)
+        ops.softmax_thresh(S, P, ld=Nkp, rows=BH * Nq, M=Nk, Mpad=Nkp, thresh=0.0)
+        vT = _tb(v, Nk, D, D, BH, Nk * D)                                # [BH, D, Nkp]
+        O = torch.empty(BH, Nq, D, device=dev)
+        _nt(P, vT, Nq, D, Nkp, Nkp, Nkp, O, D, batch=BH, sA=Nq * Nkp, sB=D * Nkp, sC=Nq * D)
+        ctx.save_for_backward(q, k, v, P)
+        ctx.scale = scale
+        return O
+
+    @staticmethod
+    def backward(ctx, dO):
+        q, k, v, P = ctx.saved_tensors
+        BH, Nq, D = q.shape
+        Nk, Nkp, Nqp = k.shape[1], P.shape[2], _r8(q.shape[1])
+        dev = q.device
+        dO = dO.contiguous()
+        dP = torch.zeros(BH, Nq, Nkp, device=dev)
+        _nt(dO, v, Nq, Nk, D, D, D, dP, Nkp, batch=BH, sA=Nq * D, sB=Nk * D, sC=Nq * Nkp)
+        PT = _tb(P, Nq, Nk, Nkp, BH, Nq * Nkp)                           # [BH, Nk, Nqp]
+        dOT = _tb(dO, Nq, D, D, BH, Nq * D)                              # [BH, D, Nqp]
+        dV = torch.empty(BH, Nk, D, device=dev)
+        _nt(PT, dOT, Nk, D, Nqp, Nqp, Nqp, dV, D, batch=BH, sA=Nk * Nqp, sB=D * Nqp, sC=Nk * D)
+        dS = torch.zeros(BH, Nq, Nkp, device=dev)
+        L.check(L.load().sp3_softmax_bwd(P.data_ptr(), dP.data_ptr(), None, dS.data_ptr(), Nkp, BH * Nq, Nk, ctx.scale, L.stream_ptr()),
+                "sp3_softmax_bwd")
+        kT = _tb(k, Nk, D, D, BH, Nk * D)                                # [BH, D, Nkp]
+        dq = torch.empty(BH, Nq, D, device=dev)
+        _nt(dS, kT, Nq, D, Nkp, Nkp, Nkp, dq, D, batch=BH, sA=Nq * Nkp, sB=D * Nkp, sC=Nq * D)
+        dST = _tb(dS, Nq, Nk, Nkp, BH, Nq * Nkp)                         # [BH, Nk, Nqp]
+        qT = _tb(q, Nq, D, D, BH, Nq * D)                                # [BH, D, Nqp]
+        dk = torch.empty(BH, Nk, D, device=dev)
+        _nt(dST, qT, Nk, D, Nqp, Nqp, Nqp, dk, D, batch=BH, sA=Nk * Nqp, sB=D * Nqp, sC=Nk * D)
+        return dq, dk, dV, None
+
+
+def _heads(t, B, N, H, pos, base):
+    """[B, N, H*hd] -> [B*H, N, hd] contiguous, RoPE applied first if pos is given (in place on the [B, N, H, hd] copy)"""
+    hd = t.shape[-1] // H
+    t = t.reshape(B, N, H, hd).contiguous()
+    if pos is not None:
+        from .curope import cuRoPE2D_func
+        t = cuRoPE2D_func.apply(t, pos, base, 1.0)
+    return t.permute(0, 2, 1, 3).reshape(B * H, N, hd).contiguous()
+
+
+def self_attention(x, pos, P, pre, heads, base=100.0, use_rope=True, res=None):
+    """croco/models/blocks.py:94-112; P: dict of parameters, pre: key prefix ('...attn.'); res is added by the projection"""
+    B, N, C_ = x.shape
+    qkv = linear(x, P[pre + "qkv.weight"], P[pre + "qkv.bias"]).reshape(B, N, 3, C_)
+    rp = pos if use_rope else None
+    q, k, v = _heads(qkv[:, :, 0], B, N, heads, rp, base), _heads(qkv[:, :, 1], B, N, heads, rp, base), _heads(qkv[:, :, 2], B, N, heads, None, base)
+    o = _Attention.apply(q, k, v, (C_ // heads) ** -0.5)
+    o = o.reshape(B, heads, N, C_ // heads).permute(0, 2, 1, 3).reshape(B, N, C_)
+    return linear(o, P[pre + "proj.weight"], P[pre + "proj.bias"], res)
+
+
+def cross_attention(xq, y, qpos, kpos, P, pre, heads, base=100.0, res=None):
+    """croco/models/blocks.py:149-169"""
+    B, Nq, C_ = xq.shape
+    Nk = y.shape[1]
+    q = _heads(linear(xq, P[pre + "projq.weight"], P[pre + "projq.bias"]), B, Nq, heads, qpos, base)
+    k = _heads(linear(y, P[pre + "projk.weight"], P[pre + "projk.bias"]), B, Nk, heads, kpos, base)
+    v = _heads(linear(y, P[pre + "projv.weight"], P[pre + "projv.bias"]), B, Nk, heads, None, base)
+    o = _Attention.apply(q, k, v, (C_ // heads) ** -0.5)
+    o = o.reshape(B, heads, Nq, C_ // heads).permute(0, 2, 1, 3).reshape(B, Nq, C_)
+    return linear(o, P[pre + "proj.weight"], P[pre + "proj.bias"], res)
+
+
+def mlp(x, P, pre, res=None):
+    """croco/models/blocks.py:73-79"""
+    h = _Gelu.apply(linear(x, P[pre + "fc1.weight"], P[pre + "fc1.bias"]))
+    return linear(h, P[pre + "fc2.weight"], P[pre + "fc2.bias"], res)
+
+
+def block(x, pos, P, pre, heads, base=100.0, use_rope=True, eps=1e-6):
+    """Pre-LN ViT block, croco/models/blocks.py:127-130 (the residual adds ride in the GEMM epilogues)"""
+    x = self_attention(layer_norm(x, P[pre + "norm1.weight"], P[pre + "norm1.bias"], eps), pos, P, pre + "attn.", heads, base, use_rope, res=x)
+    return mlp(layer_norm(x, P[pre + "norm2.weight"], P[pre + "norm2.bias"], eps), P, pre + "mlp.", res=x)
+
+
+def decoder_block(x, y, xpos, ypos, P, pre, heads, base=100.0, eps=1e-6):
+    """croco/models/blocks.py:186-191"""
+    x = self_attention(layer_norm(x, P[pre + "norm1.weight"], P[pre + "norm1.bias"], eps), xpos, P, pre + "attn.", heads, base, res=x)
+    yn = layer_norm(y, P[pre + "norm_y.weight"], P[pre + "norm_y.bias"], eps)
+    x = cross_attention(layer_norm(x, P[pre + "norm2.weight"], P[pre + "norm2.bias"], eps), yn, xpos, ypos, P, pre + "cross_attn.", heads, base, res=x)
+    return mlp(layer_norm(x, P[pre + "norm3.weight"], P[pre + "norm3.bias"], eps), P, pre + "mlp.", res=x)
