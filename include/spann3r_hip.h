@@ -361,6 +361,17 @@ int sp3_transpose_batched(const float* src, int64_t ld_src, int64_t stride_src, 
 /* exact-erf GELU (nn.GELU, croco/models/blocks.py:73-79) of the train-mode blocks and its backward dx = dy * gelu'(x) */
 int sp3_gelu(const float* x, float* y, int64_t n, void* stream);
 int sp3_gelu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream);
+/* train-mode DPT head pieces (croco/models/dpt_block.py:120-218, dust3r/heads/postprocess.py:10-58), NHWC fp32:
+ * sp3_im2col3x3 / sp3_col2im3x3 : the 3x3, pad 1, stride 1|2 convolution as a GEMM over col [B*OH*OW, 9*C] (k = (ky*3+kx)*C + c) and the
+ *   adjoint gather that turns d col back into d x;  sp3_relu / sp3_relu_bwd;  sp3_upsample2x_bwd : adjoint of sp3_upsample2x;
+ * sp3_postprocess(_bwd) : raw [M, 4] -> pts3d [M, 3] = xyz / |xyz| * expm1(|xyz|), conf [M] = 1 + exp(c), and its backward. */
+int sp3_im2col3x3(const float* x, float* col, int B, int H, int W, int C, int stride, void* stream);
+int sp3_col2im3x3(const float* dcol, float* dx, int B, int H, int W, int C, int stride, void* stream);
+int sp3_relu(const float* x, float* y, int64_t n, void* stream);
+int sp3_relu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream);
+int sp3_upsample2x_bwd(const float* dy, float* dx, int B, int H, int W, int C, int outH, int outW, void* stream);
+int sp3_postprocess(const float* raw, float* pts, float* conf, int64_t M, void* stream);
+int sp3_postprocess_bwd(const float* raw, const float* dpts, const float* dconf, float* draw, int64_t M, void* stream);
 int sp3_mul(const float* a, const float* b, float* out, int64_t n, void* stream);
 int sp3_softmax_bwd(const float* A, const float* dAd, const float* mask, float* dS, int64_t ld, int rows, int T, float alpha, void* stream);
 int sp3_layernorm_bwd(const float* x, int64_t ldx, const float* gamma, const float* dy, int64_t ldy, const float* dx_add, int64_t ld_add,

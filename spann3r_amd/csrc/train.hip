@@ -119,6 +119,128 @@ __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __res
   *o = (accumulate ? *o : 0.f) + (float)s;
 }
 
+// ---- DPT head pieces (croco/models/dpt_block.py, dust3r/heads/postprocess.py), NHWC fp32 ----
+// col[(b, oy, ox), (ky*3 + kx)*C + c] = x[b, oy*s - 1 + ky, ox*s - 1 + kx, c] (0 outside): the 3x3 / pad 1 convolution as a GEMM
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const float* __restrict__ x, float* __restrict__ col, int H, int W, int C, int OH,
+                                                        int OW, int stride, int64_t total4) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total4) return;
+  const int c4 = C >> 2;
+  const int cc = (int)(idx % c4);
+  int64_t r = idx / c4;
+  const int tap = (int)(r % 9);
+  r /= 9;
+  const int ox = (int)(r % OW);
+  r /= OW;
+  const int oy = (int)(r % OH);
+  const int b = (int)(r / OH);
+  const int iy = oy * stride - 1 + tap / 3, ix = ox * stride - 1 + tap % 3;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = reinterpret_cast<const float4*>(x)[(((int64_t)b * H + iy) * W + ix) * c4 + cc];
+  reinterpret_cast<float4*>(col)[idx] = v;
+}
+
+// the adjoint, gather form: dx[b, iy, ix, c] = sum over taps of dcol[(b, oy, ox), tap, c] with oy*s - 1 + ky == iy (fixed order)
+__global__ __launch_bounds__(256) void col2im3x3_kernel(const float* __restrict__ dcol, float* __restrict__ dx, int H, int W, int C, int OH,
+                                                        int OW, int stride, int64_t total4) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total4) return;
+  const int c4 = C >> 2;
+  const int cc = (int)(idx % c4);
+  int64_t r = idx / c4;
+  const int ix = (int)(r % W);
+  r /= W;
+  const int iy = (int)(r % H);
+  const int b = (int)(r / H);
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int ky = 0; ky < 3; ++ky) {
+    const int ty = iy + 1 - ky;
+    if (ty < 0 || ty % stride) continue;
+    const int oy = ty / stride;
+    if (oy >= OH) continue;
+    for (int kx = 0; kx < 3; ++kx) {
+      const int tx = ix + 1 - kx;
+      if (tx < 0 || tx % stride) continue;
+      const int ox = tx / stride;
+      if (ox >= OW) continue;
+      const float4 v = reinterpret_cast<const float4*>(dcol)[((((int64_t)b * OH + oy) * OW + ox) * 9 + ky * 3 + kx) * c4 + cc];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+  }
+  reinterpret_cast<float4*>(dx)[idx] = a;
+}
+
+__global__ __launch_bounds__(256) void relu_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) y[i] = fmaxf(x[i], 0.f);
+}
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dx[i] = x[i] > 0.f ? dy[i] : 0.f;
+}
+
+// adjoint of upsample2x_kernel (dpt.hip: bilinear x2, align_corners=True, optional crop to outH x outW), gather form
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int H, int W, int C, int outH,
+                                                             int outW, int64_t total) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % C);
+  int64_t r = idx / C;
+  const int ix = (int)(r % W);
+  r /= W;
+  const int iy = (int)(r % H);
+  const int b = (int)(r / H);
+  const int OH = 2 * H, OW = 2 * W;
+  const float sh = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
+  const float sw = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
+  auto weight = [](int o, float sc, int n, int i) -> float {        // weight of source index i in output index o, as the forward computes it
+    const float f = sc * (float)o;
+    int i0 = (int)f;
+    i0 = i0 < n - 1 ? i0 : n - 1;
+    const int i1 = i0 < n - 1 ? i0 + 1 : i0;
+    const float l = f - (float)i0;
+    return (i0 == i ? 1.f - l : 0.f) + (i1 == i ? l : 0.f);
+  };
+  const int oy_lo = sh > 0.f ? max(0, (int)floorf((iy - 1) / sh) - 1) : 0, oy_hi = sh > 0.f ? min(outH - 1, (int)ceilf((iy + 1) / sh) + 1) : outH - 1;
+  const int ox_lo = sw > 0.f ? max(0, (int)floorf((ix - 1) / sw) - 1) : 0, ox_hi = sw > 0.f ? min(outW - 1, (int)ceilf((ix + 1) / sw) + 1) : outW - 1;
+  float a = 0.f;
+  for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+    const float wy = weight(oy, sh, H, iy);
+    if (wy == 0.f) continue;
+    for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+      const float wx = weight(ox, sw, W, ix);
+      if (wx != 0.f) a += wy * wx * dy[(((int64_t)b * outH + oy) * outW + ox) * C + c];
+    }
+  }
+  dx[idx] = a;
+}
+
+// dust3r/heads/postprocess.py:10-58 (depth 'exp', conf 'exp' + 1): raw [M, 4] -> pts [M, 3] = xyz / |xyz| * expm1(|xyz|), conf = 1 + exp(c)
+__global__ __launch_bounds__(256) void postprocess_kernel(const float* __restrict__ raw, float* __restrict__ pts, float* __restrict__ conf, int64_t M) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= M) return;
+  const float4 v = reinterpret_cast<const float4*>(raw)[i];
+  const float d = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+  const float s = expm1f(d) / fmaxf(d, 1e-8f);
+  pts[3 * i] = v.x * s; pts[3 * i + 1] = v.y * s; pts[3 * i + 2] = v.z * s;
+  conf[i] = 1.0f + __expf(v.w);
+}
+__global__ __launch_bounds__(256) void postprocess_bwd_kernel(const float* __restrict__ raw, const float* __restrict__ dpts, const float* __restrict__ dconf,
+                                                              float* __restrict__ draw, int64_t M) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= M) return;
+  const float4 v = reinterpret_cast<const float4*>(raw)[i];
+  const float d = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z), dc = fmaxf(d, 1e-8f);
+  // pts = xyz * g(d), g = expm1(d) / d:  d pts = g dxyz + xyz g'(d) (xhat . dxyz), g' = (exp(d) d - expm1(d)) / d^2
+  const float g = expm1f(d) / dc, gp = d > 1e-8f ? (__expf(d) * d - expm1f(d)) / (d * d) : 0.5f;
+  const float gx = dpts[3 * i], gy = dpts[3 * i + 1], gz = dpts[3 * i + 2];
+  const float dot = (v.x * gx + v.y * gy + v.z * gz) * gp / dc;
+  float4 o;
+  o.x = g * gx + v.x * dot; o.y = g * gy + v.y * dot; o.z = g * gz + v.z * dot;
+  o.w = dconf[i] * __expf(v.w);
+  reinterpret_cast<float4*>(draw)[i] = o;
+}
+
 }  // namespace
 
 #define ST(s) reinterpret_cast<hipStream_t>(s)
@@ -179,5 +301,60 @@ extern "C" int sp3_layernorm_bwd(const float* x, int64_t ldx, const float* gamma
                      ld_add, dx, ld_dx, scratch, rows, C, eps);
   hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, ST(stream), scratch, nblk, C, dgamma, dbeta, accumulate);
   SP3_LAUNCH_CHECK("sp3_layernorm_bwd");
+  return 0;
+}
+
+
+extern "C" int sp3_im2col3x3(const float* x, float* col, int B, int H, int W, int C, int stride, void* stream) {
+  SP3_CHECK(x && col && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && (stride == 1 || stride == 2), "sp3_im2col3x3: bad arguments");
+  const int OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
+  const int64_t total4 = (int64_t)B * OH * OW * 9 * (C / 4);
+  hipLaunchKernelGGL(im2col3x3_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, ST(stream), x, col, H, W, C, OH, OW, stride, total4);
+  SP3_LAUNCH_CHECK("sp3_im2col3x3");
+  return 0;
+}
+
+extern "C" int sp3_col2im3x3(const float* dcol, float* dx, int B, int H, int W, int C, int stride, void* stream) {
+  SP3_CHECK(dcol && dx && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && (stride == 1 || stride == 2), "sp3_col2im3x3: bad arguments");
+  const int OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
+  const int64_t total4 = (int64_t)B * H * W * (C / 4);
+  hipLaunchKernelGGL(col2im3x3_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, ST(stream), dcol, dx, H, W, C, OH, OW, stride, total4);
+  SP3_LAUNCH_CHECK("sp3_col2im3x3");
+  return 0;
+}
+
+extern "C" int sp3_relu(const float* x, float* y, int64_t n, void* stream) {
+  SP3_CHECK(x && y && n > 0, "sp3_relu: bad arguments");
+  hipLaunchKernelGGL(relu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ST(stream), x, y, n);
+  SP3_LAUNCH_CHECK("sp3_relu");
+  return 0;
+}
+
+extern "C" int sp3_relu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream) {
+  SP3_CHECK(x && dy && dx && n > 0, "sp3_relu_bwd: bad arguments");
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ST(stream), x, dy, dx, n);
+  SP3_LAUNCH_CHECK("sp3_relu_bwd");
+  return 0;
+}
+
+extern "C" int sp3_upsample2x_bwd(const float* dy, float* dx, int B, int H, int W, int C, int outH, int outW, void* stream) {
+  SP3_CHECK(dy && dx && B > 0 && H > 0 && W > 0 && C > 0 && outH > 0 && outH <= 2 * H && outW > 0 && outW <= 2 * W, "sp3_upsample2x_bwd: bad arguments");
+  const int64_t total = (int64_t)B * H * W * C;
+  hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ST(stream), dy, dx, H, W, C, outH, outW, total);
+  SP3_LAUNCH_CHECK("sp3_upsample2x_bwd");
+  return 0;
+}
+
+extern "C" int sp3_postprocess(const float* raw, float* pts, float* conf, int64_t M, void* stream) {
+  SP3_CHECK(raw && pts && conf && M > 0 && (reinterpret_cast<uintptr_t>(raw) & 15) == 0, "sp3_postprocess: bad arguments");
+  hipLaunchKernelGGL(postprocess_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ST(stream), raw, pts, conf, M);
+  SP3_LAUNCH_CHECK("sp3_postprocess");
+  return 0;
+}
+
+extern "C" int sp3_postprocess_bwd(const float* raw, const float* dpts, const float* dconf, float* draw, int64_t M, void* stream) {
+  SP3_CHECK(raw && dpts && dconf && draw && M > 0, "sp3_postprocess_bwd: bad arguments");
+  hipLaunchKernelGGL(postprocess_bwd_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ST(stream), raw, dpts, dconf, draw, M);
+  SP3_LAUNCH_CHECK("sp3_postprocess_bwd");
   return 0;
 }

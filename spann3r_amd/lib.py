@@ -125,6 +125,13 @@ _PROTOS = {
     "sp3_transpose_batched": [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "sp3_gelu": [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
     "sp3_gelu_bwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
+    "sp3_im2col3x3": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "sp3_col2im3x3": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "sp3_relu": [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
+    "sp3_relu_bwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
+    "sp3_upsample2x_bwd": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "sp3_postprocess": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
+    "sp3_postprocess_bwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
     "sp3_mul": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
     "sp3_softmax_bwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_void_p],
     "sp3_layernorm_bwd": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,

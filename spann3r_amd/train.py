@@ -156,17 +156,17 @@ def _pad8(x):
 
 
 class _Linear(torch.autograd.Function):
-    """y = x W^T + b (+ res); x [R, K], W [N, K]"""
+    """y = x W^T + b (+ res) (+ res2); x [R, K], W [N, K]"""
 
     @staticmethod
-    def forward(ctx, x, W, b, res):
+    def forward(ctx, x, W, b, res, res2):
         R, K = x.shape
         N = W.shape[0]
         y = torch.empty(R, N, device=x.device)
         xp, Wp = _pad8(x), _pad8(W)
-        _nt(xp, Wp, R, N, xp.shape[1], xp.shape[1], Wp.shape[1], y, N, bias=b, res=res)
+        ops.gemm(xp, Wp, y, M=R, N=N, K=xp.shape[1], lda=xp.shape[1], ldc=N, ldw=Wp.shape[1], bias=b, res1=res, ldr1=N, res2=res2, ldr2=N)
         ctx.save_for_backward(x, W)
-        ctx.has = (b is not None, res is not None)
+        ctx.has = (b is not None, res is not None, res2 is not None)
         return y
 
     @staticmethod
@@ -187,12 +187,13 @@ class _Linear(torch.autograd.Function):
         if ctx.has[0] and ctx.needs_input_grad[2]:
             db = torch.zeros(N, device=dev)
             ops.colsum_accum(dy, N, R, N, db)
-        return dx, dW, db, (dy if ctx.has[1] else None)
+        return dx, dW, db, (dy if ctx.has[1] else None), (dy if ctx.has[2] else None)
 
 
-def linear(x, W, b=None, res=None):
+def linear(x, W, b=None, res=None, res2=None):
     sh = x.shape
-    y = _Linear.apply(x.reshape(-1, sh[-1]).contiguous(), W, b, None if res is None else res.reshape(-1, W.shape[0]).contiguous())
+    flat = lambda t: None if t is None else t.reshape(-1, W.shape[0]).contiguous()
+    y = _Linear.apply(x.reshape(-1, sh[-1]).contiguous(), W.contiguous(), b, flat(res), flat(res2))
     return y.reshape(*sh[:-1], W.shape[0])
 
 
@@ -333,3 +334,149 @@ def decoder_block(x, y, xpos, ypos, P, pre, heads, base=100.0, eps=1e-6):
     yn = layer_norm(y, P[pre + "norm_y.weight"], P[pre + "norm_y.bias"], eps)
     x = cross_attention(layer_norm(x, P[pre + "norm2.weight"], P[pre + "norm2.bias"], eps), yn, xpos, ypos, P, pre + "cross_attn.", heads, base, res=x)
     return mlp(layer_norm(x, P[pre + "norm3.weight"], P[pre + "norm3.bias"], eps), P, pre + "mlp.", res=x)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# DPT head in train mode (dust3r/heads/dpt_head.py:34-65, croco/models/dpt_block.py:120-218,356-410, postprocess.py:10-58)
+# on NHWC maps: every convolution is im2col (or a reshape) + the linear op above, so its backward is two GEMMs + col2im.
+class _Im2col3x3(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, stride):
+        B, H, W, C_ = x.shape
+        x = x.contiguous()
+        OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
+        col = torch.empty(B * OH * OW, 9 * C_, device=x.device)
+        L.check(L.load().sp3_im2col3x3(x.data_ptr(), col.data_ptr(), B, H, W, C_, stride, L.stream_ptr()), "sp3_im2col3x3")
+        ctx.geo = (B, H, W, C_, stride)
+        return col
+
+    @staticmethod
+    def backward(ctx, dcol):
+        B, H, W, C_, stride = ctx.geo
+        dcol = dcol.contiguous()
+        dx = torch.empty(B, H, W, C_, device=dcol.device)
+        L.check(L.load().sp3_col2im3x3(dcol.data_ptr(), dx.data_ptr(), B, H, W, C_, stride, L.stream_ptr()), "sp3_col2im3x3")
+        return dx, None
+
+
+class _Relu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        L.check(L.load().sp3_relu(x.data_ptr(), y.data_ptr(), x.numel(), L.stream_ptr()), "sp3_relu")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        L.check(L.load().sp3_relu_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), L.stream_ptr()), "sp3_relu_bwd")
+        return dx
+
+
+class _Upsample2x(torch.autograd.Function):
+    """F.interpolate(scale_factor=2, bilinear, align_corners=True) on NHWC, optionally cropped to (outH, outW)"""
+
+    @staticmethod
+    def forward(ctx, x, outH, outW):
+        B, H, W, C_ = x.shape
+        x = x.contiguous()
+        y = torch.empty(B, outH, outW, C_, device=x.device)
+        ops.upsample2x(x, y, B=B, H=H, W_=W, C_=C_, outH=outH, outW=outW)
+        ctx.geo = (B, H, W, C_, outH, outW)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, H, W, C_, outH, outW = ctx.geo
+        dy = dy.contiguous()
+        dx = torch.empty(B, H, W, C_, device=dy.device)
+        L.check(L.load().sp3_upsample2x_bwd(dy.data_ptr(), dx.data_ptr(), B, H, W, C_, outH, outW, L.stream_ptr()), "sp3_upsample2x_bwd")
+        return dx, None, None
+
+
+class _Postprocess(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, raw):
+        raw = raw.contiguous()
+        M = raw.numel() // 4
+        pts, conf = torch.empty(M, 3, device=raw.device), torch.empty(M, device=raw.device)
+        L.check(L.load().sp3_postprocess(raw.data_ptr(), pts.data_ptr(), conf.data_ptr(), M, L.stream_ptr()), "sp3_postprocess")
+        ctx.save_for_backward(raw)
+        return pts.reshape(*raw.shape[:-1], 3), conf.reshape(raw.shape[:-1])
+
+    @staticmethod
+    def backward(ctx, dpts, dconf):
+        (raw,) = ctx.saved_tensors
+        M = raw.numel() // 4
+        dpts = (torch.zeros(M, 3, device=raw.device) if dpts is None else dpts.contiguous())
+        dconf = (torch.zeros(M, device=raw.device) if dconf is None else dconf.contiguous())
+        draw = torch.empty_like(raw)
+        L.check(L.load().sp3_postprocess_bwd(raw.data_ptr(), dpts.data_ptr(), dconf.data_ptr(), draw.data_ptr(), M, L.stream_ptr()),
+                "sp3_postprocess_bwd")
+        return draw
+
+
+def conv3x3(x, W, b=None, stride=1, res=None, res2=None):
+    """x NHWC [B,H,W,Cin], W [Cout,Cin,3,3] (the reference's Conv2d layout), padding 1 -> [B,OH,OW,Cout]"""
+    B, H, Wd, Cin = x.shape
+    OH, OW = (H - 1) // stride + 1, (Wd - 1) // stride + 1
+    Wm = W.permute(0, 2, 3, 1).reshape(W.shape[0], 9 * Cin)
+    y = linear(_Im2col3x3.apply(x, stride), Wm, b, res, res2)
+    return y.reshape(B, OH, OW, W.shape[0])
+
+
+def conv1x1(x, W, b=None):
+    return linear(x, W.reshape(W.shape[0], -1), b)
+
+
+def conv_transpose_ks(x, W, b, k):
+    """ConvTranspose2d(kernel = stride = k): x NHWC [B,H,W,Cin], W [Cin,Cout,k,k] -> [B,kH,kW,Cout]"""
+    B, H, Wd, Cin = x.shape
+    Co = W.shape[1]
+    Wm = W.permute(2, 3, 1, 0).reshape(k * k * Co, Cin)
+    y = linear(x, Wm, b.repeat(k * k))
+    return y.reshape(B, H, Wd, k, k, Co).permute(0, 1, 3, 2, 4, 5).reshape(B, H * k, Wd * k, Co)
+
+
+def _rcu(x, P, p, res2=None):
+    """ResidualConvUnit_custom (dpt_block.py:120-142): conv2(relu(conv1(relu(x)))) + x (+ res2)"""
+    o = conv3x3(_Relu.apply(x), P[p + "conv1.weight"], P[p + "conv1.bias"])
+    return conv3x3(_Relu.apply(o), P[p + "conv2.weight"], P[p + "conv2.bias"], res=x, res2=res2)
+
+
+def _fusion(P, p, x0, x1=None, crop=None):
+    """FeatureFusionBlock_custom (dpt_block.py:190-218); the 1x1 out_conv is applied before the bilinear x2 (they commute)"""
+    out = x0 if x1 is None else _rcu(x1, P, p + "resConfUnit1.", res2=x0)
+    out = _rcu(out, P, p + "resConfUnit2.")
+    out = conv1x1(out, P[p + "out_conv.weight"], P[p + "out_conv.bias"])
+    H, W = out.shape[1:3]
+    oh, ow = (2 * H, 2 * W) if crop is None else crop
+    return _Upsample2x.apply(out, oh, ow)
+
+
+def dpt_head(dec, nh, nw, P, cfg, num):
+    """dec: list of dec_depth+1 token tensors [B, nh*nw, C] -> (pts3d [B,H,W,3], conf [B,H,W]); P holds the reference's
+    parameters under their own names (dust3r.downstream_head{num}.dpt.*)"""
+    p = "dust3r.downstream_head%d.dpt." % num
+    B = dec[0].shape[0]
+    Lr = [dec[h].reshape(B, nh, nw, -1) for h in cfg.hooks]
+    a = p + "act_postprocess."
+    l0 = conv_transpose_ks(conv1x1(Lr[0], P[a + "0.0.weight"], P[a + "0.0.bias"]), P[a + "0.1.weight"], P[a + "0.1.bias"], 4)
+    l1 = conv_transpose_ks(conv1x1(Lr[1], P[a + "1.0.weight"], P[a + "1.0.bias"]), P[a + "1.1.weight"], P[a + "1.1.bias"], 2)
+    l2 = conv1x1(Lr[2], P[a + "2.0.weight"], P[a + "2.0.bias"])
+    l3 = conv3x3(conv1x1(Lr[3], P[a + "3.0.weight"], P[a + "3.0.bias"]), P[a + "3.1.weight"], P[a + "3.1.bias"], stride=2)
+    rn = [conv3x3(l, P[p + "scratch.layer%d_rn.weight" % (i + 1)]) for i, l in enumerate((l0, l1, l2, l3))]
+    r = p + "scratch.refinenet"
+    p4 = _fusion(P, r + "4.", rn[3], crop=(nh, nw))
+    p3 = _fusion(P, r + "3.", p4, rn[2])
+    p2 = _fusion(P, r + "2.", p3, rn[1])
+    p1 = _fusion(P, r + "1.", p2, rn[0])
+    h = conv3x3(p1, P[p + "head.0.weight"], P[p + "head.0.bias"])
+    h = _Upsample2x.apply(h, 2 * h.shape[1], 2 * h.shape[2])
+    h = _Relu.apply(conv3x3(h, P[p + "head.2.weight"], P[p + "head.2.bias"]))
+    raw = conv1x1(h, P[p + "head.4.weight"], P[p + "head.4.bias"])
+    return _Postprocess.apply(raw)

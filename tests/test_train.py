@@ -116,3 +116,37 @@ def test_vit_blocks_forward_backward(cross):
     assert rel_err(res["hip"][0], res["ref"][0]) < 1e-5
     for k, v in res["ref"][1].items():
         assert rel_err(res["hip"][1][k], v) < 3e-4, (k, rel_err(res["hip"][1][k], v))
+
+
+@pytest.mark.gpu
+def test_dpt_head_train_forward_backward(tiny_sd):
+    """DPT head + postprocess in train mode (im2col + linear convolutions, bilinear adjoint, expm1 head) against the oracle's
+    downstream_head in float64 + autograd: outputs, gradients w.r.t. the four hooked decoder outputs and every head parameter"""
+    from spann3r_amd import train as T, TINY
+    from oracle import spann3r_oracle as O
+    cfg = TINY
+    B, nh, nw = 1, 3, 4
+    g = torch.Generator().manual_seed(2)
+    widths = [cfg.enc_dim] + [cfg.dec_dim] * cfg.dec_depth
+    dec0 = [torch.randn(B, nh * nw, w_, generator=g) for w_ in widths]
+    H, W = nh * cfg.patch, nw * cfg.patch
+    gp, gc = torch.randn(B, H, W, 3, generator=g), torch.randn(B, H, W, generator=g)
+    keys = [k for k in tiny_sd if k.startswith("dust3r.downstream_head1.dpt.")]
+    res = {}
+    for name, dt, dev in (("hip", torch.float32, "cuda"), ("ref", torch.float64, "cpu")):
+        P = {k: tiny_sd[k].to(dt).to(dev).requires_grad_(True) for k in keys}
+        dec = [d.to(dt).to(dev).requires_grad_(i in cfg.hooks) for i, d in enumerate(dec0)]
+        if name == "hip":
+            pts, conf = T.dpt_head(dec, nh, nw, P, cfg, 1)
+        else:
+            r = O.downstream_head(dec, torch.tensor([[H, W]] * B), P, cfg, 1)
+            pts, conf = r["pts3d"], r["conf"]
+        (pts * gp.to(dt).to(dev)).sum().add((conf * gc.to(dt).to(dev)).sum()).backward()
+        grads = {k: (None if v.grad is None else v.grad.cpu()) for k, v in P.items()}     # (refinenet4.resConfUnit1 is never used)
+        grads.update({"dec%d" % i: dec[i].grad.cpu() for i in cfg.hooks})
+        res[name] = (pts.detach().cpu(), conf.detach().cpu(), grads)
+    assert rel_err(res["hip"][0], res["ref"][0]) < 1e-4 and rel_err(res["hip"][1], res["ref"][1]) < 1e-4
+    assert {k for k, v in res["hip"][2].items() if v is None} == {k for k, v in res["ref"][2].items() if v is None}
+    worst = max((rel_err(res["hip"][2][k], v), k) for k, v in res["ref"][2].items() if v is not None)
+    print("DPT head gradients: worst rel err %.2e (%s) over %d tensors" % (worst[0], worst[1], len(res["ref"][2])))
+    assert worst[0] < 1e-3, worst
