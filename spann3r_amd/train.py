@@ -480,3 +480,109 @@ def dpt_head(dec, nh, nw, P, cfg, num):
     h = _Relu.apply(conv3x3(h, P[p + "head.2.weight"], P[p + "head.2.bias"]))
     raw = conv1x1(h, P[p + "head.4.weight"], P[p + "head.4.bias"])
     return _Postprocess.apply(raw)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Spann3R.forward in train mode (spann3r/model.py:473-539 with self.training: memory attn_thresh = 0, dropout on the read,
+# unconditional add_mem) assembled from the ops above: every arithmetic step of the forward and of the backward is a HIP
+# kernel; torch records the tape and moves tensors between layouts.
+def _positions(B, nh, nw, device):
+    ys, xs = torch.meshgrid(torch.arange(nh, device=device), torch.arange(nw, device=device), indexing="ij")
+    return torch.stack((ys.reshape(-1), xs.reshape(-1)), -1)[None].expand(B, -1, -1).contiguous()
+
+
+def _patchify(img, patch):
+    """[B, C, H, W] -> [B, nh*nw, C*patch*patch] in the element order of a Conv2d(k = s = patch) weight"""
+    B, C_, H, W = img.shape
+    nh, nw = H // patch, W // patch
+    return img.reshape(B, C_, nh, patch, nw, patch).permute(0, 2, 4, 1, 3, 5).reshape(B, nh * nw, C_ * patch * patch), nh, nw
+
+
+def encode_image(img, P, cfg):
+    """dust3r/model.py:131-154"""
+    x, nh, nw = _patchify(img.float(), cfg.patch)
+    W = P["dust3r.patch_embed.proj.weight"]
+    x = linear(x, W.reshape(W.shape[0], -1), P["dust3r.patch_embed.proj.bias"])
+    pos = _positions(img.shape[0], nh, nw, img.device)
+    for i in range(cfg.enc_depth):
+        x = block(x, pos, P, "dust3r.enc_blocks.%d." % i, cfg.enc_heads, cfg.rope_base)
+    return layer_norm(x, P["dust3r.enc_norm.weight"], P["dust3r.enc_norm.bias"], 1e-6), pos, (nh, nw)
+
+
+def decoder(f1, pos1, f2, pos2, P, cfg):
+    """dust3r/model.py:186-205"""
+    outs1, outs2 = [f1], [f2]
+    a = linear(f1, P["dust3r.decoder_embed.weight"], P["dust3r.decoder_embed.bias"])
+    b = linear(f2, P["dust3r.decoder_embed.weight"], P["dust3r.decoder_embed.bias"])
+    for i in range(cfg.dec_depth):
+        na = decoder_block(a, b, pos1, pos2, P, "dust3r.dec_blocks.%d." % i, cfg.dec_heads, cfg.rope_base)
+        nb = decoder_block(b, a, pos2, pos1, P, "dust3r.dec_blocks2.%d." % i, cfg.dec_heads, cfg.rope_base)
+        a, b = na, nb
+        outs1.append(a)
+        outs2.append(b)
+    outs1[-1] = layer_norm(outs1[-1], P["dust3r.dec_norm.weight"], P["dust3r.dec_norm.bias"], 1e-6)
+    outs2[-1] = layer_norm(outs2[-1], P["dust3r.dec_norm.weight"], P["dust3r.dec_norm.bias"], 1e-6)
+    return outs1, outs2
+
+
+def encode_feat_key(feat, dec_last, P, num):
+    """spann3r/model.py:299-303"""
+    p = "attn_head_%d." % num
+    x = torch.cat((feat, dec_last), dim=-1)
+    return linear(_Gelu.apply(linear(x, P[p + "0.weight"], P[p + "0.bias"])), P[p + "2.weight"], P[p + "2.bias"])
+
+
+def encode_cur_value(pts3d, feat_k, P, cfg):
+    """spann3r/model.py:305-320 (use_feat=False) -> cur_v + feat_k (the sum add_mem stores, :519)"""
+    x, nh, nw = _patchify(pts3d.permute(0, 3, 1, 2), cfg.patch)
+    W = P["pos_patch_embed.proj.weight"]
+    x = linear(x, W.reshape(W.shape[0], -1), P["pos_patch_embed.proj.bias"])
+    pos = _positions(pts3d.shape[0], nh, nw, pts3d.device)
+    for i in range(cfg.val_depth):
+        x = block(x, pos, P, "value_encoder.%d." % i, cfg.enc_heads, cfg.rope_base, use_rope=False)
+    x = layer_norm(x, P["value_norm.weight"], P["value_norm.bias"], 1e-6)
+    return linear(x, P["value_out.weight"], P["value_out.bias"], res=feat_k)
+
+
+def forward_train(P, frames, cfg, dropout_p=0.0, generator=None):
+    """-> (preds, preds_all) of Spann3R.forward in train mode.  P: {reference parameter name: tensor} (leaves of the tape);
+    frames: list of dicts with img [B,3,H,W] on the device (landscape or square; `true_shape` is not consulted: training
+    batches are rectified); dropout_p: spann3r/model.py:229 memory_dropout (0.15 in training), drawn from `generator`."""
+    mem_k = mem_v = None
+    feat2 = pos2 = feat_k2 = None
+    preds, preds_all = None, []
+    nq, nk, nv = (P["norm_q.weight"], P["norm_q.bias"]), (P["norm_k.weight"], P["norm_k.bias"]), (P["norm_v.weight"], P["norm_v.bias"])
+    for i in range(len(frames) - 1):
+        v1, v2 = frames[i], frames[i + 1]
+        if feat2 is None:
+            f, p, grid = encode_image(torch.cat((v1["img"], v2["img"]), 0), P, cfg)
+            (feat1, feat2), (pos1, pos2) = f.chunk(2, 0), p.chunk(2, 0)
+        else:
+            feat1, pos1 = feat2, pos2
+            feat2, pos2, grid = encode_image(v2["img"], P, cfg)
+        if feat_k2 is not None:
+            mask = None
+            if dropout_p > 0:
+                keep = torch.rand(feat_k2.shape[0], feat_k2.shape[1], mem_k.shape[1], device=feat_k2.device, generator=generator) >= dropout_p
+                mask = keep.float() / (1.0 - dropout_p)
+            feat_fuse = memory_read_train(feat_k2, mem_k, mem_v, nq, nk, nv, mask)
+        else:
+            feat_fuse = feat1
+        dec1, dec2 = decoder(feat_fuse, pos1, feat2, pos2, P, cfg)
+        feat_k1 = encode_feat_key(feat1, dec1[-1], P, 1)
+        feat_k2 = encode_feat_key(feat2, dec2[-1], P, 2)
+        pts1, conf1 = dpt_head(dec1, grid[0], grid[1], P, cfg, 1)
+        pts2, conf2 = dpt_head(dec2, grid[0], grid[1], P, cfg, 2)
+        v = encode_cur_value(pts1, feat_k1, P, cfg)
+        mem_k = feat_k1 if mem_k is None else torch.cat((mem_k, feat_k1), 1)
+        mem_v = v if mem_v is None else torch.cat((mem_v, v), 1)
+        res2 = {"pts3d_in_other_view": pts2, "conf": conf2}
+        if preds is None:
+            res1 = {"pts3d": pts1, "conf": conf1}
+            preds = [res1]
+        else:
+            res1 = {"pts3d_in_other_view": pts1, "conf": conf1}
+            preds.append(res1)
+        preds_all.append((res1, res2))
+    preds.append(res2)
+    return preds, preds_all

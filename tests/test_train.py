@@ -150,3 +150,56 @@ def test_dpt_head_train_forward_backward(tiny_sd):
     worst = max((rel_err(res["hip"][2][k], v), k) for k, v in res["ref"][2].items() if v is not None)
     print("DPT head gradients: worst rel err %.2e (%s) over %d tensors" % (worst[0], worst[1], len(res["ref"][2])))
     assert worst[0] < 1e-3, worst
+
+
+def _synth_gts(n, B, H, W, seed, dtype, device):
+    g = torch.Generator().manual_seed(seed)
+    gts = []
+    for i in range(n):
+        Q, _ = torch.linalg.qr(torch.randn(B, 3, 3, generator=g))
+        pose = torch.eye(4).repeat(B, 1, 1)
+        pose[:, :3, :3] = Q
+        pose[:, :3, 3] = torch.randn(B, 3, generator=g) * 0.3
+        pts = torch.randn(B, H, W, 3, generator=g) + torch.tensor([0.0, 0.0, 3.0])
+        valid = torch.rand(B, H, W, generator=g) < 0.85
+        gts.append(dict(pts3d=pts.to(dtype).to(device), valid_mask=valid.to(device), camera_pose=pose.to(dtype).to(device)))
+    return gts
+
+
+@pytest.mark.gpu
+def test_training_step_gradients_match_oracle(tiny_sd):
+    """A whole train-mode step on the tiny geometry (2 encoder / 10 decoder layers, full widths): Spann3R.forward in train mode
+    (spann3r/model.py:473-539) -> ConfLoss_t -> backward, every kernel HIP, against float64 autograd through the oracle's
+    forward + criterion: the loss and the gradient of EVERY parameter tensor."""
+    from spann3r_amd import train as T, TINY
+    from spann3r_amd.loss import ConfLoss_t, Regr3D_t, L21
+    from spann3r_amd.weights import synth_frames
+    from oracle import spann3r_oracle as O, loss_oracle as LO
+    n, B, H, W = 3, 1, 32, 48
+    frames = synth_frames(n, H, W, batch=B, seed=11)
+    # hip
+    P = {k: v.float().cuda().requires_grad_(True) for k, v in tiny_sd.items() if v.is_floating_point()}
+    preds, preds_all = T.forward_train(P, [{"img": f["img"].cuda()} for f in frames], TINY)
+    gts = _synth_gts(n, B, H, W, 5, torch.float32, "cuda")
+    loss, details, factor = ConfLoss_t(Regr3D_t(L21, norm_mode="avg_dis", fix_first=False), alpha=0.4).compute_frame_loss(gts, preds_all)
+    (loss + factor).backward()
+    # oracle, float64
+    P64 = {k: v.double().requires_grad_(True) for k, v in tiny_sd.items() if v.is_floating_point()}
+    _, pa64 = O.forward.__wrapped__([{"img": f["img"].double()} for f in frames], P64, TINY, training_policy=True)
+    l64, _, f64 = LO.conf_loss_t(_synth_gts(n, B, H, W, 5, torch.float64, "cpu"), pa64, 0.4, False)
+    (l64 + f64).backward()
+    assert abs(float(loss) + float(factor) - float(l64) - float(f64)) < 1e-4 * abs(float(l64))
+    assert rel_err(preds_all[-1][1]["pts3d_in_other_view"].detach().cpu(), pa64[-1][1]["pts3d_in_other_view"].detach()) < 1e-4
+    gmax = max(float(v.grad.abs().max()) for v in P64.values() if v.grad is not None)
+    worst, n_checked = (0.0, None), 0
+    for k, v in P64.items():
+        if v.grad is None:
+            assert P[k].grad is None or float(P[k].grad.abs().max()) < 1e-6 * gmax, k
+            continue
+        e = float((P[k].grad.cpu().double() - v.grad).abs().max()) / max(float(v.grad.abs().max()), 1e-4 * gmax)
+        n_checked += 1
+        if e > worst[0]:
+            worst = (e, k)
+    print("training step: loss %.6f (oracle %.6f), %d parameter gradients, worst scaled error %.2e (%s)" %
+          (float(loss) + float(factor), float(l64) + float(f64), n_checked, worst[0], worst[1]))
+    assert worst[0] < 2e-3, worst
