@@ -372,6 +372,10 @@ int sp3_relu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* st
 int sp3_upsample2x_bwd(const float* dy, float* dx, int B, int H, int W, int C, int outH, int outW, void* stream);
 int sp3_postprocess(const float* raw, float* pts, float* conf, int64_t M, void* stream);
 int sp3_postprocess_bwd(const float* raw, const float* dpts, const float* dconf, float* draw, int64_t M, void* stream);
+/* torch.optim.AdamW update of one parameter tensor (spann3r/training.py:327; decoupled weight decay, bias correction for `step` >= 1);
+ * the gradient is multiplied by grad_scale first (1 / accum_iter, or the clip coefficient of clip_grad_norm_, croco/utils/misc.py:274). */
+int sp3_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+              int step, float grad_scale, void* stream);
 int sp3_mul(const float* a, const float* b, float* out, int64_t n, void* stream);
 int sp3_softmax_bwd(const float* A, const float* dAd, const float* mask, float* dS, int64_t ld, int rows, int T, float alpha, void* stream);
 int sp3_layernorm_bwd(const float* x, int64_t ldx, const float* gamma, const float* dy, int64_t ldy, const float* dx_add, int64_t ld_add,

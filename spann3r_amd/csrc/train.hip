@@ -241,6 +241,21 @@ __global__ __launch_bounds__(256) void postprocess_bwd_kernel(const float* __res
   reinterpret_cast<float4*>(draw)[i] = o;
 }
 
+// torch.optim.AdamW (the optimizer of spann3r/training.py:327), one parameter tensor per launch, decoupled weight decay:
+//   p *= 1 - lr wd;  m = b1 m + (1 - b1) g;  v = b2 v + (1 - b2) g^2;  p -= lr / bc1 * m / (sqrt(v) / sqrt(bc2) + eps)
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                    int64_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float rsbc2,
+                                                    float gscale) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i] * gscale;
+  float pi = p[i] * (1.0f - lr * wd);
+  const float mi = b1 * m[i] + (1.0f - b1) * gi;
+  const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+  pi -= (lr / bc1) * mi / (sqrtf(vi) * rsbc2 + eps);
+  p[i] = pi; m[i] = mi; v[i] = vi;
+}
+
 }  // namespace
 
 #define ST(s) reinterpret_cast<hipStream_t>(s)
@@ -356,5 +371,16 @@ extern "C" int sp3_postprocess_bwd(const float* raw, const float* dpts, const fl
   SP3_CHECK(raw && dpts && dconf && draw && M > 0, "sp3_postprocess_bwd: bad arguments");
   hipLaunchKernelGGL(postprocess_bwd_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ST(stream), raw, dpts, dconf, draw, M);
   SP3_LAUNCH_CHECK("sp3_postprocess_bwd");
+  return 0;
+}
+
+
+extern "C" int sp3_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                         int step, float grad_scale, void* stream) {
+  SP3_CHECK(p && g && m && v && n > 0 && step >= 1, "sp3_adamw: bad arguments");
+  const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ST(stream), p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
+                     bc1, 1.0f / sqrtf(bc2), grad_scale);
+  SP3_LAUNCH_CHECK("sp3_adamw");
   return 0;
 }

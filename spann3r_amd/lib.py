@@ -132,6 +132,8 @@ _PROTOS = {
     "sp3_upsample2x_bwd": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "sp3_postprocess": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
     "sp3_postprocess_bwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
+    "sp3_adamw": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int,
+                  C.c_float, C.c_void_p],
     "sp3_mul": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
     "sp3_softmax_bwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_void_p],
     "sp3_layernorm_bwd": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,

@@ -940,8 +940,23 @@ class Spann3R(nn.Module):
             self._pinned = None
 
     # ------------------------------------------------------------------ forward (:473-539)
-    @torch.no_grad()
     def forward(self, frames, return_memory=False):
+        if self.training and self.mem_dropout.training and torch.is_grad_enabled():
+            # a training step (train.py / spann3r/training.py:216): the autograd-recording forward of spann3r_amd/train.py --
+            # memory attn_thresh = 0, dropout on the read, unconditional add_mem; HIP forward AND backward kernels.
+            # (model.train() with model.mem_dropout.eval() keeps selecting the forward-only growing-bank policy below.)
+            if return_memory:
+                raise NotImplementedError("return_memory in a training step (the memory is a list of tape tensors there)")
+            if not frames[0]["img"].is_cuda:
+                raise RuntimeError("spann3r_amd runs on an MI355X (HIP kernels); there is no CPU path -- move the frames to the GPU")
+            from . import train as T
+            P = {k: v for k, v in self.state_dict(keep_vars=True).items() if v.is_floating_point()}
+            p_drop = self.mem_dropout.p if self.mem_dropout.training else 0.0
+            return T.forward_train(P, frames, self.cfg, dropout_p=p_drop)
+        with torch.no_grad():
+            return self._forward_inference(frames, return_memory)
+
+    def _forward_inference(self, frames, return_memory):
         if self.training and self.mem_dropout.training and self.mem_dropout.p > 0:
             # train-mode memory policy needs a dropout mask on the attention (spann3r/model.py:167-168); the
             # forward-only build runs it with dropout disabled, the same idiom the survey probe used on the reference

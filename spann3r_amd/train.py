@@ -586,3 +586,29 @@ def forward_train(P, frames, cfg, dropout_p=0.0, generator=None):
         preds_all.append((res1, res2))
     preds.append(res2)
     return preds, preds_all
+
+
+class AdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW(params, lr, betas, eps, weight_decay) with the update in a HIP kernel (sp3_adamw), the optimizer of
+    spann3r/training.py:327.  `step(grad_scale=...)` multiplies every gradient first (gradient clipping / accumulation)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale=1.0):
+        lib = L.load()
+        for gr in self.param_groups:
+            b1, b2 = gr["betas"]
+            for p in gr["params"]:
+                if p.grad is None:
+                    continue
+                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+                    raise RuntimeError("AdamW (HIP): fp32 contiguous parameters on the GPU")
+                st = self.state[p]
+                if not st:
+                    st["step"], st["m"], st["v"] = 0, torch.zeros_like(p), torch.zeros_like(p)
+                st["step"] += 1
+                g = p.grad.contiguous()
+                L.check(lib.sp3_adamw(p.data_ptr(), g.data_ptr(), st["m"].data_ptr(), st["v"].data_ptr(), p.numel(), float(gr["lr"]), b1, b2,
+                                      float(gr["eps"]), float(gr["weight_decay"]), st["step"], float(grad_scale), L.stream_ptr()), "sp3_adamw")
