@@ -8,8 +8,6 @@ The forward and the backward run in the HIP kernels of csrc/loss.hip (sp3_conf_l
 buffers; torch only stacks the per-frame tensors, owns the autograd edge back to the predictions and computes the two
 unmasked `conf_left / conf_right` monitoring means.  Supported: L21, norm_mode 'avg_dis', gt_scale False -- the
 configuration the reference trains with; anything else raises NotImplementedError.  There is no CPU path."""
-import ctypes as C
-
 import torch
 
 from . import lib as L

@@ -11,7 +11,6 @@ ground-truth poses of synthetic scenes with gross outliers and against its own n
 WITH OPENCV IS UNPINNED (no cv2 to compare with): expect the same pose up to the noise of the inlier set, not bit parity."""
 import json
 import math
-import struct
 
 import numpy as np
 import torch

@@ -1,7 +1,6 @@
 """Training criterion: the CPU oracle against the golden dump of the unmodified reference
 (tests/golden/loss_conf.npz: loss, details, factor loss, autograd gradients), and the HIP forward / backward against the
 oracle (float64 + autograd) on the same seeded inputs."""
-import numpy as np
 import pytest
 import torch
 

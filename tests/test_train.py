@@ -72,7 +72,6 @@ def test_memory_read_train_forward_backward(B, P, T, C, drop):
 
 
 def _block_params(C, seed, cross, dtype, device):
-    from spann3r_amd.weights import hash_uniform          # any deterministic source will do; plain seeded randn here
     g = torch.Generator().manual_seed(seed)
     rn = lambda *s: torch.randn(*s, generator=g)
     P = {}
