@@ -216,10 +216,10 @@ def downstream_head(dec, true_shape, sd, cfg, num):
 
 
 def encode_cur_value(pts3d, sd, cfg):
-    """spann3r/model.py:305-320 (use_feat=False, mem_pos_enc=False -> no RoPE in the value encoder)."""
+    """spann3r/model.py:305-320 (use_feat=False; RoPE in the value encoder only with mem_pos_enc, :232-234)."""
     x, pos = patch_embed(pts3d.permute(0, 3, 1, 2), sd, "pos_patch_embed.", cfg.patch)
     for i in range(cfg.val_depth):
-        x = block(x, pos, sd, "value_encoder.%d." % i, cfg.enc_heads, cfg.rope_base, use_rope=False)
+        x = block(x, pos, sd, "value_encoder.%d." % i, cfg.enc_heads, cfg.rope_base, use_rope=getattr(cfg, "mem_pos_enc", False))
     x = layer_norm(x, sd["value_norm.weight"], sd["value_norm.bias"], 1e-6)
     return F.linear(x, sd["value_out.weight"], sd["value_out.bias"])
 

@@ -23,6 +23,7 @@ class Spann3RConfig:
     dpt_feat: int = 256      # dust3r/heads/dpt_head.py:101
     dpt_last: int = 128      # feature_dim // 2
     key_dim: int = 1792      # enc_dim + dec_dim (spann3r/model.py:250)
+    mem_pos_enc: bool = False  # Spann3R(mem_pos_enc=True): RoPE in the value-encoder blocks (spann3r/model.py:232-234)
 
     @property
     def head_dim(self):

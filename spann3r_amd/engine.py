@@ -632,12 +632,12 @@ class Engine:
         nh, nw = H // p, W_ // p
         P = nh * nw
         R = B * P
-        _, _, zero_pos = self.positions(B, nh, nw)
+        _, pos32, zero_pos = self.positions(B, nh, nw)
         col = self.wsp("im2col_val", R, 3 * p * p)
         sb, sy, sx, sc = pts3d.stride()
         ops.im2col_patch(pts3d, col, B=B, C_=3, H=H, W_=W_, p=p, strides=(sb, sc, sy, sx))
-        # rope=None in the reference (mem_pos_enc=False): all-zero positions make the fused RoPE the identity
-        x, xp, st = self._vit(col, R, B, P, "pospatch", "val", cfg.val_depth, zero_pos, tag="_val")
+        # rope=None in the reference unless mem_pos_enc (spann3r/model.py:232-234): all-zero positions make the fused RoPE the identity
+        x, xp, st = self._vit(col, R, B, P, "pospatch", "val", cfg.val_depth, pos32 if cfg.mem_pos_enc else zero_pos, tag="_val")
         # value_norm folded into value_out; + feat_k1 in the epilogue
         ops.gemm(xp, w["value_out.w"], out, M=R, N=E, K=E, lda=E, ldc=E, bias=w["value_out.b"], res1=res, ldr1=E,
                  ln=ops.LnFold(st, E, w["value_out.s"], 1e-6))

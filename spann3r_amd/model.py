@@ -667,8 +667,6 @@ class Spann3R(nn.Module):
         if use_feat:
             raise NotImplementedError("use_feat=True (value encoder on 768-d decoder features, 48-d heads) is not on the "
                                       "hot path the MI355X build covers; demo/eval/app all use use_feat=False")
-        if mem_pos_enc:
-            raise NotImplementedError("mem_pos_enc=True is not used by any reference entry point")
         self.use_feat = use_feat
         self.mem_pos_enc = mem_pos_enc
         # spann3r/model.py:248: only its .training flag and p matter for the forward-only build
@@ -684,6 +682,9 @@ class Spann3R(nn.Module):
             ckpt = torch.load(dus3r_name, map_location="cpu", weights_only=True)
             cfg = Spann3RConfig.from_ctor_string(ckpt["args"].model)
         self.cfg = cfg or FULL
+        if mem_pos_enc != self.cfg.mem_pos_enc:
+            import dataclasses
+            self.cfg = dataclasses.replace(self.cfg, mem_pos_enc=bool(mem_pos_enc))
         self.add_module("dust3r", _Dust3RFacade(self))       # the parameter tree below hangs the DUSt3R weights into it
         self._params = _build_param_tree(self, param_spec(self.cfg))
         # no network: without a checkpoint file the weights are seeded synthetic ones

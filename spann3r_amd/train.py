@@ -539,7 +539,7 @@ def encode_cur_value(pts3d, feat_k, P, cfg):
     x = linear(x, W.reshape(W.shape[0], -1), P["pos_patch_embed.proj.bias"])
     pos = _positions(pts3d.shape[0], nh, nw, pts3d.device)
     for i in range(cfg.val_depth):
-        x = block(x, pos, P, "value_encoder.%d." % i, cfg.enc_heads, cfg.rope_base, use_rope=False)
+        x = block(x, pos, P, "value_encoder.%d." % i, cfg.enc_heads, cfg.rope_base, use_rope=cfg.mem_pos_enc)
     x = layer_norm(x, P["value_norm.weight"], P["value_norm.bias"], 1e-6)
     return linear(x, P["value_out.weight"], P["value_out.bias"], res=feat_k)
 

@@ -40,13 +40,13 @@ from spann3r_amd.weights import (synth_state_dict, synth_frames, state_dict_fing
                                  hash_uniform, _stream_id)
 
 
-def build_reference(cfg, sd, tag):
+def build_reference(cfg, sd, tag, mem_pos_enc=False):
     """Instantiate the reference through its real loader (dust3r/model.py:27-51)."""
     from spann3r.model import Spann3R
     path = "/tmp/golden_dust3r_%s.pth" % tag
     torch.save({"args": argparse.Namespace(model=cfg.ctor_string()),
                 "model": {k[len("dust3r."):]: v for k, v in sd.items() if k.startswith("dust3r.")}}, path)
-    m = Spann3R(dus3r_name=path, use_feat=False)
+    m = Spann3R(dus3r_name=path, use_feat=False, mem_pos_enc=mem_pos_enc)
     missing = m.load_state_dict(sd, strict=True)
     print(missing)
     os.remove(path)
@@ -160,6 +160,14 @@ def make_tiny():
         out["train_pred%d_pts" % j] = npf(p["pts3d" if j == 0 else "pts3d_in_other_view"])
         out["train_pred%d_conf" % j] = npf(p["conf"])
     out["train_mem_attn"] = npf(sp_t.mem_attn)
+    # Spann3R(mem_pos_enc=True): RoPE inside the value encoder (spann3r/model.py:232-234): final predictions + memory values
+    m3 = build_reference(cfg, sd, "tiny", mem_pos_enc=True)
+    with torch.no_grad():
+        preds_p, _, sp_p = m3(frames, return_memory=True)
+    for j, p in enumerate(preds_p):
+        out["mpe_pred%d_pts" % j] = npf(p["pts3d" if j == 0 else "pts3d_in_other_view"])
+        out["mpe_pred%d_conf" % j] = npf(p["conf"])
+    out["mpe_mem_v"] = npf(sp_p.mem_v)
     np.savez_compressed(os.path.join(HERE, "spann3r_tiny.npz"), **out)
     print("tiny: %d arrays" % len(out))
 

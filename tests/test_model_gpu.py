@@ -102,6 +102,27 @@ def test_tiny_forward_vs_golden(tiny_model, precision, tol):
         assert [mem.wm, mem.lm] == list(g["mem_wm_lm"])
 
 
+@pytest.mark.parametrize("precision,tol", [("fp32", TOL_FP32), ("bf16", TOL_BF16)])
+def test_tiny_mem_pos_enc_vs_golden(tiny_sd, precision, tol):
+    """Spann3R(mem_pos_enc=True) (spann3r/model.py:232-234: RoPE in the value encoder) against the reference dump"""
+    from spann3r_amd import Spann3R, TINY
+    from spann3r_amd.weights import synth_frames
+    g = load_golden("spann3r_tiny.npz")
+    H, W = map(int, g["meta_hw"])
+    m = Spann3R(dus3r_name=None, cfg=TINY, init_weights=False, mem_pos_enc=True)
+    m.load_state_dict(tiny_sd, strict=True)
+    m = m.to(DEV).eval().set_precision(precision)
+    assert m.cfg.mem_pos_enc
+    preds, _, mem = m(to_dev(synth_frames(int(g["meta_frames"]), H, W)), return_memory=True)
+    worst = 0.0
+    for j, p in enumerate(preds):
+        worst = max(worst, rel_err(p["pts3d" if j == 0 else "pts3d_in_other_view"].cpu(), g["mpe_pred%d_pts" % j]),
+                    rel_err(p["conf"].cpu(), g["mpe_pred%d_conf" % j]))
+    assert worst < tol, worst
+    if precision == "fp32":
+        assert rel_err(mem.mem_v.cpu(), g["mpe_mem_v"]) < tol
+
+
 def test_graph_replay_equals_eager(tiny_model):
     """1st call of a geometry runs eagerly, 2nd captures + replays hipGraphs, 3rd replays: all bit-identical,
     and identical to use_graphs=False (same kernels, same order)."""

@@ -57,6 +57,19 @@ def test_tiny_training_policy(tiny_sd):
     assert rel_err(mem.mem_attn, g["train_mem_attn"]) < 1e-4
 
 
+def test_tiny_mem_pos_enc(tiny_sd):
+    """Spann3R(mem_pos_enc=True): RoPE inside the value-encoder blocks (spann3r/model.py:232-234)"""
+    import dataclasses
+    g = load_golden("spann3r_tiny.npz")
+    H, W = map(int, g["meta_hw"])
+    frames = synth_frames(int(g["meta_frames"]), H, W)
+    preds, _, mem = O.forward(frames, tiny_sd, dataclasses.replace(TINY, mem_pos_enc=True), return_memory=True)
+    for j, p in enumerate(preds):
+        assert rel_err(p["pts3d" if j == 0 else "pts3d_in_other_view"], g["mpe_pred%d_pts" % j]) < TOL
+        assert rel_err(p["conf"], g["mpe_pred%d_conf" % j]) < TOL
+    assert rel_err(mem.mem_v, g["mpe_mem_v"]) < TOL and rel_err(mem.mem_v, g["mem_v"]) > 1e-2       # (it does change the values)
+
+
 def test_memory_bank(tiny_sd):
     """Stand-alone SpatialMemory: similarity skips, working->long-term hand-over, one prune."""
     import importlib.util, os
