@@ -141,6 +141,10 @@ typedef struct sp3_gemm_desc {
   int32_t sm_nt;
   float sm_thresh;
   float* sm_zout;
+  /* --- fp32 operands (wdtype SP3_F32, A fp32), register-ring tiles 0-3: products through three bf16 MFMAs per k-block
+   *   (hi.hi + hi.lo + lo.hi of a bf16 split of both operands: 16 mantissa bits per product, fp32 accumulate) instead of the
+   *   fp32 MFMA -- 2-3x the matrix rate, the "f32x3" precision mode of the model.  Ignored for bf16 operands. */
+  int32_t f32x3;
 } sp3_gemm_desc;
 int sp3_gemm(const sp3_gemm_desc* desc_host, void* stream);
 /* Two differently shaped groups of problems in ONE launch (grid.y = a.batch + b.batch), e.g. a decoder layer's self-attention

@@ -189,6 +189,36 @@ template <> struct MM<float, float> {
       }
     }
   }
+  // f32x3: the 8 fp32 values a lane holds of a k-block are split into bf16 (hi, lo) pairs and the block's product is three
+  // v_mfma_f32_16x16x32_bf16 (hi.hi + hi.lo + lo.hi; the dropped lo.lo term is 2^-16 relative) instead of eight
+  // v_mfma_f32_16x16x4_f32: products carry 16 mantissa bits (TF32, which the reference enables on its own GPUs, carries 10),
+  // accumulation stays fp32.  The fp32 MFMA rate, not the bytes, bounds the fp32 GEMMs of the per-frame step.
+  static __device__ __forceinline__ void split8(const float4& x0, const float4& x1, bf16x8& hi, bf16x8& lo) {
+    const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const __bf16 h = (__bf16)x[e];
+      hi[e] = h;
+      lo[e] = (__bf16)(x[e] - (float)h);
+    }
+  }
+  template <int MF, int NF>
+  static __device__ __forceinline__ void mma_x3(f32x4 (&acc)[MF][NF], const AReg (&a)[MF], const WReg (&w)[NF]) {
+    bf16x8 wh[NF], wl[NF];
+#pragma unroll
+    for (int n = 0; n < NF; ++n) split8(w[n].v[0], w[n].v[1], wh[n], wl[n]);
+#pragma unroll
+    for (int m = 0; m < MF; ++m) {
+      bf16x8 ah, al;
+      split8(a[m].v[0], a[m].v[1], ah, al);
+#pragma unroll
+      for (int n = 0; n < NF; ++n) {
+        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wh[n], acc[m][n], 0, 0, 0);
+        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wl[n], acc[m][n], 0, 0, 0);
+        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wh[n], acc[m][n], 0, 0, 0);
+      }
+    }
+  }
   template <int MF, int NF>
   static __device__ __forceinline__ void mma_half(f32x4 (&acc)[MF][NF], const AReg (&a)[MF], const WReg (&w)[NF]) {
 #pragma unroll
@@ -472,6 +502,7 @@ void gemm_kernel(const GemmArgs args) {
   const int kb_lo = kz * per;
   const int kb_hi = (kb_lo + per) < nkb_all ? (kb_lo + per) : nkb_all;
   const bool relu = d.relu_in != 0;
+  const bool x3 = d.f32x3 != 0;              // (fp32 operands only; register-ring tiles)
 
   typename M_::AReg a[STAGES][MF];
   typename M_::WReg w[STAGES][NF];
@@ -529,6 +560,9 @@ void gemm_kernel(const GemmArgs args) {
     if (!FULL) {
 #pragma unroll
       for (int n = 0; n < NF; ++n) M_::fixW(w[st][n], wm0[st], wm1[st]);
+    }
+    if constexpr (sizeof(TA) == 4 && sizeof(TW) == 4 && MF * NF <= 8) {      // (the 4x4-fragment fp32 tile has no registers to spare)
+      if (x3) { M_::template mma_x3<MF, NF>(acc, a[st], w[st]); return; }
     }
     M_::template mma<MF, NF>(acc, a[st], w[st]);
   };

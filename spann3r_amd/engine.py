@@ -29,11 +29,12 @@ def _rope_tables(max_pos, base, device):
 
 class Engine:
     def __init__(self, cfg: Spann3RConfig, params: dict, device, precision="fp32"):
-        assert precision in ("fp32", "bf16")
+        assert precision in ("fp32", "f32x3", "bf16")
         self.cfg = cfg
         self.device = torch.device(device)
         self.precision = precision
-        self.wdt = torch.float32 if precision == "fp32" else torch.bfloat16
+        # "f32x3": fp32 weights and activations, GEMM products through three bf16 MFMAs (ops.F32X3, set by the model)
+        self.wdt = torch.bfloat16 if precision == "bf16" else torch.float32
         self.adt = self.wdt          # dtype of activations that only feed GEMMs
         import os
         self.packed_attn = precision == "bf16"      # fragment-order q/k/v + wave-split attention kernel

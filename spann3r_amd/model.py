@@ -726,7 +726,10 @@ class Spann3R(nn.Module):
 
     # ------------------------------------------------------------------ engine management
     def set_precision(self, precision):
-        assert precision in ("fp32", "bf16")
+        """'fp32': fp32 operands, fp32 MFMA (exact fp32 products; the strictest parity mode).  'f32x3': fp32 operands, every
+        GEMM product through three bf16 MFMAs of a (hi, lo) split (16 mantissa bits per product -- TF32, which the reference
+        enables on its own GPUs, has 10 -- fp32 accumulation): the fast parity mode.  'bf16': bf16 operands (benchmark mode)."""
+        assert precision in ("fp32", "f32x3", "bf16")
         self.precision = precision
         return self
 
@@ -966,10 +969,12 @@ class Spann3R(nn.Module):
         self._pinned = None
         eng = self.engine
         self._pinned = eng
+        prev, ops.F32X3 = ops.F32X3, self.precision == "f32x3"     # read when a GEMM descriptor is filled (also at graph capture)
         try:
             return self._forward(eng, frames, return_memory)
         finally:
             self._pinned = None
+            ops.F32X3 = prev
 
     def _uniform_true_hw(self, frames):
         """(true_h, true_w) if every frame carries the same image shape and the same true_shape for the whole batch

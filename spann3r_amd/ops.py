@@ -301,11 +301,15 @@ class PackedWeightGroup(PackedWeight):
         self.stride = items[0].data.numel()
 
 
+F32X3 = False        # fp32 GEMMs through three bf16 MFMAs per k-block (sp3_gemm_desc.f32x3); set by the model's "f32x3" precision
+
+
 def _w(d, W):
     """fills the W fields of a GemmDesc from a tensor or a PackedWeight"""
     d.W = W.data_ptr()
     d.w_packed = int(isinstance(W, PackedWeight))
     d.wdtype = wdtype_of(W)
+    d.f32x3 = int(F32X3 and d.wdtype == F32)
 
 
 class LnFold:

@@ -747,6 +747,36 @@ def test_paired_launch_equals_two_launches(dt):
             pass
 
 
+def test_gemm_f32x3_products():
+    """fp32 operands through three bf16 MFMAs per k-block (sp3_gemm_desc.f32x3): ~16 mantissa bits per product, fp32 accumulate"""
+    ops = _ops()
+    M, N, K = 196, 768, 1024
+    A, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2) * 0.05, rnd(N, seed=3)
+    ref = A.double() @ W.double().T + b.double()
+    outs = {}
+    for x3 in (False, True):
+        ops.F32X3 = x3
+        try:
+            for tile in (0, 1):
+                out = torch.empty(M, N, device=DEV)
+                ops.gemm(A.to(DEV), W.to(DEV), out, M=M, N=N, K=K, lda=K, ldc=N, bias=b.to(DEV), tile=tile)
+                outs[(x3, tile)] = rel_err(out.cpu(), ref)
+        finally:
+            ops.F32X3 = False
+    assert max(outs[(False, 0)], outs[(False, 1)]) < 2e-6                      # exact fp32 products
+    assert 2e-6 < max(outs[(True, 0)], outs[(True, 1)]) < 3e-5, outs            # 2^-16-class products, far inside TF32's 5e-4
+    # bf16 operands are untouched by the switch
+    ops.F32X3 = True
+    try:
+        o1, o2 = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+        ops.gemm(A.to(DEV).to(torch.bfloat16), W.to(DEV).to(torch.bfloat16), o1, M=M, N=N, K=K, lda=K, ldc=N)
+        ops.F32X3 = False
+        ops.gemm(A.to(DEV).to(torch.bfloat16), W.to(DEV).to(torch.bfloat16), o2, M=M, N=N, K=K, lda=K, ldc=N)
+    finally:
+        ops.F32X3 = False
+    assert torch.equal(o1, o2)
+
+
 def test_cos_sim_append_prune_gather():
     ops = _ops()
     T, P, C = 3, 50, 1024
