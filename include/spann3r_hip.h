@@ -208,6 +208,8 @@ int sp3_rope_2d(void* tokens, int dtype, int B, int N, int H, int D, int64_t sB,
  * (croco/models/blocks.py:105-109 and 162-166).  q [B,Nq,heads,64] / k [B,Nk,heads,64] with row
  * strides ldq/ldk and batch strides sq/sk (elements, `dtype`), already RoPE'd; vt as written by
  * the ROPE_VT epilogue; out fp32 (or bf16 if out_bf16) [B*Nq, ldo] with head h at columns [64h, 64h+64).
+ * dtype: SP3_F32 | SP3_BF16 | 2 = fp32 operands with every product through three bf16 MFMAs of a (hi, lo) split (the
+ * "f32x3" precision of the model: 16 mantissa bits per product, fp32 softmax and accumulation).
  */
 int sp3_attention(const void* q, int64_t sq, int64_t ldq, const void* k, int64_t sk, int64_t ldk,
                   const void* vt, int64_t vt_ld, void* out, int64_t ldo, int out_bf16,

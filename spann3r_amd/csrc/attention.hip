@@ -18,6 +18,7 @@ namespace {
 template <typename T> struct AttnT;
 
 template <> struct AttnT<__bf16> {
+  using Store = __bf16;
   // ---- S^T block: 16 keys x 16 queries, contraction over d = 64 in two MFMAs
   struct QReg { bf16x8 v[2]; };
   static __device__ __forceinline__ void loadQ(QReg& r, const __bf16* row, int g) {
@@ -55,6 +56,7 @@ template <> struct AttnT<__bf16> {
 };
 
 template <> struct AttnT<float> {
+  using Store = float;
   struct QReg { float4 v[4]; };
   static __device__ __forceinline__ void loadQ(QReg& r, const float* row, int g) {
     const float4* p = reinterpret_cast<const float4*>(row + 16 * g);
@@ -92,13 +94,75 @@ template <> struct AttnT<float> {
 // One workgroup = 16 query rows of one head; its 4 waves split the 64-key tiles (tile t goes to wave t & 3), each with its own
 // online softmax; the partial (m, l, O^T) states are merged through LDS (wave w finishes d-block w) -- at N = 196 every wave
 // has ONE tile, so the dependent chain is 1 tile instead of 4 (fp32 mode: 21 -> 8 us per launch).
-template <typename T>
-__global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ Q, int64_t sq, int64_t ldq,
-                                                       const T* __restrict__ K, int64_t sk, int64_t ldk,
-                                                       const T* __restrict__ VT, int64_t vt_ld, void* __restrict__ O,
+// fp32 operands, every product through three bf16 MFMAs of a (hi, lo) split (the model's "f32x3" precision, see gemm.hip)
+struct F32X3 {};
+__device__ __forceinline__ void split8f(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const __bf16 h = (__bf16)x[e];
+    hi[e] = h;
+    lo[e] = (__bf16)(x[e] - (float)h);
+  }
+}
+__device__ __forceinline__ f32x4 mfma3(const bf16x8& ah, const bf16x8& al, const bf16x8& bh, const bf16x8& bl, f32x4 c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+}
+template <> struct AttnT<F32X3> {
+  using Store = float;
+  struct QReg { bf16x8 h[2], l[2]; };                       // d = 16g .. 16g+15 of the head, split once per workgroup
+  static __device__ __forceinline__ void loadQ(QReg& r, const float* row, int g) {
+    const float4* p = reinterpret_cast<const float4*>(row + 16 * g);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const float4 a = p[2 * u], b = p[2 * u + 1];
+      const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      split8f(x, r.h[u], r.l[u]);
+    }
+  }
+  static __device__ __forceinline__ f32x4 qk(const float* krow, int g, const QReg& q) {
+    const float4* p = reinterpret_cast<const float4*>(krow + 16 * g);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const float4 a = p[2 * u], b = p[2 * u + 1];
+      const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      bf16x8 kh, kl;
+      split8f(x, kh, kl);
+      s = mfma3(kh, kl, q.h[u], q.l[u], s);
+    }
+    return s;
+  }
+  // O^T += V^T . P^T over the 64 keys of a tile, 32 keys per MFMA: lane g supplies keys 32u + 4g + (0..3) and 32u + 16 + 4g + (0..3)
+  static __device__ __forceinline__ void pv(f32x4 (&o)[4], const float* vt_head, int64_t vt_ld, int kbase, int g, int dl,
+                                            const f32x4 (&p)[4]) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const float px[8] = {p[2 * u][0], p[2 * u][1], p[2 * u][2], p[2 * u][3], p[2 * u + 1][0], p[2 * u + 1][1], p[2 * u + 1][2], p[2 * u + 1][3]};
+      bf16x8 ph, pl;
+      split8f(px, ph, pl);
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        const float* vr = vt_head + (int64_t)(db * 16 + dl) * vt_ld + kbase + 32 * u + 4 * g;
+        const float4 lo4 = *reinterpret_cast<const float4*>(vr), hi4 = *reinterpret_cast<const float4*>(vr + 16);
+        const float vx[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+        bf16x8 vh, vl;
+        split8f(vx, vh, vl);
+        o[db] = mfma3(vh, vl, ph, pl, o[db]);
+      }
+    }
+  }
+};
+
+template <typename TT>
+__global__ __launch_bounds__(256) void attention_kernel(const typename AttnT<TT>::Store* __restrict__ Q, int64_t sq, int64_t ldq,
+                                                       const typename AttnT<TT>::Store* __restrict__ K, int64_t sk, int64_t ldk,
+                                                       const typename AttnT<TT>::Store* __restrict__ VT, int64_t vt_ld, void* __restrict__ O,
                                                        int64_t ldo, int out_bf16, int out_packed, int heads, int Nq, int Nk,
                                                        float scale) {
-  using A = AttnT<T>;
+  using A = AttnT<TT>;
+  using T = typename A::Store;
   __shared__ float sh_o[4][4][64][4];   // [wave][db][lane][r]
   __shared__ float sh_m[4][64], sh_l[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, ql = lane & 15;
@@ -346,13 +410,17 @@ extern "C" int sp3_attention_ex(const void* q, int64_t sq, int64_t ldq, const vo
   SP3_CHECK(B > 0 && heads > 0 && Nq > 0 && Nk > 0, "sp3_attention: bad shape");
   SP3_CHECK(vt_ld >= ((Nk + 63) / 64) * 64 && vt_ld % 8 == 0, "sp3_attention: vt_ld=%lld must be >= Nk padded to 64", (long long)vt_ld);
   SP3_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && (out_packed || ldo % 4 == 0), "sp3_attention: row strides must keep 16-byte alignment");
-  SP3_CHECK(dtype == SP3_F32 || dtype == SP3_BF16, "sp3_attention: bad dtype %d", dtype);
+  SP3_CHECK(dtype == SP3_F32 || dtype == SP3_BF16 || dtype == 2, "sp3_attention: bad dtype %d (0 fp32, 1 bf16, 2 fp32 operands with bf16x3 products)", dtype);
   dim3 grid((Nq + 15) / 16, heads, B);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == SP3_BF16)
     hipLaunchKernelGGL(attention_kernel<__bf16>, grid, dim3(256), 0, st, reinterpret_cast<const __bf16*>(q), sq, ldq,
                        reinterpret_cast<const __bf16*>(k), sk, ldk, reinterpret_cast<const __bf16*>(vt), vt_ld, out, ldo,
                        out_bf16, out_packed, heads, Nq, Nk, scale);
+  else if (dtype == 2)
+    hipLaunchKernelGGL(attention_kernel<F32X3>, grid, dim3(256), 0, st, reinterpret_cast<const float*>(q), sq, ldq,
+                       reinterpret_cast<const float*>(k), sk, ldk, reinterpret_cast<const float*>(vt), vt_ld, out, ldo, out_bf16,
+                       out_packed, heads, Nq, Nk, scale);
   else
     hipLaunchKernelGGL(attention_kernel<float>, grid, dim3(256), 0, st, reinterpret_cast<const float*>(q), sq, ldq,
                        reinterpret_cast<const float*>(k), sk, ldk, reinterpret_cast<const float*>(vt), vt_ld, out, ldo, out_bf16,

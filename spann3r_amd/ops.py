@@ -557,7 +557,8 @@ def attention(q, sq, ldq, k, sk, ldk, vt, vt_ld, out, ldo, *, B, heads, Nq, Nk, 
            B * heads * 64.0 * (es * (Nq + 2 * Nk) + 4 * Nq),
            lambda: L.check(L.load().sp3_attention_ex(q.data_ptr(), sq, ldq, k.data_ptr(), sk, ldk, vt.data_ptr(), vt_ld,
                                                      out.data_ptr(), ldo, int(out.dtype == torch.bfloat16), _is_packed(out),
-                                                     B, heads, Nq, Nk, float(scale), wdtype_of(vt), L.stream_ptr()),
+                                                     B, heads, Nq, Nk, float(scale), (2 if (F32X3 and es == 4) else wdtype_of(vt)),
+                                                     L.stream_ptr()),
                            "sp3_attention"))
     return out
 

@@ -747,6 +747,30 @@ def test_paired_launch_equals_two_launches(dt):
             pass
 
 
+def test_attention_f32x3():
+    """fp32 attention with bf16x3 products against float64, next to the exact-fp32 kernel"""
+    ops = _ops()
+    B, heads, Nq, Nk = 2, 3, 50, 196
+    C = heads * 64
+    q, k, v = rnd(B, Nq, heads, 64, seed=1) * 2, rnd(B, Nk, heads, 64, seed=2), rnd(B, Nk, heads, 64, seed=3)
+    npk = (Nk + 63) // 64 * 64
+    vt = torch.zeros(B * heads * 64, npk)
+    vt.view(B, heads, 64, npk)[..., :Nk] = v.permute(0, 2, 3, 1)
+    a = torch.softmax(torch.einsum("bqhd,bkhd->bhqk", q.double(), k.double()) * 0.125, -1)
+    ref = torch.einsum("bhqk,bkhd->bqhd", a, v.double()).reshape(B * Nq, C)
+    errs = {}
+    for x3 in (False, True):
+        ops.F32X3 = x3
+        try:
+            out = torch.empty(B * Nq, C, device=DEV)
+            ops.attention(q.reshape(B, Nq, C).to(DEV), Nq * C, C, k.reshape(B, Nk, C).to(DEV), Nk * C, C, vt.to(DEV), npk, out, C,
+                          B=B, heads=heads, Nq=Nq, Nk=Nk, scale=0.125)
+            errs[x3] = rel_err(out.cpu(), ref)
+        finally:
+            ops.F32X3 = False
+    assert errs[False] < 2e-6 and 1e-6 < errs[True] < 5e-5, errs
+
+
 def test_gemm_f32x3_products():
     """fp32 operands through three bf16 MFMAs per k-block (sp3_gemm_desc.f32x3): ~16 mantissa bits per product, fp32 accumulate"""
     ops = _ops()
