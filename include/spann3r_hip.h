@@ -351,6 +351,14 @@ int sp3_conf_loss_forward(const float* P, const float* Cf, const float* G, const
                           float alpha, int fix_first, void* ws, float* out7, float* ent_out, void* stream);
 int sp3_conf_loss_backward(const float* P, const float* Cf, const float* G, const uint8_t* V, const float* pose0, int n, int B, int HW,
                            float alpha, int fix_first, const void* ws, const float* grad_scale2, float* dP, float* dC, void* stream);
+/* Regr3D_t_ScaleShiftInv(L21, gt_scale) forward (spann3r/loss.py:292-368; the validation criterion of spann3r/training.py:39,152):
+ * same stacked buffers as sp3_conf_loss_forward (no confidences); the joint median-depth shift and median-centre / median-norm
+ * scale (torch.nanmedian: lower middle element) are radix selections on the device.  out (device, 6 + E floats): loss (the SUM over
+ * the E entries of the mean Euclidean error), factor loss, mean gt_shift_z, pred_shift_z, gt_scale, pred_scale, then the mean error of
+ * every entry.  ws: sp3_ssi_loss_ws_bytes(n, B, HW) bytes of device scratch. */
+int64_t sp3_ssi_loss_ws_bytes(int n, int B, int HW);
+int sp3_ssi_loss_forward(const float* P, const float* G, const uint8_t* V, const float* pose0, int n, int B, int HW, int fix_first,
+                         int gt_scale, void* ws, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Pieces of the BACKWARD of the spatial-memory read in its training form (attn_thresh = 0, mem_dropout; forward:

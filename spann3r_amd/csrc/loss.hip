@@ -258,3 +258,215 @@ extern "C" int sp3_conf_loss_backward(const float* P, const float* Cf, const flo
   SP3_LAUNCH_CHECK("sp3_conf_loss_backward");
   return 0;
 }
+
+// =====================================================================================================================
+// Regr3D_t_ScaleShiftInv(L21, gt_scale) (spann3r/loss.py:292-368; the validation criterion of spann3r/training.py:39,152):
+// avg_dis normalisation of the predictions (and of the ground truth unless gt_scale), joint median-depth shift, joint
+// median-centre / median-norm scale, then the sum over the entries of the mean Euclidean error.  Forward only (it runs under
+// torch.no_grad).  The medians (torch.nanmedian: the LOWER middle element) are radix selections on the device: 4 passes of
+// 8 bits over the order-preserving integer image of the floats, integer histograms (atomics commute: deterministic).
+namespace {
+
+__device__ __forceinline__ unsigned fkey(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(unsigned k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+// state[row] = {prefix, k, done-mask, count}; hist[row][256]
+__global__ __launch_bounds__(256) void select_hist_kernel(const float* __restrict__ vals, int64_t L, const unsigned* __restrict__ state,
+                                                          unsigned* __restrict__ hist, int pass) {
+  const int row = blockIdx.y;
+  const unsigned prefix = state[4 * row], mask = pass == 0 ? 0u : (0xffffffffu << (32 - 8 * pass));
+  const int shift = 24 - 8 * pass;
+  __shared__ unsigned h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const float* v = vals + (int64_t)row * L;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < L; i += (int64_t)gridDim.x * 256) {
+    const float f = v[i];
+    if (f != f) continue;                                   // NaN = invalid point
+    const unsigned k = fkey(f);
+    if ((k & mask) == (prefix & mask)) atomicAdd(&h[(k >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  if (h[threadIdx.x]) atomicAdd(&hist[row * 256 + threadIdx.x], h[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void select_pick_kernel(unsigned* __restrict__ state, unsigned* __restrict__ hist, int pass, float* __restrict__ out) {
+  const int row = blockIdx.x;
+  __shared__ unsigned h[256];
+  h[threadIdx.x] = hist[row * 256 + threadIdx.x];
+  hist[row * 256 + threadIdx.x] = 0;                        // ready for the next pass
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned k = state[4 * row + 1];
+    if (pass == 0) {
+      unsigned tot = 0;
+      for (int d = 0; d < 256; ++d) tot += h[d];
+      state[4 * row + 3] = tot;
+      k = tot ? (tot - 1) / 2 : 0;                          // torch.nanmedian: the lower of the two middle elements
+    }
+    unsigned cum = 0;
+    int d = 0;
+    for (; d < 255; ++d) {
+      if (cum + h[d] > k) break;
+      cum += h[d];
+    }
+    state[4 * row] |= (unsigned)d << (24 - 8 * pass);
+    state[4 * row + 1] = k - cum;
+    if (pass == 3) out[row] = state[4 * row + 3] ? fkey_inv(state[4 * row]) : __uint_as_float(0x7fc00000u);
+  }
+}
+
+struct SsiArgs {
+  const float* P; const float* G; const uint8_t* V; const float* pose0; const float* fac;   // fac [B][4]: fp, fg, ...
+  const float* med;                                                                          // medians so far (layout below)
+  float* vals;                                                                               // [rows][n*HW]
+  int n, B, HW, gt_scale, stage;
+};
+// med layout: [0, 2B): shift z (gt rows 0..B-1, pred B..2B-1); [2B, 8B): centres (gt x, y, z, pred x, y, z; B each); [8B, 10B): scales
+__device__ __forceinline__ void ssi_points(const SsiArgs& a, const float* Rt, int i, int b, int x, float (&g)[3], float (&p)[3]) {
+  const float* gp = a.G + (((int64_t)i * a.B + b) * a.HW + x) * 3;
+  const float ifg = a.gt_scale ? 1.0f : 1.0f / a.fac[4 * b + 1], ifp = 1.0f / a.fac[4 * b];
+  g[0] = (Rt[0] * gp[0] + Rt[1] * gp[1] + Rt[2] * gp[2] + Rt[9]) * ifg;
+  g[1] = (Rt[3] * gp[0] + Rt[4] * gp[1] + Rt[5] * gp[2] + Rt[10]) * ifg;
+  g[2] = (Rt[6] * gp[0] + Rt[7] * gp[1] + Rt[8] * gp[2] + Rt[11]) * ifg;
+  const float* pp = a.P + (((int64_t)norm_entry(i, a.n) * a.B + b) * a.HW + x) * 3;
+  p[0] = pp[0] * ifp; p[1] = pp[1] * ifp; p[2] = pp[2] * ifp;
+}
+
+// stage 0: z of gt / pred (2B rows); stage 1: shifted x, y, z of gt / pred (6B rows); stage 2: |p - centre| (2B rows)
+__global__ __launch_bounds__(256) void ssi_values_kernel(const SsiArgs a) {
+  __shared__ float Rt[12];
+  const int i = blockIdx.y, b = blockIdx.z;
+  if (threadIdx.x == 0) inv_affine(a.pose0 + b * 16, Rt, Rt + 9);
+  __syncthreads();
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= a.HW) return;
+  const int64_t L = (int64_t)a.n * a.HW, o = (int64_t)i * a.HW + x;
+  const bool ok = a.V[((int64_t)i * a.B + b) * a.HW + x] != 0;
+  const float qnan = __uint_as_float(0x7fc00000u);
+  float g[3], p[3];
+  ssi_points(a, Rt, i, b, x, g, p);
+  const int B = a.B;
+  if (a.stage == 0) {
+    a.vals[(int64_t)b * L + o] = ok ? g[2] : qnan;
+    a.vals[(int64_t)(B + b) * L + o] = ok ? p[2] : qnan;
+    return;
+  }
+  g[2] -= a.med[b]; p[2] -= a.med[B + b];
+  if (a.stage == 1) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      a.vals[(int64_t)(c * B + b) * L + o] = ok ? g[c] : qnan;
+      a.vals[(int64_t)((3 + c) * B + b) * L + o] = ok ? p[c] : qnan;
+    }
+    return;
+  }
+  float dg = 0.f, dp = 0.f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float u = g[c] - a.med[2 * B + c * B + b], w = p[c] - a.med[2 * B + (3 + c) * B + b];
+    dg += u * u; dp += w * w;
+  }
+  a.vals[(int64_t)b * L + o] = ok ? sqrtf(dg) : qnan;
+  a.vals[(int64_t)(B + b) * L + o] = ok ? sqrtf(dp) : qnan;
+}
+
+// per (entry e, b): sum over the valid pixels of |pred' - gt'| and the count -> terms [E][B][2] (double)
+__global__ __launch_bounds__(NT) void ssi_terms_kernel(const SsiArgs a, double* __restrict__ terms) {
+  __shared__ double sh[NT / 64];
+  __shared__ float Rt[12];
+  const int e = blockIdx.x, b = blockIdx.y, i = (e + 1) >> 1, B = a.B;
+  if (threadIdx.x == 0) inv_affine(a.pose0 + b * 16, Rt, Rt + 9);
+  __syncthreads();
+  const float ifg = a.gt_scale ? 1.0f : 1.0f / a.fac[4 * b + 1], ifp = 1.0f / a.fac[4 * b];
+  const float sg = a.med[8 * B + b], sp = fminf(fmaxf(a.med[9 * B + b], 1e-3f), 1e3f);
+  const float mp = a.gt_scale ? sg / sp : sp / sg, mg = a.gt_scale ? 1.0f : sg / sp;
+  const float zg = a.med[b], zp = a.med[B + b];
+  const float* p = a.P + ((int64_t)e * B + b) * a.HW * 3;
+  const float* gq = a.G + ((int64_t)i * B + b) * a.HW * 3;
+  const uint8_t* v = a.V + ((int64_t)i * B + b) * a.HW;
+  double s = 0.0, c = 0.0;
+  for (int x = threadIdx.x; x < a.HW; x += NT) {
+    if (!v[x]) continue;
+    const float gx = gq[3 * x], gy = gq[3 * x + 1], gz = gq[3 * x + 2];
+    const float tx = (Rt[0] * gx + Rt[1] * gy + Rt[2] * gz + Rt[9]) * ifg * mg;
+    const float ty = (Rt[3] * gx + Rt[4] * gy + Rt[5] * gz + Rt[10]) * ifg * mg;
+    const float tz = ((Rt[6] * gx + Rt[7] * gy + Rt[8] * gz + Rt[11]) * ifg - zg) * mg;
+    const float dx = p[3 * x] * ifp * mp - tx, dy = p[3 * x + 1] * ifp * mp - ty, dz = (p[3 * x + 2] * ifp - zp) * mp - tz;
+    s += (double)sqrtf(dx * dx + dy * dy + dz * dz);
+    c += 1.0;
+  }
+  s = block_sum(s, sh); c = block_sum(c, sh);
+  if (threadIdx.x == 0) { terms[((int64_t)e * B + b) * 2] = s; terms[((int64_t)e * B + b) * 2 + 1] = c; }
+}
+
+// out: [0] loss (sum over entries of the mean error), [1] factor loss, [2] gt_shift_z mean, [3] pred_shift_z mean, [4] gt_scale mean,
+// [5] pred_scale mean (clipped), [6 + e] mean error of entry e
+__global__ void ssi_finish_kernel(const double* __restrict__ terms, const float* __restrict__ med, const float* __restrict__ scal, int E, int B,
+                                  int gt_scale, float* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double loss = 0.0;
+  for (int e = 0; e < E; ++e) {
+    double s = 0.0, c = 0.0;
+    for (int b = 0; b < B; ++b) { s += terms[((int64_t)e * B + b) * 2]; c += terms[((int64_t)e * B + b) * 2 + 1]; }
+    out[6 + e] = (float)(s / c);
+    loss += s / c;
+  }
+  out[0] = (float)loss;
+  out[1] = gt_scale ? 0.f : scal[0];
+  double m[4] = {0, 0, 0, 0};
+  for (int b = 0; b < B; ++b) {
+    m[0] += med[b]; m[1] += med[B + b]; m[2] += med[8 * B + b];
+    m[3] += fminf(fmaxf(med[9 * B + b], 1e-3f), 1e3f);
+  }
+  for (int k = 0; k < 4; ++k) out[2 + k] = (float)(m[k] / B);
+}
+
+}  // namespace
+
+// floats of device scratch the forward needs
+extern "C" int64_t sp3_ssi_loss_ws_bytes(int n, int B, int HW) {
+  const int64_t rows = 6 * (int64_t)B;
+  return (int64_t)sizeof(double) * ((int64_t)n * B * 3 + (int64_t)2 * (n - 1) * B * 2) + 4 * (rows * (int64_t)n * HW + rows * 256 + rows * 4 + 10 * B + 4 * B + 16) + 256;
+}
+
+extern "C" int sp3_ssi_loss_forward(const float* P, const float* G, const uint8_t* V, const float* pose0, int n, int B, int HW, int fix_first,
+                                    int gt_scale, void* ws, float* out, void* stream) {
+  SP3_CHECK(P && G && V && pose0 && ws && out && n >= 2 && B > 0 && HW > 0, "sp3_ssi_loss_forward: bad arguments");
+  SP3_CHECK((reinterpret_cast<uintptr_t>(ws) & 7) == 0 && 6 * B <= 65535, "sp3_ssi_loss_forward: workspace alignment / batch");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int E = 2 * (n - 1);
+  const int64_t L = (int64_t)n * HW, rows = 6 * (int64_t)B;
+  double* sums = reinterpret_cast<double*>(ws);
+  double* terms = sums + (int64_t)n * B * 3;
+  float* vals = reinterpret_cast<float*>(terms + (int64_t)E * B * 2);
+  unsigned* hist = reinterpret_cast<unsigned*>(vals + rows * L);
+  unsigned* state = hist + rows * 256;
+  float* med = reinterpret_cast<float*>(state + rows * 4);
+  float* fac = med + 10 * B;
+  float* scal = fac + 4 * B;
+  hipLaunchKernelGGL(loss_norm_sums, dim3(n, B), dim3(NT), 0, st, P, G, V, pose0, n, B, HW, sums);
+  hipLaunchKernelGGL(loss_factors, dim3(1), dim3(64), 0, st, sums, n, B, fix_first, fac, scal);
+  SsiArgs a{P, G, V, pose0, fac, med, vals, n, B, HW, gt_scale, 0};
+  const int nrows[3] = {2 * B, 6 * B, 2 * B};
+  const int moff[3] = {0, 2 * B, 8 * B};
+  const int hb = (int)((L + 256 * 16 - 1) / (256 * 16)) < 1 ? 1 : (int)((L + 256 * 16 - 1) / (256 * 16));
+  for (int stage = 0; stage < 3; ++stage) {
+    a.stage = stage;
+    hipLaunchKernelGGL(ssi_values_kernel, dim3((HW + 255) / 256, n, B), dim3(256), 0, st, a);
+    if (hipMemsetAsync(hist, 0, (size_t)(rows * 256 + rows * 4) * 4, st) != hipSuccess) { sp3_set_error("sp3_ssi_loss_forward: memset failed"); return 2; }
+    for (int pass = 0; pass < 4; ++pass) {
+      hipLaunchKernelGGL(select_hist_kernel, dim3(hb, nrows[stage]), dim3(256), 0, st, vals, L, state, hist, pass);
+      hipLaunchKernelGGL(select_pick_kernel, dim3(nrows[stage]), dim3(256), 0, st, state, hist, pass, med + moff[stage]);
+    }
+  }
+  hipLaunchKernelGGL(ssi_terms_kernel, dim3(E, B), dim3(NT), 0, st, a, terms);
+  hipLaunchKernelGGL(ssi_finish_kernel, dim3(1), dim3(64), 0, st, terms, med, scal, E, B, gt_scale, out);
+  SP3_LAUNCH_CHECK("sp3_ssi_loss_forward");
+  return 0;
+}

@@ -146,11 +146,13 @@ _PROTOS = {
                           C.c_void_p, C.c_void_p],
     "sp3_pnp_gn_accum": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p],
     "sp3_pnp_score": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p],
+    "sp3_ssi_loss_forward": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                             C.c_void_p],
     "sp3_preprocess_image": [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                              C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                              C.c_void_p, C.c_void_p],
 }
-EXPORTS = sorted(list(_PROTOS) + ["sp3_last_error", "sp3_version", "sp3_conf_loss_ws_bytes"])
+EXPORTS = sorted(list(_PROTOS) + ["sp3_last_error", "sp3_version", "sp3_conf_loss_ws_bytes", "sp3_ssi_loss_ws_bytes"])
 
 
 def load():
@@ -167,6 +169,8 @@ def load():
     lib.sp3_version.restype = C.c_int
     lib.sp3_conf_loss_ws_bytes.restype = C.c_int64
     lib.sp3_conf_loss_ws_bytes.argtypes = [C.c_int, C.c_int]
+    lib.sp3_ssi_loss_ws_bytes.restype = C.c_int64
+    lib.sp3_ssi_loss_ws_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
     for name, argtypes in _PROTOS.items():
         fn = getattr(lib, name)
         fn.restype = C.c_int

@@ -7,7 +7,8 @@
 The forward and the backward run in the HIP kernels of csrc/loss.hip (sp3_conf_loss_forward / _backward) on stacked
 buffers; torch only stacks the per-frame tensors, owns the autograd edge back to the predictions and computes the two
 unmasked `conf_left / conf_right` monitoring means.  Supported: L21, norm_mode 'avg_dis', gt_scale False -- the
-configuration the reference trains with; anything else raises NotImplementedError.  There is no CPU path."""
+configuration the reference trains with -- and `Regr3D_t_ScaleShiftInv(L21, gt_scale=...)`, the validation criterion of
+training.py:39 (forward only: it runs under torch.no_grad there); anything else raises NotImplementedError.  There is no CPU path."""
 import torch
 
 from . import lib as L
@@ -130,3 +131,53 @@ class ConfLoss_t:
                           name + "loss_left": sum(per[e][0] for e in left), name + "loss_right": sum(per[e][0] for e in right),
                           name + "conf_left": sum(cm[e] for e in left), name + "conf_right": sum(cm[e] for e in right)})
         return loss, details, factor
+
+
+def _stack_inputs(gts, preds, with_conf):
+    n = len(gts)
+    if n < 2 or len(preds) != n - 1:
+        raise ValueError("compute_frame_loss: %d views need %d prediction pairs, got %d" % (n, n - 1, len(preds)))
+    ent = _entries(n)
+    P = torch.stack([_pts(preds[s][side]).float() for s, side in ent])
+    if P.device.type != "cuda":
+        raise RuntimeError("the criteria run on the GPU (HIP kernels); there is no CPU path")
+    E, B, H, W = P.shape[:4]
+    dev = P.device
+    G = torch.stack([g["pts3d"].to(dev, torch.float32) for g in gts]).reshape(n, B, H * W, 3).contiguous()
+    V = torch.stack([g["valid_mask"].to(dev) for g in gts]).reshape(n, B, H * W).contiguous().view(torch.uint8)
+    pose0 = gts[0]["camera_pose"].to(dev, torch.float32).reshape(B, 16).contiguous()
+    Cf = torch.stack([preds[s][side]["conf"].float() for s, side in ent]) if with_conf else None
+    return ent, P.reshape(E, B, H * W, 3).contiguous(), Cf, G, V, pose0
+
+
+class Regr3D_t_ScaleShiftInv:
+    """spann3r/loss.py:292-368 (Regr3D_t_ScaleInv over Regr3D_t_ShiftInv over Regr3D_t): the validation criterion
+    `Regr3D_t_ScaleShiftInv(L21, gt_scale=True)` of training.py:39.  Forward only."""
+
+    def __init__(self, criterion, norm_mode="avg_dis", gt_scale=False, fix_first=True):
+        if not isinstance(criterion, L21Loss) or norm_mode != "avg_dis":
+            raise NotImplementedError("Regr3D_t_ScaleShiftInv: L21 and norm_mode='avg_dis' only")
+        self.criterion, self.norm_mode, self.gt_scale, self.fix_first = criterion, norm_mode, gt_scale, fix_first
+
+    def to(self, *_a, **_k):
+        return self
+
+    @torch.no_grad()
+    def compute_frame_loss(self, gts, preds):
+        ent, P, _, G, V, pose0 = _stack_inputs(gts, preds, False)
+        E, B, HW = P.shape[:3]
+        n = len(gts)
+        lib = L.load()
+        ws = torch.empty(int(lib.sp3_ssi_loss_ws_bytes(n, B, HW)) // 8 + 1, dtype=torch.float64, device=P.device)
+        out = torch.empty(6 + E, device=P.device)
+        L.check(lib.sp3_ssi_loss_forward(P.data_ptr(), G.data_ptr(), V.data_ptr(), pose0.data_ptr(), n, B, HW, int(self.fix_first),
+                                         int(self.gt_scale), ws.data_ptr(), out.data_ptr(), L.stream_ptr()), "sp3_ssi_loss_forward")
+        o = out.tolist()
+        name = "Regr3D_t_ScaleShiftInv"
+        left = [e for e, (s, side) in enumerate(ent) if side == 0 and s != 0]
+        right = [e for e, (s, side) in enumerate(ent) if side == 1 and s + 1 != n - 1]
+        cm = [float(preds[s][side]["conf"].float().mean()) for s, side in ent]
+        details = {name + "_pts3d_1": o[6], name + "_pts3d_2": o[7], name + "loss_left": sum(o[6 + e] for e in left),
+                   name + "loss_right": sum(o[6 + e] for e in right), name + "conf_left": sum(cm[e] for e in left),
+                   name + "conf_right": sum(cm[e] for e in right), "gt_shift_z": o[2], "pred_shift_z": o[3], "gt_scale": o[4], "pred_scale": o[5]}
+        return out[0].clone(), details, out[1].clone()

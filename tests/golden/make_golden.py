@@ -355,6 +355,18 @@ def make_loss():
         for j, t in enumerate(leaves):
             out[tag + "_grad%d" % j] = npf(t.grad)
         print("loss", tag, float(loss), float(factor), {k: round(float(v), 5) for k, v in details.items()})
+    # the test criterion of spann3r/training.py:39
+    from spann3r.loss import Regr3D_t_ScaleShiftInv
+    for tag, seed, gsc in (("t1", 21, True), ("t2", 22, False)):
+        gts, preds_all = synth_loss_case(seed)
+        with torch.no_grad():
+            loss, details, factor = Regr3D_t_ScaleShiftInv(L21, gt_scale=gsc).compute_frame_loss(gts, preds_all)
+        out[tag + "_meta"] = np.array([seed, int(gsc)], np.int64)
+        out[tag + "_loss"] = np.float32(float(loss))
+        out[tag + "_factor"] = np.float32(float(factor))
+        for k, v in details.items():
+            out[tag + "_detail_" + k] = np.float32(float(v))
+        print("ssi", tag, float(loss), float(factor), {k: round(float(v), 5) for k, v in details.items()})
     np.savez_compressed(os.path.join(HERE, "loss_conf.npz"), **out)
 
 

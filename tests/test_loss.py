@@ -84,3 +84,34 @@ def test_hip_loss_scales_with_upstream_gradient_and_empty_masks():
     assert abs(float(loss) - float(l64)) < 2e-6 * abs(float(l64))
     for a, b in zip(leaves, leaves64):
         assert rel_err(a.grad.cpu(), b.grad) < 5e-6 and torch.isfinite(a.grad).all()
+
+
+@pytest.mark.parametrize("tag", ["t1", "t2"])
+def test_test_criterion_oracle_matches_reference_dump(tag):
+    """Regr3D_t_ScaleShiftInv (the validation criterion of spann3r/training.py:39)"""
+    g = load_golden("loss_conf.npz")
+    seed, gsc = [int(v) for v in g[tag + "_meta"]]
+    gts, preds_all = synth_loss_case(seed)
+    loss, details, factor = LO.regr3d_t_scale_shift_inv(gts, preds_all, gt_scale=bool(gsc))
+    assert abs(float(loss) - float(g[tag + "_loss"])) < 3e-6 * abs(float(g[tag + "_loss"]))
+    assert abs(float(factor) - float(g[tag + "_factor"])) < 1e-6
+    for k, v in details.items():
+        assert abs(v - float(g[tag + "_detail_" + k])) < 1e-5 * max(1.0, abs(v)), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["t1", "t2"])
+def test_hip_test_criterion(tag):
+    from spann3r_amd.loss import Regr3D_t_ScaleShiftInv, L21
+    g = load_golden("loss_conf.npz")
+    seed, gsc = [int(v) for v in g[tag + "_meta"]]
+    gts, preds_all = synth_loss_case(seed)
+    dev = lambda d: {k: v.cuda() for k, v in d.items()}
+    loss, details, factor = Regr3D_t_ScaleShiftInv(L21, gt_scale=bool(gsc)).compute_frame_loss(
+        [dev(x) for x in gts], [(dev(a), dev(b)) for a, b in preds_all])
+    assert abs(float(loss) - float(g[tag + "_loss"])) < 1e-5 * abs(float(g[tag + "_loss"]))
+    assert abs(float(factor) - float(g[tag + "_factor"])) < 1e-6
+    for k in ("Regr3D_t_ScaleShiftInv_pts3d_1", "Regr3D_t_ScaleShiftInv_pts3d_2", "Regr3D_t_ScaleShiftInvloss_left",
+              "Regr3D_t_ScaleShiftInvloss_right", "Regr3D_t_ScaleShiftInvconf_left", "Regr3D_t_ScaleShiftInvconf_right",
+              "gt_shift_z", "pred_shift_z", "gt_scale", "pred_scale"):
+        assert abs(details[k] - float(g[tag + "_detail_" + k])) < 2e-5 * max(1.0, abs(details[k])), (k, details[k], float(g[tag + "_detail_" + k]))
