@@ -108,9 +108,14 @@ class GradReducer:
     ~153 GB/s per GPU) and a ring all-reduce of S bytes over N ranks moves 2 S (N-1)/N per link at ~2 (N-1) latency hops, so
     buckets are large (64 MB default: > 95 % of the bandwidth term at 8 ranks) -- the NVSwitch-era 25 MB default of DDP
     is latency-dominated here.  Parameters without a gradient contribute zeros (find_unused_parameters=True semantics).
-    With no process group initialised every call is a no-op (single-GPU runs)."""
+    With no process group initialised every call is a no-op (single-GPU runs).
 
-    def __init__(self, params, bucket_mb=64.0, group=None):
+    overlap=True registers a post-accumulate-grad hook on every parameter: `prepare()` before `backward()` arms the buckets, a
+    bucket's all-reduce is launched from inside the backward pass the moment its last gradient has been accumulated (the
+    collective of the last layers runs while the first layers are still being differentiated), and `finish()` after
+    `backward()` launches whatever is left (buckets holding unused parameters), waits and writes the means back."""
+
+    def __init__(self, params, bucket_mb=64.0, group=None, overlap=False):
         import torch
         self.params = [p for p in params if p.requires_grad]
         self.group = group
@@ -127,35 +132,67 @@ class GradReducer:
         self._flat = [None] * len(self.buckets)
         self._work = []
         self._torch = torch
+        self.launched_in_backward = 0          # (statistics of the last step: buckets whose collective started from a hook)
+        self._armed = False
+        self._pending = None
+        self._bucket_of = {id(p): i for i, b in enumerate(self.buckets) for p in b}
+        if overlap:
+            for p in self.params:
+                p.register_post_accumulate_grad_hook(self._on_grad)
+
+    def prepare(self):
+        """arm the hooks for the backward pass that follows (overlap=True)"""
+        self._work = [None] * len(self.buckets)
+        self._pending = [len(b) for b in self.buckets]
+        self.launched_in_backward = 0
+        self._armed = self.active()
+
+    def _on_grad(self, p):
+        if not self._armed:
+            return
+        i = self._bucket_of[id(p)]
+        self._pending[i] -= 1
+        if self._pending[i] == 0:
+            self._work[i] = self._launch(i)
+            self.launched_in_backward += 1
+
+    def _launch(self, i):
+        import torch.distributed as dist
+        torch = self._torch
+        bucket = self.buckets[i]
+        n = sum(p.numel() for p in bucket)
+        dev = bucket[0].device
+        if self._flat[i] is None or self._flat[i].device != dev:
+            self._flat[i] = torch.empty(n, dtype=torch.float32, device=dev)
+        flat, o = self._flat[i], 0
+        for p in bucket:
+            v = flat[o:o + p.numel()]
+            if p.grad is None:
+                v.zero_()
+            else:
+                v.copy_(p.grad.reshape(-1))
+            o += p.numel()
+        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def active(self):
         import torch.distributed as dist
         return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
 
     def start(self):
-        """pack + launch the all-reduces (call right after backward)"""
+        """pack + launch the all-reduces of every bucket that has not started yet (call right after backward)"""
         if not self.active():
             return
-        import torch.distributed as dist
-        torch = self._torch
-        self._work = []
-        for i, bucket in enumerate(self.buckets):
-            n = sum(p.numel() for p in bucket)
-            dev = bucket[0].device
-            if self._flat[i] is None or self._flat[i].device != dev:
-                self._flat[i] = torch.empty(n, dtype=torch.float32, device=dev)
-            flat, o = self._flat[i], 0
-            for p in bucket:
-                v = flat[o:o + p.numel()]
-                if p.grad is None:
-                    v.zero_()
-                else:
-                    v.copy_(p.grad.reshape(-1))
-                o += p.numel()
-            self._work.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if not self._armed:
+            self._work = [None] * len(self.buckets)
+        for i in range(len(self.buckets)):
+            if self._work[i] is None:
+                self._work[i] = self._launch(i)
+        self._armed = False
 
     def finish(self):
-        """wait for the collectives, write the averaged gradients back"""
+        """launch what the hooks have not (unused parameters), wait for the collectives, write the averaged gradients back"""
+        if self._armed:
+            self.start()
         if not self._work:
             return
         import torch.distributed as dist

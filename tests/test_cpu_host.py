@@ -225,8 +225,31 @@ for i, p in enumerate(params):
     dist.all_gather(allg, loc)
     assert torch.allclose(p.grad, sum(allg) / world, atol=1e-7), i
 assert frozen.grad is None
+# overlap=True: the collectives start from inside backward, bucket by bucket, in reverse layer order
+torch.manual_seed(1)
+net = torch.nn.Sequential(torch.nn.Linear(40, 64), torch.nn.Tanh(), torch.nn.Linear(64, 64), torch.nn.Tanh(), torch.nn.Linear(64, 8))
+unused = torch.nn.Parameter(torch.ones(5))
+red2 = GradReducer(list(net.parameters()) + [unused], bucket_mb=0.012, overlap=True)
+assert len(red2.buckets) >= 3
+x = torch.randn(16, 40, generator=torch.Generator().manual_seed(200 + rank))
+red2.prepare()
+net(x).square().mean().backward()
+started = red2.launched_in_backward
+red2.finish()
+assert started >= 2, started                               # all buckets but the one holding the unused parameter
+ref = torch.nn.Sequential(torch.nn.Linear(40, 64), torch.nn.Tanh(), torch.nn.Linear(64, 64), torch.nn.Tanh(), torch.nn.Linear(64, 8))
+ref.load_state_dict(net.state_dict())
+tot = [torch.zeros_like(p) for p in ref.parameters()]
+for r in range(world):
+    ref.zero_grad()
+    ref(torch.randn(16, 40, generator=torch.Generator().manual_seed(200 + r))).square().mean().backward()
+    for t, p in zip(tot, ref.parameters()):
+        t += p.grad
+for p, t in zip(net.parameters(), tot):
+    assert torch.allclose(p.grad, t / world, atol=1e-7)
+assert torch.equal(unused.grad, torch.zeros(5))            # contributed zeros on every rank
 if rank == 0:
-    print("OK grads")
+    print("OK grads", started)
 dist.destroy_process_group()
 '''
 

@@ -223,8 +223,10 @@ def test_model_train_mode_runs_a_step(tiny_sd):
     preds, preds_all = m(frames)
     assert preds_all[0][0]["pts3d"].requires_grad and len(preds) == n
     loss, details, factor = crit.compute_frame_loss(_synth_gts(n, B, H, W, 5, torch.float32, "cuda"), preds_all)
+    red = GradReducer(m.parameters(), overlap=True)
+    red.prepare()
     (loss + factor).backward()
-    GradReducer(m.parameters()).reduce()                  # single process: no-op, same call sequence as the multi-GPU step
+    red.finish()                                          # single process: no-op, same call sequence as the multi-GPU step
     w0 = m.state_dict()["dust3r.dec_blocks.0.mlp.fc1.weight"].clone()
     g = m.state_dict(keep_vars=True)["dust3r.dec_blocks.0.mlp.fc1.weight"].grad
     assert g is not None and torch.isfinite(g).all() and float(g.abs().max()) > 0
