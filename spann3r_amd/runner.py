@@ -191,9 +191,12 @@ class GradReducer:
 
     def finish(self):
         """launch what the hooks have not (unused parameters), wait for the collectives, write the averaged gradients back"""
+        if not self.active():
+            self._work, self._armed = [], False
+            return
         if self._armed:
             self.start()
-        if not self._work:
+        if not self._work or any(w is None for w in self._work):
             return
         import torch.distributed as dist
         torch = self._torch
