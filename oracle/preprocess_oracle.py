@@ -105,10 +105,11 @@ def _camera_matrix_of_crop(K, in_res, out_res, scaling=1, offset_factor=0.5):   
     return _c2o(Kc)
 
 
-def demo_plan(H, W, resolution):
+def demo_plan(H, W, resolution, rng=None):
     """Bookkeeping of `_crop_resize_if_necessary` (base_stereo_view_dataset.py:140-194) for a Demo view (demo.py:66-70:
-    float32 pseudo intrinsics, principal point (W//2, H//2); aug_crop off; for square images the resolution is kept as
-    given -- the reference flips a coin there).  The same float32 / float64 operations in the same order, because the
+    float32 pseudo intrinsics, principal point (W//2, H//2); aug_crop off; for near-square crops with a non-square
+    resolution the reference draws `rng.integers(2)` (:174-177): pass the same generator to reproduce it, rng=None keeps the
+    resolution as given = the coin landing on 0).  The same float32 / float64 operations in the same order, because the
     final crop offset is a rounded difference of two camera matrices.  resolution = (width, height), width >= height.
     Returns dict(crop0=(l,t,r,b), resize=(w,h), crop1=(l,t,r,b), out=(w,h))."""
     K = np.array([[1.0, 0, W // 2], [0, 1.0, H // 2], [0, 0, 1]], dtype=np.float32)
@@ -124,6 +125,9 @@ def demo_plan(H, W, resolution):
     assert res[0] >= res[1]
     if H1 > 1.1 * W1:                                                   # :170-173 portrait -> transposed resolution
         res = res[::-1]
+    elif 0.9 < H1 / W1 < 1.1 and res[0] != res[1]:                      # :174-177 square: (portrait, landscape) at random
+        if rng is not None and rng.integers(2):
+            res = res[::-1]
     in_res = np.array((W1, H1))
     scale_final = max(np.array(res) / in_res) + 1e-8                    # cropping.py:67
     out_res = np.floor(in_res * scale_final).astype(int)                # :68
@@ -134,16 +138,21 @@ def demo_plan(H, W, resolution):
                 crop1=(int(l2), int(t2), int(l2) + res[0], int(t2) + res[1]), out=res)
 
 
-def preprocess_view(rgb, resolution):
-    """decoded RGB frame [H, W, 3] uint8 -> (img float32 [3, h, w] in [-1, 1] rectified to landscape, true_shape int32 [2])
-    exactly as Demo -> BaseStereoViewDataset.__getitem__ hands it to the model."""
+def view_u8(rgb, resolution, rng=None):
+    """the uint8 image `_crop_resize_if_necessary` returns (crop on the principal point, Lanczos resize, centre crop)"""
     H, W, _ = rgb.shape
-    p = demo_plan(H, W, resolution)
+    p = demo_plan(H, W, resolution, rng)
     l, t, r, b = p["crop0"]
     x = rgb[t:b, l:r]
     x = resample_u8(x, *p["resize"])
     l, t, r, b = p["crop1"]
-    x = x[t:b, l:r]
+    return x[t:b, l:r]
+
+
+def preprocess_view(rgb, resolution, rng=None):
+    """decoded RGB frame [H, W, 3] uint8 -> (img float32 [3, h, w] in [-1, 1] rectified to landscape, true_shape int32 [2])
+    exactly as Demo -> BaseStereoViewDataset.__getitem__ hands it to the model."""
+    x = view_u8(rgb, resolution, rng)
     true_shape = np.int32((x.shape[0], x.shape[1]))
     img = ((x.astype(np.float32) / np.float32(255.0)) - np.float32(0.5)) / np.float32(0.5)     # ToTensor + Normalize
     img = np.ascontiguousarray(img.transpose(2, 0, 1))

@@ -25,6 +25,7 @@
 //    with fp32 accumulation; bf16-mode activations are either already bf16 (a_bf16) or fp32 converted
 //    on load (v_cvt_pk_bf16_f32).
 #include "common.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -151,6 +152,10 @@ template <> struct MM<__bf16, __bf16> {
       for (int n = 0; n < NF; ++n)
         acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m].v[0], w[n].v[0], acc[m][n], 0, 0, 0);
   }
+  // one 16-byte fragment half against one 16-byte fragment half (the pipelined LDS loop keeps bare halves in registers)
+  static __device__ __forceinline__ void mma16(f32x4& acc, const bf16x8& a, const bf16x8& w) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, w, acc, 0, 0, 0);
+  }
 };
 
 template <> struct MM<float, float> {
@@ -230,6 +235,12 @@ template <> struct MM<float, float> {
         acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].v[0].z, w[n].v[0].z, acc[m][n], 0, 0, 0);
         acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m].v[0].w, w[n].v[0].w, acc[m][n], 0, 0, 0);
       }
+  }
+  static __device__ __forceinline__ void mma16(f32x4& acc, const float4& a, const float4& w) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w.w, acc, 0, 0, 0);
   }
 };
 
@@ -478,7 +489,7 @@ void gemm_kernel(const GemmArgs args) {
   constexpr int TPR = NT >= 8 * BM ? 8 : NT >= 4 * BM ? 4 : NT >= 2 * BM ? 2 : 1;
   // partials requested up front per thread: 4 where registers are short (the register-ring tiles, the 128-row LDS tiles
   // that live on three workgroups per CU); the weight-streaming LDS tiles take all of a 1024-wide row (32 groups)
-  constexpr int NPRE = (LDSK && STAGES >= 3) ? 32 / TPR : 4;
+  constexpr int NPRE = (LDSK && LOOP != -1 && STAGES >= 3) ? 32 / TPR : 4;
   const int srow = tid / TPR, sj = tid % TPR;
   float2 sp[NPRE];
 #pragma unroll
@@ -719,6 +730,153 @@ void gemm_kernel(const GemmArgs args) {
     }
     if (tr && tid == 0) tr[1] = clock64();
     __syncthreads();                                     // the ring is dead: the epilogue slab re-uses its bytes
+  } else
+  if constexpr (LOOP == -1) {
+    // ---- pipelined LDS-staged K loop (the many-row GEMMs: whole-sequence encoder, 512x512 steps, long-bank memory reads,
+    // training).  Same ring of fragment-order stages as LOOP 1 (one stage = BM/16 A blocks + BN/16 W blocks of 2 KB, moved
+    // by global_load_lds pieces dealt round-robin over the waves), but
+    //  * a slot is refilled right behind the barrier that publishes the NEXT stage (by then every wave holds the old
+    //    stage in registers), so NST-1 stages are in flight while one is multiplied (HBM-cold weight panels);
+    //  * a wave keeps TWO fragment sets in registers: while the MFMAs of one 16-byte half (WK = 1) / of one stage's own
+    //    half (WK = 2: the wave pair splits every k-block) run, the ds_reads of the next one are already in flight --
+    //    LOOP 1 reads a whole stage and then waits for it before its first MFMA;
+    //  * 8-wave workgroups (two waves per SIMD): 256x128 (4x2 waves of 64x64) and 128x128 (2x2 waves x 2 K halves).
+    static_assert(sizeof(TA) == sizeof(TW), "LDS-staged loop: A and W in the MFMA dtype (fragment order)");
+    static_assert(WK <= 2, "pipelined LDS loop: K over at most 2 waves");
+    constexpr int NW = NT / 64;
+    constexpr int NBLK = BM / 16 + BN / 16, STAGE_BYTES = NBLK * 2048, NINSTR = 2 * NBLK, PER = (NINSTR + NW - 1) / NW;
+    constexpr int NST = STAGES;
+    static_assert(NST >= 2 && NST <= 4 && PER * (NST - 1) < 64, "stage ring: 2..4 stages, vmcnt is a 6-bit count");
+    char* lds_b = reinterpret_cast<char*>(smem);
+    const int nkb_pad = (d.K + KB - 1) / KB;
+    const int rb_max = (d.M + 15) / 16 - 1, nb_max = (d.N + 15) / 16 - 1;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const char* src[PER];
+    int dst[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      int j = wave_u + i * NW;                            // piece 0 .. NINSTR-1: A row blocks first, then W column blocks
+      j = j < NINSTR ? j : NINSTR - 1;                    // surplus slot: repeats the last piece (constant vmcnt per stage)
+      const int blk = j >> 1;
+      const char* base;
+      if (blk < BM / 16) {
+        int rb = (m0 >> 4) + blk;
+        rb = rb < rb_max ? rb : rb_max;                   // rows past M: re-read the last block (masked at the store)
+        base = reinterpret_cast<const char*>(A + (int64_t)rb * nkb_pad * (2048 / sizeof(TA)));
+      } else {
+        int nb = (n0 >> 4) + blk - BM / 16;
+        nb = nb < nb_max ? nb : nb_max;
+        base = reinterpret_cast<const char*>(W + (int64_t)nb * (int)((d.ldw + KB - 1) / KB) * (2048 / sizeof(TW)));
+      }
+      src[i] = base + (j & 1) * 1024 + lane * 16;
+      dst[i] = j * 1024;
+    }
+    auto issue = [&](int slot, int kb) {
+#pragma unroll
+      for (int i = 0; i < PER; ++i) glds16(src[i] + (int64_t)kb * 2048, lds_b + slot * STAGE_BYTES + dst[i]);
+    };
+    // this wave's DMA pieces retire in order: "at most pend stages' worth outstanding" == every older stage has landed
+    auto wait_pending = [&](int pend) {
+      if (pend >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PER) : "memory");
+      else if (pend == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+      else if (pend == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    const int nk = kb_hi - kb_lo;
+#pragma unroll
+    for (int s_ = 0; s_ < NST; ++s_)
+      if (s_ < nk) issue(s_, kb_lo + s_);
+    using V16 = std::remove_reference_t<decltype(((typename M_::AReg*)nullptr)->v[0])>;
+    using W16 = std::remove_reference_t<decltype(((typename M_::WReg*)nullptr)->v[0])>;
+    static_assert(sizeof(V16) == 16 && sizeof(W16) == 16, "fragment halves are 16 bytes");
+    V16 fa[2][MF];
+    W16 fw[2][NF];
+    auto read_half = [&](auto buf_tag, int slot, int half) {
+      constexpr int BUF = decltype(buf_tag)::value;
+      const char* st = lds_b + slot * STAGE_BYTES + half * 1024 + lane * 16;
+#pragma unroll
+      for (int m = 0; m < MF; ++m) fa[BUF][m] = *reinterpret_cast<const V16*>(st + (wm * MF + m) * 2048);
+#pragma unroll
+      for (int n = 0; n < NF; ++n) fw[BUF][n] = *reinterpret_cast<const W16*>(st + (BM / 16 + wn * NF + n) * 2048);
+    };
+    // A unit = the MF x NF MFMAs of one register set.  Its FIRST MFMA is where hipcc puts the lgkmcnt wait for the set
+    // (a full drain: across the loop's back edge its waitcnt pass does not count), so the ds_reads of the NEXT set are
+    // issued right behind that first MFMA -- nothing else is outstanding at the wait -- and fly under the other MF*NF-1.
+    auto mma_first = [&](auto buf_tag) {
+      constexpr int BUF = decltype(buf_tag)::value;
+      M_::mma16(acc[0][0], fa[BUF][0], fw[BUF][0]);
+    };
+    auto mma_rest = [&](auto buf_tag) {
+      constexpr int BUF = decltype(buf_tag)::value;
+#pragma unroll
+      for (int m = 0; m < MF; ++m)
+#pragma unroll
+        for (int n = 0; n < NF; ++n)
+          if (m + n > 0) M_::mma16(acc[m][n], fa[BUF][m], fw[BUF][n]);
+    };
+    // publish stage s (>= 1).  A wave gets here right behind the first MFMA of its last unit of stage s-1, i.e. with every
+    // read of stage s-1 returned: own pieces of stage s landed -> barrier (everybody's pieces landed, nobody reads slot
+    // s-1 any more) -> that slot is refilled with stage s+NST-1.  NST-1 stages are in flight while one is multiplied.
+    auto sync_stage = [&](int s) {
+      const int newer = nk - 1 - s;                                    // stages after s that exist
+      wait_pending(newer < NST - 2 ? newer : NST - 2);
+      // (the reads of stage s-1 were issued a unit ago and have returned; the explicit drain makes the refill below safe
+      // whatever partial lgkmcnt hipcc chooses for the MFMA in front of this call)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (s + NST - 1 < nk) issue((s + NST - 1) % NST, kb_lo + s + NST - 1);
+    };
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    {
+      const int newer = nk - 1;
+      wait_pending(newer < NST - 1 ? newer : NST - 1);
+      asm volatile("s_barrier" ::: "memory");
+    }
+    int slot = 0;
+    if constexpr (WK == 1) {
+      read_half(B0{}, 0, 0);
+      for (int i = 0; i < nk; ++i) {
+        mma_first(B0{});                                   // (stage i, half 0)
+        __builtin_amdgcn_sched_barrier(0);
+        read_half(B1{}, slot, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_rest(B0{});
+        mma_first(B1{});                                   // (stage i, half 1)
+        __builtin_amdgcn_sched_barrier(0);
+        slot = slot + 1 == NST ? 0 : slot + 1;
+        if (i + 1 < nk) {
+          sync_stage(i + 1);
+          read_half(B0{}, slot, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mma_rest(B1{});
+      }
+    } else {
+      read_half(B0{}, 0, wk);
+      for (int i = 0; i < nk; i += 2) {
+        mma_first(B0{});                                   // stage i (this wave's half)
+        __builtin_amdgcn_sched_barrier(0);
+        if (i + 1 < nk) {
+          slot = slot + 1 == NST ? 0 : slot + 1;
+          sync_stage(i + 1);
+          read_half(B1{}, slot, wk);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mma_rest(B0{});
+        if (i + 1 < nk) {
+          mma_first(B1{});                                 // stage i+1
+          __builtin_amdgcn_sched_barrier(0);
+          if (i + 2 < nk) {
+            slot = slot + 1 == NST ? 0 : slot + 1;
+            sync_stage(i + 2);
+            read_half(B0{}, slot, wk);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          mma_rest(B1{});
+        }
+      }
+    }
+    __syncthreads();                                     // the stages are dead: the epilogue slab re-uses their bytes
   } else
   if constexpr (LDSK) {
     // ---- LDS-staged K loop.  Stage = BM/16 A blocks + BN/16 W blocks of 2 KB (one fragment block = 64 lanes x 32 B, the
@@ -1075,29 +1233,33 @@ void gemm_kernel(const GemmArgs args) {
   // iteration i+1 cannot be hoisted above the stores of iteration i)
   if constexpr (LDSK && (NT % (BN / 4)) == 0) {
     constexpr int CG = BN / 4, RSTEP = NT / CG, ITER = (BM + RSTEP - 1) / RSTEP;
-    if (d.epi == SP3_EPI_PLAIN && (d.N & 3) == 0 && ITER <= 4) {
+    // (the pipelined tiles walk up to 16 row steps per thread: residual rows are requested 4 steps at a time)
+    if (d.epi == SP3_EPI_PLAIN && (d.N & 3) == 0 && (ITER <= 4 || LOOP == -1)) {
       const int c4 = ec4, gn = n0 + c4, row0 = tid / CG;
       if (gn < d.N) {
         const float4 b4 = pre_b4, s4 = pre_s4;            // (N % 4 == 0: the group is whole, epre held)
-        float4 r1[ITER], r2[ITER];
-        int gmc[ITER];
+        constexpr int CHK = ITER < 4 ? ITER : 4;
 #pragma unroll
-        for (int it = 0; it < ITER; ++it) {
-          const int gm = m0 + row0 + it * RSTEP;
+        for (int it0 = 0; it0 < ITER; it0 += CHK) {
+        float4 r1[CHK], r2[CHK];
+        int gmc[CHK];
+#pragma unroll
+        for (int it = 0; it < CHK; ++it) {
+          const int gm = m0 + row0 + (it0 + it) * RSTEP;
           gmc[it] = gm < d.M ? gm : d.M - 1;              // clamped: unconditional loads
           r1[it] = r2[it] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         if (d.res1) {
 #pragma unroll
-          for (int it = 0; it < ITER; ++it) r1[it] = *reinterpret_cast<const float4*>(d.res1 + ((int64_t)bz * d.M + gmc[it]) * d.ldr1 + gn);
+          for (int it = 0; it < CHK; ++it) r1[it] = *reinterpret_cast<const float4*>(d.res1 + ((int64_t)bz * d.M + gmc[it]) * d.ldr1 + gn);
         }
         if (d.res2) {
 #pragma unroll
-          for (int it = 0; it < ITER; ++it) r2[it] = *reinterpret_cast<const float4*>(d.res2 + ((int64_t)bz * d.M + gmc[it]) * d.ldr2 + gn);
+          for (int it = 0; it < CHK; ++it) r2[it] = *reinterpret_cast<const float4*>(d.res2 + ((int64_t)bz * d.M + gmc[it]) * d.ldr2 + gn);
         }
 #pragma unroll
-        for (int it = 0; it < ITER; ++it) {
-          const int row = row0 + it * RSTEP, gm = m0 + row;
+        for (int it = 0; it < CHK; ++it) {
+          const int row = row0 + (it0 + it) * RSTEP, gm = m0 + row;
           if (row < BM && gm < d.M) {
             const float4 a4 = lds_sum4(row, c4);
             float v[4] = {a4.x * alpha, a4.y * alpha, a4.z * alpha, a4.w * alpha};
@@ -1147,6 +1309,7 @@ void gemm_kernel(const GemmArgs args) {
               else { o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3]; }
             }
           }
+        }
         }
       }
       if constexpr (LOOP >= 2) {
@@ -1421,6 +1584,19 @@ int dispatch_tile(const sp3_gemm_desc& d, int tile, hipStream_t stream) {
       }
       sp3_set_error("sp3_gemm: tile %d needs bf16 A and the plain loader", tile);
       return 1;
+    case 20: case 21: case 22: case 23:               // pipelined LDS-staged operands (many-row GEMMs)
+      if constexpr (sizeof(TA) == sizeof(TW) && LOADER == SP3_LOAD_PLAIN) {
+        if (d.a_packed && d.w_packed && !d.A2 && d.K % MM<TA, TW>::KB == 0) {
+          switch (tile) {
+            case 20: return launch<TA, TW, LOADER, 4, 4, 4, 2, 1, 3, -1>(d, stream);   // 256x128, 4x2 waves of 64x64, 3 slots
+            case 21: return launch<TA, TW, LOADER, 4, 4, 2, 2, 2, 4, -1>(d, stream);   // 128x128, 2x2 waves of 64x64 x 2 K halves, 4 slots
+            case 22: return launch<TA, TW, LOADER, 4, 4, 2, 1, 2, 3, -1>(d, stream);   // 128x64,  2x1 waves of 64x64 x 2 K halves
+            default: return launch<TA, TW, LOADER, 4, 4, 1, 1, 2, 4, -1>(d, stream);   // 64x64,   1 wave pair (2 K halves), 4 slots
+          }
+        }
+      }
+      sp3_set_error("sp3_gemm: tile %d (pipelined LDS) needs fragment-order A and W in the MFMA dtype, whole k-blocks, no split A", tile);
+      return 1;
     case 5: case 6: case 7: case 8: case 9: case 10: case 11: case 12: case 13: case 14: case 15: case 16: case 17:     // LDS-staged operands
       if constexpr (sizeof(TA) == sizeof(TW) && LOADER == SP3_LOAD_PLAIN) {
         if (d.a_packed && d.w_packed && !d.A2 && d.K % MM<TA, TW>::KB == 0) {
@@ -1535,7 +1711,15 @@ static int gemm_prepare(sp3_gemm_desc& d, int& tile_out) {
     const long t128 = (long)((d.M + 63) / 64) * ((d.N + 127) / 128) * d.batch;
     const bool lds_ok = d.loader == SP3_LOAD_PLAIN && !d.sm_stats_out && sk == 1 && d.a_packed && d.w_packed && d.a_bf16 && !d.A2 &&
                         d.epi != SP3_EPI_PARTIAL && d.K % 64 == 0;
-    if (lds_ok && d.M >= 1024 && d.N >= 2304 && d.N % 128 == 0) {
+    // SP3_PIPE_TILES=0 switches the pipelined LDS tiles (20-23) off: A/B runs against the round-2 tile choice
+    static const bool pipe_on = [] { const char* e = getenv("SP3_PIPE_TILES"); return !(e && e[0] == '0'); }();
+    if (lds_ok && pipe_on && d.M >= 512) {
+      // many-row GEMMs on packed bf16 operands: the largest pipelined tile that still gives (almost) every CU a workgroup
+      const long mt256 = (d.M + 255) / 256, mt128 = (d.M + 127) / 128, nt128 = (d.N + 127) / 128, nt64 = (d.N + 63) / 64;
+      if (mt256 * nt128 * d.batch >= 192) tile = 20;
+      else if (mt128 * nt128 * d.batch >= 192) tile = 21;
+      else tile = 22;
+    } else if (lds_ok && d.M >= 1024 && d.N >= 2304 && d.N % 128 == 0) {
       // LDS-staged operands (tools/bench_gemm2.py --big, HBM-cold weights, also grouped launches): 128x128 for large grids
       // / N multiple of 4096, else 128x64
       tile = (d.N % 4096 == 0 || (long)((d.M + 127) / 128) * (d.N / 128) * d.batch >= 1024) ? 5 : 6;

@@ -1,43 +1,54 @@
-"""Drop-in for the reference's `models.curope` package (croco/models/curope/{__init__,curope2d}.py) on top of the
-MI355X kernel `sp3_rope_2d`.  `croco/models/pos_embed.py:106-110` only needs `cuRoPE2D` to be importable."""
+"""`models.curope`-compatible surface on top of the MI355X kernel `sp3_rope_2d`.
+
+The reference selects its native RoPE by importing `cuRoPE2D` (croco/models/pos_embed.py:106-110); the compiled
+extension it wraps exports one routine, `rope_2d` (croco/models/curope/curope.cpp:49-69).  With `shims/` on sys.path the
+reference's own wrapper runs unchanged on `rope_2d` below; the classes here are for code that imports this package
+directly (spann3r_amd.train) and are written against the kernel's contract, not the reference's wrapper:
+
+* `rope_2d(tokens[B,N,H,D], positions[B,N,2] int64, base, fwd)` rotates `tokens` in place (fwd = +1) or applies the
+  inverse rotation (fwd = -1).  A rotation is orthogonal, so the vector-Jacobian product of the forward op is the
+  inverse rotation of the incoming gradient.
+* `Rope2D` keeps the incoming gradient intact (the reference rotates `grad_res` in place, which is only safe when
+  nobody else holds that tensor): the backward rotates a private copy.
+"""
 import torch
 
 from . import ops
 
 
 def rope_2d(tokens, positions, base, fwd):
-    """curope.rope_2d(tokens[B,N,H,D] (modified in place), positions[B,N,2] int64, base, fwd)  -- curope.cpp:49-69"""
     ops.rope_2d(tokens, positions, base, fwd)
 
 
-class cuRoPE2D_func(torch.autograd.Function):
-    """curope2d.py:12-29: forward and backward both run the kernel in place (backward with -F0)."""
+class Rope2D(torch.autograd.Function):
+    """y = R(pos) x on a [B,N,H,D] tensor, in place; dx = R(pos)^T dy, out of place."""
 
     @staticmethod
-    def forward(ctx, tokens, positions, base, F0=1):
-        ctx.save_for_backward(positions)
-        ctx.saved_base = base
-        ctx.saved_F0 = F0
-        rope_2d(tokens, positions, base, F0)
-        ctx.mark_dirty(tokens)
-        return tokens
+    def forward(ctx, x_bnhd, positions, base, sign=1.0):
+        ops.rope_2d(x_bnhd, positions, base, sign)
+        ctx.mark_dirty(x_bnhd)
+        ctx.rot = (positions, float(base), float(sign))      # integer positions: nothing for autograd to track
+        return x_bnhd
 
     @staticmethod
-    def backward(ctx, grad_res):
-        positions, base, F0 = ctx.saved_tensors[0], ctx.saved_base, ctx.saved_F0
-        rope_2d(grad_res, positions, base, -F0)
-        ctx.mark_dirty(grad_res)
-        return grad_res, None, None, None
+    def backward(ctx, dy):
+        positions, base, sign = ctx.rot
+        dx = dy.clone(memory_format=torch.contiguous_format)
+        ops.rope_2d(dx, positions, base, -sign)
+        return dx, None, None, None
+
+
+cuRoPE2D_func = Rope2D           # the name the reference's wrapper module uses for its autograd function
 
 
 class cuRoPE2D(torch.nn.Module):
-    """curope2d.py:32-40: tokens [B,H,N,D]; the kernel sees the [B,N,H,D] transposed view."""
+    """Module form with the reference's constructor (`freq`, `F0`) and call convention: tokens arrive as [B,H,N,D] and are
+    rotated in place through their [B,N,H,D] view; the same tensor is returned."""
 
     def __init__(self, freq=100.0, F0=1.0):
         super().__init__()
-        self.base = freq
-        self.F0 = F0
+        self.base, self.F0 = freq, F0
 
     def forward(self, tokens, positions):
-        cuRoPE2D_func.apply(tokens.transpose(1, 2), positions, self.base, self.F0)
+        Rope2D.apply(tokens.transpose(1, 2), positions, self.base, self.F0)
         return tokens

@@ -111,6 +111,13 @@ def pick_tile(M, N, batch=1, splitk=1, conv=False, K=0, packed_bf16=False, plain
     t64 = ((M + 63) // 64) * ((N + 63) // 64) * batch * splitk
     t128 = ((M + 63) // 64) * ((N + 127) // 128) * batch
     lds_ok = not conv and splitk == 1 and packed_bf16 and K % 64 == 0
+    if lds_ok and PIPE_TILES and M >= 512:
+        mt256, mt128, nt128 = (M + 255) // 256, (M + 127) // 128, (N + 127) // 128
+        if mt256 * nt128 * batch >= 192:
+            return 20
+        if mt128 * nt128 * batch >= 192:
+            return 21
+        return 22
     if lds_ok and M >= 1024 and N >= 2304 and N % 128 == 0:
         return 5 if (N % 4096 == 0 or ((M + 127) // 128) * (N // 128) * batch >= 1024) else 6
     if not conv and M >= 1024:
@@ -125,6 +132,9 @@ def pick_tile(M, N, batch=1, splitk=1, conv=False, K=0, packed_bf16=False, plain
         return 0
     return 0
 
+
+import os as _os
+PIPE_TILES = _os.environ.get("SP3_PIPE_TILES", "1")[:1] != "0"     # mirrors the switch in csrc/gemm.hip (A/B runs)
 
 _pair = None
 

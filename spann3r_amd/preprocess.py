@@ -78,10 +78,16 @@ def _crop_matrix(K, in_res, out_res, scaling=1, offset_factor=0.5):
     return _c2o(Kc)
 
 
-def plan_view(H, W, resolution):
+def plan_view(H, W, resolution, rng=None):
     """Where the reference's `_crop_resize_if_necessary` cuts and what it resizes to, for a Demo view (float32 pseudo
     intrinsics, principal point (W//2, H//2)).  resolution = (width, height) with width >= height, or an int (square).
-    The camera-matrix arithmetic is kept in the reference's dtypes and order: the final offset is a ROUNDED difference."""
+    The camera-matrix arithmetic is kept in the reference's dtypes and order: the final offset is a ROUNDED difference.
+    Pinned against the reference's own functions (tests/golden/crop_plan.npz).
+
+    Near-square crops (0.9 < H/W < 1.1) with a non-square resolution: the reference picks portrait or landscape with
+    `rng.integers(2)` (base_stereo_view_dataset.py:174-177; the dataset's per-item generator).  Pass that generator as `rng`
+    to reproduce its draw; with rng=None (inference: demo.py always asks for a square 224 resolution, where the branch is
+    never taken) the choice is deterministic: the resolution as given, i.e. landscape."""
     if isinstance(resolution, int):
         resolution = (resolution, resolution)
     K = np.array([[1.0, 0, W // 2], [0, 1.0, H // 2], [0, 0, 1]], dtype=np.float32)
@@ -98,6 +104,9 @@ def plan_view(H, W, resolution):
         raise ValueError("resolution must be (width, height) with width >= height")
     if H1 > 1.1 * W1:
         res = res[::-1]
+    elif 0.9 < H1 / W1 < 1.1 and res[0] != res[1]:
+        if rng is not None and rng.integers(2):
+            res = res[::-1]
     in_res = np.array((W1, H1))
     scale_final = max(np.array(res) / in_res) + 1e-8
     out_res = np.floor(in_res * scale_final).astype(int)
@@ -107,7 +116,7 @@ def plan_view(H, W, resolution):
     return dict(crop0=(l, t, r, b), resize=(int(out_res[0]), int(out_res[1])), crop1=(int(l2), int(t2), int(l2) + res[0], int(t2) + res[1]), out=res)
 
 
-def preprocess_image(rgb, resolution, device="cuda"):
+def preprocess_image(rgb, resolution, device="cuda", rng=None):
     """rgb: uint8 [H, W, 3] (numpy array or torch tensor, host or device) -> (img fp32 [1, 3, h, w] on the device in
     [-1, 1], rectified to landscape; true_shape int32 [1, 2] on the CPU)."""
     t = torch.as_tensor(rgb)
@@ -115,7 +124,7 @@ def preprocess_image(rgb, resolution, device="cuda"):
         raise TypeError("expected a uint8 [H, W, 3] RGB frame")
     src = t.to(device).contiguous()                       # the only host -> device copy: the raw bytes
     H, W, _ = src.shape
-    p = plan_view(H, W, resolution)
+    p = plan_view(H, W, resolution, rng)
     l, tt, r, b = p["crop0"]
     W1, H1 = r - l, b - tt
     W2, H2 = p["resize"]

@@ -17,8 +17,13 @@ What is dumped (SURVEY.md §8c "recommended dumps"):
                       subsampled outputs, per-step feat_fuse / feat_k / cur_v, final mem_attn / mem_count
   spann3r_cfg3_512x13.npz  24/12 model, 13 frames of 512x512, train memory policy with dropout off (BASELINE config 3,
                       growing bank: 11 reads, bank up to 11264 tokens), same dumps
+  crop_plan.npz       the reference's OWN BaseStereoViewDataset._crop_resize_if_necessary (base_stereo_view_dataset.py:
+                      140-194) + cropping.py:54-121 run on 12 input shapes (cv2 / torchvision, absent from the image and
+                      unused by these functions' image path, are stubbed): every crop box, the resize target and the
+                      uint8 image that comes out
 """
 import argparse
+import hashlib
 import os
 import sys
 import time
@@ -385,8 +390,80 @@ def make_postprocess():
     np.savez_compressed(os.path.join(HERE, "postprocess.npz"), **out)
 
 
+def make_crop():
+    """f3 pin: the crop / resize plan of the reference's own functions.  `cropping.py` imports cv2 (used only for the depth map,
+    cropping.py:73-75) and `dust3r.utils.image` imports torchvision (ImgNorm); neither is installed here and neither touches the
+    image path of `_crop_resize_if_necessary`, so both are stubbed in sys.modules before the UNMODIFIED modules are imported.
+    The crop boxes are recorded by wrapping `cropping.crop_image_depthmap` / `ImageList.resize`; the function's uint8 output
+    image is dumped too (Pillow does the pixel work: the installed Pillow is the third-party dependency)."""
+    import types
+    cv2 = types.ModuleType("cv2")
+    cv2.INTER_NEAREST, cv2.IMREAD_UNCHANGED, cv2.IMREAD_COLOR = 0, -1, 1
+
+    def _resize(a, size, fx=None, fy=None, interpolation=None):      # nearest, depth map only (not part of the fixture)
+        w, h = int(size[0]), int(size[1])
+        yy = (np.arange(h) * a.shape[0] / h).astype(int).clip(0, a.shape[0] - 1)
+        xx = (np.arange(w) * a.shape[1] / w).astype(int).clip(0, a.shape[1] - 1)
+        return a[yy][:, xx]
+    cv2.resize = _resize
+    tv, tvf = types.ModuleType("torchvision"), types.ModuleType("torchvision.transforms")
+    for n in ("Compose", "ToTensor", "Normalize", "ColorJitter"):
+        setattr(tvf, n, lambda *a, **k: None)
+    tv.transforms = tvf
+    sys.modules.setdefault("cv2", cv2)
+    sys.modules.setdefault("torchvision", tv)
+    sys.modules.setdefault("torchvision.transforms", tvf)
+    import dust3r.datasets.utils.cropping as cropping
+    from dust3r.datasets.base.base_stereo_view_dataset import BaseStereoViewDataset
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from test_preprocess import _image
+
+    rec = {}
+    real_crop, real_resize = cropping.crop_image_depthmap, cropping.ImageList.resize
+
+    def crop(image, depthmap, K, bbox):
+        rec.setdefault("crops", []).append(tuple(int(v) for v in bbox))
+        return real_crop(image, depthmap, K, bbox)
+
+    def resize(self, size, **kw):
+        rec["resize"] = tuple(int(v) for v in size)
+        return real_resize(self, size, **kw)
+    cropping.crop_image_depthmap, cropping.ImageList.resize = crop, resize
+    cases = [((480, 640), (224, 224)), ((640, 480), (224, 224)), ((375, 500), (512, 384)), ((700, 500), (512, 384)),
+             ((1080, 1920), (512, 384)), ((481, 641), (224, 224)), ((1000, 751), (512, 384)), ((97, 131), (224, 224)),
+             ((720, 1280), (512, 288)), ((333, 517), (512, 336)),
+             # near-square input, non-square resolution: the reference draws rng.integers(2) (:174-177); both outcomes
+             ((1000, 1000), (512, 384)), ((528, 500), (512, 384))]
+    out = {"n": np.int32(len(cases))}
+    dummy = types.SimpleNamespace(aug_crop=0)
+    for i, (hw, res) in enumerate(cases):
+        H, W = hw
+        rgb = _image(H, W, seed=H + i)
+        K = np.array([[1.0, 0, W // 2], [0, 1.0, H // 2], [0, 0, 1]], dtype=np.float32)      # spann3r/datasets/demo.py:77-78
+        for seed in ((0, 1, 2, 3) if i >= 10 else (0,)):
+            rec.clear()
+            rng = np.random.default_rng(seed)
+            img, _, K2 = BaseStereoViewDataset._crop_resize_if_necessary(dummy, rgb, np.ones((H, W), np.float32), K.copy(), res,
+                                                                       rng=rng, info="case%d" % i)
+            tag = "c%d_s%d_" % (i, seed)
+            out[tag + "hw"], out[tag + "res"] = np.int32(hw), np.int32(res)
+            out[tag + "crop0"], out[tag + "crop1"] = np.int32(rec["crops"][0]), np.int32(rec["crops"][1])
+            out[tag + "resize"] = np.int32(rec["resize"])
+            a = np.ascontiguousarray(np.asarray(img))
+            # the whole image as a digest (bit-exact comparison without 8 MB of noise in the repository) + its centre patch
+            out[tag + "img_shape"] = np.int32(a.shape)
+            out[tag + "img_sha256"] = np.frombuffer(hashlib.sha256(a.tobytes()).digest(), np.uint8)
+            out[tag + "img_centre"] = a[a.shape[0] // 2 - 8: a.shape[0] // 2 + 8, a.shape[1] // 2 - 8: a.shape[1] // 2 + 8].copy()
+            out[tag + "K"] = np.float32(K2)
+            out[tag + "coin"] = np.int32(np.random.default_rng(seed).integers(2))
+    np.savez_compressed(os.path.join(HERE, "crop_plan.npz"), **out)
+    print("crop_plan.npz:", len(cases), "shapes")
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["tiny", "full", "memory"]
+    if "crop" in what:
+        make_crop()
     if "postprocess" in what:
         make_postprocess()
     if "loss" in what:

@@ -57,7 +57,7 @@ def test_gemm_plain(wdt, M, N, K, tile, packed):
     assert rel_err(out.cpu(), ref) < TOL[wdt], (M, N, K, tile)
 
 
-LDS_TILES = [5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15]          # 13-15: bf16 only, at most 64 k-blocks per K slice
+LDS_TILES = [5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 20, 21, 22, 23]    # 13-15: bf16 only, at most 64 k-blocks per K slice; 20-23: pipelined
 
 
 @pytest.mark.parametrize("wdt", [torch.bfloat16, torch.float32])
@@ -84,7 +84,7 @@ def test_gemm_lds_staged_tile(M, N, K, wdt):
     ref = cast(A).double() @ cast(W).double().T
     out1 = torch.empty(M, N, device=DEV)
     ops.gemm(Ap, Wp, out1, M=M, N=N, K=K, lda=K, ldc=N, tile=1)          # a register-ring tile
-    tiles = [t for t in LDS_TILES if t < 13 or wdt == torch.bfloat16]
+    tiles = [t for t in LDS_TILES if t < 13 or t >= 20 or wdt == torch.bfloat16]
     for tile in tiles:
         out = torch.full((M, N), float("nan"), device=DEV)
         ops.gemm(Ap, Wp, out, M=M, N=N, K=K, lda=K, ldc=N, tile=tile)
@@ -92,13 +92,13 @@ def test_gemm_lds_staged_tile(M, N, K, wdt):
         # the same launch must agree with the register-ring tiles to fp32 summation order
         assert rel_err(out.cpu(), out1.cpu()) < 1e-5, tile
     nkb = K // KB
-    for tile, S in ((7, 2), (8, 3), (11, 4), (13, 2), (14, 3)):
+    for tile, S in ((7, 2), (8, 3), (11, 4), (13, 2), (14, 3), (20, 2), (21, 3), (22, 5), (23, 4)):
         if nkb >= S and tile in tiles:                                                     # split-K partials of the streaming tiles
             part = torch.full((S, M, N), float("nan"), device=DEV)
             ops.gemm(Ap, Wp, part, M=M, N=N, K=K, lda=K, ldc=N, splitk=S, tile=tile)
             assert rel_err(part.sum(0).cpu(), ref) < tol, (tile, S)
     if N % 32 == 0:
-        for tile in (5, 7, 8, 11, 13, 14):
+        for tile in (5, 7, 8, 11, 13, 14, 20, 21, 22, 23):
             if tile not in tiles:
                 continue
             # producer epilogue: bias + residual, row statistics, packed copy
@@ -117,13 +117,49 @@ def test_gemm_lds_staged_tile(M, N, K, wdt):
             s_n = Wf.float().sum(1).to(DEV)
             b2 = (rnd(256, seed=8) + W2 @ beta).to(DEV)
             h = ops.PackedAct(M, 256, wdt, DEV)
-            if N % KB == 0 and (tile < 13 or N <= 1024):          # the role tiles fold a LayerNorm of at most 1024 columns
+            if N % KB == 0 and (tile < 13 or tile >= 20 or N <= 1024):          # the role tiles fold a LayerNorm of at most 1024 columns
                 ops.gemm(c2, ops.PackedWeight(Wf.to(DEV)), h, M=M, N=256, K=N, lda=N, ldc=256, bias=b2, act=ops.ACT_GELU,
                          ln=ops.LnFold(st, N, s_n, 1e-6), tile=tile)
                 xf = x.cpu().double()
                 mu, var = xf.mean(1, keepdim=True), xf.var(1, unbiased=False, keepdim=True)
                 y = ((cast(x.cpu()).double() @ Wf.double().T) - mu * Wf.double().sum(1)[None]) / torch.sqrt(var + 1e-6) + b2.cpu().double()
                 assert rel_err(h.to_dense().float().cpu(), F.gelu(y)) < (8e-3 if wdt == torch.bfloat16 else 1e-4), tile
+
+
+@pytest.mark.parametrize("tile", [20, 21, 22, 23])
+def test_gemm_pipelined_tiles_long_k_and_groups(tile):
+    """the pipelined LDS tiles on what the model throws at them: a long contraction with an odd number of k-blocks (ring
+    wrap-around, both unroll parities), a grouped launch (two problems, per-problem bias) and the automatic tile choice;
+    results must equal the register-ring tile's to summation order and be identical from run to run"""
+    ops = _ops()
+    wdt = torch.bfloat16
+    for (M, N, K, G) in ((1100, 320, 64 * 37, 1), (520, 768, 64 * 12, 2), (1960, 1024, 4096, 1)):
+        As = [rnd(M, K, seed=11 + g) for g in range(G)]
+        Ws = [rnd(N, K, seed=21 + g) * 0.05 for g in range(G)]
+        bias = rnd(G, N, seed=5).to(DEV)
+        if G == 1:
+            A = ops.PackedAct.from_dense(As[0].to(DEV).to(wdt))
+            W = ops.PackedWeight(Ws[0].to(DEV).to(wdt))
+            kw = dict(M=M, N=N, K=K, lda=K, ldc=N, bias=bias[0])
+        else:
+            A = ops.PackedAct.group(G, M, K, wdt, DEV)
+            for g in range(G):
+                pd = ops.PackedAct.from_dense(As[g].to(DEV).to(wdt)).data.view(-1)
+                assert pd.numel() == A.stride
+                A.at(g).data[:pd.numel()].copy_(pd)
+            W = ops.PackedWeightGroup([ops.PackedWeight(w.to(DEV).to(wdt)) for w in Ws])
+            kw = dict(M=M, N=N, K=K, lda=K, ldc=N, bias=bias, batch=G, strideA=A.stride, strideW=W.stride, strideC=M * N, sb={"bias": N * 4})
+        outs = {}
+        for t in (1, tile, tile, -1):
+            out = torch.full((G, M, N), float("nan"), device=DEV)
+            ops.gemm(A, W, out, tile=t, **kw)
+            outs.setdefault(t, []).append(out.cpu())
+        for g in range(G):
+            ref = bf(As[g]).double() @ bf(Ws[g]).double().T + bias[g].cpu().double()
+            assert rel_err(outs[tile][0][g], ref) < 2e-3, (tile, M, N, K, g)
+            assert rel_err(outs[tile][0][g], outs[1][0][g]) < 1e-5
+            assert rel_err(outs[-1][0][g], outs[1][0][g]) < 1e-5
+        assert torch.equal(outs[tile][0], outs[tile][1])
 
 
 @pytest.mark.parametrize("wdt", [torch.float32, torch.bfloat16])

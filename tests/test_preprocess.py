@@ -62,6 +62,58 @@ def test_host_tables_and_plans_match_oracle():
         PP.preprocess_image(np.zeros((4, 4, 3), np.float32), 224, device="cpu")
 
 
+def _crop_cases():
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "crop_plan.npz"))
+    tags = sorted({k.rsplit("_", 1)[0] for k in g.files if k.endswith("_hw")})
+    return g, tags
+
+
+def test_crop_plan_equals_the_references_own_functions():
+    """f3 pin: tests/golden/crop_plan.npz was written by the reference's unmodified `_crop_resize_if_necessary` +
+    cropping.py (make_golden.py crop).  Integer work: every box, the resize target and the uint8 image must be EQUAL --
+    for the oracle's restatement and for the product's plan (incl. the rng draw of near-square inputs)."""
+    import hashlib
+    g, tags = _crop_cases()
+    assert len(tags) >= 12
+    flips = 0
+    for t in tags:
+        H, W = (int(v) for v in g[t + "_hw"])
+        res = tuple(int(v) for v in g[t + "_res"])
+        seed = int(t.split("_s")[1])
+        want = dict(crop0=tuple(g[t + "_crop0"].tolist()), resize=tuple(g[t + "_resize"].tolist()), crop1=tuple(g[t + "_crop1"].tolist()))
+        for plan in (PO.demo_plan(H, W, res, np.random.default_rng(seed)), PP.plan_view(H, W, res, np.random.default_rng(seed))):
+            assert {k: plan[k] for k in want} == want, (t, plan, want)
+        flips += int(want["crop1"][2] - want["crop1"][0] != res[0])
+        i = int(t[1:].split("_")[0])
+        img = PO.view_u8(_image(H, W, seed=H + i), res, np.random.default_rng(seed))
+        assert tuple(img.shape) == tuple(g[t + "_img_shape"].tolist())
+        c = img[img.shape[0] // 2 - 8: img.shape[0] // 2 + 8, img.shape[1] // 2 - 8: img.shape[1] // 2 + 8]
+        assert np.array_equal(c, g[t + "_img_centre"])
+        assert hashlib.sha256(np.ascontiguousarray(img).tobytes()).digest() == g[t + "_img_sha256"].tobytes(), t
+    assert flips >= 3          # portraits and at least one coin flip are in the fixture
+
+
+@pytest.mark.gpu
+def test_preprocess_kernels_equal_the_reference_output():
+    """the device pipeline against the uint8 images the reference's own function produced (same fixture): ImgNorm of a uint8
+    image is exactly invertible, so the fp32 output is mapped back to bytes and hashed"""
+    import hashlib
+    g, tags = _crop_cases()
+    for t in tags:
+        H, W = (int(v) for v in g[t + "_hw"])
+        res = tuple(int(v) for v in g[t + "_res"])
+        seed, i = int(t.split("_s")[1]), int(t[1:].split("_")[0])
+        img, ts = PP.preprocess_image(_image(H, W, seed=H + i), res, rng=np.random.default_rng(seed))
+        x = img[0].cpu().numpy()
+        h, w = ts[0].tolist()
+        if h > w:                                              # portraits come back rotated to landscape
+            x = x.transpose(0, 2, 1)
+        u8 = np.rint((x * np.float32(0.5) + np.float32(0.5)) * 255.0).astype(np.uint8).transpose(1, 2, 0)
+        assert tuple(u8.shape) == tuple(g[t + "_img_shape"].tolist())
+        assert hashlib.sha256(np.ascontiguousarray(u8).tobytes()).digest() == g[t + "_img_sha256"].tobytes(), t
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("hw,res", [((480, 640), 224), ((640, 480), 224), ((375, 500), (512, 384)), ((700, 500), (512, 384)),
                                     ((97, 131), 224), ((1080, 1920), (512, 288))])

@@ -52,7 +52,9 @@ if args.big:
               ("enc proj", 1960, 1024, 1024, 1), ("c3 dec qkv", 1024, 2304, 768, 2), ("c3 dec fc1", 1024, 3072, 768, 2),
               ("c3 dec fc2", 1024, 768, 3072, 2), ("c3 dec proj", 1024, 768, 768, 2), ("c3 val fc1", 1024, 4096, 1024, 1),
               ("c3 val proj", 1024, 1024, 1024, 1), ("c3 val fc2", 1024, 1024, 4096, 1), ("c3 key 2", 1024, 1024, 1792, 2)]
-    tiles = [1, 2, 5, 6]
+    shapes += [("enc16 qkv", 16384, 3072, 1024, 1), ("enc16 fc2", 16384, 1024, 4096, 1), ("read S", 1024, 50176, 1024, 1),
+               ("read PV", 1024, 1024, 50176, 1), ("train fc1", 784, 4096, 1024, 1), ("train dec", 784, 768, 3072, 2)]
+    tiles = [1, 5, 6, 20, 21, 22, 23]
 else:
     M = args.M
     shapes = [("dec qkv", M, 2304, 768, 2), ("dec proj", M, 768, 768, 2), ("dec ckv", M, 1536, 768, 2), ("dec fc1", M, 3072, 768, 2),
@@ -83,8 +85,8 @@ for name, M, N, K, G in shapes:
     ACT = ops.ACT_GELU if ("fc1" in name or name == "key 0") else ops.ACT_NONE
     part = torch.empty(8 * G * M * N, device=dev)
     for tile in tiles:
-        BN = {0: 32, 9: 32}.get(tile, 64)
-        BM = {0: 32, 4: 32, 18: 16, 20: 64, 21: 64, 8: 208, 12: 208, 15: 208, 5: 128, 6: 128, 1: 64, 2: 64}.get(tile, 112)
+        BN = {0: 32, 9: 32, 5: 128, 20: 128, 21: 128, 2: 128}.get(tile, 64)
+        BM = {0: 32, 4: 32, 18: 16, 20: 256, 21: 128, 22: 128, 23: 64, 8: 208, 12: 208, 15: 208, 5: 128, 6: 128, 1: 64, 2: 64}.get(tile, 112)
         wgs = ((M + BM - 1) // BM) * ((N + BN - 1) // BN) * G
         sks = [0]
         if not args.big and tile != 0 and G == 1:
