@@ -435,7 +435,7 @@ void gemm_kernel(const GemmArgs args) {
   const TW* W = reinterpret_cast<const TW*>(d.W) + (int64_t)bz * d.strideW;
 
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  int64_t* tr0 = (LOOP == 0 && args.d.trace && blockIdx.x < 8 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) ? args.d.trace + blockIdx.x * 64 : nullptr;
+  int64_t* tr0 = ((LOOP == 0 || LOOP == -1) && args.d.trace && blockIdx.x < 8 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) ? args.d.trace + blockIdx.x * 64 : nullptr;
   if (tr0) { tr0[0] = clock64(); tr0[3] = wall_clock64(); }
   ARows<TA, LOADER, MF> arows;
   arows.init(d, A, m0 + wm * MF * 16, lane, M_::KB, M_::CH);
@@ -827,11 +827,13 @@ void gemm_kernel(const GemmArgs args) {
     };
     using B0 = std::integral_constant<int, 0>;
     using B1 = std::integral_constant<int, 1>;
+    if (tr0) tr0[5] = clock64();
     {
       const int newer = nk - 1;
       wait_pending(newer < NST - 1 ? newer : NST - 1);
       asm volatile("s_barrier" ::: "memory");
     }
+    if (tr0) tr0[6] = clock64();
     int slot = 0;
     if constexpr (WK == 1) {
       read_half(B0{}, 0, 0);
@@ -1318,6 +1320,7 @@ void gemm_kernel(const GemmArgs args) {
           d.trace[blockIdx.x * 64 + 4] = wall_clock64();
         }
       }
+      if (tr0) { tr0[2] = clock64(); tr0[4] = wall_clock64(); }
       return;
     }
   }
@@ -1713,11 +1716,15 @@ static int gemm_prepare(sp3_gemm_desc& d, int& tile_out) {
                         d.epi != SP3_EPI_PARTIAL && d.K % 64 == 0;
     // SP3_PIPE_TILES=0 switches the pipelined LDS tiles (20-23) off: A/B runs against the round-2 tile choice
     static const bool pipe_on = [] { const char* e = getenv("SP3_PIPE_TILES"); return !(e && e[0] == '0'); }();
-    if (lds_ok && pipe_on && d.M >= 512) {
-      // many-row GEMMs on packed bf16 operands: the largest pipelined tile that still gives (almost) every CU a workgroup
-      const long mt256 = (d.M + 255) / 256, mt128 = (d.M + 127) / 128, nt128 = (d.N + 127) / 128, nt64 = (d.N + 63) / 64;
-      if (mt256 * nt128 * d.batch >= 192) tile = 20;
-      else if (mt128 * nt128 * d.batch >= 192) tile = 21;
+    // (split-K partials too: the PARTIAL epilogue is tile-agnostic; every K slice must hold whole k-blocks)
+    const bool pipe_ok = d.loader == SP3_LOAD_PLAIN && !d.sm_stats_out && d.a_packed && d.w_packed && d.a_bf16 && !d.A2 && d.K % 64 == 0 &&
+                         (sk == 1 || d.epi == SP3_EPI_PARTIAL);
+    if (pipe_ok && pipe_on && d.M >= 512) {
+      // many-row GEMMs on packed bf16 operands: the largest pipelined tile that still gives most CUs a workgroup
+      // (tools/bench_gemm2.py --big on MI355X, profiles/r03_gemm_manyrow_tile_sweep.txt)
+      const long mt256 = (d.M + 255) / 256, mt128 = (d.M + 127) / 128, nt128 = (d.N + 127) / 128;
+      if (mt256 * nt128 * d.batch * sk >= 144) tile = 20;
+      else if (mt128 * nt128 * d.batch * sk >= 200) tile = 21;
       else tile = 22;
     } else if (lds_ok && d.M >= 1024 && d.N >= 2304 && d.N % 128 == 0) {
       // LDS-staged operands (tools/bench_gemm2.py --big, HBM-cold weights, also grouped launches): 128x128 for large grids

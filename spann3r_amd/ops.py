@@ -106,16 +106,16 @@ _TILE_NAMES = {0: "32x32xk4", 1: "64x64", 2: "64x128", 3: "64x64xk4", 4: "32x64x
                14: "112x64wreg4", 15: "208x64wreg8", 16: "112x64wreg4l6", 17: "112x64wreg8l4"}
 
 
-def pick_tile(M, N, batch=1, splitk=1, conv=False, K=0, packed_bf16=False, plain=False, ln_nt=0):
+def pick_tile(M, N, batch=1, splitk=1, conv=False, K=0, packed_bf16=False, plain=False, ln_nt=0, pipe_ok=False):
     """Mirror of the auto heuristic in csrc/gemm.hip (kept in sync so profiles can be keyed by instantiation)."""
     t64 = ((M + 63) // 64) * ((N + 63) // 64) * batch * splitk
     t128 = ((M + 63) // 64) * ((N + 127) // 128) * batch
     lds_ok = not conv and splitk == 1 and packed_bf16 and K % 64 == 0
-    if lds_ok and PIPE_TILES and M >= 512:
+    if pipe_ok and PIPE_TILES and M >= 512:
         mt256, mt128, nt128 = (M + 255) // 256, (M + 127) // 128, (N + 127) // 128
-        if mt256 * nt128 * batch >= 192:
+        if mt256 * nt128 * batch * splitk >= 144:
             return 20
-        if mt128 * nt128 * batch >= 192:
+        if mt128 * nt128 * batch * splitk >= 200:
             return 21
         return 22
     if lds_ok and M >= 1024 and N >= 2304 and N % 128 == 0:
@@ -174,11 +174,16 @@ class pair:
         return False
 
 
+def _pipe_ok(d):
+    return bool(d.loader == L.LOAD_PLAIN and d.a_packed and d.w_packed and d.a_bf16 and not d.A2 and not d.sm_stats_out and d.K % 64 == 0
+                and (max(d.splitk, 1) == 1 or d.epi == L.EPI_PARTIAL))
+
+
 def _pick(d):
     d.tile = pick_tile(d.M, d.N, max(d.batch, 1), max(d.splitk, 1), d.loader == L.LOAD_CONV3X3, d.K,
                        bool(d.a_packed and d.w_packed and d.a_bf16 and not d.A2 and d.epi != L.EPI_PARTIAL
                             and not d.sm_stats_out),
-                       d.epi == L.EPI_PLAIN, d.ln_nt if d.ln_stats else 0)
+                       d.epi == L.EPI_PLAIN, d.ln_nt if d.ln_stats else 0, _pipe_ok(d))
 
 
 def _gemm_cost(d):
@@ -196,10 +201,7 @@ def _gemm_launch(d, what, loader_name):
     if d.loader == L.LOAD_SOFTMAX:
         d.tile = 1 if d.tile == 1 else 0
     if d.tile < 0:
-        d.tile = pick_tile(d.M, d.N, max(d.batch, 1), max(d.splitk, 1), d.loader == L.LOAD_CONV3X3, d.K,
-                           bool(d.a_packed and d.w_packed and d.a_bf16 and not d.A2 and d.epi != L.EPI_PARTIAL
-                                and not d.sm_stats_out),
-                           d.epi == L.EPI_PLAIN, d.ln_nt if d.ln_stats else 0)
+        _pick(d)
     if _prof is None:
         L.check(L.load().sp3_gemm(C.byref(d), L.stream_ptr()), what)
         return

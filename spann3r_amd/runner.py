@@ -101,117 +101,196 @@ class GradReducer:
     """Gradient averaging across the data-parallel ranks, the part of torch DistributedDataParallel that training.py:322-325
     relies on (one process per GPU; backend "nccl" is RCCL over xGMI, "gloo" in the CPU tests).
 
-    Gradients are packed into flat fp32 buckets in REVERSE parameter order (the order a backward pass finishes them) and
-    each bucket is all-reduced with async_op=True as soon as it is packed, so the collectives of the early buckets overlap
-    the packing of the later ones (and, on the GPU, run on RCCL's own stream next to the backward kernels); `finish()`
-    waits, scales by 1/world and scatters the averages back into `.grad`.  Bucket size: xGMI is point-to-point (7 links x
-    ~153 GB/s per GPU) and a ring all-reduce of S bytes over N ranks moves 2 S (N-1)/N per link at ~2 (N-1) latency hops, so
-    buckets are large (64 MB default: > 95 % of the bandwidth term at 8 ranks) -- the NVSwitch-era 25 MB default of DDP
-    is latency-dominated here.  Parameters without a gradient contribute zeros (find_unused_parameters=True semantics).
-    With no process group initialised every call is a no-op (single-GPU runs).
+    Layout.  Parameters are grouped into buckets in REVERSE parameter order (the order a backward pass finishes them) and
+    every bucket owns ONE flat fp32 buffer; each parameter's `.grad` IS a view of its bucket (`flat=True`, the default), so
+    autograd accumulates straight into the buffer the collective runs on: no pack / unpack copies, one all-reduce and one
+    scale per bucket.  A parameter starts at a multiple of `align` elements (default 1024) so that bucket-wide kernels (the
+    multi-tensor AdamW, the gradient-norm reduction) can look up per-parameter constants per 1024-element chunk
+    (`chunk_table`).  `zero_grad()` zeroes the buckets (never `set_to_none`: that would detach the views; a detached or
+    replaced `.grad` is noticed at launch time and copied in, so foreign optimizers still work, just slower).
+    Bucket size: xGMI is point-to-point (7 links x ~153 GB/s per GPU) and a ring all-reduce of S bytes over N ranks moves
+    2 S (N-1)/N per link at ~2 (N-1) latency hops, so buckets are large (64 MB default: > 95 % of the bandwidth term at 8
+    ranks) -- the NVSwitch-era 25 MB default of DDP is latency-dominated here.
 
-    overlap=True registers a post-accumulate-grad hook on every parameter: `prepare()` before `backward()` arms the buckets, a
-    bucket's all-reduce is launched from inside the backward pass the moment its last gradient has been accumulated (the
-    collective of the last layers runs while the first layers are still being differentiated), and `finish()` after
-    `backward()` launches whatever is left (buckets holding unused parameters), waits and writes the means back."""
+    Ordering.  Collectives are matched across ranks by ISSUE ORDER, so buckets are launched strictly in bucket-index order
+    on every rank: with `overlap=True` a post-accumulate-grad hook marks a bucket ready when its last gradient of this
+    backward pass has arrived and launches every consecutive ready bucket from the first unlaunched one (a ready bucket
+    behind an unready one waits, as in DDP); `finish()` launches the rest in order -- buckets holding parameters that got
+    no gradient on THIS rank (find_unused_parameters=True semantics: they contribute zeros) -- waits, and divides by the
+    world size.  Which parameters were used on ANY rank is exchanged as a bitmap (one small MAX all-reduce, as DDP does):
+    `unused_everywhere()` lists the parameters an optimizer should skip (torch leaves their .grad None and skips them).
+    With no process group (or world 1, unless `force=True`: single-GPU tests of the RCCL path) every call is a no-op."""
 
-    def __init__(self, params, bucket_mb=64.0, group=None, overlap=False):
-        import torch
+    def __init__(self, params, bucket_mb=64.0, group=None, overlap=False, flat=True, align=1024, force=False):
         self.params = [p for p in params if p.requires_grad]
-        self.group = group
+        self.group, self.flat, self.align, self.force = group, flat, (align if flat else 1), force
         self.buckets, cur, size = [], [], 0
         cap = int(bucket_mb * (1 << 20)) // 4
+        pad = lambda n: (n + self.align - 1) // self.align * self.align
         for p in reversed(self.params):
-            if cur and size + p.numel() > cap:
+            if cur and size + pad(p.numel()) > cap:
                 self.buckets.append(cur)
                 cur, size = [], 0
             cur.append(p)
-            size += p.numel()
+            size += pad(p.numel())
         if cur:
             self.buckets.append(cur)
+        self.offsets = []                               # per bucket: element offset of each parameter
+        self.sizes = []
+        for b in self.buckets:
+            o, offs = 0, []
+            for p in b:
+                offs.append(o)
+                o += pad(p.numel())
+            self.offsets.append(offs)
+            self.sizes.append(o)
         self._flat = [None] * len(self.buckets)
-        self._work = []
-        self._torch = torch
+        self._work = [None] * len(self.buckets)
+        self._used = None
+        self._used_work = None
         self.launched_in_backward = 0          # (statistics of the last step: buckets whose collective started from a hook)
         self._armed = False
+        self._started = False
+        self._next = 0
         self._pending = None
         self._bucket_of = {id(p): i for i, b in enumerate(self.buckets) for p in b}
+        self._index_of = {id(p): j for j, p in enumerate(self.params)}
+        self._touched = [False] * len(self.params)
+        if flat:
+            self._attach()
         if overlap:
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._on_grad)
+
+    # ------------------------------------------------------------------ flat buckets
+    def _buffer(self, i):
+        dev = self.buckets[i][0].device
+        if self._flat[i] is None or self._flat[i].device != dev:
+            self._flat[i] = torch.zeros(self.sizes[i], dtype=torch.float32, device=dev)
+        return self._flat[i]
+
+    def _view(self, i, j):
+        p = self.buckets[i][j]
+        o = self.offsets[i][j]
+        return self._buffer(i)[o:o + p.numel()].view_as(p)
+
+    def _attach(self):
+        """(re)point every .grad at its bucket slice, keeping the values of gradients that already exist"""
+        for i, b in enumerate(self.buckets):
+            for j, p in enumerate(b):
+                v = self._view(i, j)
+                if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
+                    v.copy_(p.grad)
+                    self._touched[self._index_of[id(p)]] = True
+                p.grad = v
+
+    def flat_buffers(self):
+        """[(flat gradient buffer, [(parameter, element offset)])] per bucket, for bucket-wide kernels"""
+        return [(self._buffer(i), list(zip(b, self.offsets[i]))) for i, b in enumerate(self.buckets)]
+
+    def zero_grad(self):
+        for i in range(len(self.buckets)):
+            if self.flat:
+                self._buffer(i).zero_()
+            else:
+                for p in self.buckets[i]:
+                    p.grad = None
+        self._touched = [False] * len(self.params)
+        if self.flat:
+            self._attach()
+
+    # ------------------------------------------------------------------ collectives
+    def active(self):
+        if not (dist.is_available() and dist.is_initialized()):
+            return False
+        return self.force or dist.get_world_size(self.group) > 1
 
     def prepare(self):
         """arm the hooks for the backward pass that follows (overlap=True)"""
         self._work = [None] * len(self.buckets)
         self._pending = [len(b) for b in self.buckets]
+        self._next = 0
+        self._started = False
         self.launched_in_backward = 0
         self._armed = self.active()
 
     def _on_grad(self, p):
+        self._touched[self._index_of[id(p)]] = True
         if not self._armed:
             return
         i = self._bucket_of[id(p)]
         self._pending[i] -= 1
-        if self._pending[i] == 0:
-            self._work[i] = self._launch(i)
+        # strictly in bucket order: a ready bucket behind an unready one waits for it (or for finish())
+        while self._next < len(self.buckets) and self._pending[self._next] <= 0:
+            self._work[self._next] = self._launch(self._next)
+            self._next += 1
             self.launched_in_backward += 1
 
     def _launch(self, i):
-        import torch.distributed as dist
-        torch = self._torch
-        bucket = self.buckets[i]
-        n = sum(p.numel() for p in bucket)
-        dev = bucket[0].device
-        if self._flat[i] is None or self._flat[i].device != dev:
-            self._flat[i] = torch.empty(n, dtype=torch.float32, device=dev)
-        flat, o = self._flat[i], 0
-        for p in bucket:
-            v = flat[o:o + p.numel()]
+        flat = self._buffer(i)
+        for j, p in enumerate(self.buckets[i]):
+            v = self._view(i, j)
             if p.grad is None:
-                v.zero_()
-            else:
-                v.copy_(p.grad.reshape(-1))
-            o += p.numel()
+                if not self.flat:
+                    v.zero_()
+                else:
+                    v.zero_()
+                    p.grad = v
+            elif p.grad.data_ptr() != v.data_ptr():       # somebody replaced .grad (foreign zero_grad / optimizer): copy it in
+                v.copy_(p.grad.reshape(p.shape))
+                if self.flat:
+                    p.grad = v
         return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
-    def active(self):
-        import torch.distributed as dist
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
-
     def start(self):
-        """pack + launch the all-reduces of every bucket that has not started yet (call right after backward)"""
-        if not self.active():
+        """launch, in bucket order, the all-reduce of every bucket that has not started yet (call right after backward)"""
+        if not self.active() or self._started:
             return
         if not self._armed:
             self._work = [None] * len(self.buckets)
-        for i in range(len(self.buckets)):
-            if self._work[i] is None:
-                self._work[i] = self._launch(i)
+            self._next = 0
+        self._started = True
+        while self._next < len(self.buckets):
+            self._work[self._next] = self._launch(self._next)
+            self._next += 1
         self._armed = False
+        # which parameters got a gradient on ANY rank (without hooks: whatever holds a non-None gradient counts as used)
+        touched = self._touched
+        if not any(touched):
+            touched = [p.grad is not None for p in self.params]
+        used = torch.tensor([1 if t else 0 for t in touched], dtype=torch.int32, device=self.params[0].device)
+        self._used = used
+        self._used_work = dist.all_reduce(used, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
 
     def finish(self):
-        """launch what the hooks have not (unused parameters), wait for the collectives, write the averaged gradients back"""
+        """launch what the hooks have not (buckets with parameters unused on this rank), wait for the collectives, average"""
         if not self.active():
-            self._work, self._armed = [], False
+            self._armed = False
             return
-        if self._armed:
-            self.start()
-        if not self._work or any(w is None for w in self._work):
-            return
-        import torch.distributed as dist
-        torch = self._torch
+        self.start()                                      # (also the path of finish() without prepare() / start())
         inv = 1.0 / dist.get_world_size(self.group)
-        for w, flat, bucket in zip(self._work, self._flat, self.buckets):
+        for i, (w, bucket) in enumerate(zip(self._work, self.buckets)):
             w.wait()
-            o = 0
-            for p in bucket:
-                g = flat[o:o + p.numel()].view_as(p) * inv
-                if p.grad is None:
-                    p.grad = g.clone()
-                else:
-                    p.grad.copy_(g)
-                o += p.numel()
-        self._work = []
+            flat = self._flat[i]
+            flat.mul_(inv)
+            if not self.flat:
+                for j, p in enumerate(bucket):
+                    g = self._view(i, j)
+                    if p.grad is None:
+                        p.grad = g.clone()
+                    else:
+                        p.grad.copy_(g)
+        self._used_work.wait()
+        self._work = [None] * len(self.buckets)
+        self._next = 0
+        self._started = False
+
+    def unused_everywhere(self):
+        """parameters that received no gradient on any rank in the step just reduced (DDP leaves their .grad None)"""
+        if self._used is None:
+            return []
+        u = self._used.cpu().tolist()
+        return [p for p, f in zip(self.params, u) if not f]
 
     def reduce(self):
         self.start()

@@ -217,6 +217,10 @@ for i, p in enumerate(params):
 mine = [None if p.grad is None else p.grad.clone() for p in params]
 red = GradReducer(params + [frozen], bucket_mb=0.01)     # ~2600 floats per bucket -> several buckets
 assert len(red.buckets) >= 3 and red.buckets[0][0] is params[-1]
+# flat buckets: every .grad is a view of its bucket, the existing values were adopted
+for (flat, items) in red.flat_buffers():
+    for p, o in items:
+        assert p.grad.data_ptr() == flat.data_ptr() + 4 * o and o %% 1024 == 0
 red.start(); red.finish()
 # reference: gather every rank's gradients and average
 for i, p in enumerate(params):
@@ -224,7 +228,12 @@ for i, p in enumerate(params):
     allg = [torch.zeros_like(loc) for _ in range(world)]
     dist.all_gather(allg, loc)
     assert torch.allclose(p.grad, sum(allg) / world, atol=1e-7), i
-assert frozen.grad is None
+assert frozen.grad is None and red.unused_everywhere() == []
+# finish() alone (no prepare / start) still reduces: ranks never diverge silently
+for p in params:
+    p.grad.fill_(float(rank + 1))
+red.finish()
+assert all(torch.allclose(p.grad, torch.full_like(p.grad, (1 + world) / 2.0)) for p in params)
 # overlap=True: the collectives start from inside backward, bucket by bucket, in reverse layer order
 torch.manual_seed(1)
 net = torch.nn.Sequential(torch.nn.Linear(40, 64), torch.nn.Tanh(), torch.nn.Linear(64, 64), torch.nn.Tanh(), torch.nn.Linear(64, 8))
@@ -236,7 +245,7 @@ red2.prepare()
 net(x).square().mean().backward()
 started = red2.launched_in_backward
 red2.finish()
-assert started >= 2, started                               # all buckets but the one holding the unused parameter
+assert started == 0, started                               # the unused parameter sits in bucket 0: everything waits for finish()
 ref = torch.nn.Sequential(torch.nn.Linear(40, 64), torch.nn.Tanh(), torch.nn.Linear(64, 64), torch.nn.Tanh(), torch.nn.Linear(64, 8))
 ref.load_state_dict(net.state_dict())
 tot = [torch.zeros_like(p) for p in ref.parameters()]
@@ -248,6 +257,38 @@ for r in range(world):
 for p, t in zip(net.parameters(), tot):
     assert torch.allclose(p.grad, t / world, atol=1e-7)
 assert torch.equal(unused.grad, torch.zeros(5))            # contributed zeros on every rank
+assert [q is unused for q in red2.unused_everywhere()] == [True]
+# a parameter unused on ONE rank only (a head that rank 1's batch never reaches): hooks fire in different patterns on the
+# two ranks, the collectives must still pair up bucket by bucket (ADVICE r2: issue order, not readiness order)
+torch.manual_seed(2)
+trunk, head_a, head_b = torch.nn.Linear(30, 50), torch.nn.Linear(50, 50), torch.nn.Linear(50, 50)
+allp = list(trunk.parameters()) + list(head_a.parameters()) + list(head_b.parameters())
+red3 = GradReducer(allp, bucket_mb=0.008, overlap=True)
+assert len(red3.buckets) >= 3
+for step in range(2):
+    red3.zero_grad()
+    red3.prepare()
+    xin = torch.randn(8, 30, generator=torch.Generator().manual_seed(300 + 10 * step + rank))
+    h = torch.tanh(trunk(xin))
+    out = head_a(h) if rank == 0 else head_a(h) + head_b(h) * 0.5        # rank 0 never touches head_b
+    out.square().mean().backward()
+    red3.finish()
+    want = [torch.zeros_like(p) for p in allp]
+    for r in range(world):
+        for p in allp:
+            p_ = p.detach()
+        t2, a2, b2 = torch.nn.Linear(30, 50), torch.nn.Linear(50, 50), torch.nn.Linear(50, 50)
+        t2.load_state_dict(trunk.state_dict()); a2.load_state_dict(head_a.state_dict()); b2.load_state_dict(head_b.state_dict())
+        xin2 = torch.randn(8, 30, generator=torch.Generator().manual_seed(300 + 10 * step + r))
+        h2 = torch.tanh(t2(xin2))
+        o2 = a2(h2) if r == 0 else a2(h2) + b2(h2) * 0.5
+        o2.square().mean().backward()
+        for w_, q in zip(want, list(t2.parameters()) + list(a2.parameters()) + list(b2.parameters())):
+            if q.grad is not None:
+                w_ += q.grad
+    for p, w_ in zip(allp, want):
+        assert torch.allclose(p.grad, w_ / world, atol=1e-6), step
+    assert red3.unused_everywhere() == []
 if rank == 0:
     print("OK grads", started)
 dist.destroy_process_group()

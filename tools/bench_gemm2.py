@@ -18,6 +18,7 @@ ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--only", default="", help="comma list of op names")
 ap.add_argument("--tiles", default="")
 ap.add_argument("--mb", type=int, default=320, help="MB of distinct weight copies to cycle through")
+ap.add_argument("--ksweep", action="store_true", help="one many-row shape at several K: fixed cost vs cost per k-block")
 args = ap.parse_args()
 dev = "cuda"
 DT = torch.bfloat16 if args.dtype == "bf16" else torch.float32
@@ -62,6 +63,9 @@ else:
               ("val fc2", M, 1024, 4096, 1), ("key 0", M, 1792, 1792, 2), ("key 2", M, 1024, 1792, 2)]
     tiles = [0, 13, 14, 16, 17]
 
+if args.ksweep:
+    shapes = [("k%d" % K, 1960, 4096, K, 1) for K in (128, 512, 1024, 2048, 4096)] + [("n1k k%d" % K, 1960, 1024, K, 1) for K in (128, 1024, 4096)]
+    tiles = [5, 20, 21, 22]
 print("%-12s %-18s %-5s %-3s %8s %9s %9s" % ("op", "MxNxK x batch", "tile", "sk", "us", "TFLOP/s", "W GB/s"))
 if args.tiles:
     tiles = [int(t) for t in args.tiles.split(',')]

@@ -1,0 +1,38 @@
+#!/bin/bash
+# One entry point for the GPU-box sessions of a round (gpurun ships the repository and runs ONE command):
+#   gpurun --timeout 900 -- 'bash tools/gpu_run.sh <tag> <stage> [<stage> ...]'
+# Every stage writes under gpurun_out/<tag>/ (merged back by gpurun).  Stages:
+#   optests   kernel-level parity tests (tests/test_ops_gpu.py)          gemmsweep  tile sweep of the many-row GEMMs
+#   modeltests tests/test_model_gpu.py                                    alltests   the whole -m gpu suite
+#   bench     python bench.py (default line)                              benchfast  bench.py without extras / CPU baseline
+#   benchab   benchfast with SP3_PIPE_TILES=1 and =0                      prof       rocprofv3 --kernel-trace --stats of benchfast
+#   train     tools/train_step_time.py                                    memread    tools/bench_memread.py
+set -u
+cd "$(dirname "$0")/.."
+TAG=$1; shift
+OUT=gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+for stage in "$@"; do
+  echo "=== $stage $(date +%T)" | tee -a "$OUT/log.txt"
+  case $stage in
+    optests)    timeout 900 python -m pytest tests/test_ops_gpu.py -x -q -m gpu > "$OUT/optests.txt" 2>&1; tail -5 "$OUT/optests.txt" ;;
+    pipetests)  timeout 600 python -m pytest tests/test_ops_gpu.py -x -q -m gpu -k "lds_staged or pipelined" > "$OUT/pipetests.txt" 2>&1; tail -15 "$OUT/pipetests.txt" ;;
+    modeltests) timeout 1200 python -m pytest tests/test_model_gpu.py -x -q -m gpu > "$OUT/modeltests.txt" 2>&1; tail -5 "$OUT/modeltests.txt" ;;
+    alltests)   timeout 2400 python -m pytest tests -x -q -m gpu > "$OUT/alltests.txt" 2>&1; tail -8 "$OUT/alltests.txt" ;;
+    gemmsweep)  timeout 600 python tools/bench_gemm2.py --big > "$OUT/gemmsweep.txt" 2>&1; cat "$OUT/gemmsweep.txt" ;;
+    ksweep)     timeout 600 python tools/bench_gemm2.py --big --ksweep > "$OUT/ksweep_cold.txt" 2>&1; cat "$OUT/ksweep_cold.txt"; timeout 600 python tools/bench_gemm2.py --big --ksweep --mb 1 > "$OUT/ksweep_warm.txt" 2>&1; cat "$OUT/ksweep_warm.txt" ;;
+    pmcgemm)    for C in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" ; do
+                  n=$(echo $C | cut -d" " -f1); (cd /tmp && timeout 300 rocprofv3 --pmc $C -d "$OLDPWD/$OUT/pmc_$n" -o run --output-format csv -- python "$OLDPWD/tools/bench_gemm2.py" --big --only "enc16 fc2,enc fc1" --tiles 20,5 > "$OLDPWD/$OUT/pmc_$n.log" 2>&1); F=$(find "$OUT/pmc_$n" -name "*counter_collection.csv" | head -1); python tools/pmc_csv.py "$F" > "$OUT/pmc_$n.txt" 2>&1; rm -rf "$OUT/pmc_$n"; cat "$OUT/pmc_$n.txt"; done ;;
+    tracegemm)  for t in 20 22; do for a in gelu noact; do timeout 120 python tools/trace_gemm.py $t $a >> "$OUT/tracegemm.txt" 2>&1; done; done; cat "$OUT/tracegemm.txt" ;;
+    bench)      timeout 900 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; head -c 1500 "$OUT/bench.json"; tail -3 "$OUT/bench.err" ;;
+    benchfast)  timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > "$OUT/benchfast.json" 2> "$OUT/benchfast.err"; head -c 1200 "$OUT/benchfast.json"; tail -3 "$OUT/benchfast.err" ;;
+    benchab)    for v in 1 0; do SP3_PIPE_TILES=$v timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --no-profile > "$OUT/bench_pipe$v.json" 2> "$OUT/bench_pipe$v.err"; echo "PIPE=$v"; head -c 400 "$OUT/bench_pipe$v.json"; echo; tail -2 "$OUT/bench_pipe$v.err"; done ;;
+    bench3)     timeout 600 python bench.py --size 512 --frames 50 --train-policy --steps 3 --warmup 2 --no-cpu-baseline --no-extras > "$OUT/bench3.json" 2> "$OUT/bench3.err"; head -c 1500 "$OUT/bench3.json"; tail -3 "$OUT/bench3.err" ;;
+    prof)       (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/prof" -o run -- python "$OLDPWD/bench.py" --steps 6 --warmup 3 --no-cpu-baseline --no-profile --no-extras > "$OLDPWD/$OUT/prof.log" 2>&1); DB=$(find "$OUT/prof" -name "*results.db" | head -1); python tools/rocpd_stats.py "$DB" > "$OUT/prof_stats.md" 2>&1; python tools/rocpd_lastseq.py "$DB" > "$OUT/prof_lastseq.txt" 2>&1; rm -rf "$OUT/prof"; head -40 "$OUT/prof_stats.md" ;;
+    train)      timeout 900 python tools/train_step_time.py > "$OUT/train.txt" 2>&1; tail -20 "$OUT/train.txt" ;;
+    memread)    timeout 600 python tools/bench_memread.py > "$OUT/memread.txt" 2>&1; tail -30 "$OUT/memread.txt" ;;
+    *)          echo "unknown stage $stage" ;;
+  esac
+done
+echo "=== done $(date +%T)" | tee -a "$OUT/log.txt"
