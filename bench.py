@@ -59,6 +59,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-extras", action="store_true", help="skip the fp32 and config-3 secondary measurements")
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--train-policy", action="store_true", help="growing bank (train-mode memory policy, dropout off)")
+    ap.add_argument("--train", action="store_true", help="time the training step (BASELINE config 5 per rank: batch 4, 5 frames of 224x224, "
+                                                         "ConfLoss backward through the memory fusion, AdamW) instead of the forward")
+    ap.add_argument("--train-precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--train-batch", type=int, default=4)
     ap.add_argument("--schedule", default="", help="comma list of schedule switches to turn OFF: batch_encode, defer_head2, "
                                                    "grouped_decoder (debugging / A-B runs; default = the shipped schedule)")
     return ap.parse_args(argv)
@@ -262,6 +266,61 @@ def memread_replay(model, reps=20):
                       "replay" % reps}
 
 
+def synth_training_batch(seq_id, n_frames, size, batch, dev):
+    """frames + synthetic ground truth (pts3d ~ N((0,0,3), 1), valid_mask ~ Bernoulli(0.9), camera_pose = I)"""
+    import torch
+    from spann3r_amd.runner import make_sequence
+    frames = make_sequence(seq_id, n_frames, size, size, batch=batch, device=dev)
+    g = torch.Generator().manual_seed(7000 + seq_id)
+    gts = []
+    for _ in range(n_frames):
+        gts.append(dict(pts3d=(torch.randn(batch, size, size, 3, generator=g) + torch.tensor([0., 0., 3.])).to(dev),
+                        valid_mask=(torch.rand(batch, size, size, generator=g) < 0.9).to(dev),
+                        camera_pose=torch.eye(4).repeat(batch, 1, 1).to(dev)))
+    return frames, gts
+
+
+def train_measure(dev, steps, warmup, precision, batch, n_frames=5, size=224, world=1):
+    """seconds per training step of the full model on this rank (forward + ConfLoss + backward incl. bucket all-reduces + clip + AdamW)"""
+    import torch
+    import torch.distributed as dist
+    from spann3r_amd import Spann3R, FULL
+    from spann3r_amd.weights import synth_state_dict
+    from spann3r_amd import train as T
+    model = Spann3R(dus3r_name=None, cfg=FULL, init_weights=False)
+    model.load_state_dict(synth_state_dict(0, FULL), strict=True)
+    model = model.to(dev)
+    ts = T.TrainStep(model, precision=precision)
+    rank = int(os.environ.get("RANK", "0"))
+    frames, gts = synth_training_batch(rank, n_frames, size, batch, dev)
+    torch.cuda.reset_peak_memory_stats()
+    for _ in range(warmup):
+        loss, norm = ts.run(frames, gts)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss, norm = ts.run(frames, gts)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    sec = (time.perf_counter() - t0) / steps
+    # algorithmic FLOPs: forward of (n frames encoded, n-1 steps) per sample, backward = 2x forward
+    fl = 3.0 * batch * flops_per_sequence(n_frames, size)
+    out = {"seconds_per_step": sec, "frames_per_s": batch * n_frames / sec, "loss": float(loss), "grad_norm": float(norm) if norm is not None else None,
+           "achieved_tflops": fl / sec / 1e12, "frac_of_mfma_peak": fl / sec / 1e12 / PEAK_TFLOPS["bf16" if precision == "bf16" else "fp32"],
+           "peak_memory_gb": torch.cuda.max_memory_allocated() / 2 ** 30, "precision": precision, "batch": batch, "frames": n_frames, "size": size,
+           "rccl_ranks": world, "buckets": len(ts.reducer.buckets), "buckets_reduced_inside_backward": ts.reducer.launched_in_backward,
+           "what": "one optimisation step: train-mode Spann3R.forward (HIP autograd ops) + ConfLoss_t(Regr3D_t(L21, avg_dis), 0.4) + backward through the "
+                   "memory fusion + bucketed gradient all-reduce (RCCL, world %d) + global-norm clip 1.0 + AdamW on flat buckets" % world}
+    T.set_precision("fp32")
+    del ts, model
+    torch.cuda.empty_cache()
+    return out
+
+
 def cpu_baseline(sd, size, train_policy):
     """The CPU oracle on this box's host cores: warm-up, a thread-count sweep on a short sequence, then the median of 3
     runs of the bounded sample at the best count."""
@@ -324,6 +383,22 @@ def main():
     dev = torch.device("cuda", local)
 
     from spann3r_amd.runner import make_sequence, gather_stats, aggregate, shard
+
+    if args.train:
+        # BASELINE config 5: data-parallel training, batch 4 per rank ("scaling": weak); value = frames/s over all ranks
+        tr = train_measure(dev, args.steps, args.warmup, args.train_precision, args.train_batch, world=world)
+        stats = gather_stats(args.train_batch * 5 * args.steps, tr["seconds_per_step"] * args.steps, device=dev)
+        fps, _, max_seconds = aggregate(stats)
+        if rank == 0:
+            print(json.dumps({"metric": "training frames/sec (batch %d x %d ranks, 5-frame 224px sequences, ConfLoss backward, AdamW)" % (args.train_batch, world),
+                              "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": 1e3 * max_seconds / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                              "dtype": args.train_precision, "data": "synthetic (seeded frames / ground truth, seeded random-init weights)",
+                              "config": {"workload": "train step, BASELINE config 5 per rank: batch %d, 5 frames of 224x224" % args.train_batch,
+                                         "parallelism": "dp%d (RCCL bucket all-reduce inside backward)" % world}, "train": tr}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     model, sd = build_model(args.precision, dev, args.train_policy, tuple(filter(None, args.schedule.split(","))), not args.no_graphs)
     # rank r owns sequences {s : s mod world == r}; a handful of distinct sequences, cycled
@@ -409,6 +484,15 @@ def main():
         out["config3"] = c3
         del m3
         torch.cuda.empty_cache()
+
+    # ---- the training step (BASELINE config 5, one rank's share): bf16 products, flat buckets, device-side clip
+    if world == 1 and not args.no_extras and args.precision == "bf16":
+        try:
+            del model
+        except NameError:
+            pass
+        torch.cuda.empty_cache()
+        out["train"] = train_measure(dev, 3, 2, "bf16", 4)
 
     # ---- CPU baseline: the oracle (port of the reference algorithm) on this box's host cores, bounded sample
     if world == 1 and not args.no_cpu_baseline:

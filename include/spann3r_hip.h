@@ -391,6 +391,23 @@ int sp3_postprocess_bwd(const float* raw, const float* dpts, const float* dconf,
 int sp3_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
               int step, float grad_scale, void* stream);
 int sp3_mul(const float* a, const float* b, float* out, int64_t n, void* stream);
+/* bf16 training step (spann3r/training.py:170-259 under bf16 autocast): fp32 row-major [rows, cols] (row stride ld) -> the GEMM's bf16
+ * fragment order, as [rows, cols] (dst, nullable) and / or as its transpose [cols, rows] (dstT, nullable) in one pass; pads are written
+ * as zeros.  With both forms every product of a Linear's backward (dX = dY . W, dW = dY^T . X) is an sp3_gemm A . W^T launch on packed
+ * bf16 operands: the ATen calls they replace are the matmuls autograd derives for nn.Linear (croco/models/blocks.py:73-112). */
+int sp3_pack_bf16(const float* src, int64_t ld, int rows, int cols, void* dst, void* dstT, void* stream);
+/* torch.nn.utils.clip_grad_norm_ (croco/utils/misc.py:262-288, called with clip_grad = 1.0 by spann3r/training.py:227-228) on flat
+ * gradient buckets, without a host round trip: sp3_sumsq_partial writes sp3_sumsq_blocks(n) partial sums of squares of one bucket
+ * (fixed order: deterministic), sp3_clip_coef reduces `count` partials of all buckets to out[0] = extra_scale * min(1, max_norm /
+ * (norm + 1e-6)) and out[1] = norm (of the gradients times |extra_scale|; max_norm <= 0: no clipping). */
+int64_t sp3_sumsq_blocks(int64_t n);
+int sp3_sumsq_partial(const float* g, int64_t n, double* partial, void* stream);
+int sp3_clip_coef(const double* partial, int count, float max_norm, float extra_scale, float* out, void* stream);
+/* torch.optim.AdamW (spann3r/training.py:327) over one flat bucket of n elements (n % 1024 == 0): p, g, m, v share the element layout;
+ * chunk_table holds (weight_decay, lr_scale) per 1024-element chunk (lr_scale < 0: chunk untouched -- parameters without a gradient
+ * on any rank); the gradient is multiplied by grad_scale * grad_scale_dev[0] (device scalar, nullable: sp3_clip_coef's out[0]). */
+int sp3_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, const float* chunk_table, float lr, float beta1, float beta2,
+                   float eps, int step, const float* grad_scale_dev, float grad_scale, void* stream);
 int sp3_softmax_bwd(const float* A, const float* dAd, const float* mask, float* dS, int64_t ld, int rows, int T, float alpha, void* stream);
 int sp3_layernorm_bwd(const float* x, int64_t ldx, const float* gamma, const float* dy, int64_t ldy, const float* dx_add, int64_t ld_add,
                       float* dx, int64_t ld_dx, float* dgamma, float* dbeta, int accumulate, float* scratch, int rows, int C, float eps,

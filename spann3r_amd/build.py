@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libspann3r_hip.so")
-SOURCES = ["error.cpp", "gemm.hip", "norm_rope.hip", "attention.hip", "memory.hip", "dpt.hip", "conv.hip", "preproc.hip", "loss.hip", "train.hip", "postproc.hip"]
+SOURCES = ["error.cpp", "gemm.hip", "norm_rope.hip", "attention.hip", "memory.hip", "dpt.hip", "conv.hip", "preproc.hip", "loss.hip", "train.hip", "train2.hip", "postproc.hip"]
 
 
 def needs_build():

@@ -224,6 +224,20 @@ template <> struct MM<float, float> {
       }
     }
   }
+  // f32x3 = 2 ("bf16 products"): fp32 operands in memory, rounded to bf16 on their way into ONE v_mfma_f32_16x16x32_bf16 per
+  // k-block, fp32 accumulate -- the arithmetic of a bf16-autocast matmul on fp32 master tensors (training step, bf16 mode)
+  template <int MF, int NF>
+  static __device__ __forceinline__ void mma_x1(f32x4 (&acc)[MF][NF], const AReg (&a)[MF], const WReg (&w)[NF]) {
+    bf16x8 wh[NF];
+#pragma unroll
+    for (int n = 0; n < NF; ++n) wh[n] = cvt8(w[n].v[0], w[n].v[1]);
+#pragma unroll
+    for (int m = 0; m < MF; ++m) {
+      const bf16x8 ah = cvt8(a[m].v[0], a[m].v[1]);
+#pragma unroll
+      for (int n = 0; n < NF; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wh[n], acc[m][n], 0, 0, 0);
+    }
+  }
   template <int MF, int NF>
   static __device__ __forceinline__ void mma_half(f32x4 (&acc)[MF][NF], const AReg (&a)[MF], const WReg (&w)[NF]) {
 #pragma unroll
@@ -513,7 +527,7 @@ void gemm_kernel(const GemmArgs args) {
   const int kb_lo = kz * per;
   const int kb_hi = (kb_lo + per) < nkb_all ? (kb_lo + per) : nkb_all;
   const bool relu = d.relu_in != 0;
-  const bool x3 = d.f32x3 != 0;              // (fp32 operands only; register-ring tiles)
+  const int xmode = d.f32x3;                 // 1: three bf16 MFMAs per product, 2: one (fp32 operands only; register-ring tiles)
 
   typename M_::AReg a[STAGES][MF];
   typename M_::WReg w[STAGES][NF];
@@ -573,7 +587,8 @@ void gemm_kernel(const GemmArgs args) {
       for (int n = 0; n < NF; ++n) M_::fixW(w[st][n], wm0[st], wm1[st]);
     }
     if constexpr (sizeof(TA) == 4 && sizeof(TW) == 4 && MF * NF <= 8) {      // (the 4x4-fragment fp32 tile has no registers to spare)
-      if (x3) { M_::template mma_x3<MF, NF>(acc, a[st], w[st]); return; }
+      if (xmode == 1) { M_::template mma_x3<MF, NF>(acc, a[st], w[st]); return; }
+      if (xmode == 2) { M_::template mma_x1<MF, NF>(acc, a[st], w[st]); return; }
     }
     M_::template mma<MF, NF>(acc, a[st], w[st]);
   };

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
   }
 }
 
-// LayerNorm backward, one wave per row (C <= 4096, C % 4 == 0): xh = (x - mean) rstd,
+// LayerNorm backward, one wave per row (C <= 2048: 8*C*4 bytes of dynamic LDS stay under the 64 KB default; C % 4 == 0): xh = (x - mean) rstd,
 //   dx = rstd (dy g - mean(dy g) - xh mean(dy g xh)) (+ dx_add), and this row's share of dgamma / dbeta goes to
 //   part[row_block][2][C] (row blocks of 4 rows = one workgroup; summed in fixed order by ln_param_reduce).
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
@@ -310,7 +310,7 @@ extern "C" int sp3_layernorm_bwd(const float* x, int64_t ldx, const float* gamma
                                  int64_t ld_add, float* dx, int64_t ld_dx, float* dgamma, float* dbeta, int accumulate, float* scratch,
                                  int rows, int C, float eps, void* stream) {
   SP3_CHECK(x && gamma && dy && dx && dgamma && dbeta && scratch, "sp3_layernorm_bwd: null pointer");
-  SP3_CHECK(rows > 0 && C > 0 && C % 4 == 0 && C <= 4096, "sp3_layernorm_bwd: rows=%d C=%d", rows, C);
+  SP3_CHECK(rows > 0 && C > 0 && C % 4 == 0 && C <= 2048, "sp3_layernorm_bwd: rows=%d C=%d (C <= 2048, C %% 4 == 0)", rows, C);
   const int nblk = (rows + 3) / 4;
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(256), (size_t)8 * C * sizeof(float), ST(stream), x, ldx, gamma, dy, ldy, dx_add,
                      ld_add, dx, ld_dx, scratch, rows, C, eps);

@@ -1,0 +1,178 @@
+// Training step, bf16 mode (spann3r/training.py:170-259): the pieces that turn the fp32 autograd tape into
+// bf16 MFMA work and the optimizer into a handful of bucket-wide launches.
+//  * sp3_pack_bf16   : fp32 row-major [rows, cols] -> the GEMM's bf16 fragment order (common.h packed_off), as [rows, cols]
+//                      and / or as the TRANSPOSE [cols, rows] in the same pass.  Every product of a Linear's backward is then
+//                      an A . W^T launch on packed operands (dX = dY . (W^T)^T, dW = dY^T . (X^T)^T) -- no fp32 transposes.
+//  * sp3_sumsq_partial / sp3_clip_coef : global gradient norm of the flat gradient buckets in a fixed order (deterministic)
+//                      and torch.nn.utils.clip_grad_norm_'s coefficient, left ON THE DEVICE for the update kernel
+//                      (croco/utils/misc.py:262-288 calls it with clip_grad = 1.0, training.py:227-228).
+//  * sp3_adamw_flat  : torch.optim.AdamW over a whole flat bucket (parameters, gradients, moments share one element layout);
+//                      weight decay / lr scale / skip are looked up per 1024-element chunk (parameters start on chunk
+//                      boundaries: runner.GradReducer), the gradient scale is read from device memory.
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+// one workgroup = a 64 x 64 tile of the source through LDS; both outputs are written as whole 16-byte fragment pieces,
+// 16 consecutive lanes = 256 contiguous bytes.  Elements outside [rows, cols] are written as zeros (the contraction pad of
+// the GEMM must be zero); row blocks beyond the allocation are skipped.
+__global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict__ src, int64_t ld, int rows, int cols,
+                                                        __bf16* __restrict__ dst, __bf16* __restrict__ dstT) {
+  __shared__ float t[64][65];
+  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64, tid = threadIdx.x;
+  const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int rl = (tid >> 4) + 16 * i, cl = (tid & 15) * 4;
+    const int r = r0 + rl, c = c0 + cl;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < rows) {
+      const float* p = src + (int64_t)r * ld + c;
+      if (vec && c + 3 < cols) v = *reinterpret_cast<const float4*>(p);
+      else {
+        if (c < cols) v.x = p[0];
+        if (c + 1 < cols) v.y = p[1];
+        if (c + 2 < cols) v.z = p[2];
+        if (c + 3 < cols) v.w = p[3];
+      }
+    }
+    t[rl][cl] = v.x; t[rl][cl + 1] = v.y; t[rl][cl + 2] = v.z; t[rl][cl + 3] = v.w;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int p = tid + 256 * i;                       // piece: (mbl, h, g, r): 16 consecutive r are contiguous in memory
+    const int mbl = p >> 7, h = (p >> 6) & 1, g = (p >> 4) & 3, r = p & 15;
+    if (dst) {
+      const int mb = (r0 >> 4) + mbl, nb = (rows + 15) >> 4, nkb = (cols + 63) >> 6;
+      if (mb < nb) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (__bf16)t[mbl * 16 + r][g * 16 + h * 8 + e];
+        const int64_t off = (((((int64_t)mb * nkb + blockIdx.x) * 2 + h) * 4 + g) * 16 + r) * 8;
+        *reinterpret_cast<bf16x8*>(dst + off) = o;
+      }
+    }
+    if (dstT) {
+      const int mb = (c0 >> 4) + mbl, nb = (cols + 15) >> 4, nkb = (rows + 63) >> 6;
+      if (mb < nb) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (__bf16)t[g * 16 + h * 8 + e][mbl * 16 + r];
+        const int64_t off = (((((int64_t)mb * nkb + blockIdx.y) * 2 + h) * 4 + g) * 16 + r) * 8;
+        *reinterpret_cast<bf16x8*>(dstT + off) = o;
+      }
+    }
+  }
+}
+
+constexpr int kSumChunk = 16384;                      // elements per workgroup of the norm's first stage
+
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, int64_t n, double* __restrict__ partial) {
+  __shared__ double sh[4];
+  const int64_t b0 = (int64_t)blockIdx.x * kSumChunk;
+  double s = 0.0;
+  for (int64_t i = b0 + threadIdx.x * 4; i < b0 + kSumChunk && i < n; i += 1024) {
+    if (i + 3 < n) {
+      const float4 v = *reinterpret_cast<const float4*>(g + i);
+      s += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    } else {
+      for (int64_t j = i; j < n; ++j) s += (double)g[j] * g[j];
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// out[0] = extra_scale * min(1, max_norm / (norm + 1e-6)), out[1] = norm   (max_norm <= 0: no clipping, out[0] = extra_scale)
+__global__ __launch_bounds__(256) void clip_coef_kernel(const double* __restrict__ partial, int count, float max_norm, float extra_scale,
+                                                        float* __restrict__ out) {
+  __shared__ double sh[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < count; i += 256) s += partial[i];       // fixed assignment, fixed order: deterministic
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float norm = (float)sqrt(sh[0]) * fabsf(extra_scale);          // the norm of the gradients as the optimizer sees them
+    float coef = 1.0f;
+    if (max_norm > 0.f) coef = fminf(1.0f, max_norm / (norm + 1e-6f));
+    out[0] = extra_scale * coef;
+    out[1] = norm;
+  }
+}
+
+__global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                         float* __restrict__ v, int64_t n, const float2* __restrict__ chunk, float lr,
+                                                         float b1, float b2, float eps, float bc1, float rsbc2, const float* __restrict__ gscale_p,
+                                                         float gscale_c) {
+  const float2 cw = chunk[blockIdx.x];                 // (weight decay, lr scale; < 0: leave the chunk alone)
+  if (cw.y < 0.f) return;
+  const float gs = gscale_c * (gscale_p ? gscale_p[0] : 1.0f);
+  const float lr_ = lr * cw.y;
+  const int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x * 4;
+  if (i >= n) return;
+  float4 pv = *reinterpret_cast<float4*>(p + i), mv = *reinterpret_cast<float4*>(m + i), vv = *reinterpret_cast<float4*>(v + i);
+  const float4 gv = *reinterpret_cast<const float4*>(g + i);
+  float pp[4] = {pv.x, pv.y, pv.z, pv.w}, mm[4] = {mv.x, mv.y, mv.z, mv.w}, vs[4] = {vv.x, vv.y, vv.z, vv.w};
+  const float gg[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float gi = gg[e] * gs;
+    float pi = pp[e] * (1.0f - lr_ * cw.x);
+    mm[e] = b1 * mm[e] + (1.0f - b1) * gi;
+    vs[e] = b2 * vs[e] + (1.0f - b2) * gi * gi;
+    pi -= (lr_ / bc1) * mm[e] / (sqrtf(vs[e]) * rsbc2 + eps);
+    pp[e] = pi;
+  }
+  *reinterpret_cast<float4*>(p + i) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+  *reinterpret_cast<float4*>(m + i) = make_float4(mm[0], mm[1], mm[2], mm[3]);
+  *reinterpret_cast<float4*>(v + i) = make_float4(vs[0], vs[1], vs[2], vs[3]);
+}
+
+}  // namespace
+
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+
+extern "C" int sp3_pack_bf16(const float* src, int64_t ld, int rows, int cols, void* dst, void* dstT, void* stream) {
+  SP3_CHECK(src && (dst || dstT) && rows > 0 && cols > 0 && ld >= cols, "sp3_pack_bf16: bad arguments (rows=%d cols=%d ld=%lld)", rows, cols, (long long)ld);
+  SP3_CHECK(((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(dstT)) & 15) == 0, "sp3_pack_bf16: outputs must be 16-byte aligned");
+  const dim3 grid((cols + 63) / 64, (rows + 63) / 64);
+  SP3_CHECK(grid.y <= 65535, "sp3_pack_bf16: too many rows for one launch (%d)", rows);
+  hipLaunchKernelGGL(pack_bf16_kernel, grid, dim3(256), 0, ST(stream), src, ld, rows, cols, reinterpret_cast<__bf16*>(dst), reinterpret_cast<__bf16*>(dstT));
+  SP3_LAUNCH_CHECK("sp3_pack_bf16");
+  return 0;
+}
+
+extern "C" int64_t sp3_sumsq_blocks(int64_t n) { return (n + kSumChunk - 1) / kSumChunk; }
+
+extern "C" int sp3_sumsq_partial(const float* g, int64_t n, double* partial, void* stream) {
+  SP3_CHECK(g && partial && n > 0 && (reinterpret_cast<uintptr_t>(g) & 15) == 0, "sp3_sumsq_partial: bad arguments");
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3((unsigned)sp3_sumsq_blocks(n)), dim3(256), 0, ST(stream), g, n, partial);
+  SP3_LAUNCH_CHECK("sp3_sumsq_partial");
+  return 0;
+}
+
+extern "C" int sp3_clip_coef(const double* partial, int count, float max_norm, float extra_scale, float* out, void* stream) {
+  SP3_CHECK(partial && out && count > 0, "sp3_clip_coef: bad arguments");
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, ST(stream), partial, count, max_norm, extra_scale, out);
+  SP3_LAUNCH_CHECK("sp3_clip_coef");
+  return 0;
+}
+
+extern "C" int sp3_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, const float* chunk_table, float lr, float beta1,
+                              float beta2, float eps, int step, const float* grad_scale_dev, float grad_scale, void* stream) {
+  SP3_CHECK(p && g && m && v && chunk_table && n > 0 && n % 1024 == 0 && step >= 1, "sp3_adamw_flat: bad arguments (n=%lld must be a multiple of 1024)", (long long)n);
+  const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adamw_flat_kernel, dim3((unsigned)(n / 1024)), dim3(256), 0, ST(stream), p, g, m, v, n,
+                     reinterpret_cast<const float2*>(chunk_table), lr, beta1, beta2, eps, bc1, 1.0f / sqrtf(bc2), grad_scale_dev, grad_scale);
+  SP3_LAUNCH_CHECK("sp3_adamw_flat");
+  return 0;
+}

@@ -572,24 +572,18 @@ class Engine:
         t = [self.ws("dpt%d_pp%d" % (num, i), (R, ld[i])) for i in range(4)]
         pairable = len({dec[hk[i]].dtype for i in range(4)}) == 1          # one kernel instance per pair (same operand dtypes)
         # the four hooks are independent: two launches of two differently shaped problems each (sp3_gemm2)
+        import contextlib
+        pair = ops.pair if pairable else contextlib.nullcontext
         for i0 in (0, 2):
-            ctx = ops.pair() if pairable else None
-            if ctx:
-                ctx.__enter__()
-            for i in (i0, i0 + 1):
-                ops.gemm(dec[hk[i]], w[pre + "pp%d.w" % i], t[i], M=R, N=ld[i], K=dims[i], lda=dims[i], ldc=ld[i], bias=w[pre + "pp%d.b" % i])
-            if ctx:
-                ctx.__exit__(None, None, None)
+            with pair():
+                for i in (i0, i0 + 1):
+                    ops.gemm(dec[hk[i]], w[pre + "pp%d.w" % i], t[i], M=R, N=ld[i], K=dims[i], lda=dims[i], ldc=ld[i], bias=w[pre + "pp%d.b" % i])
         # act_postprocess tails (croco/models/dpt_block.py:356-410)
         l0 = self.ws("dpt%d_l0" % num, (B * 16 * nh * nw, ld[0]))
         l1 = self.ws("dpt%d_l1" % num, (B * 4 * nh * nw, ld[1]))
-        ctx = ops.pair() if pairable else None
-        if ctx:
-            ctx.__enter__()
-        ops.conv_transpose_ks(t[0], w[pre + "pp0t.w"], l0, B=B, H=nh, W_=nw, Cin=ld[0], Cout=ld[0], ks=4, bias=w[pre + "pp0t.b"])
-        ops.conv_transpose_ks(t[1], w[pre + "pp1t.w"], l1, B=B, H=nh, W_=nw, Cin=ld[1], Cout=ld[1], ks=2, bias=w[pre + "pp1t.b"])
-        if ctx:
-            ctx.__exit__(None, None, None)
+        with pair():
+            ops.conv_transpose_ks(t[0], w[pre + "pp0t.w"], l0, B=B, H=nh, W_=nw, Cin=ld[0], Cout=ld[0], ks=4, bias=w[pre + "pp0t.b"])
+            ops.conv_transpose_ks(t[1], w[pre + "pp1t.w"], l1, B=B, H=nh, W_=nw, Cin=ld[1], Cout=ld[1], ks=2, bias=w[pre + "pp1t.b"])
         l2 = t[2]
         h3, w3 = (nh - 1) // 2 + 1, (nw - 1) // 2 + 1
         l3 = self.ws("dpt%d_l3" % num, (B * h3 * w3, ld[3]))

@@ -136,6 +136,11 @@ _PROTOS = {
     "sp3_adamw": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int,
                   C.c_float, C.c_void_p],
     "sp3_mul": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
+    "sp3_pack_bf16": [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
+    "sp3_sumsq_partial": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p],
+    "sp3_clip_coef": [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p],
+    "sp3_adamw_flat": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float,
+                       C.c_int, C.c_void_p, C.c_float, C.c_void_p],
     "sp3_softmax_bwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_void_p],
     "sp3_layernorm_bwd": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                           C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p],
@@ -152,7 +157,7 @@ _PROTOS = {
                              C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                              C.c_void_p, C.c_void_p],
 }
-EXPORTS = sorted(list(_PROTOS) + ["sp3_last_error", "sp3_version", "sp3_conf_loss_ws_bytes", "sp3_ssi_loss_ws_bytes"])
+EXPORTS = sorted(list(_PROTOS) + ["sp3_last_error", "sp3_version", "sp3_conf_loss_ws_bytes", "sp3_ssi_loss_ws_bytes", "sp3_sumsq_blocks"])
 
 
 def load():

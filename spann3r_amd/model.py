@@ -738,6 +738,9 @@ class Spann3R(nn.Module):
 
     @property
     def engine(self) -> Engine:
+        # every entry point (forward, the reference-shaped stage methods, offline_reconstruction, model.dust3r) fetches the
+        # engine first: the product mode of the fp32 GEMMs follows the model's precision from here
+        ops.F32X3 = self.precision == "f32x3"
         if self._pinned is not None:          # inside forward(): weights cannot change, skip the version scan
             return self._pinned
         dev = self._params["norm_q.weight"].device

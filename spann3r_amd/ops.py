@@ -103,7 +103,8 @@ def set_profiler(p):
 
 _TILE_NAMES = {0: "32x32xk4", 1: "64x64", 2: "64x128", 3: "64x64xk4", 4: "32x64xk4", 18: "16x64xk4", 5: "128x128lds", 6: "128x64lds", 7: "112x64lds",
                8: "208x64lds", 9: "112x32lds", 10: "112x64lds2w", 11: "112x64lds8w", 12: "208x64lds8w", 13: "112x64wreg8",
-               14: "112x64wreg4", 15: "208x64wreg8", 16: "112x64wreg4l6", 17: "112x64wreg8l4"}
+               14: "112x64wreg4", 15: "208x64wreg8", 16: "112x64wreg4l6", 17: "112x64wreg8l4",
+               20: "256x128pipe", 21: "128x128pipe", 22: "128x64pipe", 23: "64x64pipe"}
 
 
 def pick_tile(M, N, batch=1, splitk=1, conv=False, K=0, packed_bf16=False, plain=False, ln_nt=0, pipe_ok=False):
@@ -313,7 +314,8 @@ class PackedWeightGroup(PackedWeight):
         self.stride = items[0].data.numel()
 
 
-F32X3 = False        # fp32 GEMMs through three bf16 MFMAs per k-block (sp3_gemm_desc.f32x3); set by the model's "f32x3" precision
+F32X3 = False        # fp32 GEMMs through three bf16 MFMAs per k-block (sp3_gemm_desc.f32x3 = 1); set by the model's "f32x3" precision
+F32_BF16 = False     # fp32 operands rounded to bf16 inside the GEMM, one bf16 MFMA per k-block (f32x3 = 2): bf16 training step
 
 
 def _w(d, W):
@@ -321,7 +323,7 @@ def _w(d, W):
     d.W = W.data_ptr()
     d.w_packed = int(isinstance(W, PackedWeight))
     d.wdtype = wdtype_of(W)
-    d.f32x3 = int(F32X3 and d.wdtype == F32)
+    d.f32x3 = (2 if F32_BF16 else int(F32X3)) if d.wdtype == F32 else 0
 
 
 class LnFold:
@@ -646,6 +648,21 @@ def pack_stats(x, packed, stats, *, rows, C_, ldx=None):
     _f32(x, "x")
     L.check(L.load().sp3_pack_stats(x.data_ptr(), C_ if ldx is None else ldx, rows, C_, packed.data_ptr(),
                                     int(packed.dtype == torch.bfloat16), stats.data_ptr(), L.stream_ptr()), "sp3_pack_stats")
+
+
+def pack_bf16(x2d, want=True, want_t=False):
+    """fp32 row-major [rows, cols] (any row stride) -> (PackedAct [rows, cols] or None, PackedAct [cols, rows] or None) in bf16
+    fragment order, one launch (sp3_pack_bf16); the pads of both are zeros."""
+    rows, cols = x2d.shape
+    _f32(x2d, "x")
+    if x2d.stride(1) != 1:
+        x2d = x2d.contiguous()
+    alloc = lambda r, c: torch.empty(packed_shape(r, c, torch.bfloat16), dtype=torch.bfloat16, device=x2d.device)
+    a = PackedAct(rows, cols, torch.bfloat16, x2d.device, data=alloc(rows, cols)) if want else None
+    t = PackedAct(cols, rows, torch.bfloat16, x2d.device, data=alloc(cols, rows)) if want_t else None
+    _timed("pack_bf16", 0.0, rows * cols * (4.0 + 2.0 * (bool(want) + bool(want_t))),
+           lambda: L.check(L.load().sp3_pack_bf16(x2d.data_ptr(), x2d.stride(0), rows, cols, L.ptr(a), L.ptr(t), L.stream_ptr()), "sp3_pack_bf16"))
+    return a, t
 
 
 def gather_packed_rows(src, dst, sel, n_sel, C_):

@@ -7,17 +7,62 @@ with attn_thresh = 0 and nn.Dropout on the attention, :475):
 `memory_read_train` returns `out` with an autograd edge to feat, mem_k, mem_v and the six LayerNorm parameters; the
 backward is four sp3_gemm launches (fp32 MFMA) with the transposes, the softmax / dropout backward and the LayerNorm
 backward of csrc/train.hip in between.  The dropout mask is an input (0 or 1/(1-p), drawn by the caller: the reference's
-comes from torch's RNG stream and cannot be matched bit for bit by any other implementation).  Gradient averaging across
-ranks: `spann3r_amd.runner.GradReducer`; the criterion: `spann3r_amd.loss`.  What is NOT here: backward passes of the ViT
-encoder / decoder / DPT heads (the model's forward refuses train mode with active dropout for that reason)."""
+comes from torch's RNG stream and cannot be matched bit for bit by any other implementation).
+
+Below it: every other stage of the train-mode forward (ViT blocks, decoder blocks, key MLPs, DPT heads, value encoder) as
+autograd ops with HIP forward and backward, `forward_train` (= Spann3R.forward in train mode), and the optimizer side of
+spann3r/training.py:216-231: `FlatAdamW` (bucket-wide AdamW launches on the flat layout of `runner.GradReducer`, with the
+global gradient-norm clip of croco/utils/misc.py:262-288 computed on the device).  Gradient averaging across ranks:
+`spann3r_amd.runner.GradReducer`; the criterion: `spann3r_amd.loss`.
+
+Precision (`set_precision`): "fp32" = fp32 MFMA everywhere (the parity build: gradients within 1e-5 of float64 autograd);
+"bf16" = what the reference's bf16 autocast would compute: every Linear runs on bf16 fragment-order copies of its operands
+(sp3_pack_bf16 makes X, X^T, dY, dY^T; W and W^T are packed once per optimizer step) through the pipelined bf16 GEMM tiles with
+fp32 accumulation -- forward, dX = dY . W and dW = dY^T . X are all plain A . W^T launches, no fp32 transposes -- and the
+remaining fp32 GEMMs (attention, the memory read) round their operands to bf16 on the way into the MFMA (sp3_gemm f32x3 = 2).
+Master weights, gradients, LayerNorm, softmax, the residual stream and the optimizer stay fp32."""
 import torch
 
 from . import lib as L
 from . import ops
 
 
+PRECISION = "fp32"
+_wcache = {}          # id(weight) -> (version, packed W, packed W^T): refreshed when the optimizer has stepped
+
+
+def set_precision(p):
+    """"fp32" | "bf16" for every op of this module (forward and backward), see the module docstring"""
+    global PRECISION
+    if p not in ("fp32", "bf16"):
+        raise ValueError("training precision must be 'fp32' or 'bf16'")
+    PRECISION = p
+    ops.F32_BF16 = p == "bf16"
+
+
+def invalidate_weight_cache():
+    _wcache.clear()
+
+
+def _packed_weight(W, key):
+    """(W, W^T) of a [N, K] fp32 matrix as bf16 fragment-order GEMM operands.  key: identifies the CONTENT (parameter id, its
+    version, what was derived from it) or None (no caching); optimizers call invalidate_weight_cache() after a step."""
+    ent = _wcache.get(key) if key is not None else None
+    if ent is None:
+        a, t = ops.pack_bf16(W.detach(), True, True)
+        N, K = W.shape
+        ent = (ops.PackedWeight.wrap(a.data, N, K), ops.PackedWeight.wrap(t.data, K, N))
+        if key is not None:
+            _wcache[key] = ent
+    return ent
+
+
 def _r8(n):
     return (n + 7) // 8 * 8
+
+
+def _r64(n):
+    return (n + 63) // 64 * 64
 
 
 def _transpose(src, rows, cols, ld_src, ld_dst=None):
@@ -159,41 +204,66 @@ class _Linear(torch.autograd.Function):
     """y = x W^T + b (+ res) (+ res2); x [R, K], W [N, K]"""
 
     @staticmethod
-    def forward(ctx, x, W, b, res, res2):
+    def forward(ctx, x, W, b, res, res2, wkey):
         R, K = x.shape
         N = W.shape[0]
         y = torch.empty(R, N, device=x.device)
+        ctx.has = (b is not None, res is not None, res2 is not None)
+        ctx.bf16 = PRECISION == "bf16"
+        if ctx.bf16:
+            # bf16 operands in fragment order; X^T is made in the same pass and is all the backward keeps of x
+            need_t = ctx.needs_input_grad[1]
+            xp, xT = ops.pack_bf16(x, True, need_t)
+            Wp, WT = _packed_weight(W, wkey)
+            ops.gemm(xp, Wp, y, M=R, N=N, K=_r64(K), lda=K, ldc=N, bias=b, res1=res, ldr1=N, res2=res2, ldr2=N)
+            ctx.xT, ctx.WT, ctx.shape = xT, WT, (R, K, N)
+            return y
         xp, Wp = _pad8(x), _pad8(W)
         ops.gemm(xp, Wp, y, M=R, N=N, K=xp.shape[1], lda=xp.shape[1], ldc=N, ldw=Wp.shape[1], bias=b, res1=res, ldr1=N, res2=res2, ldr2=N)
         ctx.save_for_backward(x, W)
-        ctx.has = (b is not None, res is not None, res2 is not None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, W = ctx.saved_tensors
-        R, K = x.shape
-        N = W.shape[0]
         dy = dy.contiguous()
-        dev = x.device
+        dev = dy.device
         dx = dW = db = None
-        if ctx.needs_input_grad[0]:
-            WT = _tb(W, N, K, K)[0]                                      # [K, r8(N)]
-            dyp = _pad8(dy)
-            dx = _nt(dyp, WT, R, K, dyp.shape[1], dyp.shape[1], WT.shape[1], torch.empty(R, K, device=dev), K)
-        if ctx.needs_input_grad[1]:
-            dyT, xT = _tb(dy, R, N, N)[0], _tb(x, R, K, K)[0]            # [N, r8(R)], [K, r8(R)]
-            dW = _nt(dyT, xT, N, K, dyT.shape[1], dyT.shape[1], xT.shape[1], torch.empty(N, K, device=dev), K)
+        if ctx.bf16:
+            R, K, N = ctx.shape
+            need_w = ctx.needs_input_grad[1]
+            dyp, dyT = ops.pack_bf16(dy, ctx.needs_input_grad[0], need_w)
+            if ctx.needs_input_grad[0]:           # dX = dY . W = dY . (W^T)^T: contraction over N
+                dx = torch.empty(R, K, device=dev)
+                ops.gemm(dyp, ctx.WT, dx, M=R, N=K, K=_r64(N), lda=N, ldc=K)
+            if need_w:                            # dW = dY^T . X = (dY^T) . (X^T)^T: contraction over the rows
+                dW = torch.empty(N, K, device=dev)
+                ops.gemm(dyT, ops.PackedWeight.wrap(ctx.xT.data, K, R), dW, M=N, N=K, K=_r64(R), lda=R, ldc=K)
+            ctx.xT = ctx.WT = None
+        else:
+            x, W = ctx.saved_tensors
+            R, K = x.shape
+            N = W.shape[0]
+            if ctx.needs_input_grad[0]:
+                WT = _tb(W, N, K, K)[0]                                      # [K, r8(N)]
+                dyp = _pad8(dy)
+                dx = _nt(dyp, WT, R, K, dyp.shape[1], dyp.shape[1], WT.shape[1], torch.empty(R, K, device=dev), K)
+            if ctx.needs_input_grad[1]:
+                dyT, xT = _tb(dy, R, N, N)[0], _tb(x, R, K, K)[0]            # [N, r8(R)], [K, r8(R)]
+                dW = _nt(dyT, xT, N, K, dyT.shape[1], dyT.shape[1], xT.shape[1], torch.empty(N, K, device=dev), K)
         if ctx.has[0] and ctx.needs_input_grad[2]:
             db = torch.zeros(N, device=dev)
             ops.colsum_accum(dy, N, R, N, db)
-        return dx, dW, db, (dy if ctx.has[1] else None), (dy if ctx.has[2] else None)
+        return dx, dW, db, (dy if ctx.has[1] else None), (dy if ctx.has[2] else None), None
 
 
-def linear(x, W, b=None, res=None, res2=None):
+def linear(x, W, b=None, res=None, res2=None, wkey=None):
+    """wkey: cache key of the packed bf16 copies of W (default: the parameter itself when W is a leaf; derived matrices -- a
+    permuted convolution weight -- pass (id(parameter), tag))"""
     sh = x.shape
     flat = lambda t: None if t is None else t.reshape(-1, W.shape[0]).contiguous()
-    y = _Linear.apply(x.reshape(-1, sh[-1]).contiguous(), W.contiguous(), b, flat(res), flat(res2))
+    if wkey is None and W.is_leaf:
+        wkey = (id(W), "linear", W._version, W.data_ptr())
+    y = _Linear.apply(x.reshape(-1, sh[-1]).contiguous(), W.contiguous(), b, flat(res), flat(res2), wkey)
     return y.reshape(*sh[:-1], W.shape[0])
 
 
@@ -425,12 +495,12 @@ def conv3x3(x, W, b=None, stride=1, res=None, res2=None):
     B, H, Wd, Cin = x.shape
     OH, OW = (H - 1) // stride + 1, (Wd - 1) // stride + 1
     Wm = W.permute(0, 2, 3, 1).reshape(W.shape[0], 9 * Cin)
-    y = linear(_Im2col3x3.apply(x, stride), Wm, b, res, res2)
+    y = linear(_Im2col3x3.apply(x, stride), Wm, b, res, res2, wkey=(id(W), "conv3x3", W._version))
     return y.reshape(B, OH, OW, W.shape[0])
 
 
 def conv1x1(x, W, b=None):
-    return linear(x, W.reshape(W.shape[0], -1), b)
+    return linear(x, W.reshape(W.shape[0], -1), b, wkey=(id(W), "conv1x1", W._version))
 
 
 def conv_transpose_ks(x, W, b, k):
@@ -438,7 +508,7 @@ def conv_transpose_ks(x, W, b, k):
     B, H, Wd, Cin = x.shape
     Co = W.shape[1]
     Wm = W.permute(2, 3, 1, 0).reshape(k * k * Co, Cin)
-    y = linear(x, Wm, b.repeat(k * k))
+    y = linear(x, Wm, b.repeat(k * k), wkey=(id(W), "convT", W._version))
     return y.reshape(B, H, Wd, k, k, Co).permute(0, 1, 3, 2, 4, 5).reshape(B, H * k, Wd * k, Co)
 
 
@@ -502,7 +572,7 @@ def encode_image(img, P, cfg):
     """dust3r/model.py:131-154"""
     x, nh, nw = _patchify(img.float(), cfg.patch)
     W = P["dust3r.patch_embed.proj.weight"]
-    x = linear(x, W.reshape(W.shape[0], -1), P["dust3r.patch_embed.proj.bias"])
+    x = linear(x, W.reshape(W.shape[0], -1), P["dust3r.patch_embed.proj.bias"], wkey=(id(W), "patch", W._version))
     pos = _positions(img.shape[0], nh, nw, img.device)
     for i in range(cfg.enc_depth):
         x = block(x, pos, P, "dust3r.enc_blocks.%d." % i, cfg.enc_heads, cfg.rope_base)
@@ -536,7 +606,7 @@ def encode_cur_value(pts3d, feat_k, P, cfg):
     """spann3r/model.py:305-320 (use_feat=False) -> cur_v + feat_k (the sum add_mem stores, :519)"""
     x, nh, nw = _patchify(pts3d.permute(0, 3, 1, 2), cfg.patch)
     W = P["pos_patch_embed.proj.weight"]
-    x = linear(x, W.reshape(W.shape[0], -1), P["pos_patch_embed.proj.bias"])
+    x = linear(x, W.reshape(W.shape[0], -1), P["pos_patch_embed.proj.bias"], wkey=(id(W), "patch", W._version))
     pos = _positions(pts3d.shape[0], nh, nw, pts3d.device)
     for i in range(cfg.val_depth):
         x = block(x, pos, P, "value_encoder.%d." % i, cfg.enc_heads, cfg.rope_base, use_rope=cfg.mem_pos_enc)
@@ -612,3 +682,151 @@ class AdamW(torch.optim.Optimizer):
                 g = p.grad.contiguous()
                 L.check(lib.sp3_adamw(p.data_ptr(), g.data_ptr(), st["m"].data_ptr(), st["v"].data_ptr(), p.numel(), float(gr["lr"]), b1, b2,
                                       float(gr["eps"]), float(gr["weight_decay"]), st["step"], float(grad_scale), L.stream_ptr()), "sp3_adamw")
+
+
+def parameter_groups(model, weight_decay):
+    """The two groups croco/utils/misc.py:404-455 get_parameter_groups builds at layer_decay = 1 (spann3r/training.py:327): no weight
+    decay for 1-D parameters and biases, `weight_decay` for the rest."""
+    decay, no_decay = [], []
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        (no_decay if (p.dim() == 1 or name.endswith(".bias")) else decay).append(p)
+    return [{"params": no_decay, "weight_decay": 0.0, "lr_scale": 1.0}, {"params": decay, "weight_decay": weight_decay, "lr_scale": 1.0}]
+
+
+class TrainStep:
+    """One optimisation step of spann3r/training.py:216-231 on one rank: train-mode forward (HIP autograd ops), ConfLoss_t,
+    backward with the bucket all-reduces launched from inside it (RCCL when a process group is up), global-norm clip and AdamW on
+    the flat buckets.  `run(frames, gts)` returns (loss, gradient norm) as device scalars (no host sync)."""
+
+    def __init__(self, model, lr=5e-5, weight_decay=0.05, betas=(0.9, 0.95), clip_grad=1.0, precision="bf16", bucket_mb=64.0, force_collectives=False):
+        from .loss import ConfLoss_t, Regr3D_t, L21
+        from .runner import GradReducer
+        set_precision(precision)
+        self.model = model.train()
+        self.reducer = GradReducer(list(model.parameters()), bucket_mb=bucket_mb, overlap=True, force=force_collectives)
+        self.opt = FlatAdamW(parameter_groups(model, weight_decay), self.reducer, lr=lr, betas=betas, weight_decay=weight_decay)
+        self.crit = ConfLoss_t(Regr3D_t(L21, norm_mode="avg_dis", fix_first=False), alpha=0.4)      # training.py:37
+        self.clip_grad = clip_grad
+
+    def run(self, frames, gts):
+        self.reducer.zero_grad()
+        self.reducer.prepare()
+        preds, preds_all = self.model(frames)
+        loss, details, factor = self.crit.compute_frame_loss(gts, preds_all)
+        total = loss + factor
+        total.backward()
+        self.reducer.finish()
+        norm = self.opt.step(max_norm=self.clip_grad, skip=self.reducer.unused_everywhere() if self.reducer.active() else ())
+        return total.detach(), norm
+
+
+class FlatAdamW:
+    """AdamW + global gradient-norm clipping on the flat bucket layout of `runner.GradReducer` -- the optimizer side of
+    spann3r/training.py:216-231 (`loss_scaler(loss, optimizer, clip_grad=1.0, parameters=model.parameters())`,
+    croco/utils/misc.py:262-288; AdamW(param_groups, lr, betas=(0.9, 0.95)) of :327) in a handful of launches per step:
+
+      * every parameter becomes a view of a flat fp32 buffer with the element layout of its gradient bucket (one buffer per
+        bucket; moments m, v likewise), so the update of a bucket is ONE sp3_adamw_flat launch; weight decay and the
+        group's lr scale are looked up per 1024-element chunk (parameters start on chunk boundaries);
+      * `step(max_norm=...)` first reduces sum(g^2) of every bucket in a fixed order (sp3_sumsq_partial, sp3_clip_coef) and
+        leaves clip_grad_norm_'s coefficient on the device; the update kernels read it from there (no host sync; the norm is
+        returned as a device scalar like the reference's `norm`);
+      * parameters that received no gradient on any rank (`reducer.unused_everywhere()`; torch leaves their .grad None and
+        AdamW skips them) are skipped through the chunk table.
+
+    groups: torch-style parameter groups ([{"params": [...], "weight_decay": w, "lr_scale": s}, ...], as
+    croco/utils/misc.py get_parameter_groups builds them) or a plain parameter list.  `param_groups[i]["lr"]` may be changed
+    between steps (misc.adjust_learning_rate)."""
+
+    def __init__(self, groups, reducer, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        groups = list(groups)
+        if groups and not isinstance(groups[0], dict):
+            groups = [{"params": groups}]
+        self.param_groups = []
+        for g in groups:
+            g = dict(g)
+            g["params"] = [p for p in g["params"] if p.requires_grad]
+            g.setdefault("lr", lr * g.get("lr_scale", 1.0))
+            g.setdefault("weight_decay", weight_decay)
+            g.setdefault("betas", betas)
+            g.setdefault("eps", eps)
+            self.param_groups.append(g)
+        self.reducer = reducer
+        self.betas, self.eps = betas, eps
+        self.step_count = 0
+        self._group_of = {id(p): gi for gi, g in enumerate(self.param_groups) for p in g["params"]}
+        missing = [p for p in reducer.params if id(p) not in self._group_of]
+        if missing or len(self._group_of) != len(reducer.params):
+            raise ValueError("FlatAdamW: the parameter groups and the GradReducer must hold the same parameters")
+        self.flat_p, self.flat_m, self.flat_v, self._tables, self._table_key = [], [], [], [], None
+        with torch.no_grad():
+            for gbuf, items in reducer.flat_buffers():
+                fp = torch.zeros_like(gbuf)
+                for p, o in items:
+                    if not (p.is_cuda and p.dtype == torch.float32):
+                        raise RuntimeError("FlatAdamW: fp32 parameters on the GPU")
+                    v = fp[o:o + p.numel()].view_as(p)
+                    v.copy_(p.data)
+                    p.data = v                      # the parameter now lives in the flat buffer (state_dict etc. unchanged)
+                self.flat_p.append(fp)
+                self.flat_m.append(torch.zeros_like(gbuf))
+                self.flat_v.append(torch.zeros_like(gbuf))
+        nblk = [int(L.load().sp3_sumsq_blocks(g.numel())) for g, _ in reducer.flat_buffers()]
+        self._nblk = nblk
+        dev = self.flat_p[0].device
+        self._partials = torch.zeros(sum(nblk), dtype=torch.float64, device=dev)
+        self._coef = torch.ones(2, dtype=torch.float32, device=dev)
+        invalidate_weight_cache()
+
+    def zero_grad(self, set_to_none=False):
+        self.reducer.zero_grad()
+
+    def _chunk_tables(self, skip):
+        """(weight decay, lr / lr of group 0; -1 = skip) per 1024-element chunk and bucket; rebuilt only when the groups' lr ratios,
+        weight decays or the skipped set change"""
+        base = self.param_groups[0]["lr"] or 1.0
+        key = (tuple((g["weight_decay"], g["lr"] / base) for g in self.param_groups), tuple(sorted(id(p) for p in skip)))
+        if key == self._table_key:
+            return self._tables
+        skip_ids = {id(p) for p in skip}
+        tabs = []
+        for gbuf, items in self.reducer.flat_buffers():
+            t = torch.zeros(gbuf.numel() // 1024, 2)
+            t[:, 1] = -1.0                          # alignment gaps between parameters: nothing to update
+            for p, o in items:
+                g = self.param_groups[self._group_of[id(p)]]
+                c0, c1 = o // 1024, (o + p.numel() + 1023) // 1024
+                t[c0:c1, 0] = g["weight_decay"]
+                t[c0:c1, 1] = -1.0 if id(p) in skip_ids else g["lr"] / base
+            tabs.append(t.to(gbuf.device))
+        self._tables, self._table_key = tabs, key
+        return tabs
+
+    @torch.no_grad()
+    def step(self, grad_scale=1.0, max_norm=None, skip=()):
+        """One AdamW update of every bucket.  The gradients are multiplied by grad_scale (1 / accum_iter, 1 / world ...) and, when
+        max_norm is given, by clip_grad_norm_'s coefficient min(1, max_norm / (||grad_scale * g|| + 1e-6)).  Returns the gradient norm
+        (device scalar) when max_norm is given."""
+        lib = L.load()
+        self.step_count += 1
+        bufs = self.reducer.flat_buffers()
+        coef_ptr, gs = None, float(grad_scale)
+        if max_norm is not None:
+            off = 0
+            for (g, _), nb in zip(bufs, self._nblk):
+                L.check(lib.sp3_sumsq_partial(g.data_ptr(), g.numel(), self._partials[off:].data_ptr(), L.stream_ptr()), "sp3_sumsq_partial")
+                off += nb
+            L.check(lib.sp3_clip_coef(self._partials.data_ptr(), off, float(max_norm), float(grad_scale), self._coef.data_ptr(), L.stream_ptr()),
+                    "sp3_clip_coef")
+            coef_ptr, gs = self._coef.data_ptr(), 1.0
+        tabs = self._chunk_tables(skip)
+        base = self.param_groups[0]["lr"]
+        b1, b2 = self.betas
+        for (g, _), fp, fm, fv, tab in zip(bufs, self.flat_p, self.flat_m, self.flat_v, tabs):
+            L.check(lib.sp3_adamw_flat(fp.data_ptr(), g.data_ptr(), fm.data_ptr(), fv.data_ptr(), g.numel(), tab.data_ptr(), float(base), b1, b2,
+                                       float(self.eps), self.step_count, coef_ptr, gs, L.stream_ptr()), "sp3_adamw_flat")
+            fp[:0].zero_()                          # bumps the version counter the parameter views share: weight caches notice
+        invalidate_weight_cache()
+        return self._coef[1] if max_norm is not None else None

@@ -255,3 +255,173 @@ def test_adamw_kernel_matches_torch():
         oa.step(); ob.step()
     for pa, pb in zip(a, b):
         assert rel_err(pa.detach().cpu(), pb.detach()) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------- bf16 step, flat optimizer, RCCL
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,C", [(784, 1024), (100, 200), (65, 4), (3, 130), (1568, 768)])
+def test_pack_bf16_both_layouts(R, C):
+    """sp3_pack_bf16 == the host-side fragment-order packing (ops.PackedAct.from_dense) of the bf16-rounded matrix and of its
+    transpose, pads zero, for aligned and ragged shapes and a strided source"""
+    from spann3r_amd import ops
+    g = torch.Generator().manual_seed(R + C)
+    big = torch.randn(R, C + 12, generator=g).cuda()
+    x = big[:, 4:4 + C]                                     # row stride != cols, unaligned start unless C % 4 == 0 offsets agree
+    a, t = ops.pack_bf16(x, True, True)
+    ref = ops.PackedAct.from_dense(x.contiguous().to(torch.bfloat16))
+    refT = ops.PackedAct.from_dense(x.t().contiguous().to(torch.bfloat16))
+    assert torch.equal(a.data.view(-1), ref.data.view(-1))
+    assert torch.equal(t.data.view(-1), refT.data.view(-1))
+    only_t = ops.pack_bf16(x, False, True)
+    assert only_t[0] is None and torch.equal(only_t[1].data.view(-1), refT.data.view(-1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,K,N", [(784, 1024, 3072), (196, 768, 768), (50, 200, 4), (1568, 864, 256)])
+def test_linear_bf16_forward_backward(R, K, N):
+    """the bf16 Linear (packed operands, no transposes): y, dX, dW, db against float64 on the bf16-rounded operands"""
+    from spann3r_amd import train as T
+    g = torch.Generator().manual_seed(R)
+    x0, W0, b0, r0, d0 = torch.randn(R, K, generator=g), torch.randn(N, K, generator=g) * K ** -0.5, torch.randn(N, generator=g), torch.randn(R, N, generator=g), torch.randn(R, N, generator=g)
+    bf = lambda t: t.to(torch.bfloat16).double()
+    T.set_precision("bf16")
+    try:
+        x, W, b = x0.cuda().requires_grad_(True), torch.nn.Parameter(W0.cuda()), b0.cuda().requires_grad_(True)
+        y = T.linear(x, W, b, res=r0.cuda())
+        y.backward(d0.cuda())
+        y2 = T.linear(x.detach(), W, b.detach())            # second use: cached packed weights
+    finally:
+        T.set_precision("fp32")
+        T.invalidate_weight_cache()
+    yr = bf(x0) @ bf(W0).T + b0.double() + r0.double()
+    assert rel_err(y.detach().cpu(), yr) < 1e-5
+    assert rel_err(y2.cpu(), yr - r0.double()) < 1e-5
+    assert rel_err(x.grad.cpu(), bf(d0) @ bf(W0)) < 1e-5
+    assert rel_err(W.grad.cpu(), bf(d0).T @ bf(x0)) < 1e-5
+    assert rel_err(b.grad.cpu(), d0.double().sum(0)) < 1e-5
+
+
+@pytest.mark.gpu
+def test_training_step_bf16_gradients(tiny_sd):
+    """the whole train-mode step in bf16 mode (bf16 products, fp32 accumulate / master tensors) against float64 autograd through the
+    oracle: loss within 2e-3, every parameter gradient within 2e-2 of the oracle's (scaled by the tensor's own maximum) --
+    the rounding of ~40 chained bf16 GEMMs, not an approximation of the algorithm"""
+    from spann3r_amd import train as T, TINY
+    from spann3r_amd.loss import ConfLoss_t, Regr3D_t, L21
+    from spann3r_amd.weights import synth_frames
+    from oracle import spann3r_oracle as O, loss_oracle as LO
+    n, B, H, W = 3, 2, 32, 48
+    frames = synth_frames(n, H, W, batch=B, seed=11)
+    P = {k: v.float().cuda().requires_grad_(True) for k, v in tiny_sd.items() if v.is_floating_point()}
+    T.set_precision("bf16")
+    try:
+        preds, preds_all = T.forward_train(P, [{"img": f["img"].cuda()} for f in frames], TINY)
+        gts = _synth_gts(n, B, H, W, 5, torch.float32, "cuda")
+        loss, details, factor = ConfLoss_t(Regr3D_t(L21, norm_mode="avg_dis", fix_first=False), alpha=0.4).compute_frame_loss(gts, preds_all)
+        (loss + factor).backward()
+    finally:
+        T.set_precision("fp32")
+        T.invalidate_weight_cache()
+    P64 = {k: v.double().requires_grad_(True) for k, v in tiny_sd.items() if v.is_floating_point()}
+    _, pa64 = O.forward.__wrapped__([{"img": f["img"].double()} for f in frames], P64, TINY, training_policy=True)
+    l64, _, f64 = LO.conf_loss_t(_synth_gts(n, B, H, W, 5, torch.float64, "cpu"), pa64, 0.4, False)
+    (l64 + f64).backward()
+    assert abs(float(loss) + float(factor) - float(l64) - float(f64)) < 2e-3 * abs(float(l64))
+    gmax = max(float(v.grad.abs().max()) for v in P64.values() if v.grad is not None)
+    worst, nchk = (0.0, None), 0
+    for k, v in P64.items():
+        if v.grad is None:
+            continue
+        e = float((P[k].grad.cpu().double() - v.grad).abs().max()) / max(float(v.grad.abs().max()), 1e-3 * gmax)
+        nchk += 1
+        worst = max(worst, (e, k))
+    print("bf16 training step: loss %.5f (oracle %.5f), %d gradients, worst scaled error %.2e (%s)" % (float(loss) + float(factor), float(l64) + float(f64), nchk, worst[0], worst[1]))
+    assert worst[0] < 2e-2, worst
+
+
+@pytest.mark.gpu
+def test_flat_adamw_and_clip_match_torch():
+    """FlatAdamW on the GradReducer's flat buckets == torch.optim.AdamW + clip_grad_norm_ (float64) over several steps: two
+    parameter groups (decay / no decay), a changing lr, gradient scaling, the returned norm; parameters stay views of the flat
+    buffers and gradients accumulate in place"""
+    from spann3r_amd import train as T
+    from spann3r_amd.runner import GradReducer
+    g = torch.Generator().manual_seed(0)
+    shapes = [(257, 33), (1000,), (64, 64), (5,), (3000, 7)]
+    w0 = [torch.randn(*s, generator=g) for s in shapes]
+    a = [torch.nn.Parameter(t.clone().cuda()) for t in w0]
+    b = [torch.nn.Parameter(t.clone().double()) for t in w0]
+    red = GradReducer(a, bucket_mb=0.05)
+    assert len(red.buckets) >= 2
+    groups = lambda ps: [{"params": [p for p in ps if p.dim() == 1], "weight_decay": 0.0}, {"params": [p for p in ps if p.dim() > 1], "weight_decay": 0.05}]
+    oa = T.FlatAdamW(groups(a), red, lr=3e-3, betas=(0.9, 0.95), eps=1e-8)
+    ob = torch.optim.AdamW(groups(b), lr=3e-3, betas=(0.9, 0.95), eps=1e-8)
+    for (flat, items) in red.flat_buffers():
+        for p, o in items:
+            assert p.grad.data_ptr() == flat.data_ptr() + 4 * o
+    for it in range(5):
+        oa.zero_grad()
+        ob.zero_grad()
+        scale = 0.5 if it % 2 else 1.0
+        for pa, pb in zip(a, b):
+            gr = torch.randn(pa.shape, generator=g) * (3.0 if it < 3 else 0.01)      # clipped steps and unclipped ones
+            pa.grad.add_(gr.cuda())                       # accumulates into the bucket view, as autograd does
+            pb.grad = gr.double() * scale
+        for grp_a, grp_b in zip(oa.param_groups, ob.param_groups):
+            grp_a["lr"] = grp_b["lr"] = 3e-3 * (1.0 - 0.1 * it)
+        norm_b = torch.nn.utils.clip_grad_norm_(b, 1.0)
+        norm_a = oa.step(grad_scale=scale, max_norm=1.0)
+        ob.step()
+        assert abs(float(norm_a) - float(norm_b)) < 1e-5 * float(norm_b)
+    for pa, pb in zip(a, b):
+        assert rel_err(pa.detach().cpu(), pb.detach()) < 2e-6
+    # a skipped parameter (no gradient on any rank) is left alone
+    before = [p.detach().clone() for p in a]
+    oa.step(skip=[a[1]])
+    assert torch.equal(a[1].detach(), before[1]) and not torch.equal(a[0].detach(), before[0])
+
+
+@pytest.mark.gpu
+def test_rccl_gradient_all_reduce_runs_on_the_device(tiny_sd):
+    """RCCL on the GPU (one rank, collectives forced): the bucket all-reduces are launched from inside backward by the
+    post-accumulate-grad hooks, in bucket order, on flat gradient buffers; a whole TrainStep (forward, ConfLoss, backward,
+    all-reduce, clip, AdamW) runs on top and changes the parameters"""
+    import torch.distributed as dist
+    from spann3r_amd import Spann3R, TINY
+    from spann3r_amd import train as T
+    from spann3r_amd.weights import synth_frames
+    own = not dist.is_initialized()
+    if own:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29617")
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        m = Spann3R(dus3r_name=None, cfg=TINY, init_weights=False)
+        m.load_state_dict(tiny_sd, strict=True)
+        m = m.cuda()
+        ts = T.TrainStep(m, precision="bf16", bucket_mb=4.0, force_collectives=True)
+        assert ts.reducer.active() and len(ts.reducer.buckets) >= 3
+        n, B, H, W = 3, 2, 32, 48
+        frames = [{"img": f["img"].cuda()} for f in synth_frames(n, H, W, batch=B, seed=3)]
+        gts = _synth_gts(n, B, H, W, 5, torch.float32, "cuda")
+        w0 = m.state_dict()["dust3r.dec_blocks.0.mlp.fc1.weight"].clone()
+        l0, n0 = ts.run(frames, gts)
+        assert ts.reducer.launched_in_backward >= 1          # collectives started while backward was still running
+        l1, n1 = ts.run(frames, gts)
+        torch.cuda.synchronize()
+        assert torch.isfinite(l0) and torch.isfinite(n0) and float(n0) > 0
+        assert not torch.equal(m.state_dict()["dust3r.dec_blocks.0.mlp.fc1.weight"], w0)
+        assert float(l1) < float(l0)                         # the same batch twice: the step went downhill
+        # world 1: the averaged gradient is the local one
+        g = torch.randn(1000, device="cuda")
+        p = torch.nn.Parameter(torch.zeros(1000, device="cuda"))
+        from spann3r_amd.runner import GradReducer
+        r = GradReducer([p], force=True)
+        p.grad.copy_(g)
+        r.reduce()
+        assert torch.equal(p.grad, g)
+    finally:
+        T.set_precision("fp32")
+        T.invalidate_weight_cache()
+        if own:
+            dist.destroy_process_group()
