@@ -290,7 +290,7 @@ def train_measure(dev, steps, warmup, precision, batch, n_frames=5, size=224, wo
     model = Spann3R(dus3r_name=None, cfg=FULL, init_weights=False)
     model.load_state_dict(synth_state_dict(0, FULL), strict=True)
     model = model.to(dev)
-    ts = T.TrainStep(model, precision=precision)
+    ts = T.TrainStep(model, precision=precision, graph=(world == 1))
     rank = int(os.environ.get("RANK", "0"))
     frames, gts = synth_training_batch(rank, n_frames, size, batch, dev)
     torch.cuda.reset_peak_memory_stats()
@@ -312,7 +312,7 @@ def train_measure(dev, steps, warmup, precision, batch, n_frames=5, size=224, wo
     out = {"seconds_per_step": sec, "frames_per_s": batch * n_frames / sec, "loss": float(loss), "grad_norm": float(norm) if norm is not None else None,
            "achieved_tflops": fl / sec / 1e12, "frac_of_mfma_peak": fl / sec / 1e12 / PEAK_TFLOPS["bf16" if precision == "bf16" else "fp32"],
            "peak_memory_gb": torch.cuda.max_memory_allocated() / 2 ** 30, "precision": precision, "batch": batch, "frames": n_frames, "size": size,
-           "rccl_ranks": world, "buckets": len(ts.reducer.buckets), "buckets_reduced_inside_backward": ts.reducer.launched_in_backward,
+           "rccl_ranks": world, "buckets": len(ts.reducer.buckets), "buckets_reduced_inside_backward": ts.reducer.launched_in_backward, "hip_graph": bool(ts.graph),
            "what": "one optimisation step: train-mode Spann3R.forward (HIP autograd ops) + ConfLoss_t(Regr3D_t(L21, avg_dis), 0.4) + backward through the "
                    "memory fusion + bucketed gradient all-reduce (RCCL, world %d) + global-norm clip 1.0 + AdamW on flat buckets" % world}
     T.set_precision("fp32")

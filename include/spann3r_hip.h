@@ -401,13 +401,19 @@ int sp3_pack_bf16(const float* src, int64_t ld, int rows, int cols, void* dst, v
  * (fixed order: deterministic), sp3_clip_coef reduces `count` partials of all buckets to out[0] = extra_scale * min(1, max_norm /
  * (norm + 1e-6)) and out[1] = norm (of the gradients times |extra_scale|; max_norm <= 0: no clipping). */
 int64_t sp3_sumsq_blocks(int64_t n);
+/* out[j] (+)= sum_r x[r, j] for a tall fp32 matrix (the bias gradient of a Linear / convolution: autograd's dY.sum(0)), two deterministic
+ * stages; scratch: sp3_colsum_rows_ws(rows, N) floats */
+int64_t sp3_colsum_rows_ws(int rows, int N);
+int sp3_colsum_rows(const float* x, int64_t ld, int rows, int N, float* out, int accumulate, float* scratch, void* stream);
 int sp3_sumsq_partial(const float* g, int64_t n, double* partial, void* stream);
-int sp3_clip_coef(const double* partial, int count, float max_norm, float extra_scale, float* out, void* stream);
+int sp3_clip_coef(const double* partial, int count, float max_norm, float extra_scale, float* out, int* step_counter, void* stream);
+   /* step_counter (nullable): incremented by one -- the optimizer's step count kept on the device so that a captured step replays */
 /* torch.optim.AdamW (spann3r/training.py:327) over one flat bucket of n elements (n % 1024 == 0): p, g, m, v share the element layout;
  * chunk_table holds (weight_decay, lr_scale) per 1024-element chunk (lr_scale < 0: chunk untouched -- parameters without a gradient
  * on any rank); the gradient is multiplied by grad_scale * grad_scale_dev[0] (device scalar, nullable: sp3_clip_coef's out[0]). */
 int sp3_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, const float* chunk_table, float lr, float beta1, float beta2,
-                   float eps, int step, const float* grad_scale_dev, float grad_scale, void* stream);
+                   float eps, int step, const float* grad_scale_dev, float grad_scale, const int* step_dev, const float* lr_dev, void* stream);
+   /* step_dev / lr_dev (nullable): the step count / learning rate are read from device memory instead (hipGraph replay of the step) */
 int sp3_softmax_bwd(const float* A, const float* dAd, const float* mask, float* dS, int64_t ld, int rows, int T, float alpha, void* stream);
 int sp3_layernorm_bwd(const float* x, int64_t ldx, const float* gamma, const float* dy, int64_t ldy, const float* dx_add, int64_t ld_add,
                       float* dx, int64_t ld_dx, float* dgamma, float* dbeta, int accumulate, float* scratch, int rows, int C, float eps,

@@ -108,15 +108,26 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     part[(int64_t)blockIdx.x * 2 * C + c] = (sh[c] + sh[2 * C + c]) + (sh[4 * C + c] + sh[6 * C + c]);
 }
 
-// dgamma / dbeta [2][C] (+= if accumulate) = sum over the row blocks, fixed order
+// dgamma / dbeta [2][C] (+= if accumulate) = sum over the row blocks, fixed order: a workgroup owns 64 of the 2C columns, its 4
+// waves take the row blocks b = w, w+4, ... (two independent chains each), the partial sums meet in LDS in wave order
 __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, int accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= 2 * C) return;
-  double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += (double)part[(int64_t)b * 2 * C + c];
-  float* o = c < C ? dgamma + c : dbeta + (c - C);
-  *o = (accumulate ? *o : 0.f) + (float)s;
+  __shared__ double sh[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  double s0 = 0.0, s1 = 0.0;
+  if (c < 2 * C) {
+    int b = w;
+    for (; b + 4 < nblk; b += 8) { s0 += (double)part[(int64_t)b * 2 * C + c]; s1 += (double)part[(int64_t)(b + 4) * 2 * C + c]; }
+    if (b < nblk) s0 += (double)part[(int64_t)b * 2 * C + c];
+  }
+  sh[w][lane] = s0 + s1;
+  __syncthreads();
+  if (w == 0 && c < 2 * C) {
+    const double s = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+    float* o = c < C ? dgamma + c : dbeta + (c - C);
+    *o = (accumulate ? *o : 0.f) + (float)s;
+  }
 }
 
 // ---- DPT head pieces (croco/models/dpt_block.py, dust3r/heads/postprocess.py), NHWC fp32 ----
@@ -314,7 +325,7 @@ extern "C" int sp3_layernorm_bwd(const float* x, int64_t ldx, const float* gamma
   const int nblk = (rows + 3) / 4;
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(256), (size_t)8 * C * sizeof(float), ST(stream), x, ldx, gamma, dy, ldy, dx_add,
                      ld_add, dx, ld_dx, scratch, rows, C, eps);
-  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, ST(stream), scratch, nblk, C, dgamma, dbeta, accumulate);
+  hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, ST(stream), scratch, nblk, C, dgamma, dbeta, accumulate);
   SP3_LAUNCH_CHECK("sp3_layernorm_bwd");
   return 0;
 }

@@ -67,6 +67,37 @@ __global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict_
   }
 }
 
+// column sums of a tall matrix (the bias gradient db = sum_r dY[r, :]) in two deterministic stages: a workgroup takes 64 columns of a
+// 256-row chunk (its 4 waves interleave the rows, coalesced 256-byte segments), partial[chunk][col]; then one thread per column
+// adds the chunks in order
+constexpr int kColChunk = 256;
+
+__global__ __launch_bounds__(256) void colsum_rows_partial_kernel(const float* __restrict__ x, int64_t ld, int rows, int N, float* __restrict__ partial) {
+  __shared__ float sh[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + lane;
+  const int r0 = blockIdx.y * kColChunk, r1 = (r0 + kColChunk) < rows ? (r0 + kColChunk) : rows;
+  float s0 = 0.f, s1 = 0.f;
+  if (j < N) {
+    int r = r0 + w;
+    for (; r + 4 < r1; r += 8) { s0 += x[(int64_t)r * ld + j]; s1 += x[(int64_t)(r + 4) * ld + j]; }
+    if (r < r1) s0 += x[(int64_t)r * ld + j];
+  }
+  sh[w][lane] = s0 + s1;
+  __syncthreads();
+  if (w == 0 && j < N) partial[(int64_t)blockIdx.y * N + j] = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
+}
+
+__global__ __launch_bounds__(256) void colsum_rows_finish_kernel(const float* __restrict__ partial, int nchunk, int N, float* __restrict__ out, int accumulate) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= N) return;
+  double s0 = 0.0, s1 = 0.0;
+  int c = 0;
+  for (; c + 1 < nchunk; c += 2) { s0 += (double)partial[(int64_t)c * N + j]; s1 += (double)partial[(int64_t)(c + 1) * N + j]; }
+  if (c < nchunk) s0 += (double)partial[(int64_t)c * N + j];
+  out[j] = (accumulate ? out[j] : 0.f) + (float)(s0 + s1);
+}
+
 constexpr int kSumChunk = 16384;                      // elements per workgroup of the norm's first stage
 
 __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, int64_t n, double* __restrict__ partial) {
@@ -90,7 +121,7 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restr
 
 // out[0] = extra_scale * min(1, max_norm / (norm + 1e-6)), out[1] = norm   (max_norm <= 0: no clipping, out[0] = extra_scale)
 __global__ __launch_bounds__(256) void clip_coef_kernel(const double* __restrict__ partial, int count, float max_norm, float extra_scale,
-                                                        float* __restrict__ out) {
+                                                        float* __restrict__ out, int* __restrict__ step_ctr) {
   __shared__ double sh[256];
   double s = 0.0;
   for (int i = threadIdx.x; i < count; i += 256) s += partial[i];       // fixed assignment, fixed order: deterministic
@@ -106,15 +137,22 @@ __global__ __launch_bounds__(256) void clip_coef_kernel(const double* __restrict
     if (max_norm > 0.f) coef = fminf(1.0f, max_norm / (norm + 1e-6f));
     out[0] = extra_scale * coef;
     out[1] = norm;
+    if (step_ctr) step_ctr[0] += 1;                     // the optimizer's step count lives on the device (hipGraph replays)
   }
 }
 
 __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                          float* __restrict__ v, int64_t n, const float2* __restrict__ chunk, float lr,
                                                          float b1, float b2, float eps, float bc1, float rsbc2, const float* __restrict__ gscale_p,
-                                                         float gscale_c) {
+                                                         float gscale_c, const int* __restrict__ step_dev, const float* __restrict__ lr_dev) {
   const float2 cw = chunk[blockIdx.x];                 // (weight decay, lr scale; < 0: leave the chunk alone)
   if (cw.y < 0.f) return;
+  if (step_dev) {                                      // bias corrections from the device-side step count
+    const float st = (float)step_dev[0];
+    bc1 = 1.0f - powf(b1, st);
+    rsbc2 = 1.0f / sqrtf(1.0f - powf(b2, st));
+  }
+  if (lr_dev) lr = lr_dev[0];
   const float gs = gscale_c * (gscale_p ? gscale_p[0] : 1.0f);
   const float lr_ = lr * cw.y;
   const int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x * 4;
@@ -151,6 +189,18 @@ extern "C" int sp3_pack_bf16(const float* src, int64_t ld, int rows, int cols, v
   return 0;
 }
 
+extern "C" int64_t sp3_colsum_rows_ws(int rows, int N) { return (int64_t)((rows + kColChunk - 1) / kColChunk) * N; }
+
+extern "C" int sp3_colsum_rows(const float* x, int64_t ld, int rows, int N, float* out, int accumulate, float* scratch, void* stream) {
+  SP3_CHECK(x && out && scratch && rows > 0 && N > 0 && ld >= N, "sp3_colsum_rows: bad arguments");
+  const int nchunk = (rows + kColChunk - 1) / kColChunk;
+  SP3_CHECK(nchunk <= 65535, "sp3_colsum_rows: too many rows (%d)", rows);
+  hipLaunchKernelGGL(colsum_rows_partial_kernel, dim3((N + 63) / 64, nchunk), dim3(256), 0, ST(stream), x, ld, rows, N, scratch);
+  hipLaunchKernelGGL(colsum_rows_finish_kernel, dim3((N + 255) / 256), dim3(256), 0, ST(stream), scratch, nchunk, N, out, accumulate);
+  SP3_LAUNCH_CHECK("sp3_colsum_rows");
+  return 0;
+}
+
 extern "C" int64_t sp3_sumsq_blocks(int64_t n) { return (n + kSumChunk - 1) / kSumChunk; }
 
 extern "C" int sp3_sumsq_partial(const float* g, int64_t n, double* partial, void* stream) {
@@ -160,19 +210,22 @@ extern "C" int sp3_sumsq_partial(const float* g, int64_t n, double* partial, voi
   return 0;
 }
 
-extern "C" int sp3_clip_coef(const double* partial, int count, float max_norm, float extra_scale, float* out, void* stream) {
+extern "C" int sp3_clip_coef(const double* partial, int count, float max_norm, float extra_scale, float* out, int* step_counter, void* stream) {
   SP3_CHECK(partial && out && count > 0, "sp3_clip_coef: bad arguments");
-  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, ST(stream), partial, count, max_norm, extra_scale, out);
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, ST(stream), partial, count, max_norm, extra_scale, out, step_counter);
   SP3_LAUNCH_CHECK("sp3_clip_coef");
   return 0;
 }
 
 extern "C" int sp3_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, const float* chunk_table, float lr, float beta1,
-                              float beta2, float eps, int step, const float* grad_scale_dev, float grad_scale, void* stream) {
-  SP3_CHECK(p && g && m && v && chunk_table && n > 0 && n % 1024 == 0 && step >= 1, "sp3_adamw_flat: bad arguments (n=%lld must be a multiple of 1024)", (long long)n);
-  const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+                              float beta2, float eps, int step, const float* grad_scale_dev, float grad_scale, const int* step_dev,
+                              const float* lr_dev, void* stream) {
+  SP3_CHECK(p && g && m && v && chunk_table && n > 0 && n % 1024 == 0 && (step >= 1 || step_dev), "sp3_adamw_flat: bad arguments (n=%lld must be a multiple of 1024)", (long long)n);
+  const int st_ = step >= 1 ? step : 1;
+  const float bc1 = 1.0f - powf(beta1, (float)st_), bc2 = 1.0f - powf(beta2, (float)st_);
   hipLaunchKernelGGL(adamw_flat_kernel, dim3((unsigned)(n / 1024)), dim3(256), 0, ST(stream), p, g, m, v, n,
-                     reinterpret_cast<const float2*>(chunk_table), lr, beta1, beta2, eps, bc1, 1.0f / sqrtf(bc2), grad_scale_dev, grad_scale);
+                     reinterpret_cast<const float2*>(chunk_table), lr, beta1, beta2, eps, bc1, 1.0f / sqrtf(bc2), grad_scale_dev, grad_scale,
+                     step_dev, lr_dev);
   SP3_LAUNCH_CHECK("sp3_adamw_flat");
   return 0;
 }

@@ -137,10 +137,11 @@ _PROTOS = {
                   C.c_float, C.c_void_p],
     "sp3_mul": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
     "sp3_pack_bf16": [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
+    "sp3_colsum_rows": [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p],
     "sp3_sumsq_partial": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p],
-    "sp3_clip_coef": [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p],
+    "sp3_clip_coef": [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p],
     "sp3_adamw_flat": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float,
-                       C.c_int, C.c_void_p, C.c_float, C.c_void_p],
+                       C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p],
     "sp3_softmax_bwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_void_p],
     "sp3_layernorm_bwd": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                           C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p],
@@ -157,7 +158,7 @@ _PROTOS = {
                              C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                              C.c_void_p, C.c_void_p],
 }
-EXPORTS = sorted(list(_PROTOS) + ["sp3_last_error", "sp3_version", "sp3_conf_loss_ws_bytes", "sp3_ssi_loss_ws_bytes", "sp3_sumsq_blocks"])
+EXPORTS = sorted(list(_PROTOS) + ["sp3_last_error", "sp3_version", "sp3_conf_loss_ws_bytes", "sp3_ssi_loss_ws_bytes", "sp3_sumsq_blocks", "sp3_colsum_rows_ws"])
 
 
 def load():
@@ -176,6 +177,10 @@ def load():
     lib.sp3_conf_loss_ws_bytes.argtypes = [C.c_int, C.c_int]
     lib.sp3_ssi_loss_ws_bytes.restype = C.c_int64
     lib.sp3_ssi_loss_ws_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.sp3_sumsq_blocks.restype = C.c_int64
+    lib.sp3_sumsq_blocks.argtypes = [C.c_int64]
+    lib.sp3_colsum_rows_ws.restype = C.c_int64
+    lib.sp3_colsum_rows_ws.argtypes = [C.c_int, C.c_int]
     for name, argtypes in _PROTOS.items():
         fn = getattr(lib, name)
         fn.restype = C.c_int

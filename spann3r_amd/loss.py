@@ -100,9 +100,10 @@ class ConfLoss_t:
     def get_name(self):
         return "ConfLoss(Regr3D_t(%r))" % (self.pixel_loss.criterion,)
 
-    def compute_frame_loss(self, gts, preds, dist_clip=None):
+    def compute_frame_loss(self, gts, preds, dist_clip=None, monitor=True):
         """gts: the batch (list of n views with pts3d [B,H,W,3], valid_mask [B,H,W] bool, camera_pose [B,4,4]);
-        preds: Spann3R.forward's preds_all (n-1 pairs).  -> (loss, details, loss_factor), as the reference."""
+        preds: Spann3R.forward's preds_all (n-1 pairs).  -> (loss, details, loss_factor), as the reference.
+        monitor=False: `details` stays empty and nothing is read back to the host (a step captured in a hipGraph)."""
         n = len(gts)
         if n < 2 or len(preds) != n - 1:
             raise ValueError("compute_frame_loss: %d views need %d prediction pairs, got %d" % (n, n - 1, len(preds)))
@@ -121,6 +122,8 @@ class ConfLoss_t:
         pose0 = gts[0]["camera_pose"].to(dev, torch.float32).reshape(B, 16).contiguous()
         loss, factor, out, per = _ConfRegr.apply(P.reshape(E, B, H * W, 3), Cf.reshape(E, B, H * W), G, V, pose0, self.alpha,
                                                  self.pixel_loss.fix_first)
+        if not monitor:
+            return loss, {}, factor
         o, per = out.tolist(), per.tolist()                                         # (one sync: the reference floats them too)
         name = "Regr3D_t"
         left = [e for e, (s, side) in enumerate(ent) if side == 0 and s != 0]      # i != 0 (:207)

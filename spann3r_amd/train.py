@@ -57,6 +57,31 @@ def _packed_weight(W, key):
     return ent
 
 
+def _colsum(dy, out=None):
+    """db = dY.sum(0) of a contiguous fp32 [R, N] (two deterministic stages); `out` given: accumulated into it"""
+    R, N = dy.shape
+    ws = torch.empty(int(L.load().sp3_colsum_rows_ws(R, N)), device=dy.device)
+    acc = out is not None
+    if out is None:
+        out = torch.empty(N, device=dy.device)
+    L.check(L.load().sp3_colsum_rows(dy.data_ptr(), dy.stride(0), R, N, out.data_ptr(), int(acc), ws.data_ptr(), L.stream_ptr()), "sp3_colsum_rows")
+    return out
+
+
+def _into_grad(p, compute):
+    """Accumulate a parameter gradient straight into the flat-bucket view that IS p.grad (runner.GradReducer): `compute(out, acc)`
+    writes (acc = False) or adds (acc = True) the gradient in place; the post-accumulate-grad hooks autograd would have run (the
+    reducer's bucket bookkeeping) are run by hand.  Returns True when done (the caller then returns None to autograd)."""
+    if not (isinstance(p, torch.nn.Parameter) and p.grad is not None and p.grad.is_contiguous() and getattr(p, "_sp3_direct_grad", False)):
+        return False
+    compute(p.grad, True)
+    p._sp3_pending = getattr(p, "_sp3_pending", 1) - 1      # a weight used k times in the forward gets k contributions:
+    if p._sp3_pending <= 0:                                 # the hooks run once, behind the last one (as AccumulateGrad does)
+        for h in (p._post_accumulate_grad_hooks or {}).values():
+            h(p)
+    return True
+
+
 def _r8(n):
     return (n + 7) // 8 * 8
 
@@ -217,6 +242,9 @@ class _Linear(torch.autograd.Function):
             Wp, WT = _packed_weight(W, wkey)
             ops.gemm(xp, Wp, y, M=R, N=N, K=_r64(K), lda=K, ldc=N, bias=b, res1=res, ldr1=N, res2=res2, ldr2=N)
             ctx.xT, ctx.WT, ctx.shape = xT, WT, (R, K, N)
+            ctx.Wparam = W if (isinstance(W, torch.nn.Parameter) and W.dim() == 2) else None
+            if ctx.Wparam is not None and need_t:
+                W._sp3_pending = getattr(W, "_sp3_pending", 0) + 1
             return y
         xp, Wp = _pad8(x), _pad8(W)
         ops.gemm(xp, Wp, y, M=R, N=N, K=xp.shape[1], lda=xp.shape[1], ldc=N, ldw=Wp.shape[1], bias=b, res1=res, ldr1=N, res2=res2, ldr2=N)
@@ -231,13 +259,17 @@ class _Linear(torch.autograd.Function):
         if ctx.bf16:
             R, K, N = ctx.shape
             need_w = ctx.needs_input_grad[1]
-            dyp, dyT = ops.pack_bf16(dy, ctx.needs_input_grad[0], need_w)
+            dyp, dyT = ops.pack_bf16(dy, ctx.needs_input_grad[0], need_w) if (ctx.needs_input_grad[0] or need_w) else (None, None)
             if ctx.needs_input_grad[0]:           # dX = dY . W = dY . (W^T)^T: contraction over N
                 dx = torch.empty(R, K, device=dev)
                 ops.gemm(dyp, ctx.WT, dx, M=R, N=K, K=_r64(N), lda=N, ldc=K)
             if need_w:                            # dW = dY^T . X = (dY^T) . (X^T)^T: contraction over the rows
-                dW = torch.empty(N, K, device=dev)
-                ops.gemm(dyT, ops.PackedWeight.wrap(ctx.xT.data, K, R), dW, M=N, N=K, K=_r64(R), lda=R, ldc=K)
+                xTw = ops.PackedWeight.wrap(ctx.xT.data, K, R)
+                def dw_into(out, acc):
+                    ops.gemm(dyT, xTw, out, M=N, N=K, K=_r64(R), lda=R, ldc=K, res1=out if acc else None, ldr1=K)
+                if not _into_grad(ctx.Wparam, dw_into):
+                    dW = torch.empty(N, K, device=dev)
+                    dw_into(dW, False)
             ctx.xT = ctx.WT = None
         else:
             x, W = ctx.saved_tensors
@@ -251,8 +283,7 @@ class _Linear(torch.autograd.Function):
                 dyT, xT = _tb(dy, R, N, N)[0], _tb(x, R, K, K)[0]            # [N, r8(R)], [K, r8(R)]
                 dW = _nt(dyT, xT, N, K, dyT.shape[1], dyT.shape[1], xT.shape[1], torch.empty(N, K, device=dev), K)
         if ctx.has[0] and ctx.needs_input_grad[2]:
-            db = torch.zeros(N, device=dev)
-            ops.colsum_accum(dy, N, R, N, db)
+            db = _colsum(dy)
         return dx, dW, db, (dy if ctx.has[1] else None), (dy if ctx.has[2] else None), None
 
 
@@ -698,9 +729,14 @@ def parameter_groups(model, weight_decay):
 class TrainStep:
     """One optimisation step of spann3r/training.py:216-231 on one rank: train-mode forward (HIP autograd ops), ConfLoss_t,
     backward with the bucket all-reduces launched from inside it (RCCL when a process group is up), global-norm clip and AdamW on
-    the flat buckets.  `run(frames, gts)` returns (loss, gradient norm) as device scalars (no host sync)."""
+    the flat buckets.  `run(frames, gts)` returns (loss, gradient norm) as device scalars (no host sync).
 
-    def __init__(self, model, lr=5e-5, weight_decay=0.05, betas=(0.9, 0.95), clip_grad=1.0, precision="bf16", bucket_mb=64.0, force_collectives=False):
+    graph=True (single rank): the whole step -- ~35 000 kernel launches at batch 4 -- is captured once into a hipGraph and
+    replayed; the batch is copied into static buffers, the optimizer's step count and learning rate live on the device
+    (`set_lr`).  Shapes must not change between steps (training batches of one resolution)."""
+
+    def __init__(self, model, lr=5e-5, weight_decay=0.05, betas=(0.9, 0.95), clip_grad=1.0, precision="bf16", bucket_mb=64.0, force_collectives=False,
+                 graph=False):
         from .loss import ConfLoss_t, Regr3D_t, L21
         from .runner import GradReducer
         set_precision(precision)
@@ -709,17 +745,51 @@ class TrainStep:
         self.opt = FlatAdamW(parameter_groups(model, weight_decay), self.reducer, lr=lr, betas=betas, weight_decay=weight_decay)
         self.crit = ConfLoss_t(Regr3D_t(L21, norm_mode="avg_dis", fix_first=False), alpha=0.4)      # training.py:37
         self.clip_grad = clip_grad
+        self.graph = bool(graph) and not self.reducer.active()
+        self._g = self._static = self._out = None
 
-    def run(self, frames, gts):
+    def set_lr(self, lr):
+        for g in self.opt.param_groups:
+            g["lr"] = lr * g.get("lr_scale", 1.0)
+
+    def _body(self, frames, gts, monitor):
         self.reducer.zero_grad()
         self.reducer.prepare()
+        for p in self.reducer.params:
+            p._sp3_pending = 0
         preds, preds_all = self.model(frames)
-        loss, details, factor = self.crit.compute_frame_loss(gts, preds_all)
+        loss, details, factor = self.crit.compute_frame_loss(gts, preds_all, monitor=monitor)
         total = loss + factor
         total.backward()
         self.reducer.finish()
         norm = self.opt.step(max_norm=self.clip_grad, skip=self.reducer.unused_everywhere() if self.reducer.active() else ())
         return total.detach(), norm
+
+    def run(self, frames, gts):
+        if not self.graph:
+            return self._body(frames, gts, monitor=False)
+        if self._g is None:
+            clone = lambda d: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in d.items()}
+            self._static = ([clone(f) for f in frames], [clone(g) for g in gts])
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                # warm-up off the capture: allocator pools, caches, chunk tables
+                for _ in range(2):
+                    self._body(*self._static, monitor=False)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.opt.capture_mode(True)
+            self._g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._g):
+                self._out = self._body(*self._static, monitor=False)
+        else:
+            for dst, src in zip(self._static[0] + self._static[1], list(frames) + list(gts)):
+                for k, v in src.items():
+                    if torch.is_tensor(v):
+                        dst[k].copy_(v, non_blocking=True)
+        self.opt.sync_lr()
+        self._g.replay()
+        return self._out
 
 
 class FlatAdamW:
@@ -778,7 +848,20 @@ class FlatAdamW:
         dev = self.flat_p[0].device
         self._partials = torch.zeros(sum(nblk), dtype=torch.float64, device=dev)
         self._coef = torch.ones(2, dtype=torch.float32, device=dev)
+        self._step_dev = torch.zeros(1, dtype=torch.int32, device=dev)      # step count on the device (incremented by sp3_clip_coef)
+        self._lr_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._capture = False
+        for p in reducer.params:
+            p._sp3_direct_grad = True               # _Linear.backward may accumulate dW straight into the bucket view
         invalidate_weight_cache()
+
+    def capture_mode(self, on):
+        """on: step count and learning rate are read from device memory by the update kernels (a captured step replays them)"""
+        self._capture = bool(on)
+        self._step_dev.fill_(self.step_count)
+
+    def sync_lr(self):
+        self._lr_dev.fill_(float(self.param_groups[0]["lr"]))
 
     def zero_grad(self, set_to_none=False):
         self.reducer.zero_grad()
@@ -813,20 +896,22 @@ class FlatAdamW:
         self.step_count += 1
         bufs = self.reducer.flat_buffers()
         coef_ptr, gs = None, float(grad_scale)
-        if max_norm is not None:
+        if max_norm is not None or self._capture:
             off = 0
             for (g, _), nb in zip(bufs, self._nblk):
                 L.check(lib.sp3_sumsq_partial(g.data_ptr(), g.numel(), self._partials[off:].data_ptr(), L.stream_ptr()), "sp3_sumsq_partial")
                 off += nb
-            L.check(lib.sp3_clip_coef(self._partials.data_ptr(), off, float(max_norm), float(grad_scale), self._coef.data_ptr(), L.stream_ptr()),
-                    "sp3_clip_coef")
+            L.check(lib.sp3_clip_coef(self._partials.data_ptr(), off, float(max_norm if max_norm is not None else 0.0), float(grad_scale),
+                                      self._coef.data_ptr(), self._step_dev.data_ptr(), L.stream_ptr()), "sp3_clip_coef")
             coef_ptr, gs = self._coef.data_ptr(), 1.0
         tabs = self._chunk_tables(skip)
         base = self.param_groups[0]["lr"]
         b1, b2 = self.betas
         for (g, _), fp, fm, fv, tab in zip(bufs, self.flat_p, self.flat_m, self.flat_v, tabs):
             L.check(lib.sp3_adamw_flat(fp.data_ptr(), g.data_ptr(), fm.data_ptr(), fv.data_ptr(), g.numel(), tab.data_ptr(), float(base), b1, b2,
-                                       float(self.eps), self.step_count, coef_ptr, gs, L.stream_ptr()), "sp3_adamw_flat")
-            fp[:0].zero_()                          # bumps the version counter the parameter views share: weight caches notice
+                                       float(self.eps), self.step_count, coef_ptr, gs, self._step_dev.data_ptr() if self._capture else None,
+                                       self._lr_dev.data_ptr() if self._capture else None, L.stream_ptr()), "sp3_adamw_flat")
+            if not self._capture:
+                fp[:0].zero_()                      # bumps the version counter the parameter views share: weight caches notice
         invalidate_weight_cache()
         return self._coef[1] if max_norm is not None else None

@@ -39,3 +39,15 @@ for it in range(a.steps):
     print("step %d (%s): loss %.4f |g| %.3f  forward %.3f s  loss+backward %.3f s  clip+AdamW %.4f s  total %.3f s  (batch %d, %d frames of %dx%d, peak memory %.1f GB)" %
           (it, a.precision, float(loss.detach()) + float(fac), float(norm), t1 - t0, t2 - t1, t3 - t2, t3 - t0, a.batch, a.frames, a.size, a.size,
            torch.cuda.max_memory_allocated() / 2**30))
+
+# the same step captured once into a hipGraph and replayed (TrainStep(graph=True)): what bench.py --train times on one rank
+del ts
+torch.cuda.empty_cache()
+m2 = Spann3R(dus3r_name=None, cfg=cfg, init_weights=False)
+m2.load_state_dict(synth_state_dict(0, cfg))
+tg = T.TrainStep(m2.cuda(), precision=a.precision, graph=True)
+for it in range(a.steps + 1):
+    sync(); t0 = time.time()
+    loss, norm = tg.run(frames, gts)
+    sync(); t1 = time.time()
+    print("graph step %d (%s): loss %.4f |g| %.3f  total %.3f s%s" % (it, a.precision, float(loss), float(norm), t1 - t0, "  (warm-up + capture)" if it == 0 else ""))
