@@ -60,8 +60,13 @@ def _packed_weight(W, key):
 def _colsum(dy, out=None):
     """db = dY.sum(0) of a contiguous fp32 [R, N] (two deterministic stages); `out` given: accumulated into it"""
     R, N = dy.shape
-    ws = torch.empty(int(L.load().sp3_colsum_rows_ws(R, N)), device=dy.device)
     acc = out is not None
+    if R <= 2048:                                   # short: one workgroup per 64 columns walks all rows (one launch)
+        if out is None:
+            out = torch.zeros(N, device=dy.device)
+        ops.colsum_accum(dy, dy.stride(0), R, N, out)
+        return out
+    ws = torch.empty(int(L.load().sp3_colsum_rows_ws(R, N)), device=dy.device)
     if out is None:
         out = torch.empty(N, device=dy.device)
     L.check(L.load().sp3_colsum_rows(dy.data_ptr(), dy.stride(0), R, N, out.data_ptr(), int(acc), ws.data_ptr(), L.stream_ptr()), "sp3_colsum_rows")
@@ -653,9 +658,17 @@ def forward_train(P, frames, cfg, dropout_p=0.0, generator=None):
     feat2 = pos2 = feat_k2 = None
     preds, preds_all = None, []
     nq, nk, nv = (P["norm_q.weight"], P["norm_q.bias"]), (P["norm_k.weight"], P["norm_k.bias"]), (P["norm_v.weight"], P["norm_v.bias"])
+    # the encoder sees every frame once and does not depend on the memory (spann3r/model.py:293-295): all n frames go through it
+    # as ONE batch (rows n*B*P per GEMM instead of five passes of B*P rows); the reference encodes frame by frame, same values
+    same = all(f["img"].shape == frames[0]["img"].shape for f in frames)
+    if same:
+        f_all, p_all, grid = encode_image(torch.cat([f["img"] for f in frames], 0), P, cfg)
+        feats, poss = f_all.chunk(len(frames), 0), p_all.chunk(len(frames), 0)
     for i in range(len(frames) - 1):
         v1, v2 = frames[i], frames[i + 1]
-        if feat2 is None:
+        if same:
+            feat1, pos1, feat2, pos2 = feats[i], poss[i], feats[i + 1], poss[i + 1]
+        elif feat2 is None:
             f, p, grid = encode_image(torch.cat((v1["img"], v2["img"]), 0), P, cfg)
             (feat1, feat2), (pos1, pos2) = f.chunk(2, 0), p.chunk(2, 0)
         else:

@@ -519,3 +519,59 @@ def test_offline_reconstruction_vs_reference(tiny_model):
     finally:
         m.NBV_CHUNK = 16
     assert [int(i) for i in used1] == g["idx_used"].tolist()
+
+
+def test_decoder_bit_stable_next_to_a_busy_third_stream(full_sd):
+    """The guard for the packed-FP32 workaround (spann3r_amd/build.py DEVICE_FLAGS; DESIGN.md "Packed-FP32"): the two-stream
+    bf16 decoder run concurrently with an encoder pass on a third stream must produce the same BITS as the serial run in every
+    workspace buffer, every time -- with v_pk_fma_f32 in the GEMM epilogues about one run in 50 came out with wrong lanes
+    48..63.  (tools/check_decoder_ws.py is the long-running form of this probe.)"""
+    import dataclasses
+    from spann3r_amd import Spann3R, FULL, ops
+    m = Spann3R(dus3r_name=None, cfg=FULL, init_weights=False)
+    m.load_state_dict(full_sd, strict=True)
+    m = m.cuda().eval().set_precision("bf16")
+    eng = m.engine
+    eng.cfg = dataclasses.replace(eng.cfg, dec_depth=2)
+    torch.manual_seed(0)
+    f1, f2 = torch.randn(1, 196, 1024, device="cuda"), torch.randn(1, 196, 1024, device="cuda")
+    pos = eng.positions(1, 14, 14)[1]
+    data = lambda t: t.data if isinstance(t, ops.PackedAct) else t
+
+    def run(conc):
+        main = torch.cuda.current_stream()
+        st = eng.side_streams()
+        if conc:
+            st[3].wait_stream(main)
+            with torch.cuda.stream(st[3]):
+                eng._vit(eng.wsp("im2col_pre", 196, 768), 196, 1, 196, "patch", "enc", 24, pos, tag="_pre")
+        eng.decoder(f1, f2, 1, 14, 14, 14, 14, streams=st)
+        if conc:
+            main.wait_stream(st[3])
+        torch.cuda.synchronize()
+        return {k: data(v).clone() for k, v in eng._ws.items() if "_pre" not in str(k[0] if k[0] != "packed" else k[1])}
+    run(True)
+    ref = run(False)
+    for it in range(40):
+        out = run(True)
+        bad = [k for k in ref if k in out and not torch.equal(ref[k].view(torch.uint8), out[k].view(torch.uint8))]
+        assert not bad, (it, bad[:3])
+
+
+def test_forward_is_deterministic_run_to_run(tiny_model):
+    """the same sequence four times, eager and graph replay, fp32 and bf16: identical bits (no atomics, fixed reduction orders)"""
+    from spann3r_amd.weights import synth_frames
+    m = tiny_model
+    frames = to_dev(synth_frames(5, 64, 64, seed=4))
+    try:
+        for prec in ("fp32", "bf16"):
+            m.set_precision(prec)
+            for graphs in (False, True):
+                m.use_graphs = graphs
+                ref = m(frames)[0]
+                for _ in range(3):
+                    out = m(frames)[0]
+                    assert all(torch.equal(a["conf"], b["conf"]) for a, b in zip(ref, out)), (prec, graphs)
+    finally:
+        m.set_precision("fp32")
+        m.use_graphs = True
