@@ -215,9 +215,14 @@ def downstream_head(dec, true_shape, sd, cfg, num):
     raise NotImplementedError("mixed portrait/landscape batch")
 
 
-def encode_cur_value(pts3d, sd, cfg):
-    """spann3r/model.py:305-320 (use_feat=False; RoPE in the value encoder only with mem_pos_enc, :232-234)."""
-    x, pos = patch_embed(pts3d.permute(0, 3, 1, 2), sd, "pos_patch_embed.", cfg.patch)
+def encode_cur_value(pts3d, sd, cfg, dec_last=None, pos1=None):
+    """spann3r/model.py:305-320: the value comes from the predicted pointmap through pos_patch_embed (use_feat=False) or from
+    the last decoder output dec1[-1] with ITS positions (use_feat=True, :312-314: 768-wide blocks, 16 heads of 48); RoPE in the
+    value encoder only with mem_pos_enc (:232-234)."""
+    if getattr(cfg, "use_feat", False):
+        x, pos = dec_last, pos1
+    else:
+        x, pos = patch_embed(pts3d.permute(0, 3, 1, 2), sd, "pos_patch_embed.", cfg.patch)
     for i in range(cfg.val_depth):
         x = block(x, pos, sd, "value_encoder.%d." % i, cfg.enc_heads, cfg.rope_base, use_rope=getattr(cfg, "mem_pos_enc", False))
     x = layer_norm(x, sd["value_norm.weight"], sd["value_norm.bias"], 1e-6)
@@ -343,7 +348,7 @@ def forward(frames, sd, cfg, training_policy=False, return_memory=False, taps=No
         feat_k2 = encode_feat_key(feat2, dec2[-1], sd, 2)                         # :508
         res1 = downstream_head(dec1, shape1, sd, cfg, 1)                          # :512
         res2 = downstream_head(dec2, shape2, sd, cfg, 2)                          # :513
-        cur_v = encode_cur_value(res1["pts3d"], sd, cfg)                          # :516
+        cur_v = encode_cur_value(res1["pts3d"], sd, cfg, dec1[-1], pos1)          # :516
         if taps is not None:
             taps.setdefault("steps", []).append(dict(
                 feat1=feat1, feat2=feat2, feat_fuse=feat_fuse, dec1=list(dec1), dec2=list(dec2),
@@ -429,7 +434,7 @@ def offline_reconstruction(frames, graph, sd, cfg):
             used.append(id_n)
         feat_k1 = encode_feat_key(feat1, dec1[-1], sd, 1)
         feat_k2 = encode_feat_key(feat2, dec2[-1], sd, 2)
-        cur_v = encode_cur_value(res1["pts3d"], sd, cfg)
+        cur_v = encode_cur_value(res1["pts3d"], sd, cfg, dec1[-1], pos1)
         mem.add_mem_check(feat_k1, cur_v + feat_k1)
         res2["pts3d_in_other_view"] = res2.pop("pts3d")
         if preds is None:

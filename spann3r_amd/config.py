@@ -24,10 +24,16 @@ class Spann3RConfig:
     dpt_last: int = 128      # feature_dim // 2
     key_dim: int = 1792      # enc_dim + dec_dim (spann3r/model.py:250)
     mem_pos_enc: bool = False  # Spann3R(mem_pos_enc=True): RoPE in the value-encoder blocks (spann3r/model.py:232-234)
+    use_feat: bool = False     # Spann3R(use_feat=True): the value encoder runs on dec1[-1] (768 wide, 16 heads of 48; :225,312-314)
 
     @property
     def head_dim(self):
         return self.enc_dim // self.enc_heads
+
+    @property
+    def val_dim(self):
+        """width of the value encoder (spann3r/model.py:225: 768 if use_feat else 1024); its head count is always 16 (:228)"""
+        return self.dec_dim if self.use_feat else self.enc_dim
 
     @property
     def hooks(self):

@@ -81,15 +81,30 @@ class Engine:
             w[dst + "fc2.w"], w[dst + "fc2.b"] = mat(p[src + "mlp.fc2.weight"]), vec(p[src + "mlp.fc2.bias"])
 
         w["patch.w"], w["patch.b"] = mat(p["dust3r.patch_embed.proj.weight"]), vec(p["dust3r.patch_embed.proj.bias"])
-        w["pospatch.w"], w["pospatch.b"] = mat(p["pos_patch_embed.proj.weight"]), vec(p["pos_patch_embed.proj.bias"])
+        if not cfg.use_feat:
+            w["pospatch.w"], w["pospatch.b"] = mat(p["pos_patch_embed.proj.weight"]), vec(p["pos_patch_embed.proj.bias"])
         for i in range(cfg.enc_depth):
             block("enc%d." % i, "dust3r.enc_blocks.%d." % i)
             fold("enc%d.fc1" % i, p["dust3r.enc_blocks.%d.mlp.fc1.weight" % i], p["dust3r.enc_blocks.%d.mlp.fc1.bias" % i],
                  "dust3r.enc_blocks.%d.norm2" % i)
         for i in range(cfg.val_depth):
-            block("val%d." % i, "value_encoder.%d." % i)
-            fold("val%d.fc1" % i, p["value_encoder.%d.mlp.fc1.weight" % i], p["value_encoder.%d.mlp.fc1.bias" % i],
-                 "value_encoder.%d.norm2" % i)
+            src = "value_encoder.%d." % i
+            if cfg.use_feat:
+                # 16 heads of 48 (spann3r/model.py:225,228) -> zero-padded to 64 per head: qkv rows, proj columns (_attn_core)
+                Hh, hd, Cv = cfg.enc_heads, cfg.val_dim // cfg.enc_heads, cfg.val_dim
+                qw = p[src + "attn.qkv.weight"].detach().to(dev, torch.float32).reshape(3, Hh, hd, Cv)
+                qb = p[src + "attn.qkv.bias"].detach().to(dev, torch.float32).reshape(3, Hh, hd)
+                qwp, qbp = torch.zeros(3, Hh, 64, Cv, device=dev), torch.zeros(3, Hh, 64, device=dev)
+                qwp[:, :, :hd], qbp[:, :, :hd] = qw, qb
+                fold("val%d.qkv" % i, qwp.reshape(3 * Hh * 64, Cv), qbp.reshape(-1), src + "norm1")
+                pw = p[src + "attn.proj.weight"].detach().to(dev, torch.float32).reshape(Cv, Hh, hd)
+                pwp = torch.zeros(Cv, Hh, 64, device=dev)
+                pwp[:, :, :hd] = pw
+                w["val%d.proj.w" % i], w["val%d.proj.b" % i] = mat(pwp.reshape(Cv, Hh * 64)), vec(p[src + "attn.proj.bias"])
+                w["val%d.fc2.w" % i], w["val%d.fc2.b" % i] = mat(p[src + "mlp.fc2.weight"]), vec(p[src + "mlp.fc2.bias"])
+            else:
+                block("val%d." % i, src)
+            fold("val%d.fc1" % i, p[src + "mlp.fc1.weight"], p[src + "mlp.fc1.bias"], src + "norm2")
         for n, s in (("enc_norm", "dust3r.enc_norm"), ("dec_norm", "dust3r.dec_norm"),
                      ("norm_q", "norm_q"), ("norm_k", "norm_k"), ("norm_v", "norm_v")):
             w[n + ".w"], w[n + ".b"] = vec(p[s + ".weight"]), vec(p[s + ".bias"])
@@ -180,28 +195,34 @@ class Engine:
     # Activations that only feed a GEMM (LayerNorm outputs, attention outputs, GELU outputs) are stored in `adt`
     # (bf16 in bf16 mode: exactly the rounding the MFMA operand conversion would apply on load, at half the traffic);
     # the residual stream, LayerNorm statistics and everything the API returns stay fp32.
-    def _attn_core(self, xp, st, R, B, P, C, heads, pre, pos32, ao, tag=""):
-        """norm1 (folded) + qkv projection with fused bias + 2-D RoPE + per-head V^T store, then softmax(qk^T/8)v
-        (croco/models/blocks.py:94-109, 128).  xp/st: fragment-order copy and row-statistics partials of the stream x."""
+    def _attn_core(self, xp, st, R, B, P, C, heads, pre, pos32, ao, tag="", head_dim=64):
+        """norm1 (folded) + qkv projection with fused bias + 2-D RoPE + per-head V^T store, then softmax(qk^T/sqrt(d))v
+        (croco/models/blocks.py:94-109, 128).  xp/st: fragment-order copy and row-statistics partials of the stream x.
+        The kernels keep 64-wide heads: narrower ones (head_dim < 64: the 16 x 48 heads of the use_feat value encoder) run on
+        weights zero-padded to 64 per head at pack time -- q.k is unchanged by zero columns, the padded v columns come out 0
+        and meet zero columns of the padded output projection; only the softmax scale carries the true head_dim.
+        A = heads * 64 is the width of q / k / v and of `ao`, C the width of the stream."""
         w = self.w
+        A = heads * 64
         npad = (P + 63) // 64 * 64
+        scale = head_dim ** -0.5
         ln = ops.LnFold(st, C, w[pre + "qkv.s"], 1e-6)
         if self.packed_attn:
             # fragment-order q/k (+ PV-order V) straight from the projection epilogue; zero pad rows are never written
-            qkp = self.ws("qkp" + tag, ops.packed_shape(B * npad, 2 * C, self.wdt), self.wdt, zero=True)
+            qkp = self.ws("qkp" + tag, ops.packed_shape(B * npad, 2 * A, self.wdt), self.wdt, zero=True)
             vtp = self.ws("vtp" + tag, (B * heads * npad * 64,), self.wdt, zero=True)
-            ops.proj_rope_vt(xp, w[pre + "qkv.w"], w[pre + "qkv.b"], qkp, 0, vtp, npad, M=R, N=3 * C, K=C, lda=C,
-                             rope_cols=2 * C, pos=pos32, cos=self.cos, sin=self.sin, tokens=P, heads=heads, qkv_packed=True,
+            ops.proj_rope_vt(xp, w[pre + "qkv.w"], w[pre + "qkv.b"], qkp, 0, vtp, npad, M=R, N=3 * A, K=C, lda=C,
+                             rope_cols=2 * A, pos=pos32, cos=self.cos, sin=self.sin, tokens=P, heads=heads, qkv_packed=True,
                              ln=ln)
-            ops.attention_packed(qkp, 2 * C, 0, npad, qkp, 2 * C, C, npad, vtp, ao, C, B=B, heads=heads, Nq=P, Nk=P,
-                                 scale=64 ** -0.5)
+            ops.attention_packed(qkp, 2 * A, 0, npad, qkp, 2 * A, A, npad, vtp, ao, A, B=B, heads=heads, Nq=P, Nk=P,
+                                 scale=scale)
             return
-        qk = self.ws("qk" + tag, (R, 2 * C), self.wdt)
+        qk = self.ws("qk" + tag, (R, 2 * A), self.wdt)
         vt = self.ws("vt" + tag, (B * heads * 64, npad), self.wdt, zero=True)
-        ops.proj_rope_vt(xp, w[pre + "qkv.w"], w[pre + "qkv.b"], qk, 2 * C, vt, npad, M=R, N=3 * C, K=C, lda=C,
-                         rope_cols=2 * C, pos=pos32, cos=self.cos, sin=self.sin, tokens=P, heads=heads, ln=ln)
-        ops.attention(qk, P * 2 * C, 2 * C, qk[:, C:], P * 2 * C, 2 * C, vt, npad, ao, C, B=B, heads=heads, Nq=P, Nk=P,
-                      scale=64 ** -0.5)
+        ops.proj_rope_vt(xp, w[pre + "qkv.w"], w[pre + "qkv.b"], qk, 2 * A, vt, npad, M=R, N=3 * A, K=C, lda=C,
+                         rope_cols=2 * A, pos=pos32, cos=self.cos, sin=self.sin, tokens=P, heads=heads, ln=ln)
+        ops.attention(qk, P * 2 * A, 2 * A, qk[:, A:], P * 2 * A, 2 * A, vt, npad, ao, A, B=B, heads=heads, Nq=P, Nk=P,
+                      scale=scale)
 
     def _norm(self, name):
         return (self.w[name + ".w"], self.w[name + ".b"])
@@ -224,12 +245,13 @@ class Engine:
         ops.gemm(xp, w[pre + "fc1.w"], h, M=R, N=Hd, K=C, lda=C, ldc=Hd, bias=w[pre + "fc1.b"], act=ACT_GELU,
                  ln=ops.LnFold(st, C, w[pre + "fc1.s"], 1e-6))
 
-    def _block(self, x, xpA, stA, xpB, stB, R, B, P, C, heads, pre, pos32, tag="", last=False):
+    def _block(self, x, xpA, stA, xpB, stB, R, B, P, C, heads, pre, pos32, tag="", last=False, head_dim=64):
         """Pre-LN ViT block on the fp32 stream x (croco/models/blocks.py:127-130): 5 launches, no LayerNorm kernel.
         (xpA, stA) describe x on entry and on exit (unless `last`); (xpB, stB) are scratch for the mid-block state."""
-        ao = self.wsp("attn_out" + tag, R, C)
-        self._attn_core(xpA, stA, R, B, P, C, heads, pre, pos32, ao, tag=tag)
-        self._update(ao, pre + "proj", R, C, C, x, x, xpB, stB)
+        A = heads * 64                                  # attention width (= C unless the heads are zero-padded, _attn_core)
+        ao = self.wsp("attn_out" + tag, R, A)
+        self._attn_core(xpA, stA, R, B, P, C, heads, pre, pos32, ao, tag=tag, head_dim=head_dim)
+        self._update(ao, pre + "proj", R, C, A, x, x, xpB, stB)
         Hd = C * self.cfg.mlp_ratio
         h = self.wsp("mlp_hidden" + tag, R, Hd)
         self._mlp_fc1(xpB, stB, R, C, pre, h)
@@ -616,6 +638,27 @@ class Engine:
         raw = self.ws("dpt_raw%d" % num, (B, OH, OW, 4)) if want_raw else None
         ops.head_final(c, w[pre + "h4.w"], w[pre + "h4.b"], B * OH * OW, Lc, pts, conf, raw)
         return pts, conf, raw
+
+    def encode_cur_value_feat(self, tok, out, res):
+        """spann3r/model.py:312-314 (use_feat=True): value_out(value_norm(value_encoder(dec1[-1]))) -- 6 blocks of width 768 with
+        16 heads of 48 (zero-padded to 64, _attn_core) and no RoPE; `res` (feat_k1) is added by the finishing GEMM if given.
+        tok fp32 [B,P,768]."""
+        cfg, w = self.cfg, self.w
+        B, P, Cv = tok.shape
+        assert Cv == cfg.val_dim and not cfg.mem_pos_enc
+        R, E = B * P, cfg.enc_dim
+        zero_pos = self.ws("valf_zero_pos", (R, 2), torch.int32, zero=True)     # rope=None (:232-234): all-zero positions = identity
+        x = self.ws("valf_x", (R, Cv))
+        xpA, xpB = self.wsp("valf_xpA", R, Cv), self.wsp("valf_xpB", R, Cv)
+        stA, stB = self.stats("valf_stA", R, Cv), self.stats("valf_stB", R, Cv)
+        ops.copy2d(tok.reshape(R, Cv), Cv, x, Cv, R, Cv)                       # the stream is updated in place: keep dec1[-1] intact
+        ops.pack_stats(x, xpA, stA, rows=R, C_=Cv)
+        for i in range(cfg.val_depth):
+            self._block(x, xpA, stA, xpB, stB, R, B, P, Cv, cfg.enc_heads, "val%d." % i, zero_pos, tag="_valf",
+                        head_dim=Cv // cfg.enc_heads)
+        ops.gemm(xpA, w["value_out.w"], out, M=R, N=E, K=Cv, lda=Cv, ldc=E, bias=w["value_out.b"], res1=res, ldr1=E,
+                 ln=ops.LnFold(stA, Cv, w["value_out.s"], 1e-6))
+        return out
 
     def encode_cur_value(self, pts3d, out, res):
         """spann3r/model.py:305-320 (use_feat=False): pos_patch_embed(pts3d as a 3-channel image) -> 6 blocks without

@@ -7,6 +7,7 @@ but is a static-capacity device arena with LayerNorm applied once at write time.
 All arithmetic runs in the HIP kernels of libspann3r_hip.so; there is no CPU / eager-torch path.
 """
 import argparse
+import collections
 import os
 import weakref
 
@@ -435,7 +436,8 @@ class _SequenceRunner:
         self.v = torch.empty(B, self.P, self.E, device=dev)
         self.mem = None
         self.k2_aux = (None, None)
-        self.graphs = {}
+        self.graphs = collections.OrderedDict()        # key -> (hipGraph, device bytes its capture allocated), least recently used first
+        self.graph_bytes = 0
         self.seen = set()
         self.out = None
         self.batched = False          # True: the frames of the sequence were encoded up front (encode_sequence)
@@ -450,6 +452,7 @@ class _SequenceRunner:
         if self.mem is None or self.mem.cap < need:
             self.mem = SpatialMemory(self.eng, self.B, self.P, capacity=need, attn_thresh=0.0 if self.training else 5e-4)
             self.graphs.clear()
+            self.graph_bytes = 0
             self.seen.clear()
         self.mem.reset()
         return self.mem
@@ -467,7 +470,7 @@ class _SequenceRunner:
             self.img_all = torch.empty(n * B, 3, self.H, self.W, device=self.eng.device)
             self.feats = torch.empty(n * B, self.P, self.E, device=self.eng.device)
             # every graph that baked in the old buffers dies with them: the encoder's AND the deferred head's (reads feats)
-            self.graphs = {k: g for k, g in self.graphs.items() if k[0] not in ("enc", "head2")}
+            self._drop_graphs(lambda k: k[0] in ("enc", "head2"))
             self.seen = {k for k in self.seen if k[0] not in ("enc", "head2")}
         slots = [(f["img"], self.img_all[i * B:(i + 1) * B]) for i, f in enumerate(frames)]
         fast = [p for p in slots if p[0].is_cuda and p[0].dtype == torch.float32 and p[0].is_contiguous() and p[0].shape == p[1].shape]
@@ -494,7 +497,7 @@ class _SequenceRunner:
         D = self.model.cfg.dec_dim
         if self.seq_dec2 is None or self.seq_dec2[0].shape[0] < rows:
             self.seq_dec2 = [torch.empty(rows, D, device=self.eng.device) for _ in range(3)]
-            self.graphs = {k: g for k, g in self.graphs.items() if k[0] != "head2"}
+            self._drop_graphs(lambda k: k[0] == "head2")
             self.seen = {k for k in self.seen if k[0] != "head2"}
         self.defer2 = True
 
@@ -536,18 +539,37 @@ class _SequenceRunner:
     def load_pair(self, i):
         ops.copy_multi([self.pair_copy(i)])
 
+    def _drop_graphs(self, pred):
+        for k in [k for k in self.graphs if pred(k)]:
+            self.graph_bytes -= self.graphs.pop(k)[1]
+
+    MAX_GRAPHS = 256                     # per geometry: a 50-frame growing-bank sequence uses ~100 (one per bank length and step kind)
+    MAX_GRAPH_BYTES = 1 << 30            # device memory the captures of one geometry may pin in their pool
+
     def _graphed(self, key, fn, use_graphs):
-        """eager the first time a key is seen (creates the workspaces), captured the second time, replayed afterwards"""
+        """eager the first time a key is seen (creates the workspaces), captured the second time, replayed afterwards.
+        The captured graphs are an LRU bounded in count and in the device bytes their captures allocated (all captures of a
+        runner share one memory pool); an evicted key is simply captured again when it comes back."""
         if not use_graphs:
             fn()
         elif key in self.graphs:
-            self.graphs[key].replay()
+            self.graphs.move_to_end(key)
+            self.graphs[key][0].replay()
         elif key in self.seen:
             torch.cuda.synchronize()
+            if getattr(self, "_pool", None) is None:
+                self._pool = torch.cuda.graph_pool_handle()
+            before = torch.cuda.memory_allocated()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, pool=self._pool):
                 fn()
-            self.graphs[key] = g
+            nbytes = max(0, torch.cuda.memory_allocated() - before)
+            self.graphs[key] = (g, nbytes)
+            self.graph_bytes += nbytes
+            while len(self.graphs) > self.MAX_GRAPHS or (self.graph_bytes > self.MAX_GRAPH_BYTES and len(self.graphs) > 1):
+                _, (old, ob) = self.graphs.popitem(last=False)
+                self.graph_bytes -= ob
+                del old
             g.replay()
         else:
             self.seen.add(key)
@@ -614,7 +636,10 @@ class _SequenceRunner:
                 pts2, conf2, _ = eng.dpt_head(dec2, B, self.hh, self.hw, 2)
         pts1, conf1, _ = eng.dpt_head(dec1, B, self.hh, self.hw, 1)
         # portrait results are handed on axis-swapped (landscape_only wrapper); the value encoder sees that view
-        eng.encode_cur_value(pts1.swapaxes(1, 2) if self.swap else pts1, self.v, self.k1)   # v = cur_v + feat_k1
+        if eng.cfg.use_feat:                    # spann3r/model.py:312-314: the value comes from dec1[-1], not from the pointmap
+            eng.encode_cur_value_feat(dec1[-1], self.v, self.k1)
+        else:
+            eng.encode_cur_value(pts1.swapaxes(1, 2) if self.swap else pts1, self.v, self.k1)   # v = cur_v + feat_k1
         mem.stage_write(self.k1, self.v)
         if not self.defer2:
             main.wait_stream(st[2])
@@ -664,9 +689,10 @@ class Spann3R(nn.Module):
                  use_feat=False, mem_pos_enc=False, memory_dropout=0.15, cfg: Spann3RConfig = None,
                  init_weights=True):
         super().__init__()
-        if use_feat:
-            raise NotImplementedError("use_feat=True (value encoder on 768-d decoder features, 48-d heads) is not on the "
-                                      "hot path the MI355X build covers; demo/eval/app all use use_feat=False")
+        if use_feat and mem_pos_enc:
+            raise NotImplementedError("use_feat=True together with mem_pos_enc=True (RoPE on 48-wide heads inside the value encoder) "
+                                      "is not built: the attention kernels keep 64-wide heads (48-wide ones run zero-padded, which "
+                                      "the rotary pairing does not survive); each option alone is supported")
         self.use_feat = use_feat
         self.mem_pos_enc = mem_pos_enc
         # spann3r/model.py:248: only its .training flag and p matter for the forward-only build
@@ -682,9 +708,9 @@ class Spann3R(nn.Module):
             ckpt = torch.load(dus3r_name, map_location="cpu", weights_only=True)
             cfg = Spann3RConfig.from_ctor_string(ckpt["args"].model)
         self.cfg = cfg or FULL
-        if mem_pos_enc != self.cfg.mem_pos_enc:
+        if mem_pos_enc != self.cfg.mem_pos_enc or use_feat != self.cfg.use_feat:
             import dataclasses
-            self.cfg = dataclasses.replace(self.cfg, mem_pos_enc=bool(mem_pos_enc))
+            self.cfg = dataclasses.replace(self.cfg, mem_pos_enc=bool(mem_pos_enc), use_feat=bool(use_feat))
         self.add_module("dust3r", _Dust3RFacade(self))       # the parameter tree below hangs the DUSt3R weights into it
         self._params = _build_param_tree(self, param_spec(self.cfg))
         # no network: without a checkpoint file the weights are seeded synthetic ones
@@ -709,8 +735,9 @@ class Spann3R(nn.Module):
                     if k in own:
                         own[k].copy_(v)
                 # spann3r/model.py:241-242: pos_patch_embed starts as a copy of the DUSt3R patch embed
-                self._params["pos_patch_embed.proj.weight"].copy_(self._params["dust3r.patch_embed.proj.weight"])
-                self._params["pos_patch_embed.proj.bias"].copy_(self._params["dust3r.patch_embed.proj.bias"])
+                if not self.cfg.use_feat:
+                    self._params["pos_patch_embed.proj.weight"].copy_(self._params["dust3r.patch_embed.proj.weight"])
+                    self._params["pos_patch_embed.proj.bias"].copy_(self._params["dust3r.patch_embed.proj.bias"])
         self.precision = "fp32"
         self._engine = None
         self._engine_key = None
@@ -827,6 +854,10 @@ class Spann3R(nn.Module):
         return res
 
     def encode_cur_value(self, res1, dec1, pos1, shape1, add=None):         # :312-320
+        if self.cfg.use_feat:                                               # :313-314: value from the last decoder output
+            tok = dec1[-1]
+            out = torch.empty(tok.shape[0], tok.shape[1], self.cfg.enc_dim, device=tok.device)
+            return self.engine.encode_cur_value_feat(tok, out, add)
         pts = res1["pts3d"]
         B = pts.shape[0]
         P = (pts.shape[1] // self.cfg.patch) * (pts.shape[2] // self.cfg.patch)

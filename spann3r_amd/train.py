@@ -638,12 +638,15 @@ def encode_feat_key(feat, dec_last, P, num):
     return linear(_Gelu.apply(linear(x, P[p + "0.weight"], P[p + "0.bias"])), P[p + "2.weight"], P[p + "2.bias"])
 
 
-def encode_cur_value(pts3d, feat_k, P, cfg):
-    """spann3r/model.py:305-320 (use_feat=False) -> cur_v + feat_k (the sum add_mem stores, :519)"""
-    x, nh, nw = _patchify(pts3d.permute(0, 3, 1, 2), cfg.patch)
-    W = P["pos_patch_embed.proj.weight"]
-    x = linear(x, W.reshape(W.shape[0], -1), P["pos_patch_embed.proj.bias"], wkey=(id(W), "patch", W._version))
-    pos = _positions(pts3d.shape[0], nh, nw, pts3d.device)
+def encode_cur_value(pts3d, feat_k, P, cfg, dec_last=None, pos1=None):
+    """spann3r/model.py:305-320 -> cur_v + feat_k (the sum add_mem stores, :519); use_feat: the value encoder runs on dec1[-1]"""
+    if cfg.use_feat:
+        x, pos = dec_last, pos1
+    else:
+        x, nh, nw = _patchify(pts3d.permute(0, 3, 1, 2), cfg.patch)
+        W = P["pos_patch_embed.proj.weight"]
+        x = linear(x, W.reshape(W.shape[0], -1), P["pos_patch_embed.proj.bias"], wkey=(id(W), "patch", W._version))
+        pos = _positions(pts3d.shape[0], nh, nw, pts3d.device)
     for i in range(cfg.val_depth):
         x = block(x, pos, P, "value_encoder.%d." % i, cfg.enc_heads, cfg.rope_base, use_rope=cfg.mem_pos_enc)
     x = layer_norm(x, P["value_norm.weight"], P["value_norm.bias"], 1e-6)
@@ -687,7 +690,7 @@ def forward_train(P, frames, cfg, dropout_p=0.0, generator=None):
         feat_k2 = encode_feat_key(feat2, dec2[-1], P, 2)
         pts1, conf1 = dpt_head(dec1, grid[0], grid[1], P, cfg, 1)
         pts2, conf2 = dpt_head(dec2, grid[0], grid[1], P, cfg, 2)
-        v = encode_cur_value(pts1, feat_k1, P, cfg)
+        v = encode_cur_value(pts1, feat_k1, P, cfg, dec1[-1], pos1)
         mem_k = feat_k1 if mem_k is None else torch.cat((mem_k, feat_k1), 1)
         mem_v = v if mem_v is None else torch.cat((mem_v, v), 1)
         res2 = {"pts3d_in_other_view": pts2, "conf": conf2}

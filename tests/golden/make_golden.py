@@ -17,6 +17,8 @@ What is dumped (SURVEY.md §8c "recommended dumps"):
                       subsampled outputs, per-step feat_fuse / feat_k / cur_v, final mem_attn / mem_count
   spann3r_cfg3_512x13.npz  24/12 model, 13 frames of 512x512, train memory policy with dropout off (BASELINE config 3,
                       growing bank: 11 reads, bank up to 11264 tokens), same dumps
+  spann3r_cfg3_512x50.npz  the same at the benched length of config 3 (50 frames, last read over 49152 bank tokens): the frames
+                      and steps around T = 24 and T = 48, the final mem_attn / mem_count (`cfg3long`)
   crop_plan.npz       the reference's OWN BaseStereoViewDataset._crop_resize_if_necessary (base_stereo_view_dataset.py:
                       140-194) + cropping.py:54-121 run on 12 input shapes (cv2 / torchvision, absent from the image and
                       unused by these functions' image path, are stubbed): every crop box, the resize target and the
@@ -42,16 +44,16 @@ torch.serialization.add_safe_globals([argparse.Namespace])
 
 from spann3r_amd.config import TINY, FULL  # noqa: E402
 from spann3r_amd.weights import (synth_state_dict, synth_frames, state_dict_fingerprint,  # noqa: E402
-                                 hash_uniform, _stream_id)
+                                 hash_uniform, _stream_id, stress_state_dict)
 
 
-def build_reference(cfg, sd, tag, mem_pos_enc=False):
+def build_reference(cfg, sd, tag, mem_pos_enc=False, use_feat=False):
     """Instantiate the reference through its real loader (dust3r/model.py:27-51)."""
     from spann3r.model import Spann3R
     path = "/tmp/golden_dust3r_%s.pth" % tag
     torch.save({"args": argparse.Namespace(model=cfg.ctor_string()),
                 "model": {k[len("dust3r."):]: v for k, v in sd.items() if k.startswith("dust3r.")}}, path)
-    m = Spann3R(dus3r_name=path, use_feat=False, mem_pos_enc=mem_pos_enc)
+    m = Spann3R(dus3r_name=path, use_feat=use_feat, mem_pos_enc=mem_pos_enc)
     missing = m.load_state_dict(sd, strict=True)
     print(missing)
     os.remove(path)
@@ -177,6 +179,31 @@ def make_tiny():
     print("tiny: %d arrays" % len(out))
 
 
+def make_usefeat():
+    """Spann3R(use_feat=True) (spann3r/model.py:225,312-314: the value encoder works on dec1[-1]: 768-wide blocks, 16 heads of 48,
+    no pos_patch_embed) on the tiny depths, 4 frames of 64x80, eval policy and the growing-bank policy: predictions, memory values"""
+    import dataclasses
+    cfg = dataclasses.replace(TINY, use_feat=True)
+    H, W, NF = 64, 80, 4
+    sd = synth_state_dict(0, cfg)
+    frames = synth_frames(NF, H, W, batch=2, seed=41)
+    out = {"meta_hw": np.array([H, W]), "meta_frames": np.array(NF), "meta_seed": np.array(41), "meta_batch": np.array(2),
+           "fingerprint": np.array(state_dict_fingerprint(sd))}
+    m = build_reference(cfg, sd, "usefeat", use_feat=True)
+    for tag, train in (("eval", False), ("train", True)):
+        if train:
+            m.train()
+            m.mem_dropout.eval()
+        with torch.no_grad():
+            preds, preds_all, sp = m(frames, return_memory=True)
+        for j, p in enumerate(preds):
+            out["%s_pred%d_pts" % (tag, j)] = npf(p["pts3d" if j == 0 else "pts3d_in_other_view"])
+            out["%s_pred%d_conf" % (tag, j)] = npf(p["conf"])
+        out[tag + "_mem_v"], out[tag + "_mem_k"] = npf(sp.mem_v), npf(sp.mem_k)
+    np.savez_compressed(os.path.join(HERE, "spann3r_usefeat.npz"), **out)
+    print("usefeat: %d arrays" % len(out))
+
+
 def make_full():
     cfg, H, W, NF = FULL, 224, 224, 5
     sd = synth_state_dict(0, cfg)
@@ -190,7 +217,11 @@ def make_full():
            "fingerprint": np.array(state_dict_fingerprint(sd)), "ref_seconds": np.array(dt),
            "ref_threads": np.array(torch.get_num_threads())}
     S = 4
+    if keep is not None:                  # long sequences: only the listed frames / steps are dumped (keeps the file small)
+        out["meta_keep"] = np.array(sorted(keep))
     for j, p in enumerate(preds):
+        if keep is not None and j not in keep:
+            continue
         pts = p["pts3d" if j == 0 else "pts3d_in_other_view"]
         out["pred%d_pts_sub" % j] = npf(pts[:, ::S, ::S])
         out["pred%d_conf_sub" % j] = npf(p["conf"][:, ::S, ::S])
@@ -208,10 +239,12 @@ def make_full():
     print("full224: %d arrays" % len(out))
 
 
-def make_sequence_fixture(name, H, W, NF, train_policy, S):
+def make_sequence_fixture(name, H, W, NF, train_policy, S, keep=None, stress=False):
     """A whole benched configuration: outputs subsampled by S pixels, token tensors by (7, 16)."""
     cfg = FULL
     sd = synth_state_dict(0, cfg)
+    if stress:                            # trained-like statistics (spann3r_amd.weights.stress_state_dict)
+        sd = stress_state_dict(7, cfg)
     m = build_reference(cfg, sd, name)
     if train_policy:                      # SURVEY.md Appendix A.6: growing bank, deterministic
         m.train()
@@ -224,16 +257,24 @@ def make_sequence_fixture(name, H, W, NF, train_policy, S):
     out = {"meta_hw": np.array([H, W]), "meta_frames": np.array(NF), "meta_seed": np.array(0), "meta_sub": np.array(S),
            "meta_train_policy": np.array(int(train_policy)), "fingerprint": np.array(state_dict_fingerprint(sd)),
            "ref_seconds": np.array(dt), "ref_threads": np.array(torch.get_num_threads())}
+    if keep is not None:                  # long sequences: only the listed frames / steps are dumped (keeps the file small)
+        out["meta_keep"] = np.array(sorted(keep))
     for j, p in enumerate(preds):
+        if keep is not None and j not in keep:
+            continue
         pts = p["pts3d" if j == 0 else "pts3d_in_other_view"]
         out["pred%d_pts_sub" % j] = npf(pts[:, ::S, ::S])
         out["pred%d_conf_sub" % j] = npf(p["conf"][:, ::S, ::S])
         out["pred%d_stats" % j] = np.array([float(pts.double().mean()), float(pts.double().abs().mean()),
                                             float(p["conf"].double().mean())])
     for i, (r1, r2) in enumerate(preds_all):      # the view-2 result of every step (only the last one is in preds)
+        if keep is not None and i not in keep:
+            continue
         out["step%d_pts2_sub" % i] = npf(r2["pts3d_in_other_view"][:, ::S, ::S])
         out["step%d_conf2_sub" % i] = npf(r2["conf"][:, ::S, ::S])
     for i, s in enumerate(steps):
+        if keep is not None and i not in keep:
+            continue
         for k in ("feat_fuse", "feat_k1", "feat_k2", "cur_v"):
             out["s%d_%s_sub" % (i, k)] = npf(s[k][:, ::7, ::16])
     out["mem_k_sub"], out["mem_v_sub"] = npf(sp.mem_k[:, ::7, ::16]), npf(sp.mem_v[:, ::7, ::16])
@@ -390,6 +431,55 @@ def make_postprocess():
     np.savez_compressed(os.path.join(HERE, "postprocess.npz"), **out)
 
 
+def make_traingrad():
+    """f1 at FULL geometry: one training step of the UNMODIFIED reference in float64 -- Spann3R.forward in train mode (memory
+    dropout 0 so that the step is deterministic), spann3r/loss.py ConfLoss_t(Regr3D_t(L21, avg_dis), 0.4).compute_frame_loss,
+    (loss + factor).backward() -- on the 24/12-layer model and 3 frames of 64x80, batch 2.  Dumped: loss, factor and, for every
+    parameter tensor, max |grad| plus a strided sample of its gradient (<= 256 elements): the device step is compared against
+    the reference itself at full depth and width (the tiny-geometry test compares all 724 tensors against the oracle)."""
+    from spann3r.loss import Regr3D_t, ConfLoss_t
+    from dust3r.losses import L21
+    cfg, H, W, NF, B = FULL, 64, 80, 3, 2
+    sd = synth_state_dict(0, cfg)
+    m = build_reference(cfg, sd, "traingrad").double()
+    m.train()
+    m.mem_dropout.p = 0.0
+    frames = synth_frames(NF, H, W, batch=B, seed=77)
+    g = torch.Generator().manual_seed(78)
+    views = []
+    for i, f in enumerate(frames):
+        Q, _ = torch.linalg.qr(torch.randn(B, 3, 3, generator=g))
+        pose = torch.eye(4).repeat(B, 1, 1)
+        pose[:, :3, :3] = Q
+        pose[:, :3, 3] = torch.randn(B, 3, generator=g) * 0.3
+        views.append(dict(img=f["img"].double(), true_shape=torch.tensor([[H, W]] * B, dtype=torch.int32),
+                          pts3d=(torch.randn(B, H, W, 3, generator=g) + torch.tensor([0.0, 0.0, 3.0])).double(),
+                          valid_mask=torch.rand(B, H, W, generator=g) < 0.85, camera_pose=pose.double()))
+    t = time.time()
+    preds, preds_all = m(views)
+    crit = ConfLoss_t(Regr3D_t(L21, norm_mode="avg_dis", fix_first=False), alpha=0.4)
+    loss, details, factor = crit.compute_frame_loss(views, preds_all)
+    (loss + factor).backward()
+    print("traingrad: reference float64 step %.1f s, loss %.6f factor %.6f" % (time.time() - t, float(loss), float(factor)))
+    out = {"meta": np.array([H, W, NF, B, 77, 78]), "loss": np.float64(float(loss)), "factor": np.float64(float(factor)),
+           "fingerprint": np.array(state_dict_fingerprint(sd))}
+    for k in ("pts3d", "valid_mask", "camera_pose"):
+        out["gt_" + k] = np.stack([v[k].numpy() for v in views])
+    names = []
+    for name, p in m.named_parameters():
+        if p.grad is None:
+            continue
+        gflat = p.grad.reshape(-1)
+        step = max(1, gflat.numel() // 256)
+        names.append(name)
+        out["g_" + name + "_max"] = np.float64(float(gflat.abs().max()))
+        out["g_" + name + "_sample"] = gflat[::step][:256].numpy().astype(np.float64)
+        out["g_" + name + "_step"] = np.int64(step)
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "train_grad_full.npz"), **out)
+    print("train_grad_full.npz: %d parameter gradients" % len(names))
+
+
 def make_crop():
     """f3 pin: the crop / resize plan of the reference's own functions.  `cropping.py` imports cv2 (used only for the depth map,
     cropping.py:73-75) and `dust3r.utils.image` imports torchvision (ImgNorm); neither is installed here and neither touches the
@@ -464,6 +554,10 @@ if __name__ == "__main__":
     what = sys.argv[1:] or ["tiny", "full", "memory"]
     if "crop" in what:
         make_crop()
+    if "usefeat" in what:
+        make_usefeat()
+    if "traingrad" in what:
+        make_traingrad()
     if "postprocess" in what:
         make_postprocess()
     if "loss" in what:
@@ -482,3 +576,10 @@ if __name__ == "__main__":
         make_sequence_fixture("spann3r_cfg2_224x10", 224, 224, 10, False, 4)
     if "cfg3" in what:
         make_sequence_fixture("spann3r_cfg3_512x13", 512, 512, 13, True, 8)
+    if "stress" in what:
+        # trained-like weight statistics through the reference: the parity claim of the fast fp32 mode (f32x3) is tested here
+        make_sequence_fixture("spann3r_stress_224x6", 224, 224, 6, False, 4, stress=True)
+    if "cfg3long" in what:
+        # BASELINE config 3 at its benched length: 50 frames, bank up to 49152 tokens at the last read (split-K 16 plan);
+        # frames / steps around T = 24 and T = 48 and the final state are kept
+        make_sequence_fixture("spann3r_cfg3_512x50", 512, 512, 50, True, 8, keep={0, 23, 24, 25, 46, 47, 48, 49})

@@ -103,8 +103,12 @@ def test_constructor_from_reference_checkpoint(tiny_sd):
     assert Spann3RConfig.from_ctor_string(TINY.ctor_string("PatchEmbedDust3R")) == TINY
     with pytest.raises(ValueError):
         Spann3RConfig.from_ctor_string("AsymmetricCroCo3DStereo(enc_embed_dim=768, dec_depth=12)")
-    with pytest.raises(NotImplementedError):
-        Spann3R(dus3r_name=None, use_feat=True)
+    with pytest.raises(NotImplementedError):                  # the one unsupported combination (RoPE on zero-padded 48-wide heads)
+        Spann3R(dus3r_name=None, cfg=TINY, use_feat=True, mem_pos_enc=True, init_weights=False)
+    uf = Spann3R(dus3r_name=None, cfg=TINY, use_feat=True, init_weights=False)       # spann3r/model.py:225,239: 768-wide value encoder
+    keys = set(uf.state_dict().keys())
+    assert "pos_patch_embed.proj.weight" not in keys and tuple(uf.state_dict()["value_out.weight"].shape) == (1024, 768)
+    assert tuple(uf.state_dict()["value_encoder.5.mlp.fc1.weight"].shape) == (3072, 768)
     with pytest.raises(FileNotFoundError):                    # a mistyped path must not silently build synthetic weights
         Spann3R(dus3r_name="/nonexistent/DUSt3R.pth")
 

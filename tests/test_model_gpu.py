@@ -124,6 +124,40 @@ def test_tiny_mem_pos_enc_vs_golden(tiny_sd, precision, tol):
         assert rel_err(mem.mem_v.cpu(), g["mpe_mem_v"]) < tol
 
 
+@pytest.mark.parametrize("precision,tol", [("fp32", TOL_FP32), ("bf16", TOL_BF16)])
+def test_tiny_use_feat_vs_golden(precision, tol):
+    """Spann3R(use_feat=True) (spann3r/model.py:225,312-314: value encoder on dec1[-1], 768-wide blocks with 16 heads of 48 -- run
+    zero-padded to the kernels' 64-wide heads -- and no pos_patch_embed) against the reference dump, eval and growing-bank policy"""
+    import dataclasses
+    from spann3r_amd import Spann3R, TINY
+    from spann3r_amd.weights import synth_frames, synth_state_dict, state_dict_fingerprint
+    g = load_golden("spann3r_usefeat.npz")
+    cfg = dataclasses.replace(TINY, use_feat=True)
+    sd = synth_state_dict(0, cfg)
+    assert state_dict_fingerprint(sd) == float(g["fingerprint"]) and "pos_patch_embed.proj.weight" not in sd
+    assert tuple(sd["value_encoder.0.attn.qkv.weight"].shape) == (3 * 768, 768)
+    H, W = map(int, g["meta_hw"])
+    m = Spann3R(dus3r_name=None, cfg=TINY, init_weights=False, use_feat=True)
+    assert set(m.state_dict().keys()) == set(sd.keys())
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV).eval().set_precision(precision)
+    frames = to_dev(synth_frames(int(g["meta_frames"]), H, W, batch=int(g["meta_batch"]), seed=int(g["meta_seed"])))
+    for tag in ("eval", "train"):
+        if tag == "train":
+            m.train()
+            m.mem_dropout.eval()
+        preds, _, mem = m(frames, return_memory=True)
+        worst = 0.0
+        for j, p in enumerate(preds):
+            worst = max(worst, rel_err(p["pts3d" if j == 0 else "pts3d_in_other_view"].cpu(), g["%s_pred%d_pts" % (tag, j)]),
+                        rel_err(p["conf"].cpu(), g["%s_pred%d_conf" % (tag, j)]))
+        assert worst < tol, (tag, worst)
+        if precision == "fp32":
+            assert rel_err(mem.mem_v.cpu(), g[tag + "_mem_v"]) < tol
+    with pytest.raises(NotImplementedError):
+        Spann3R(dus3r_name=None, cfg=TINY, init_weights=False, use_feat=True, mem_pos_enc=True)
+
+
 def test_graph_replay_equals_eager(tiny_model):
     """1st call of a geometry runs eagerly, 2nd captures + replays hipGraphs, 3rd replays: all bit-identical,
     and identical to use_graphs=False (same kernels, same order)."""
@@ -433,14 +467,22 @@ def _run_sequence_fixture(name, full_sd, precision):
     finally:
         _SequenceRunner.run = orig
     err = {"pts": 0.0, "conf": 0.0, "pts2": 0.0, "fuse": 0.0, "k": 0.0}
+    keep = set(g["meta_keep"].tolist()) if "meta_keep" in g.files else None       # long fixtures hold a subset of frames / steps
+    kept = lambda i: keep is None or i in keep
     for j, p in enumerate(preds):
+        if not kept(j):
+            continue
         pts = p["pts3d" if j == 0 else "pts3d_in_other_view"]
         err["pts"] = max(err["pts"], rel_err(pts[:, ::S, ::S].cpu(), g["pred%d_pts_sub" % j]))
         err["conf"] = max(err["conf"], rel_err(p["conf"][:, ::S, ::S].cpu(), g["pred%d_conf_sub" % j]))
     for i, (_, r2) in enumerate(preds_all):
+        if not kept(i):
+            continue
         err["pts2"] = max(err["pts2"], rel_err(r2["pts3d_in_other_view"][:, ::S, ::S].cpu(), g["step%d_pts2_sub" % i]),
                           rel_err(r2["conf"][:, ::S, ::S].cpu(), g["step%d_conf2_sub" % i]))
     for i, t in enumerate(taps):
+        if not kept(i):
+            continue
         if i > 0:                            # step 0 has no memory read (feat_fuse = feat1)
             err["fuse"] = max(err["fuse"], rel_err(t["fuse"], g["s%d_feat_fuse_sub" % i]))
         err["k"] = max(err["k"], rel_err(t["k1"], g["s%d_feat_k1_sub" % i]), rel_err(t["k2"], g["s%d_feat_k2_sub" % i]))
@@ -464,6 +506,32 @@ def test_cfg3_512x13_vs_reference(full_sd, precision, tol):
     """BASELINE config 3: 512x512, growing bank (train policy, dropout off), 13 frames = 11 memory reads over up to
     11264 bank tokens, against the reference dump."""
     err = _run_sequence_fixture("spann3r_cfg3_512x13.npz", full_sd, precision)
+    assert max(err.values()) < tol, err
+
+
+@pytest.mark.parametrize("precision,tol", [("f32x3", TOL_FP32), ("bf16", TOL_BF16)])
+def test_cfg3_512x50_vs_reference(full_sd, precision, tol):
+    """BASELINE config 3 at its BENCHED length: 50 frames of 512x512, growing bank -- the reads at T = 24 / 48 run the split-K 8 / 16
+    plans of the long-bank path (up to 49152 bank tokens x 1024 queries) that the 13-frame fixture never reaches; frames and steps
+    around them, the last frame and the final mem_attn / mem_count against the reference dump."""
+    import os
+    if not os.path.exists(os.path.join(os.path.dirname(__file__), "golden", "spann3r_cfg3_512x50.npz")):
+        pytest.skip("fixture not generated (tests/golden/make_golden.py cfg3long)")
+    err = _run_sequence_fixture("spann3r_cfg3_512x50.npz", full_sd, precision)
+    assert max(err.values()) < tol, err
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", TOL_FP32), ("f32x3", 5e-4), ("bf16", 6e-2)])
+def test_stress_weights_224x6_vs_reference(precision, tol):
+    """The parity claim of the fast fp32 mode on TRAINED-LIKE statistics (spann3r_amd.weights.stress_state_dict: per-channel weight
+    scales spanning 100x, LayerNorm gains 0.25..4, massive-activation channels of +-40 in the residual streams, near-one-hot memory
+    softmax), 6 frames of 224x224 through the unmodified reference: f32x3 (three bf16 MFMAs per product) must stay within 5e-4."""
+    import os
+    if not os.path.exists(os.path.join(os.path.dirname(__file__), "golden", "spann3r_stress_224x6.npz")):
+        pytest.skip("fixture not generated (tests/golden/make_golden.py stress)")
+    from spann3r_amd.config import FULL
+    from spann3r_amd.weights import stress_state_dict
+    err = _run_sequence_fixture("spann3r_stress_224x6.npz", stress_state_dict(7, FULL), precision)
     assert max(err.values()) < tol, err
 
 

@@ -176,3 +176,21 @@ def test_offline_reconstruction(tiny_sd):
         assert rel_err(p["conf"], g["pred%d_conf" % j]) < TOL
     for i, (_, r2) in enumerate(preds_all):
         assert rel_err(r2["conf"], g["step%d_conf2" % i]) < TOL
+
+
+def test_tiny_use_feat():
+    """oracle with cfg.use_feat (value encoder on dec1[-1], 16 heads of 48) against the reference dump of Spann3R(use_feat=True)"""
+    import dataclasses
+    from spann3r_amd.weights import synth_state_dict
+    g = load_golden("spann3r_usefeat.npz")
+    cfg = dataclasses.replace(TINY, use_feat=True)
+    sd = synth_state_dict(0, cfg)
+    assert state_dict_fingerprint(sd) == float(g["fingerprint"])
+    H, W = map(int, g["meta_hw"])
+    frames = synth_frames(int(g["meta_frames"]), H, W, batch=int(g["meta_batch"]), seed=int(g["meta_seed"]))
+    for tag, tp in (("eval", False), ("train", True)):
+        preds, _, mem = O.forward(frames, sd, cfg, training_policy=tp, return_memory=True)
+        for j, p in enumerate(preds):
+            assert rel_err(p["pts3d" if j == 0 else "pts3d_in_other_view"], g["%s_pred%d_pts" % (tag, j)]) < TOL
+            assert rel_err(p["conf"], g["%s_pred%d_conf" % (tag, j)]) < TOL
+        assert rel_err(mem.mem_v, g[tag + "_mem_v"]) < TOL

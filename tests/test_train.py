@@ -474,3 +474,60 @@ def test_train_step_hip_graph_replay_matches_eager(tiny_sd):
     assert all(map(lambda t: t[0] == t[0] and t[1] > 0, traj[True][0]))
     assert abs(traj[True][0][1][0] - traj[True][0][2][0]) > 0            # different batches -> different losses: inputs are refreshed
     assert not torch.equal(traj[True][1], tiny_sd["dust3r.dec_blocks.1.attn.qkv.weight"].cuda())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("bf16", 6e-2)])
+def test_full_geometry_gradients_vs_reference_step(full_sd, precision, tol):
+    """BASELINE config 5's step at FULL depth and width (24 encoder / 12 decoder layers, ViT-L / ViT-B / DPT) against ONE TRAINING
+    STEP OF THE UNMODIFIED REFERENCE run in float64 (tests/golden/make_golden.py traingrad: Spann3R.forward in train mode +
+    spann3r/loss.py ConfLoss_t + backward): the loss and a strided sample of EVERY parameter gradient (~1090 tensors).
+    fp32 mode: each tensor within 1e-4 of the reference (scaled by the tensor's own maximum, floored at 1e-4 of the global one);
+    bf16 mode: global relative L2 error of the sampled gradients within 6e-2 (measured 3e-2: operand rounding of ~80 chained GEMMs)."""
+    import numpy as np
+    from spann3r_amd import train as T, FULL
+    from spann3r_amd.loss import ConfLoss_t, Regr3D_t, L21
+    from spann3r_amd.weights import synth_frames, state_dict_fingerprint, alias_of
+    path = os.path.join(os.path.dirname(__file__), "golden", "train_grad_full.npz")
+    if not os.path.exists(path):
+        pytest.skip("fixture not generated (tests/golden/make_golden.py traingrad)")
+    g = np.load(path)
+    assert state_dict_fingerprint(full_sd) == float(g["fingerprint"])
+    H, W, NF, B, fseed, _ = (int(v) for v in g["meta"])
+    frames = [{"img": f["img"].cuda()} for f in synth_frames(NF, H, W, batch=B, seed=fseed)]
+    gts = [dict(pts3d=torch.from_numpy(g["gt_pts3d"][i]).float().cuda(), valid_mask=torch.from_numpy(g["gt_valid_mask"][i]).cuda(),
+                camera_pose=torch.from_numpy(g["gt_camera_pose"][i]).float().cuda()) for i in range(NF)]
+    P = {k: v.float().cuda().requires_grad_(True) for k, v in full_sd.items() if v.is_floating_point()}
+    T.set_precision(precision)
+    try:
+        preds, preds_all = T.forward_train(P, frames, FULL, dropout_p=0.0)
+        loss, details, factor = ConfLoss_t(Regr3D_t(L21, norm_mode="avg_dis", fix_first=False), alpha=0.4).compute_frame_loss(gts, preds_all)
+        (loss + factor).backward()
+    finally:
+        T.set_precision("fp32")
+        T.invalidate_weight_cache()
+    ref_total = float(g["loss"]) + float(g["factor"])
+    assert abs(float(loss) + float(factor) - ref_total) < (1e-4 if precision == "fp32" else 5e-3) * abs(ref_total)
+    names = [str(n) for n in g["names"]]
+    gmax = max(float(g["g_" + n + "_max"]) for n in names)
+    worst, num, den = (0.0, None), 0.0, 0.0
+    for n in names:
+        p = P.get(n)
+        if p is None or p.grad is None:
+            other = [k for k in P if alias_of(k) == n or alias_of(n) == k]
+            p = next((P[k] for k in other if P[k].grad is not None), None)
+        assert p is not None and p.grad is not None, n
+        step = int(g["g_" + n + "_step"])
+        mine = p.grad.reshape(-1)[::step][:256].double().cpu().numpy()
+        ref = g["g_" + n + "_sample"]
+        d = np.abs(mine - ref)
+        e = float(d.max()) / max(float(g["g_" + n + "_max"]), 1e-4 * gmax)
+        num, den = num + float((d ** 2).sum()), den + float((ref ** 2).sum())
+        worst = max(worst, (e, n))
+    print("full-geometry step (%s): loss %.6f (reference %.6f), %d gradient tensors sampled, worst scaled error %.2e (%s), global rel. L2 %.2e"
+          % (precision, float(loss) + float(factor), ref_total, len(names), worst[0], worst[1], (num / den) ** 0.5))
+    assert len(names) > 1000
+    if precision == "fp32":
+        assert worst[0] < tol, worst
+    else:
+        assert (num / den) ** 0.5 < tol
