@@ -274,6 +274,10 @@ typedef struct sp3_bank_write_desc {
 int sp3_bank_write(const sp3_bank_write_desc* desc_host, void* stream);
 int sp3_softmax_thresh(const float* S, float* P, int64_t ld, int64_t strideS, int rows, int M, int Mpad,
                        float thresh, int batch, void* P_packed, int64_t stride_packed, int packed_bf16, void* stream);
+/* the packed-only form of sp3_softmax_thresh for long banks, two streaming launches (row statistics; then one contiguous kilobyte of
+ * fragment-order probabilities per wave store): same arithmetic with v_exp_f32; rowstat_ws: batch * rows * 4 floats */
+int sp3_softmax_pack(const float* S, int64_t ld, int64_t strideS, int rows, int M, float thresh, int batch, void* P_packed,
+                     int64_t stride_packed, int packed_bf16, float* rowstat_ws, void* stream);
 int sp3_colsum_accum(const float* P, int64_t ld, int rows, int M, float* mem_attn, void* stream);
 int sp3_colsum_packed(const void* P_packed, int packed_bf16, int rows, int M, float* mem_attn, void* stream);
 /* the column sums of the two-launch read (sp3_gemm, loader SP3_LOAD_SOFTMAX): mem_attn[j] += sum_r [p >= thresh] p / Z'_r,

@@ -1251,7 +1251,7 @@ void gemm_kernel(const GemmArgs args) {
   if constexpr (LDSK && (NT % (BN / 4)) == 0) {
     constexpr int CG = BN / 4, RSTEP = NT / CG, ITER = (BM + RSTEP - 1) / RSTEP;
     // (the pipelined tiles walk up to 16 row steps per thread: residual rows are requested 4 steps at a time)
-    if (d.epi == SP3_EPI_PLAIN && (d.N & 3) == 0 && (ITER <= 4 || LOOP == -1)) {
+    if (d.epi == SP3_EPI_PLAIN && (d.N & 3) == 0 && (ITER <= 4 || LOOP == -1) && !d.sm_stats_out) {
       const int c4 = ec4, gn = n0 + c4, row0 = tid / CG;
       if (gn < d.N) {
         const float4 b4 = pre_b4, s4 = pre_s4;            // (N % 4 == 0: the group is whole, epre held)
@@ -1602,13 +1602,15 @@ int dispatch_tile(const sp3_gemm_desc& d, int tile, hipStream_t stream) {
       }
       sp3_set_error("sp3_gemm: tile %d needs bf16 A and the plain loader", tile);
       return 1;
-    case 20: case 21: case 22: case 23:               // pipelined LDS-staged operands (many-row GEMMs)
+    case 20: case 21: case 22: case 23: case 24: case 25:   // pipelined LDS-staged operands (many-row GEMMs; 24 / 25: the memory read)
       if constexpr (sizeof(TA) == sizeof(TW) && LOADER == SP3_LOAD_PLAIN) {
         if (d.a_packed && d.w_packed && !d.A2 && d.K % MM<TA, TW>::KB == 0) {
           switch (tile) {
             case 20: return launch<TA, TW, LOADER, 4, 4, 4, 2, 1, 3, -1>(d, stream);   // 256x128, 4x2 waves of 64x64, 3 slots
             case 21: return launch<TA, TW, LOADER, 4, 4, 2, 2, 2, 4, -1>(d, stream);   // 128x128, 2x2 waves of 64x64 x 2 K halves, 4 slots
             case 22: return launch<TA, TW, LOADER, 4, 4, 2, 1, 2, 3, -1>(d, stream);   // 128x64,  2x1 waves of 64x64 x 2 K halves
+            case 24: return launch<TA, TW, LOADER, 4, 2, 1, 1, 2, 4, -1>(d, stream);   // 64x32,   1 wave pair, 4 slots (score GEMM of the read)
+            case 25: return launch<TA, TW, LOADER, 2, 2, 1, 1, 2, 4, -1>(d, stream);   // 32x32,   1 wave pair, 4 slots
             default: return launch<TA, TW, LOADER, 4, 4, 1, 1, 2, 4, -1>(d, stream);   // 64x64,   1 wave pair (2 K halves), 4 slots
           }
         }
@@ -1765,7 +1767,7 @@ static int gemm_prepare(sp3_gemm_desc& d, int& tile_out) {
       (void)t64;
     }
   }
-  SP3_CHECK(!d.sm_stats_out || tile <= 3, "sp3_gemm: sm_stats_out needs a register-ring tile (0-3)");
+  SP3_CHECK(!d.sm_stats_out || tile <= 3 || tile >= 20, "sp3_gemm: sm_stats_out needs a register-ring tile (0-3) or a pipelined one (20-25)");
   tile_out = tile;
   return 0;
 }

@@ -90,6 +90,89 @@ __global__ __launch_bounds__(256) void softmax_thresh_kernel(const float* __rest
   }
 }
 
+// ---- long banks: the probabilities of a read as the P.V GEMM's fragment-order operand, in two streaming launches.
+// softmax_thresh_kernel above walks a row three to four times with libm expf and scatters 16-byte pieces 256 bytes apart; at
+// 1024 queries x 50176 bank tokens that was 342 us, the largest launch of the read.  Here: (1) one workgroup per row reduces
+// (max, 1 / sum exp, 1 / kept mass) with float4 loads and v_exp_f32; (2) a workgroup owns two 2 KB fragment blocks (16 rows x
+// one k-block each): a thread reads the 32 bytes of scores behind its 16-byte piece, and a wave stores ONE CONTIGUOUS KILOBYTE.
+__global__ __launch_bounds__(256) void softmax_rowstat_kernel(const float* __restrict__ S, int64_t ld, int64_t strideS, int rows, int M, float thresh,
+                                                              float4* __restrict__ rowstat) {
+  __shared__ float sh[8];
+  const float* s = S + (int64_t)blockIdx.y * strideS + (int64_t)blockIdx.x * ld;
+  const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(S) & 15) == 0) && ((strideS & 3) == 0);
+  const int M4 = vec ? (M & ~3) : 0;
+  float mx = -INFINITY, sum = 0.f;
+  auto upd = [&](float v) {
+    if (v > mx) { sum = sum * __expf(mx - v) + 1.0f; mx = v; }
+    else sum += __expf(v - mx);
+  };
+  for (int j = threadIdx.x * 4; j < M4; j += 1024) {
+    const float4 v = *reinterpret_cast<const float4*>(s + j);
+    const float m4 = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+    if (m4 > mx) { sum *= __expf(mx - m4); mx = m4; }                // (first element: 0 * exp(-inf) = 0)
+    sum += (__expf(v.x - mx) + __expf(v.y - mx)) + (__expf(v.z - mx) + __expf(v.w - mx));
+  }
+  for (int j = M4 + threadIdx.x; j < M; j += 256) upd(s[j]);
+  const float gmx = block_reduce_max(mx, sh);
+  sum = block_reduce_sum(mx == -INFINITY ? 0.f : sum * __expf(mx - gmx), sh);
+  const float inv = 1.0f / sum;
+  float rk = 1.0f;
+  if (thresh > 0.f) {
+    float kept = 0.f;
+    for (int j = threadIdx.x * 4; j < M4; j += 1024) {
+      const float4 v = *reinterpret_cast<const float4*>(s + j);
+      const float p[4] = {__expf(v.x - gmx) * inv, __expf(v.y - gmx) * inv, __expf(v.z - gmx) * inv, __expf(v.w - gmx) * inv};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) kept += p[e] < thresh ? 0.f : p[e];
+    }
+    for (int j = M4 + threadIdx.x; j < M; j += 256) { const float p = __expf(s[j] - gmx) * inv; kept += p < thresh ? 0.f : p; }
+    rk = 1.0f / block_reduce_sum(kept, sh);
+  }
+  if (threadIdx.x == 0) rowstat[(int64_t)blockIdx.y * rows + blockIdx.x] = make_float4(gmx, inv, rk, 0.f);
+}
+
+template <typename TP>
+__global__ __launch_bounds__(256) void softmax_pack_kernel(const float* __restrict__ S, int64_t ld, int64_t strideS, int rows, int M, int Kp,
+                                                           float thresh, const float4* __restrict__ rowstat, TP* __restrict__ Pk,
+                                                           int64_t stridePk) {
+  constexpr int E = 16 / (int)sizeof(TP), KB = 8 * E;
+  const int t = threadIdx.x & 127, kb = blockIdx.x * 2 + (threadIdx.x >> 7), nkb = Kp / KB;
+  if (kb >= nkb) return;
+  const int h = t >> 6, g = (t >> 4) & 3, r = t & 15;
+  const int row = blockIdx.y * 16 + r;
+  const int k0 = kb * KB + g * 2 * E + h * E;
+  float p[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) p[e] = 0.f;
+  if (row < rows && k0 < M) {
+    const float* s = S + (int64_t)blockIdx.z * strideS + (int64_t)row * ld + k0;
+    const float4 st = rowstat[(int64_t)blockIdx.z * rows + row];
+    float v[E];
+    if (k0 + E <= M && ((reinterpret_cast<uintptr_t>(s) & 15) == 0)) {
+#pragma unroll
+      for (int q = 0; q < E / 4; ++q) {
+        const float4 x = reinterpret_cast<const float4*>(s)[q];
+        v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < E; ++e) v[e] = (k0 + e) < M ? s[e] : -INFINITY;
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      float q = __expf(v[e] - st.x) * st.y;
+      if (thresh > 0.f) q = (q < thresh ? 0.f : q) * st.z;
+      p[e] = (k0 + e) < M ? q : 0.f;
+    }
+  }
+  TP o[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) o[e] = (TP)p[e];
+  typedef __attribute__((ext_vector_type(4))) unsigned int u4;
+  TP* dst = Pk + (int64_t)blockIdx.z * stridePk + (((int64_t)blockIdx.y * nkb + kb) * 128 + t) * E;
+  *reinterpret_cast<u4*>(dst) = *reinterpret_cast<const u4*>(o);
+}
+
 // mem_attn[j] += sum_r P[r, j] from the fragment-order probabilities [rows, Kp]: one workgroup per 64-column k-block
 // walks the row blocks (2 KB each, contiguous), every thread keeps the partial sums of its 16 bytes, the 16 rows x 2
 // halves of a column meet in LDS in a fixed order (one writer per column: deterministic, no atomics).
@@ -491,6 +574,23 @@ extern "C" int sp3_softmax_thresh(const float* S, float* P, int64_t ld, int64_t 
                        reinterpret_cast<float*>(P_packed), Kp, stride_packed);
   }
   SP3_LAUNCH_CHECK("sp3_softmax_thresh");
+  return 0;
+}
+
+extern "C" int sp3_softmax_pack(const float* S, int64_t ld, int64_t strideS, int rows, int M, float thresh, int batch, void* P_packed,
+                                int64_t stride_packed, int packed_bf16, float* rowstat_ws, void* stream) {
+  SP3_CHECK(S && P_packed && rowstat_ws && rows > 0 && M > 0 && ld >= M && batch > 0, "sp3_softmax_pack: bad arguments");
+  SP3_CHECK((reinterpret_cast<uintptr_t>(P_packed) & 15) == 0 && (reinterpret_cast<uintptr_t>(rowstat_ws) & 15) == 0 && rows <= 65535 * 16,
+            "sp3_softmax_pack: P_packed / rowstat_ws must be 16-byte aligned");
+  float4* rs = reinterpret_cast<float4*>(rowstat_ws);
+  hipLaunchKernelGGL(softmax_rowstat_kernel, dim3(rows, batch), dim3(256), 0, ST(stream), S, ld, strideS, rows, M, thresh, rs);
+  const int KB = packed_bf16 ? 64 : 32, Kp = (M + KB - 1) / KB * KB, nkb = Kp / KB, nrb = (rows + 15) / 16;
+  const dim3 grid((nkb + 1) / 2, nrb, batch);
+  if (packed_bf16) hipLaunchKernelGGL(softmax_pack_kernel<__bf16>, grid, dim3(256), 0, ST(stream), S, ld, strideS, rows, M, Kp, thresh, rs,
+                                      reinterpret_cast<__bf16*>(P_packed), stride_packed);
+  else hipLaunchKernelGGL(softmax_pack_kernel<float>, grid, dim3(256), 0, ST(stream), S, ld, strideS, rows, M, Kp, thresh, rs,
+                          reinterpret_cast<float*>(P_packed), stride_packed);
+  SP3_LAUNCH_CHECK("sp3_softmax_pack");
   return 0;
 }
 

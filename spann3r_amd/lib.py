@@ -93,6 +93,8 @@ _PROTOS = {
                              C.c_void_p],
     "sp3_softmax_thresh": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float,
                            C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p],
+    "sp3_softmax_pack": [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,
+                         C.c_void_p],
     "sp3_colsum_packed": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
     "sp3_colsum_softmax": [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p],
     "sp3_bank_write": [C.POINTER(BankWriteDesc), C.c_void_p],

@@ -226,8 +226,8 @@ class SpatialMemory:
                 self._flush_attn()
         else:
             pk = eng.ws("mem_P_packed", (B, Pp * self.cap), eng.adt, zero=True)
-            ops.softmax_thresh(S, None, ld=ld, rows=P, M=M, Mpad=M, thresh=self.attn_thresh, batch=B, strideS=P * ld,
-                               packed=pk, stride_packed=pk.shape[1])
+            ops.softmax_pack(S, pk, eng.ws("mem_rowstat", (B * P * 4,)), ld=ld, rows=P, M=M, thresh=self.attn_thresh, batch=B, strideS=P * ld,
+                             stride_packed=pk.shape[1])
             for b in range(B):
                 A = ops.PackedAct(P, Kp, eng.adt, eng.device, data=pk[b])
                 Wv = ops.PackedWeight.wrap(bk["v_hat_t"][b], C, self.cap)

@@ -104,7 +104,7 @@ def set_profiler(p):
 _TILE_NAMES = {0: "32x32xk4", 1: "64x64", 2: "64x128", 3: "64x64xk4", 4: "32x64xk4", 18: "16x64xk4", 5: "128x128lds", 6: "128x64lds", 7: "112x64lds",
                8: "208x64lds", 9: "112x32lds", 10: "112x64lds2w", 11: "112x64lds8w", 12: "208x64lds8w", 13: "112x64wreg8",
                14: "112x64wreg4", 15: "208x64wreg8", 16: "112x64wreg4l6", 17: "112x64wreg8l4",
-               20: "256x128pipe", 21: "128x128pipe", 22: "128x64pipe", 23: "64x64pipe"}
+               20: "256x128pipe", 21: "128x128pipe", 22: "128x64pipe", 23: "64x64pipe", 24: "64x32pipe", 25: "32x32pipe"}
 
 
 def pick_tile(M, N, batch=1, splitk=1, conv=False, K=0, packed_bf16=False, plain=False, ln_nt=0, pipe_ok=False):
@@ -596,6 +596,14 @@ def softmax_thresh(S, P, *, ld, rows, M, Mpad, thresh, batch=1, strideS=0, packe
     _timed("softmax_thresh", 8.0 * batch * rows * M, (4.0 + (0.0 if P is None else 4.0) + (0.0 if packed is None else packed.element_size())) * batch * rows * M,
            lambda: L.check(L.load().sp3_softmax_thresh(S.data_ptr(), L.ptr(P), ld, strideS, rows, M, Mpad, float(thresh),
                                                        batch, L.ptr(packed), stride_packed, int(pbf), L.stream_ptr()), "sp3_softmax_thresh"))
+
+
+def softmax_pack(S, packed, rowstat, *, ld, rows, M, thresh, batch=1, strideS=0, stride_packed=0):
+    """long banks: rows of S -> thresholded, renormalised probabilities as the P.V GEMM's fragment-order operand (two streaming
+    launches, sp3_softmax_pack); rowstat: fp32 [batch * rows * 4] workspace"""
+    _timed("softmax_pack", 8.0 * batch * rows * M, (4.0 + packed.element_size()) * batch * rows * M,
+           lambda: L.check(L.load().sp3_softmax_pack(S.data_ptr(), ld, strideS, rows, M, float(thresh), batch, packed.data_ptr(), stride_packed,
+                                                     int(packed.dtype == torch.bfloat16), rowstat.data_ptr(), L.stream_ptr()), "sp3_softmax_pack"))
 
 
 def colsum_accum(P, ld, rows, M, mem_attn):

@@ -219,10 +219,10 @@ def synth_state_dict(seed: int = 0, cfg: Spann3RConfig = FULL, dtype=torch.float
 def stress_state_dict(seed: int = 7, cfg: Spann3RConfig = FULL):
     """`synth_state_dict` reshaped towards the statistics of a TRAINED checkpoint, the regime the fast parity mode (f32x3) has
     to survive (random-init weights have a tiny dynamic range): per-output-channel scales of every Linear spanning
-    100x (10^-1 .. 10^1, log-uniform; attention / MLP output projections 10^-1 .. 10^0.5 so the residual stream stays
-    finite), LayerNorm gains spanning 0.25 .. 4 with non-zero shifts, a few massive-activation channels in the residual streams
+    two decades (1/11 .. 11, ~log-uniform; attention / MLP output projections 1/8 .. 3 so the residual stream stays finite),
+    LayerNorm gains spanning 0.25 .. 4 with non-zero shifts, a few massive-activation channels in the residual streams
     (patch-embed / decoder-embed biases of +-40 on 4 channels, as trained ViTs have), and 3x sharper memory logits (norm_q /
-    norm_k gains x sqrt(3)) so that the spatial-memory softmax is close to one-hot.  Integer-hash streams only: every platform
+    norm_k gains x 1.75) so that the spatial-memory softmax is close to one-hot.  Integer-hash streams only: every platform
     regenerates the same bits."""
     sd = synth_state_dict(seed, cfg)
     out = OrderedDict()
@@ -233,19 +233,26 @@ def stress_state_dict(seed: int = 7, cfg: Spann3RConfig = FULL):
             continue
         t = t.clone()
         u = lambda n, tag: torch.from_numpy(hash_uniform(n, _stream_id(seed, key + "#" + tag)))      # in [-1, 1)
+
+        def logscale(n, tag, lo, hi):
+            """~log-uniform factors in [2^lo, 2^hi) from IEEE mul / add / ldexp only (libm's pow differs in the last bit between
+            CPUs, and the fixtures must regenerate bit for bit): (1 + frac) * 2^floor of a uniform exponent"""
+            x = (u(n, tag) + 1.0) * (0.5 * (hi - lo)) + lo
+            e = torch.floor(x)
+            return torch.ldexp(1.0 + (x - e), e.to(torch.int32))
         is_lin = key.endswith(".weight") and t.dim() == 2
         if ".dpt.head.4." in key:
             # the raw pointmap norm r goes through expm1: keep r ~ 1..3 as trained checkpoints do (depths of metres, not of 10^4:
             # at r ~ 10 a 1e-4 error of r alone is a 1e-3 error of the pointmap, whatever the kernels do)
             t *= 0.25
         elif is_lin and any(k in key for k in ("attn.proj", "mlp.fc2", "cross_attn.proj")):
-            t *= torch.pow(10.0, 0.75 * u(t.shape[0], "rows") - 0.25)[:, None]          # 10^-1 .. 10^0.5
+            t *= logscale(t.shape[0], "rows", -3.0, 1.5)[:, None]                       # 1/8 .. ~3
         elif is_lin:
-            t *= torch.pow(10.0, u(t.shape[0], "rows"))[:, None]                         # 10^-1 .. 10^1
+            t *= logscale(t.shape[0], "rows", -3.5, 3.5)[:, None]                       # 1/11 .. 11: two decades
         elif key.endswith(".weight") and t.dim() == 1 and ("norm" in key):
-            t = t * torch.pow(4.0, u(t.shape[0], "gain"))
+            t = t * logscale(t.shape[0], "gain", -2.0, 2.0)                              # 0.25 .. 4
             if key.startswith("norm_q.") or key.startswith("norm_k."):
-                t = t * 3.0 ** 0.5
+                t = t * 1.75                                                             # ~3x sharper memory logits
         elif key.endswith(".bias") and "norm" in key:
             t = t + 0.5 * u(t.shape[0], "shift")
         elif key in ("dust3r.patch_embed.proj.bias", "dust3r.decoder_embed.bias", "pos_patch_embed.proj.bias"):

@@ -601,6 +601,16 @@ def test_softmax_thresh_and_colsum(thresh, pdt):
                        packed=pk2, stride_packed=rp * Kp)
     d2 = ops.PackedAct(rows, Kp, pdt, DEV, data=pk2[0].view(ops.packed_shape(rows, Kp, pdt))).to_dense()
     assert torch.equal(d2, dense[0])
+    # the streaming two-launch form the long-bank read uses (sp3_softmax_pack): same probabilities (v_exp_f32 instead of libm
+    # expf: a last-bit difference before the bf16 rounding; entries at the threshold may flip), pad rows AND pads written as zeros
+    pk3 = torch.full((B, rp * Kp), float("nan"), device=DEV, dtype=pdt)
+    ops.softmax_pack(S.to(DEV), pk3, torch.empty(B * rows * 4, device=DEV), ld=ld, rows=rows, M=M, thresh=thresh, batch=B, strideS=rows * ld,
+                     stride_packed=rp * Kp)
+    assert not torch.isnan(pk3.float()).any()
+    for b_ in range(B):
+        d3 = ops.PackedAct(rows, Kp, pdt, DEV, data=pk3[b_].view(ops.packed_shape(rows, Kp, pdt))).to_dense()
+        assert float((d3.double() - dense[b_].double()).abs().sum(-1).max()) < (5e-3 if pdt == torch.bfloat16 else 1e-4)
+        assert float(d3[:, M:].float().abs().max()) == 0.0
     a = torch.softmax(S[..., :M].double(), -1)
     if thresh > 0:
         a32 = torch.softmax(S[..., :M], -1)

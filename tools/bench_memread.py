@@ -31,17 +31,29 @@ def main():
     out = torch.zeros(P, C, device=dev); attn = torch.zeros(cap, device=dev)
     pk = torch.zeros(((P + 15) // 16 * 16) * Kp, device=dev, dtype=wdt)
     ln = ops.LnFold(qs, C, s_bank, 1e-5)
+    part = torch.zeros(16 * P * C, device=dev)
+    rowstat = torch.zeros(P * 4, device=dev)
+    long_bank = M > 8192
     steps = {
         "S gemm": lambda b: ops.gemm(qp, ops.PackedWeight.wrap(b[0].data, M, C), S, M=P, N=M, K=C, lda=C, ldc=cap, alpha=1 / 32., bias=b_bank, ln=ln),
         "S gemm + stats": lambda b: ops.gemm(qp, ops.PackedWeight.wrap(b[0].data, M, C), S, M=P, N=M, K=C, lda=C, ldc=cap, alpha=1 / 32., bias=b_bank, ln=ln, sm_stats_out=st),
+        **{"S gemm + stats, tile %d" % t: (lambda b, t=t: ops.gemm(qp, ops.PackedWeight.wrap(b[0].data, M, C), S, M=P, N=M, K=C, lda=C, ldc=cap, alpha=1 / 32., bias=b_bank, ln=ln, sm_stats_out=st, tile=t)) for t in (22, 23, 24, 25)},
+        **{"PV gemm (packed P), tile %d" % t: (lambda b, t=t: ops.gemm(ops.PackedAct(P, Kp, wdt, dev, data=pk), ops.PackedWeight.wrap(b[1].data, C, cap), out, M=P, N=C, K=Kp, lda=Kp, ldc=C, ldw=cap, res1=q, ldr1=C, tile=t)) for t in (23, 24, 25)},
+        "softmax_pack (2 launches)": lambda b: ops.softmax_pack(S, pk, rowstat, ld=cap, rows=P, M=M, thresh=5e-4, batch=1, strideS=P * cap, stride_packed=pk.numel()),
         "softmax_thresh": lambda b: ops.softmax_thresh(S, None, ld=cap, rows=P, M=M, Mpad=M, thresh=5e-4, batch=1, strideS=P * cap, packed=pk, stride_packed=pk.numel()),
         "PV gemm (packed P)": lambda b: ops.gemm(ops.PackedAct(P, Kp, wdt, dev, data=pk), ops.PackedWeight.wrap(b[1].data, C, cap), out, M=P, N=C, K=Kp, lda=Kp, ldc=C, ldw=cap, res1=q, ldr1=C),
         "colsum_packed": lambda b: ops.colsum_packed(pk, P, M, attn),
+        "PV gemm (packed P, split-K 16 partials)": lambda b: ops.gemm(ops.PackedAct(P, Kp, wdt, dev, data=pk), ops.PackedWeight.wrap(b[1].data, C, cap), part, M=P, N=C, K=Kp, lda=Kp, ldc=C, ldw=cap, splitk=16),
+        "reduce (16 partials + q)": lambda b: ops.reduce_ln(part, 16, P, C, res=q, ldres=C, x_out=out, ldx=C),
         "PV gemm (softmax loader)": lambda b: ops.gemm(S, ops.PackedWeight.wrap(b[1].data, C, cap), out, M=P, N=C, K=M, lda=cap, ldc=C, ldw=cap, res1=q, ldr1=C, softmax=(st, 5e-4, zk)),
         "PV gemm (softmax loader, 32x32)": lambda b: ops.gemm(S, ops.PackedWeight.wrap(b[1].data, C, cap), out, M=P, N=C, K=M, lda=cap, ldc=C, ldw=cap, res1=q, ldr1=C, softmax=(st, 5e-4, zk), tile=1),
         "colsum_softmax": lambda b: ops.colsum_softmax(S, cap, P, M, zk, 5e-4, attn),
     }
     for name, fn in steps.items():
+        if long_bank and ("tile 2" in name or "softmax loader" in name or "stats" in name or name == "colsum_softmax" or name == "PV gemm (packed P)"):
+            continue                                   # long banks run: S gemm, softmax_thresh, split-K PV, reduce, colsum_packed
+        if not long_bank and ("split-K" in name or "reduce" in name):
+            continue
         for b in banks[:3]: fn(b)
         torch.cuda.synchronize()
         gr = torch.cuda.CUDAGraph()

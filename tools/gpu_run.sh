@@ -34,6 +34,7 @@ for stage in "$@"; do
     trainprof)  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/tprof" -o run -- python "$OLDPWD/tools/train_step_time.py" --precision bf16 --steps 2 > "$OLDPWD/$OUT/trainprof.log" 2>&1); DB=$(find "$OUT/tprof" -name "*results.db" | head -1); python tools/rocpd_stats.py "$DB" > "$OUT/trainprof_stats.md" 2>&1; rm -rf "$OUT/tprof"; head -45 "$OUT/trainprof_stats.md" | cut -c1-200 ;;
     traintests) timeout 1500 python -m pytest tests/test_train.py tests/test_loss.py -x -q -m gpu -s > "$OUT/traintests.txt" 2>&1; grep -v "^$" "$OUT/traintests.txt" | tail -25 ;;
     memread)    timeout 600 python tools/bench_memread.py > "$OUT/memread.txt" 2>&1; tail -30 "$OUT/memread.txt" ;;
+    memreadlong) timeout 600 python tools/bench_memread.py --tokens 50176 --rows 1024 --copies 3 > "$OUT/memread_long.txt" 2>&1; tail -30 "$OUT/memread_long.txt" ;;
     *)          echo "unknown stage $stage" ;;
   esac
 done
