@@ -30,7 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 METRIC = "frames/sec/GPU (224px, 10-frame seq) + mem-bank cross-attn HBM GB/s"
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "f32x3": 2500.0 / 3}       # dense MFMA peaks, MI355X_MICROARCH.md (f32x3: 3 bf16 MFMAs per product)
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "f32x3": 2500.0 / 3, "f32x6": 2500.0 / 6}       # dense MFMA peaks, MI355X_MICROARCH.md (f32x3 / f32x6: 3 / 6 bf16 MFMAs per product)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -51,7 +51,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "f32x3"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "f32x3", "f32x6"])
     ap.add_argument("--frames", type=int, default=10)
     ap.add_argument("--size", type=int, default=224)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -454,6 +454,12 @@ def main():
                         "what": "same workload, fp32 operands with every GEMM product through three bf16 MFMAs of a (hi, lo) split (16 "
                                 "mantissa bits per product, fp32 accumulate): the fast parity mode, held to the same <=1e-3 vs the "
                                 "reference as fp32 (tests/test_model_gpu.py)"}
+        model.set_precision("f32x6")
+        x6_frames, x6_s = time_sequences(model, seqs, 6, 3)
+        out["f32x6"] = {"value": x6_frames / x6_s, "unit": "frames/s", "steps": 6,
+                        "what": "same workload, fp32 operands, every GEMM product through SIX bf16 MFMAs of a three-way (h, m, l) split: 24 operand "
+                                "bits, fp32-grade products, fp32 accumulate; exact-fp32 attention.  The fast parity mode that also holds 1e-3 on "
+                                "trained-like weight statistics (stress fixture), where f32x3 measures 1.4e-3"}
         model.set_precision("bf16")
         # how the same GPU fills with more independent work per launch: 4 sequences batched into one forward (B = 4).
         # NOT the headline configuration (BASELINE config 2 is batch 1): reported next to it.

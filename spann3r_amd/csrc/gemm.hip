@@ -224,6 +224,41 @@ template <> struct MM<float, float> {
       }
     }
   }
+  // f32x3 = 3 ("f32x6"): a THREE-way bf16 split x = h + m + l (24 mantissa bits: the whole fp32 significand) and the six products
+  // down to 2^-16 of the leading one (hh, hm, mh, mm, hl, lh; the dropped ml, lm, ll are <= 2^-24): fp32-grade products at 6 bf16 MFMAs
+  // per k-block instead of 8 fp32 ones at 1/16 of the rate each.  The two-way split of mode 1 keeps 16 operand bits, which is not
+  // enough once the residual stream carries massive-activation channels: the LayerNorm fold subtracts rstd * mean * s from a GEMM
+  // whose terms are 40x larger than the result (tests/test_model_gpu.py stress fixture: 1.4e-3 with x3, fp32-level with x6).
+  static __device__ __forceinline__ void split8x3(const float4& x0, const float4& x1, bf16x8& h, bf16x8& m, bf16x8& l) {
+    const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const __bf16 hh = (__bf16)x[e];
+      const float r1 = x[e] - (float)hh;
+      const __bf16 mm = (__bf16)r1;
+      h[e] = hh; m[e] = mm; l[e] = (__bf16)(r1 - (float)mm);
+    }
+  }
+  template <int MF, int NF>
+  static __device__ __forceinline__ void mma_x6(f32x4 (&acc)[MF][NF], const AReg (&a)[MF], const WReg (&w)[NF]) {
+    bf16x8 wh[NF], wm[NF], wl[NF];
+#pragma unroll
+    for (int n = 0; n < NF; ++n) split8x3(w[n].v[0], w[n].v[1], wh[n], wm[n], wl[n]);
+#pragma unroll
+    for (int m = 0; m < MF; ++m) {
+      bf16x8 ah, am, al;
+      split8x3(a[m].v[0], a[m].v[1], ah, am, al);
+#pragma unroll
+      for (int n = 0; n < NF; ++n) {                    // smallest terms first
+        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, wh[n], acc[m][n], 0, 0, 0);
+        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wl[n], acc[m][n], 0, 0, 0);
+        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, wm[n], acc[m][n], 0, 0, 0);
+        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, wh[n], acc[m][n], 0, 0, 0);
+        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wm[n], acc[m][n], 0, 0, 0);
+        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, wh[n], acc[m][n], 0, 0, 0);
+      }
+    }
+  }
   // f32x3 = 2 ("bf16 products"): fp32 operands in memory, rounded to bf16 on their way into ONE v_mfma_f32_16x16x32_bf16 per
   // k-block, fp32 accumulate -- the arithmetic of a bf16-autocast matmul on fp32 master tensors (training step, bf16 mode)
   template <int MF, int NF>
@@ -400,7 +435,10 @@ __device__ __forceinline__ void static_for(F&& f) {
 constexpr int kWRing = 12;
 constexpr int kMaxKb = 64;                 // k-blocks per K slice the role loop is unrolled for (K / splitk <= 4096 in bf16)
 
-template <typename TA, typename TW, int LOADER, int MF, int NF, int WM, int WN, int WK, int STAGES, int LOOP = 0>
+// XM (fp32 operands, register-ring tiles): how a k-block's products are formed -- 0: fp32 MFMAs; 1 / 3: three / six bf16 MFMAs of a
+// two- / three-way split (f32x3 / f32x6); 2: one bf16 MFMA of the rounded operands.  A compile-time choice: as a run-time branch the
+// six-product code cost every mode its second wave per SIMD (187 -> 209 registers).
+template <typename TA, typename TW, int LOADER, int MF, int NF, int WM, int WN, int WK, int STAGES, int LOOP = 0, int XM = 0>
 __global__ __launch_bounds__(64 * (WM * WN * WK + (LOOP >= 2 ? LOOP : 0)), (gemm_min_waves<TA, LOADER, MF, NF, WK>()))
 void gemm_kernel(const GemmArgs args) {
   // local copy: grouped launches shift the per-problem pointers below (kernarg segment, wave-uniform select)
@@ -527,7 +565,6 @@ void gemm_kernel(const GemmArgs args) {
   const int kb_lo = kz * per;
   const int kb_hi = (kb_lo + per) < nkb_all ? (kb_lo + per) : nkb_all;
   const bool relu = d.relu_in != 0;
-  const int xmode = d.f32x3;                 // 1: three bf16 MFMAs per product, 2: one (fp32 operands only; register-ring tiles)
 
   typename M_::AReg a[STAGES][MF];
   typename M_::WReg w[STAGES][NF];
@@ -586,11 +623,13 @@ void gemm_kernel(const GemmArgs args) {
 #pragma unroll
       for (int n = 0; n < NF; ++n) M_::fixW(w[st][n], wm0[st], wm1[st]);
     }
-    if constexpr (sizeof(TA) == 4 && sizeof(TW) == 4 && MF * NF <= 8) {      // (the 4x4-fragment fp32 tile has no registers to spare)
-      if (xmode == 1) { M_::template mma_x3<MF, NF>(acc, a[st], w[st]); return; }
-      if (xmode == 2) { M_::template mma_x1<MF, NF>(acc, a[st], w[st]); return; }
+    if constexpr (sizeof(TA) == 4 && sizeof(TW) == 4 && XM != 0) {
+      if constexpr (XM == 1) M_::template mma_x3<MF, NF>(acc, a[st], w[st]);
+      else if constexpr (XM == 2) M_::template mma_x1<MF, NF>(acc, a[st], w[st]);
+      else M_::template mma_x6<MF, NF>(acc, a[st], w[st]);
+    } else {
+      M_::template mma<MF, NF>(acc, a[st], w[st]);
     }
-    M_::template mma<MF, NF>(acc, a[st], w[st]);
   };
   using FullT = std::integral_constant<bool, true>;
   using TailT = std::integral_constant<bool, false>;
@@ -1547,7 +1586,7 @@ void gemm_kernel(const GemmArgs args) {
 // sp3_gemm2: the second group of problems of the launch being dispatched (same kernel instance), or null
 thread_local const sp3_gemm_desc* g_pair = nullptr;
 
-template <typename TA, typename TW, int LOADER, int MF, int NF, int WM, int WN, int WK, int STAGES, int LOOP = 0>
+template <typename TA, typename TW, int LOADER, int MF, int NF, int WM, int WN, int WK, int STAGES, int LOOP = 0, int XM = 0>
 int launch(const sp3_gemm_desc& d, hipStream_t stream) {
   constexpr bool LDSK = LOOP != 0;
   constexpr int BM = MF * 16 * WM, BN = NF * 16 * WN, NT = 64 * (WM * WN * WK + (LOOP >= 2 ? LOOP : 0));
@@ -1561,7 +1600,7 @@ int launch(const sp3_gemm_desc& d, hipStream_t stream) {
     const size_t stages = (size_t)STAGES * (BM / 16 + (LOOP >= 2 ? 0 : BN / 16)) * 2048;      // the epilogue slab aliases the ring
     lds = lds > stages ? lds : stages;
   }
-  auto kern = gemm_kernel<TA, TW, LOADER, MF, NF, WM, WN, WK, STAGES, LOOP>;
+  auto kern = gemm_kernel<TA, TW, LOADER, MF, NF, WM, WN, WK, STAGES, LOOP, XM>;
   if (lds > 64 * 1024) {
     static bool raised = false;     // one-time opt-in to > 64 KiB of dynamic LDS for this instantiation
     if (!raised) {
@@ -1590,6 +1629,22 @@ int launch(const sp3_gemm_desc& d, hipStream_t stream) {
 
 template <typename TA, typename TW, int LOADER>
 int dispatch_tile(const sp3_gemm_desc& d, int tile, hipStream_t stream) {
+  if constexpr (sizeof(TA) == 4 && sizeof(TW) == 4) {
+    // fp32 operands on the register-ring tiles 0-2: the product mode (sp3_gemm_desc.f32x3) selects the kernel instance
+    const int xm = d.f32x3;
+    if (xm >= 1 && xm <= 3 && tile >= 0 && tile <= 2) {
+#define SP3_XM_TILES(XM_)                                                                         \
+      switch (tile) {                                                                             \
+        case 0: return launch<TA, TW, LOADER, 2, 2, 1, 1, 4, 3, 0, XM_>(d, stream);               \
+        case 1: return launch<TA, TW, LOADER, 2, 2, 2, 2, 1, 2, 0, XM_>(d, stream);               \
+        default: return launch<TA, TW, LOADER, 2, 4, 2, 2, 1, 2, 0, XM_>(d, stream);              \
+      }
+      if (xm == 1) { SP3_XM_TILES(1) }
+      if (xm == 2) { SP3_XM_TILES(2) }
+      SP3_XM_TILES(3)
+#undef SP3_XM_TILES
+    }
+  }
   switch (tile) {
     case 0: return launch<TA, TW, LOADER, 2, 2, 1, 1, 4, 3>(d, stream);   // 32x32, K over 4 waves
     case 1: return launch<TA, TW, LOADER, 2, 2, 2, 2, 1, 2>(d, stream);   // 64x64, wave tile 32x32

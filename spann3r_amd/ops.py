@@ -315,6 +315,7 @@ class PackedWeightGroup(PackedWeight):
 
 
 F32X3 = False        # fp32 GEMMs through three bf16 MFMAs per k-block (sp3_gemm_desc.f32x3 = 1); set by the model's "f32x3" precision
+F32X6 = False        # fp32 GEMMs through six bf16 MFMAs of a three-way split (f32x3 = 3): fp32-grade products; "f32x6" precision
 F32_BF16 = False     # fp32 operands rounded to bf16 inside the GEMM, one bf16 MFMA per k-block (f32x3 = 2): bf16 training step
 
 
@@ -323,7 +324,7 @@ def _w(d, W):
     d.W = W.data_ptr()
     d.w_packed = int(isinstance(W, PackedWeight))
     d.wdtype = wdtype_of(W)
-    d.f32x3 = (2 if F32_BF16 else int(F32X3)) if d.wdtype == F32 else 0
+    d.f32x3 = (2 if F32_BF16 else 3 if F32X6 else int(F32X3)) if d.wdtype == F32 else 0
 
 
 class LnFold:

@@ -657,6 +657,8 @@ def forward_train(P, frames, cfg, dropout_p=0.0, generator=None):
     """-> (preds, preds_all) of Spann3R.forward in train mode.  P: {reference parameter name: tensor} (leaves of the tape);
     frames: list of dicts with img [B,3,H,W] on the device (landscape or square; `true_shape` is not consulted: training
     batches are rectified); dropout_p: spann3r/model.py:229 memory_dropout (0.15 in training), drawn from `generator`."""
+    ops.F32_BF16 = PRECISION == "bf16"       # (an inference call in between may have reset the product mode of the fp32 GEMMs)
+    ops.F32X3 = ops.F32X6 = False
     mem_k = mem_v = None
     feat2 = pos2 = feat_k2 = None
     preds, preds_all = None, []
