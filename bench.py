@@ -375,8 +375,14 @@ def main():
         sys.exit(2)
     if os.environ.get("SP3_BENCH_CORES"):
         os.sched_setaffinity(0, {int(c) for c in os.environ["SP3_BENCH_CORES"].split(",")})
-    if world > 1:
+    # SP3_FORCE_DIST=1: bring RCCL up also for a one-rank job (tests: the stats all_gather and the rendezvous of the self-spawned
+    # ranks run through the same code as an 8-GPU job)
+    use_dist = world > 1 or os.environ.get("SP3_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", init_method="env://")   # 'nccl' IS RCCL on ROCm
     torch.cuda.set_device(local)
@@ -396,7 +402,7 @@ def main():
                               "dtype": args.train_precision, "data": "synthetic (seeded frames / ground truth, seeded random-init weights)",
                               "config": {"workload": "train step, BASELINE config 5 per rank: batch %d, 5 frames of 224x224" % args.train_batch,
                                          "parallelism": "dp%d (RCCL bucket all-reduce inside backward)" % world}, "train": tr}))
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
 
@@ -410,7 +416,7 @@ def main():
     fps, tot_frames, max_seconds = aggregate(stats)
 
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
 
@@ -424,6 +430,7 @@ def main():
                    "hip_graphs": bool(model.use_graphs)},
         "per_gpu_frames_per_s": fps / world,
         "per_rank_seconds": [round(float(s), 6) for s in stats[:, 1]],
+        "rccl_ranks": dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 0,
     }
     fl = flops_per_sequence(args.frames, args.size)
     out["end_to_end"] = {"algorithmic_gflop_per_step": fl / 1e9,
@@ -504,7 +511,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(sd, args.size, args.train_policy)
     print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -432,7 +432,8 @@ def make_postprocess():
 
 
 def make_traingrad():
-    """f1 at FULL geometry: one training step of the UNMODIFIED reference in float64 -- Spann3R.forward in train mode (memory
+    """f1 at FULL geometry: one training step of the UNMODIFIED reference (float32: its downstream_head casts the tokens with
+    .float(), spann3r/model.py:329, so a float64 copy of the module does not run) -- Spann3R.forward in train mode (memory
     dropout 0 so that the step is deterministic), spann3r/loss.py ConfLoss_t(Regr3D_t(L21, avg_dis), 0.4).compute_frame_loss,
     (loss + factor).backward() -- on the 24/12-layer model and 3 frames of 64x80, batch 2.  Dumped: loss, factor and, for every
     parameter tensor, max |grad| plus a strided sample of its gradient (<= 256 elements): the device step is compared against
@@ -441,7 +442,7 @@ def make_traingrad():
     from dust3r.losses import L21
     cfg, H, W, NF, B = FULL, 64, 80, 3, 2
     sd = synth_state_dict(0, cfg)
-    m = build_reference(cfg, sd, "traingrad").double()
+    m = build_reference(cfg, sd, "traingrad")
     m.train()
     m.mem_dropout.p = 0.0
     frames = synth_frames(NF, H, W, batch=B, seed=77)
@@ -452,15 +453,15 @@ def make_traingrad():
         pose = torch.eye(4).repeat(B, 1, 1)
         pose[:, :3, :3] = Q
         pose[:, :3, 3] = torch.randn(B, 3, generator=g) * 0.3
-        views.append(dict(img=f["img"].double(), true_shape=torch.tensor([[H, W]] * B, dtype=torch.int32),
-                          pts3d=(torch.randn(B, H, W, 3, generator=g) + torch.tensor([0.0, 0.0, 3.0])).double(),
-                          valid_mask=torch.rand(B, H, W, generator=g) < 0.85, camera_pose=pose.double()))
+        views.append(dict(img=f["img"], true_shape=torch.tensor([[H, W]] * B, dtype=torch.int32),
+                          pts3d=torch.randn(B, H, W, 3, generator=g) + torch.tensor([0.0, 0.0, 3.0]),
+                          valid_mask=torch.rand(B, H, W, generator=g) < 0.85, camera_pose=pose))
     t = time.time()
     preds, preds_all = m(views)
     crit = ConfLoss_t(Regr3D_t(L21, norm_mode="avg_dis", fix_first=False), alpha=0.4)
     loss, details, factor = crit.compute_frame_loss(views, preds_all)
     (loss + factor).backward()
-    print("traingrad: reference float64 step %.1f s, loss %.6f factor %.6f" % (time.time() - t, float(loss), float(factor)))
+    print("traingrad: reference float32 step %.1f s, loss %.6f factor %.6f" % (time.time() - t, float(loss), float(factor)))
     out = {"meta": np.array([H, W, NF, B, 77, 78]), "loss": np.float64(float(loss)), "factor": np.float64(float(factor)),
            "fingerprint": np.array(state_dict_fingerprint(sd))}
     for k in ("pts3d", "valid_mask", "camera_pose"):

@@ -649,3 +649,41 @@ def test_forward_is_deterministic_run_to_run(tiny_model):
     finally:
         m.set_precision("fp32")
         m.use_graphs = True
+
+
+def _bench_argv(n):
+    return ["--gpus", str(n), "--steps", "2", "--warmup", "1", "--frames", "3", "--size", "64", "--no-extras", "--no-cpu-baseline", "--no-profile"]
+
+
+def test_bench_self_spawn_one_rank_through_rccl(capsys):
+    """bench.spawn_ranks (the no-launcher path of `python bench.py --gpus N`) end to end with one rank and RCCL forced up: rendezvous
+    on 127.0.0.1, sequence sharding, the device-side all_gather of the per-rank stats, rank 0's JSON line"""
+    import json
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    os.environ["SP3_FORCE_DIST"] = "1"
+    try:
+        rc = bench.spawn_ranks(1, _bench_argv(1))
+    finally:
+        os.environ.pop("SP3_FORCE_DIST", None)
+    assert rc == 0
+    line = [l for l in capsys.readouterr().out.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 1 and out["rccl_ranks"] == 1 and out["value"] > 0 and len(out["per_rank_seconds"]) == 1
+    assert bench.spawn_ranks(torch.cuda.device_count() + 1, _bench_argv(torch.cuda.device_count() + 1)) != 0     # never a smaller job
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (the driver's 8-GPU node)")
+def test_bench_two_ranks_over_rccl(capsys):
+    """two ranks, one per GPU: sequences sharded, stats all_gather over RCCL / xGMI, whole-job frames/s from the slower rank"""
+    import json
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    assert bench.spawn_ranks(2, _bench_argv(2)) == 0
+    out = json.loads([l for l in capsys.readouterr().out.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and len(out["per_rank_seconds"]) == 2
+    assert abs(out["value"] - 2 * 2 * 3 / max(out["per_rank_seconds"])) < 1e-6 * out["value"]

@@ -9,6 +9,9 @@ from conftest import rel_err
 from oracle import train_oracle as TO
 
 
+MEMREAD_GRAD_TOL = 2e-4
+
+
 def _inputs(B, P, T, C, seed, dtype=torch.float32, device="cpu", p_drop=0.15):
     g = torch.Generator().manual_seed(seed)
     rn = lambda *s: torch.randn(*s, generator=g)
@@ -60,11 +63,14 @@ def test_memory_read_train_forward_backward(B, P, T, C, drop):
     l64, m64, d64 = _inputs(B, P, T, C, seed=P, dtype=torch.float64)
     ref, gref = _run(TO.memory_read_train, l64, m64 if drop else None, d64)
     assert rel_err(out.cpu(), ref) < 1e-5
+    worst = (0.0, None)
     for k in grads:
         if k == "bk":        # softmax is invariant to a shift of every score of a row: d out / d beta_k == 0 exactly
             assert float(gref[k].abs().max()) < 1e-12 and float(grads[k].abs().max()) < 1e-5 * float(grads["gk"].abs().max())
             continue
-        assert rel_err(grads[k].cpu(), gref[k]) < 2e-4, (k, rel_err(grads[k].cpu(), gref[k]))
+        worst = max(worst, (rel_err(grads[k].cpu(), gref[k]), k))
+    print("memory read (train) gradients: worst rel err %.2e (%s)" % worst)
+    assert worst[0] < MEMREAD_GRAD_TOL, worst
     # deterministic: a second run gives the same bits
     leaves2, _, _ = _inputs(B, P, T, C, seed=P, device="cuda")
     out2, grads2 = _run(memory_read_train, leaves2, mask if drop else None, dout)
@@ -113,8 +119,9 @@ def test_vit_blocks_forward_backward(cross):
         out.backward(d0.to(dt).to(dev))
         res[name] = (out.detach().cpu(), {**{k: v.grad.cpu() for k, v in P.items()}, "x": x.grad.cpu(), **({"y": y.grad.cpu()} if cross else {})})
     assert rel_err(res["hip"][0], res["ref"][0]) < 1e-5
-    for k, v in res["ref"][1].items():
-        assert rel_err(res["hip"][1][k], v) < 3e-4, (k, rel_err(res["hip"][1][k], v))
+    worst = max((rel_err(res["hip"][1][k], v), k) for k, v in res["ref"][1].items())
+    print("ViT block (cross=%s) gradients: worst rel err %.2e (%s)" % (cross, worst[0], worst[1]))
+    assert worst[0] < 3e-4, worst
 
 
 @pytest.mark.gpu
@@ -148,7 +155,7 @@ def test_dpt_head_train_forward_backward(tiny_sd):
     assert {k for k, v in res["hip"][2].items() if v is None} == {k for k, v in res["ref"][2].items() if v is None}
     worst = max((rel_err(res["hip"][2][k], v), k) for k, v in res["ref"][2].items() if v is not None)
     print("DPT head gradients: worst rel err %.2e (%s) over %d tensors" % (worst[0], worst[1], len(res["ref"][2])))
-    assert worst[0] < 1e-3, worst
+    assert worst[0] < 1.5e-5, worst          # measured 1.1e-6
 
 
 def _synth_gts(n, B, H, W, seed, dtype, device):
@@ -201,7 +208,7 @@ def test_training_step_gradients_match_oracle(tiny_sd):
             worst = (e, k)
     print("training step: loss %.6f (oracle %.6f), %d parameter gradients, worst scaled error %.2e (%s)" %
           (float(loss) + float(factor), float(l64) + float(f64), n_checked, worst[0], worst[1]))
-    assert worst[0] < 2e-3, worst
+    assert worst[0] < 6e-5, worst            # measured 5.5e-6 (norm_q.bias)
 
 
 @pytest.mark.gpu
@@ -477,12 +484,13 @@ def test_train_step_hip_graph_replay_matches_eager(tiny_sd):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("bf16", 6e-2)])
+@pytest.mark.parametrize("precision,tol", [("fp32", 3e-4), ("bf16", 6e-2)])
 def test_full_geometry_gradients_vs_reference_step(full_sd, precision, tol):
     """BASELINE config 5's step at FULL depth and width (24 encoder / 12 decoder layers, ViT-L / ViT-B / DPT) against ONE TRAINING
-    STEP OF THE UNMODIFIED REFERENCE run in float64 (tests/golden/make_golden.py traingrad: Spann3R.forward in train mode +
+    STEP OF THE UNMODIFIED REFERENCE (torch CPU float32, tests/golden/make_golden.py traingrad: Spann3R.forward in train mode +
     spann3r/loss.py ConfLoss_t + backward): the loss and a strided sample of EVERY parameter gradient (~1090 tensors).
-    fp32 mode: each tensor within 1e-4 of the reference (scaled by the tensor's own maximum, floored at 1e-4 of the global one);
+    fp32 mode: each tensor within 3e-4 of the reference (scaled by the tensor's own maximum, floored at 1e-4 of the global one;
+    both sides carry fp32 rounding through ~80 chained GEMMs);
     bf16 mode: global relative L2 error of the sampled gradients within 6e-2 (measured 3e-2: operand rounding of ~80 chained GEMMs)."""
     import numpy as np
     from spann3r_amd import train as T, FULL
