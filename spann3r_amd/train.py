@@ -206,8 +206,11 @@ def memory_read_train(feat, mem_k, mem_v, norm_q, norm_k, norm_v, mask=None, eps
 # :186-191 (DecoderBlock).
 def _nt(A, Bm, M, N, K, lda, ldb, out, ldc, bias=None, res=None, alpha=1.0, batch=1, sA=0, sB=0, sC=0):
     """out[M, N] (row stride ldc) = alpha * A[M, K] . Bm[N, K]^T (+ bias) (+ res); K % 8 == 0 (operands zero-padded)"""
+    # short contractions (the per-head products of attention: K = 64 or ~200): the 32x32 tile splits K over its 4 waves and would
+    # leave half of them without a k-block; the 64x64 tile gives every wave its own 32x32 sub-tile
+    tile = 1 if (K <= 256 and batch > 1 and M >= 64) else -1
     ops.gemm(A, Bm, out, M=M, N=N, K=K, lda=lda, ldc=ldc, ldw=ldb, bias=bias, res1=res, ldr1=ldc, alpha=alpha,
-             batch=batch, strideA=sA, strideW=sB, strideC=sC)
+             batch=batch, strideA=sA, strideW=sB, strideC=sC, tile=tile)
     return out
 
 
