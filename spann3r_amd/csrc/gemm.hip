@@ -1791,9 +1791,15 @@ static int gemm_prepare(sp3_gemm_desc& d, int& tile_out) {
     // (split-K partials too: the PARTIAL epilogue is tile-agnostic; every K slice must hold whole k-blocks)
     const bool pipe_ok = d.loader == SP3_LOAD_PLAIN && !d.sm_stats_out && d.a_packed && d.w_packed && d.a_bf16 && !d.A2 && d.K % 64 == 0 &&
                          (sk == 1 || d.epi == SP3_EPI_PARTIAL);
-    if (pipe_ok && pipe_on && d.M >= 512) {
-      // many-row GEMMs on packed bf16 operands: the largest pipelined tile that still gives most CUs a workgroup
-      // (tools/bench_gemm2.py --big on MI355X, profiles/r03_gemm_manyrow_tile_sweep.txt)
+    // In the model (profiles/r03_a_*): the RoPE / V^T epilogue and the GELU -> packed epilogue of the WIDE many-row GEMMs (q/k/v
+    // projection, fc1: N >= 2304) run faster on the 128-row LDS tiles 5 / 6 (their epilogue walks 4 row steps per thread, the
+    // 256 x 128 tile 16: 39.7 vs 29.2 us for the encoder's q/k/v), so those keep the round-2 choice; everything else with
+    // many rows (N < 2304: proj, fc2, key MLPs, decoder side GEMMs; split-K partials; very wide score GEMMs of the long-bank
+    // read) goes to the pipelined tiles.
+    const bool wide_legacy = lds_ok && d.M >= 1024 && d.N >= 2304 && d.N % 128 == 0 && d.N < 16384;
+    if (pipe_ok && pipe_on && d.M >= 512 && d.epi != SP3_EPI_ROPE_VT && !wide_legacy) {
+      // the largest pipelined tile that still gives most CUs a workgroup (tools/bench_gemm2.py --big on MI355X,
+      // profiles/r03_gemm_manyrow_tile_sweep.txt)
       const long mt256 = (d.M + 255) / 256, mt128 = (d.M + 127) / 128, nt128 = (d.N + 127) / 128;
       if (mt256 * nt128 * d.batch * sk >= 144) tile = 20;
       else if (mt128 * nt128 * d.batch * sk >= 200) tile = 21;

@@ -107,12 +107,13 @@ _TILE_NAMES = {0: "32x32xk4", 1: "64x64", 2: "64x128", 3: "64x64xk4", 4: "32x64x
                20: "256x128pipe", 21: "128x128pipe", 22: "128x64pipe", 23: "64x64pipe", 24: "64x32pipe", 25: "32x32pipe"}
 
 
-def pick_tile(M, N, batch=1, splitk=1, conv=False, K=0, packed_bf16=False, plain=False, ln_nt=0, pipe_ok=False):
+def pick_tile(M, N, batch=1, splitk=1, conv=False, K=0, packed_bf16=False, plain=False, ln_nt=0, pipe_ok=False, rope=False):
     """Mirror of the auto heuristic in csrc/gemm.hip (kept in sync so profiles can be keyed by instantiation)."""
     t64 = ((M + 63) // 64) * ((N + 63) // 64) * batch * splitk
     t128 = ((M + 63) // 64) * ((N + 127) // 128) * batch
     lds_ok = not conv and splitk == 1 and packed_bf16 and K % 64 == 0
-    if pipe_ok and PIPE_TILES and M >= 512:
+    wide_legacy = lds_ok and M >= 1024 and N >= 2304 and N % 128 == 0 and N < 16384
+    if pipe_ok and PIPE_TILES and M >= 512 and not rope and not wide_legacy:
         mt256, mt128, nt128 = (M + 255) // 256, (M + 127) // 128, (N + 127) // 128
         if mt256 * nt128 * batch * splitk >= 144:
             return 20
@@ -184,7 +185,7 @@ def _pick(d):
     d.tile = pick_tile(d.M, d.N, max(d.batch, 1), max(d.splitk, 1), d.loader == L.LOAD_CONV3X3, d.K,
                        bool(d.a_packed and d.w_packed and d.a_bf16 and not d.A2 and d.epi != L.EPI_PARTIAL
                             and not d.sm_stats_out),
-                       d.epi == L.EPI_PLAIN, d.ln_nt if d.ln_stats else 0, _pipe_ok(d))
+                       d.epi == L.EPI_PLAIN, d.ln_nt if d.ln_stats else 0, _pipe_ok(d), d.epi == L.EPI_ROPE_VT)
 
 
 def _gemm_cost(d):
