@@ -30,7 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 METRIC = "frames/sec/GPU (224px, 10-frame seq) + mem-bank cross-attn HBM GB/s"
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "f32x3": 2500.0 / 3, "f32x6": 2500.0 / 6}       # dense MFMA peaks, MI355X_MICROARCH.md (f32x3 / f32x6: 3 / 6 bf16 MFMAs per product)
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "f32x3": 2500.0 / 3, "f32x6": 2500.0 / 6, "f16x3": 2500.0 / 3}       # dense MFMA peaks, MI355X_MICROARCH.md (f32x3 / f32x6: 3 / 6 bf16 MFMAs per product)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -51,7 +51,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "f32x3", "f32x6"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "f32x3", "f32x6", "f16x3"])
     ap.add_argument("--frames", type=int, default=10)
     ap.add_argument("--size", type=int, default=224)
     ap.add_argument("--no-cpu-baseline", action="store_true")

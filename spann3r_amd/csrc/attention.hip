@@ -155,6 +155,72 @@ template <> struct AttnT<F32X3> {
   }
 };
 
+// fp32 operands, fp16 two-way split x = h + l * 2^-11 (22 operand bits; the model's "f16x3" precision, see gemm.hip): three fp16 MFMAs per
+// product, exact in fp32; the cross terms are summed separately and folded in with 2^-11
+struct F16X3 {};
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+__device__ __forceinline__ void split8h(const float (&x)[8], f16x8& hi, f16x8& lo) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const _Float16 h = (_Float16)x[e];
+    hi[e] = h;
+    lo[e] = (_Float16)((x[e] - (float)h) * 2048.0f);
+  }
+}
+__device__ __forceinline__ f32x4 mfma3h(const f16x8& ah, const f16x8& al, const f16x8& bh, const f16x8& bl, f32x4 c) {
+  f32x4 x = {0.f, 0.f, 0.f, 0.f};
+  x = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, x, 0, 0, 0);
+  x = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, x, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, c, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) c[r] = fmaf(x[r], 1.0f / 2048.0f, c[r]);
+  return c;
+}
+template <> struct AttnT<F16X3> {
+  using Store = float;
+  struct QReg { f16x8 h[2], l[2]; };
+  static __device__ __forceinline__ void loadQ(QReg& r, const float* row, int g) {
+    const float4* p = reinterpret_cast<const float4*>(row + 16 * g);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const float4 a = p[2 * u], b = p[2 * u + 1];
+      const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      split8h(x, r.h[u], r.l[u]);
+    }
+  }
+  static __device__ __forceinline__ f32x4 qk(const float* krow, int g, const QReg& q) {
+    const float4* p = reinterpret_cast<const float4*>(krow + 16 * g);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const float4 a = p[2 * u], b = p[2 * u + 1];
+      const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      f16x8 kh, kl;
+      split8h(x, kh, kl);
+      s = mfma3h(kh, kl, q.h[u], q.l[u], s);
+    }
+    return s;
+  }
+  static __device__ __forceinline__ void pv(f32x4 (&o)[4], const float* vt_head, int64_t vt_ld, int kbase, int g, int dl,
+                                            const f32x4 (&p)[4]) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const float px[8] = {p[2 * u][0], p[2 * u][1], p[2 * u][2], p[2 * u][3], p[2 * u + 1][0], p[2 * u + 1][1], p[2 * u + 1][2], p[2 * u + 1][3]};
+      f16x8 ph, pl;
+      split8h(px, ph, pl);
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        const float* vr = vt_head + (int64_t)(db * 16 + dl) * vt_ld + kbase + 32 * u + 4 * g;
+        const float4 lo4 = *reinterpret_cast<const float4*>(vr), hi4 = *reinterpret_cast<const float4*>(vr + 16);
+        const float vx[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+        f16x8 vh, vl;
+        split8h(vx, vh, vl);
+        o[db] = mfma3h(vh, vl, ph, pl, o[db]);
+      }
+    }
+  }
+};
+
 template <typename TT>
 __global__ __launch_bounds__(256) void attention_kernel(const typename AttnT<TT>::Store* __restrict__ Q, int64_t sq, int64_t ldq,
                                                        const typename AttnT<TT>::Store* __restrict__ K, int64_t sk, int64_t ldk,
@@ -410,13 +476,18 @@ extern "C" int sp3_attention_ex(const void* q, int64_t sq, int64_t ldq, const vo
   SP3_CHECK(B > 0 && heads > 0 && Nq > 0 && Nk > 0, "sp3_attention: bad shape");
   SP3_CHECK(vt_ld >= ((Nk + 63) / 64) * 64 && vt_ld % 8 == 0, "sp3_attention: vt_ld=%lld must be >= Nk padded to 64", (long long)vt_ld);
   SP3_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && (out_packed || ldo % 4 == 0), "sp3_attention: row strides must keep 16-byte alignment");
-  SP3_CHECK(dtype == SP3_F32 || dtype == SP3_BF16 || dtype == 2, "sp3_attention: bad dtype %d (0 fp32, 1 bf16, 2 fp32 operands with bf16x3 products)", dtype);
+  SP3_CHECK(dtype == SP3_F32 || dtype == SP3_BF16 || dtype == 2 || dtype == 3,
+            "sp3_attention: bad dtype %d (0 fp32, 1 bf16, 2 / 3: fp32 operands with bf16x3 / fp16x3 split products)", dtype);
   dim3 grid((Nq + 15) / 16, heads, B);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == SP3_BF16)
     hipLaunchKernelGGL(attention_kernel<__bf16>, grid, dim3(256), 0, st, reinterpret_cast<const __bf16*>(q), sq, ldq,
                        reinterpret_cast<const __bf16*>(k), sk, ldk, reinterpret_cast<const __bf16*>(vt), vt_ld, out, ldo,
                        out_bf16, out_packed, heads, Nq, Nk, scale);
+  else if (dtype == 3)
+    hipLaunchKernelGGL(attention_kernel<F16X3>, grid, dim3(256), 0, st, reinterpret_cast<const float*>(q), sq, ldq,
+                       reinterpret_cast<const float*>(k), sk, ldk, reinterpret_cast<const float*>(vt), vt_ld, out, ldo, out_bf16,
+                       out_packed, heads, Nq, Nk, scale);
   else if (dtype == 2)
     hipLaunchKernelGGL(attention_kernel<F32X3>, grid, dim3(256), 0, st, reinterpret_cast<const float*>(q), sq, ldq,
                        reinterpret_cast<const float*>(k), sk, ldk, reinterpret_cast<const float*>(vt), vt_ld, out, ldo, out_bf16,

@@ -259,6 +259,37 @@ template <> struct MM<float, float> {
       }
     }
   }
+  // f32x3 = 4 ("f16x3"): a TWO-way split into fp16 halves, x = h + l * 2^-11 with h = fp16(x), l = fp16((x - h) * 2^11): 22 operand
+  // bits (bf16 halves: 16) for the same three MFMAs -- hh into the main accumulator, hl + lh into a second one that is scaled by
+  // 2^-11 when the accumulators leave the K loop.  Every product is exact in fp32 (11 x 11 bits), accumulation is fp32.  Operands
+  // must stay below fp16's 65504 (activations and weights of this model do; the fp32 / f32x6 modes have no such limit).
+  typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+  static __device__ __forceinline__ void split8h(const float4& x0, const float4& x1, f16x8& h, f16x8& l) {
+    const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const _Float16 hh = (_Float16)x[e];
+      h[e] = hh;
+      l[e] = (_Float16)((x[e] - (float)hh) * 2048.0f);
+    }
+  }
+  template <int MF, int NF>
+  static __device__ __forceinline__ void mma_h3(f32x4 (&acc)[MF][NF], f32x4 (&accx)[MF][NF], const AReg (&a)[MF], const WReg (&w)[NF]) {
+    f16x8 wh[NF], wl[NF];
+#pragma unroll
+    for (int n = 0; n < NF; ++n) split8h(w[n].v[0], w[n].v[1], wh[n], wl[n]);
+#pragma unroll
+    for (int m = 0; m < MF; ++m) {
+      f16x8 ah, al;
+      split8h(a[m].v[0], a[m].v[1], ah, al);
+#pragma unroll
+      for (int n = 0; n < NF; ++n) {
+        accx[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wh[n], accx[m][n], 0, 0, 0);
+        accx[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wl[n], accx[m][n], 0, 0, 0);
+        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wh[n], acc[m][n], 0, 0, 0);
+      }
+    }
+  }
   // f32x3 = 2 ("bf16 products"): fp32 operands in memory, rounded to bf16 on their way into ONE v_mfma_f32_16x16x32_bf16 per
   // k-block, fp32 accumulate -- the arithmetic of a bf16-autocast matmul on fp32 master tensors (training step, bf16 mode)
   template <int MF, int NF>
@@ -517,10 +548,18 @@ void gemm_kernel(const GemmArgs args) {
   }
 
   f32x4 acc[MF][NF];
+  constexpr bool XACC = sizeof(TA) == 4 && sizeof(TW) == 4 && XM == 4;      // f16x3: the cross terms' accumulator
+  f32x4 accx[XACC ? MF : 1][XACC ? NF : 1];
 #pragma unroll
   for (int m = 0; m < MF; ++m)
 #pragma unroll
     for (int n = 0; n < NF; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if constexpr (XACC) {
+#pragma unroll
+    for (int m = 0; m < MF; ++m)
+#pragma unroll
+      for (int n = 0; n < NF; ++n) accx[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
   // Epilogue operands that depend on the column only (bias, LayerNorm column sums): NT is a multiple of BN/4, so a thread
   // keeps one 4-column group through the whole epilogue -> request them NOW.  Every launch has its own vectors, cold in
@@ -626,6 +665,7 @@ void gemm_kernel(const GemmArgs args) {
     if constexpr (sizeof(TA) == 4 && sizeof(TW) == 4 && XM != 0) {
       if constexpr (XM == 1) M_::template mma_x3<MF, NF>(acc, a[st], w[st]);
       else if constexpr (XM == 2) M_::template mma_x1<MF, NF>(acc, a[st], w[st]);
+      else if constexpr (XM == 4) M_::template mma_h3<MF, NF>(acc, accx, a[st], w[st]);
       else M_::template mma_x6<MF, NF>(acc, a[st], w[st]);
     } else {
       M_::template mma<MF, NF>(acc, a[st], w[st]);
@@ -1136,6 +1176,14 @@ void gemm_kernel(const GemmArgs args) {
       }
     }
   }
+  if constexpr (XACC) {           // f16x3: fold the cross terms in (x = h + l 2^-11)
+#pragma unroll
+    for (int m = 0; m < MF; ++m)
+#pragma unroll
+      for (int n = 0; n < NF; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[m][n][r] = fmaf(accx[m][n][r], 1.0f / 2048.0f, acc[m][n][r]);
+  }
   // ---- accumulators -> LDS (C layout: col = lane&15, row = 4*(lane>>4) + reg)
   if (LOOP < 2 || wave < NCW) {
     float* slab = smem + (size_t)wk * BM * LDS_LD;
@@ -1632,7 +1680,7 @@ int dispatch_tile(const sp3_gemm_desc& d, int tile, hipStream_t stream) {
   if constexpr (sizeof(TA) == 4 && sizeof(TW) == 4) {
     // fp32 operands on the register-ring tiles 0-2: the product mode (sp3_gemm_desc.f32x3) selects the kernel instance
     const int xm = d.f32x3;
-    if (xm >= 1 && xm <= 3 && tile >= 0 && tile <= 2) {
+    if (xm >= 1 && xm <= 4 && tile >= 0 && tile <= 2) {
 #define SP3_XM_TILES(XM_)                                                                         \
       switch (tile) {                                                                             \
         case 0: return launch<TA, TW, LOADER, 2, 2, 1, 1, 4, 3, 0, XM_>(d, stream);               \
@@ -1641,6 +1689,7 @@ int dispatch_tile(const sp3_gemm_desc& d, int tile, hipStream_t stream) {
       }
       if (xm == 1) { SP3_XM_TILES(1) }
       if (xm == 2) { SP3_XM_TILES(2) }
+      if (xm == 4) { SP3_XM_TILES(4) }
       SP3_XM_TILES(3)
 #undef SP3_XM_TILES
     }

@@ -98,6 +98,34 @@ __global__ __launch_bounds__(256) void colsum_rows_finish_kernel(const float* __
   out[j] = (accumulate ? out[j] : 0.f) + (float)(s0 + s1);
 }
 
+// short matrices (a few thousand rows: the token GEMMs' bias gradients): ONE launch, a 1024-thread workgroup per 64 columns, its 16
+// waves interleave the rows with four independent chains each (64 rows in flight per column group), partials meet in LDS in wave order
+__global__ __launch_bounds__(1024) void colsum_rows_single_kernel(const float* __restrict__ x, int64_t ld, int rows, int N, float* __restrict__ out,
+                                                                  int accumulate) {
+  __shared__ float sh[16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + lane;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (j < N) {
+    int r = w;
+    for (; r + 48 < rows; r += 64) {
+      s0 += x[(int64_t)r * ld + j];
+      s1 += x[(int64_t)(r + 16) * ld + j];
+      s2 += x[(int64_t)(r + 32) * ld + j];
+      s3 += x[(int64_t)(r + 48) * ld + j];
+    }
+    for (; r < rows; r += 16) s0 += x[(int64_t)r * ld + j];
+  }
+  sh[w][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (w == 0 && j < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += sh[i][lane];
+    out[j] = (accumulate ? out[j] : 0.f) + t;
+  }
+}
+
 constexpr int kSumChunk = 16384;                      // elements per workgroup of the norm's first stage
 
 __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, int64_t n, double* __restrict__ partial) {
@@ -193,6 +221,11 @@ extern "C" int64_t sp3_colsum_rows_ws(int rows, int N) { return (int64_t)((rows 
 
 extern "C" int sp3_colsum_rows(const float* x, int64_t ld, int rows, int N, float* out, int accumulate, float* scratch, void* stream) {
   SP3_CHECK(x && out && scratch && rows > 0 && N > 0 && ld >= N, "sp3_colsum_rows: bad arguments");
+  if (rows <= 8192) {
+    hipLaunchKernelGGL(colsum_rows_single_kernel, dim3((N + 63) / 64), dim3(1024), 0, ST(stream), x, ld, rows, N, out, accumulate);
+    SP3_LAUNCH_CHECK("sp3_colsum_rows");
+    return 0;
+  }
   const int nchunk = (rows + kColChunk - 1) / kColChunk;
   SP3_CHECK(nchunk <= 65535, "sp3_colsum_rows: too many rows (%d)", rows);
   hipLaunchKernelGGL(colsum_rows_partial_kernel, dim3((N + 63) / 64, nchunk), dim3(256), 0, ST(stream), x, ld, rows, N, scratch);

@@ -29,7 +29,7 @@ def _rope_tables(max_pos, base, device):
 
 class Engine:
     def __init__(self, cfg: Spann3RConfig, params: dict, device, precision="fp32"):
-        assert precision in ("fp32", "f32x3", "f32x6", "bf16")
+        assert precision in ("fp32", "f32x3", "f32x6", "f16x3", "bf16")
         self.cfg = cfg
         self.device = torch.device(device)
         self.precision = precision

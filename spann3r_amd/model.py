@@ -758,7 +758,7 @@ class Spann3R(nn.Module):
         enables on its own GPUs, has 10 -- fp32 accumulation).  'f32x6': three-way split, six bf16 MFMAs per product: fp32-grade
         products (24 operand bits) at bf16 MFMA speed -- the fast PARITY mode: it holds the 1e-3 bar also on trained-like weight
         statistics, where 'f32x3' does not (tests/test_model_gpu.py stress fixture).  'bf16': bf16 operands (benchmark mode)."""
-        assert precision in ("fp32", "f32x3", "f32x6", "bf16")
+        assert precision in ("fp32", "f32x3", "f32x6", "f16x3", "bf16")
         self.precision = precision
         return self
 
@@ -769,7 +769,7 @@ class Spann3R(nn.Module):
     def engine(self) -> Engine:
         # every entry point (forward, the reference-shaped stage methods, offline_reconstruction, model.dust3r) fetches the
         # engine first: the product mode of the fp32 GEMMs follows the model's precision from here
-        ops.F32X3, ops.F32X6, ops.F32_BF16 = self.precision == "f32x3", self.precision == "f32x6", False
+        ops.F32X3, ops.F32X6, ops.F16X3, ops.F32_BF16 = self.precision == "f32x3", self.precision == "f32x6", self.precision == "f16x3", False
         if self._pinned is not None:          # inside forward(): weights cannot change, skip the version scan
             return self._pinned
         dev = self._params["norm_q.weight"].device

@@ -317,6 +317,7 @@ class PackedWeightGroup(PackedWeight):
 
 F32X3 = False        # fp32 GEMMs through three bf16 MFMAs per k-block (sp3_gemm_desc.f32x3 = 1); set by the model's "f32x3" precision
 F32X6 = False        # fp32 GEMMs through six bf16 MFMAs of a three-way split (f32x3 = 3): fp32-grade products; "f32x6" precision
+F16X3 = False        # fp32 GEMMs through three fp16 MFMAs of a two-way (h, l * 2^-11) split (f32x3 = 4): 22 operand bits; "f16x3" precision
 F32_BF16 = False     # fp32 operands rounded to bf16 inside the GEMM, one bf16 MFMA per k-block (f32x3 = 2): bf16 training step
 
 
@@ -325,7 +326,7 @@ def _w(d, W):
     d.W = W.data_ptr()
     d.w_packed = int(isinstance(W, PackedWeight))
     d.wdtype = wdtype_of(W)
-    d.f32x3 = (2 if F32_BF16 else 3 if F32X6 else int(F32X3)) if d.wdtype == F32 else 0
+    d.f32x3 = (2 if F32_BF16 else 3 if F32X6 else 4 if F16X3 else int(F32X3)) if d.wdtype == F32 else 0
 
 
 class LnFold:
@@ -573,7 +574,7 @@ def attention(q, sq, ldq, k, sk, ldk, vt, vt_ld, out, ldo, *, B, heads, Nq, Nk, 
            B * heads * 64.0 * (es * (Nq + 2 * Nk) + 4 * Nq),
            lambda: L.check(L.load().sp3_attention_ex(q.data_ptr(), sq, ldq, k.data_ptr(), sk, ldk, vt.data_ptr(), vt_ld,
                                                      out.data_ptr(), ldo, int(out.dtype == torch.bfloat16), _is_packed(out),
-                                                     B, heads, Nq, Nk, float(scale), (2 if (F32X3 and es == 4) else wdtype_of(vt)),
+                                                     B, heads, Nq, Nk, float(scale), (2 if (F32X3 and es == 4) else 3 if (F16X3 and es == 4) else wdtype_of(vt)),
                                                      L.stream_ptr()),
                            "sp3_attention"))
     return out

@@ -61,12 +61,7 @@ def _colsum(dy, out=None):
     """db = dY.sum(0) of a contiguous fp32 [R, N] (two deterministic stages); `out` given: accumulated into it"""
     R, N = dy.shape
     acc = out is not None
-    if R <= 2048:                                   # short: one workgroup per 64 columns walks all rows (one launch)
-        if out is None:
-            out = torch.zeros(N, device=dy.device)
-        ops.colsum_accum(dy, dy.stride(0), R, N, out)
-        return out
-    ws = torch.empty(int(L.load().sp3_colsum_rows_ws(R, N)), device=dy.device)
+    ws = torch.empty(int(L.load().sp3_colsum_rows_ws(R, N)) if R > 8192 else 4, device=dy.device)
     if out is None:
         out = torch.empty(N, device=dy.device)
     L.check(L.load().sp3_colsum_rows(dy.data_ptr(), dy.stride(0), R, N, out.data_ptr(), int(acc), ws.data_ptr(), L.stream_ptr()), "sp3_colsum_rows")
@@ -661,7 +656,7 @@ def forward_train(P, frames, cfg, dropout_p=0.0, generator=None):
     frames: list of dicts with img [B,3,H,W] on the device (landscape or square; `true_shape` is not consulted: training
     batches are rectified); dropout_p: spann3r/model.py:229 memory_dropout (0.15 in training), drawn from `generator`."""
     ops.F32_BF16 = PRECISION == "bf16"       # (an inference call in between may have reset the product mode of the fp32 GEMMs)
-    ops.F32X3 = ops.F32X6 = False
+    ops.F32X3 = ops.F32X6 = ops.F16X3 = False
     mem_k = mem_v = None
     feat2 = pos2 = feat_k2 = None
     preds, preds_all = None, []

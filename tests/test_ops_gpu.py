@@ -817,6 +817,36 @@ def test_attention_f32x3():
     assert errs[False] < 2e-6 and 1e-6 < errs[True] < 5e-5, errs
 
 
+def test_attention_and_gemm_f16x3():
+    """fp16 two-way split products (x = h + l * 2^-11, three fp16 MFMAs): within a few 1e-7 of float64, i.e. fp32-grade"""
+    ops = _ops()
+    B, heads, Nq, Nk = 2, 3, 50, 196
+    C = heads * 64
+    q, k, v = rnd(B, Nq, heads, 64, seed=1) * 2, rnd(B, Nk, heads, 64, seed=2), rnd(B, Nk, heads, 64, seed=3)
+    npk = (Nk + 63) // 64 * 64
+    vt = torch.zeros(B * heads * 64, npk)
+    vt.view(B, heads, 64, npk)[..., :Nk] = v.permute(0, 2, 3, 1)
+    a = torch.softmax(torch.einsum("bqhd,bkhd->bhqk", q.double(), k.double()) * 0.125, -1)
+    ref = torch.einsum("bhqk,bkhd->bqhd", a, v.double()).reshape(B * Nq, C)
+    M, N, K = 196, 768, 1024
+    A, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2) * 0.05, rnd(N, seed=3)
+    gref = A.double() @ W.double().T + b.double()
+    ops.F16X3 = True
+    try:
+        out = torch.empty(B * Nq, C, device=DEV)
+        ops.attention(q.reshape(B, Nq, C).to(DEV), Nq * C, C, k.reshape(B, Nk, C).to(DEV), Nk * C, C, vt.to(DEV), npk, out, C,
+                      B=B, heads=heads, Nq=Nq, Nk=Nk, scale=0.125)
+        ea = rel_err(out.cpu(), ref)
+        eg = []
+        for tile in (0, 1, 2):
+            o = torch.empty(M, N, device=DEV)
+            ops.gemm(A.to(DEV), W.to(DEV), o, M=M, N=N, K=K, lda=K, ldc=N, bias=b.to(DEV), tile=tile)
+            eg.append(rel_err(o.cpu(), gref))
+    finally:
+        ops.F16X3 = False
+    assert ea < 3e-6 and max(eg) < 3e-6, (ea, eg)
+
+
 def test_gemm_f32x3_products():
     """fp32 operands through three bf16 MFMAs per k-block (sp3_gemm_desc.f32x3): ~16 mantissa bits per product, fp32 accumulate"""
     ops = _ops()

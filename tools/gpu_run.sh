@@ -36,6 +36,8 @@ for stage in "$@"; do
     traintests) timeout 1500 python -m pytest tests/test_train.py tests/test_loss.py -x -q -m gpu -s > "$OUT/traintests.txt" 2>&1; grep -v "^$" "$OUT/traintests.txt" | tail -25 ;;
     memread)    timeout 600 python tools/bench_memread.py > "$OUT/memread.txt" 2>&1; tail -30 "$OUT/memread.txt" ;;
     memreadlong) timeout 600 python tools/bench_memread.py --tokens 50176 --rows 1024 --copies 3 > "$OUT/memread_long.txt" 2>&1; tail -30 "$OUT/memread_long.txt" ;;
+    f16x3)      timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_model_gpu.py -x -q -m gpu -s -k "f16x3 or stress or precision or f32x3" > "$OUT/f16x3_tests.txt" 2>&1; grep -v "^$" "$OUT/f16x3_tests.txt" | tail -25
+                timeout 600 python bench.py --precision f16x3 --steps 10 --warmup 3 --no-cpu-baseline --no-extras > "$OUT/bench_f16x3.json" 2> "$OUT/bench_f16x3.err"; head -c 1200 "$OUT/bench_f16x3.json"; tail -3 "$OUT/bench_f16x3.err" ;;
     *)          echo "unknown stage $stage" ;;
   esac
 done
