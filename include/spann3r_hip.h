@@ -376,6 +376,10 @@ int sp3_ssi_loss_forward(const float* P, const float* G, const uint8_t* V, const
 int sp3_transpose(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int rows, int cols, void* stream);
 int sp3_transpose_batched(const float* src, int64_t ld_src, int64_t stride_src, float* dst, int64_t ld_dst, int64_t stride_dst, int rows,
                           int cols, int batch, void* stream);       /* `batch` matrices, element strides between them */
+/* same, and columns [rows, pad_to) of every destination row are written as zeros (pad_to <= ld_dst, pad_to - rows < 32): the
+ * contraction pad of the next GEMM without a separate fill launch */
+int sp3_transpose_pad(const float* src, int64_t ld_src, int64_t stride_src, float* dst, int64_t ld_dst, int64_t stride_dst, int rows,
+                      int cols, int batch, int pad_to, void* stream);
 /* exact-erf GELU (nn.GELU, croco/models/blocks.py:73-79) of the train-mode blocks and its backward dx = dy * gelu'(x) */
 int sp3_gelu(const float* x, float* y, int64_t n, void* stream);
 int sp3_gelu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream);
@@ -419,6 +423,27 @@ int sp3_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, cons
                    float eps, int step, const float* grad_scale_dev, float grad_scale, const int* step_dev, const float* lr_dev, void* stream);
    /* step_dev / lr_dev (nullable): the step count / learning rate are read from device memory instead (hipGraph replay of the step) */
 int sp3_softmax_bwd(const float* A, const float* dAd, const float* mask, float* dS, int64_t ld, int rows, int T, float alpha, void* stream);
+/* same, and dS[:, T .. Tpad) = 0 (Tpad <= ld) */
+int sp3_softmax_bwd_pad(const float* A, const float* dAd, const float* mask, float* dS, int64_t ld, int rows, int T, int Tpad, float alpha,
+                        void* stream);
+/* Multi-head attention in training (croco/models/blocks.py:100-108 Attention.forward, :160-166 CrossAttention.forward): the
+ * reshape / permute(0, 2, 1, 3) / RoPE2D between the projections and the per-head products, and their backward, for up to three
+ * tensors (q, k, v / dq, dk, dv) in ONE launch.  A part reads element (b, n, h, d) at src + b*s_b + n*s_n + h*s_h + d, rotates the
+ * token by RoPE2D (pos != NULL: int64 [B*N, 2] (y, x) positions; fwd = +1: croco/models/pos_embed.py:96-157 forward, fwd = -1: its
+ * transpose = the backward), and writes it to dst + b*d_b + n*d_n + h*d_h + d (dst nullable) and to the per-head transpose
+ * dstT [B*H][hd][r8(N)] (nullable; pad columns zero), which is the W operand of the A . W^T GEMMs contracted over tokens.
+ * hd <= 64, hd % 4 == 0; every stride a multiple of 4 elements, pointers 16-byte aligned. */
+typedef struct sp3_head_part {
+  const float* src;
+  int64_t s_b, s_n, s_h;
+  float* dst;
+  int64_t d_b, d_n, d_h;
+  float* dstT;
+  const int64_t* pos;
+  int32_t N;
+  float fwd;
+} sp3_head_part;
+int sp3_head_shuffle(const sp3_head_part* parts, int nparts, int B, int H, int hd, float rope_base, void* stream);
 int sp3_layernorm_bwd(const float* x, int64_t ldx, const float* gamma, const float* dy, int64_t ldy, const float* dx_add, int64_t ld_add,
                       float* dx, int64_t ld_dx, float* dgamma, float* dbeta, int accumulate, float* scratch, int rows, int C, float eps,
                       void* stream);

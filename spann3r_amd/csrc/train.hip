@@ -8,9 +8,9 @@
 
 namespace {
 
-// dst[c * ldd + r] = src[r * lds + c], 32 x 32 tiles through LDS; columns [rows, ldd) of dst are left untouched
+// dst[c * ldd + r] = src[r * lds + c], 32 x 32 tiles through LDS; columns [rows, pad_to) of dst are zeroed, [pad_to, ldd) left untouched
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, int64_t lds_, float* __restrict__ dst, int64_t ldd,
-                                                        int rows, int cols, int64_t bs_src, int64_t bs_dst) {
+                                                        int rows, int cols, int64_t bs_src, int64_t bs_dst, int pad_to) {
   __shared__ float t[32][33];
   src += (int64_t)blockIdx.z * bs_src;
   dst += (int64_t)blockIdx.z * bs_dst;
@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 #pragma unroll
   for (int k = 0; k < 32; k += 8) {
     const int c = c0 + ty + k, r = r0 + tx;
-    if (c < cols && r < rows) dst[(int64_t)c * ldd + r] = t[tx][ty + k];
+    if (c < cols && r < pad_to) dst[(int64_t)c * ldd + r] = t[tx][ty + k];          // (rows >= `rows` were loaded as zeros)
   }
 }
 
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void mul_kernel(const float* __restrict__ a, c
 
 // dS[r, :] = alpha * A[r, :] (.) (dA[r, :] - sum_j dA[r, j] A[r, j]),  dA = dAd (.) mask (mask may be null): one workgroup per row
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ A, const float* __restrict__ dAd, const float* __restrict__ mask,
-                                                          float* __restrict__ dS, int64_t ld, int T, float alpha) {
+                                                          float* __restrict__ dS, int64_t ld, int T, float alpha, int Tpad) {
   __shared__ double sh[4];
   const int64_t o = (int64_t)blockIdx.x * ld;
   double dot = 0.0;
@@ -67,6 +67,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
     const float da = dAd[o + j] * (mask ? mask[o + j] : 1.0f);
     dS[o + j] = alpha * A[o + j] * (da - tot);
   }
+  for (int j = T + threadIdx.x; j < Tpad; j += 256) dS[o + j] = 0.f;
 }
 
 // LayerNorm backward, one wave per row (C <= 2048: 8*C*4 bytes of dynamic LDS stay under the 64 KB default; C % 4 == 0): xh = (x - mean) rstd,
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 extern "C" int sp3_transpose(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int rows, int cols, void* stream) {
   SP3_CHECK(src && dst && rows > 0 && cols > 0 && ld_src >= cols && ld_dst >= rows, "sp3_transpose: bad arguments");
   hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32, 1), dim3(256), 0, ST(stream), src, ld_src, dst, ld_dst, rows,
-                     cols, (int64_t)0, (int64_t)0);
+                     cols, (int64_t)0, (int64_t)0, rows);
   SP3_LAUNCH_CHECK("sp3_transpose");
   return 0;
 }
@@ -283,8 +284,18 @@ extern "C" int sp3_transpose_batched(const float* src, int64_t ld_src, int64_t s
                                      int rows, int cols, int batch, void* stream) {
   SP3_CHECK(src && dst && rows > 0 && cols > 0 && batch > 0 && batch <= 65535 && ld_src >= cols && ld_dst >= rows, "sp3_transpose_batched: bad arguments");
   hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32, batch), dim3(256), 0, ST(stream), src, ld_src, dst, ld_dst, rows,
-                     cols, stride_src, stride_dst);
+                     cols, stride_src, stride_dst, rows);
   SP3_LAUNCH_CHECK("sp3_transpose_batched");
+  return 0;
+}
+
+extern "C" int sp3_transpose_pad(const float* src, int64_t ld_src, int64_t stride_src, float* dst, int64_t ld_dst, int64_t stride_dst,
+                                 int rows, int cols, int batch, int pad_to, void* stream) {
+  SP3_CHECK(src && dst && rows > 0 && cols > 0 && batch > 0 && batch <= 65535 && ld_src >= cols && ld_dst >= pad_to && pad_to >= rows &&
+            pad_to <= (rows + 31) / 32 * 32, "sp3_transpose_pad: bad arguments (rows=%d pad_to=%d ld_dst=%lld)", rows, pad_to, (long long)ld_dst);
+  hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32, batch), dim3(256), 0, ST(stream), src, ld_src, dst, ld_dst, rows,
+                     cols, stride_src, stride_dst, pad_to);
+  SP3_LAUNCH_CHECK("sp3_transpose_pad");
   return 0;
 }
 
@@ -312,8 +323,16 @@ extern "C" int sp3_mul(const float* a, const float* b, float* out, int64_t n, vo
 extern "C" int sp3_softmax_bwd(const float* A, const float* dAd, const float* mask, float* dS, int64_t ld, int rows, int T, float alpha,
                                void* stream) {
   SP3_CHECK(A && dAd && dS && rows > 0 && T > 0 && ld >= T, "sp3_softmax_bwd: bad arguments");
-  hipLaunchKernelGGL(softmax_bwd_kernel, dim3(rows), dim3(256), 0, ST(stream), A, dAd, mask, dS, ld, T, alpha);
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3(rows), dim3(256), 0, ST(stream), A, dAd, mask, dS, ld, T, alpha, T);
   SP3_LAUNCH_CHECK("sp3_softmax_bwd");
+  return 0;
+}
+
+extern "C" int sp3_softmax_bwd_pad(const float* A, const float* dAd, const float* mask, float* dS, int64_t ld, int rows, int T, int Tpad,
+                                   float alpha, void* stream) {
+  SP3_CHECK(A && dAd && dS && rows > 0 && T > 0 && Tpad >= T && ld >= Tpad, "sp3_softmax_bwd_pad: bad arguments");
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3(rows), dim3(256), 0, ST(stream), A, dAd, mask, dS, ld, T, alpha, Tpad);
+  SP3_LAUNCH_CHECK("sp3_softmax_bwd_pad");
   return 0;
 }
 

@@ -67,6 +67,66 @@ __global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict_
   }
 }
 
+// Head shuffle of multi-head attention in training (croco/models/blocks.py:100-108, :160-166: the reshape / permute / RoPE between
+// the projections and the per-head products).  A part moves one [B, N, H, hd] tensor between two stridings, optionally rotating
+// it by RoPE2D (fwd = +1) or its transpose (fwd = -1, the backward), and optionally also writes the per-head TRANSPOSE
+// [B*H, hd, r8(N)] (pad columns zero) the A . W^T GEMMs need for the products contracted over tokens.  Up to three parts (q, k, v or
+// dq, dk, dv) per launch: what were ~11 ATen copies, two rope launches and a transpose per attention is one launch.
+// Workgroup = 64 tokens x hd (<= 64) of one (b, h) through LDS.
+struct HeadShuffleArgs { sp3_head_part p[3]; int B, H, hd; float base; };
+
+__global__ __launch_bounds__(256) void head_shuffle_kernel(HeadShuffleArgs a) {
+  __shared__ float t[64][65];
+  const sp3_head_part& P = a.p[blockIdx.z];
+  const int N = P.N, n0 = blockIdx.x * 64, tid = threadIdx.x, hd = a.hd;
+  if (n0 >= N) return;
+  const int b = blockIdx.y / a.H, h = blockIdx.y - b * a.H;
+  const float* src = P.src + (int64_t)b * P.s_b + (int64_t)h * P.s_h;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int tl = (tid >> 4) + 16 * i, d = (tid & 15) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n0 + tl < N && d < hd) v = *reinterpret_cast<const float4*>(src + (int64_t)(n0 + tl) * P.s_n + d);
+    t[tl][d] = v.x; t[tl][d + 1] = v.y; t[tl][d + 2] = v.z; t[tl][d + 3] = v.w;
+  }
+  __syncthreads();
+  if (P.pos) {                                       // pair i of a token: (du, du + Q), du = axis * 2Q + f (norm_rope.hip rope2d_kernel)
+    const int Q = hd >> 2;
+    for (int idx = tid; idx < 64 * 2 * Q; idx += 256) {
+      const int tl = idx / (2 * Q), i = idx - tl * 2 * Q;
+      if (n0 + tl >= N) continue;
+      const int axis = i / Q, f = i - axis * Q;
+      const float pz = (float)P.pos[((int64_t)b * N + n0 + tl) * 2 + axis];
+      const float ang = pz * (P.fwd / powf(a.base, (float)f / (float)Q));
+      const float cs = cosf(ang), sn = sinf(ang);
+      const int du = axis * 2 * Q + f, dv = du + Q;
+      const float u = t[tl][du], v = t[tl][dv];
+      t[tl][du] = u * cs - v * sn;
+      t[tl][dv] = v * cs + u * sn;
+    }
+    __syncthreads();
+  }
+  if (P.dst) {
+    float* dst = P.dst + (int64_t)b * P.d_b + (int64_t)h * P.d_h;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int tl = (tid >> 4) + 16 * i, d = (tid & 15) * 4;
+      if (n0 + tl < N && d < hd)
+        *reinterpret_cast<float4*>(dst + (int64_t)(n0 + tl) * P.d_n + d) = make_float4(t[tl][d], t[tl][d + 1], t[tl][d + 2], t[tl][d + 3]);
+    }
+  }
+  if (P.dstT) {
+    const int Np = (N + 7) & ~7;
+    float* dT = P.dstT + (int64_t)blockIdx.y * hd * Np;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int d = (tid >> 4) + 16 * i, tl = (tid & 15) * 4;
+      if (d < hd && n0 + tl < Np)                    // (tokens >= N were loaded as zeros: the pad columns)
+        *reinterpret_cast<float4*>(dT + (int64_t)d * Np + n0 + tl) = make_float4(t[tl][d], t[tl + 1][d], t[tl + 2][d], t[tl + 3][d]);
+    }
+  }
+}
+
 // column sums of a tall matrix (the bias gradient db = sum_r dY[r, :]) in two deterministic stages: a workgroup takes 64 columns of a
 // 256-row chunk (its 4 waves interleave the rows, coalesced 256-byte segments), partial[chunk][col]; then one thread per column
 // adds the chunks in order
@@ -260,5 +320,28 @@ extern "C" int sp3_adamw_flat(float* p, const float* g, float* m, float* v, int6
                      reinterpret_cast<const float2*>(chunk_table), lr, beta1, beta2, eps, bc1, 1.0f / sqrtf(bc2), grad_scale_dev, grad_scale,
                      step_dev, lr_dev);
   SP3_LAUNCH_CHECK("sp3_adamw_flat");
+  return 0;
+}
+
+extern "C" int sp3_head_shuffle(const sp3_head_part* parts, int nparts, int B, int H, int hd, float base, void* stream) {
+  SP3_CHECK(parts && nparts >= 1 && nparts <= 3 && B > 0 && H > 0 && hd > 0 && hd <= 64 && hd % 4 == 0 && (int64_t)B * H <= 65535,
+            "sp3_head_shuffle: bad arguments (nparts=%d B=%d H=%d hd=%d)", nparts, B, H, hd);
+  HeadShuffleArgs a;
+  a.B = B; a.H = H; a.hd = hd; a.base = base;
+  int nmax = 0;
+  for (int i = 0; i < nparts; ++i) {
+    const sp3_head_part& p = parts[i];
+    SP3_CHECK(p.src && (p.dst || p.dstT) && p.N > 0, "sp3_head_shuffle: part %d: null pointer or N <= 0", i);
+    SP3_CHECK(((p.s_b | p.s_n | p.s_h) & 3) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 15) == 0, "sp3_head_shuffle: part %d: source not 16-byte aligned", i);
+    SP3_CHECK(!p.dst || ((((p.d_b | p.d_n | p.d_h) & 3) == 0) && (reinterpret_cast<uintptr_t>(p.dst) & 15) == 0),
+              "sp3_head_shuffle: part %d: destination not 16-byte aligned", i);
+    SP3_CHECK(!p.dstT || (reinterpret_cast<uintptr_t>(p.dstT) & 15) == 0, "sp3_head_shuffle: part %d: transposed destination not 16-byte aligned", i);
+    SP3_CHECK(!p.pos || (p.fwd == 1.0f || p.fwd == -1.0f), "sp3_head_shuffle: part %d: fwd must be +1 or -1", i);
+    a.p[i] = p;
+    nmax = p.N > nmax ? p.N : nmax;
+  }
+  for (int i = nparts; i < 3; ++i) a.p[i] = parts[0];
+  hipLaunchKernelGGL(head_shuffle_kernel, dim3((nmax + 63) / 64, B * H, nparts), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+  SP3_LAUNCH_CHECK("sp3_head_shuffle");
   return 0;
 }

@@ -46,6 +46,15 @@ class GemmDesc(C.Structure):
     ]
 
 
+class HeadPart(C.Structure):
+    """sp3_head_part (include/spann3r_hip.h)"""
+    _fields_ = [
+        ("src", C.c_void_p), ("s_b", C.c_int64), ("s_n", C.c_int64), ("s_h", C.c_int64),
+        ("dst", C.c_void_p), ("d_b", C.c_int64), ("d_n", C.c_int64), ("d_h", C.c_int64),
+        ("dstT", C.c_void_p), ("pos", C.c_void_p), ("N", C.c_int32), ("fwd", C.c_float),
+    ]
+
+
 class ReduceLnDesc(C.Structure):
     _fields_ = [
         ("partial", C.c_void_p), ("split_stride", C.c_int64), ("bias", C.c_void_p), ("res", C.c_void_p),
@@ -126,6 +135,9 @@ _PROTOS = {
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "sp3_transpose": [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p],
     "sp3_transpose_batched": [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "sp3_transpose_pad": [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "sp3_softmax_bwd_pad": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p],
+    "sp3_head_shuffle": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p],
     "sp3_gelu": [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
     "sp3_gelu_bwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
     "sp3_im2col3x3": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],

@@ -28,6 +28,7 @@ from . import ops
 
 
 PRECISION = "fp32"
+FUSED_HEADS = True    # attention through _MHA (one shuffle launch each way); False: the separate ATen reshapes + _Attention (tests compare the two)
 _wcache = {}          # id(weight) -> (version, packed W, packed W^T): refreshed when the optimizer has stepped
 
 
@@ -72,14 +73,28 @@ def _into_grad(p, compute):
     """Accumulate a parameter gradient straight into the flat-bucket view that IS p.grad (runner.GradReducer): `compute(out, acc)`
     writes (acc = False) or adds (acc = True) the gradient in place; the post-accumulate-grad hooks autograd would have run (the
     reducer's bucket bookkeeping) are run by hand.  Returns True when done (the caller then returns None to autograd)."""
-    if not (isinstance(p, torch.nn.Parameter) and p.grad is not None and p.grad.is_contiguous() and getattr(p, "_sp3_direct_grad", False)):
+    if not _direct_ok(p):
         return False
     compute(p.grad, True)
-    p._sp3_pending = getattr(p, "_sp3_pending", 1) - 1      # a weight used k times in the forward gets k contributions:
+    _contributed(p)
+    return True
+
+
+def _contributed(p):
+    p._sp3_pending = getattr(p, "_sp3_pending", 1) - 1      # a parameter used k times in the forward gets k contributions:
     if p._sp3_pending <= 0:                                 # the hooks run once, behind the last one (as AccumulateGrad does)
         for h in (p._post_accumulate_grad_hooks or {}).values():
             h(p)
-    return True
+
+
+def _direct_ok(p):
+    return isinstance(p, torch.nn.Parameter) and p.grad is not None and p.grad.is_contiguous() and getattr(p, "_sp3_direct_grad", False)
+
+
+def _expect(p):
+    """forward side of _into_grad: one more contribution to p.grad is owed by a backward of this tape"""
+    if isinstance(p, torch.nn.Parameter):
+        p._sp3_pending = getattr(p, "_sp3_pending", 0) + 1
 
 
 def _r8(n):
@@ -92,18 +107,28 @@ def _r64(n):
 
 def _transpose(src, rows, cols, ld_src, ld_dst=None):
     ld_dst = _r8(rows) if ld_dst is None else ld_dst
-    dst = torch.zeros(cols, ld_dst, device=src.device)
-    L.check(L.load().sp3_transpose(src.data_ptr(), ld_src, dst.data_ptr(), ld_dst, rows, cols, L.stream_ptr()), "sp3_transpose")
+    if ld_dst - rows >= 8:
+        dst = torch.zeros(cols, ld_dst, device=src.device)
+        L.check(L.load().sp3_transpose(src.data_ptr(), ld_src, dst.data_ptr(), ld_dst, rows, cols, L.stream_ptr()), "sp3_transpose")
+    else:                       # the kernel writes the (< 8) pad columns itself: no fill launch
+        dst = torch.empty(cols, ld_dst, device=src.device)
+        L.check(L.load().sp3_transpose_pad(src.data_ptr(), ld_src, 0, dst.data_ptr(), ld_dst, 0, rows, cols, 1, ld_dst, L.stream_ptr()), "sp3_transpose_pad")
     return dst
 
 
-def _ln_bwd(x, gamma, dy, dx_add, eps):
+def _ln_bwd(x, gamma, dy, dx_add, eps, direct=None):
+    """direct = (gamma parameter, beta parameter): their gradients are ADDED to the flat-bucket views (-> dx, None, None)"""
     rows, C = x.shape
     dx = torch.empty_like(x)
-    dg, db = torch.empty(C, device=x.device), torch.empty(C, device=x.device)
+    acc = direct is not None and _direct_ok(direct[0]) and _direct_ok(direct[1])
+    dg, db = (direct[0].grad, direct[1].grad) if acc else (torch.empty(C, device=x.device), torch.empty(C, device=x.device))
     scratch = torch.empty((rows + 3) // 4 * 2 * C, device=x.device)
     L.check(L.load().sp3_layernorm_bwd(x.data_ptr(), C, gamma.data_ptr(), dy.data_ptr(), dy.stride(0), L.ptr(dx_add), C, dx.data_ptr(), C,
-                                       dg.data_ptr(), db.data_ptr(), 0, scratch.data_ptr(), rows, C, eps, L.stream_ptr()), "sp3_layernorm_bwd")
+                                       dg.data_ptr(), db.data_ptr(), int(acc), scratch.data_ptr(), rows, C, eps, L.stream_ptr()), "sp3_layernorm_bwd")
+    if acc:
+        _contributed(direct[0])
+        _contributed(direct[1])
+        return dx, None, None
     return dx, dg, db
 
 
@@ -153,7 +178,7 @@ class _MemoryReadTrain(torch.autograd.Function):
         f32 = lambda *s: torch.empty(*s, device=dev)
         # dAd = dO . V_hat^T  ->  W[N = T, K = C] = V_hat (row-major): the transpose of the stored V_hat^T
         vh = _transpose(vht, C, T, Tp, ld_dst=C)                       # [T, C]
-        dAd = torch.zeros(P, Tp, device=dev)
+        dAd = f32(P, Tp)                                                # (columns [T, Tp) are never read)
         ops.gemm(dO, vh, dAd, M=P, N=T, K=C, lda=C, ldc=Tp)
         # dV_hat = Ad^T . dO  ->  A = Ad^T [T, Pp], W[N = C, K = Pp] = dO^T
         AdT = _transpose(Ad, P, T, Tp)                                  # [T, Pp] (pad columns zero)
@@ -161,9 +186,9 @@ class _MemoryReadTrain(torch.autograd.Function):
         dVh = f32(T, C)
         ops.gemm(AdT, dOT, dVh, M=T, N=C, K=Pp, lda=Pp, ldc=C)
         # softmax (+ dropout) backward, scaled by 1 / sqrt(C)
-        dS = torch.zeros(P, Tp, device=dev)
-        L.check(L.load().sp3_softmax_bwd(A.data_ptr(), dAd.data_ptr(), L.ptr(mask), dS.data_ptr(), Tp, P, T, ctx.alpha, L.stream_ptr()),
-                "sp3_softmax_bwd")
+        dS = f32(P, Tp)                                                 # (pad columns zeroed by the kernel)
+        L.check(L.load().sp3_softmax_bwd_pad(A.data_ptr(), dAd.data_ptr(), L.ptr(mask), dS.data_ptr(), Tp, P, T, Tp, ctx.alpha, L.stream_ptr()),
+                "sp3_softmax_bwd_pad")
         # dq_hat = dS . K_hat  ->  W[N = C, K = Tp] = K_hat^T ;  dK_hat = dS^T . q_hat  ->  A = dS^T [T, Pp], W[N = C, K = Pp] = q_hat^T
         khT = _transpose(kh, T, C, C)                                   # [C, Tp]
         dqh = f32(P, C)
@@ -212,9 +237,9 @@ def _nt(A, Bm, M, N, K, lda, ldb, out, ldc, bias=None, res=None, alpha=1.0, batc
 def _tb(src, rows, cols, ld_src, batch=1, stride_src=0):
     """batched transpose with the new row length padded to 8 (zeros): [batch, rows, cols] -> [batch, cols, r8(rows)]"""
     ldd = _r8(rows)
-    dst = torch.zeros(batch, cols, ldd, device=src.device)
-    L.check(L.load().sp3_transpose_batched(src.data_ptr(), ld_src, stride_src, dst.data_ptr(), ldd, cols * ldd, rows, cols, batch,
-                                           L.stream_ptr()), "sp3_transpose_batched")
+    dst = torch.empty(batch, cols, ldd, device=src.device)          # (pad columns zeroed by the kernel)
+    L.check(L.load().sp3_transpose_pad(src.data_ptr(), ld_src, stride_src, dst.data_ptr(), ldd, cols * ldd, rows, cols, batch, ldd,
+                                       L.stream_ptr()), "sp3_transpose_pad")
     return dst
 
 
@@ -238,6 +263,9 @@ class _Linear(torch.autograd.Function):
         y = torch.empty(R, N, device=x.device)
         ctx.has = (b is not None, res is not None, res2 is not None)
         ctx.bf16 = PRECISION == "bf16"
+        ctx.bparam = b if (b is not None and ctx.needs_input_grad[2] and isinstance(b, torch.nn.Parameter)) else None
+        if ctx.bparam is not None:
+            _expect(b)
         if ctx.bf16:
             # bf16 operands in fragment order; X^T is made in the same pass and is all the backward keeps of x
             need_t = ctx.needs_input_grad[1]
@@ -247,7 +275,7 @@ class _Linear(torch.autograd.Function):
             ctx.xT, ctx.WT, ctx.shape = xT, WT, (R, K, N)
             ctx.Wparam = W if (isinstance(W, torch.nn.Parameter) and W.dim() == 2) else None
             if ctx.Wparam is not None and need_t:
-                W._sp3_pending = getattr(W, "_sp3_pending", 0) + 1
+                _expect(W)
             return y
         xp, Wp = _pad8(x), _pad8(W)
         ops.gemm(xp, Wp, y, M=R, N=N, K=xp.shape[1], lda=xp.shape[1], ldc=N, ldw=Wp.shape[1], bias=b, res1=res, ldr1=N, res2=res2, ldr2=N)
@@ -286,7 +314,8 @@ class _Linear(torch.autograd.Function):
                 dyT, xT = _tb(dy, R, N, N)[0], _tb(x, R, K, K)[0]            # [N, r8(R)], [K, r8(R)]
                 dW = _nt(dyT, xT, N, K, dyT.shape[1], dyT.shape[1], xT.shape[1], torch.empty(N, K, device=dev), K)
         if ctx.has[0] and ctx.needs_input_grad[2]:
-            db = _colsum(dy)
+            if not _into_grad(ctx.bparam, lambda out, acc: _colsum(dy, out=out)):
+                db = _colsum(dy)
         return dx, dW, db, (dy if ctx.has[1] else None), (dy if ctx.has[2] else None), None
 
 
@@ -309,12 +338,17 @@ class _LayerNorm(torch.autograd.Function):
         ops.layernorm(x, g, b, eps, y, rows=R, C_=C_)
         ctx.save_for_backward(x, g)
         ctx.eps = eps
+        ctx.direct = None
+        if ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and isinstance(g, torch.nn.Parameter) and isinstance(b, torch.nn.Parameter):
+            ctx.direct = (g, b)
+            _expect(g)
+            _expect(b)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, g = ctx.saved_tensors
-        dx, dg, db = _ln_bwd(x, g, dy.contiguous(), None, ctx.eps)
+        dx, dg, db = _ln_bwd(x, g, dy.contiguous(), None, ctx.eps, ctx.direct)
         return dx, dg, db, None
 
 
@@ -350,7 +384,7 @@ class _Attention(torch.autograd.Function):
         Nk = k.shape[1]
         Nkp = _r8(Nk)
         dev = q.device
-        S = torch.zeros(BH, Nq, Nkp, device=dev)
+        S = torch.empty(BH, Nq, Nkp, device=dev)                          # (the softmax reads Nk columns and zeroes the pad of P)
         _nt(q, k, Nq, Nk, D, D, D, S, Nkp, alpha=scale, batch=BH, sA=Nq * D, sB=Nk * D, sC=Nq * Nkp)
         P = torch.empty_like(S)
         ops.softmax_thresh(S, P, ld=Nkp, rows=BH * Nq, M=Nk, Mpad=Nkp, thresh=0.0)
@@ -368,15 +402,15 @@ class _Attention(torch.autograd.Function):
         Nk, Nkp, Nqp = k.shape[1], P.shape[2], _r8(q.shape[1])
         dev = q.device
         dO = dO.contiguous()
-        dP = torch.zeros(BH, Nq, Nkp, device=dev)
+        dP = torch.empty(BH, Nq, Nkp, device=dev)
         _nt(dO, v, Nq, Nk, D, D, D, dP, Nkp, batch=BH, sA=Nq * D, sB=Nk * D, sC=Nq * Nkp)
         PT = _tb(P, Nq, Nk, Nkp, BH, Nq * Nkp)                           # [BH, Nk, Nqp]
         dOT = _tb(dO, Nq, D, D, BH, Nq * D)                              # [BH, D, Nqp]
         dV = torch.empty(BH, Nk, D, device=dev)
         _nt(PT, dOT, Nk, D, Nqp, Nqp, Nqp, dV, D, batch=BH, sA=Nk * Nqp, sB=D * Nqp, sC=Nk * D)
-        dS = torch.zeros(BH, Nq, Nkp, device=dev)
-        L.check(L.load().sp3_softmax_bwd(P.data_ptr(), dP.data_ptr(), None, dS.data_ptr(), Nkp, BH * Nq, Nk, ctx.scale, L.stream_ptr()),
-                "sp3_softmax_bwd")
+        dS = torch.empty(BH, Nq, Nkp, device=dev)
+        L.check(L.load().sp3_softmax_bwd_pad(P.data_ptr(), dP.data_ptr(), None, dS.data_ptr(), Nkp, BH * Nq, Nk, Nkp, ctx.scale, L.stream_ptr()),
+                "sp3_softmax_bwd_pad")
         kT = _tb(k, Nk, D, D, BH, Nk * D)                                # [BH, D, Nkp]
         dq = torch.empty(BH, Nq, D, device=dev)
         _nt(dS, kT, Nq, D, Nkp, Nkp, Nkp, dq, D, batch=BH, sA=Nq * Nkp, sB=D * Nkp, sC=Nq * D)
@@ -385,6 +419,105 @@ class _Attention(torch.autograd.Function):
         dk = torch.empty(BH, Nk, D, device=dev)
         _nt(dST, qT, Nk, D, Nqp, Nqp, Nqp, dk, D, batch=BH, sA=Nk * Nqp, sB=D * Nqp, sC=Nk * D)
         return dq, dk, dV, None
+
+
+def _head_shuffle(parts, B, H, hd, base):
+    """parts: up to three dicts (src, s = (s_b, s_n, s_h), N, and dst + d = (d_b, d_n, d_h) and / or dstT, pos, fwd): sp3_head_shuffle"""
+    arr = (L.HeadPart * len(parts))()
+    for a, p in zip(arr, parts):
+        a.src, (a.s_b, a.s_n, a.s_h), a.N = p["src"].data_ptr(), p["s"], p["N"]
+        dst, dstT, pos = p.get("dst"), p.get("dstT"), p.get("pos")
+        a.dst = L.ptr(dst)
+        if dst is not None:
+            a.d_b, a.d_n, a.d_h = p["d"]
+        a.dstT, a.pos, a.fwd = L.ptr(dstT), L.ptr(pos), float(p.get("fwd", 1.0))
+    L.check(L.load().sp3_head_shuffle(arr, len(parts), B, H, hd, float(base), L.stream_ptr()), "sp3_head_shuffle")
+
+
+class _MHA(torch.autograd.Function):
+    """Multi-head attention between the projections (croco/models/blocks.py:100-108 and :160-166): RoPE2D on q and k, the per-head
+    products, the head merge -- on the projections' own outputs.  Self-attention: a = qkv [B, N, 3C] (b = c = None); cross-attention:
+    a = q [B, Nq, C], b = k, c = v [B, Nk, C].  Forward: 1 shuffle + S GEMM + softmax + P.V GEMM + 1 shuffle; backward: 1 shuffle
+    (dO per head and transposed) + 4 GEMMs + 2 transposes + softmax backward + 1 shuffle (inverse RoPE, head merge into d qkv).
+    Saved for the backward: v, q^T, k^T per head and the probabilities."""
+
+    @staticmethod
+    def forward(ctx, a, b, c, posq, posk, heads, scale, base):
+        self_mode = b is None
+        a = a.contiguous()
+        if not self_mode:
+            b, c = b.contiguous(), c.contiguous()
+        B, Nq = a.shape[0], a.shape[1]
+        C_ = a.shape[2] // 3 if self_mode else a.shape[2]
+        Nk = Nq if self_mode else b.shape[1]
+        H, hd = heads, C_ // heads
+        BH, Nqp, Nkp = B * H, _r8(Nq), _r8(Nk)
+        dev = a.device
+        f32 = lambda *sh: torch.empty(*sh, device=dev)
+        need = any(ctx.needs_input_grad[:3])
+        q, k, v = f32(BH, Nq, hd), f32(BH, Nk, hd), f32(BH, Nk, hd)
+        qT, kT, vT = (f32(BH, hd, Nqp) if need else None), (f32(BH, hd, Nkp) if need else None), f32(BH, hd, Nkp)
+        if self_mode:
+            srcs = [(a, 0), (a, C_), (a, 2 * C_)]
+        else:
+            srcs = [(a, 0), (b, 0), (c, 0)]
+        parts = []
+        for (t, off), N, dst, dstT, pos in zip(srcs, (Nq, Nk, Nk), (q, k, v), (qT, kT, vT), (posq, posk, None)):
+            ld = t.shape[2]
+            parts.append(dict(src=t[0, 0, off:], s=(N * ld, ld, hd), N=N, dst=dst, d=(H * N * hd, hd, N * hd), dstT=dstT, pos=pos, fwd=1.0))
+        _head_shuffle(parts, B, H, hd, base)
+        S = f32(BH, Nq, Nkp)
+        _nt(q, k, Nq, Nk, hd, hd, hd, S, Nkp, alpha=scale, batch=BH, sA=Nq * hd, sB=Nk * hd, sC=Nq * Nkp)
+        P = S                                                              # in place: a thread reads and writes its own columns
+        ops.softmax_thresh(S, P, ld=Nkp, rows=BH * Nq, M=Nk, Mpad=Nkp, thresh=0.0)
+        O = f32(BH, Nq, hd)
+        _nt(P, vT, Nq, hd, Nkp, Nkp, Nkp, O, hd, batch=BH, sA=Nq * Nkp, sB=hd * Nkp, sC=Nq * hd)
+        out = f32(B, Nq, C_)
+        _head_shuffle([dict(src=O, s=(H * Nq * hd, hd, Nq * hd), N=Nq, dst=out, d=(Nq * C_, C_, hd))], B, H, hd, base)
+        if need:
+            ctx.save_for_backward(v, qT, kT, P, posq if posq is not None else torch.empty(0, device=dev), posk if posk is not None else torch.empty(0, device=dev))
+        ctx.geo = (self_mode, B, Nq, Nk, C_, H, hd, scale, base, a.shape[2], (None if self_mode else (b.shape[2], c.shape[2])))
+        return out
+
+    @staticmethod
+    def backward(ctx, dOm):
+        v, qT, kT, P, posq, posk = ctx.saved_tensors
+        self_mode, B, Nq, Nk, C_, H, hd, scale, base, lda, ldbc = ctx.geo
+        posq = posq if posq.numel() else None
+        posk = posk if posk.numel() else None
+        BH, Nqp, Nkp = B * H, _r8(Nq), _r8(Nk)
+        dev = dOm.device
+        f32 = lambda *sh: torch.empty(*sh, device=dev)
+        dOm = dOm.contiguous()
+        dO, dOT = f32(BH, Nq, hd), f32(BH, hd, Nqp)
+        _head_shuffle([dict(src=dOm, s=(Nq * C_, C_, hd), N=Nq, dst=dO, d=(H * Nq * hd, hd, Nq * hd), dstT=dOT)], B, H, hd, base)
+        dP = f32(BH, Nq, Nkp)
+        _nt(dO, v, Nq, Nk, hd, hd, hd, dP, Nkp, batch=BH, sA=Nq * hd, sB=Nk * hd, sC=Nq * Nkp)
+        PT = _tb(P, Nq, Nk, Nkp, BH, Nq * Nkp)                           # [BH, Nk, Nqp]
+        dV = f32(BH, Nk, hd)
+        _nt(PT, dOT, Nk, hd, Nqp, Nqp, Nqp, dV, hd, batch=BH, sA=Nk * Nqp, sB=hd * Nqp, sC=Nk * hd)
+        dS = dP                                                            # in place (same reasoning as the forward softmax)
+        L.check(L.load().sp3_softmax_bwd_pad(P.data_ptr(), dP.data_ptr(), None, dS.data_ptr(), Nkp, BH * Nq, Nk, Nkp, scale, L.stream_ptr()),
+                "sp3_softmax_bwd_pad")
+        dq = f32(BH, Nq, hd)
+        _nt(dS, kT, Nq, hd, Nkp, Nkp, Nkp, dq, hd, batch=BH, sA=Nq * Nkp, sB=hd * Nkp, sC=Nq * hd)
+        dST = _tb(dS, Nq, Nk, Nkp, BH, Nq * Nkp)                         # [BH, Nk, Nqp]
+        dk = f32(BH, Nk, hd)
+        _nt(dST, qT, Nk, hd, Nqp, Nqp, Nqp, dk, hd, batch=BH, sA=Nk * Nqp, sB=hd * Nqp, sC=Nk * hd)
+        if self_mode:
+            da = f32(B, Nq, 3 * C_)
+            dsts = [(da, 0), (da, C_), (da, 2 * C_)]
+        else:
+            da, db, dc = f32(B, Nq, C_), f32(B, Nk, C_), f32(B, Nk, C_)
+            dsts = [(da, 0), (db, 0), (dc, 0)]
+        parts = []
+        for (t, off), N, src, pos in zip(dsts, (Nq, Nk, Nk), (dq, dk, dV), (posq, posk, None)):
+            ld = t.shape[2]
+            parts.append(dict(src=src, s=(H * N * hd, hd, N * hd), N=N, dst=t[0, 0, off:], d=(N * ld, ld, hd), pos=pos, fwd=-1.0))
+        _head_shuffle(parts, B, H, hd, base)
+        if self_mode:
+            return da, None, None, None, None, None, None, None
+        return da, db, dc, None, None, None, None, None
 
 
 def _heads(t, B, N, H, pos, base):
@@ -400,11 +533,15 @@ def _heads(t, B, N, H, pos, base):
 def self_attention(x, pos, P, pre, heads, base=100.0, use_rope=True, res=None):
     """croco/models/blocks.py:94-112; P: dict of parameters, pre: key prefix ('...attn.'); res is added by the projection"""
     B, N, C_ = x.shape
-    qkv = linear(x, P[pre + "qkv.weight"], P[pre + "qkv.bias"]).reshape(B, N, 3, C_)
+    qkv = linear(x, P[pre + "qkv.weight"], P[pre + "qkv.bias"])
     rp = pos if use_rope else None
-    q, k, v = _heads(qkv[:, :, 0], B, N, heads, rp, base), _heads(qkv[:, :, 1], B, N, heads, rp, base), _heads(qkv[:, :, 2], B, N, heads, None, base)
-    o = _Attention.apply(q, k, v, (C_ // heads) ** -0.5)
-    o = o.reshape(B, heads, N, C_ // heads).permute(0, 2, 1, 3).reshape(B, N, C_)
+    if FUSED_HEADS:
+        o = _MHA.apply(qkv, None, None, rp, rp, heads, (C_ // heads) ** -0.5, base)
+    else:
+        qkv = qkv.reshape(B, N, 3, C_)
+        q, k, v = _heads(qkv[:, :, 0], B, N, heads, rp, base), _heads(qkv[:, :, 1], B, N, heads, rp, base), _heads(qkv[:, :, 2], B, N, heads, None, base)
+        o = _Attention.apply(q, k, v, (C_ // heads) ** -0.5)
+        o = o.reshape(B, heads, N, C_ // heads).permute(0, 2, 1, 3).reshape(B, N, C_)
     return linear(o, P[pre + "proj.weight"], P[pre + "proj.bias"], res)
 
 
@@ -412,11 +549,15 @@ def cross_attention(xq, y, qpos, kpos, P, pre, heads, base=100.0, res=None):
     """croco/models/blocks.py:149-169"""
     B, Nq, C_ = xq.shape
     Nk = y.shape[1]
-    q = _heads(linear(xq, P[pre + "projq.weight"], P[pre + "projq.bias"]), B, Nq, heads, qpos, base)
-    k = _heads(linear(y, P[pre + "projk.weight"], P[pre + "projk.bias"]), B, Nk, heads, kpos, base)
-    v = _heads(linear(y, P[pre + "projv.weight"], P[pre + "projv.bias"]), B, Nk, heads, None, base)
-    o = _Attention.apply(q, k, v, (C_ // heads) ** -0.5)
-    o = o.reshape(B, heads, Nq, C_ // heads).permute(0, 2, 1, 3).reshape(B, Nq, C_)
+    q = linear(xq, P[pre + "projq.weight"], P[pre + "projq.bias"])
+    k = linear(y, P[pre + "projk.weight"], P[pre + "projk.bias"])
+    v = linear(y, P[pre + "projv.weight"], P[pre + "projv.bias"])
+    if FUSED_HEADS:
+        o = _MHA.apply(q, k, v, qpos, kpos, heads, (C_ // heads) ** -0.5, base)
+    else:
+        q, k, v = _heads(q, B, Nq, heads, qpos, base), _heads(k, B, Nk, heads, kpos, base), _heads(v, B, Nk, heads, None, base)
+        o = _Attention.apply(q, k, v, (C_ // heads) ** -0.5)
+        o = o.reshape(B, heads, Nq, C_ // heads).permute(0, 2, 1, 3).reshape(B, Nq, C_)
     return linear(o, P[pre + "proj.weight"], P[pre + "proj.bias"], res)
 
 

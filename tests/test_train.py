@@ -95,13 +95,100 @@ def _block_params(C, seed, cross, dtype, device):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,N,H,hd,rope", [(2, 196, 3, 64, True), (1, 37, 2, 64, True), (3, 70, 4, 48, False), (2, 64, 1, 64, True)])
+def test_head_shuffle_split_rope_transpose_and_merge(B, N, H, hd, rope):
+    """sp3_head_shuffle: [B, N, 3C] -> per-head q, k (RoPE2D), v and their transposes (pad columns zero) in one launch; the
+    backward direction (inverse rotation, merge) is its exact transpose"""
+    from spann3r_amd import train as T
+    from oracle import spann3r_oracle as O
+    C = H * hd
+    g = torch.Generator().manual_seed(N)
+    qkv = torch.randn(B, N, 3 * C, generator=g)
+    nh = 7 if N % 7 == 0 else 1
+    pos = O.positions(B, nh, N // nh)
+    Np = (N + 7) // 8 * 8
+    outs, outsT = [], []
+    parts = []
+    dev_qkv, dev_pos = qkv.cuda(), pos.cuda()
+    for i in range(3):
+        dst = torch.full((B * H, N, hd), float("nan"), device="cuda")
+        dstT = torch.full((B * H, hd, Np), float("nan"), device="cuda")
+        outs.append(dst); outsT.append(dstT)
+        parts.append(dict(src=dev_qkv[0, 0, i * C:], s=(N * 3 * C, 3 * C, hd), N=N, dst=dst, d=(H * N * hd, hd, N * hd), dstT=dstT,
+                          pos=dev_pos if (rope and i < 2) else None, fwd=1.0))
+    T._head_shuffle(parts, B, H, hd, 100.0)
+    for i in range(3):
+        ref = qkv[:, :, i * C:(i + 1) * C].reshape(B, N, H, hd).permute(0, 2, 1, 3).double()        # [B, H, N, hd]
+        if rope and i < 2:
+            ref = O.rope2d(ref, pos, 100.0)
+        ref = ref.reshape(B * H, N, hd)
+        assert rel_err(outs[i].cpu(), ref) < 1e-6
+        tT = outsT[i].cpu()
+        assert torch.equal(tT[:, :, :N], outs[i].cpu().transpose(1, 2)) and float(tT[:, :, N:].abs().sum()) == 0.0
+    # merge with the inverse rotation undoes the split exactly up to rounding
+    back = torch.full((B, N, 3 * C), float("nan"), device="cuda")
+    parts = [dict(src=outs[i], s=(H * N * hd, hd, N * hd), N=N, dst=back[0, 0, i * C:], d=(N * 3 * C, 3 * C, hd),
+                  pos=dev_pos if (rope and i < 2) else None, fwd=-1.0) for i in range(3)]
+    T._head_shuffle(parts, B, H, hd, 100.0)
+    assert rel_err(back.cpu(), qkv) < 1e-6
+
+
+@pytest.mark.gpu
+def test_transpose_and_softmax_backward_write_their_pads():
+    from spann3r_amd import train as T
+    from spann3r_amd import lib as L
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(5, 197, 50, generator=g).cuda()
+    t = T._tb(x, 197, 50, 50, 5, 197 * 50)
+    assert t.shape == (5, 50, 200) and torch.equal(t[:, :, :197], x.transpose(1, 2)) and float(t[:, :, 197:].abs().sum()) == 0.0
+    t2 = T._transpose(x[0], 197, 50, 50)
+    assert torch.equal(t2, t[0])
+    A = torch.softmax(torch.randn(40, 197, generator=g), -1)
+    dA = torch.randn(40, 197, generator=g)
+    Ap, dAp = torch.zeros(40, 200), torch.zeros(40, 200)
+    Ap[:, :197], dAp[:, :197] = A, dA
+    dS = torch.full((40, 200), float("nan"), device="cuda")
+    L.check(L.load().sp3_softmax_bwd_pad(Ap.cuda().data_ptr(), dAp.cuda().data_ptr(), None, dS.data_ptr(), 200, 40, 197, 200, 0.5, L.stream_ptr()), "x")
+    ref = 0.5 * A.double() * (dA.double() - (dA.double() * A.double()).sum(-1, keepdim=True))
+    assert rel_err(dS[:, :197].cpu(), ref) < 1e-5 and float(dS[:, 197:].abs().sum()) == 0.0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cross", [False, True])
-def test_vit_blocks_forward_backward(cross):
+def test_fused_heads_match_the_separate_reshapes(cross):
+    """_MHA (one shuffle launch each way) against the ATen reshapes + _Attention it replaces: same GEMMs, same values"""
+    from spann3r_amd import train as T
+    from oracle import spann3r_oracle as O
+    B, nh, nw, C, H = 2, 14, 14, 192, 3
+    N = nh * nw
+    g = torch.Generator().manual_seed(5)
+    x0, y0, d0 = torch.randn(B, N, C, generator=g), torch.randn(B, N + 5, C, generator=g), torch.randn(B, N, C, generator=g)
+    pos = O.positions(B, nh, nw).cuda()
+    ypos = torch.cat((pos, pos[:, :5]), 1).contiguous()
+    res = {}
+    try:
+        for fused in (True, False):
+            T.FUSED_HEADS = fused
+            P = _block_params(C, 3, cross, torch.float32, "cuda")
+            x, y = x0.cuda().requires_grad_(True), y0.cuda().requires_grad_(True)
+            out = T.decoder_block(x, y, pos, ypos, P, "b.", H) if cross else T.block(x, pos, P, "b.", H)
+            out.backward(d0.cuda())
+            res[fused] = (out.detach(), {**{k: v.grad for k, v in P.items()}, "x": x.grad, **({"y": y.grad} if cross else {})})
+    finally:
+        T.FUSED_HEADS = True
+    assert rel_err(res[True][0], res[False][0]) < 1e-6
+    worst = max((rel_err(res[True][1][k], v), k) for k, v in res[False][1].items())
+    assert worst[0] < 2e-6, worst
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cross,grid", [(False, (5, 7)), (True, (5, 7)), (False, (14, 14)), (True, (14, 14))])
+def test_vit_blocks_forward_backward(cross, grid):
     """Block / DecoderBlock (croco/models/blocks.py:127-130,186-191) in train mode: HIP forward and backward against the
     oracle's functional block in float64 + autograd"""
     from spann3r_amd import train as T
     from oracle import spann3r_oracle as O
-    B, nh, nw, C, H = 2, 5, 7, 128, 2                     # head_dim 64: the RoPE kernel's geometry
+    B, (nh, nw), C, H = 2, grid, 128, 2                   # head_dim 64: the RoPE kernel's geometry
     N = nh * nw
     g = torch.Generator().manual_seed(1)
     x0, y0, d0 = torch.randn(B, N, C, generator=g), torch.randn(B, N + 5, C, generator=g), torch.randn(B, N, C, generator=g)
