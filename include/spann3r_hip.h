@@ -431,7 +431,7 @@ int sp3_softmax_bwd_pad(const float* A, const float* dAd, const float* mask, flo
  * tensors (q, k, v / dq, dk, dv) in ONE launch.  A part reads element (b, n, h, d) at src + b*s_b + n*s_n + h*s_h + d, rotates the
  * token by RoPE2D (pos != NULL: int64 [B*N, 2] (y, x) positions; fwd = +1: croco/models/pos_embed.py:96-157 forward, fwd = -1: its
  * transpose = the backward), and writes it to dst + b*d_b + n*d_n + h*d_h + d (dst nullable) and to the per-head transpose
- * dstT [B*H][hd][r8(N)] (nullable; pad columns zero), which is the W operand of the A . W^T GEMMs contracted over tokens.
+ * dstT [B*H][hd][ldT] (nullable; pad columns zero), which is the W operand of the A . W^T GEMMs contracted over tokens.
  * hd <= 64, hd % 4 == 0; every stride a multiple of 4 elements, pointers 16-byte aligned. */
 typedef struct sp3_head_part {
   const float* src;
@@ -442,8 +442,34 @@ typedef struct sp3_head_part {
   const int64_t* pos;
   int32_t N;
   float fwd;
+  int64_t ldT;          /* row length of dstT; columns [N, ldT) are zeroed; 0: N rounded up to 8; at most N rounded up to 64 */
 } sp3_head_part;
 int sp3_head_shuffle(const sp3_head_part* parts, int nparts, int B, int H, int hd, float rope_base, void* stream);
+/* Attention of the train-mode blocks (croco/models/blocks.py:100-108, :160-166: softmax(q k^T * scale) v per head, head_dim 64) as
+ * flash-style kernels with a backward -- what torch's autograd derives for those lines, without materialising the attention matrix.
+ *   forward : sp3_attention's kernel on fp32 operands (q, k already rotated; vt = per-head V^T [B*heads][64][vt_ld], zero padded to a
+ *             multiple of 64 keys), also leaving lse[b*heads + h][query] = log sum_j exp(s_j) for the backward;
+ *   backward: dq, dk, dv from (q, k, v, out, d out, lse) with the probabilities recomputed; two launches (16 queries / 16 keys per
+ *             workgroup); the per-head transposes qT, doT [B*heads][64][ldTq] and kT [..][ldTk] (sp3_head_shuffle) feed the products
+ *             contracted over tokens; D is a [B*heads][Nq] scratch (rowsum(d out (.) out)).
+ * bf16_products: 0 = exact fp32 MFMA, 1 = operands rounded to bf16 into one bf16 MFMA per product (fp32 accumulation, bf16 training).
+ * Element (b, n, h, d) of q / k / v / out / dout / dq / dk / dv is at p + b*s + n*ld + h*64 + d (strides in elements, multiples of 4). */
+int sp3_attention_train_fwd(const float* q, int64_t sq, int64_t ldq, const float* k, int64_t sk, int64_t ldk, const float* vt, int64_t vt_ld,
+                            float* out, int64_t ldo, float* lse, int B, int heads, int Nq, int Nk, float scale, int bf16_products, void* stream);
+typedef struct sp3_attn_bwd_desc {
+  const float *q, *k, *v, *o, *dout;
+  int64_t sq, ldq, sk, ldk, sv, ldv, so, ldo, sdo, lddo;
+  const float *qT, *kT, *doT;
+  int64_t ldTq, ldTk;
+  const float* lse;
+  float* D;
+  float *dq, *dk, *dv;
+  int64_t sdq, lddq, sdk, lddk, sdv, lddv;
+  int32_t B, heads, Nq, Nk;
+  float scale;
+  int32_t bf16_products;
+} sp3_attn_bwd_desc;
+int sp3_attention_train_bwd(const sp3_attn_bwd_desc* d, void* stream);
 int sp3_layernorm_bwd(const float* x, int64_t ldx, const float* gamma, const float* dy, int64_t ldy, const float* dx_add, int64_t ld_add,
                       float* dx, int64_t ld_dx, float* dgamma, float* dbeta, int accumulate, float* scratch, int rows, int C, float eps,
                       void* stream);

@@ -221,12 +221,45 @@ template <> struct AttnT<F16X3> {
   }
 };
 
+// fp32 operands rounded to bf16 on the way into ONE bf16 MFMA per product (training in "bf16" precision: what bf16 autocast computes)
+struct BF16X1 {};
+template <> struct AttnT<BF16X1> {
+  using Store = float;
+  struct QReg { bf16x8 v[2]; };
+  static __device__ __forceinline__ void loadQ(QReg& r, const float* row, int g) {
+    const float4* p = reinterpret_cast<const float4*>(row + 16 * g);
+    r.v[0] = cvt8(p[0], p[1]);
+    r.v[1] = cvt8(p[2], p[3]);
+  }
+  static __device__ __forceinline__ f32x4 qk(const float* krow, int g, const QReg& q) {
+    const float4* p = reinterpret_cast<const float4*>(krow + 16 * g);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cvt8(p[0], p[1]), q.v[0], s, 0, 0, 0);
+    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cvt8(p[2], p[3]), q.v[1], s, 0, 0, 0);
+    return s;
+  }
+  static __device__ __forceinline__ void pv(f32x4 (&o)[4], const float* vt_head, int64_t vt_ld, int kbase, int g, int dl,
+                                            const f32x4 (&p)[4]) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      bf16x8 pb;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pb[j] = (__bf16)p[2 * u + (j >> 2)][j & 3];
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        const float* vr = vt_head + (int64_t)(db * 16 + dl) * vt_ld + kbase + 32 * u + 4 * g;
+        o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cvt8(*reinterpret_cast<const float4*>(vr), *reinterpret_cast<const float4*>(vr + 16)), pb, o[db], 0, 0, 0);
+      }
+    }
+  }
+};
+
 template <typename TT>
 __global__ __launch_bounds__(256) void attention_kernel(const typename AttnT<TT>::Store* __restrict__ Q, int64_t sq, int64_t ldq,
                                                        const typename AttnT<TT>::Store* __restrict__ K, int64_t sk, int64_t ldk,
                                                        const typename AttnT<TT>::Store* __restrict__ VT, int64_t vt_ld, void* __restrict__ O,
                                                        int64_t ldo, int out_bf16, int out_packed, int heads, int Nq, int Nk,
-                                                       float scale) {
+                                                       float scale, float* __restrict__ lse) {
   using A = AttnT<TT>;
   using T = typename A::Store;
   __shared__ float sh_o[4][4][64][4];   // [wave][db][lane][r]
@@ -308,6 +341,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const typename AttnT<TT>
     acc.x += ow.x * sc; acc.y += ow.y * sc; acc.z += ow.z * sc; acc.w += ow.w * sc;
   }
   const float inv = 1.0f / L;
+  if (lse && wave == 0 && g == 0 && q0 + ql < Nq) lse[(int64_t)(b * heads + h) * Nq + q0 + ql] = M + logf(L);   // (training: the backward's softmax)
   if (q0 + ql < Nq) {
     const int row = b * Nq + q0 + ql;
     const int col = h * 64 + db * 16 + 4 * g;
@@ -467,6 +501,153 @@ __global__ __launch_bounds__(256) void attention_packed_kernel(const __bf16* __r
   }
 }
 
+
+// ------------------------------------------------------------------ training: the backward of softmax(q k^T * scale) v
+// Same register layout as the forward (a lane owns one row of the 16-row block its workgroup works on; the other axis is streamed
+// in 64-row tiles, one tile per wave per round, partial sums merged through LDS), probabilities recomputed from the saved
+// log-sum-exp:   P = exp(S - lse),  dP = dO V^T,  dS = P (.) (dP - D) * scale,  D = rowsum(dO (.) O),
+//   dq = dS k   (workgroup = 16 queries; streams k, v rows and k^T),
+//   dk = dS^T q, dv = P^T dO   (workgroup = 16 keys; streams q, dO rows and q^T, dO^T).
+// Every product is one of the forward's two MFMA forms (AttnT::qk: rows x registers contracted over the head dimension;
+// AttnT::pv: transposed stream x register tile contracted over the streamed axis), so the precision modes are the forward's.
+struct AttnBwdArgs {
+  const float *q, *k, *v, *o, *dout;           // [B][N][..]: element (b, n, h, d) at p + b*s + n*ld + h*64 + d
+  int64_t sq, ldq, sk, ldk, sv, ldv, so, ldo, sdo, lddo;
+  const float *qT, *kT, *doT;                  // [B*heads][64][ldT]: per-head transposes, zero padded to a multiple of 64 rows of the other axis
+  int64_t ldTq, ldTk;
+  const float* lse;                            // [B*heads][Nq]
+  float* D;                                    // [B*heads][Nq] (written by the dq kernel, read by the dk / dv kernel)
+  float *dq, *dk, *dv;
+  int64_t sdq, lddq, sdk, lddk, sdv, lddv;
+  int heads, Nq, Nk;
+  float scale;
+};
+
+template <typename TT>
+__global__ __launch_bounds__(256) void attention_bwd_dq_kernel(AttnBwdArgs a) {
+  using A = AttnT<TT>;
+  __shared__ float sh_o[4][4][64][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, ql = lane & 15;
+  const int h = blockIdx.y, b = blockIdx.z, q0 = blockIdx.x * 16;
+  const int Nq = a.Nq, Nk = a.Nk;
+  const int qrow = min(q0 + ql, Nq - 1);
+  const int64_t bh = (int64_t)b * a.heads + h;
+  typename A::QReg qreg, doreg;
+  const float* dorow = a.dout + (int64_t)b * a.sdo + (int64_t)qrow * a.lddo + h * 64;
+  A::loadQ(qreg, a.q + (int64_t)b * a.sq + (int64_t)qrow * a.ldq + h * 64, g);
+  A::loadQ(doreg, dorow, g);
+  float Dq = 0.f;
+  {
+    const float4* po = reinterpret_cast<const float4*>(a.o + (int64_t)b * a.so + (int64_t)qrow * a.ldo + h * 64 + 16 * g);
+    const float4* pd = reinterpret_cast<const float4*>(dorow + 16 * g);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 x = po[i], y = pd[i];
+      Dq += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
+    }
+    Dq += __shfl_xor(Dq, 16);
+    Dq += __shfl_xor(Dq, 32);
+  }
+  const float lq = a.lse[bh * Nq + qrow];
+  const float* kbase = a.k + (int64_t)b * a.sk + h * 64;
+  const float* vbase = a.v + (int64_t)b * a.sv + h * 64;
+  const float* kT = a.kT + bh * 64 * a.ldTk;
+  f32x4 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int kb = wave * 64; kb < Nk; kb += 256) {
+    f32x4 ds[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int krow = min(kb + 16 * t + ql, Nk - 1);
+      const f32x4 s = A::qk(kbase + (int64_t)krow * a.ldk, g, qreg);
+      const f32x4 dp = A::qk(vbase + (int64_t)krow * a.ldv, g, doreg);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kb + 16 * t + 4 * g + r;
+        const float p = key < Nk ? expf(s[r] * a.scale - lq) : 0.f;
+        ds[t][r] = p * (dp[r] - Dq) * a.scale;
+      }
+    }
+    A::pv(acc, kT, a.ldTk, kb, g, ql, ds);
+  }
+#pragma unroll
+  for (int db = 0; db < 4; ++db)
+    *reinterpret_cast<float4*>(&sh_o[wave][db][lane][0]) = make_float4(acc[db][0], acc[db][1], acc[db][2], acc[db][3]);
+  __syncthreads();
+  const int db = wave;
+  float4 sum = *reinterpret_cast<const float4*>(&sh_o[0][db][lane][0]);
+#pragma unroll
+  for (int w = 1; w < 4; ++w) {
+    const float4 x = *reinterpret_cast<const float4*>(&sh_o[w][db][lane][0]);
+    sum.x += x.x; sum.y += x.y; sum.z += x.z; sum.w += x.w;
+  }
+  if (q0 + ql < Nq) {
+    *reinterpret_cast<float4*>(a.dq + (int64_t)b * a.sdq + (int64_t)(q0 + ql) * a.lddq + h * 64 + db * 16 + 4 * g) = sum;
+    if (wave == 0 && g == 0) a.D[bh * Nq + q0 + ql] = Dq;
+  }
+}
+
+template <typename TT>
+__global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(AttnBwdArgs a) {
+  using A = AttnT<TT>;
+  __shared__ float sh_k[4][4][64][4], sh_v[4][4][64][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, kl = lane & 15;
+  const int h = blockIdx.y, b = blockIdx.z, k0 = blockIdx.x * 16;
+  const int Nq = a.Nq, Nk = a.Nk;
+  const int krow = min(k0 + kl, Nk - 1);
+  const int64_t bh = (int64_t)b * a.heads + h;
+  typename A::QReg kreg, vreg;
+  A::loadQ(kreg, a.k + (int64_t)b * a.sk + (int64_t)krow * a.ldk + h * 64, g);
+  A::loadQ(vreg, a.v + (int64_t)b * a.sv + (int64_t)krow * a.ldv + h * 64, g);
+  const float* qbase = a.q + (int64_t)b * a.sq + h * 64;
+  const float* dobase = a.dout + (int64_t)b * a.sdo + h * 64;
+  const float* qT = a.qT + bh * 64 * a.ldTq;
+  const float* doT = a.doT + bh * 64 * a.ldTq;
+  const float* lse = a.lse + bh * Nq;
+  const float* Dv = a.D + bh * Nq;
+  f32x4 acck[4], accv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { acck[i] = f32x4{0.f, 0.f, 0.f, 0.f}; accv[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  for (int qb = wave * 64; qb < Nq; qb += 256) {
+    f32x4 pt[4], ds[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int qrow = min(qb + 16 * t + kl, Nq - 1);
+      const f32x4 s = A::qk(qbase + (int64_t)qrow * a.ldq, g, kreg);          // [query 16t+4g+r][key kl]
+      const f32x4 dp = A::qk(dobase + (int64_t)qrow * a.lddo, g, vreg);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qi = qb + 16 * t + 4 * g + r;
+        const int qc = min(qi, Nq - 1);
+        const float p = qi < Nq ? expf(s[r] * a.scale - lse[qc]) : 0.f;
+        pt[t][r] = p;
+        ds[t][r] = p * (dp[r] - Dv[qc]) * a.scale;
+      }
+    }
+    A::pv(accv, doT, a.ldTq, qb, g, kl, pt);       // dv^T[d][key] += dO^T[d][query] P[query][key]
+    A::pv(acck, qT, a.ldTq, qb, g, kl, ds);        // dk^T[d][key] += q^T[d][query] dS[query][key]
+  }
+#pragma unroll
+  for (int db = 0; db < 4; ++db) {
+    *reinterpret_cast<float4*>(&sh_k[wave][db][lane][0]) = make_float4(acck[db][0], acck[db][1], acck[db][2], acck[db][3]);
+    *reinterpret_cast<float4*>(&sh_v[wave][db][lane][0]) = make_float4(accv[db][0], accv[db][1], accv[db][2], accv[db][3]);
+  }
+  __syncthreads();
+  const int db = wave;
+  float4 sk_ = *reinterpret_cast<const float4*>(&sh_k[0][db][lane][0]), sv_ = *reinterpret_cast<const float4*>(&sh_v[0][db][lane][0]);
+#pragma unroll
+  for (int w = 1; w < 4; ++w) {
+    const float4 x = *reinterpret_cast<const float4*>(&sh_k[w][db][lane][0]), y = *reinterpret_cast<const float4*>(&sh_v[w][db][lane][0]);
+    sk_.x += x.x; sk_.y += x.y; sk_.z += x.z; sk_.w += x.w;
+    sv_.x += y.x; sv_.y += y.y; sv_.z += y.z; sv_.w += y.w;
+  }
+  if (k0 + kl < Nk) {
+    *reinterpret_cast<float4*>(a.dk + (int64_t)b * a.sdk + (int64_t)(k0 + kl) * a.lddk + h * 64 + db * 16 + 4 * g) = sk_;
+    *reinterpret_cast<float4*>(a.dv + (int64_t)b * a.sdv + (int64_t)(k0 + kl) * a.lddv + h * 64 + db * 16 + 4 * g) = sv_;
+  }
+}
+
 }  // namespace
 
 extern "C" int sp3_attention_ex(const void* q, int64_t sq, int64_t ldq, const void* k, int64_t sk, int64_t ldk, const void* vt,
@@ -483,19 +664,19 @@ extern "C" int sp3_attention_ex(const void* q, int64_t sq, int64_t ldq, const vo
   if (dtype == SP3_BF16)
     hipLaunchKernelGGL(attention_kernel<__bf16>, grid, dim3(256), 0, st, reinterpret_cast<const __bf16*>(q), sq, ldq,
                        reinterpret_cast<const __bf16*>(k), sk, ldk, reinterpret_cast<const __bf16*>(vt), vt_ld, out, ldo,
-                       out_bf16, out_packed, heads, Nq, Nk, scale);
+                       out_bf16, out_packed, heads, Nq, Nk, scale, (float*)nullptr);
   else if (dtype == 3)
     hipLaunchKernelGGL(attention_kernel<F16X3>, grid, dim3(256), 0, st, reinterpret_cast<const float*>(q), sq, ldq,
                        reinterpret_cast<const float*>(k), sk, ldk, reinterpret_cast<const float*>(vt), vt_ld, out, ldo, out_bf16,
-                       out_packed, heads, Nq, Nk, scale);
+                       out_packed, heads, Nq, Nk, scale, (float*)nullptr);
   else if (dtype == 2)
     hipLaunchKernelGGL(attention_kernel<F32X3>, grid, dim3(256), 0, st, reinterpret_cast<const float*>(q), sq, ldq,
                        reinterpret_cast<const float*>(k), sk, ldk, reinterpret_cast<const float*>(vt), vt_ld, out, ldo, out_bf16,
-                       out_packed, heads, Nq, Nk, scale);
+                       out_packed, heads, Nq, Nk, scale, (float*)nullptr);
   else
     hipLaunchKernelGGL(attention_kernel<float>, grid, dim3(256), 0, st, reinterpret_cast<const float*>(q), sq, ldq,
                        reinterpret_cast<const float*>(k), sk, ldk, reinterpret_cast<const float*>(vt), vt_ld, out, ldo, out_bf16,
-                       out_packed, heads, Nq, Nk, scale);
+                       out_packed, heads, Nq, Nk, scale, (float*)nullptr);
   SP3_LAUNCH_CHECK("sp3_attention");
   return 0;
 }
@@ -521,5 +702,50 @@ extern "C" int sp3_attention_packed(const void* qp, int q_cols, int q_col0, int 
                      npad_k, reinterpret_cast<const __bf16*>(vtp), out, ldo, out_bf16, out_packed, heads, Nq, Nk, scale, o_group,
                      o_group_rows);
   SP3_LAUNCH_CHECK("sp3_attention_packed");
+  return 0;
+}
+
+extern "C" int sp3_attention_train_fwd(const float* q, int64_t sq, int64_t ldq, const float* k, int64_t sk, int64_t ldk, const float* vt,
+                                       int64_t vt_ld, float* out, int64_t ldo, float* lse, int B, int heads, int Nq, int Nk, float scale,
+                                       int bf16_products, void* stream) {
+  SP3_CHECK(q && k && vt && out && lse, "sp3_attention_train_fwd: null pointer");
+  SP3_CHECK(B > 0 && heads > 0 && Nq > 0 && Nk > 0 && B <= 65535 && heads <= 65535, "sp3_attention_train_fwd: bad shape");
+  SP3_CHECK(vt_ld >= ((Nk + 63) / 64) * 64 && vt_ld % 8 == 0, "sp3_attention_train_fwd: vt_ld=%lld must be >= Nk padded to 64", (long long)vt_ld);
+  SP3_CHECK(ldq % 4 == 0 && ldk % 4 == 0 && ldo % 4 == 0 && sq % 4 == 0 && sk % 4 == 0, "sp3_attention_train_fwd: strides must keep 16-byte alignment");
+  dim3 grid((Nq + 15) / 16, heads, B);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (bf16_products)
+    hipLaunchKernelGGL(attention_kernel<BF16X1>, grid, dim3(256), 0, st, q, sq, ldq, k, sk, ldk, vt, vt_ld, (void*)out, ldo, 0, 0, heads, Nq, Nk, scale, lse);
+  else
+    hipLaunchKernelGGL(attention_kernel<float>, grid, dim3(256), 0, st, q, sq, ldq, k, sk, ldk, vt, vt_ld, (void*)out, ldo, 0, 0, heads, Nq, Nk, scale, lse);
+  SP3_LAUNCH_CHECK("sp3_attention_train_fwd");
+  return 0;
+}
+
+extern "C" int sp3_attention_train_bwd(const sp3_attn_bwd_desc* d, void* stream) {
+  SP3_CHECK(d && d->q && d->k && d->v && d->o && d->dout && d->qT && d->kT && d->doT && d->lse && d->D && d->dq && d->dk && d->dv,
+            "sp3_attention_train_bwd: null pointer");
+  SP3_CHECK(d->B > 0 && d->heads > 0 && d->Nq > 0 && d->Nk > 0 && d->B <= 65535 && d->heads <= 65535, "sp3_attention_train_bwd: bad shape");
+  SP3_CHECK(d->ldTq >= ((d->Nq + 63) / 64) * 64 && d->ldTk >= ((d->Nk + 63) / 64) * 64 && d->ldTq % 4 == 0 && d->ldTk % 4 == 0,
+            "sp3_attention_train_bwd: the transposed operands must be padded to a multiple of 64 (ldTq=%lld ldTk=%lld)", (long long)d->ldTq, (long long)d->ldTk);
+  const int64_t strides[] = {d->sq, d->ldq, d->sk, d->ldk, d->sv, d->ldv, d->so, d->ldo, d->sdo, d->lddo, d->sdq, d->lddq, d->sdk, d->lddk, d->sdv, d->lddv};
+  for (int64_t x : strides) SP3_CHECK(x % 4 == 0, "sp3_attention_train_bwd: strides must keep 16-byte alignment");
+  AttnBwdArgs a;
+  a.q = d->q; a.k = d->k; a.v = d->v; a.o = d->o; a.dout = d->dout;
+  a.sq = d->sq; a.ldq = d->ldq; a.sk = d->sk; a.ldk = d->ldk; a.sv = d->sv; a.ldv = d->ldv; a.so = d->so; a.ldo = d->ldo; a.sdo = d->sdo; a.lddo = d->lddo;
+  a.qT = d->qT; a.kT = d->kT; a.doT = d->doT; a.ldTq = d->ldTq; a.ldTk = d->ldTk;
+  a.lse = d->lse; a.D = d->D; a.dq = d->dq; a.dk = d->dk; a.dv = d->dv;
+  a.sdq = d->sdq; a.lddq = d->lddq; a.sdk = d->sdk; a.lddk = d->lddk; a.sdv = d->sdv; a.lddv = d->lddv;
+  a.heads = d->heads; a.Nq = d->Nq; a.Nk = d->Nk; a.scale = d->scale;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const dim3 gq((d->Nq + 15) / 16, d->heads, d->B), gk((d->Nk + 15) / 16, d->heads, d->B);
+  if (d->bf16_products) {
+    hipLaunchKernelGGL(attention_bwd_dq_kernel<BF16X1>, gq, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(attention_bwd_dkv_kernel<BF16X1>, gk, dim3(256), 0, st, a);
+  } else {
+    hipLaunchKernelGGL(attention_bwd_dq_kernel<float>, gq, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(attention_bwd_dkv_kernel<float>, gk, dim3(256), 0, st, a);
+  }
+  SP3_LAUNCH_CHECK("sp3_attention_train_bwd");
   return 0;
 }

@@ -116,13 +116,13 @@ __global__ __launch_bounds__(256) void head_shuffle_kernel(HeadShuffleArgs a) {
     }
   }
   if (P.dstT) {
-    const int Np = (N + 7) & ~7;
+    const int64_t Np = P.ldT > 0 ? P.ldT : (int64_t)((N + 7) & ~7);
     float* dT = P.dstT + (int64_t)blockIdx.y * hd * Np;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int d = (tid >> 4) + 16 * i, tl = (tid & 15) * 4;
       if (d < hd && n0 + tl < Np)                    // (tokens >= N were loaded as zeros: the pad columns)
-        *reinterpret_cast<float4*>(dT + (int64_t)d * Np + n0 + tl) = make_float4(t[tl][d], t[tl + 1][d], t[tl + 2][d], t[tl + 3][d]);
+        *reinterpret_cast<float4*>(dT + d * Np + n0 + tl) = make_float4(t[tl][d], t[tl + 1][d], t[tl + 2][d], t[tl + 3][d]);
     }
   }
 }
@@ -335,7 +335,8 @@ extern "C" int sp3_head_shuffle(const sp3_head_part* parts, int nparts, int B, i
     SP3_CHECK(((p.s_b | p.s_n | p.s_h) & 3) == 0 && (reinterpret_cast<uintptr_t>(p.src) & 15) == 0, "sp3_head_shuffle: part %d: source not 16-byte aligned", i);
     SP3_CHECK(!p.dst || ((((p.d_b | p.d_n | p.d_h) & 3) == 0) && (reinterpret_cast<uintptr_t>(p.dst) & 15) == 0),
               "sp3_head_shuffle: part %d: destination not 16-byte aligned", i);
-    SP3_CHECK(!p.dstT || (reinterpret_cast<uintptr_t>(p.dstT) & 15) == 0, "sp3_head_shuffle: part %d: transposed destination not 16-byte aligned", i);
+    SP3_CHECK(!p.dstT || ((reinterpret_cast<uintptr_t>(p.dstT) & 15) == 0 && (p.ldT == 0 || (p.ldT % 4 == 0 && p.ldT >= p.N && p.ldT <= (p.N + 63) / 64 * 64))),
+              "sp3_head_shuffle: part %d: transposed destination (16-byte aligned, N <= ldT <= N rounded up to 64, ldT %% 4 == 0)", i);
     SP3_CHECK(!p.pos || (p.fwd == 1.0f || p.fwd == -1.0f), "sp3_head_shuffle: part %d: fwd must be +1 or -1", i);
     a.p[i] = p;
     nmax = p.N > nmax ? p.N : nmax;

@@ -51,8 +51,18 @@ class HeadPart(C.Structure):
     _fields_ = [
         ("src", C.c_void_p), ("s_b", C.c_int64), ("s_n", C.c_int64), ("s_h", C.c_int64),
         ("dst", C.c_void_p), ("d_b", C.c_int64), ("d_n", C.c_int64), ("d_h", C.c_int64),
-        ("dstT", C.c_void_p), ("pos", C.c_void_p), ("N", C.c_int32), ("fwd", C.c_float),
+        ("dstT", C.c_void_p), ("pos", C.c_void_p), ("N", C.c_int32), ("fwd", C.c_float), ("ldT", C.c_int64),
     ]
+
+
+class AttnBwdDesc(C.Structure):
+    """sp3_attn_bwd_desc (include/spann3r_hip.h)"""
+    _fields_ = ([(n, C.c_void_p) for n in ("q", "k", "v", "o", "dout")]
+                + [(n, C.c_int64) for n in ("sq", "ldq", "sk", "ldk", "sv", "ldv", "so", "ldo", "sdo", "lddo")]
+                + [(n, C.c_void_p) for n in ("qT", "kT", "doT")] + [("ldTq", C.c_int64), ("ldTk", C.c_int64)]
+                + [("lse", C.c_void_p), ("D", C.c_void_p), ("dq", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p)]
+                + [(n, C.c_int64) for n in ("sdq", "lddq", "sdk", "lddk", "sdv", "lddv")]
+                + [("B", C.c_int32), ("heads", C.c_int32), ("Nq", C.c_int32), ("Nk", C.c_int32), ("scale", C.c_float), ("bf16_products", C.c_int32)])
 
 
 class ReduceLnDesc(C.Structure):
@@ -138,6 +148,9 @@ _PROTOS = {
     "sp3_transpose_pad": [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "sp3_softmax_bwd_pad": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p],
     "sp3_head_shuffle": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p],
+    "sp3_attention_train_fwd": [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p],
+    "sp3_attention_train_bwd": [C.c_void_p, C.c_void_p],
     "sp3_gelu": [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
     "sp3_gelu_bwd": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
     "sp3_im2col3x3": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],

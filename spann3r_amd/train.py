@@ -28,6 +28,7 @@ from . import ops
 
 
 PRECISION = "fp32"
+FLASH_ATTENTION = True   # heads of 64: sp3_attention_train_fwd / _bwd (no attention matrix in memory); False: GEMMs + softmax kernels (_MHA)
 FUSED_HEADS = True    # attention through _MHA (one shuffle launch each way); False: the separate ATen reshapes + _Attention (tests compare the two)
 _wcache = {}          # id(weight) -> (version, packed W, packed W^T): refreshed when the optimizer has stepped
 
@@ -357,6 +358,44 @@ def layer_norm(x, g, b, eps):
     return _LayerNorm.apply(x.reshape(-1, sh[-1]).contiguous(), g, b, eps).reshape(sh)
 
 
+class _LayerNormRes(torch.autograd.Function):
+    """x -> (x, LN(x)) for the pre-LN residual pattern x + f(LN(x)): the gradient arriving on the pass-through x is added inside the
+    LayerNorm backward kernel (dx_add) instead of by a separate accumulation launch"""
+
+    @staticmethod
+    def forward(ctx, x, g, b, eps):
+        R, C_ = x.shape
+        y = torch.empty_like(x)
+        ops.layernorm(x, g, b, eps, y, rows=R, C_=C_)
+        ctx.save_for_backward(x, g)
+        ctx.eps = eps
+        ctx.direct = None
+        ctx.set_materialize_grads(False)
+        if ctx.needs_input_grad[1] and ctx.needs_input_grad[2] and isinstance(g, torch.nn.Parameter) and isinstance(b, torch.nn.Parameter):
+            ctx.direct = (g, b)
+            _expect(g)
+            _expect(b)
+        return x.view_as(x), y
+
+    @staticmethod
+    def backward(ctx, dxp, dy):
+        x, g = ctx.saved_tensors
+        if dy is None:
+            if ctx.direct is not None:
+                _contributed(ctx.direct[0])
+                _contributed(ctx.direct[1])
+            return dxp, None, None, None
+        dx, dg, db = _ln_bwd(x, g, dy.contiguous(), None if dxp is None else dxp.contiguous(), ctx.eps, ctx.direct)
+        return dx, dg, db, None
+
+
+def layer_norm_res(x, g, b, eps):
+    """-> (x, LN(x)); use the returned x as the residual operand"""
+    sh = x.shape
+    xp, y = _LayerNormRes.apply(x.reshape(-1, sh[-1]).contiguous(), g, b, eps)
+    return xp.reshape(sh), y.reshape(sh)
+
+
 class _Gelu(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
@@ -430,7 +469,7 @@ def _head_shuffle(parts, B, H, hd, base):
         a.dst = L.ptr(dst)
         if dst is not None:
             a.d_b, a.d_n, a.d_h = p["d"]
-        a.dstT, a.pos, a.fwd = L.ptr(dstT), L.ptr(pos), float(p.get("fwd", 1.0))
+        a.dstT, a.pos, a.fwd, a.ldT = L.ptr(dstT), L.ptr(pos), float(p.get("fwd", 1.0)), int(p.get("ldT", 0))
     L.check(L.load().sp3_head_shuffle(arr, len(parts), B, H, hd, float(base), L.stream_ptr()), "sp3_head_shuffle")
 
 
@@ -520,6 +559,105 @@ class _MHA(torch.autograd.Function):
         return da, db, dc, None, None, None, None, None
 
 
+class _FlashMHA(torch.autograd.Function):
+    """The same op as _MHA (heads of 64) without the attention matrix: sp3_attention_train_fwd / _bwd recompute the probabilities
+    from the saved log-sum-exp.  Forward: 1 shuffle (RoPE'd q, k in token-major layout, V^T, and q^T / k^T for the backward) + 1
+    attention launch writing the merged output; backward: 1 shuffle (dO^T) + 2 launches (dq | dk, dv, written straight into the
+    gradient of the projections' output) + 1 in-place shuffle (inverse RoPE on dq, dk).  v is read in place from the projection
+    output.  Saved: the projection output(s), RoPE'd q / k, q^T, k^T, the output and lse."""
+
+    @staticmethod
+    def forward(ctx, a, b, c, posq, posk, heads, scale, base):
+        self_mode = b is None
+        a = a.contiguous()
+        if not self_mode:
+            b, c = b.contiguous(), c.contiguous()
+        B, Nq = a.shape[0], a.shape[1]
+        C_ = a.shape[2] // 3 if self_mode else a.shape[2]
+        Nk = Nq if self_mode else b.shape[1]
+        H, hd = heads, C_ // heads
+        assert hd == 64
+        BH, Tq, Tk = B * H, _r64(Nq), _r64(Nk)
+        dev = a.device
+        f32 = lambda *sh: torch.empty(*sh, device=dev)
+        need = any(ctx.needs_input_grad[:3])
+        # sources: (tensor, column offset, row length)
+        qs, ks, vs = ((a, 0, 3 * C_), (a, C_, 3 * C_), (a, 2 * C_, 3 * C_)) if self_mode else ((a, 0, C_), (b, 0, C_), (c, 0, C_))
+        vT = f32(BH, hd, Tk)
+        qT, kT = (f32(BH, hd, Tq), f32(BH, hd, Tk)) if need else (None, None)
+        parts = [dict(src=vs[0][0, 0, vs[1]:], s=(Nk * vs[2], vs[2], hd), N=Nk, dstT=vT, ldT=Tk)]
+        rope = posq is not None
+        if rope:            # rotated copies in token-major layout [B, N, C]
+            qr, kr = f32(B, Nq, C_), f32(B, Nk, C_)
+            parts.append(dict(src=qs[0][0, 0, qs[1]:], s=(Nq * qs[2], qs[2], hd), N=Nq, dst=qr, d=(Nq * C_, C_, hd), dstT=qT, ldT=Tq, pos=posq, fwd=1.0))
+            parts.append(dict(src=ks[0][0, 0, ks[1]:], s=(Nk * ks[2], ks[2], hd), N=Nk, dst=kr, d=(Nk * C_, C_, hd), dstT=kT, ldT=Tk, pos=posk, fwd=1.0))
+            qv, kv = (qr, 0, C_), (kr, 0, C_)
+        else:               # no rotation: q and k are read where the projection left them
+            if need:
+                parts.append(dict(src=qs[0][0, 0, qs[1]:], s=(Nq * qs[2], qs[2], hd), N=Nq, dstT=qT, ldT=Tq))
+                parts.append(dict(src=ks[0][0, 0, ks[1]:], s=(Nk * ks[2], ks[2], hd), N=Nk, dstT=kT, ldT=Tk))
+            qv, kv = qs, ks
+        _head_shuffle(parts, B, H, hd, base)
+        out, lse = f32(B, Nq, C_), f32(BH, Nq)
+        bf = int(PRECISION == "bf16")
+        qp, kp = qv[0][0, 0, qv[1]:], kv[0][0, 0, kv[1]:]
+        L.check(L.load().sp3_attention_train_fwd(qp.data_ptr(), Nq * qv[2], qv[2], kp.data_ptr(), Nk * kv[2], kv[2], vT.data_ptr(), Tk,
+                                                 out.data_ptr(), C_, lse.data_ptr(), B, H, Nq, Nk, float(scale), bf, L.stream_ptr()), "sp3_attention_train_fwd")
+        if need:
+            none = torch.empty(0, device=dev)
+            ctx.save_for_backward(qv[0], kv[0], vs[0], qT, kT, out, lse, posq if rope else none, posk if rope else none)
+        ctx.geo = (self_mode, rope, B, Nq, Nk, C_, H, scale, base, bf, qv[1:], kv[1:], vs[1:])
+        return out
+
+    @staticmethod
+    def backward(ctx, dOm):
+        qt, kt, vt_, qT, kT, out, lse, posq, posk = ctx.saved_tensors
+        self_mode, rope, B, Nq, Nk, C_, H, scale, base, bf, (qo, qld), (ko, kld), (vo, vld) = ctx.geo
+        hd, BH, Tq, Tk = 64, B * H, _r64(Nq), _r64(Nk)
+        dev = dOm.device
+        f32 = lambda *sh: torch.empty(*sh, device=dev)
+        dOm = dOm.contiguous()
+        doT = f32(BH, hd, Tq)
+        _head_shuffle([dict(src=dOm, s=(Nq * C_, C_, hd), N=Nq, dstT=doT, ldT=Tq)], B, H, hd, base)
+        if self_mode:
+            da = f32(B, Nq, 3 * C_)
+            gq, gk, gv = (da, 0, 3 * C_), (da, C_, 3 * C_), (da, 2 * C_, 3 * C_)
+        else:
+            da, db, dc = f32(B, Nq, C_), f32(B, Nk, C_), f32(B, Nk, C_)
+            gq, gk, gv = (da, 0, C_), (db, 0, C_), (dc, 0, C_)
+        D = f32(BH, Nq)
+        d = L.AttnBwdDesc()
+        P = lambda t, off: t[0, 0, off:].data_ptr()
+        d.q, d.sq, d.ldq = P(qt, qo), Nq * qld, qld
+        d.k, d.sk, d.ldk = P(kt, ko), Nk * kld, kld
+        d.v, d.sv, d.ldv = P(vt_, vo), Nk * vld, vld
+        d.o, d.so, d.ldo = out.data_ptr(), Nq * C_, C_
+        d.dout, d.sdo, d.lddo = dOm.data_ptr(), Nq * C_, C_
+        d.qT, d.kT, d.doT, d.ldTq, d.ldTk = qT.data_ptr(), kT.data_ptr(), doT.data_ptr(), Tq, Tk
+        d.lse, d.D = lse.data_ptr(), D.data_ptr()
+        d.dq, d.sdq, d.lddq = P(gq[0], gq[1]), Nq * gq[2], gq[2]
+        d.dk, d.sdk, d.lddk = P(gk[0], gk[1]), Nk * gk[2], gk[2]
+        d.dv, d.sdv, d.lddv = P(gv[0], gv[1]), Nk * gv[2], gv[2]
+        d.B, d.heads, d.Nq, d.Nk, d.scale, d.bf16_products = B, H, Nq, Nk, float(scale), bf
+        import ctypes
+        L.check(L.load().sp3_attention_train_bwd(ctypes.byref(d), L.stream_ptr()), "sp3_attention_train_bwd")
+        if rope:            # the gradients of the rotated q, k -> of the projections' outputs: R^T in place
+            parts = []
+            for (t, off, ld), N, pos in ((gq, Nq, posq), (gk, Nk, posk)):
+                v = t[0, 0, off:]
+                parts.append(dict(src=v, s=(N * ld, ld, hd), N=N, dst=v, d=(N * ld, ld, hd), pos=pos, fwd=-1.0))
+            _head_shuffle(parts, B, H, hd, base)
+        if self_mode:
+            return da, None, None, None, None, None, None, None
+        return da, db, dc, None, None, None, None, None
+
+
+def _mha(a, b, c, posq, posk, heads, scale, base):
+    C_ = a.shape[2] // 3 if b is None else a.shape[2]
+    fn = _FlashMHA if (FLASH_ATTENTION and C_ // heads == 64) else _MHA
+    return fn.apply(a, b, c, posq, posk, heads, scale, base)
+
+
 def _heads(t, B, N, H, pos, base):
     """[B, N, H*hd] -> [B*H, N, hd] contiguous, RoPE applied first if pos is given (in place on the [B, N, H, hd] copy)"""
     hd = t.shape[-1] // H
@@ -536,7 +674,7 @@ def self_attention(x, pos, P, pre, heads, base=100.0, use_rope=True, res=None):
     qkv = linear(x, P[pre + "qkv.weight"], P[pre + "qkv.bias"])
     rp = pos if use_rope else None
     if FUSED_HEADS:
-        o = _MHA.apply(qkv, None, None, rp, rp, heads, (C_ // heads) ** -0.5, base)
+        o = _mha(qkv, None, None, rp, rp, heads, (C_ // heads) ** -0.5, base)
     else:
         qkv = qkv.reshape(B, N, 3, C_)
         q, k, v = _heads(qkv[:, :, 0], B, N, heads, rp, base), _heads(qkv[:, :, 1], B, N, heads, rp, base), _heads(qkv[:, :, 2], B, N, heads, None, base)
@@ -553,7 +691,7 @@ def cross_attention(xq, y, qpos, kpos, P, pre, heads, base=100.0, res=None):
     k = linear(y, P[pre + "projk.weight"], P[pre + "projk.bias"])
     v = linear(y, P[pre + "projv.weight"], P[pre + "projv.bias"])
     if FUSED_HEADS:
-        o = _MHA.apply(q, k, v, qpos, kpos, heads, (C_ // heads) ** -0.5, base)
+        o = _mha(q, k, v, qpos, kpos, heads, (C_ // heads) ** -0.5, base)
     else:
         q, k, v = _heads(q, B, Nq, heads, qpos, base), _heads(k, B, Nk, heads, kpos, base), _heads(v, B, Nk, heads, None, base)
         o = _Attention.apply(q, k, v, (C_ // heads) ** -0.5)
@@ -569,16 +707,21 @@ def mlp(x, P, pre, res=None):
 
 def block(x, pos, P, pre, heads, base=100.0, use_rope=True, eps=1e-6):
     """Pre-LN ViT block, croco/models/blocks.py:127-130 (the residual adds ride in the GEMM epilogues)"""
-    x = self_attention(layer_norm(x, P[pre + "norm1.weight"], P[pre + "norm1.bias"], eps), pos, P, pre + "attn.", heads, base, use_rope, res=x)
-    return mlp(layer_norm(x, P[pre + "norm2.weight"], P[pre + "norm2.bias"], eps), P, pre + "mlp.", res=x)
+    x, h = layer_norm_res(x, P[pre + "norm1.weight"], P[pre + "norm1.bias"], eps)
+    x = self_attention(h, pos, P, pre + "attn.", heads, base, use_rope, res=x)
+    x, h = layer_norm_res(x, P[pre + "norm2.weight"], P[pre + "norm2.bias"], eps)
+    return mlp(h, P, pre + "mlp.", res=x)
 
 
 def decoder_block(x, y, xpos, ypos, P, pre, heads, base=100.0, eps=1e-6):
     """croco/models/blocks.py:186-191"""
-    x = self_attention(layer_norm(x, P[pre + "norm1.weight"], P[pre + "norm1.bias"], eps), xpos, P, pre + "attn.", heads, base, res=x)
+    x, h = layer_norm_res(x, P[pre + "norm1.weight"], P[pre + "norm1.bias"], eps)
+    x = self_attention(h, xpos, P, pre + "attn.", heads, base, res=x)
     yn = layer_norm(y, P[pre + "norm_y.weight"], P[pre + "norm_y.bias"], eps)
-    x = cross_attention(layer_norm(x, P[pre + "norm2.weight"], P[pre + "norm2.bias"], eps), yn, xpos, ypos, P, pre + "cross_attn.", heads, base, res=x)
-    return mlp(layer_norm(x, P[pre + "norm3.weight"], P[pre + "norm3.bias"], eps), P, pre + "mlp.", res=x)
+    x, h = layer_norm_res(x, P[pre + "norm2.weight"], P[pre + "norm2.bias"], eps)
+    x = cross_attention(h, yn, xpos, ypos, P, pre + "cross_attn.", heads, base, res=x)
+    x, h = layer_norm_res(x, P[pre + "norm3.weight"], P[pre + "norm3.bias"], eps)
+    return mlp(h, P, pre + "mlp.", res=x)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -122,7 +122,7 @@ def test_head_shuffle_split_rope_transpose_and_merge(B, N, H, hd, rope):
         if rope and i < 2:
             ref = O.rope2d(ref, pos, 100.0)
         ref = ref.reshape(B * H, N, hd)
-        assert rel_err(outs[i].cpu(), ref) < 1e-6
+        assert rel_err(outs[i].cpu(), ref) < 5e-6            # (fp32 sin / cos of the angles)
         tT = outsT[i].cpu()
         assert torch.equal(tT[:, :, :N], outs[i].cpu().transpose(1, 2)) and float(tT[:, :, N:].abs().sum()) == 0.0
     # merge with the inverse rotation undoes the split exactly up to rounding
@@ -130,7 +130,7 @@ def test_head_shuffle_split_rope_transpose_and_merge(B, N, H, hd, rope):
     parts = [dict(src=outs[i], s=(H * N * hd, hd, N * hd), N=N, dst=back[0, 0, i * C:], d=(N * 3 * C, 3 * C, hd),
                   pos=dev_pos if (rope and i < 2) else None, fwd=-1.0) for i in range(3)]
     T._head_shuffle(parts, B, H, hd, 100.0)
-    assert rel_err(back.cpu(), qkv) < 1e-6
+    assert rel_err(back.cpu(), qkv) < 5e-6
 
 
 @pytest.mark.gpu
@@ -156,7 +156,7 @@ def test_transpose_and_softmax_backward_write_their_pads():
 @pytest.mark.gpu
 @pytest.mark.parametrize("cross", [False, True])
 def test_fused_heads_match_the_separate_reshapes(cross):
-    """_MHA (one shuffle launch each way) against the ATen reshapes + _Attention it replaces: same GEMMs, same values"""
+    """_FlashMHA (no attention matrix) and _MHA (one shuffle launch each way around the GEMMs) against the ATen reshapes + _Attention"""
     from spann3r_amd import train as T
     from oracle import spann3r_oracle as O
     B, nh, nw, C, H = 2, 14, 14, 192, 3
@@ -167,23 +167,26 @@ def test_fused_heads_match_the_separate_reshapes(cross):
     ypos = torch.cat((pos, pos[:, :5]), 1).contiguous()
     res = {}
     try:
-        for fused in (True, False):
-            T.FUSED_HEADS = fused
+        for mode, (fused, flash) in {"flash": (True, True), "gemm": (True, False), "aten": (False, False)}.items():
+            T.FUSED_HEADS, T.FLASH_ATTENTION = fused, flash
             P = _block_params(C, 3, cross, torch.float32, "cuda")
             x, y = x0.cuda().requires_grad_(True), y0.cuda().requires_grad_(True)
             out = T.decoder_block(x, y, pos, ypos, P, "b.", H) if cross else T.block(x, pos, P, "b.", H)
             out.backward(d0.cuda())
-            res[fused] = (out.detach(), {**{k: v.grad for k, v in P.items()}, "x": x.grad, **({"y": y.grad} if cross else {})})
+            res[mode] = (out.detach(), {**{k: v.grad for k, v in P.items()}, "x": x.grad, **({"y": y.grad} if cross else {})})
     finally:
-        T.FUSED_HEADS = True
-    assert rel_err(res[True][0], res[False][0]) < 1e-6
-    worst = max((rel_err(res[True][1][k], v), k) for k, v in res[False][1].items())
-    assert worst[0] < 2e-6, worst
+        T.FUSED_HEADS = T.FLASH_ATTENTION = True
+    for mode in ("flash", "gemm"):
+        assert rel_err(res[mode][0], res["aten"][0]) < 2e-6, mode
+        worst = max((rel_err(res[mode][1][k], v), k) for k, v in res["aten"][1].items())
+        print("attention path %s vs the ATen reshapes: worst gradient rel err %.2e (%s)" % (mode, worst[0], worst[1]))
+        assert worst[0] < 5e-6, (mode, worst)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cross,grid", [(False, (5, 7)), (True, (5, 7)), (False, (14, 14)), (True, (14, 14))])
-def test_vit_blocks_forward_backward(cross, grid):
+@pytest.mark.parametrize("cross,grid,rope", [(False, (5, 7), True), (True, (5, 7), True), (False, (14, 14), True), (True, (14, 14), True),
+                                             (False, (14, 14), False)])
+def test_vit_blocks_forward_backward(cross, grid, rope):
     """Block / DecoderBlock (croco/models/blocks.py:127-130,186-191) in train mode: HIP forward and backward against the
     oracle's functional block in float64 + autograd"""
     from spann3r_amd import train as T
@@ -200,9 +203,9 @@ def test_vit_blocks_forward_backward(cross, grid):
         x = x0.to(dt).to(dev).requires_grad_(True)
         y = y0.to(dt).to(dev).requires_grad_(True)
         if name == "hip":
-            out = T.decoder_block(x, y, pos.to(dev), ypos.to(dev), P, "b.", H) if cross else T.block(x, pos.to(dev), P, "b.", H)
+            out = T.decoder_block(x, y, pos.to(dev), ypos.to(dev), P, "b.", H) if cross else T.block(x, pos.to(dev), P, "b.", H, use_rope=rope)
         else:
-            out = O.decoder_block(x, y, pos, ypos, P, "b.", H, 100.0) if cross else O.block(x, pos, P, "b.", H, 100.0)
+            out = O.decoder_block(x, y, pos, ypos, P, "b.", H, 100.0) if cross else O.block(x, pos, P, "b.", H, 100.0, use_rope=rope)
         out.backward(d0.to(dt).to(dev))
         res[name] = (out.detach().cpu(), {**{k: v.grad.cpu() for k, v in P.items()}, "x": x.grad.cpu(), **({"y": y.grad.cpu()} if cross else {})})
     assert rel_err(res["hip"][0], res["ref"][0]) < 1e-5
