@@ -448,17 +448,19 @@ int sp3_head_shuffle(const sp3_head_part* parts, int nparts, int B, int H, int h
 /* Attention of the train-mode blocks (croco/models/blocks.py:100-108, :160-166: softmax(q k^T * scale) v per head, head_dim 64) as
  * flash-style kernels with a backward -- what torch's autograd derives for those lines, without materialising the attention matrix.
  *   forward : sp3_attention's kernel on fp32 operands (q, k already rotated; vt = per-head V^T [B*heads][64][vt_ld], zero padded to a
- *             multiple of 64 keys), also leaving lse[b*heads + h][query] = log sum_j exp(s_j) for the backward;
- *   backward: dq, dk, dv from (q, k, v, out, d out, lse) with the probabilities recomputed; two launches (16 queries / 16 keys per
+ *             multiple of 64 keys), also leaving lse[b*heads + h][query] = (max_j s_j, 1 / sum_j exp(s_j - max)) for the backward
+ *             (two floats: one folded log-sum-exp would round a large maximum into the recomputed probabilities);
+ *   backward: dq, dk, dv from (q, k, v, d out, lse) with the probabilities recomputed; two launches (16 queries / 16 keys per
  *             workgroup); the per-head transposes qT, doT [B*heads][64][ldTq] and kT [..][ldTk] (sp3_head_shuffle) feed the products
- *             contracted over tokens; D is a [B*heads][Nq] scratch (rowsum(d out (.) out)).
+ *             contracted over tokens; lse is the forward's [B*heads][Nq][2]; D is a [B*heads][Nq] scratch: rowsum(P (.) dP) of the recomputed, rounded P and dP, so that the
+ *             rows of dS sum to zero as in the unfused softmax backward (rowsum(d out (.) out) leaks a common-mode term in fp32).
  * bf16_products: 0 = exact fp32 MFMA, 1 = operands rounded to bf16 into one bf16 MFMA per product (fp32 accumulation, bf16 training).
- * Element (b, n, h, d) of q / k / v / out / dout / dq / dk / dv is at p + b*s + n*ld + h*64 + d (strides in elements, multiples of 4). */
+ * Element (b, n, h, d) of q / k / v / dout / dq / dk / dv is at p + b*s + n*ld + h*64 + d (strides in elements, multiples of 4). */
 int sp3_attention_train_fwd(const float* q, int64_t sq, int64_t ldq, const float* k, int64_t sk, int64_t ldk, const float* vt, int64_t vt_ld,
                             float* out, int64_t ldo, float* lse, int B, int heads, int Nq, int Nk, float scale, int bf16_products, void* stream);
 typedef struct sp3_attn_bwd_desc {
-  const float *q, *k, *v, *o, *dout;
-  int64_t sq, ldq, sk, ldk, sv, ldv, so, ldo, sdo, lddo;
+  const float *q, *k, *v, *dout;
+  int64_t sq, ldq, sk, ldk, sv, ldv, sdo, lddo;
   const float *qT, *kT, *doT;
   int64_t ldTq, ldTk;
   const float* lse;

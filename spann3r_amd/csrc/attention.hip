@@ -341,7 +341,10 @@ __global__ __launch_bounds__(256) void attention_kernel(const typename AttnT<TT>
     acc.x += ow.x * sc; acc.y += ow.y * sc; acc.z += ow.z * sc; acc.w += ow.w * sc;
   }
   const float inv = 1.0f / L;
-  if (lse && wave == 0 && g == 0 && q0 + ql < Nq) lse[(int64_t)(b * heads + h) * Nq + q0 + ql] = M + logf(L);   // (training: the backward's softmax)
+  // training: the backward recomputes P = exp(s - M) / L.  (M, 1 / L) are kept apart: folded into one log-sum-exp, the fp32 rounding of a
+  // large M would rescale the whole row of recomputed probabilities by 1 +- |M| * 2^-24 -- an error the forward never made.
+  if (lse && wave == 0 && g == 0 && q0 + ql < Nq)
+    *reinterpret_cast<float2*>(lse + 2 * ((int64_t)(b * heads + h) * Nq + q0 + ql)) = make_float2(M, inv);
   if (q0 + ql < Nq) {
     const int row = b * Nq + q0 + ql;
     const int col = h * 64 + db * 16 + 4 * g;
@@ -505,17 +508,17 @@ __global__ __launch_bounds__(256) void attention_packed_kernel(const __bf16* __r
 // ------------------------------------------------------------------ training: the backward of softmax(q k^T * scale) v
 // Same register layout as the forward (a lane owns one row of the 16-row block its workgroup works on; the other axis is streamed
 // in 64-row tiles, one tile per wave per round, partial sums merged through LDS), probabilities recomputed from the saved
-// log-sum-exp:   P = exp(S - lse),  dP = dO V^T,  dS = P (.) (dP - D) * scale,  D = rowsum(dO (.) O),
+// softmax statistics:   P = exp(S - max) / sum,  dP = dO V^T,  dS = P (.) (dP - D) * scale,  D = rowsum(dO (.) O),
 //   dq = dS k   (workgroup = 16 queries; streams k, v rows and k^T),
 //   dk = dS^T q, dv = P^T dO   (workgroup = 16 keys; streams q, dO rows and q^T, dO^T).
 // Every product is one of the forward's two MFMA forms (AttnT::qk: rows x registers contracted over the head dimension;
 // AttnT::pv: transposed stream x register tile contracted over the streamed axis), so the precision modes are the forward's.
 struct AttnBwdArgs {
-  const float *q, *k, *v, *o, *dout;           // [B][N][..]: element (b, n, h, d) at p + b*s + n*ld + h*64 + d
-  int64_t sq, ldq, sk, ldk, sv, ldv, so, ldo, sdo, lddo;
+  const float *q, *k, *v, *dout;               // [B][N][..]: element (b, n, h, d) at p + b*s + n*ld + h*64 + d
+  int64_t sq, ldq, sk, ldk, sv, ldv, sdo, lddo;
   const float *qT, *kT, *doT;                  // [B*heads][64][ldT]: per-head transposes, zero padded to a multiple of 64 rows of the other axis
   int64_t ldTq, ldTk;
-  const float* lse;                            // [B*heads][Nq]
+  const float* lse;                            // [B*heads][Nq][2]: (row max, 1 / row sum) of the forward's softmax
   float* D;                                    // [B*heads][Nq] (written by the dq kernel, read by the dk / dv kernel)
   float *dq, *dk, *dv;
   int64_t sdq, lddq, sdk, lddk, sdv, lddv;
@@ -527,48 +530,69 @@ template <typename TT>
 __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(AttnBwdArgs a) {
   using A = AttnT<TT>;
   __shared__ float sh_o[4][4][64][4];
+  __shared__ double sh_d[4][16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, ql = lane & 15;
   const int h = blockIdx.y, b = blockIdx.z, q0 = blockIdx.x * 16;
   const int Nq = a.Nq, Nk = a.Nk;
   const int qrow = min(q0 + ql, Nq - 1);
   const int64_t bh = (int64_t)b * a.heads + h;
   typename A::QReg qreg, doreg;
-  const float* dorow = a.dout + (int64_t)b * a.sdo + (int64_t)qrow * a.lddo + h * 64;
   A::loadQ(qreg, a.q + (int64_t)b * a.sq + (int64_t)qrow * a.ldq + h * 64, g);
-  A::loadQ(doreg, dorow, g);
-  float Dq = 0.f;
-  {
-    const float4* po = reinterpret_cast<const float4*>(a.o + (int64_t)b * a.so + (int64_t)qrow * a.ldo + h * 64 + 16 * g);
-    const float4* pd = reinterpret_cast<const float4*>(dorow + 16 * g);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float4 x = po[i], y = pd[i];
-      Dq += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
-    }
-    Dq += __shfl_xor(Dq, 16);
-    Dq += __shfl_xor(Dq, 32);
-  }
-  const float lq = a.lse[bh * Nq + qrow];
+  A::loadQ(doreg, a.dout + (int64_t)b * a.sdo + (int64_t)qrow * a.lddo + h * 64, g);
+  const float2 lq = *reinterpret_cast<const float2*>(a.lse + 2 * (bh * Nq + qrow));          // (row max, 1 / row sum) of the forward
   const float* kbase = a.k + (int64_t)b * a.sk + h * 64;
   const float* vbase = a.v + (int64_t)b * a.sv + h * 64;
   const float* kT = a.kT + bh * 64 * a.ldTk;
-  f32x4 acc[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int kb = wave * 64; kb < Nk; kb += 256) {
-    f32x4 ds[4];
+  // (p, dp) of a 64-key tile: p[t][r] = P[query ql][key kb + 16t + 4g + r], dp likewise
+  auto tile = [&](int kb, f32x4 (&p)[4], f32x4 (&dp)[4]) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int krow = min(kb + 16 * t + ql, Nk - 1);
       const f32x4 s = A::qk(kbase + (int64_t)krow * a.ldk, g, qreg);
-      const f32x4 dp = A::qk(vbase + (int64_t)krow * a.ldv, g, doreg);
+      dp[t] = A::qk(vbase + (int64_t)krow * a.ldv, g, doreg);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = kb + 16 * t + 4 * g + r;
-        const float p = key < Nk ? expf(s[r] * a.scale - lq) : 0.f;
-        ds[t][r] = p * (dp[r] - Dq) * a.scale;
-      }
+      for (int r = 0; r < 4; ++r) p[t][r] = (kb + 16 * t + 4 * g + r) < Nk ? expf(s[r] * a.scale - lq.x) * lq.y : 0.f;
     }
+  };
+  // pass 1: D = sum_j P_j dP_j from the SAME rounded (P, dP) the second pass uses -- the rows of dS then sum to zero exactly as in
+  // the textbook softmax backward (rowsum(dO (.) O) is the same number only in exact arithmetic; in fp32 the difference leaks a
+  // common-mode term into every layer's dq and compounds with depth).  The wave's first tile stays in registers for pass 2.
+  f32x4 p0[4], dp0[4];
+  double dsum = 0.0;
+  for (int kb = wave * 64; kb < Nk; kb += 256) {
+    f32x4 p[4], dp[4];
+    tile(kb, p, dp);
+    float part = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part += p[t][r] * dp[t][r];
+    dsum += (double)part;
+    if (kb == wave * 64) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { p0[t] = p[t]; dp0[t] = dp[t]; }
+    }
+  }
+  dsum += __shfl_xor(dsum, 16);
+  dsum += __shfl_xor(dsum, 32);
+  if (g == 0) sh_d[wave][ql] = dsum;
+  __syncthreads();
+  const float Dq = (float)((sh_d[0][ql] + sh_d[1][ql]) + (sh_d[2][ql] + sh_d[3][ql]));
+  f32x4 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int kb = wave * 64; kb < Nk; kb += 256) {
+    f32x4 p[4], dp[4], ds[4];
+    if (kb == wave * 64) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { p[t] = p0[t]; dp[t] = dp0[t]; }
+    } else {
+      tile(kb, p, dp);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ds[t][r] = p[t][r] * (dp[t][r] - Dq) * a.scale;
     A::pv(acc, kT, a.ldTk, kb, g, ql, ds);
   }
 #pragma unroll
@@ -604,7 +628,7 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(AttnBwdArgs a) {
   const float* dobase = a.dout + (int64_t)b * a.sdo + h * 64;
   const float* qT = a.qT + bh * 64 * a.ldTq;
   const float* doT = a.doT + bh * 64 * a.ldTq;
-  const float* lse = a.lse + bh * Nq;
+  const float2* lse = reinterpret_cast<const float2*>(a.lse) + bh * Nq;
   const float* Dv = a.D + bh * Nq;
   f32x4 acck[4], accv[4];
 #pragma unroll
@@ -620,7 +644,8 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(AttnBwdArgs a) {
       for (int r = 0; r < 4; ++r) {
         const int qi = qb + 16 * t + 4 * g + r;
         const int qc = min(qi, Nq - 1);
-        const float p = qi < Nq ? expf(s[r] * a.scale - lse[qc]) : 0.f;
+        const float2 st = lse[qc];
+        const float p = qi < Nq ? expf(s[r] * a.scale - st.x) * st.y : 0.f;
         pt[t][r] = p;
         ds[t][r] = p * (dp[r] - Dv[qc]) * a.scale;
       }
@@ -723,16 +748,16 @@ extern "C" int sp3_attention_train_fwd(const float* q, int64_t sq, int64_t ldq, 
 }
 
 extern "C" int sp3_attention_train_bwd(const sp3_attn_bwd_desc* d, void* stream) {
-  SP3_CHECK(d && d->q && d->k && d->v && d->o && d->dout && d->qT && d->kT && d->doT && d->lse && d->D && d->dq && d->dk && d->dv,
+  SP3_CHECK(d && d->q && d->k && d->v && d->dout && d->qT && d->kT && d->doT && d->lse && d->D && d->dq && d->dk && d->dv,
             "sp3_attention_train_bwd: null pointer");
   SP3_CHECK(d->B > 0 && d->heads > 0 && d->Nq > 0 && d->Nk > 0 && d->B <= 65535 && d->heads <= 65535, "sp3_attention_train_bwd: bad shape");
   SP3_CHECK(d->ldTq >= ((d->Nq + 63) / 64) * 64 && d->ldTk >= ((d->Nk + 63) / 64) * 64 && d->ldTq % 4 == 0 && d->ldTk % 4 == 0,
             "sp3_attention_train_bwd: the transposed operands must be padded to a multiple of 64 (ldTq=%lld ldTk=%lld)", (long long)d->ldTq, (long long)d->ldTk);
-  const int64_t strides[] = {d->sq, d->ldq, d->sk, d->ldk, d->sv, d->ldv, d->so, d->ldo, d->sdo, d->lddo, d->sdq, d->lddq, d->sdk, d->lddk, d->sdv, d->lddv};
+  const int64_t strides[] = {d->sq, d->ldq, d->sk, d->ldk, d->sv, d->ldv, d->sdo, d->lddo, d->sdq, d->lddq, d->sdk, d->lddk, d->sdv, d->lddv};
   for (int64_t x : strides) SP3_CHECK(x % 4 == 0, "sp3_attention_train_bwd: strides must keep 16-byte alignment");
   AttnBwdArgs a;
-  a.q = d->q; a.k = d->k; a.v = d->v; a.o = d->o; a.dout = d->dout;
-  a.sq = d->sq; a.ldq = d->ldq; a.sk = d->sk; a.ldk = d->ldk; a.sv = d->sv; a.ldv = d->ldv; a.so = d->so; a.ldo = d->ldo; a.sdo = d->sdo; a.lddo = d->lddo;
+  a.q = d->q; a.k = d->k; a.v = d->v; a.dout = d->dout;
+  a.sq = d->sq; a.ldq = d->ldq; a.sk = d->sk; a.ldk = d->ldk; a.sv = d->sv; a.ldv = d->ldv; a.sdo = d->sdo; a.lddo = d->lddo;
   a.qT = d->qT; a.kT = d->kT; a.doT = d->doT; a.ldTq = d->ldTq; a.ldTk = d->ldTk;
   a.lse = d->lse; a.D = d->D; a.dq = d->dq; a.dk = d->dk; a.dv = d->dv;
   a.sdq = d->sdq; a.lddq = d->lddq; a.sdk = d->sdk; a.lddk = d->lddk; a.sdv = d->sdv; a.lddv = d->lddv;

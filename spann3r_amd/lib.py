@@ -57,8 +57,8 @@ class HeadPart(C.Structure):
 
 class AttnBwdDesc(C.Structure):
     """sp3_attn_bwd_desc (include/spann3r_hip.h)"""
-    _fields_ = ([(n, C.c_void_p) for n in ("q", "k", "v", "o", "dout")]
-                + [(n, C.c_int64) for n in ("sq", "ldq", "sk", "ldk", "sv", "ldv", "so", "ldo", "sdo", "lddo")]
+    _fields_ = ([(n, C.c_void_p) for n in ("q", "k", "v", "dout")]
+                + [(n, C.c_int64) for n in ("sq", "ldq", "sk", "ldk", "sv", "ldv", "sdo", "lddo")]
                 + [(n, C.c_void_p) for n in ("qT", "kT", "doT")] + [("ldTq", C.c_int64), ("ldTk", C.c_int64)]
                 + [("lse", C.c_void_p), ("D", C.c_void_p), ("dq", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p)]
                 + [(n, C.c_int64) for n in ("sdq", "lddq", "sdk", "lddk", "sdv", "lddv")]

@@ -28,8 +28,9 @@ from . import ops
 
 
 PRECISION = "fp32"
-FLASH_ATTENTION = True   # heads of 64: sp3_attention_train_fwd / _bwd (no attention matrix in memory); False: GEMMs + softmax kernels (_MHA)
-FUSED_HEADS = True    # attention through _MHA (one shuffle launch each way); False: the separate ATen reshapes + _Attention (tests compare the two)
+import os as _os
+FLASH_ATTENTION = _os.environ.get("SP3_TRAIN_FLASH", "1") != "0"   # heads of 64: sp3_attention_train_fwd / _bwd (no attention matrix in memory); False: GEMMs + softmax kernels (_MHA)
+FUSED_HEADS = _os.environ.get("SP3_TRAIN_FUSED_HEADS", "1") != "0"    # attention through _MHA (one shuffle launch each way); False: the separate ATen reshapes + _Attention (tests compare the two)
 _wcache = {}          # id(weight) -> (version, packed W, packed W^T): refreshed when the optimizer has stepped
 
 
@@ -391,6 +392,8 @@ class _LayerNormRes(torch.autograd.Function):
 
 def layer_norm_res(x, g, b, eps):
     """-> (x, LN(x)); use the returned x as the residual operand"""
+    if _os.environ.get("SP3_TRAIN_LNRES", "1") == "0":
+        return x, layer_norm(x, g, b, eps)
     sh = x.shape
     xp, y = _LayerNormRes.apply(x.reshape(-1, sh[-1]).contiguous(), g, b, eps)
     return xp.reshape(sh), y.reshape(sh)
@@ -564,7 +567,7 @@ class _FlashMHA(torch.autograd.Function):
     from the saved log-sum-exp.  Forward: 1 shuffle (RoPE'd q, k in token-major layout, V^T, and q^T / k^T for the backward) + 1
     attention launch writing the merged output; backward: 1 shuffle (dO^T) + 2 launches (dq | dk, dv, written straight into the
     gradient of the projections' output) + 1 in-place shuffle (inverse RoPE on dq, dk).  v is read in place from the projection
-    output.  Saved: the projection output(s), RoPE'd q / k, q^T, k^T, the output and lse."""
+    output.  Saved: the projection output(s), RoPE'd q / k, q^T, k^T and lse."""
 
     @staticmethod
     def forward(ctx, a, b, c, posq, posk, heads, scale, base):
@@ -598,20 +601,20 @@ class _FlashMHA(torch.autograd.Function):
                 parts.append(dict(src=ks[0][0, 0, ks[1]:], s=(Nk * ks[2], ks[2], hd), N=Nk, dstT=kT, ldT=Tk))
             qv, kv = qs, ks
         _head_shuffle(parts, B, H, hd, base)
-        out, lse = f32(B, Nq, C_), f32(BH, Nq)
+        out, lse = f32(B, Nq, C_), f32(BH, Nq, 2)            # lse: (row max, 1 / row sum) per query
         bf = int(PRECISION == "bf16")
         qp, kp = qv[0][0, 0, qv[1]:], kv[0][0, 0, kv[1]:]
         L.check(L.load().sp3_attention_train_fwd(qp.data_ptr(), Nq * qv[2], qv[2], kp.data_ptr(), Nk * kv[2], kv[2], vT.data_ptr(), Tk,
                                                  out.data_ptr(), C_, lse.data_ptr(), B, H, Nq, Nk, float(scale), bf, L.stream_ptr()), "sp3_attention_train_fwd")
         if need:
             none = torch.empty(0, device=dev)
-            ctx.save_for_backward(qv[0], kv[0], vs[0], qT, kT, out, lse, posq if rope else none, posk if rope else none)
+            ctx.save_for_backward(qv[0], kv[0], vs[0], qT, kT, lse, posq if rope else none, posk if rope else none)
         ctx.geo = (self_mode, rope, B, Nq, Nk, C_, H, scale, base, bf, qv[1:], kv[1:], vs[1:])
         return out
 
     @staticmethod
     def backward(ctx, dOm):
-        qt, kt, vt_, qT, kT, out, lse, posq, posk = ctx.saved_tensors
+        qt, kt, vt_, qT, kT, lse, posq, posk = ctx.saved_tensors
         self_mode, rope, B, Nq, Nk, C_, H, scale, base, bf, (qo, qld), (ko, kld), (vo, vld) = ctx.geo
         hd, BH, Tq, Tk = 64, B * H, _r64(Nq), _r64(Nk)
         dev = dOm.device
@@ -631,7 +634,6 @@ class _FlashMHA(torch.autograd.Function):
         d.q, d.sq, d.ldq = P(qt, qo), Nq * qld, qld
         d.k, d.sk, d.ldk = P(kt, ko), Nk * kld, kld
         d.v, d.sv, d.ldv = P(vt_, vo), Nk * vld, vld
-        d.o, d.so, d.ldo = out.data_ptr(), Nq * C_, C_
         d.dout, d.sdo, d.lddo = dOm.data_ptr(), Nq * C_, C_
         d.qT, d.kT, d.doT, d.ldTq, d.ldTk = qT.data_ptr(), kT.data_ptr(), doT.data_ptr(), Tq, Tk
         d.lse, d.D = lse.data_ptr(), D.data_ptr()

@@ -148,9 +148,44 @@ def test_transpose_and_softmax_backward_write_their_pads():
     Ap, dAp = torch.zeros(40, 200), torch.zeros(40, 200)
     Ap[:, :197], dAp[:, :197] = A, dA
     dS = torch.full((40, 200), float("nan"), device="cuda")
-    L.check(L.load().sp3_softmax_bwd_pad(Ap.cuda().data_ptr(), dAp.cuda().data_ptr(), None, dS.data_ptr(), 200, 40, 197, 200, 0.5, L.stream_ptr()), "x")
+    Ad, dAd = Ap.cuda(), dAp.cuda()
+    L.check(L.load().sp3_softmax_bwd_pad(Ad.data_ptr(), dAd.data_ptr(), None, dS.data_ptr(), 200, 40, 197, 200, 0.5, L.stream_ptr()), "sp3_softmax_bwd_pad")
     ref = 0.5 * A.double() * (dA.double() - (dA.double() * A.double()).sum(-1, keepdim=True))
     assert rel_err(dS[:, :197].cpu(), ref) < 1e-5 and float(dS[:, 197:].abs().sum()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gain", [1.0, 6.0])
+def test_flash_attention_is_as_close_to_float64_as_the_materialised_one(gain):
+    """The two fp32 attention paths of the train-mode blocks against float64 on the same q, k, v (gain 6: peaked softmax rows with
+    scores of +-60): output and the three input gradients.  Neither reproduces the other's rounding, both must sit at fp32 level."""
+    from spann3r_amd import train as T
+    B, N, Nk, H = 2, 196, 201, 4
+    C = 64 * H
+    g = torch.Generator().manual_seed(11)
+    q0, k0, v0, d0 = (torch.randn(B, n, C, generator=g) for n in (N, Nk, Nk, N))
+    q0, k0 = q0 * gain, k0 * gain
+    scale = 64 ** -0.5
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q0, k0, v0))
+    hd = lambda t, n: t.reshape(B, n, H, 64).transpose(1, 2)
+    a = torch.softmax(hd(qd, N) @ hd(kd, Nk).transpose(-1, -2) * scale, -1)
+    ref = (a @ hd(vd, Nk)).transpose(1, 2).reshape(B, N, C)
+    ref.backward(d0.double())
+    refs = [ref.detach(), qd.grad, kd.grad, vd.grad]
+    errs = {}
+    try:
+        for mode, flash in (("flash", True), ("gemm", False)):
+            T.FLASH_ATTENTION = flash
+            q, k, v = (t.cuda().requires_grad_(True) for t in (q0, k0, v0))
+            out = T._mha(q, k, v, None, None, H, scale, 100.0)
+            out.backward(d0.cuda())
+            errs[mode] = [rel_err(x.detach().cpu(), r) for x, r in zip((out, q.grad, k.grad, v.grad), refs)]
+    finally:
+        T.FLASH_ATTENTION = True
+    print("attention vs float64 (gain %g): flash %s, materialised %s" % (gain, ["%.1e" % e for e in errs["flash"]], ["%.1e" % e for e in errs["gemm"]]))
+    lim = 2e-6 if gain == 1.0 else 4e-5           # measured 7e-7 / 1.3e-5 (flash), 6e-7 / 9e-6 (materialised): scores of +-60 cost 2 digits in both
+    assert max(errs["flash"]) < lim and max(errs["gemm"]) < lim, errs
+    assert all(f < 3 * m + 3e-7 for f, m in zip(errs["flash"], errs["gemm"])), errs
 
 
 @pytest.mark.gpu
@@ -574,15 +609,19 @@ def test_train_step_hip_graph_replay_matches_eager(tiny_sd):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("precision,tol", [("fp32", 2e-5), ("bf16", 3e-2)])
-def test_full_geometry_gradients_vs_reference_step(full_sd, precision, tol):
+@pytest.mark.parametrize("precision,flash,tol", [("fp32", False, 2e-5), ("fp32", True, 6e-5), ("bf16", True, 3e-2)])
+def test_full_geometry_gradients_vs_reference_step(full_sd, precision, flash, tol):
     """BASELINE config 5's step at FULL depth and width (24 encoder / 12 decoder layers, ViT-L / ViT-B / DPT) against ONE TRAINING
     STEP OF THE UNMODIFIED REFERENCE (torch CPU float32, tests/golden/make_golden.py traingrad: Spann3R.forward in train mode +
     spann3r/loss.py ConfLoss_t + backward): the loss and a strided sample of EVERY parameter gradient (~1090 tensors).
-    fp32 mode: global relative L2 error of the sampled gradients within 2e-5 (measured 3.6e-6) and every tensor within 1e-3 of the
-    reference scaled by the tensor's own maximum (measured worst 3.2e-4, a bias = a sum over 10^4 pixels: both sides carry fp32
-    rounding through ~80 chained GEMMs and differently ordered sums);
-    bf16 mode: global relative L2 error within 3e-2 (measured 7.6e-3: operand rounding of ~80 chained GEMMs)."""
+    fp32 mode, attention materialised (S, softmax, P.V as the reference computes them): global relative L2 error of the sampled
+    gradients within 2e-5 (measured 2.0e-6) and every tensor within 2e-3 of the reference scaled by the tensor's own maximum
+    (measured worst 3.2e-4, a bias = a sum over 10^4 pixels: both sides carry fp32 rounding through ~80 chained GEMMs and
+    differently ordered sums);
+    fp32 mode, flash attention (the default): within 6e-5 (measured 3.2e-5, worst tensor 8.4e-4).  The reference is an fp32 run, not
+    the truth: the materialised path repeats its order of operations and therefore its rounding, the online softmax does not.
+    Against float64 both paths have the same error (test_flash_attention_is_as_close_to_float64_as_the_materialised_one);
+    bf16 mode: global relative L2 error within 3e-2 (measured 8.0e-3: operand rounding of ~80 chained GEMMs)."""
     import numpy as np
     from spann3r_amd import train as T, FULL
     from spann3r_amd.loss import ConfLoss_t, Regr3D_t, L21
@@ -598,18 +637,20 @@ def test_full_geometry_gradients_vs_reference_step(full_sd, precision, tol):
                 camera_pose=torch.from_numpy(g["gt_camera_pose"][i]).float().cuda()) for i in range(NF)]
     P = {k: v.float().cuda().requires_grad_(True) for k, v in full_sd.items() if v.is_floating_point()}
     T.set_precision(precision)
+    T.FLASH_ATTENTION = flash
     try:
         preds, preds_all = T.forward_train(P, frames, FULL, dropout_p=0.0)
         loss, details, factor = ConfLoss_t(Regr3D_t(L21, norm_mode="avg_dis", fix_first=False), alpha=0.4).compute_frame_loss(gts, preds_all)
         (loss + factor).backward()
     finally:
         T.set_precision("fp32")
+        T.FLASH_ATTENTION = True
         T.invalidate_weight_cache()
     ref_total = float(g["loss"]) + float(g["factor"])
     assert abs(float(loss) + float(factor) - ref_total) < (1e-4 if precision == "fp32" else 5e-3) * abs(ref_total)
     names = [str(n) for n in g["names"]]
     gmax = max(float(g["g_" + n + "_max"]) for n in names)
-    worst, num, den = (0.0, None), 0.0, 0.0
+    worst, num, den, contrib = (0.0, None), 0.0, 0.0, []
     for n in names:
         p = P.get(n)
         if p is None or p.grad is None:
@@ -622,10 +663,12 @@ def test_full_geometry_gradients_vs_reference_step(full_sd, precision, tol):
         d = np.abs(mine - ref)
         e = float(d.max()) / max(float(g["g_" + n + "_max"]), 1e-4 * gmax)
         num, den = num + float((d ** 2).sum()), den + float((ref ** 2).sum())
+        contrib.append((float((d ** 2).sum()), float((ref ** 2).sum()), n))
         worst = max(worst, (e, n))
+    print("largest error contributions:", ["%s %.1e of %.1e" % (n, a, b) for a, b, n in sorted(contrib, reverse=True)[:6]])
     print("full-geometry step (%s): loss %.6f (reference %.6f), %d gradient tensors sampled, worst scaled error %.2e (%s), global rel. L2 %.2e"
           % (precision, float(loss) + float(factor), ref_total, len(names), worst[0], worst[1], (num / den) ** 0.5))
     assert len(names) > 1000
     assert (num / den) ** 0.5 < tol
     if precision == "fp32":
-        assert worst[0] < 1e-3, worst
+        assert worst[0] < 2e-3, worst

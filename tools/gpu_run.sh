@@ -31,9 +31,10 @@ for stage in "$@"; do
     bench3)     timeout 600 python bench.py --size 512 --frames 50 --train-policy --steps 3 --warmup 2 --no-cpu-baseline --no-extras > "$OUT/bench3.json" 2> "$OUT/bench3.err"; head -c 1500 "$OUT/bench3.json"; tail -3 "$OUT/bench3.err" ;;
     prof)       (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/prof" -o run -- python "$OLDPWD/bench.py" --steps 6 --warmup 3 --no-cpu-baseline --no-profile --no-extras > "$OLDPWD/$OUT/prof.log" 2>&1); DB=$(find "$OUT/prof" -name "*results.db" | head -1); python tools/rocpd_stats.py "$DB" > "$OUT/prof_stats.md" 2>&1; python tools/rocpd_lastseq.py "$DB" > "$OUT/prof_lastseq.txt" 2>&1; rm -rf "$OUT/prof"; head -40 "$OUT/prof_stats.md" ;;
     pmcbench)   for C in FETCH_SIZE WRITE_SIZE; do (cd /tmp && timeout 600 rocprofv3 --pmc $C -d "$OLDPWD/$OUT/pmcb_$C" -o run -- python "$OLDPWD/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-profile --no-extras --no-graphs > "$OLDPWD/$OUT/pmcb_$C.log" 2>&1); DB=$(find "$OUT/pmcb_$C" -name "*results.db" | head -1); python tools/rocpd_pmc_grid.py "$DB" --json "$OUT/pmc_$C.json" > "$OUT/pmc_${C}_by_grid.md" 2>&1; rm -rf "$OUT/pmcb_$C"; head -12 "$OUT/pmc_${C}_by_grid.md" | cut -c1-200; done ;;
+    trainbf)    timeout 900 python tools/train_step_time.py --precision bf16 >> "$OUT/train.txt" 2>&1; tail -12 "$OUT/train.txt" ;;
     train)      for pr in bf16 fp32; do timeout 900 python tools/train_step_time.py --precision $pr >> "$OUT/train.txt" 2>&1; done; tail -20 "$OUT/train.txt" ;;
     trainprof)  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/tprof" -o run -- python "$OLDPWD/tools/train_step_time.py" --precision bf16 --steps 2 > "$OLDPWD/$OUT/trainprof.log" 2>&1); DB=$(find "$OUT/tprof" -name "*results.db" | head -1); python tools/rocpd_stats.py "$DB" > "$OUT/trainprof_stats.md" 2>&1; rm -rf "$OUT/tprof"; head -45 "$OUT/trainprof_stats.md" | cut -c1-200 ;;
-    traintests) timeout 1500 python -m pytest tests/test_train.py tests/test_loss.py -x -q -m gpu -s > "$OUT/traintests.txt" 2>&1; grep -v "^$" "$OUT/traintests.txt" | tail -25 ;;
+    traintests) timeout 1500 python -m pytest tests/test_train.py tests/test_loss.py -q -m gpu -s > "$OUT/traintests.txt" 2>&1; grep -v "^$" "$OUT/traintests.txt" | tail -25 ;;
     memread)    timeout 600 python tools/bench_memread.py > "$OUT/memread.txt" 2>&1; tail -30 "$OUT/memread.txt" ;;
     memreadlong) timeout 600 python tools/bench_memread.py --tokens 50176 --rows 1024 --copies 3 > "$OUT/memread_long.txt" 2>&1; tail -30 "$OUT/memread_long.txt" ;;
     f16x3)      timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_model_gpu.py -x -q -m gpu -s -k "f16x3 or stress or precision or f32x3" > "$OUT/f16x3_tests.txt" 2>&1; grep -v "^$" "$OUT/f16x3_tests.txt" | tail -25
