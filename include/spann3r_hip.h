@@ -404,6 +404,11 @@ int sp3_mul(const float* a, const float* b, float* out, int64_t n, void* stream)
  * as zeros.  With both forms every product of a Linear's backward (dX = dY . W, dW = dY^T . X) is an sp3_gemm A . W^T launch on packed
  * bf16 operands: the ATen calls they replace are the matmuls autograd derives for nn.Linear (croco/models/blocks.py:73-112). */
 int sp3_pack_bf16(const float* src, int64_t ld, int rows, int cols, void* dst, void* dstT, void* stream);
+/* same launch, and colsum[j] (+)= sum_r src[r, j] (the bias gradient of the Linear whose dY is being packed; rows <= 8192): partial_ws holds
+ * ceil(rows / 64) * ceil(cols / 64) * 64 floats, counter_ws ceil(cols / 64) zero-initialised counters that the launch leaves at zero
+ * (one launch at a time per workspace).  Fixed summation order: deterministic. */
+int sp3_pack_bf16_colsum(const float* src, int64_t ld, int rows, int cols, void* dst, void* dstT, float* colsum, int accumulate,
+                         float* partial_ws, unsigned* counter_ws, void* stream);
 /* torch.nn.utils.clip_grad_norm_ (croco/utils/misc.py:262-288, called with clip_grad = 1.0 by spann3r/training.py:227-228) on flat
  * gradient buckets, without a host round trip: sp3_sumsq_partial writes sp3_sumsq_blocks(n) partial sums of squares of one bucket
  * (fixed order: deterministic), sp3_clip_coef reduces `count` partials of all buckets to out[0] = extra_scale * min(1, max_norm /
@@ -444,7 +449,10 @@ typedef struct sp3_head_part {
   float fwd;
   int64_t ldT;          /* row length of dstT; columns [N, ldT) are zeroed; 0: N rounded up to 8; at most N rounded up to 64 */
 } sp3_head_part;
-int sp3_head_shuffle(const sp3_head_part* parts, int nparts, int B, int H, int hd, float rope_base, void* stream);
+int sp3_head_shuffle(const sp3_head_part* parts, int nparts, int B, int H, int hd, float rope_base, const float* cos_tab,
+                     const float* sin_tab, int tab_len, void* stream);
+   /* cos_tab / sin_tab (nullable): cos / sin of position * rope_base^(-f / (hd/4)) as [tab_len][hd / 4] fp32; positions outside the table
+    * (or no table) are computed in the kernel */
 /* Attention of the train-mode blocks (croco/models/blocks.py:100-108, :160-166: softmax(q k^T * scale) v per head, head_dim 64) as
  * flash-style kernels with a backward -- what torch's autograd derives for those lines, without materialising the attention matrix.
  *   forward : sp3_attention's kernel on fp32 operands (q, k already rotated; vt = per-head V^T [B*heads][64][vt_ld], zero padded to a

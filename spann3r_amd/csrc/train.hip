@@ -109,6 +109,94 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     part[(int64_t)blockIdx.x * 2 * C + c] = (sh[c] + sh[2 * C + c]) + (sh[4 * C + c] + sh[6 * C + c]);
 }
 
+// Same arithmetic with the row held in registers (V float4 per lane: C <= 256 V; 16-byte aligned rows): x, dy and gamma are read ONCE
+// with 16-byte loads instead of three passes of 4-byte ones, a wave takes RPW consecutive rows and keeps its dgamma / dbeta share in
+// registers, so a workgroup (4 RPW rows) writes one partial block: fewer, fuller blocks for ln_param_reduce.
+template <int V, int RPW>
+__global__ __launch_bounds__(256) void layernorm_bwd_reg_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
+                                                                const float* __restrict__ dy, int64_t ldy, const float* __restrict__ dx_add,
+                                                                int64_t lda, float* __restrict__ dx, int64_t ldo, float* __restrict__ part,
+                                                                int rows, int C, float eps) {
+  extern __shared__ float sh[];                       // [4][2][C]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float4 gm[V], ag[V], ab[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    const int c = (lane + 64 * j) * 4;
+    gm[j] = c < C ? *reinterpret_cast<const float4*>(gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    ag[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    ab[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int row0 = (blockIdx.x * 4 + w) * RPW;
+#pragma unroll
+  for (int i = 0; i < RPW; ++i) {
+    const int row = row0 + i;
+    if (row >= rows) break;
+    float4 xv[V], dv[V];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const int c = (lane + 64 * j) * 4;
+      const bool in = c < C;
+      xv[j] = in ? *reinterpret_cast<const float4*>(x + (int64_t)row * ldx + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      dv[j] = in ? *reinterpret_cast<const float4*>(dy + (int64_t)row * ldy + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      s1 += (xv[j].x + xv[j].y) + (xv[j].z + xv[j].w);
+      s2 += (xv[j].x * xv[j].x + xv[j].y * xv[j].y) + (xv[j].z * xv[j].z + xv[j].w * xv[j].w);
+    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    const float mean = s1 / C, rstd = 1.0f / sqrtf(fmaxf(s2 / C - mean * mean, 0.f) + eps);
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const int c = (lane + 64 * j) * 4;
+      if (c < C) {
+        const float xs[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w}, ds[4] = {dv[j].x, dv[j].y, dv[j].z, dv[j].w};
+        const float gs[4] = {gm[j].x, gm[j].y, gm[j].z, gm[j].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xh = (xs[e] - mean) * rstd, dg = ds[e] * gs[e];
+          a += dg; b += dg * xh;
+        }
+      }
+    }
+    a = wave_sum(a) / C; b = wave_sum(b) / C;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const int c = (lane + 64 * j) * 4;
+      if (c < C) {
+        const float xs[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w}, ds[4] = {dv[j].x, dv[j].y, dv[j].z, dv[j].w};
+        const float gs[4] = {gm[j].x, gm[j].y, gm[j].z, gm[j].w};
+        float o[4], pg[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float xh = (xs[e] - mean) * rstd;
+          o[e] = rstd * (ds[e] * gs[e] - a - xh * b);
+          pg[e] = ds[e] * xh;
+        }
+        if (dx_add) {
+          const float4 r = *reinterpret_cast<const float4*>(dx_add + (int64_t)row * lda + c);
+          o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
+        }
+        *reinterpret_cast<float4*>(dx + (int64_t)row * ldo + c) = make_float4(o[0], o[1], o[2], o[3]);
+        ag[j].x += pg[0]; ag[j].y += pg[1]; ag[j].z += pg[2]; ag[j].w += pg[3];
+        ab[j].x += ds[0]; ab[j].y += ds[1]; ab[j].z += ds[2]; ab[j].w += ds[3];
+      }
+    }
+  }
+  float* mine = sh + (size_t)w * 2 * C;
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    const int c = (lane + 64 * j) * 4;
+    if (c < C) {
+      *reinterpret_cast<float4*>(mine + c) = ag[j];
+      *reinterpret_cast<float4*>(mine + C + c) = ab[j];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * C; c += 256)
+    part[(int64_t)blockIdx.x * 2 * C + c] = (sh[c] + sh[2 * C + c]) + (sh[4 * C + c] + sh[6 * C + c]);
+}
+
 // dgamma / dbeta [2][C] (+= if accumulate) = sum over the row blocks, fixed order: a workgroup owns 64 of the 2C columns, its 4
 // waves take the row blocks b = w, w+4, ... (two independent chains each), the partial sums meet in LDS in wave order
 __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ dgamma,
@@ -341,9 +429,29 @@ extern "C" int sp3_layernorm_bwd(const float* x, int64_t ldx, const float* gamma
                                  int rows, int C, float eps, void* stream) {
   SP3_CHECK(x && gamma && dy && dx && dgamma && dbeta && scratch, "sp3_layernorm_bwd: null pointer");
   SP3_CHECK(rows > 0 && C > 0 && C % 4 == 0 && C <= 2048, "sp3_layernorm_bwd: rows=%d C=%d (C <= 2048, C %% 4 == 0)", rows, C);
-  const int nblk = (rows + 3) / 4;
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(256), (size_t)8 * C * sizeof(float), ST(stream), x, ldx, gamma, dy, ldy, dx_add,
-                     ld_add, dx, ld_dx, scratch, rows, C, eps);
+  int nblk = (rows + 3) / 4;
+  const bool al = (((ldx | ldy | ld_dx | (dx_add ? ld_add : 0)) & 3) == 0) &&
+                  (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(dx_add) |
+                     reinterpret_cast<uintptr_t>(gamma)) & 15) == 0);
+  const int V = (C + 255) / 256;
+  if (al && V <= 8) {
+    constexpr int RPW = 2;
+    nblk = (rows + 4 * RPW - 1) / (4 * RPW);
+    const size_t lds = (size_t)8 * C * sizeof(float);
+#define SP3_LNB(v) hipLaunchKernelGGL((layernorm_bwd_reg_kernel<v, RPW>), dim3(nblk), dim3(256), lds, ST(stream), x, ldx, gamma, dy, ldy, dx_add, ld_add, dx, ld_dx, scratch, rows, C, eps)
+    switch (V) {
+      case 1: SP3_LNB(1); break;
+      case 2: SP3_LNB(2); break;
+      case 3: SP3_LNB(3); break;
+      case 4: SP3_LNB(4); break;
+      case 5: case 6: SP3_LNB(6); break;
+      default: SP3_LNB(8); break;
+    }
+#undef SP3_LNB
+  } else {
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(256), (size_t)8 * C * sizeof(float), ST(stream), x, ldx, gamma, dy, ldy, dx_add,
+                       ld_add, dx, ld_dx, scratch, rows, C, eps);
+  }
   hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * C + 63) / 64), dim3(256), 0, ST(stream), scratch, nblk, C, dgamma, dbeta, accumulate);
   SP3_LAUNCH_CHECK("sp3_layernorm_bwd");
   return 0;

@@ -17,8 +17,12 @@ namespace {
 // one workgroup = a 64 x 64 tile of the source through LDS; both outputs are written as whole 16-byte fragment pieces,
 // 16 consecutive lanes = 256 contiguous bytes.  Elements outside [rows, cols] are written as zeros (the contraction pad of
 // the GEMM must be zero); row blocks beyond the allocation are skipped.
+// colsum (nullable): the column sums of src (a Linear's bias gradient, autograd's dY.sum(0)) ride along: every workgroup leaves the sums of
+// its 64 x 64 tile in partial[row tile][col]; the LAST workgroup of a column tile to arrive (a counter per column tile, reset for the next
+// launch) adds the row tiles in a fixed order -- one launch, deterministic, no separate reduction kernel.
 __global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict__ src, int64_t ld, int rows, int cols,
-                                                        __bf16* __restrict__ dst, __bf16* __restrict__ dstT) {
+                                                        __bf16* __restrict__ dst, __bf16* __restrict__ dstT, float* __restrict__ colsum,
+                                                        int accumulate, float* partial, unsigned* counter) {
   __shared__ float t[64][65];
   const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64, tid = threadIdx.x;
   const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
@@ -65,6 +69,34 @@ __global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict_
       }
     }
   }
+  if (colsum) {
+    __shared__ unsigned last;
+    __shared__ float fin[4][64];
+    const int64_t ldp = (int64_t)gridDim.x * 64;
+    if (tid < 64) {
+      float s = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < 64; ++r) s += t[r][tid];              // (rows beyond `rows` were loaded as zeros)
+      partial[(int64_t)blockIdx.y * ldp + c0 + tid] = s;
+      __threadfence();
+    }
+    __syncthreads();
+    if (tid == 0) last = atomicAdd(&counter[blockIdx.x], 1u) == gridDim.y - 1 ? 1u : 0u;
+    __syncthreads();
+    if (last) {
+      __threadfence();
+      const int c = tid & 63, q = tid >> 6;
+      float s = 0.f;
+      for (int by = q; by < (int)gridDim.y; by += 4) s += __hip_atomic_load(&partial[(int64_t)by * ldp + c0 + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      fin[q][c] = s;
+      __syncthreads();
+      if (q == 0 && c0 + c < cols) {
+        const float tot = (fin[0][c] + fin[1][c]) + (fin[2][c] + fin[3][c]);
+        colsum[c0 + c] = (accumulate ? colsum[c0 + c] : 0.f) + tot;
+      }
+      if (tid == 0) counter[blockIdx.x] = 0u;
+    }
+  }
 }
 
 // Head shuffle of multi-head attention in training (croco/models/blocks.py:100-108, :160-166: the reshape / permute / RoPE between
@@ -73,7 +105,7 @@ __global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict_
 // [B*H, hd, r8(N)] (pad columns zero) the A . W^T GEMMs need for the products contracted over tokens.  Up to three parts (q, k, v or
 // dq, dk, dv) per launch: what were ~11 ATen copies, two rope launches and a transpose per attention is one launch.
 // Workgroup = 64 tokens x hd (<= 64) of one (b, h) through LDS.
-struct HeadShuffleArgs { sp3_head_part p[3]; int B, H, hd; float base; };
+struct HeadShuffleArgs { sp3_head_part p[3]; int B, H, hd; float base; const float *cos_tab, *sin_tab; int tab_len; };   // tables [tab_len][hd / 4]
 
 __global__ __launch_bounds__(256) void head_shuffle_kernel(HeadShuffleArgs a) {
   __shared__ float t[64][65];
@@ -96,9 +128,15 @@ __global__ __launch_bounds__(256) void head_shuffle_kernel(HeadShuffleArgs a) {
       const int tl = idx / (2 * Q), i = idx - tl * 2 * Q;
       if (n0 + tl >= N) continue;
       const int axis = i / Q, f = i - axis * Q;
-      const float pz = (float)P.pos[((int64_t)b * N + n0 + tl) * 2 + axis];
-      const float ang = pz * (P.fwd / powf(a.base, (float)f / (float)Q));
-      const float cs = cosf(ang), sn = sinf(ang);
+      const int64_t pi = P.pos[((int64_t)b * N + n0 + tl) * 2 + axis];
+      float cs, sn;
+      if (pi >= 0 && pi < a.tab_len) {               // the caller's table (positions are small grid coordinates): no libm calls per pair
+        cs = a.cos_tab[pi * Q + f];
+        sn = P.fwd * a.sin_tab[pi * Q + f];
+      } else {
+        const float ang = (float)pi * (P.fwd / powf(a.base, (float)f / (float)Q));
+        cs = cosf(ang); sn = sinf(ang);
+      }
       const int du = axis * 2 * Q + f, dv = du + Q;
       const float u = t[tl][du], v = t[tl][dv];
       t[tl][du] = u * cs - v * sn;
@@ -272,8 +310,22 @@ extern "C" int sp3_pack_bf16(const float* src, int64_t ld, int rows, int cols, v
   SP3_CHECK(((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(dstT)) & 15) == 0, "sp3_pack_bf16: outputs must be 16-byte aligned");
   const dim3 grid((cols + 63) / 64, (rows + 63) / 64);
   SP3_CHECK(grid.y <= 65535, "sp3_pack_bf16: too many rows for one launch (%d)", rows);
-  hipLaunchKernelGGL(pack_bf16_kernel, grid, dim3(256), 0, ST(stream), src, ld, rows, cols, reinterpret_cast<__bf16*>(dst), reinterpret_cast<__bf16*>(dstT));
+  hipLaunchKernelGGL(pack_bf16_kernel, grid, dim3(256), 0, ST(stream), src, ld, rows, cols, reinterpret_cast<__bf16*>(dst), reinterpret_cast<__bf16*>(dstT),
+                     (float*)nullptr, 0, (float*)nullptr, (unsigned*)nullptr);
   SP3_LAUNCH_CHECK("sp3_pack_bf16");
+  return 0;
+}
+
+extern "C" int sp3_pack_bf16_colsum(const float* src, int64_t ld, int rows, int cols, void* dst, void* dstT, float* colsum, int accumulate,
+                                    float* partial_ws, unsigned* counter_ws, void* stream) {
+  SP3_CHECK(src && (dst || dstT) && colsum && partial_ws && counter_ws && rows > 0 && cols > 0 && ld >= cols,
+            "sp3_pack_bf16_colsum: bad arguments (rows=%d cols=%d ld=%lld)", rows, cols, (long long)ld);
+  SP3_CHECK(((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(dstT)) & 15) == 0, "sp3_pack_bf16_colsum: outputs must be 16-byte aligned");
+  SP3_CHECK(rows <= 8192, "sp3_pack_bf16_colsum: rows=%d > 8192 (taller matrices: sp3_pack_bf16 + sp3_colsum_rows)", rows);
+  const dim3 grid((cols + 63) / 64, (rows + 63) / 64);
+  hipLaunchKernelGGL(pack_bf16_kernel, grid, dim3(256), 0, ST(stream), src, ld, rows, cols, reinterpret_cast<__bf16*>(dst), reinterpret_cast<__bf16*>(dstT),
+                     colsum, accumulate, partial_ws, counter_ws);
+  SP3_LAUNCH_CHECK("sp3_pack_bf16_colsum");
   return 0;
 }
 
@@ -323,11 +375,13 @@ extern "C" int sp3_adamw_flat(float* p, const float* g, float* m, float* v, int6
   return 0;
 }
 
-extern "C" int sp3_head_shuffle(const sp3_head_part* parts, int nparts, int B, int H, int hd, float base, void* stream) {
+extern "C" int sp3_head_shuffle(const sp3_head_part* parts, int nparts, int B, int H, int hd, float base, const float* cos_tab,
+                                const float* sin_tab, int tab_len, void* stream) {
   SP3_CHECK(parts && nparts >= 1 && nparts <= 3 && B > 0 && H > 0 && hd > 0 && hd <= 64 && hd % 4 == 0 && (int64_t)B * H <= 65535,
             "sp3_head_shuffle: bad arguments (nparts=%d B=%d H=%d hd=%d)", nparts, B, H, hd);
   HeadShuffleArgs a;
   a.B = B; a.H = H; a.hd = hd; a.base = base;
+  a.cos_tab = cos_tab; a.sin_tab = sin_tab; a.tab_len = (cos_tab && sin_tab) ? tab_len : 0;
   int nmax = 0;
   for (int i = 0; i < nparts; ++i) {
     const sp3_head_part& p = parts[i];

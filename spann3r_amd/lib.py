@@ -147,7 +147,7 @@ _PROTOS = {
     "sp3_transpose_batched": [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "sp3_transpose_pad": [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "sp3_softmax_bwd_pad": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p],
-    "sp3_head_shuffle": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p],
+    "sp3_head_shuffle": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p],
     "sp3_attention_train_fwd": [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                 C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p],
     "sp3_attention_train_bwd": [C.c_void_p, C.c_void_p],
@@ -164,6 +164,7 @@ _PROTOS = {
                   C.c_float, C.c_void_p],
     "sp3_mul": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
     "sp3_pack_bf16": [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
+    "sp3_pack_bf16_colsum": [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
     "sp3_colsum_rows": [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p],
     "sp3_sumsq_partial": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p],
     "sp3_clip_coef": [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p],

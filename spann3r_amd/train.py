@@ -245,6 +245,18 @@ def _tb(src, rows, cols, ld_src, batch=1, stride_src=0):
     return dst
 
 
+def _bf16_tile(M, N):
+    """Tile of a training Linear's bf16 GEMMs (forward, dX, dW at ~800 rows; tools/bench_gemm2.py --train on MI355X): the 128x128
+    pipelined tile as soon as it yields ~100 workgroups, else the 32x32 pipelined one (600-1000 workgroups, 7-9 us instead of the
+    128x64 tile's 13 with 72-112 workgroups on 256 CUs); large problems keep the library's own choice."""
+    if M < 512:
+        return -1
+    mt256, mt128, nt128 = (M + 255) // 256, (M + 127) // 128, (N + 127) // 128
+    if mt256 * nt128 >= 144:
+        return -1
+    return 21 if mt128 * nt128 >= 100 else 25
+
+
 def _pad8(x):
     """[R, N] -> contiguous [R, r8(N)] with zero columns (no copy when N % 8 == 0)"""
     R, N = x.shape
@@ -273,7 +285,7 @@ class _Linear(torch.autograd.Function):
             need_t = ctx.needs_input_grad[1]
             xp, xT = ops.pack_bf16(x, True, need_t)
             Wp, WT = _packed_weight(W, wkey)
-            ops.gemm(xp, Wp, y, M=R, N=N, K=_r64(K), lda=K, ldc=N, bias=b, res1=res, ldr1=N, res2=res2, ldr2=N)
+            ops.gemm(xp, Wp, y, M=R, N=N, K=_r64(K), lda=K, ldc=N, bias=b, res1=res, ldr1=N, res2=res2, ldr2=N, tile=_bf16_tile(R, N))
             ctx.xT, ctx.WT, ctx.shape = xT, WT, (R, K, N)
             ctx.Wparam = W if (isinstance(W, torch.nn.Parameter) and W.dim() == 2) else None
             if ctx.Wparam is not None and need_t:
@@ -289,17 +301,31 @@ class _Linear(torch.autograd.Function):
         dy = dy.contiguous()
         dev = dy.device
         dx = dW = db = None
+        bias_done = False
         if ctx.bf16:
             R, K, N = ctx.shape
             need_w = ctx.needs_input_grad[1]
-            dyp, dyT = ops.pack_bf16(dy, ctx.needs_input_grad[0], need_w) if (ctx.needs_input_grad[0] or need_w) else (None, None)
+            need_b = ctx.has[0] and ctx.needs_input_grad[2]
+            dyp = dyT = None
+            if ctx.needs_input_grad[0] or need_w:
+                if need_b and R <= 8192:            # the bias gradient rides in the pack launch (straight into the bucket when it may)
+                    direct = _direct_ok(ctx.bparam)
+                    tgt = ctx.bparam.grad if direct else torch.empty(N, device=dev)
+                    dyp, dyT = ops.pack_bf16(dy, ctx.needs_input_grad[0], need_w, colsum=tgt, accumulate=direct)
+                    if direct:
+                        _contributed(ctx.bparam)
+                    else:
+                        db = tgt
+                    bias_done = True
+                else:
+                    dyp, dyT = ops.pack_bf16(dy, ctx.needs_input_grad[0], need_w)
             if ctx.needs_input_grad[0]:           # dX = dY . W = dY . (W^T)^T: contraction over N
                 dx = torch.empty(R, K, device=dev)
-                ops.gemm(dyp, ctx.WT, dx, M=R, N=K, K=_r64(N), lda=N, ldc=K)
+                ops.gemm(dyp, ctx.WT, dx, M=R, N=K, K=_r64(N), lda=N, ldc=K, tile=_bf16_tile(R, K))
             if need_w:                            # dW = dY^T . X = (dY^T) . (X^T)^T: contraction over the rows
                 xTw = ops.PackedWeight.wrap(ctx.xT.data, K, R)
                 def dw_into(out, acc):
-                    ops.gemm(dyT, xTw, out, M=N, N=K, K=_r64(R), lda=R, ldc=K, res1=out if acc else None, ldr1=K)
+                    ops.gemm(dyT, xTw, out, M=N, N=K, K=_r64(R), lda=R, ldc=K, res1=out if acc else None, ldr1=K, tile=_bf16_tile(N, K))
                 if not _into_grad(ctx.Wparam, dw_into):
                     dW = torch.empty(N, K, device=dev)
                     dw_into(dW, False)
@@ -315,7 +341,7 @@ class _Linear(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 dyT, xT = _tb(dy, R, N, N)[0], _tb(x, R, K, K)[0]            # [N, r8(R)], [K, r8(R)]
                 dW = _nt(dyT, xT, N, K, dyT.shape[1], dyT.shape[1], xT.shape[1], torch.empty(N, K, device=dev), K)
-        if ctx.has[0] and ctx.needs_input_grad[2]:
+        if ctx.has[0] and ctx.needs_input_grad[2] and not bias_done:
             if not _into_grad(ctx.bparam, lambda out, acc: _colsum(dy, out=out)):
                 db = _colsum(dy)
         return dx, dW, db, (dy if ctx.has[1] else None), (dy if ctx.has[2] else None), None
@@ -463,6 +489,19 @@ class _Attention(torch.autograd.Function):
         return dq, dk, dV, None
 
 
+_rope_tabs = {}
+
+
+def _rope_table(base, hd, device, n=256):
+    """cos / sin of p * base^(-f / (hd/4)) for p < n as fp32 [n, hd/4] (croco/models/pos_embed.py:118-129 get_cos_sin, from float64)"""
+    key = (float(base), hd, str(device))
+    if key not in _rope_tabs:
+        Q = hd // 4
+        ang = torch.arange(n, dtype=torch.float64)[:, None] * (float(base) ** (-torch.arange(Q, dtype=torch.float64) / Q))[None]
+        _rope_tabs[key] = (ang.cos().float().to(device).contiguous(), ang.sin().float().to(device).contiguous(), n)
+    return _rope_tabs[key]
+
+
 def _head_shuffle(parts, B, H, hd, base):
     """parts: up to three dicts (src, s = (s_b, s_n, s_h), N, and dst + d = (d_b, d_n, d_h) and / or dstT, pos, fwd): sp3_head_shuffle"""
     arr = (L.HeadPart * len(parts))()
@@ -473,7 +512,8 @@ def _head_shuffle(parts, B, H, hd, base):
         if dst is not None:
             a.d_b, a.d_n, a.d_h = p["d"]
         a.dstT, a.pos, a.fwd, a.ldT = L.ptr(dstT), L.ptr(pos), float(p.get("fwd", 1.0)), int(p.get("ldT", 0))
-    L.check(L.load().sp3_head_shuffle(arr, len(parts), B, H, hd, float(base), L.stream_ptr()), "sp3_head_shuffle")
+    ct, st, n = _rope_table(base, hd, parts[0]["src"].device) if any(p.get("pos") is not None for p in parts) else (None, None, 0)
+    L.check(L.load().sp3_head_shuffle(arr, len(parts), B, H, hd, float(base), L.ptr(ct), L.ptr(st), n, L.stream_ptr()), "sp3_head_shuffle")
 
 
 class _MHA(torch.autograd.Function):

@@ -409,6 +409,30 @@ def test_pack_bf16_both_layouts(R, C):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("R,C", [(784, 768), (784, 3072), (100, 200), (3, 130), (8192, 64)])
+def test_pack_bf16_column_sums_ride_along(R, C):
+    """sp3_pack_bf16_colsum: the bias gradient dY.sum(0) from the pack launch (last-arriving workgroup reduces in a fixed order):
+    equal to float64 within fp32 rounding, bit-identical across launches, accumulates, leaves its counters at zero"""
+    from spann3r_amd import ops
+    g = torch.Generator().manual_seed(R + C)
+    x = torch.randn(R, C, generator=g).cuda()
+    ref = x.double().sum(0).cpu()
+    outs = []
+    for rep in range(3):
+        out = torch.full((C,), float("nan"), device="cuda")
+        a, t = ops.pack_bf16(x, True, rep != 1, colsum=out)
+        outs.append(out.clone())
+    a0, _ = ops.pack_bf16(x, True, False)
+    assert torch.equal(a.data, a0.data)
+    assert rel_err(outs[0].cpu(), ref) < 2e-6
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    acc = torch.ones(C, device="cuda")
+    ops.pack_bf16(x, True, False, colsum=acc, accumulate=True)
+    assert torch.allclose(acc, outs[0] + 1.0, rtol=0, atol=1e-5 * float(outs[0].abs().max()))
+    assert int(ops._pack_ws[str(x.device)][1].abs().sum()) == 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("R,K,N", [(784, 1024, 3072), (196, 768, 768), (50, 200, 4), (1568, 864, 256)])
 def test_linear_bf16_forward_backward(R, K, N):
     """the bf16 Linear (packed operands, no transposes): y, dX, dW, db against float64 on the bf16-rounded operands"""

@@ -18,6 +18,7 @@ ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--only", default="", help="comma list of op names")
 ap.add_argument("--tiles", default="")
 ap.add_argument("--mb", type=int, default=320, help="MB of distinct weight copies to cycle through")
+ap.add_argument("--train", action="store_true", help="the training step's Linear shapes at batch 4 (784 rows; dW: contraction over the rows), fp32 row-major output")
 ap.add_argument("--ksweep", action="store_true", help="one many-row shape at several K: fixed cost vs cost per k-block")
 args = ap.parse_args()
 dev = "cuda"
@@ -63,6 +64,13 @@ else:
               ("val fc2", M, 1024, 4096, 1), ("key 0", M, 1792, 1792, 2), ("key 2", M, 1024, 1792, 2)]
     tiles = [0, 13, 14, 16, 17]
 
+if args.train:
+    shapes = []
+    for C, Hd, tag in ((768, 3072, "dec"), (1024, 4096, "val")):
+        for nm, N, K in (("proj", C, C), ("qkv", 3 * C, C), ("fc1", Hd, C), ("fc2", C, Hd)):
+            shapes.append(("%s %s" % (tag, nm), 784, N, K, 1))            # forward; dX is the same launch with N and K swapped
+            shapes.append(("%s %s dW" % (tag, nm), N, K, 832, 1))         # dW = dY^T . X, contraction over the 784 rows (padded to 64)
+    tiles = [0, 1, 21, 22, 23, 24, 25]
 if args.ksweep:
     shapes = [("k%d" % K, 1960, 4096, K, 1) for K in (128, 512, 1024, 2048, 4096)] + [("n1k k%d" % K, 1960, 1024, K, 1) for K in (128, 1024, 4096)]
     tiles = [5, 20, 21, 22]
@@ -84,13 +92,13 @@ for name, M, N, K, G in shapes:
         out = ops.PackedAct.group(G, M, N, DT, dev)
     else:
         A = ops.PackedAct.from_dense(torch.randn(M, K, device=dev).to(DT))
-        out = ops.PackedAct(M, N, DT, dev)
+        out = torch.empty(M, N, device=dev) if args.train else ops.PackedAct(M, N, DT, dev)
     bias = torch.randn(G, N, device=dev)
-    ACT = ops.ACT_GELU if ("fc1" in name or name == "key 0") else ops.ACT_NONE
+    ACT = ops.ACT_GELU if (("fc1" in name or name == "key 0") and not args.train) else ops.ACT_NONE
     part = torch.empty(8 * G * M * N, device=dev)
     for tile in tiles:
-        BN = {0: 32, 9: 32, 5: 128, 20: 128, 21: 128, 2: 128}.get(tile, 64)
-        BM = {0: 32, 4: 32, 18: 16, 20: 256, 21: 128, 22: 128, 23: 64, 8: 208, 12: 208, 15: 208, 5: 128, 6: 128, 1: 64, 2: 64}.get(tile, 112)
+        BN = {0: 32, 9: 32, 5: 128, 20: 128, 21: 128, 2: 128, 24: 32, 25: 32}.get(tile, 64)
+        BM = {0: 32, 4: 32, 18: 16, 20: 256, 21: 128, 22: 128, 23: 64, 24: 64, 25: 32, 8: 208, 12: 208, 15: 208, 5: 128, 6: 128, 1: 64, 2: 64}.get(tile, 112)
         wgs = ((M + BM - 1) // BM) * ((N + BN - 1) // BN) * G
         sks = [0]
         if not args.big and tile != 0 and G == 1:
