@@ -189,6 +189,39 @@ def test_flash_attention_is_as_close_to_float64_as_the_materialised_one(gain):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("N,Nk", [(196, 201), (64, 256), (300, 260), (37, 500)])
+def test_flash_attention_bf16_products(N, Nk):
+    """bf16 training precision: the LDS-staged kernels (<= 256 tokens) and the streaming ones (longer sequences) against float64, next to
+    the materialised path with the same operand rounding (fp32 operands rounded to bf16 inside the GEMMs)"""
+    from spann3r_amd import train as T
+    B, H = 2, 3
+    C = 64 * H
+    g = torch.Generator().manual_seed(N)
+    q0, k0, v0, d0 = (torch.randn(B, n, C, generator=g) for n in (N, Nk, Nk, N))
+    scale = 64 ** -0.5
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q0, k0, v0))
+    hd = lambda t, n: t.reshape(B, n, H, 64).transpose(1, 2)
+    a = torch.softmax(hd(qd, N) @ hd(kd, Nk).transpose(-1, -2) * scale, -1)
+    ref = (a @ hd(vd, Nk)).transpose(1, 2).reshape(B, N, C)
+    ref.backward(d0.double())
+    refs = [ref.detach(), qd.grad, kd.grad, vd.grad]
+    errs = {}
+    T.set_precision("bf16")
+    try:
+        for mode, flash in (("flash", True), ("gemm", False)):
+            T.FLASH_ATTENTION = flash
+            q, k, v = (t.cuda().requires_grad_(True) for t in (q0, k0, v0))
+            out = T._mha(q, k, v, None, None, H, scale, 100.0)
+            out.backward(d0.cuda())
+            errs[mode] = [rel_err(x.detach().cpu(), r) for x, r in zip((out, q.grad, k.grad, v.grad), refs)]
+    finally:
+        T.FLASH_ATTENTION = True
+        T.set_precision("fp32")
+    print("bf16 attention vs float64 (%d x %d): flash %s, materialised %s" % (N, Nk, ["%.1e" % e for e in errs["flash"]], ["%.1e" % e for e in errs["gemm"]]))
+    assert max(errs["flash"]) < 2e-2 and all(f < 2 * m + 2e-3 for f, m in zip(errs["flash"], errs["gemm"])), errs
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cross", [False, True])
 def test_fused_heads_match_the_separate_reshapes(cross):
     """_FlashMHA (no attention matrix) and _MHA (one shuffle launch each way around the GEMMs) against the ATen reshapes + _Attention"""
@@ -322,18 +355,24 @@ def test_training_step_gradients_match_oracle(tiny_sd):
     assert abs(float(loss) + float(factor) - float(l64) - float(f64)) < 1e-4 * abs(float(l64))
     assert rel_err(preds_all[-1][1]["pts3d_in_other_view"].detach().cpu(), pa64[-1][1]["pts3d_in_other_view"].detach()) < 1e-4
     gmax = max(float(v.grad.abs().max()) for v in P64.values() if v.grad is not None)
-    worst, n_checked = (0.0, None), 0
+    worst, n_checked, errs, num, den = (0.0, None), 0, [], 0.0, 0.0
     for k, v in P64.items():
         if v.grad is None:
             assert P[k].grad is None or float(P[k].grad.abs().max()) < 1e-6 * gmax, k
             continue
-        e = float((P[k].grad.cpu().double() - v.grad).abs().max()) / max(float(v.grad.abs().max()), 1e-4 * gmax)
+        d = P[k].grad.cpu().double() - v.grad
+        e = float(d.abs().max()) / max(float(v.grad.abs().max()), 1e-4 * gmax)
+        num, den = num + float((d ** 2).sum()), den + float((v.grad ** 2).sum())
+        errs.append(e)
         n_checked += 1
         if e > worst[0]:
             worst = (e, k)
-    print("training step: loss %.6f (oracle %.6f), %d parameter gradients, worst scaled error %.2e (%s)" %
-          (float(loss) + float(factor), float(l64) + float(f64), n_checked, worst[0], worst[1]))
-    assert worst[0] < 6e-5, worst            # measured 5.5e-6 (norm_q.bias)
+    errs.sort()
+    print("training step: loss %.6f (oracle %.6f), %d parameter gradients, worst scaled error %.2e (%s), median %.2e, global rel. L2 %.2e" %
+          (float(loss) + float(factor), float(l64) + float(f64), n_checked, worst[0], worst[1], errs[len(errs) // 2], (num / den) ** 0.5))
+    # typical 5e-6 (norm_q.bias).  A convolution in front of a ReLU (head.2, the residual units) sums 1[pre-activation > 0] terms: a
+    # pre-activation within 1e-7 of zero flips under ANY fp32 rounding change of the forward and moves single entries by ~1e-4
+    assert (num / den) ** 0.5 < 1e-5 and errs[len(errs) // 2] < 1e-5 and worst[0] < 4e-4, worst
 
 
 @pytest.mark.gpu
