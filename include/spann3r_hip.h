@@ -404,11 +404,11 @@ int sp3_mul(const float* a, const float* b, float* out, int64_t n, void* stream)
  * as zeros.  With both forms every product of a Linear's backward (dX = dY . W, dW = dY^T . X) is an sp3_gemm A . W^T launch on packed
  * bf16 operands: the ATen calls they replace are the matmuls autograd derives for nn.Linear (croco/models/blocks.py:73-112). */
 int sp3_pack_bf16(const float* src, int64_t ld, int rows, int cols, void* dst, void* dstT, void* stream);
-/* same launch, and colsum[j] (+)= sum_r src[r, j] (the bias gradient of the Linear whose dY is being packed; rows <= 8192): partial_ws holds
- * ceil(rows / 64) * ceil(cols / 64) * 64 floats, counter_ws ceil(cols / 64) zero-initialised counters that the launch leaves at zero
- * (one launch at a time per workspace).  Fixed summation order: deterministic. */
+/* sp3_pack_bf16, and colsum[j] (+)= sum_r src[r, j] (the bias gradient of the Linear whose dY is being packed; rows <= 8192): the pack
+ * launch leaves the column sums of its 64-row tiles in partial_ws (ceil(rows / 64) * ceil(cols / 64) * 64 floats), a second small launch
+ * adds them in a fixed order: deterministic, and no second pass over src. */
 int sp3_pack_bf16_colsum(const float* src, int64_t ld, int rows, int cols, void* dst, void* dstT, float* colsum, int accumulate,
-                         float* partial_ws, unsigned* counter_ws, void* stream);
+                         float* partial_ws, void* stream);
 /* torch.nn.utils.clip_grad_norm_ (croco/utils/misc.py:262-288, called with clip_grad = 1.0 by spann3r/training.py:227-228) on flat
  * gradient buckets, without a host round trip: sp3_sumsq_partial writes sp3_sumsq_blocks(n) partial sums of squares of one bucket
  * (fixed order: deterministic), sp3_clip_coef reduces `count` partials of all buckets to out[0] = extra_scale * min(1, max_norm /

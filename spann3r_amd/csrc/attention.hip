@@ -674,263 +674,6 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(AttnBwdArgs a) {
 }
 
 
-// ------------------------------------------------------------------ training, bf16 products, sequences of <= 256 tokens: LDS-staged
-// The kernels above stream every operand tile from L2 straight into MFMA registers, a handful of dependent 16-byte loads at a time:
-// at 196 tokens they are latency-bound (20 / 30 / 55 us for forward / dq / dk,dv at batch 4 x 12 heads).  Here a workgroup owns 64
-// rows (one 16-row block per wave), copies the WHOLE other axis of its head into LDS once -- rows as bf16 [N][72] (144-byte rows:
-// conflict-free 16-byte reads), per-head transposes as bf16 [64][N64 + 8] -- with a few rounds of independent coalesced 16-byte
-// loads, and every wave then walks all tiles on its own: no cross-wave merge, no global access inside the loops.
-constexpr int kRowLd = 72;
-
-// (16 independent 16-byte loads per thread are issued before the first conversion: one round trip to L2 per 64 KB of source)
-constexpr int kStageBatch = 16;
-__device__ __forceinline__ bf16x4 cvt4(const float4 v) {
-  bf16x4 o;
-  o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
-  return o;
-}
-__device__ __forceinline__ void stage_rows(__bf16* dst, const float* src, int64_t ld, int N, int tid) {
-  const int total = N * 16;
-  for (int base = 0; base < total; base += 256 * kStageBatch) {
-    float4 v[kStageBatch];
-#pragma unroll
-    for (int j = 0; j < kStageBatch; ++j) {
-      const int idx = base + j * 256 + tid;
-      if (idx < total) v[j] = *reinterpret_cast<const float4*>(src + (int64_t)(idx >> 4) * ld + (idx & 15) * 4);
-    }
-#pragma unroll
-    for (int j = 0; j < kStageBatch; ++j) {
-      const int idx = base + j * 256 + tid;
-      if (idx < total) *reinterpret_cast<bf16x4*>(dst + (idx >> 4) * kRowLd + (idx & 15) * 4) = cvt4(v[j]);
-    }
-  }
-}
-__device__ __forceinline__ void stage_T(__bf16* dst, const float* src, int64_t ldT, int NP, int tid) {
-  const int per = NP >> 2, total = 64 * per;
-  for (int base = 0; base < total; base += 256 * kStageBatch) {
-    float4 v[kStageBatch];
-#pragma unroll
-    for (int j = 0; j < kStageBatch; ++j) {
-      const int idx = base + j * 256 + tid;
-      if (idx < total) { const int d = idx / per; v[j] = *reinterpret_cast<const float4*>(src + (int64_t)d * ldT + (idx - d * per) * 4); }
-    }
-#pragma unroll
-    for (int j = 0; j < kStageBatch; ++j) {
-      const int idx = base + j * 256 + tid;
-      if (idx < total) { const int d = idx / per; *reinterpret_cast<bf16x4*>(dst + d * (NP + 8) + (idx - d * per) * 4) = cvt4(v[j]); }
-    }
-  }
-}
-// the 16 head dimensions lane group g owns in AttnT<__bf16>'s operand layout (8g .. 8g+7 and 32+8g .. 32+8g+7), from an fp32 row
-__device__ __forceinline__ void loadQ_bf(AttnT<__bf16>::QReg& r, const float* row, int g) {
-  const float4* p0 = reinterpret_cast<const float4*>(row + 8 * g);
-  const float4* p1 = reinterpret_cast<const float4*>(row + 32 + 8 * g);
-  r.v[0] = cvt8(p0[0], p0[1]);
-  r.v[1] = cvt8(p1[0], p1[1]);
-}
-
-__global__ __launch_bounds__(256) void attention_train_fwd_lds_kernel(const float* __restrict__ Q, int64_t sq, int64_t ldq, const float* __restrict__ K,
-                                                                     int64_t sk, int64_t ldk, const float* __restrict__ VT, int64_t vt_ld,
-                                                                     float* __restrict__ O, int64_t ldo, float* __restrict__ lse, int heads, int Nq,
-                                                                     int Nk, float scale) {
-  using A = AttnT<__bf16>;
-  extern __shared__ __align__(16) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, ql = lane & 15;
-  const int h = blockIdx.y, b = blockIdx.z, q0 = blockIdx.x * 64 + wave * 16;
-  const int NkP = (Nk + 63) & ~63;
-  const int64_t bh = (int64_t)b * heads + h;
-  __bf16* sK = reinterpret_cast<__bf16*>(smem);
-  __bf16* sVT = sK + NkP * kRowLd;
-  stage_rows(sK, K + (int64_t)b * sk + h * 64, ldk, Nk, tid);
-  stage_T(sVT, VT + bh * 64 * vt_ld, vt_ld, NkP, tid);
-  A::QReg qreg;
-  loadQ_bf(qreg, Q + (int64_t)b * sq + (int64_t)min(q0 + ql, Nq - 1) * ldq + h * 64, g);
-  __syncthreads();
-  f32x4 o[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m_run = -INFINITY, l_run = 0.f;
-  for (int kb = 0; kb < Nk; kb += 64) {
-    f32x4 s[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) s[t] = A::qk(sK + min(kb + 16 * t + ql, Nk - 1) * kRowLd, g, qreg);
-    float mx = -INFINITY;
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float v = (kb + 16 * t + 4 * g + r) < Nk ? s[t][r] * scale : -INFINITY;
-        s[t][r] = v;
-        mx = fmaxf(mx, v);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = expf(m_run - m_new);
-    float ps = 0.f;
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float e = expf(s[t][r] - m_new);
-        s[t][r] = e;
-        ps += e;
-      }
-    l_run = l_run * alpha + ps;
-    m_run = m_new;
-#pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) o[db][r] *= alpha;
-    A::pv(o, sVT, NkP + 8, kb, g, ql, s);
-  }
-  l_run += __shfl_xor(l_run, 16);
-  l_run += __shfl_xor(l_run, 32);
-  const float inv = 1.0f / l_run;
-  if (q0 + ql < Nq) {
-    float* orow = O + ((int64_t)b * Nq + q0 + ql) * ldo + h * 64 + 4 * g;
-#pragma unroll
-    for (int db = 0; db < 4; ++db)
-      *reinterpret_cast<float4*>(orow + db * 16) = make_float4(o[db][0] * inv, o[db][1] * inv, o[db][2] * inv, o[db][3] * inv);
-    if (g == 0) *reinterpret_cast<float2*>(lse + 2 * (bh * Nq + q0 + ql)) = make_float2(m_run, inv);
-  }
-}
-
-__global__ __launch_bounds__(256) void attention_bwd_dq_lds_kernel(AttnBwdArgs a) {
-  using A = AttnT<__bf16>;
-  extern __shared__ __align__(16) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, ql = lane & 15;
-  const int h = blockIdx.y, b = blockIdx.z, q0 = blockIdx.x * 64 + wave * 16;
-  const int Nq = a.Nq, Nk = a.Nk, NkP = (Nk + 63) & ~63;
-  const int64_t bh = (int64_t)b * a.heads + h;
-  __bf16* sK = reinterpret_cast<__bf16*>(smem);
-  __bf16* sV = sK + NkP * kRowLd;
-  __bf16* sKT = sV + NkP * kRowLd;
-  stage_rows(sK, a.k + (int64_t)b * a.sk + h * 64, a.ldk, Nk, tid);
-  stage_rows(sV, a.v + (int64_t)b * a.sv + h * 64, a.ldv, Nk, tid);
-  stage_T(sKT, a.kT + bh * 64 * a.ldTk, a.ldTk, NkP, tid);
-  const int qrow = min(q0 + ql, Nq - 1);
-  A::QReg qreg, doreg;
-  loadQ_bf(qreg, a.q + (int64_t)b * a.sq + (int64_t)qrow * a.ldq + h * 64, g);
-  loadQ_bf(doreg, a.dout + (int64_t)b * a.sdo + (int64_t)qrow * a.lddo + h * 64, g);
-  const float2 lq = *reinterpret_cast<const float2*>(a.lse + 2 * (bh * Nq + qrow));
-  __syncthreads();
-  auto tile = [&](int kb, f32x4 (&p)[4], f32x4 (&dp)[4]) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int krow = min(kb + 16 * t + ql, Nk - 1);
-      const f32x4 s = A::qk(sK + krow * kRowLd, g, qreg);
-      dp[t] = A::qk(sV + krow * kRowLd, g, doreg);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) p[t][r] = (kb + 16 * t + 4 * g + r) < Nk ? expf(s[r] * a.scale - lq.x) * lq.y : 0.f;
-    }
-  };
-  double dsum = 0.0;
-  for (int kb = 0; kb < Nk; kb += 64) {
-    f32x4 p[4], dp[4];
-    tile(kb, p, dp);
-    float part = 0.f;
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) part += p[t][r] * dp[t][r];
-    dsum += (double)part;
-  }
-  dsum += __shfl_xor(dsum, 16);
-  dsum += __shfl_xor(dsum, 32);
-  const float Dq = (float)dsum;
-  f32x4 acc[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int kb = 0; kb < Nk; kb += 64) {
-    f32x4 p[4], dp[4], ds[4];
-    tile(kb, p, dp);
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) ds[t][r] = p[t][r] * (dp[t][r] - Dq) * a.scale;
-    A::pv(acc, sKT, NkP + 8, kb, g, ql, ds);
-  }
-  if (q0 + ql < Nq) {
-    float* orow = a.dq + (int64_t)b * a.sdq + (int64_t)(q0 + ql) * a.lddq + h * 64 + 4 * g;
-#pragma unroll
-    for (int db = 0; db < 4; ++db) *reinterpret_cast<float4*>(orow + db * 16) = make_float4(acc[db][0], acc[db][1], acc[db][2], acc[db][3]);
-    if (g == 0) a.D[bh * Nq + q0 + ql] = Dq;
-  }
-}
-
-__global__ __launch_bounds__(256) void attention_bwd_dkv_lds_kernel(AttnBwdArgs a) {
-  using A = AttnT<__bf16>;
-  extern __shared__ __align__(16) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, kl = lane & 15;
-  const int h = blockIdx.y, b = blockIdx.z, k0 = blockIdx.x * 64 + wave * 16;
-  const int Nq = a.Nq, Nk = a.Nk, NqP = (Nq + 63) & ~63;
-  const int64_t bh = (int64_t)b * a.heads + h;
-  __bf16* sQ = reinterpret_cast<__bf16*>(smem);
-  __bf16* sDO = sQ + Nq * kRowLd;
-  __bf16* sQT = sDO + Nq * kRowLd;
-  __bf16* sDOT = sQT + 64 * (NqP + 8);
-  float* sStat = reinterpret_cast<float*>(sDOT + 64 * (NqP + 8));       // [Nq][3]: row max, 1 / row sum, D
-  stage_rows(sQ, a.q + (int64_t)b * a.sq + h * 64, a.ldq, Nq, tid);
-  stage_rows(sDO, a.dout + (int64_t)b * a.sdo + h * 64, a.lddo, Nq, tid);
-  stage_T(sQT, a.qT + bh * 64 * a.ldTq, a.ldTq, NqP, tid);
-  stage_T(sDOT, a.doT + bh * 64 * a.ldTq, a.ldTq, NqP, tid);
-  for (int i = tid; i < Nq; i += 256) {
-    const float2 st = *reinterpret_cast<const float2*>(a.lse + 2 * (bh * Nq + i));
-    sStat[3 * i] = st.x; sStat[3 * i + 1] = st.y; sStat[3 * i + 2] = a.D[bh * Nq + i];
-  }
-  const int krow = min(k0 + kl, Nk - 1);
-  A::QReg kreg, vreg;
-  loadQ_bf(kreg, a.k + (int64_t)b * a.sk + (int64_t)krow * a.ldk + h * 64, g);
-  loadQ_bf(vreg, a.v + (int64_t)b * a.sv + (int64_t)krow * a.ldv + h * 64, g);
-  __syncthreads();
-  f32x4 acck[4], accv[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { acck[i] = f32x4{0.f, 0.f, 0.f, 0.f}; accv[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-  for (int qb = 0; qb < Nq; qb += 64) {
-    f32x4 pt[4], ds[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int qrow = min(qb + 16 * t + kl, Nq - 1);
-      const f32x4 s = A::qk(sQ + qrow * kRowLd, g, kreg);
-      const f32x4 dp = A::qk(sDO + qrow * kRowLd, g, vreg);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int qi = qb + 16 * t + 4 * g + r;
-        const int qc = min(qi, Nq - 1);
-        const float p = qi < Nq ? expf(s[r] * a.scale - sStat[3 * qc]) * sStat[3 * qc + 1] : 0.f;
-        pt[t][r] = p;
-        ds[t][r] = p * (dp[r] - sStat[3 * qc + 2]) * a.scale;
-      }
-    }
-    A::pv(accv, sDOT, NqP + 8, qb, g, kl, pt);
-    A::pv(acck, sQT, NqP + 8, qb, g, kl, ds);
-  }
-  if (k0 + kl < Nk) {
-    float* krow_o = a.dk + (int64_t)b * a.sdk + (int64_t)(k0 + kl) * a.lddk + h * 64 + 4 * g;
-    float* vrow_o = a.dv + (int64_t)b * a.sdv + (int64_t)(k0 + kl) * a.lddv + h * 64 + 4 * g;
-#pragma unroll
-    for (int db = 0; db < 4; ++db) {
-      *reinterpret_cast<float4*>(krow_o + db * 16) = make_float4(acck[db][0], acck[db][1], acck[db][2], acck[db][3]);
-      *reinterpret_cast<float4*>(vrow_o + db * 16) = make_float4(accv[db][0], accv[db][1], accv[db][2], accv[db][3]);
-    }
-  }
-}
-
-// dynamic LDS of the staged kernels (bytes) and the one-time opt-in above 64 KiB
-static size_t lds_fwd(int Nk) { const size_t P = (Nk + 63) & ~63; return (P * kRowLd + 64 * (P + 8)) * 2; }
-static size_t lds_dq(int Nk) { const size_t P = (Nk + 63) & ~63; return (2 * P * kRowLd + 64 * (P + 8)) * 2; }
-static size_t lds_dkv(int Nq) { const size_t P = (Nq + 63) & ~63; return (2 * (size_t)Nq * kRowLd + 2 * 64 * (P + 8)) * 2 + (size_t)Nq * 12; }
-template <typename F> static int raise_lds(F kern, bool& raised, const char* what) {      // one-time opt-in to the full 160 KB of dynamic LDS
-  if (!raised) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) { sp3_set_error("%s: cannot raise dynamic LDS to 160 KB: %s", what, hipGetErrorString(e)); return 2; }
-    raised = true;
-  }
-  return 0;
-}
-constexpr int kStagedMaxTokens = 256;
-
 }  // namespace
 
 extern "C" int sp3_attention_ex(const void* q, int64_t sq, int64_t ldq, const void* k, int64_t sk, int64_t ldk, const void* vt,
@@ -997,13 +740,7 @@ extern "C" int sp3_attention_train_fwd(const float* q, int64_t sq, int64_t ldq, 
   SP3_CHECK(ldq % 4 == 0 && ldk % 4 == 0 && ldo % 4 == 0 && sq % 4 == 0 && sk % 4 == 0, "sp3_attention_train_fwd: strides must keep 16-byte alignment");
   dim3 grid((Nq + 15) / 16, heads, B);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (bf16_products && Nk <= kStagedMaxTokens) {
-    const size_t lds = lds_fwd(Nk);
-    static bool raised = false;
-    if (raise_lds(attention_train_fwd_lds_kernel, raised, "sp3_attention_train_fwd")) return 2;
-    hipLaunchKernelGGL(attention_train_fwd_lds_kernel, dim3((Nq + 63) / 64, heads, B), dim3(256), lds, st, q, sq, ldq, k, sk, ldk, vt, vt_ld, out, ldo, lse,
-                       heads, Nq, Nk, scale);
-  } else if (bf16_products)
+  if (bf16_products)
     hipLaunchKernelGGL(attention_kernel<BF16X1>, grid, dim3(256), 0, st, q, sq, ldq, k, sk, ldk, vt, vt_ld, (void*)out, ldo, 0, 0, heads, Nq, Nk, scale, lse);
   else
     hipLaunchKernelGGL(attention_kernel<float>, grid, dim3(256), 0, st, q, sq, ldq, k, sk, ldk, vt, vt_ld, (void*)out, ldo, 0, 0, heads, Nq, Nk, scale, lse);
@@ -1028,13 +765,7 @@ extern "C" int sp3_attention_train_bwd(const sp3_attn_bwd_desc* d, void* stream)
   a.heads = d->heads; a.Nq = d->Nq; a.Nk = d->Nk; a.scale = d->scale;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const dim3 gq((d->Nq + 15) / 16, d->heads, d->B), gk((d->Nk + 15) / 16, d->heads, d->B);
-  if (d->bf16_products && d->Nq <= kStagedMaxTokens && d->Nk <= kStagedMaxTokens) {
-    const size_t l1 = lds_dq(d->Nk), l2 = lds_dkv(d->Nq);
-    static bool r1 = false, r2 = false;
-    if (raise_lds(attention_bwd_dq_lds_kernel, r1, "sp3_attention_train_bwd") || raise_lds(attention_bwd_dkv_lds_kernel, r2, "sp3_attention_train_bwd")) return 2;
-    hipLaunchKernelGGL(attention_bwd_dq_lds_kernel, dim3((d->Nq + 63) / 64, d->heads, d->B), dim3(256), l1, st, a);
-    hipLaunchKernelGGL(attention_bwd_dkv_lds_kernel, dim3((d->Nk + 63) / 64, d->heads, d->B), dim3(256), l2, st, a);
-  } else if (d->bf16_products) {
+  if (d->bf16_products) {
     hipLaunchKernelGGL(attention_bwd_dq_kernel<BF16X1>, gq, dim3(256), 0, st, a);
     hipLaunchKernelGGL(attention_bwd_dkv_kernel<BF16X1>, gk, dim3(256), 0, st, a);
   } else {

@@ -17,12 +17,12 @@ namespace {
 // one workgroup = a 64 x 64 tile of the source through LDS; both outputs are written as whole 16-byte fragment pieces,
 // 16 consecutive lanes = 256 contiguous bytes.  Elements outside [rows, cols] are written as zeros (the contraction pad of
 // the GEMM must be zero); row blocks beyond the allocation are skipped.
-// colsum (nullable): the column sums of src (a Linear's bias gradient, autograd's dY.sum(0)) ride along: every workgroup leaves the sums of
-// its 64 x 64 tile in partial[row tile][col]; the LAST workgroup of a column tile to arrive (a counter per column tile, reset for the next
-// launch) adds the row tiles in a fixed order -- one launch, deterministic, no separate reduction kernel.
+// partial (nullable): the column sums of src (a Linear's bias gradient, autograd's dY.sum(0)) ride along: every workgroup leaves the sums
+// of its 64 x 64 tile in partial[row tile][ceil64(cols)]; colsum_rows_finish_kernel adds the row tiles in order (13 values per column at
+// 784 rows instead of a second pass over dY).  (A last-arriving-workgroup reduction inside this launch was measured: the release fence
+// every workgroup then needs costs more than the extra launch.)
 __global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict__ src, int64_t ld, int rows, int cols,
-                                                        __bf16* __restrict__ dst, __bf16* __restrict__ dstT, float* __restrict__ colsum,
-                                                        int accumulate, float* partial, unsigned* counter) {
+                                                        __bf16* __restrict__ dst, __bf16* __restrict__ dstT, float* __restrict__ partial) {
   __shared__ float t[64][65];
   const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64, tid = threadIdx.x;
   const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
@@ -69,33 +69,11 @@ __global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict_
       }
     }
   }
-  if (colsum) {
-    __shared__ unsigned last;
-    __shared__ float fin[4][64];
-    const int64_t ldp = (int64_t)gridDim.x * 64;
-    if (tid < 64) {
-      float s = 0.f;
+  if (partial && tid < 64) {                                      // column sums of this tile (rows beyond `rows` were loaded as zeros)
+    float s = 0.f;
 #pragma unroll 8
-      for (int r = 0; r < 64; ++r) s += t[r][tid];              // (rows beyond `rows` were loaded as zeros)
-      partial[(int64_t)blockIdx.y * ldp + c0 + tid] = s;
-      __threadfence();
-    }
-    __syncthreads();
-    if (tid == 0) last = atomicAdd(&counter[blockIdx.x], 1u) == gridDim.y - 1 ? 1u : 0u;
-    __syncthreads();
-    if (last) {
-      __threadfence();
-      const int c = tid & 63, q = tid >> 6;
-      float s = 0.f;
-      for (int by = q; by < (int)gridDim.y; by += 4) s += __hip_atomic_load(&partial[(int64_t)by * ldp + c0 + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      fin[q][c] = s;
-      __syncthreads();
-      if (q == 0 && c0 + c < cols) {
-        const float tot = (fin[0][c] + fin[1][c]) + (fin[2][c] + fin[3][c]);
-        colsum[c0 + c] = (accumulate ? colsum[c0 + c] : 0.f) + tot;
-      }
-      if (tid == 0) counter[blockIdx.x] = 0u;
-    }
+    for (int r = 0; r < 64; ++r) s += t[r][tid];
+    partial[(int64_t)blockIdx.y * ((int64_t)gridDim.x * 64) + c0 + tid] = s;
   }
 }
 
@@ -186,13 +164,14 @@ __global__ __launch_bounds__(256) void colsum_rows_partial_kernel(const float* _
   if (w == 0 && j < N) partial[(int64_t)blockIdx.y * N + j] = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
 }
 
-__global__ __launch_bounds__(256) void colsum_rows_finish_kernel(const float* __restrict__ partial, int nchunk, int N, float* __restrict__ out, int accumulate) {
+__global__ __launch_bounds__(256) void colsum_rows_finish_kernel(const float* __restrict__ partial, int nchunk, int N, float* __restrict__ out, int accumulate,
+                                                                 int ldp) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= N) return;
   double s0 = 0.0, s1 = 0.0;
   int c = 0;
-  for (; c + 1 < nchunk; c += 2) { s0 += (double)partial[(int64_t)c * N + j]; s1 += (double)partial[(int64_t)(c + 1) * N + j]; }
-  if (c < nchunk) s0 += (double)partial[(int64_t)c * N + j];
+  for (; c + 1 < nchunk; c += 2) { s0 += (double)partial[(int64_t)c * ldp + j]; s1 += (double)partial[(int64_t)(c + 1) * ldp + j]; }
+  if (c < nchunk) s0 += (double)partial[(int64_t)c * ldp + j];
   out[j] = (accumulate ? out[j] : 0.f) + (float)(s0 + s1);
 }
 
@@ -311,20 +290,23 @@ extern "C" int sp3_pack_bf16(const float* src, int64_t ld, int rows, int cols, v
   const dim3 grid((cols + 63) / 64, (rows + 63) / 64);
   SP3_CHECK(grid.y <= 65535, "sp3_pack_bf16: too many rows for one launch (%d)", rows);
   hipLaunchKernelGGL(pack_bf16_kernel, grid, dim3(256), 0, ST(stream), src, ld, rows, cols, reinterpret_cast<__bf16*>(dst), reinterpret_cast<__bf16*>(dstT),
-                     (float*)nullptr, 0, (float*)nullptr, (unsigned*)nullptr);
+                     (float*)nullptr);
   SP3_LAUNCH_CHECK("sp3_pack_bf16");
   return 0;
 }
 
 extern "C" int sp3_pack_bf16_colsum(const float* src, int64_t ld, int rows, int cols, void* dst, void* dstT, float* colsum, int accumulate,
-                                    float* partial_ws, unsigned* counter_ws, void* stream) {
-  SP3_CHECK(src && (dst || dstT) && colsum && partial_ws && counter_ws && rows > 0 && cols > 0 && ld >= cols,
+                                    float* partial_ws, void* stream) {
+  SP3_CHECK(src && (dst || dstT) && colsum && partial_ws && rows > 0 && cols > 0 && ld >= cols,
             "sp3_pack_bf16_colsum: bad arguments (rows=%d cols=%d ld=%lld)", rows, cols, (long long)ld);
   SP3_CHECK(((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(dstT)) & 15) == 0, "sp3_pack_bf16_colsum: outputs must be 16-byte aligned");
   SP3_CHECK(rows <= 8192, "sp3_pack_bf16_colsum: rows=%d > 8192 (taller matrices: sp3_pack_bf16 + sp3_colsum_rows)", rows);
   const dim3 grid((cols + 63) / 64, (rows + 63) / 64);
   hipLaunchKernelGGL(pack_bf16_kernel, grid, dim3(256), 0, ST(stream), src, ld, rows, cols, reinterpret_cast<__bf16*>(dst), reinterpret_cast<__bf16*>(dstT),
-                     colsum, accumulate, partial_ws, counter_ws);
+                     partial_ws);
+  // partial_ws is [grid.y][grid.x * 64]: the finish kernel walks it with that row length
+  hipLaunchKernelGGL(colsum_rows_finish_kernel, dim3((cols + 255) / 256), dim3(256), 0, ST(stream), partial_ws, (int)grid.y, cols, colsum, accumulate,
+                     (int)grid.x * 64);
   SP3_LAUNCH_CHECK("sp3_pack_bf16_colsum");
   return 0;
 }
@@ -341,7 +323,7 @@ extern "C" int sp3_colsum_rows(const float* x, int64_t ld, int rows, int N, floa
   const int nchunk = (rows + kColChunk - 1) / kColChunk;
   SP3_CHECK(nchunk <= 65535, "sp3_colsum_rows: too many rows (%d)", rows);
   hipLaunchKernelGGL(colsum_rows_partial_kernel, dim3((N + 63) / 64, nchunk), dim3(256), 0, ST(stream), x, ld, rows, N, scratch);
-  hipLaunchKernelGGL(colsum_rows_finish_kernel, dim3((N + 255) / 256), dim3(256), 0, ST(stream), scratch, nchunk, N, out, accumulate);
+  hipLaunchKernelGGL(colsum_rows_finish_kernel, dim3((N + 255) / 256), dim3(256), 0, ST(stream), scratch, nchunk, N, out, accumulate, N);
   SP3_LAUNCH_CHECK("sp3_colsum_rows");
   return 0;
 }

@@ -665,11 +665,11 @@ _pack_ws = {}
 
 
 def _pack_colsum_ws(device, nby, nbx):
-    """(partial sums, counters) of sp3_pack_bf16_colsum, grown on demand; one launch at a time uses them (the training step is one stream)"""
+    """partial column sums of sp3_pack_bf16_colsum, grown on demand; one launch at a time uses them (the training step is one stream)"""
     ws = _pack_ws.get(str(device))
     need = nby * nbx * 64
-    if ws is None or ws[0].numel() < need or ws[1].numel() < nbx:
-        ws = (torch.empty(max(need, 1 << 18), device=device), torch.zeros(max(nbx, 1024), dtype=torch.int32, device=device))
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 1 << 18), device=device)
         _pack_ws[str(device)] = ws
     return ws
 
@@ -686,10 +686,10 @@ def pack_bf16(x2d, want=True, want_t=False, colsum=None, accumulate=False):
     a = PackedAct(rows, cols, torch.bfloat16, x2d.device, data=alloc(rows, cols)) if want else None
     t = PackedAct(cols, rows, torch.bfloat16, x2d.device, data=alloc(cols, rows)) if want_t else None
     if colsum is not None:
-        pw, cw = _pack_colsum_ws(x2d.device, (rows + 63) // 64, (cols + 63) // 64)
+        pw = _pack_colsum_ws(x2d.device, (rows + 63) // 64, (cols + 63) // 64)
         _timed("pack_bf16", 0.0, rows * cols * (4.0 + 2.0 * (bool(want) + bool(want_t))),
                lambda: L.check(L.load().sp3_pack_bf16_colsum(x2d.data_ptr(), x2d.stride(0), rows, cols, L.ptr(a), L.ptr(t), colsum.data_ptr(), int(accumulate),
-                                                             pw.data_ptr(), cw.data_ptr(), L.stream_ptr()), "sp3_pack_bf16_colsum"))
+                                                             pw.data_ptr(), L.stream_ptr()), "sp3_pack_bf16_colsum"))
         return a, t
     _timed("pack_bf16", 0.0, rows * cols * (4.0 + 2.0 * (bool(want) + bool(want_t))),
            lambda: L.check(L.load().sp3_pack_bf16(x2d.data_ptr(), x2d.stride(0), rows, cols, L.ptr(a), L.ptr(t), L.stream_ptr()), "sp3_pack_bf16"))

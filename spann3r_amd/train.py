@@ -493,12 +493,14 @@ _rope_tabs = {}
 
 
 def _rope_table(base, hd, device, n=256):
-    """cos / sin of p * base^(-f / (hd/4)) for p < n as fp32 [n, hd/4] (croco/models/pos_embed.py:118-129 get_cos_sin, from float64)"""
+    """cos / sin tables [n, hd/4] of RoPE2D exactly as the reference builds them (croco/models/pos_embed.py:118-129 get_cos_sin: fp32
+    inv_freq = 1 / base^(2i / D), fp32 angles t * inv_freq, fp32 cos / sin), so the rotation uses the reference's own rounded angles"""
     key = (float(base), hd, str(device))
     if key not in _rope_tabs:
-        Q = hd // 4
-        ang = torch.arange(n, dtype=torch.float64)[:, None] * (float(base) ** (-torch.arange(Q, dtype=torch.float64) / Q))[None]
-        _rope_tabs[key] = (ang.cos().float().to(device).contiguous(), ang.sin().float().to(device).contiguous(), n)
+        D = hd // 2
+        inv_freq = 1.0 / (float(base) ** (torch.arange(0, D, 2).float() / D))
+        ang = torch.einsum("i,j->ij", torch.arange(n, dtype=torch.float32), inv_freq)
+        _rope_tabs[key] = (ang.cos().to(device).contiguous(), ang.sin().to(device).contiguous(), n)
     return _rope_tabs[key]
 
 

@@ -191,8 +191,8 @@ def test_flash_attention_is_as_close_to_float64_as_the_materialised_one(gain):
 @pytest.mark.gpu
 @pytest.mark.parametrize("N,Nk", [(196, 201), (64, 256), (300, 260), (37, 500)])
 def test_flash_attention_bf16_products(N, Nk):
-    """bf16 training precision: the LDS-staged kernels (<= 256 tokens) and the streaming ones (longer sequences) against float64, next to
-    the materialised path with the same operand rounding (fp32 operands rounded to bf16 inside the GEMMs)"""
+    """bf16 training precision: the flash kernels with bf16 products (one to eight 64-row tiles per wave) against float64, next to the
+    materialised path with the same operand rounding (fp32 operands rounded to bf16 inside the GEMMs)"""
     from spann3r_amd import train as T
     B, H = 2, 3
     C = 64 * H
@@ -450,8 +450,8 @@ def test_pack_bf16_both_layouts(R, C):
 @pytest.mark.gpu
 @pytest.mark.parametrize("R,C", [(784, 768), (784, 3072), (100, 200), (3, 130), (8192, 64)])
 def test_pack_bf16_column_sums_ride_along(R, C):
-    """sp3_pack_bf16_colsum: the bias gradient dY.sum(0) from the pack launch (last-arriving workgroup reduces in a fixed order):
-    equal to float64 within fp32 rounding, bit-identical across launches, accumulates, leaves its counters at zero"""
+    """sp3_pack_bf16_colsum: the bias gradient dY.sum(0) from the pack launch's tile sums (+ a small fixed-order finish launch): equal to
+    float64 within fp32 rounding, bit-identical across launches, accumulates"""
     from spann3r_amd import ops
     g = torch.Generator().manual_seed(R + C)
     x = torch.randn(R, C, generator=g).cuda()
@@ -468,7 +468,6 @@ def test_pack_bf16_column_sums_ride_along(R, C):
     acc = torch.ones(C, device="cuda")
     ops.pack_bf16(x, True, False, colsum=acc, accumulate=True)
     assert torch.allclose(acc, outs[0] + 1.0, rtol=0, atol=1e-5 * float(outs[0].abs().max()))
-    assert int(ops._pack_ws[str(x.device)][1].abs().sum()) == 0
 
 
 @pytest.mark.gpu
