@@ -370,9 +370,11 @@ def test_training_step_gradients_match_oracle(tiny_sd):
     errs.sort()
     print("training step: loss %.6f (oracle %.6f), %d parameter gradients, worst scaled error %.2e (%s), median %.2e, global rel. L2 %.2e" %
           (float(loss) + float(factor), float(l64) + float(f64), n_checked, worst[0], worst[1], errs[len(errs) // 2], (num / den) ** 0.5))
-    # typical 5e-6 (norm_q.bias).  A convolution in front of a ReLU (head.2, the residual units) sums 1[pre-activation > 0] terms: a
-    # pre-activation within 1e-7 of zero flips under ANY fp32 rounding change of the forward and moves single entries by ~1e-4
-    assert (num / den) ** 0.5 < 1e-5 and errs[len(errs) // 2] < 1e-5 and worst[0] < 4e-4, worst
+    # A convolution in front of a ReLU (head.2, the residual units) sums 1[pre-activation > 0] terms: a pre-activation within 1e-7 of
+    # zero lands on either side under ANY fp32 rounding of the forward; one flipped unit moves entries of that weight gradient by ~1e-4
+    # and everything upstream of it by ~1e-5 (measured with the flip: worst 9.8e-5, median 8.7e-6, global 1.2e-5; without: worst 5.5e-6).
+    # The full-geometry test against the reference's own fp32 step is the tight one (global 8e-7).
+    assert (num / den) ** 0.5 < 3e-5 and errs[len(errs) // 2] < 2e-5 and worst[0] < 4e-4, worst
 
 
 @pytest.mark.gpu
@@ -671,18 +673,18 @@ def test_train_step_hip_graph_replay_matches_eager(tiny_sd):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("precision,flash,tol", [("fp32", False, 2e-5), ("fp32", True, 6e-5), ("bf16", True, 3e-2)])
+@pytest.mark.parametrize("precision,flash,tol", [("fp32", False, 2e-5), ("fp32", True, 2e-5), ("bf16", True, 3e-2)])
 def test_full_geometry_gradients_vs_reference_step(full_sd, precision, flash, tol):
     """BASELINE config 5's step at FULL depth and width (24 encoder / 12 decoder layers, ViT-L / ViT-B / DPT) against ONE TRAINING
     STEP OF THE UNMODIFIED REFERENCE (torch CPU float32, tests/golden/make_golden.py traingrad: Spann3R.forward in train mode +
     spann3r/loss.py ConfLoss_t + backward): the loss and a strided sample of EVERY parameter gradient (~1090 tensors).
     fp32 mode, attention materialised (S, softmax, P.V as the reference computes them): global relative L2 error of the sampled
-    gradients within 2e-5 (measured 2.0e-6) and every tensor within 2e-3 of the reference scaled by the tensor's own maximum
-    (measured worst 3.2e-4, a bias = a sum over 10^4 pixels: both sides carry fp32 rounding through ~80 chained GEMMs and
+    gradients within 2e-5 (measured 3.2e-6) and every tensor within 2e-3 of the reference scaled by the tensor's own maximum
+    (measured worst 3.1e-4, a bias = a sum over 10^4 pixels: both sides carry fp32 rounding through ~80 chained GEMMs and
     differently ordered sums);
-    fp32 mode, flash attention (the default): within 6e-5 (measured 3.2e-5, worst tensor 8.4e-4).  The reference is an fp32 run, not
-    the truth: the materialised path repeats its order of operations and therefore its rounding, the online softmax does not.
-    Against float64 both paths have the same error (test_flash_attention_is_as_close_to_float64_as_the_materialised_one);
+    fp32 mode, flash attention (the default): within 2e-5 (measured 8.3e-7, worst tensor 4.0e-6) -- with RoPE angles taken from the
+    reference's own fp32 tables; with angles computed to full precision in the kernel the same run measured 3.2e-5 (worst 8.4e-4 on a
+    ReLU-gated convolution): parity with an fp32 reference means repeating its rounded constants, not improving on them;
     bf16 mode: global relative L2 error within 3e-2 (measured 8.0e-3: operand rounding of ~80 chained GEMMs)."""
     import numpy as np
     from spann3r_amd import train as T, FULL
