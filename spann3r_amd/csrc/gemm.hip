@@ -1849,9 +1849,12 @@ static int gemm_prepare(sp3_gemm_desc& d, int& tile_out) {
     if (pipe_ok && pipe_on && d.M >= 512 && d.epi != SP3_EPI_ROPE_VT && !wide_legacy) {
       // the largest pipelined tile that still gives most CUs a workgroup (tools/bench_gemm2.py --big on MI355X,
       // profiles/r03_gemm_manyrow_tile_sweep.txt)
-      const long mt256 = (d.M + 255) / 256, mt128 = (d.M + 127) / 128, nt128 = (d.N + 127) / 128;
+      const long mt256 = (d.M + 255) / 256, mt128 = (d.M + 127) / 128, nt128 = (d.N + 127) / 128, nt64 = (d.N + 63) / 64;
       if (mt256 * nt128 * d.batch * sk >= 144) tile = 20;
       else if (mt128 * nt128 * d.batch * sk >= 200) tile = 21;
+      // fewer than ~200 workgroups of 128 x 64 (the 1024-row proj / fc2 GEMMs of a 512 x 512 frame): the 64 x 32 tile's 768 / 512
+      // workgroups finish first (10.9 vs 13.5 us, 28.2 vs 36.7 us at K = 4096; the 1960-row encoder GEMMs stay at 128 x 64)
+      else if (mt128 * nt64 * d.batch * sk <= 192) tile = 24;
       else tile = 22;
     } else if (lds_ok && d.M >= 1024 && d.N >= 2304 && d.N % 128 == 0) {
       // LDS-staged operands (tools/bench_gemm2.py --big, HBM-cold weights, also grouped launches): 128x128 for large grids

@@ -119,6 +119,8 @@ def pick_tile(M, N, batch=1, splitk=1, conv=False, K=0, packed_bf16=False, plain
             return 20
         if mt128 * nt128 * batch * splitk >= 200:
             return 21
+        if mt128 * ((N + 63) // 64) * batch * splitk <= 192:
+            return 24
         return 22
     if lds_ok and M >= 1024 and N >= 2304 and N % 128 == 0:
         return 5 if (N % 4096 == 0 or ((M + 127) // 128) * (N // 128) * batch >= 1024) else 6
