@@ -34,24 +34,40 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_ctypes_structs_match_the_header():
-    """sizeof / offsetof of the two descriptor structs, as gcc sees include/spann3r_hip.h, equal the ctypes mirror."""
+    """sizeof / offsetof of the descriptor structs, as gcc sees include/spann3r_hip.h, equal the ctypes mirror."""
     from spann3r_amd import lib
-    fields_g = [f[0] for f in lib.GemmDesc._fields_]
-    fields_r = [f[0] for f in lib.ReduceLnDesc._fields_]
-    src = '#include "%s"\n#include <stdio.h>\n#include <stddef.h>\nint main(){\n' % os.path.join(REPO, "include", "spann3r_hip.h")
-    src += 'printf("%zu\\n", sizeof(sp3_gemm_desc));\n'
-    src += "".join('printf("%%zu\\n", offsetof(sp3_gemm_desc, %s));\n' % f for f in fields_g)
-    src += 'printf("%zu\\n", sizeof(sp3_reduce_ln_desc));\n'
-    src += "".join('printf("%%zu\\n", offsetof(sp3_reduce_ln_desc, %s));\n' % f for f in fields_r)
-    src += "return 0;}\n"
+    pairs = [("sp3_gemm_desc", lib.GemmDesc), ("sp3_reduce_ln_desc", lib.ReduceLnDesc), ("sp3_head_part", lib.HeadPart),
+             ("sp3_attn_bwd_desc", lib.AttnBwdDesc)]
+    lines = ['#include "%s"' % os.path.join(REPO, "include", "spann3r_hip.h"), "#include <stdio.h>", "#include <stddef.h>", "int main(){"]
+    exp = []
+    for cname, cls in pairs:
+        fields = [f[0] for f in cls._fields_]
+        lines.append('printf("%%zu\\n", sizeof(%s));' % cname)
+        lines += ['printf("%%zu\\n", offsetof(%s, %s));' % (cname, f) for f in fields]
+        exp += [ctypes.sizeof(cls)] + [getattr(cls, f).offset for f in fields]
+    lines.append("return 0;}")
     with tempfile.TemporaryDirectory() as d:
         c, exe = os.path.join(d, "p.c"), os.path.join(d, "p")
-        open(c, "w").write(src)
+        open(c, "w").write("\n".join(lines) + "\n")
         subprocess.check_call(["gcc", c, "-o", exe])
         vals = [int(x) for x in subprocess.check_output([exe]).split()]
-    exp = [ctypes.sizeof(lib.GemmDesc)] + [getattr(lib.GemmDesc, f).offset for f in fields_g]
-    exp += [ctypes.sizeof(lib.ReduceLnDesc)] + [getattr(lib.ReduceLnDesc, f).offset for f in fields_r]
     assert vals == exp
+
+
+def test_training_host_side_choices():
+    """host logic of the training path: RoPE tables are the reference's own fp32 tables (croco/models/pos_embed.py:118-129 as restated by
+    the oracle), the bf16 GEMM tile rule follows the sweep"""
+    import torch
+    from spann3r_amd import train as T
+    from oracle import spann3r_oracle as O
+    for hd in (64, 48, 32):
+        c, s_, n = T._rope_table(100.0, hd, "cpu")
+        oc, os_ = O.rope_tables(n, hd // 2, 100.0)
+        assert c.shape == (256, hd // 4) and torch.equal(c, oc) and torch.equal(s_, os_)
+    assert T._bf16_tile(196, 768) == -1                 # few rows: the library's own choice
+    assert T._bf16_tile(784, 768) == 25 and T._bf16_tile(768, 768) == 25 and T._bf16_tile(784, 1024) == 25
+    assert T._bf16_tile(784, 2304) == 21 and T._bf16_tile(3072, 768) == 21 and T._bf16_tile(784, 4096) == 21
+    assert T._bf16_tile(3920, 4096) == -1 and T._bf16_tile(200704, 256) == -1
 
 
 def test_argument_validation_reports_errors_without_a_gpu():
