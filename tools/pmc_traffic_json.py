@@ -1,0 +1,55 @@
+#!/usr/bin/env python
+"""profiles/pmc_hbm_traffic.json from the two PMC passes of tools/gpu_run.sh pmcbench (FETCH_SIZE / WRITE_SIZE per (kernel, grid),
+tools/rocpd_pmc_grid.py --json): HBM bytes per launch of the bf16 GEMM instantiations, keyed as bench.py names them.
+   python tools/pmc_traffic_json.py gpurun_out/<tag>/pmc_FETCH_SIZE.json gpurun_out/<tag>/pmc_WRITE_SIZE.json "<build description>" """
+import json
+import re
+import sys
+
+NAMES = {(2, 2, 1, 1, 4, 3, 0): "32x32xk4", (7, 1, 1, 4, 2, 4, 2): "112x64wreg8", (4, 4, 4, 2, 1, 3, -1): "256x128pipe",
+         (4, 4, 2, 2, 2, 4, -1): "128x128pipe", (4, 4, 2, 1, 2, 3, -1): "128x64pipe", (4, 2, 1, 1, 2, 4, -1): "64x32pipe"}
+
+
+def key_of(row):
+    m = re.search(r"gemm_kernelIDF16bDF16bLi0E((?:Lin?\d+E)+)", row["kernel"])
+    if not m:
+        return None
+    ints = [(-int(x[1:]) if x.startswith("n") else int(x)) for x in re.findall(r"Li(n?\d+)E", m.group(1))]
+    name = NAMES.get(tuple(ints[:7]))
+    if name is None:
+        return None
+    # sp3_gemm2 (two differently shaped groups in one launch): grid.y = 4 in the per-frame step (2 + 2 problems)
+    return ("gemm2" if row["grid"][1] == 4 else "gemm") + "<Abf16,Wbf16,plain,%s>" % name
+
+
+def collect(path):
+    acc = {}
+    for r in json.load(open(path))["rows"]:
+        k = key_of(r)
+        if k:
+            a = acc.setdefault(k, [0.0, 0])
+            a[0] += r["per_launch"] * r["launches"]
+            a[1] += r["launches"]
+    return {k: (v[0] / v[1], v[1]) for k, v in acc.items()}
+
+
+def main():
+    fetch, write = collect(sys.argv[1]), collect(sys.argv[2])
+    out = {"build": sys.argv[3],
+           "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline "
+                      "--no-profile --no-extras --no-graphs (tools/gpu_run.sh pmcbench; tools/pmc_traffic_json.py)",
+           "units": "FETCH_SIZE / WRITE_SIZE are KiB per launch; traffic_bytes = 2 * FETCH * 1024 (gfx950: FETCH_SIZE counts 128-B requests as "
+                    "64 B, MI355X_MICROARCH.md) + WRITE * 1024",
+           "note": "memory-side (fabric) requests of the 8 per-XCD L2s, Infinity-Cache hits included (MI355X_MICROARCH.md): every XCD fetches its "
+                   "own copy of the activation panel, so a 196-row launch counts W + 8 x A + C; launches of one kernel are split by grid "
+                   "(tools/rocpd_pmc_grid.py) so sp3_gemm2 pairs are separate",
+           "kernels": {}}
+    for k, (f, n) in fetch.items():
+        w = write.get(k, (0.0, 0))[0]
+        out["kernels"][k] = {"fetch_kib_per_launch": f, "write_kib_per_launch": w, "traffic_bytes": int(round(2 * f * 1024 + w * 1024)), "launches": n}
+    json.dump(out, sys.stdout, indent=1)
+    print()
+
+
+if __name__ == "__main__":
+    main()
