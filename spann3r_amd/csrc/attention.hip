@@ -25,14 +25,21 @@ template <> struct AttnT<__bf16> {
     r.v[0] = *reinterpret_cast<const bf16x8*>(row + 8 * g);
     r.v[1] = *reinterpret_cast<const bf16x8*>(row + 32 + 8 * g);
   }
-  static __device__ __forceinline__ f32x4 qk(const __bf16* krow, int g, const QReg& q) {
-    const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(krow + 8 * g);
-    const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(krow + 32 + 8 * g);
+  // (the operand row is loaded and multiplied in two steps: the kernels issue the loads of a whole 64-row tile before the first MFMA)
+  struct KReg { bf16x8 v[2]; };
+  static __device__ __forceinline__ KReg loadK(const __bf16* krow, int g) {
+    KReg k;
+    k.v[0] = *reinterpret_cast<const bf16x8*>(krow + 8 * g);
+    k.v[1] = *reinterpret_cast<const bf16x8*>(krow + 32 + 8 * g);
+    return k;
+  }
+  static __device__ __forceinline__ f32x4 qk(const KReg& k, const QReg& q) {
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, q.v[0], s, 0, 0, 0);
-    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, q.v[1], s, 0, 0, 0);
+    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k.v[0], q.v[0], s, 0, 0, 0);
+    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k.v[1], q.v[1], s, 0, 0, 0);
     return s;
   }
+  static __device__ __forceinline__ f32x4 qk(const __bf16* krow, int g, const QReg& q) { return qk(loadK(krow, g), q); }
   // ---- O^T += V^T . P^T over the 64 keys of a tile: p[t][r] is key 16t+4g+r of query lane&15
   static __device__ __forceinline__ void pv(f32x4 (&o)[4], const __bf16* vt_head, int64_t vt_ld, int kbase, int g,
                                             int dl, const f32x4 (&p)[4]) {
@@ -62,12 +69,19 @@ template <> struct AttnT<float> {
     const float4* p = reinterpret_cast<const float4*>(row + 16 * g);
     r.v[0] = p[0]; r.v[1] = p[1]; r.v[2] = p[2]; r.v[3] = p[3];
   }
-  static __device__ __forceinline__ f32x4 qk(const float* krow, int g, const QReg& q) {
+  struct KReg { float4 v[4]; };
+  static __device__ __forceinline__ KReg loadK(const float* krow, int g) {
     const float4* p = reinterpret_cast<const float4*>(krow + 16 * g);
+    KReg k;
+    k.v[0] = p[0]; k.v[1] = p[1]; k.v[2] = p[2]; k.v[3] = p[3];
+    return k;
+  }
+  static __device__ __forceinline__ f32x4 qk(const float* krow, int g, const QReg& q) { return qk(loadK(krow, g), q); }
+  static __device__ __forceinline__ f32x4 qk(const KReg& k, const QReg& q) {
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const float4 kv = p[i];
+      const float4 kv = k.v[i];
       s = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.x, q.v[i].x, s, 0, 0, 0);
       s = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.y, q.v[i].y, s, 0, 0, 0);
       s = __builtin_amdgcn_mfma_f32_16x16x4f32(kv.z, q.v[i].z, s, 0, 0, 0);
@@ -77,11 +91,16 @@ template <> struct AttnT<float> {
   }
   static __device__ __forceinline__ void pv(f32x4 (&o)[4], const float* vt_head, int64_t vt_ld, int kbase, int g, int dl,
                                             const f32x4 (&p)[4]) {
+    float4 vv[4][4];                                   // all 16 loads of the tile first: one round trip, not sixteen
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int db = 0; db < 4; ++db) vv[t][db] = *reinterpret_cast<const float4*>(vt_head + (int64_t)(db * 16 + dl) * vt_ld + kbase + 16 * t + 4 * g);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
 #pragma unroll
       for (int db = 0; db < 4; ++db) {
-        const float4 va = *reinterpret_cast<const float4*>(vt_head + (int64_t)(db * 16 + dl) * vt_ld + kbase + 16 * t + 4 * g);
+        const float4 va = vv[t][db];
         o[db] = __builtin_amdgcn_mfma_f32_16x16x4f32(va.x, p[t][0], o[db], 0, 0, 0);
         o[db] = __builtin_amdgcn_mfma_f32_16x16x4f32(va.y, p[t][1], o[db], 0, 0, 0);
         o[db] = __builtin_amdgcn_mfma_f32_16x16x4f32(va.z, p[t][2], o[db], 0, 0, 0);
@@ -121,12 +140,19 @@ template <> struct AttnT<F32X3> {
       split8f(x, r.h[u], r.l[u]);
     }
   }
-  static __device__ __forceinline__ f32x4 qk(const float* krow, int g, const QReg& q) {
+  struct KReg { float4 v[4]; };
+  static __device__ __forceinline__ KReg loadK(const float* krow, int g) {
     const float4* p = reinterpret_cast<const float4*>(krow + 16 * g);
+    KReg k;
+    k.v[0] = p[0]; k.v[1] = p[1]; k.v[2] = p[2]; k.v[3] = p[3];
+    return k;
+  }
+  static __device__ __forceinline__ f32x4 qk(const float* krow, int g, const QReg& q) { return qk(loadK(krow, g), q); }
+  static __device__ __forceinline__ f32x4 qk(const KReg& k, const QReg& q) {
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const float4 a = p[2 * u], b = p[2 * u + 1];
+      const float4 a = k.v[2 * u], b = k.v[2 * u + 1];
       const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
       bf16x8 kh, kl;
       split8f(x, kh, kl);
@@ -137,6 +163,15 @@ template <> struct AttnT<F32X3> {
   // O^T += V^T . P^T over the 64 keys of a tile, 32 keys per MFMA: lane g supplies keys 32u + 4g + (0..3) and 32u + 16 + 4g + (0..3)
   static __device__ __forceinline__ void pv(f32x4 (&o)[4], const float* vt_head, int64_t vt_ld, int kbase, int g, int dl,
                                             const f32x4 (&p)[4]) {
+    float4 vlo[2][4], vhi[2][4];                       // all 16 loads of the tile first: one round trip, not eight
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        const float* vr = vt_head + (int64_t)(db * 16 + dl) * vt_ld + kbase + 32 * u + 4 * g;
+        vlo[u][db] = *reinterpret_cast<const float4*>(vr);
+        vhi[u][db] = *reinterpret_cast<const float4*>(vr + 16);
+      }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const float px[8] = {p[2 * u][0], p[2 * u][1], p[2 * u][2], p[2 * u][3], p[2 * u + 1][0], p[2 * u + 1][1], p[2 * u + 1][2], p[2 * u + 1][3]};
@@ -144,8 +179,7 @@ template <> struct AttnT<F32X3> {
       split8f(px, ph, pl);
 #pragma unroll
       for (int db = 0; db < 4; ++db) {
-        const float* vr = vt_head + (int64_t)(db * 16 + dl) * vt_ld + kbase + 32 * u + 4 * g;
-        const float4 lo4 = *reinterpret_cast<const float4*>(vr), hi4 = *reinterpret_cast<const float4*>(vr + 16);
+        const float4 lo4 = vlo[u][db], hi4 = vhi[u][db];
         const float vx[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
         bf16x8 vh, vl;
         split8f(vx, vh, vl);
@@ -188,12 +222,19 @@ template <> struct AttnT<F16X3> {
       split8h(x, r.h[u], r.l[u]);
     }
   }
-  static __device__ __forceinline__ f32x4 qk(const float* krow, int g, const QReg& q) {
+  struct KReg { float4 v[4]; };
+  static __device__ __forceinline__ KReg loadK(const float* krow, int g) {
     const float4* p = reinterpret_cast<const float4*>(krow + 16 * g);
+    KReg k;
+    k.v[0] = p[0]; k.v[1] = p[1]; k.v[2] = p[2]; k.v[3] = p[3];
+    return k;
+  }
+  static __device__ __forceinline__ f32x4 qk(const float* krow, int g, const QReg& q) { return qk(loadK(krow, g), q); }
+  static __device__ __forceinline__ f32x4 qk(const KReg& k, const QReg& q) {
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const float4 a = p[2 * u], b = p[2 * u + 1];
+      const float4 a = k.v[2 * u], b = k.v[2 * u + 1];
       const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
       f16x8 kh, kl;
       split8h(x, kh, kl);
@@ -203,6 +244,15 @@ template <> struct AttnT<F16X3> {
   }
   static __device__ __forceinline__ void pv(f32x4 (&o)[4], const float* vt_head, int64_t vt_ld, int kbase, int g, int dl,
                                             const f32x4 (&p)[4]) {
+    float4 vlo[2][4], vhi[2][4];                       // all 16 loads of the tile first: one round trip, not eight
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        const float* vr = vt_head + (int64_t)(db * 16 + dl) * vt_ld + kbase + 32 * u + 4 * g;
+        vlo[u][db] = *reinterpret_cast<const float4*>(vr);
+        vhi[u][db] = *reinterpret_cast<const float4*>(vr + 16);
+      }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const float px[8] = {p[2 * u][0], p[2 * u][1], p[2 * u][2], p[2 * u][3], p[2 * u + 1][0], p[2 * u + 1][1], p[2 * u + 1][2], p[2 * u + 1][3]};
@@ -210,8 +260,7 @@ template <> struct AttnT<F16X3> {
       split8h(px, ph, pl);
 #pragma unroll
       for (int db = 0; db < 4; ++db) {
-        const float* vr = vt_head + (int64_t)(db * 16 + dl) * vt_ld + kbase + 32 * u + 4 * g;
-        const float4 lo4 = *reinterpret_cast<const float4*>(vr), hi4 = *reinterpret_cast<const float4*>(vr + 16);
+        const float4 lo4 = vlo[u][db], hi4 = vhi[u][db];
         const float vx[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
         f16x8 vh, vl;
         split8h(vx, vh, vl);
@@ -231,25 +280,38 @@ template <> struct AttnT<BF16X1> {
     r.v[0] = cvt8(p[0], p[1]);
     r.v[1] = cvt8(p[2], p[3]);
   }
-  static __device__ __forceinline__ f32x4 qk(const float* krow, int g, const QReg& q) {
+  struct KReg { float4 v[4]; };
+  static __device__ __forceinline__ KReg loadK(const float* krow, int g) {
     const float4* p = reinterpret_cast<const float4*>(krow + 16 * g);
+    KReg k;
+    k.v[0] = p[0]; k.v[1] = p[1]; k.v[2] = p[2]; k.v[3] = p[3];
+    return k;
+  }
+  static __device__ __forceinline__ f32x4 qk(const float* krow, int g, const QReg& q) { return qk(loadK(krow, g), q); }
+  static __device__ __forceinline__ f32x4 qk(const KReg& k, const QReg& q) {
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cvt8(p[0], p[1]), q.v[0], s, 0, 0, 0);
-    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cvt8(p[2], p[3]), q.v[1], s, 0, 0, 0);
+    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cvt8(k.v[0], k.v[1]), q.v[0], s, 0, 0, 0);
+    s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cvt8(k.v[2], k.v[3]), q.v[1], s, 0, 0, 0);
     return s;
   }
   static __device__ __forceinline__ void pv(f32x4 (&o)[4], const float* vt_head, int64_t vt_ld, int kbase, int g, int dl,
                                             const f32x4 (&p)[4]) {
+    float4 vlo[2][4], vhi[2][4];                       // all 16 loads of the tile first: one round trip, not eight
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        const float* vr = vt_head + (int64_t)(db * 16 + dl) * vt_ld + kbase + 32 * u + 4 * g;
+        vlo[u][db] = *reinterpret_cast<const float4*>(vr);
+        vhi[u][db] = *reinterpret_cast<const float4*>(vr + 16);
+      }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       bf16x8 pb;
 #pragma unroll
       for (int j = 0; j < 8; ++j) pb[j] = (__bf16)p[2 * u + (j >> 2)][j & 3];
 #pragma unroll
-      for (int db = 0; db < 4; ++db) {
-        const float* vr = vt_head + (int64_t)(db * 16 + dl) * vt_ld + kbase + 32 * u + 4 * g;
-        o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cvt8(*reinterpret_cast<const float4*>(vr), *reinterpret_cast<const float4*>(vr + 16)), pb, o[db], 0, 0, 0);
-      }
+      for (int db = 0; db < 4; ++db) o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cvt8(vlo[u][db], vhi[u][db]), pb, o[db], 0, 0, 0);
     }
   }
 };
@@ -281,12 +343,15 @@ __global__ __launch_bounds__(256) void attention_kernel(const typename AttnT<TT>
 
   for (int kb = wave * 64; kb < Nk; kb += 256) {
     f32x4 s[4];
+    typename A::KReg kr[4];                      // the tile's four key blocks are requested before the first product
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       int krow = kb + 16 * t + ql;               // A-operand row = key
       krow = krow < Nk ? krow : Nk - 1;
-      s[t] = A::qk(kbase_ptr + (int64_t)krow * ldk, g, qreg);
+      kr[t] = A::loadK(kbase_ptr + (int64_t)krow * ldk, g);
     }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) s[t] = A::qk(kr[t], qreg);
     float mx = -INFINITY;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -545,11 +610,17 @@ __global__ __launch_bounds__(256) void attention_bwd_dq_kernel(AttnBwdArgs a) {
   const float* kT = a.kT + bh * 64 * a.ldTk;
   // (p, dp) of a 64-key tile: p[t][r] = P[query ql][key kb + 16t + 4g + r], dp likewise
   auto tile = [&](int kb, f32x4 (&p)[4], f32x4 (&dp)[4]) {
+    typename A::KReg kr[4], vr[4];               // 32 independent 16-byte loads in flight before the first product
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int krow = min(kb + 16 * t + ql, Nk - 1);
-      const f32x4 s = A::qk(kbase + (int64_t)krow * a.ldk, g, qreg);
-      dp[t] = A::qk(vbase + (int64_t)krow * a.ldv, g, doreg);
+      kr[t] = A::loadK(kbase + (int64_t)krow * a.ldk, g);
+      vr[t] = A::loadK(vbase + (int64_t)krow * a.ldv, g);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const f32x4 s = A::qk(kr[t], qreg);
+      dp[t] = A::qk(vr[t], doreg);
 #pragma unroll
       for (int r = 0; r < 4; ++r) p[t][r] = (kb + 16 * t + 4 * g + r) < Nk ? expf(s[r] * a.scale - lq.x) * lq.y : 0.f;
     }
@@ -635,11 +706,17 @@ __global__ __launch_bounds__(256) void attention_bwd_dkv_kernel(AttnBwdArgs a) {
   for (int i = 0; i < 4; ++i) { acck[i] = f32x4{0.f, 0.f, 0.f, 0.f}; accv[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   for (int qb = wave * 64; qb < Nq; qb += 256) {
     f32x4 pt[4], ds[4];
+    typename A::KReg qr[4], dr[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int qrow = min(qb + 16 * t + kl, Nq - 1);
-      const f32x4 s = A::qk(qbase + (int64_t)qrow * a.ldq, g, kreg);          // [query 16t+4g+r][key kl]
-      const f32x4 dp = A::qk(dobase + (int64_t)qrow * a.lddo, g, vreg);
+      qr[t] = A::loadK(qbase + (int64_t)qrow * a.ldq, g);
+      dr[t] = A::loadK(dobase + (int64_t)qrow * a.lddo, g);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const f32x4 s = A::qk(qr[t], kreg);          // [query 16t+4g+r][key kl]
+      const f32x4 dp = A::qk(dr[t], vreg);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int qi = qb + 16 * t + 4 * g + r;
