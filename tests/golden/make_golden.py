@@ -551,8 +551,40 @@ def make_crop():
     print("crop_plan.npz:", len(cases), "shapes")
 
 
+def make_pnp():
+    """f4: the poses demo.py:170-186 computes -- cv2.solvePnPRansac(points, pixel grid, K, zeros(4)) with OpenCV's defaults,
+    Rodrigues, inverse -- on the synthetic scenes of tests/test_postprocess.py.  Needs OpenCV,
+    which the build image does not have: run where it is installed (`python tests/golden/make_golden.py pnp`) and commit
+    tests/golden/pnp_cv2.npz; until then test_estimate_poses_vs_opencv skips and f4 stays 'parity unpinned'."""
+    import cv2
+    sys.path.insert(0, os.path.dirname(HERE))
+    from test_postprocess import _scene
+    out = {}
+    for tag, (seed, kw) in {"clean": (5, {}), "outliers": (6, {"outliers": 0.3}), "four": (7, {"F": 4})}.items():
+        pts, poses, f, (cx, cy) = _scene(seed, **kw)
+        F, H, W, _ = pts.shape
+        K = np.array([[f, 0, cx], [0, f, cy], [0, 0, 1]], np.float64)
+        uu, vv = np.meshgrid(np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32))
+        pix = np.stack((uu, vv), -1).reshape(-1, 2)
+        got = []
+        for j in range(F):
+            X = pts[j].reshape(-1, 3)
+            ok = np.isfinite(X).all(-1)                 # (the demo's pointmaps are finite; the scenes carry two non-finite probes)
+            _, rvec, tvec, inl = cv2.solvePnPRansac(X[ok].astype(np.float32), pix[ok], K.astype(np.float32), np.zeros(4, np.float32))
+            R, _ = cv2.Rodrigues(rvec)
+            P = np.eye(4)
+            P[:3, :3], P[:3, 3] = R, tvec[:, 0]
+            got.append(np.linalg.inv(P))                # camera-to-world, as demo.py stores it
+        out[tag + "_poses"] = np.stack(got)
+        out[tag + "_seed"] = np.array(seed)
+    np.savez_compressed(os.path.join(HERE, "pnp_cv2.npz"), **out)
+    print("pnp_cv2:", {k: v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["tiny", "full", "memory"]
+    if "pnp" in what:
+        make_pnp()
     if "crop" in what:
         make_crop()
     if "usefeat" in what:

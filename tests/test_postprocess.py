@@ -117,6 +117,23 @@ def test_pnp_oracle_recovers_ground_truth_poses():
 
 
 @pytest.mark.gpu
+def test_estimate_poses_vs_opencv():
+    """f4 against cv2.solvePnPRansac itself (tests/golden/make_golden.py pnp; OpenCV is not in the build image, so the fixture has to be
+    generated elsewhere): both are consensus estimators with their own sampling, so the poses agree to the noise of the scene, not bitwise"""
+    path = os.path.join(os.path.dirname(__file__), "golden", "pnp_cv2.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/pnp_cv2.npz not generated (needs OpenCV): f4 parity unpinned")
+    from spann3r_amd.postprocess import estimate_poses
+    g = np.load(path)
+    for tag, (seed, kw) in {"clean": (5, {}), "outliers": (6, {"outliers": 0.3}), "four": (7, {"F": 4})}.items():
+        pts, _, f, pp = _scene(seed, **kw)
+        got, _ = estimate_poses(torch.from_numpy(pts).cuda(), f, pp, seed=3)
+        for j in range(len(pts)):
+            ang, dt = _pose_err(got[j], g[tag + "_poses"][j])
+            assert ang < 0.3 and dt < 2e-2, (tag, j, ang, dt)
+
+
+@pytest.mark.gpu
 def test_estimate_poses_kernels():
     from spann3r_amd.postprocess import estimate_poses
     pts, poses, f, pp = _scene(7, F=4)
