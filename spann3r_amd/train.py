@@ -5,9 +5,9 @@ with attn_thresh = 0 and nn.Dropout on the attention, :475):
     out = dropout(softmax(LN_q(feat) . LN_k(mem_k)^T / sqrt(C))) . LN_v(mem_v) + feat
 
 `memory_read_train` returns `out` with an autograd edge to feat, mem_k, mem_v and the six LayerNorm parameters; the
-backward is four sp3_gemm launches (fp32 MFMA) with the transposes, the softmax / dropout backward and the LayerNorm
-backward of csrc/train.hip in between.  The dropout mask is an input (0 or 1/(1-p), drawn by the caller: the reference's
-comes from torch's RNG stream and cannot be matched bit for bit by any other implementation).
+backward is four sp3_gemm launches with the transposes, the softmax / dropout backward and the LayerNorm backward of
+csrc/train.hip in between.  The dropout mask is an input (0 or 1/(1-p), drawn by the caller: the reference's comes from
+torch's RNG stream and cannot be matched bit for bit by any other implementation).
 
 Below it: every other stage of the train-mode forward (ViT blocks, decoder blocks, key MLPs, DPT heads, value encoder) as
 autograd ops with HIP forward and backward, `forward_train` (= Spann3R.forward in train mode), and the optimizer side of
@@ -15,12 +15,21 @@ spann3r/training.py:216-231: `FlatAdamW` (bucket-wide AdamW launches on the flat
 global gradient-norm clip of croco/utils/misc.py:262-288 computed on the device).  Gradient averaging across ranks:
 `spann3r_amd.runner.GradReducer`; the criterion: `spann3r_amd.loss`.
 
-Precision (`set_precision`): "fp32" = fp32 MFMA everywhere (the parity build: gradients within 1e-5 of float64 autograd);
-"bf16" = what the reference's bf16 autocast would compute: every Linear runs on bf16 fragment-order copies of its operands
-(sp3_pack_bf16 makes X, X^T, dY, dY^T; W and W^T are packed once per optimizer step) through the pipelined bf16 GEMM tiles with
-fp32 accumulation -- forward, dX = dY . W and dW = dY^T . X are all plain A . W^T launches, no fp32 transposes -- and the
-remaining fp32 GEMMs (attention, the memory read) round their operands to bf16 on the way into the MFMA (sp3_gemm f32x3 = 2).
-Master weights, gradients, LayerNorm, softmax, the residual stream and the optimizer stay fp32."""
+Attention (croco/models/blocks.py:94-112, :149-169) is `_FlashMHA` for heads of 64: one sp3_head_shuffle launch (RoPE from the
+reference's own fp32 tables, per-head transposes), the flash forward sp3_attention_train_fwd, and in the backward
+sp3_attention_train_bwd (dq | dk, dv with the probabilities recomputed) between two shuffles -- the attention matrix is never
+written.  `_MHA` (other head widths, or FLASH_ATTENTION = False) keeps the shuffles around grouped GEMMs + softmax kernels;
+`_Attention` on ATen-reshaped heads (FUSED_HEADS = False) is the round-2 path the tests compare both against.
+
+Precision (`set_precision`): "fp32" = fp32 MFMA everywhere (the parity build: gradients within 1e-5 of float64 autograd,
+8e-7 of the reference's own fp32 step at full depth); "bf16" = what the reference's bf16 autocast would compute: every Linear
+runs on bf16 fragment-order copies of its operands (sp3_pack_bf16 makes X, X^T, dY, dY^T and the bias gradient's tile sums; W and
+W^T are packed once per optimizer step) through the pipelined bf16 GEMM tiles with fp32 accumulation -- forward, dX = dY . W and
+dW = dY^T . X are all plain A . W^T launches, no fp32 transposes -- the attention kernels round their fp32 operands into one bf16
+MFMA per product, and the memory read's fp32 GEMMs do the same (sp3_gemm f32x3 = 2).  Master weights, gradients (flat buckets the
+kernels accumulate into directly), LayerNorm, softmax statistics, the residual stream and the optimizer stay fp32."""
+import ctypes
+
 import torch
 
 from . import lib as L
@@ -28,9 +37,8 @@ from . import ops
 
 
 PRECISION = "fp32"
-import os as _os
-FLASH_ATTENTION = _os.environ.get("SP3_TRAIN_FLASH", "1") != "0"   # heads of 64: sp3_attention_train_fwd / _bwd (no attention matrix in memory); False: GEMMs + softmax kernels (_MHA)
-FUSED_HEADS = _os.environ.get("SP3_TRAIN_FUSED_HEADS", "1") != "0"    # attention through _MHA (one shuffle launch each way); False: the separate ATen reshapes + _Attention (tests compare the two)
+FLASH_ATTENTION = True   # heads of 64: sp3_attention_train_fwd / _bwd (no attention matrix in memory); False: GEMMs + softmax kernels (_MHA)
+FUSED_HEADS = True    # attention through _MHA (one shuffle launch each way); False: the separate ATen reshapes + _Attention (tests compare the two)
 _wcache = {}          # id(weight) -> (version, packed W, packed W^T): refreshed when the optimizer has stepped
 
 
@@ -418,8 +426,6 @@ class _LayerNormRes(torch.autograd.Function):
 
 def layer_norm_res(x, g, b, eps):
     """-> (x, LN(x)); use the returned x as the residual operand"""
-    if _os.environ.get("SP3_TRAIN_LNRES", "1") == "0":
-        return x, layer_norm(x, g, b, eps)
     sh = x.shape
     xp, y = _LayerNormRes.apply(x.reshape(-1, sh[-1]).contiguous(), g, b, eps)
     return xp.reshape(sh), y.reshape(sh)
@@ -683,7 +689,6 @@ class _FlashMHA(torch.autograd.Function):
         d.dk, d.sdk, d.lddk = P(gk[0], gk[1]), Nk * gk[2], gk[2]
         d.dv, d.sdv, d.lddv = P(gv[0], gv[1]), Nk * gv[2], gv[2]
         d.B, d.heads, d.Nq, d.Nk, d.scale, d.bf16_products = B, H, Nq, Nk, float(scale), bf
-        import ctypes
         L.check(L.load().sp3_attention_train_bwd(ctypes.byref(d), L.stream_ptr()), "sp3_attention_train_bwd")
         if rope:            # the gradients of the rotated q, k -> of the projections' outputs: R^T in place
             parts = []
