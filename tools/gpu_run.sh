@@ -6,7 +6,10 @@
 #   modeltests tests/test_model_gpu.py                                    alltests   the whole -m gpu suite
 #   bench     python bench.py (default line)                              benchfast  bench.py without extras / CPU baseline
 #   benchab   benchfast with SP3_PIPE_TILES=1 and =0                      prof       rocprofv3 --kernel-trace --stats of benchfast
-#   train     tools/train_step_time.py                                    memread    tools/bench_memread.py
+#   train     tools/train_step_time.py (bf16, fp32; trainbf: bf16 only)   memread    tools/bench_memread.py
+#   trainprof rocprofv3 --kernel-trace --stats of the training step       traintests tests/test_train.py + test_loss.py
+#   trainsweep tile sweep of the training step's ~800-row GEMM shapes     f16x3      the fp16-split mode: parity tests + bench
+#   pmcbench  rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the bench (then tools/pmc_traffic_json.py)
 set -u
 cd "$(dirname "$0")/.."
 TAG=$1; shift
