@@ -404,6 +404,10 @@ int sp3_mul(const float* a, const float* b, float* out, int64_t n, void* stream)
  * as zeros.  With both forms every product of a Linear's backward (dX = dY . W, dW = dY^T . X) is an sp3_gemm A . W^T launch on packed
  * bf16 operands: the ATen calls they replace are the matmuls autograd derives for nn.Linear (croco/models/blocks.py:73-112). */
 int sp3_pack_bf16(const float* src, int64_t ld, int rows, int cols, void* dst, void* dstT, void* stream);
+/* sp3_pack_bf16 of the 3x3 / pad 1 im2col matrix [(b, oy, ox), (ky*3 + kx)*C + c] of an NHWC fp32 map x [B, H, W, C] (stride 1 or 2; the layout
+ * of sp3_im2col3x3), gathered inside the pack launch: the operand of a 3x3 convolution's bf16 GEMMs (croco/models/dpt_block.py:120-218) without
+ * writing and re-reading the 9x larger column matrix. */
+int sp3_pack_bf16_conv3x3(const float* x, int B, int H, int W, int C, int stride, void* dst, void* dstT, void* stream);
 /* sp3_pack_bf16, and colsum[j] (+)= sum_r src[r, j] (the bias gradient of the Linear whose dY is being packed; rows <= 8192): the pack
  * launch leaves the column sums of its 64-row tiles in partial_ws (ceil(rows / 64) * ceil(cols / 64) * 64 floats), a second small launch
  * adds them in a fixed order: deterministic, and no second pass over src. */

@@ -21,17 +21,31 @@ namespace {
 // of its 64 x 64 tile in partial[row tile][ceil64(cols)]; colsum_rows_finish_kernel adds the row tiles in order (13 values per column at
 // 784 rows instead of a second pass over dY).  (A last-arriving-workgroup reduction inside this launch was measured: the release fence
 // every workgroup then needs costs more than the extra launch.)
+// conv.C != 0: src is an NHWC map [B, H, W, C] and the matrix being packed is its 3x3 / pad 1 im2col [(b, oy, ox), (ky*3 + kx)*C + c]
+// (sp3_im2col3x3's layout), gathered on the fly: the column matrix (9x the map) is never written or read.
+struct PackConv { int H, W, C, OH, OW, stride; };
+
 __global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict__ src, int64_t ld, int rows, int cols,
-                                                        __bf16* __restrict__ dst, __bf16* __restrict__ dstT, float* __restrict__ partial) {
+                                                        __bf16* __restrict__ dst, __bf16* __restrict__ dstT, float* __restrict__ partial,
+                                                        PackConv conv) {
   __shared__ float t[64][65];
   const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64, tid = threadIdx.x;
   const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
+  const int cl0 = (tid & 15) * 4;
+  const int tap = conv.C ? (c0 + cl0) / conv.C : 0, ci = conv.C ? (c0 + cl0) - tap * conv.C : 0;      // (C % 4 == 0: a float4 stays inside one tap)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int rl = (tid >> 4) + 16 * i, cl = (tid & 15) * 4;
     const int r = r0 + rl, c = c0 + cl;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r < rows) {
+    if (conv.C) {
+      if (r < rows && c < cols) {
+        const int ox = r % conv.OW, q = r / conv.OW, oy = q % conv.OH, b = q / conv.OH;
+        const int iy = oy * conv.stride - 1 + tap / 3, ix = ox * conv.stride - 1 + tap % 3;
+        if (iy >= 0 && iy < conv.H && ix >= 0 && ix < conv.W)
+          v = *reinterpret_cast<const float4*>(src + (((int64_t)b * conv.H + iy) * conv.W + ix) * conv.C + ci);
+      }
+    } else if (r < rows) {
       const float* p = src + (int64_t)r * ld + c;
       if (vec && c + 3 < cols) v = *reinterpret_cast<const float4*>(p);
       else {
@@ -290,8 +304,23 @@ extern "C" int sp3_pack_bf16(const float* src, int64_t ld, int rows, int cols, v
   const dim3 grid((cols + 63) / 64, (rows + 63) / 64);
   SP3_CHECK(grid.y <= 65535, "sp3_pack_bf16: too many rows for one launch (%d)", rows);
   hipLaunchKernelGGL(pack_bf16_kernel, grid, dim3(256), 0, ST(stream), src, ld, rows, cols, reinterpret_cast<__bf16*>(dst), reinterpret_cast<__bf16*>(dstT),
-                     (float*)nullptr);
+                     (float*)nullptr, PackConv{0, 0, 0, 0, 0, 0});
   SP3_LAUNCH_CHECK("sp3_pack_bf16");
+  return 0;
+}
+
+extern "C" int sp3_pack_bf16_conv3x3(const float* x, int B, int H, int W, int C, int stride, void* dst, void* dstT, void* stream) {
+  SP3_CHECK(x && (dst || dstT) && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && (stride == 1 || stride == 2) &&
+            (reinterpret_cast<uintptr_t>(x) & 15) == 0, "sp3_pack_bf16_conv3x3: bad arguments");
+  SP3_CHECK(((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(dstT)) & 15) == 0, "sp3_pack_bf16_conv3x3: outputs must be 16-byte aligned");
+  const int OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
+  const int64_t rows64 = (int64_t)B * OH * OW;
+  SP3_CHECK(rows64 <= 65535LL * 64, "sp3_pack_bf16_conv3x3: too many output pixels for one launch (%lld)", (long long)rows64);
+  const int rows = (int)rows64, cols = 9 * C;
+  const dim3 grid((cols + 63) / 64, (rows + 63) / 64);
+  hipLaunchKernelGGL(pack_bf16_kernel, grid, dim3(256), 0, ST(stream), x, (int64_t)cols, rows, cols, reinterpret_cast<__bf16*>(dst),
+                     reinterpret_cast<__bf16*>(dstT), (float*)nullptr, PackConv{H, W, C, OH, OW, stride});
+  SP3_LAUNCH_CHECK("sp3_pack_bf16_conv3x3");
   return 0;
 }
 
@@ -303,7 +332,7 @@ extern "C" int sp3_pack_bf16_colsum(const float* src, int64_t ld, int rows, int 
   SP3_CHECK(rows <= 8192, "sp3_pack_bf16_colsum: rows=%d > 8192 (taller matrices: sp3_pack_bf16 + sp3_colsum_rows)", rows);
   const dim3 grid((cols + 63) / 64, (rows + 63) / 64);
   hipLaunchKernelGGL(pack_bf16_kernel, grid, dim3(256), 0, ST(stream), src, ld, rows, cols, reinterpret_cast<__bf16*>(dst), reinterpret_cast<__bf16*>(dstT),
-                     partial_ws);
+                     partial_ws, PackConv{0, 0, 0, 0, 0, 0});
   // partial_ws is [grid.y][grid.x * 64]: the finish kernel walks it with that row length
   hipLaunchKernelGGL(colsum_rows_finish_kernel, dim3((cols + 255) / 256), dim3(256), 0, ST(stream), partial_ws, (int)grid.y, cols, colsum, accumulate,
                      (int)grid.x * 64);

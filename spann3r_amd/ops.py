@@ -698,6 +698,22 @@ def pack_bf16(x2d, want=True, want_t=False, colsum=None, accumulate=False):
     return a, t
 
 
+def pack_bf16_conv3x3(x, stride, want=True, want_t=False):
+    """NHWC fp32 map [B, H, W, C] -> the bf16 fragment-order copies of its 3x3 / pad 1 im2col matrix [B*OH*OW, 9C] (and / or its transpose),
+    gathered inside the pack launch (sp3_pack_bf16_conv3x3): the column matrix itself is never materialised"""
+    B, H, W_, C_ = x.shape
+    _f32(x, "x")
+    assert x.is_contiguous()
+    OH, OW = (H - 1) // stride + 1, (W_ - 1) // stride + 1
+    rows, cols = B * OH * OW, 9 * C_
+    alloc = lambda r, c: torch.empty(packed_shape(r, c, torch.bfloat16), dtype=torch.bfloat16, device=x.device)
+    a = PackedAct(rows, cols, torch.bfloat16, x.device, data=alloc(rows, cols)) if want else None
+    t = PackedAct(cols, rows, torch.bfloat16, x.device, data=alloc(cols, rows)) if want_t else None
+    _timed("pack_bf16_conv3x3", 0.0, rows * cols * 2.0 * (bool(want) + bool(want_t)) + x.numel() * 4.0,
+           lambda: L.check(L.load().sp3_pack_bf16_conv3x3(x.data_ptr(), B, H, W_, C_, stride, L.ptr(a), L.ptr(t), L.stream_ptr()), "sp3_pack_bf16_conv3x3"))
+    return a, t
+
+
 def gather_packed_rows(src, dst, sel, n_sel, C_):
     L.check(L.load().sp3_gather_packed_rows(src.data_ptr(), dst.data_ptr(), sel.data_ptr(), n_sel, C_, src.element_size(),
                                             L.stream_ptr()), "sp3_gather_packed_rows")

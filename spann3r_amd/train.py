@@ -38,6 +38,7 @@ from . import ops
 
 PRECISION = "fp32"
 FLASH_ATTENTION = True   # heads of 64: sp3_attention_train_fwd / _bwd (no attention matrix in memory); False: GEMMs + softmax kernels (_MHA)
+CONV_GATHER = True    # bf16 3x3 convolutions: im2col gathered inside the pack launch (False: sp3_im2col3x3 + pack)
 FUSED_HEADS = True    # attention through _MHA (one shuffle launch each way); False: the separate ATen reshapes + _Attention (tests compare the two)
 _wcache = {}          # id(weight) -> (version, packed W, packed W^T): refreshed when the optimizer has stepped
 
@@ -276,12 +277,23 @@ def _pad8(x):
 
 
 class _Linear(torch.autograd.Function):
-    """y = x W^T + b (+ res) (+ res2); x [R, K], W [N, K]"""
+    """y = x W^T + b (+ res) (+ res2); x [R, K], W [N, K].
+    conv = stride (bf16 mode only): x is an NHWC map [B, H, W, Cin] and the product runs on its 3x3 / pad 1 im2col matrix
+    [B*OH*OW, 9*Cin] -- gathered inside the pack launch (sp3_pack_bf16_conv3x3), never materialised; the backward's d col goes through
+    sp3_col2im3x3 and comes back as the gradient of the map."""
 
     @staticmethod
-    def forward(ctx, x, W, b, res, res2, wkey):
-        R, K = x.shape
+    def forward(ctx, x, W, b, res, res2, wkey, conv=None):
         N = W.shape[0]
+        ctx.conv = None
+        if conv is not None:
+            assert PRECISION == "bf16"
+            Bc, Hc, Wc, Cin = x.shape
+            OH, OW = (Hc - 1) // conv + 1, (Wc - 1) // conv + 1
+            R, K = Bc * OH * OW, 9 * Cin
+            ctx.conv = (Bc, Hc, Wc, Cin, conv)
+        else:
+            R, K = x.shape
         y = torch.empty(R, N, device=x.device)
         ctx.has = (b is not None, res is not None, res2 is not None)
         ctx.bf16 = PRECISION == "bf16"
@@ -291,7 +303,7 @@ class _Linear(torch.autograd.Function):
         if ctx.bf16:
             # bf16 operands in fragment order; X^T is made in the same pass and is all the backward keeps of x
             need_t = ctx.needs_input_grad[1]
-            xp, xT = ops.pack_bf16(x, True, need_t)
+            xp, xT = ops.pack_bf16_conv3x3(x, conv, True, need_t) if conv is not None else ops.pack_bf16(x, True, need_t)
             Wp, WT = _packed_weight(W, wkey)
             ops.gemm(xp, Wp, y, M=R, N=N, K=_r64(K), lda=K, ldc=N, bias=b, res1=res, ldr1=N, res2=res2, ldr2=N, tile=_bf16_tile(R, N))
             ctx.xT, ctx.WT, ctx.shape = xT, WT, (R, K, N)
@@ -330,6 +342,11 @@ class _Linear(torch.autograd.Function):
             if ctx.needs_input_grad[0]:           # dX = dY . W = dY . (W^T)^T: contraction over N
                 dx = torch.empty(R, K, device=dev)
                 ops.gemm(dyp, ctx.WT, dx, M=R, N=K, K=_r64(N), lda=N, ldc=K, tile=_bf16_tile(R, K))
+                if ctx.conv is not None:          # d col -> d map (the adjoint of the gather)
+                    Bc, Hc, Wc, Cin, stride = ctx.conv
+                    dmap = torch.empty(Bc, Hc, Wc, Cin, device=dev)
+                    L.check(L.load().sp3_col2im3x3(dx.data_ptr(), dmap.data_ptr(), Bc, Hc, Wc, Cin, stride, L.stream_ptr()), "sp3_col2im3x3")
+                    dx = dmap
             if need_w:                            # dW = dY^T . X = (dY^T) . (X^T)^T: contraction over the rows
                 xTw = ops.PackedWeight.wrap(ctx.xT.data, K, R)
                 def dw_into(out, acc):
@@ -352,7 +369,7 @@ class _Linear(torch.autograd.Function):
         if ctx.has[0] and ctx.needs_input_grad[2] and not bias_done:
             if not _into_grad(ctx.bparam, lambda out, acc: _colsum(dy, out=out)):
                 db = _colsum(dy)
-        return dx, dW, db, (dy if ctx.has[1] else None), (dy if ctx.has[2] else None), None
+        return dx, dW, db, (dy if ctx.has[1] else None), (dy if ctx.has[2] else None), None, None
 
 
 def linear(x, W, b=None, res=None, res2=None, wkey=None):
@@ -862,7 +879,12 @@ def conv3x3(x, W, b=None, stride=1, res=None, res2=None):
     B, H, Wd, Cin = x.shape
     OH, OW = (H - 1) // stride + 1, (Wd - 1) // stride + 1
     Wm = W.permute(0, 2, 3, 1).reshape(W.shape[0], 9 * Cin)
-    y = linear(_Im2col3x3.apply(x, stride), Wm, b, res, res2, wkey=(id(W), "conv3x3", W._version))
+    wkey = (id(W), "conv3x3", W._version)
+    if PRECISION == "bf16" and CONV_GATHER and Cin % 4 == 0:
+        flat = lambda t: None if t is None else t.reshape(-1, W.shape[0]).contiguous()
+        y = _Linear.apply(x.contiguous(), Wm.contiguous(), b, flat(res), flat(res2), wkey, stride)
+    else:
+        y = linear(_Im2col3x3.apply(x, stride), Wm, b, res, res2, wkey=wkey)
     return y.reshape(B, OH, OW, W.shape[0])
 
 

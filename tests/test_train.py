@@ -473,6 +473,36 @@ def test_pack_bf16_column_sums_ride_along(R, C):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("stride,geo", [(1, (2, 9, 7, 8, 12)), (2, (1, 14, 14, 64, 32)), (1, (2, 33, 20, 68, 256))])
+def test_conv3x3_gather_in_the_pack_launch(stride, geo):
+    """bf16 3x3 convolution: the im2col matrix gathered inside sp3_pack_bf16_conv3x3 gives the SAME fragment-order operands as
+    sp3_im2col3x3 + sp3_pack_bf16, hence bit-identical outputs and gradients"""
+    from spann3r_amd import train as T
+    B, H, W, Cin, Cout = geo
+    g = torch.Generator().manual_seed(H * W)
+    x0, w0, b0 = torch.randn(B, H, W, Cin, generator=g), torch.randn(Cout, Cin, 3, 3, generator=g) * 0.1, torch.randn(Cout, generator=g)
+    OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
+    r0, d0 = torch.randn(B, OH, OW, Cout, generator=g), torch.randn(B, OH, OW, Cout, generator=g)
+    res = {}
+    T.set_precision("bf16")
+    try:
+        for gather in (True, False):
+            T.CONV_GATHER = gather
+            T.invalidate_weight_cache()
+            x, w, b, r = (t.cuda().requires_grad_(True) for t in (x0, w0, b0, r0))
+            y = T.conv3x3(x, w, b, stride=stride, res=r)
+            y.backward(d0.cuda())
+            res[gather] = [y.detach(), x.grad, w.grad, b.grad, r.grad]
+    finally:
+        T.CONV_GATHER = True
+        T.set_precision("fp32")
+        T.invalidate_weight_cache()
+    assert all(torch.equal(a, c) for a, c in zip(res[True], res[False]))
+    ref = torch.nn.functional.conv2d(x0.permute(0, 3, 1, 2).double(), w0.double(), b0.double(), stride=stride, padding=1).permute(0, 2, 3, 1) + r0.double()
+    assert rel_err(res[True][0].cpu(), ref) < 2e-2
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("R,K,N", [(784, 1024, 3072), (196, 768, 768), (50, 200, 4), (1568, 864, 256)])
 def test_linear_bf16_forward_backward(R, K, N):
     """the bf16 Linear (packed operands, no transposes): y, dX, dW, db against float64 on the bf16-rounded operands"""
