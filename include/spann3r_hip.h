@@ -407,7 +407,11 @@ int sp3_pack_bf16(const float* src, int64_t ld, int rows, int cols, void* dst, v
 /* sp3_pack_bf16 of the 3x3 / pad 1 im2col matrix [(b, oy, ox), (ky*3 + kx)*C + c] of an NHWC fp32 map x [B, H, W, C] (stride 1 or 2; the layout
  * of sp3_im2col3x3), gathered inside the pack launch: the operand of a 3x3 convolution's bf16 GEMMs (croco/models/dpt_block.py:120-218) without
  * writing and re-reading the 9x larger column matrix. */
-int sp3_pack_bf16_conv3x3(const float* x, int B, int H, int W, int C, int stride, void* dst, void* dstT, void* stream);
+int sp3_pack_bf16_conv3x3(const float* x, int B, int H, int W, int C, int stride, int act, void* dst, void* dstT, void* stream);
+/* sp3_pack_bf16 with the producer's activation applied to every element as it is loaded (act: 0 none, 1 exact-erf GELU = sp3_gelu, 2 ReLU =
+ * sp3_relu; also the `act` of sp3_pack_bf16_conv3x3): Mlp's act(fc1(x)) -> fc2 (croco/models/blocks.py:73-79) and the ReLU -> convolution pairs of
+ * the DPT head (dpt_block.py:120-142) without the activation launch and its fp32 output */
+int sp3_pack_bf16_act(const float* src, int64_t ld, int rows, int cols, void* dst, void* dstT, int act, void* stream);
 /* sp3_pack_bf16, and colsum[j] (+)= sum_r src[r, j] (the bias gradient of the Linear whose dY is being packed; rows <= 8192): the pack
  * launch leaves the column sums of its 64-row tiles in partial_ws (ceil(rows / 64) * ceil(cols / 64) * 64 floats), a second small launch
  * adds them in a fixed order: deterministic, and no second pass over src. */

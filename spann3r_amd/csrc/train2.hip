@@ -23,7 +23,7 @@ namespace {
 // every workgroup then needs costs more than the extra launch.)
 // conv.C != 0: src is an NHWC map [B, H, W, C] and the matrix being packed is its 3x3 / pad 1 im2col [(b, oy, ox), (ky*3 + kx)*C + c]
 // (sp3_im2col3x3's layout), gathered on the fly: the column matrix (9x the map) is never written or read.
-struct PackConv { int H, W, C, OH, OW, stride; };
+struct PackConv { int H, W, C, OH, OW, stride, act; };      // act: 0 none, 1 exact-erf GELU, 2 ReLU applied to every element as it is loaded
 
 __global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict__ src, int64_t ld, int rows, int cols,
                                                         __bf16* __restrict__ dst, __bf16* __restrict__ dstT, float* __restrict__ partial,
@@ -54,6 +54,12 @@ __global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict_
         if (c + 2 < cols) v.z = p[2];
         if (c + 3 < cols) v.w = p[3];
       }
+    }
+    if (conv.act == 1) {                               // the producer's activation rides in the load (gelu_kernel's / relu_kernel's arithmetic)
+      v.x = 0.5f * v.x * (1.0f + erff(v.x * 0.70710678118654752f)); v.y = 0.5f * v.y * (1.0f + erff(v.y * 0.70710678118654752f));
+      v.z = 0.5f * v.z * (1.0f + erff(v.z * 0.70710678118654752f)); v.w = 0.5f * v.w * (1.0f + erff(v.w * 0.70710678118654752f));
+    } else if (conv.act == 2) {
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
     }
     t[rl][cl] = v.x; t[rl][cl + 1] = v.y; t[rl][cl + 2] = v.z; t[rl][cl + 3] = v.w;
   }
@@ -304,13 +310,24 @@ extern "C" int sp3_pack_bf16(const float* src, int64_t ld, int rows, int cols, v
   const dim3 grid((cols + 63) / 64, (rows + 63) / 64);
   SP3_CHECK(grid.y <= 65535, "sp3_pack_bf16: too many rows for one launch (%d)", rows);
   hipLaunchKernelGGL(pack_bf16_kernel, grid, dim3(256), 0, ST(stream), src, ld, rows, cols, reinterpret_cast<__bf16*>(dst), reinterpret_cast<__bf16*>(dstT),
-                     (float*)nullptr, PackConv{0, 0, 0, 0, 0, 0});
+                     (float*)nullptr, PackConv{0, 0, 0, 0, 0, 0, 0});
   SP3_LAUNCH_CHECK("sp3_pack_bf16");
   return 0;
 }
 
-extern "C" int sp3_pack_bf16_conv3x3(const float* x, int B, int H, int W, int C, int stride, void* dst, void* dstT, void* stream) {
-  SP3_CHECK(x && (dst || dstT) && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && (stride == 1 || stride == 2) &&
+extern "C" int sp3_pack_bf16_act(const float* src, int64_t ld, int rows, int cols, void* dst, void* dstT, int act, void* stream) {
+  SP3_CHECK(src && (dst || dstT) && rows > 0 && cols > 0 && ld >= cols && act >= 0 && act <= 2, "sp3_pack_bf16_act: bad arguments (rows=%d cols=%d ld=%lld act=%d)", rows, cols, (long long)ld, act);
+  SP3_CHECK(((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(dstT)) & 15) == 0, "sp3_pack_bf16_act: outputs must be 16-byte aligned");
+  const dim3 grid((cols + 63) / 64, (rows + 63) / 64);
+  SP3_CHECK(grid.y <= 65535, "sp3_pack_bf16_act: too many rows for one launch (%d)", rows);
+  hipLaunchKernelGGL(pack_bf16_kernel, grid, dim3(256), 0, ST(stream), src, ld, rows, cols, reinterpret_cast<__bf16*>(dst), reinterpret_cast<__bf16*>(dstT),
+                     (float*)nullptr, PackConv{0, 0, 0, 0, 0, 0, act});
+  SP3_LAUNCH_CHECK("sp3_pack_bf16_act");
+  return 0;
+}
+
+extern "C" int sp3_pack_bf16_conv3x3(const float* x, int B, int H, int W, int C, int stride, int act, void* dst, void* dstT, void* stream) {
+  SP3_CHECK(x && (dst || dstT) && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && (stride == 1 || stride == 2) && act >= 0 && act <= 2 &&
             (reinterpret_cast<uintptr_t>(x) & 15) == 0, "sp3_pack_bf16_conv3x3: bad arguments");
   SP3_CHECK(((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(dstT)) & 15) == 0, "sp3_pack_bf16_conv3x3: outputs must be 16-byte aligned");
   const int OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
@@ -319,7 +336,7 @@ extern "C" int sp3_pack_bf16_conv3x3(const float* x, int B, int H, int W, int C,
   const int rows = (int)rows64, cols = 9 * C;
   const dim3 grid((cols + 63) / 64, (rows + 63) / 64);
   hipLaunchKernelGGL(pack_bf16_kernel, grid, dim3(256), 0, ST(stream), x, (int64_t)cols, rows, cols, reinterpret_cast<__bf16*>(dst),
-                     reinterpret_cast<__bf16*>(dstT), (float*)nullptr, PackConv{H, W, C, OH, OW, stride});
+                     reinterpret_cast<__bf16*>(dstT), (float*)nullptr, PackConv{H, W, C, OH, OW, stride, act});
   SP3_LAUNCH_CHECK("sp3_pack_bf16_conv3x3");
   return 0;
 }
@@ -332,7 +349,7 @@ extern "C" int sp3_pack_bf16_colsum(const float* src, int64_t ld, int rows, int 
   SP3_CHECK(rows <= 8192, "sp3_pack_bf16_colsum: rows=%d > 8192 (taller matrices: sp3_pack_bf16 + sp3_colsum_rows)", rows);
   const dim3 grid((cols + 63) / 64, (rows + 63) / 64);
   hipLaunchKernelGGL(pack_bf16_kernel, grid, dim3(256), 0, ST(stream), src, ld, rows, cols, reinterpret_cast<__bf16*>(dst), reinterpret_cast<__bf16*>(dstT),
-                     partial_ws, PackConv{0, 0, 0, 0, 0, 0});
+                     partial_ws, PackConv{0, 0, 0, 0, 0, 0, 0});
   // partial_ws is [grid.y][grid.x * 64]: the finish kernel walks it with that row length
   hipLaunchKernelGGL(colsum_rows_finish_kernel, dim3((cols + 255) / 256), dim3(256), 0, ST(stream), partial_ws, (int)grid.y, cols, colsum, accumulate,
                      (int)grid.x * 64);

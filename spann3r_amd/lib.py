@@ -164,7 +164,8 @@ _PROTOS = {
                   C.c_float, C.c_void_p],
     "sp3_mul": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
     "sp3_pack_bf16": [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
-    "sp3_pack_bf16_conv3x3": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
+    "sp3_pack_bf16_conv3x3": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
+    "sp3_pack_bf16_act": [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p],
     "sp3_pack_bf16_colsum": [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p],
     "sp3_colsum_rows": [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p],
     "sp3_sumsq_partial": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p],

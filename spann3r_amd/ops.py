@@ -676,10 +676,10 @@ def _pack_colsum_ws(device, nby, nbx):
     return ws
 
 
-def pack_bf16(x2d, want=True, want_t=False, colsum=None, accumulate=False):
+def pack_bf16(x2d, want=True, want_t=False, colsum=None, accumulate=False, act=0):
     """fp32 row-major [rows, cols] (any row stride) -> (PackedAct [rows, cols] or None, PackedAct [cols, rows] or None) in bf16
     fragment order, one launch (sp3_pack_bf16); the pads of both are zeros.  colsum (fp32 [cols], rows <= 8192): x2d.sum(0) is written /
-    added there by the same launch."""
+    added there by the same launch.  act (1 GELU, 2 ReLU): applied to every element as it is loaded (sp3_pack_bf16_act)."""
     rows, cols = x2d.shape
     _f32(x2d, "x")
     if x2d.stride(1) != 1:
@@ -687,6 +687,11 @@ def pack_bf16(x2d, want=True, want_t=False, colsum=None, accumulate=False):
     alloc = lambda r, c: torch.empty(packed_shape(r, c, torch.bfloat16), dtype=torch.bfloat16, device=x2d.device)
     a = PackedAct(rows, cols, torch.bfloat16, x2d.device, data=alloc(rows, cols)) if want else None
     t = PackedAct(cols, rows, torch.bfloat16, x2d.device, data=alloc(cols, rows)) if want_t else None
+    if act:
+        assert colsum is None
+        _timed("pack_bf16", 0.0, rows * cols * (4.0 + 2.0 * (bool(want) + bool(want_t))),
+               lambda: L.check(L.load().sp3_pack_bf16_act(x2d.data_ptr(), x2d.stride(0), rows, cols, L.ptr(a), L.ptr(t), int(act), L.stream_ptr()), "sp3_pack_bf16_act"))
+        return a, t
     if colsum is not None:
         pw = _pack_colsum_ws(x2d.device, (rows + 63) // 64, (cols + 63) // 64)
         _timed("pack_bf16", 0.0, rows * cols * (4.0 + 2.0 * (bool(want) + bool(want_t))),
@@ -698,7 +703,7 @@ def pack_bf16(x2d, want=True, want_t=False, colsum=None, accumulate=False):
     return a, t
 
 
-def pack_bf16_conv3x3(x, stride, want=True, want_t=False):
+def pack_bf16_conv3x3(x, stride, want=True, want_t=False, act=0):
     """NHWC fp32 map [B, H, W, C] -> the bf16 fragment-order copies of its 3x3 / pad 1 im2col matrix [B*OH*OW, 9C] (and / or its transpose),
     gathered inside the pack launch (sp3_pack_bf16_conv3x3): the column matrix itself is never materialised"""
     B, H, W_, C_ = x.shape
@@ -710,7 +715,7 @@ def pack_bf16_conv3x3(x, stride, want=True, want_t=False):
     a = PackedAct(rows, cols, torch.bfloat16, x.device, data=alloc(rows, cols)) if want else None
     t = PackedAct(cols, rows, torch.bfloat16, x.device, data=alloc(cols, rows)) if want_t else None
     _timed("pack_bf16_conv3x3", 0.0, rows * cols * 2.0 * (bool(want) + bool(want_t)) + x.numel() * 4.0,
-           lambda: L.check(L.load().sp3_pack_bf16_conv3x3(x.data_ptr(), B, H, W_, C_, stride, L.ptr(a), L.ptr(t), L.stream_ptr()), "sp3_pack_bf16_conv3x3"))
+           lambda: L.check(L.load().sp3_pack_bf16_conv3x3(x.data_ptr(), B, H, W_, C_, stride, int(act), L.ptr(a), L.ptr(t), L.stream_ptr()), "sp3_pack_bf16_conv3x3"))
     return a, t
 
 

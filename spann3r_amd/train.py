@@ -38,6 +38,7 @@ from . import ops
 
 PRECISION = "fp32"
 FLASH_ATTENTION = True   # heads of 64: sp3_attention_train_fwd / _bwd (no attention matrix in memory); False: GEMMs + softmax kernels (_MHA)
+ACT_ON_LOAD = True    # bf16: GELU / ReLU in front of a Linear or 3x3 convolution applied by its pack launch (False: separate activation launches)
 CONV_GATHER = True    # bf16 3x3 convolutions: im2col gathered inside the pack launch (False: sp3_im2col3x3 + pack)
 FUSED_HEADS = True    # attention through _MHA (one shuffle launch each way); False: the separate ATen reshapes + _Attention (tests compare the two)
 _wcache = {}          # id(weight) -> (version, packed W, packed W^T): refreshed when the optimizer has stepped
@@ -280,12 +281,15 @@ class _Linear(torch.autograd.Function):
     """y = x W^T + b (+ res) (+ res2); x [R, K], W [N, K].
     conv = stride (bf16 mode only): x is an NHWC map [B, H, W, Cin] and the product runs on its 3x3 / pad 1 im2col matrix
     [B*OH*OW, 9*Cin] -- gathered inside the pack launch (sp3_pack_bf16_conv3x3), never materialised; the backward's d col goes through
-    sp3_col2im3x3 and comes back as the gradient of the map."""
+    sp3_col2im3x3 and comes back as the gradient of the map.
+    act_in = 1 (GELU) / 2 (ReLU), bf16 mode only: the product runs on act(x), applied as the pack launch loads x (no activation launch, no
+    fp32 act(x)); the backward multiplies d act(x) by act'(x) (sp3_gelu_bwd / sp3_relu_bwd on the saved x)."""
 
     @staticmethod
-    def forward(ctx, x, W, b, res, res2, wkey, conv=None):
+    def forward(ctx, x, W, b, res, res2, wkey, conv=None, act_in=0):
         N = W.shape[0]
         ctx.conv = None
+        ctx.act_in = act_in
         if conv is not None:
             assert PRECISION == "bf16"
             Bc, Hc, Wc, Cin = x.shape
@@ -303,7 +307,9 @@ class _Linear(torch.autograd.Function):
         if ctx.bf16:
             # bf16 operands in fragment order; X^T is made in the same pass and is all the backward keeps of x
             need_t = ctx.needs_input_grad[1]
-            xp, xT = ops.pack_bf16_conv3x3(x, conv, True, need_t) if conv is not None else ops.pack_bf16(x, True, need_t)
+            xp, xT = ops.pack_bf16_conv3x3(x, conv, True, need_t, act=act_in) if conv is not None else ops.pack_bf16(x, True, need_t, act=act_in)
+            if act_in and ctx.needs_input_grad[0]:
+                ctx.save_for_backward(x)
             Wp, WT = _packed_weight(W, wkey)
             ops.gemm(xp, Wp, y, M=R, N=N, K=_r64(K), lda=K, ldc=N, bias=b, res1=res, ldr1=N, res2=res2, ldr2=N, tile=_bf16_tile(R, N))
             ctx.xT, ctx.WT, ctx.shape = xT, WT, (R, K, N)
@@ -311,6 +317,7 @@ class _Linear(torch.autograd.Function):
             if ctx.Wparam is not None and need_t:
                 _expect(W)
             return y
+        assert not act_in, "act_in is a bf16-mode fusion"
         xp, Wp = _pad8(x), _pad8(W)
         ops.gemm(xp, Wp, y, M=R, N=N, K=xp.shape[1], lda=xp.shape[1], ldc=N, ldw=Wp.shape[1], bias=b, res1=res, ldr1=N, res2=res2, ldr2=N)
         ctx.save_for_backward(x, W)
@@ -347,6 +354,10 @@ class _Linear(torch.autograd.Function):
                     dmap = torch.empty(Bc, Hc, Wc, Cin, device=dev)
                     L.check(L.load().sp3_col2im3x3(dx.data_ptr(), dmap.data_ptr(), Bc, Hc, Wc, Cin, stride, L.stream_ptr()), "sp3_col2im3x3")
                     dx = dmap
+                if ctx.act_in:                    # d act(x) -> d x, in place (element i reads and writes only its own slot)
+                    (xraw,) = ctx.saved_tensors
+                    fn = L.load().sp3_gelu_bwd if ctx.act_in == 1 else L.load().sp3_relu_bwd
+                    L.check(fn(xraw.data_ptr(), dx.data_ptr(), dx.data_ptr(), dx.numel(), L.stream_ptr()), "sp3_gelu_bwd / sp3_relu_bwd")
             if need_w:                            # dW = dY^T . X = (dY^T) . (X^T)^T: contraction over the rows
                 xTw = ops.PackedWeight.wrap(ctx.xT.data, K, R)
                 def dw_into(out, acc):
@@ -369,17 +380,17 @@ class _Linear(torch.autograd.Function):
         if ctx.has[0] and ctx.needs_input_grad[2] and not bias_done:
             if not _into_grad(ctx.bparam, lambda out, acc: _colsum(dy, out=out)):
                 db = _colsum(dy)
-        return dx, dW, db, (dy if ctx.has[1] else None), (dy if ctx.has[2] else None), None, None
+        return dx, dW, db, (dy if ctx.has[1] else None), (dy if ctx.has[2] else None), None, None, None
 
 
-def linear(x, W, b=None, res=None, res2=None, wkey=None):
+def linear(x, W, b=None, res=None, res2=None, wkey=None, act_in=0):
     """wkey: cache key of the packed bf16 copies of W (default: the parameter itself when W is a leaf; derived matrices -- a
     permuted convolution weight -- pass (id(parameter), tag))"""
     sh = x.shape
     flat = lambda t: None if t is None else t.reshape(-1, W.shape[0]).contiguous()
     if wkey is None and W.is_leaf:
         wkey = (id(W), "linear", W._version, W.data_ptr())
-    y = _Linear.apply(x.reshape(-1, sh[-1]).contiguous(), W.contiguous(), b, flat(res), flat(res2), wkey)
+    y = _Linear.apply(x.reshape(-1, sh[-1]).contiguous(), W.contiguous(), b, flat(res), flat(res2), wkey, None, act_in)
     return y.reshape(*sh[:-1], W.shape[0])
 
 
@@ -767,8 +778,10 @@ def cross_attention(xq, y, qpos, kpos, P, pre, heads, base=100.0, res=None):
 
 def mlp(x, P, pre, res=None):
     """croco/models/blocks.py:73-79"""
-    h = _Gelu.apply(linear(x, P[pre + "fc1.weight"], P[pre + "fc1.bias"]))
-    return linear(h, P[pre + "fc2.weight"], P[pre + "fc2.bias"], res)
+    h = linear(x, P[pre + "fc1.weight"], P[pre + "fc1.bias"])
+    if PRECISION == "bf16" and ACT_ON_LOAD:           # GELU applied as fc2's pack launch loads fc1's output
+        return linear(h, P[pre + "fc2.weight"], P[pre + "fc2.bias"], res, act_in=1)
+    return linear(_Gelu.apply(h), P[pre + "fc2.weight"], P[pre + "fc2.bias"], res)
 
 
 def block(x, pos, P, pre, heads, base=100.0, use_rope=True, eps=1e-6):
@@ -874,17 +887,18 @@ class _Postprocess(torch.autograd.Function):
         return draw
 
 
-def conv3x3(x, W, b=None, stride=1, res=None, res2=None):
-    """x NHWC [B,H,W,Cin], W [Cout,Cin,3,3] (the reference's Conv2d layout), padding 1 -> [B,OH,OW,Cout]"""
+def conv3x3(x, W, b=None, stride=1, res=None, res2=None, relu_in=False):
+    """x NHWC [B,H,W,Cin], W [Cout,Cin,3,3] (the reference's Conv2d layout), padding 1 -> [B,OH,OW,Cout]; relu_in: the convolution of relu(x)"""
     B, H, Wd, Cin = x.shape
     OH, OW = (H - 1) // stride + 1, (Wd - 1) // stride + 1
     Wm = W.permute(0, 2, 3, 1).reshape(W.shape[0], 9 * Cin)
     wkey = (id(W), "conv3x3", W._version)
     if PRECISION == "bf16" and CONV_GATHER and Cin % 4 == 0:
         flat = lambda t: None if t is None else t.reshape(-1, W.shape[0]).contiguous()
-        y = _Linear.apply(x.contiguous(), Wm.contiguous(), b, flat(res), flat(res2), wkey, stride)
+        fuse = relu_in and ACT_ON_LOAD
+        y = _Linear.apply((x if fuse or not relu_in else _Relu.apply(x)).contiguous(), Wm.contiguous(), b, flat(res), flat(res2), wkey, stride, 2 if fuse else 0)
     else:
-        y = linear(_Im2col3x3.apply(x, stride), Wm, b, res, res2, wkey=wkey)
+        y = linear(_Im2col3x3.apply(_Relu.apply(x) if relu_in else x, stride), Wm, b, res, res2, wkey=wkey)
     return y.reshape(B, OH, OW, W.shape[0])
 
 
@@ -903,8 +917,8 @@ def conv_transpose_ks(x, W, b, k):
 
 def _rcu(x, P, p, res2=None):
     """ResidualConvUnit_custom (dpt_block.py:120-142): conv2(relu(conv1(relu(x)))) + x (+ res2)"""
-    o = conv3x3(_Relu.apply(x), P[p + "conv1.weight"], P[p + "conv1.bias"])
-    return conv3x3(_Relu.apply(o), P[p + "conv2.weight"], P[p + "conv2.bias"], res=x, res2=res2)
+    o = conv3x3(x, P[p + "conv1.weight"], P[p + "conv1.bias"], relu_in=True)
+    return conv3x3(o, P[p + "conv2.weight"], P[p + "conv2.bias"], res=x, res2=res2, relu_in=True)
 
 
 def _fusion(P, p, x0, x1=None, crop=None):
@@ -988,7 +1002,10 @@ def encode_feat_key(feat, dec_last, P, num):
     """spann3r/model.py:299-303"""
     p = "attn_head_%d." % num
     x = torch.cat((feat, dec_last), dim=-1)
-    return linear(_Gelu.apply(linear(x, P[p + "0.weight"], P[p + "0.bias"])), P[p + "2.weight"], P[p + "2.bias"])
+    h = linear(x, P[p + "0.weight"], P[p + "0.bias"])
+    if PRECISION == "bf16" and ACT_ON_LOAD:
+        return linear(h, P[p + "2.weight"], P[p + "2.bias"], act_in=1)
+    return linear(_Gelu.apply(h), P[p + "2.weight"], P[p + "2.bias"])
 
 
 def encode_cur_value(pts3d, feat_k, P, cfg, dec_last=None, pos1=None):

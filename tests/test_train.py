@@ -473,6 +473,38 @@ def test_pack_bf16_column_sums_ride_along(R, C):
 
 
 @pytest.mark.gpu
+def test_activation_on_load_matches_separate_launches():
+    """bf16 mode: GELU in front of fc2 and ReLU in front of a 3x3 convolution applied by the consumer's pack launch (sp3_pack_bf16_act,
+    sp3_pack_bf16_conv3x3 act) -- bit-identical values and gradients to the separate activation launches"""
+    from spann3r_amd import train as T
+    g = torch.Generator().manual_seed(3)
+    C = 64
+    P0 = {"m.fc1.weight": torch.randn(4 * C, C, generator=g) * 0.1, "m.fc1.bias": torch.randn(4 * C, generator=g) * 0.1,
+          "m.fc2.weight": torch.randn(C, 4 * C, generator=g) * 0.1, "m.fc2.bias": torch.randn(C, generator=g) * 0.1,
+          "r.conv1.weight": torch.randn(C, C, 3, 3, generator=g) * 0.05, "r.conv1.bias": torch.randn(C, generator=g) * 0.1,
+          "r.conv2.weight": torch.randn(C, C, 3, 3, generator=g) * 0.05, "r.conv2.bias": torch.randn(C, generator=g) * 0.1}
+    x0, m0, d0, e0 = torch.randn(2, 100, C, generator=g), torch.randn(2, 9, 11, C, generator=g), torch.randn(2, 100, C, generator=g), torch.randn(2, 9, 11, C, generator=g)
+    res = {}
+    T.set_precision("bf16")
+    try:
+        for on in (True, False):
+            T.ACT_ON_LOAD = on
+            T.invalidate_weight_cache()
+            P = {k: v.cuda().requires_grad_(True) for k, v in P0.items()}
+            x, m = x0.cuda().requires_grad_(True), m0.cuda().requires_grad_(True)
+            y = T.mlp(x, P, "m.", res=x)
+            z = T._rcu(m, P, "r.")
+            y.backward(d0.cuda())
+            z.backward(e0.cuda())
+            res[on] = [y.detach(), z.detach(), x.grad, m.grad] + [P[k].grad for k in sorted(P)]
+    finally:
+        T.ACT_ON_LOAD = True
+        T.set_precision("fp32")
+        T.invalidate_weight_cache()
+    assert all(torch.equal(a, b) for a, b in zip(res[True], res[False]))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("stride,geo", [(1, (2, 9, 7, 8, 12)), (2, (1, 14, 14, 64, 32)), (1, (2, 33, 20, 68, 256))])
 def test_conv3x3_gather_in_the_pack_launch(stride, geo):
     """bf16 3x3 convolution: the im2col matrix gathered inside sp3_pack_bf16_conv3x3 gives the SAME fragment-order operands as
