@@ -24,6 +24,7 @@ for stage in "$@"; do
     modeltests) timeout 1200 python -m pytest tests/test_model_gpu.py -x -q -m gpu > "$OUT/modeltests.txt" 2>&1; tail -5 "$OUT/modeltests.txt" ;;
     alltests)   timeout 2400 python -m pytest tests -x -q -m gpu > "$OUT/alltests.txt" 2>&1; tail -8 "$OUT/alltests.txt" ;;
     gemmsweep)  timeout 600 python tools/bench_gemm2.py --big > "$OUT/gemmsweep.txt" 2>&1; cat "$OUT/gemmsweep.txt" ;;
+    trainattn)  for a in "" "--cross" "--precision fp32"; do timeout 300 python tools/bench_train_attention.py $a >> "$OUT/trainattn.txt" 2>&1; done; grep "us per" "$OUT/trainattn.txt" ;;
     trainsweep) timeout 600 python tools/bench_gemm2.py --train --mb 1 > "$OUT/trainsweep.txt" 2>&1; cat "$OUT/trainsweep.txt" ;;
     ksweep)     timeout 600 python tools/bench_gemm2.py --big --ksweep > "$OUT/ksweep_cold.txt" 2>&1; cat "$OUT/ksweep_cold.txt"; timeout 600 python tools/bench_gemm2.py --big --ksweep --mb 1 > "$OUT/ksweep_warm.txt" 2>&1; cat "$OUT/ksweep_warm.txt" ;;
     pmcgemm)    for C in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum" "FETCH_SIZE" ; do
