@@ -501,7 +501,8 @@ def _pack_v_for_pv(v, npad):
     return out
 
 
-@pytest.mark.parametrize("B,heads,Nq,Nk", [(1, 16, 196, 196), (2, 12, 20, 20), (1, 12, 50, 300), (2, 3, 17, 65)])
+@pytest.mark.parametrize("B,heads,Nq,Nk", [(1, 16, 196, 196), (2, 12, 20, 20), (1, 12, 50, 300), (2, 3, 17, 65),
+                                           (1, 4, 1024, 1024), (2, 3, 100, 700), (1, 2, 70, 513)])     # (long sequences: up to 16 key tiles, 4 per wave)
 def test_attention_packed(B, heads, Nq, Nk):
     """bf16 attention on fragment-order q/k + PV-order V == softmax(qk^T/8)v on the bf16-rounded operands."""
     ops = _ops()
