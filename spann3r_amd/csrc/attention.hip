@@ -12,7 +12,6 @@
 // bf16: v_mfma_f32_16x16x32_bf16; fp32: v_mfma_f32_16x16x4_f32 (exact fp32, parity mode).
 #include "common.h"
 #include <math.h>
-#include <stdlib.h>
 
 namespace {
 
