@@ -88,7 +88,7 @@ typedef struct sp3_gemm_desc {
   int32_t heads;
   int64_t vt_ld;
   int32_t ps_k, ps_H, ps_W, ps_C;
-  int32_t tile;           /* -1 auto; 0: 32x32 (K over 4 waves); 1: 64x64; 2: 64x128; 3: 64x64 (K over 4 waves);
+  int32_t tile;           /* -1 auto (sp3_gemm_plan tells which); 30..: lean small-M instances (sp3_gemm_plan); 0: 32x32 (K over 4 waves); 1: 64x64; 2: 64x128; 3: 64x64 (K over 4 waves);
                              5 / 6: 128x128 / 128x64 with both operands staged through LDS (bf16 fragment-order A and W,
                              K % 64 == 0) */
   int32_t a_bf16;
@@ -152,6 +152,14 @@ int sp3_gemm(const sp3_gemm_desc* desc_host, void* stream);
  * (dust3r/model.py:196-198, croco/models/blocks.py:187-189), so the second launch boundary buys nothing.  Both descriptors
  * must resolve to the same kernel instance (dtypes, loader, tile; b.tile < 0 takes a's); no split-K. */
 int sp3_gemm2(const sp3_gemm_desc* a, const sp3_gemm_desc* b, void* stream);
+/* The tile sp3_gemm runs `desc` on when desc->tile < 0 (desc->tile itself is ignored), or < 0 for an invalid descriptor.  Tiles
+ * 30.. are the LEAN small-M instances (csrc/gemm_sm.hip): the per-frame step's 196-row weight-streaming Linears
+ * (croco/models/blocks.py:73-79,94-112,149-169 at batch 1) on bf16 fragment-order operands, with shape, tile and epilogue fixed at
+ * compile time -- 30 / 31: q/k/v projections (K = 1024 / 768, ROPE_VT epilogue with qkv_packed), 32 / 33: fc1 + GELU into
+ * fragment order (K = 1024 / 768), 34..38: output projections onto the fp32 residual stream (K = 1024, 4096, 768, 3072, 1792).
+ * They serve M <= 256, batch <= 2, bias set, alpha = 1, no split-K / second residual / split A; anything else runs on the general
+ * tiles above.  SP3_LEAN_GEMM=0 in the environment switches them off (A/B runs). */
+int sp3_gemm_plan(const sp3_gemm_desc* desc_host);
 
 /* ------------------------------------------------------------------------------------------
  * sp3_layernorm : nn.LayerNorm over the last dim (croco/models/blocks.py:128-129,187-190 eps 1e-6;

@@ -6,14 +6,14 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libspann3r_hip.so")
-SOURCES = ["error.cpp", "gemm.hip", "norm_rope.hip", "attention.hip", "memory.hip", "dpt.hip", "conv.hip", "preproc.hip", "loss.hip", "train.hip", "train2.hip", "postproc.hip"]
+SOURCES = ["error.cpp", "gemm.hip", "gemm_sm.hip", "norm_rope.hip", "attention.hip", "memory.hip", "dpt.hip", "conv.hip", "preproc.hip", "loss.hip", "train.hip", "train2.hip", "postproc.hip"]
 
 
 def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "common.h"),
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_sm.h"),
                                                       os.path.join(HERE, "..", "include", "spann3r_hip.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 

@@ -25,6 +25,7 @@
 //    with fp32 accumulation; bf16-mode activations are either already bf16 (a_bf16) or fp32 converted
 //    on load (v_cvt_pk_bf16_f32).
 #include "common.h"
+#include "gemm_sm.h"
 #include <cstdlib>
 #include <type_traits>
 
@@ -1914,13 +1915,39 @@ extern "C" int sp3_gemm(const sp3_gemm_desc* dp, void* stream_) {
   sp3_gemm_desc d = *dp;
   int tile = -1;
   if (int rc = gemm_prepare(d, tile)) return rc;
+  // the 196-row weight-streaming shapes of the per-frame step: lean shape-specialised instances (gemm_sm.hip, tiles 30..)
+  if (d.tile >= 30 || (d.tile < 0 && sp3_gemm_sm_tile(d) >= 0)) return sp3_gemm_sm_launch(d, nullptr, reinterpret_cast<hipStream_t>(stream_));
   return gemm_dispatch(d, tile, reinterpret_cast<hipStream_t>(stream_));
+}
+
+// The tile sp3_gemm would run this descriptor on when desc.tile < 0 (the lean instances 30.. included); < 0: invalid descriptor
+// (sp3_last_error).  Hosts use it to label profiles and to decide whether two launches can be paired.
+extern "C" int sp3_gemm_plan(const sp3_gemm_desc* dp) {
+  if (!dp) return -1;
+  sp3_gemm_desc d = *dp;
+  d.tile = -1;
+  int tile = -1;
+  if (gemm_prepare(d, tile)) return -1;
+  const int lean = sp3_gemm_sm_tile(d);
+  return lean >= 0 ? lean : tile;
 }
 
 extern "C" int sp3_gemm2(const sp3_gemm_desc* ap, const sp3_gemm_desc* bp, void* stream_) {
   SP3_CHECK(ap != nullptr && bp != nullptr, "sp3_gemm2: null descriptor");
   sp3_gemm_desc a = *ap, b = *bp;
   int ta = -1, tb = -1;
+  {
+    // both groups on one lean instance (gemm_sm.hip): decided before the legacy tiles are consulted
+    sp3_gemm_desc a0 = a, b0 = b;
+    int t0 = -1, t1 = -1;
+    const int want = a0.tile;
+    a0.tile = b0.tile = -1;
+    if (gemm_prepare(a0, t0) == 0 && gemm_prepare(b0, t1) == 0) {
+      const int la = sp3_gemm_sm_tile(a0), lb = sp3_gemm_sm_tile(b0);
+      if (la >= 30 && la == lb && (want < 0 || want == la)) return sp3_gemm_sm_launch(a0, &b0, reinterpret_cast<hipStream_t>(stream_));
+    }
+    SP3_CHECK(want < 30, "sp3_gemm2: tile %d asks for a lean instance the two groups do not share", want);
+  }
   if (int rc = gemm_prepare(a, ta)) return rc;
   if (b.tile < 0) b.tile = ta;                   // the second group runs on the first one's kernel instance
   if (int rc = gemm_prepare(b, tb)) return rc;

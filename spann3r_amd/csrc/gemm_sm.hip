@@ -1,0 +1,476 @@
+// sp3_gemm, the LEAN small-M instances ("tiles" 30..): the 196-row weight-streaming GEMMs of the per-frame step
+// (croco/models/blocks.py:73-79,94-112,149-169 at B = 1: every Linear of a decoder / value-encoder block).
+//
+// Why a second kernel family (measured, tools/ubench/gemm_sm.hip, profiles/r04_gemm_small_m_*): at 196 rows a launch is
+// ~2 us of launch boundary + one cold pass over its weights + an epilogue; the generic gemm_kernel spends another 2.5-5 us
+// per launch on things that are not the GEMM -- a ~60-field run-time descriptor, a tile map with run-time divisions, a
+// masked K tail path, epilogues that branch on a dozen options.  Here everything a shape fixes is a template constant:
+//   * K (k-blocks), tile and wave count are compile-time; the grid is 3-D (x = XCD, y = M-tile, z = group x N-tile / 8), so the
+//     tile map needs no division and the M-tiles that share a weight panel still land on one XCD, adjacent in dispatch order;
+//   * K is split over ALL waves of the workgroup (4..16) and a wave requests every operand byte it will ever need before its
+//     first MFMA (or keeps a RING of k-blocks in flight when K is long): one cold round trip per launch;
+//   * the tile is chosen per shape so that the launch is ONE round of <= ~2 workgroups per CU with the fewest operand bytes
+//     through the CUs' vector caches (the K loop is bound by L2 -> CU bytes at ~35 B/clk/CU, not by HBM or the MFMAs);
+//   * every epilogue operand (bias, LayerNorm column sums and row statistics, residual rows, RoPE positions and table rows)
+//     is requested before the K loop; partial tiles meet in LDS once; three epilogues only:
+//       SM_PACKED  bias (+ folded LayerNorm) (+ GELU) -> fragment-order bf16           (fc1, key MLP hidden)
+//       SM_STREAM  bias (+ folded LayerNorm) (+ residual) -> fp32 rows (+ per-32-column statistics + packed bf16 copy)
+//       SM_ROPE    folded LayerNorm + bias + 2-D RoPE -> fragment-order q / k, V in PV-operand order  (q/k/v projections)
+// Operands: A and W bf16 in fragment order (include/spann3r_hip.h a_packed / w_packed), fp32 accumulation.  Same arithmetic per
+// output element as gemm_kernel up to the summation order over K (WK partial sums instead of 4).
+#include "common.h"
+#include "gemm_sm.h"
+#include <cstdlib>
+
+namespace {
+
+enum { SM_PACKED = 0, SM_STREAM = 1, SM_ROPE = 2 };
+
+struct SmOp {
+  const char* A; const char* W; char* C;
+  const float* bias; const float* res1; const float* ln_stats; const float* ln_s;
+  float* stats_out; char* c2; char* vt;
+  long gA, gW, gC, gbias, gres, gstats, gs, gso, gc2, gvt;      // byte strides per group (problem) of a grouped launch
+  int N, ntz, ldc, rope_cols, act;
+};
+
+struct SmArgs {
+  SmOp op[2];                       // op[1]: second group of problems of a paired launch (blockIdx.z >= z1)
+  const float* cos; const float* sin; const int* pos;
+  int M, rb_max, z1;
+  int tokens, heads, vt_ld;
+  unsigned tok_magic;               // floor(2^32 / tokens) + 1: gm / tokens by one multiply-high (gm < 65536)
+  float ln_eps;
+};
+
+// grid = (8, mt, nz): linear workgroup id = x + 8 (y + mt z) -> XCD x; tile_m = y; z = group * ntz + zt, tile_n = 8 zt + x
+template <int MF, int NF, int WK, int NKB, int RING, int EPI>
+__global__ __launch_bounds__(64 * WK) void sm_kernel(const SmArgs a) {
+  constexpr int BM = MF * 16, BN = NF * 16, NT = 64 * WK;
+  constexpr int NKW = NKB / WK;                               // k-blocks per wave
+  constexpr int R = (RING == 0 || RING > NKW) ? NKW : RING;   // k-blocks in flight per wave
+  constexpr int LD = BN + 4, CG = BN / 4;
+  constexpr int IT = (BM * CG + NT - 1) / NT;                 // epilogue iterations per thread
+  constexpr int K = NKB * 64;
+  constexpr bool LNOK = (NKB % 4 == 0) && NKB <= 16 && BM * 4 <= NT;   // folded LayerNorm over K = 32 * (2 NKB) columns
+  constexpr int NL4 = LNOK ? NKB / 4 : 1;                     // float4 (= two partials) per thread of a 4-thread row team
+  static_assert(NKB % WK == 0, "k-blocks must divide over the waves");
+  static_assert(NT % CG == 0, "a thread keeps one column group through the epilogue");
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [WK][BM][LD] partial tiles, then rowstat [BM][2]
+  float* rowstat = smem + (size_t)WK * BM * LD;
+
+  const int tid = threadIdx.x, lane = tid & 63, wk = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool second = EPI == SM_ROPE && (int)blockIdx.z >= a.z1;
+#define OPF(f) (second ? a.op[1].f : a.op[0].f)
+  int z = (int)blockIdx.z - (second ? a.z1 : 0);
+  const int ntz = OPF(ntz);
+  const int grp = z >= ntz ? 1 : 0;
+  z -= grp * ntz;
+  const int tile_m = blockIdx.y, tile_n = z * 8 + blockIdx.x;
+  const int N = OPF(N);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  if (n0 >= N) return;
+
+  // ---- epilogue operands first (every vector of a launch is cold): bias / LayerNorm column sums of this thread's columns
+  const int ec4 = (tid % CG) * 4;
+  const int row_e0 = tid / CG;                                // epilogue row of iteration 0; iteration i: + i * NT / CG
+  const float* lnst = OPF(ln_stats);
+  const bool ln = lnst != nullptr;
+  const float* biasp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(OPF(bias)) + grp * OPF(gbias));
+  const float4 b4 = *reinterpret_cast<const float4*>(biasp + n0 + ec4);
+  float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 lp[NL4];
+  if constexpr (LNOK) {
+    if (ln) {
+      s4 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(OPF(ln_s)) + grp * OPF(gs)) + n0 + ec4);
+      const int srow = tid >> 2, sj = tid & 3;
+      if (srow < BM) {
+        int gm = m0 + srow;
+        gm = gm < a.M ? gm : a.M - 1;
+        const float4* ps = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(lnst) + grp * OPF(gstats)) + (long)gm * NKB;
+#pragma unroll
+        for (int q = 0; q < NL4; ++q) lp[q] = ps[sj + 4 * q];
+      }
+    }
+  }
+  float4 pre_r[IT];
+  float4 pre_cs[IT], pre_sn[IT];
+  if constexpr (EPI == SM_STREAM) {
+    const float* res = OPF(res1);
+    if (res) {
+      res = reinterpret_cast<const float*>(reinterpret_cast<const char*>(res) + grp * OPF(gres));
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        int gm = m0 + row_e0 + it * (NT / CG);
+        gm = gm < a.M ? gm : a.M - 1;
+        pre_r[it] = *reinterpret_cast<const float4*>(res + (long)gm * N + n0 + ec4);
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < IT; ++it) pre_r[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  const int rope_cols = EPI == SM_ROPE ? OPF(rope_cols) : 0;
+  if constexpr (EPI == SM_ROPE) {
+    if (n0 < rope_cols) {
+      const int hc = (n0 + ec4) & 63, axis = hc >> 5, i0 = hc & 15;
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        int gm = m0 + row_e0 + it * (NT / CG);
+        gm = gm < a.M ? gm : a.M - 1;
+        const int p = a.pos[(long)gm * 2 + axis];
+        pre_cs[it] = *reinterpret_cast<const float4*>(a.cos + p * 16 + i0);
+        pre_sn[it] = *reinterpret_cast<const float4*>(a.sin + p * 16 + i0);
+      }
+    }
+  }
+
+  // ---- operands: wave wk owns k-blocks wk, wk + WK, ...
+  const char* ap[MF];
+  const char* wp[NF];
+  {
+    const char* A = OPF(A) + grp * OPF(gA);
+    const char* W = OPF(W) + grp * OPF(gW);
+#pragma unroll
+    for (int m = 0; m < MF; ++m) {
+      int rb = tile_m * MF + m;
+      rb = rb < a.rb_max ? rb : a.rb_max;                      // row blocks past M: re-read the last one (masked at the store)
+      ap[m] = A + ((long)rb * NKB + wk) * 2048 + lane * 16;
+    }
+    const int nb_max = (N >> 4) - 1;
+#pragma unroll
+    for (int n = 0; n < NF; ++n) {
+      int nb = tile_n * NF + n;
+      nb = nb < nb_max ? nb : nb_max;
+      wp[n] = W + ((long)nb * NKB + wk) * 2048 + lane * 16;
+    }
+  }
+  bf16x8 av[R][MF][2], wv[R][NF][2];
+  auto load = [&](int slot, int i) {
+#pragma unroll
+    for (int n = 0; n < NF; ++n) {
+      wv[slot][n][0] = *reinterpret_cast<const bf16x8*>(wp[n] + (long)i * WK * 2048);
+      wv[slot][n][1] = *reinterpret_cast<const bf16x8*>(wp[n] + (long)i * WK * 2048 + 1024);
+    }
+#pragma unroll
+    for (int m = 0; m < MF; ++m) {
+      av[slot][m][0] = *reinterpret_cast<const bf16x8*>(ap[m] + (long)i * WK * 2048);
+      av[slot][m][1] = *reinterpret_cast<const bf16x8*>(ap[m] + (long)i * WK * 2048 + 1024);
+    }
+  };
+  f32x4 acc[MF][NF];
+#pragma unroll
+  for (int m = 0; m < MF; ++m)
+#pragma unroll
+    for (int n = 0; n < NF; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < R; ++i) load(i, i);
+#pragma unroll
+  for (int i = 0; i < NKW; ++i) {
+    const int s = i % R;
+#pragma unroll
+    for (int m = 0; m < MF; ++m)
+#pragma unroll
+      for (int n = 0; n < NF; ++n) {
+        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[s][m][0], wv[s][n][0], acc[m][n], 0, 0, 0);
+        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[s][m][1], wv[s][n][1], acc[m][n], 0, 0, 0);
+      }
+    if (i + R < NKW) load(s, i + R);
+  }
+
+  // ---- partial tiles -> LDS (C layout: col = lane & 15, row = 4 (lane >> 4) + reg); folded LayerNorm: mean / rstd of the rows
+  {
+    float* slab = smem + (size_t)wk * BM * LD;
+    const int g = lane >> 4, c = lane & 15;
+#pragma unroll
+    for (int m = 0; m < MF; ++m)
+#pragma unroll
+      for (int n = 0; n < NF; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slab[(m * 16 + 4 * g + r) * LD + n * 16 + c] = acc[m][n][r];
+  }
+  if constexpr (LNOK) {
+    if (ln) {
+      const int srow = tid >> 2;
+      if (srow < BM) {                                         // (teams of 4 lanes never straddle the BM boundary)
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < NL4; ++q) { s1 += lp[q].x + lp[q].z; s2 += lp[q].y + lp[q].w; }
+        s1 += __shfl_xor(s1, 1); s2 += __shfl_xor(s2, 1);
+        s1 += __shfl_xor(s1, 2); s2 += __shfl_xor(s2, 2);
+        if ((tid & 3) == 0) {
+          const float mean = s1 * (1.0f / (float)K);
+          const float var = fmaxf(s2 * (1.0f / (float)K) - mean * mean, 0.f);
+          rowstat[2 * srow] = mean;
+          rowstat[2 * srow + 1] = 1.0f / sqrtf(var + a.ln_eps);
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // sum of the WK partial tiles of (row, 4 columns); y = rstd * acc - rstd * mean * s + bias for a folded LayerNorm
+  auto finish4 = [&](int row, int c4, const float4& bb, const float4& ss, float (&v)[4]) {
+    float4 t = *reinterpret_cast<const float4*>(smem + row * LD + c4);
+#pragma unroll
+    for (int s = 1; s < WK; ++s) {
+      const float4 u = *reinterpret_cast<const float4*>(smem + (size_t)s * BM * LD + row * LD + c4);
+      t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+    }
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    if (LNOK && ln) {
+      const float mean = rowstat[2 * row], rstd = rowstat[2 * row + 1], rm = rstd * mean;
+      v[0] = rstd * v[0] - rm * ss.x; v[1] = rstd * v[1] - rm * ss.y;
+      v[2] = rstd * v[2] - rm * ss.z; v[3] = rstd * v[3] - rm * ss.w;
+    }
+    v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+  };
+
+  if constexpr (EPI == SM_ROPE) {
+    if (n0 >= rope_cols) {
+      // ---- V columns: PV-operand order [(b,h)][key/32][d/16][lane = 16 (key%16 / 4) + d%16][8]: 4 consecutive tokens of one
+      // column per thread are one 8-byte store (tokens % 4 == 0)
+      __bf16* vt = reinterpret_cast<__bf16*>(OPF(vt) + grp * OPF(gvt));
+      const float* lns = reinterpret_cast<const float*>(reinterpret_cast<const char*>(OPF(ln_s)) + grp * OPF(gs));
+      for (int idx = tid; idx < (BM / 4) * BN; idx += NT) {
+        const int rq = idx % (BM / 4), col = idx / (BM / 4);
+        const int gm = m0 + 4 * rq, gn = n0 + col;
+        if (gm >= a.M) continue;
+        const float bias = biasp[gn];
+        const float sn_ = ln ? lns[gn] : 0.f;
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = 4 * rq + i;
+          float x = smem[row * LD + col];
+#pragma unroll
+          for (int s_ = 1; s_ < WK; ++s_) x += smem[(size_t)s_ * BM * LD + row * LD + col];
+          if (LNOK && ln) { const float mean = rowstat[2 * row], rstd = rowstat[2 * row + 1]; x = rstd * x - rstd * mean * sn_; }
+          v[i] = x + bias;
+        }
+        const int vc = gn - rope_cols;
+        const int h = vc >> 6, dd = vc & 63;
+        const int b = (int)__umulhi((unsigned)gm, a.tok_magic), n = gm - b * a.tokens;
+        const int u = n >> 5, kk = n & 31, w16 = kk & 15;
+        const int e = 4 * (kk >> 4), lane_ = (w16 >> 2) * 16 + (dd & 15);
+        const long nU = a.vt_ld >> 5;
+        const long off = ((((long)(b * a.heads + h) * nU + u) * 4 + (dd >> 4)) * 64 + lane_) * 8 + e;
+        bf16x4 ob;
+        ob[0] = (__bf16)v[0]; ob[1] = (__bf16)v[1]; ob[2] = (__bf16)v[2]; ob[3] = (__bf16)v[3];
+        *reinterpret_cast<bf16x4*>(vt + off) = ob;
+      }
+      return;
+    }
+    // ---- q / k columns: bias, RoPE with the partner column (col ^ 16 inside the 64-wide head), fragment-order store with the
+    // rows padded per image to vt_ld tokens.  The partner group's bias / column sums sit 4 lanes away.
+    const float4 pb4 = make_float4(__shfl_xor(b4.x, 4), __shfl_xor(b4.y, 4), __shfl_xor(b4.z, 4), __shfl_xor(b4.w, 4));
+    const float4 ps4 = make_float4(__shfl_xor(s4.x, 4), __shfl_xor(s4.y, 4), __shfl_xor(s4.z, 4), __shfl_xor(s4.w, 4));
+    __bf16* out = reinterpret_cast<__bf16*>(OPF(C) + grp * OPF(gC));
+    const int is_v = (((n0 + ec4) & 63) >> 4) & 1;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int row = row_e0 + it * (NT / CG), gm = m0 + row, gn = n0 + ec4;
+      if (row >= BM || gm >= a.M) continue;
+      float v[4], pv[4];
+      finish4(row, ec4, b4, s4, v);
+      finish4(row, ec4 ^ 16, pb4, ps4, pv);
+      const float cs[4] = {pre_cs[it].x, pre_cs[it].y, pre_cs[it].z, pre_cs[it].w};
+      const float sn[4] = {pre_sn[it].x, pre_sn[it].y, pre_sn[it].z, pre_sn[it].w};
+      bf16x4 ob;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ob[e] = (__bf16)(is_v ? (v[e] * cs[e] + pv[e] * sn[e]) : (v[e] * cs[e] - pv[e] * sn[e]));
+      const int b = (int)__umulhi((unsigned)gm, a.tok_magic), n = gm - b * a.tokens;
+      *reinterpret_cast<bf16x4*>(out + packed_off(b * a.vt_ld + n, gn, rope_cols, true)) = ob;
+    }
+    return;
+  } else if constexpr (EPI == SM_PACKED) {
+    __bf16* out = reinterpret_cast<__bf16*>(OPF(C) + grp * OPF(gC));
+    const bool gelu = OPF(act) == SP3_ACT_GELU;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int row = row_e0 + it * (NT / CG), gm = m0 + row, gn = n0 + ec4;
+      if (row >= BM || gm >= a.M) continue;
+      float v[4];
+      finish4(row, ec4, b4, s4, v);
+      if (gelu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+      }
+      bf16x4 ob;
+      ob[0] = (__bf16)v[0]; ob[1] = (__bf16)v[1]; ob[2] = (__bf16)v[2]; ob[3] = (__bf16)v[3];
+      *reinterpret_cast<bf16x4*>(out + packed_off(gm, gn, N, true)) = ob;
+    }
+  } else {
+    float* out = reinterpret_cast<float*>(OPF(C) + grp * OPF(gC));
+    float* so = OPF(stats_out);
+    __bf16* c2 = reinterpret_cast<__bf16*>(OPF(c2));
+    if (so) so = reinterpret_cast<float*>(reinterpret_cast<char*>(so) + grp * OPF(gso));
+    if (c2) c2 = reinterpret_cast<__bf16*>(reinterpret_cast<char*>(c2) + grp * OPF(gc2));
+    const int ldc = OPF(ldc);
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int row = row_e0 + it * (NT / CG), gm = m0 + row, gn = n0 + ec4;
+      // (the 8 lanes of a 32-column group share a row: they enter or skip together, the shuffles below stay inside the group)
+      if (row >= BM || gm >= a.M) continue;
+      float v[4];
+      finish4(row, ec4, b4, s4, v);
+      v[0] += pre_r[it].x; v[1] += pre_r[it].y; v[2] += pre_r[it].z; v[3] += pre_r[it].w;
+      if (so) {
+        float s1 = (v[0] + v[1]) + (v[2] + v[3]);
+        float s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+#pragma unroll
+        for (int o_ = 1; o_ < 8; o_ <<= 1) { s1 += __shfl_xor(s1, o_); s2 += __shfl_xor(s2, o_); }
+        if (((gn >> 2) & 7) == 0) reinterpret_cast<float2*>(so)[(long)gm * (N >> 5) + (gn >> 5)] = make_float2(s1, s2);
+      }
+      if (c2) {
+        bf16x4 ob;
+        ob[0] = (__bf16)v[0]; ob[1] = (__bf16)v[1]; ob[2] = (__bf16)v[2]; ob[3] = (__bf16)v[3];
+        *reinterpret_cast<bf16x4*>(c2 + packed_off(gm, gn, N, true)) = ob;
+      }
+      *reinterpret_cast<float4*>(out + (long)gm * ldc + gn) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+#undef OPF
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct SmInst {
+  int tile, epi, K, MF, NF, WK;
+  int min_n;                        // N range this instance is the choice for (per problem)
+  int max_n;
+  int (*launch)(const SmArgs&, int mt, int nz, hipStream_t);
+};
+
+template <int MF, int NF, int WK, int NKB, int RING, int EPI>
+int sm_launch(const SmArgs& a, int mt, int nz, hipStream_t stream) {
+  constexpr int BM = MF * 16, BN = NF * 16;
+  constexpr size_t lds = ((size_t)WK * BM * (BN + 4) + 2 * BM) * sizeof(float);
+  static_assert(lds <= 160 * 1024, "partial tiles must fit the LDS");
+  auto kern = sm_kernel<MF, NF, WK, NKB, RING, EPI>;
+  if (lds > 64 * 1024) {
+    static bool raised = false;
+    if (!raised) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) { sp3_set_error("sp3_gemm (lean): cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e)); return 2; }
+      raised = true;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(8, mt, nz), dim3(64 * WK), lds, stream, a);
+  SP3_LAUNCH_CHECK("sp3_gemm (lean)");
+  return 0;
+}
+
+// The instances, chosen per shape from tools/ubench/gemm_sm.hip on MI355X (profiles/r04_gemm_small_m_tile_sweep.txt).
+// tile ids 30.. are what sp3_gemm_desc.tile / the profiles call them.
+const SmInst kInst[] = {
+    // ROPE (q/k/v projections): BN % 32 == 0 (the RoPE partner column lies in the tile)
+    {30, SM_ROPE, 1024, 3, 4, 8, 0, 1 << 30, sm_launch<3, 4, 8, 16, 0, SM_ROPE>},      // val / enc-step qkv: 48x64, K over 8 waves
+    {31, SM_ROPE, 768, 2, 2, 4, 0, 1 << 30, sm_launch<2, 2, 4, 12, 0, SM_ROPE>},       // decoder qkv + ckv pair, cross q: 32x32 k4
+    // PACKED (fc1 + GELU, key MLP hidden)
+    {32, SM_PACKED, 1024, 4, 4, 8, 0, 1 << 30, sm_launch<4, 4, 8, 16, 0, SM_PACKED>},  // val fc1: 64x64 k8
+    {33, SM_PACKED, 768, 2, 2, 4, 0, 1 << 30, sm_launch<2, 2, 4, 12, 0, SM_PACKED>},   // dec fc1 x2: 32x32 k4
+    // STREAM (output projections onto the residual stream)
+    {34, SM_STREAM, 1024, 2, 2, 8, 0, 1 << 30, sm_launch<2, 2, 8, 16, 0, SM_STREAM>},  // val proj, value_out: 32x32 k8
+    {35, SM_STREAM, 4096, 2, 2, 16, 0, 1 << 30, sm_launch<2, 2, 16, 64, 0, SM_STREAM>},   // val fc2: 32x32 k16
+    {36, SM_STREAM, 768, 3, 2, 6, 0, 1 << 30, sm_launch<3, 2, 6, 12, 0, SM_STREAM>},   // dec proj / cproj x2, pos patch embed: 48x32 k6
+    {37, SM_STREAM, 3072, 3, 2, 8, 0, 1 << 30, sm_launch<3, 2, 8, 48, 3, SM_STREAM>},  // dec fc2 x2: 48x32 k8, ring of 3
+    {38, SM_STREAM, 1792, 4, 2, 7, 0, 1 << 30, sm_launch<4, 2, 7, 28, 0, SM_STREAM>},  // key MLP out x2: 64x32 k7
+};
+
+bool sm_enabled() {
+  static const bool on = [] { const char* e = getenv("SP3_LEAN_GEMM"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
+int sm_kind(const sp3_gemm_desc& d) {
+  if (d.epi == SP3_EPI_ROPE_VT) return SM_ROPE;
+  if (d.out_packed) return SM_PACKED;
+  return SM_STREAM;
+}
+
+const SmInst* sm_find(const sp3_gemm_desc& d) {
+  if (!sm_enabled()) return nullptr;
+  if (d.wdtype != SP3_BF16 || !d.a_bf16 || !d.a_packed || !d.w_packed || d.loader != SP3_LOAD_PLAIN || d.A2 || d.res2 || d.relu_in ||
+      d.trace || d.sm_stats_out || d.sm_stats || d.alpha != 1.0f || d.f32x3)
+    return nullptr;
+  if (d.splitk > 1 || d.epi == SP3_EPI_PARTIAL || d.epi == SP3_EPI_PIXSHUF) return nullptr;
+  if (d.batch > 2 || d.M > 256 || d.M < 1 || (d.ldw > 0 && d.ldw != d.K) || !d.bias) return nullptr;
+  const int kind = sm_kind(d);
+  if (kind == SM_ROPE) {
+    if (!d.qkv_packed || d.rope_cols % 64 || d.N % 64 || (d.tokens & 3) || d.tokens <= 0 || d.tokens >= 65536 || d.vt_ld % 64) return nullptr;
+    if (d.rope_cols < d.N && !d.vt) return nullptr;
+  } else if (kind == SM_PACKED) {
+    if (!d.out_bf16 || d.res1 || d.stats_out || d.c2 || d.act == SP3_ACT_RELU) return nullptr;
+  } else {
+    if (d.out_bf16 || d.out_packed || d.act != SP3_ACT_NONE || (d.ldc & 3) || d.ldc < d.N) return nullptr;
+    if (d.res1 && d.ldr1 != d.N) return nullptr;
+    if ((d.stats_out || d.c2) && d.N % 32) return nullptr;
+  }
+  if (d.ln_stats && (d.ln_C != d.K || d.K > 1024 || (d.K / 64) % 4)) return nullptr;
+  for (const SmInst& s : kInst) {
+    if (s.epi != kind || s.K != d.K) continue;
+    if (d.N % (s.NF * 16) || d.N < s.min_n || d.N > s.max_n) continue;
+    if (d.ln_stats && s.MF * 16 * 4 > 64 * s.WK) continue;
+    return &s;
+  }
+  return nullptr;
+}
+
+void sm_fill(SmOp& o, const sp3_gemm_desc& d, const SmInst& s) {
+  const long G = d.batch > 1 ? 1 : 0;
+  o.A = reinterpret_cast<const char*>(d.A);
+  o.W = reinterpret_cast<const char*>(d.W);
+  o.C = reinterpret_cast<char*>(d.C);
+  o.bias = d.bias; o.res1 = d.res1; o.ln_stats = d.ln_stats; o.ln_s = d.ln_s;
+  o.stats_out = d.stats_out; o.c2 = reinterpret_cast<char*>(d.c2); o.vt = reinterpret_cast<char*>(d.vt);
+  o.gA = G * d.strideA * 2; o.gW = G * d.strideW * 2;
+  o.gC = G * d.strideC * (s.epi == SM_STREAM ? 4 : 2);
+  o.gbias = G * d.sb_bias; o.gres = G * (long)d.M * d.ldr1 * 4; o.gstats = G * d.sb_ln_stats; o.gs = G * d.sb_ln_s;
+  o.gso = G * d.sb_stats_out; o.gc2 = G * d.sb_c2; o.gvt = G * d.sb_vt;
+  o.N = d.N;
+  o.ntz = (d.N / (s.NF * 16) + 7) / 8;
+  o.ldc = (int)d.ldc;
+  o.rope_cols = d.rope_cols;
+  o.act = d.act;
+}
+
+}  // namespace
+
+int sp3_gemm_sm_tile(const sp3_gemm_desc& d) {
+  const SmInst* s = sm_find(d);
+  return s ? s->tile : -1;
+}
+
+int sp3_gemm_sm_launch(const sp3_gemm_desc& d, const sp3_gemm_desc* pair, hipStream_t stream) {
+  const SmInst* s = sm_find(d);
+  if (!s || (d.tile >= 30 && d.tile != s->tile)) {
+    sp3_set_error("sp3_gemm: no lean small-M instance for this descriptor (tile %d, M=%d N=%d K=%d epi=%d)", d.tile, d.M, d.N, d.K, d.epi);
+    return 1;
+  }
+  SmArgs a;
+  sm_fill(a.op[0], d, *s);
+  a.op[1] = a.op[0];
+  const int G0 = d.batch > 1 ? d.batch : 1;
+  int nz = a.op[0].ntz * G0;
+  a.z1 = nz;
+  if (pair) {
+    const SmInst* s2 = sm_find(*pair);
+    if (s2 != s || pair->M != d.M || pair->tokens != d.tokens || pair->heads != d.heads || pair->vt_ld != d.vt_ld || pair->pos != d.pos ||
+        pair->rope_cos != d.rope_cos || pair->rope_sin != d.rope_sin || pair->ln_eps != d.ln_eps || s->epi != SM_ROPE) {
+      sp3_set_error("sp3_gemm2: the two groups do not share a lean instance");
+      return 1;
+    }
+    sm_fill(a.op[1], *pair, *s);
+    nz += a.op[1].ntz * (pair->batch > 1 ? pair->batch : 1);
+  }
+  a.cos = d.rope_cos; a.sin = d.rope_sin; a.pos = d.pos;
+  a.M = d.M;
+  a.rb_max = (d.M + 15) / 16 - 1;
+  a.tokens = d.tokens > 0 ? d.tokens : 1;
+  a.heads = d.heads;
+  a.vt_ld = (int)d.vt_ld;
+  a.tok_magic = (unsigned)((1ull << 32) / (unsigned)a.tokens + 1);
+  a.ln_eps = d.ln_eps;
+  const int mt = (d.M + s->MF * 16 - 1) / (s->MF * 16);
+  return s->launch(a, mt, nz, stream);
+}

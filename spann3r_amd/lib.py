@@ -93,6 +93,7 @@ _lib = None
 _PROTOS = {
     "sp3_gemm": [C.POINTER(GemmDesc), C.c_void_p],
     "sp3_gemm2": [C.POINTER(GemmDesc), C.POINTER(GemmDesc), C.c_void_p],
+    "sp3_gemm_plan": [C.POINTER(GemmDesc)],
     "sp3_layernorm": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_int,
                       C.c_int, C.c_int, C.c_void_p],
     "sp3_reduce_ln": [C.POINTER(ReduceLnDesc), C.c_void_p],

@@ -104,7 +104,11 @@ def set_profiler(p):
 _TILE_NAMES = {0: "32x32xk4", 1: "64x64", 2: "64x128", 3: "64x64xk4", 4: "32x64xk4", 18: "16x64xk4", 5: "128x128lds", 6: "128x64lds", 7: "112x64lds",
                8: "208x64lds", 9: "112x32lds", 10: "112x64lds2w", 11: "112x64lds8w", 12: "208x64lds8w", 13: "112x64wreg8",
                14: "112x64wreg4", 15: "208x64wreg8", 16: "112x64wreg4l6", 17: "112x64wreg8l4",
-               20: "256x128pipe", 21: "128x128pipe", 22: "128x64pipe", 23: "64x64pipe", 24: "64x32pipe", 25: "32x32pipe"}
+               20: "256x128pipe", 21: "128x128pipe", 22: "128x64pipe", 23: "64x64pipe", 24: "64x32pipe", 25: "32x32pipe",
+               # lean small-M instances (csrc/gemm_sm.hip): epilogue, K, tile, waves over K
+               30: "lean-rope-k1024-48x64xk8", 31: "lean-rope-k768-32x32xk4", 32: "lean-packed-k1024-64x64xk8", 33: "lean-packed-k768-32x32xk4",
+               34: "lean-stream-k1024-32x32xk8", 35: "lean-stream-k4096-32x32xk16", 36: "lean-stream-k768-48x32xk6",
+               37: "lean-stream-k3072-48x32xk8", 38: "lean-stream-k1792-64x32xk7"}
 
 
 def pick_tile(M, N, batch=1, splitk=1, conv=False, K=0, packed_bf16=False, plain=False, ln_nt=0, pipe_ok=False, rope=False):
@@ -161,8 +165,12 @@ class pair:
         if len(descs) != 2:
             raise RuntimeError("ops.pair(): expected exactly two GEMM launches, got %d" % len(descs))
         (a, na), (b, _) = descs
+        if a.tile < 0 and b.tile < 0:
+            ta, tb = L.load().sp3_gemm_plan(C.byref(a)), L.load().sp3_gemm_plan(C.byref(b))
+            if ta >= 30 and ta == tb:               # both groups on one lean instance
+                a.tile = b.tile = ta
         if a.tile < 0:
-            _pick(a)
+            _pick_general(a)                        # (a lean instance for one group only: both take the general tiles)
         if b.tile < 0:
             b.tile = a.tile
         if _prof is None:
@@ -183,11 +191,19 @@ def _pipe_ok(d):
                 and (max(d.splitk, 1) == 1 or d.epi == L.EPI_PARTIAL))
 
 
-def _pick(d):
+def _pick_general(d):
     d.tile = pick_tile(d.M, d.N, max(d.batch, 1), max(d.splitk, 1), d.loader == L.LOAD_CONV3X3, d.K,
                        bool(d.a_packed and d.w_packed and d.a_bf16 and not d.A2 and d.epi != L.EPI_PARTIAL
                             and not d.sm_stats_out),
                        d.epi == L.EPI_PLAIN, d.ln_nt if d.ln_stats else 0, _pipe_ok(d), d.epi == L.EPI_ROPE_VT)
+
+
+def _pick(d):
+    t = L.load().sp3_gemm_plan(C.byref(d))          # the lean small-M instances (tiles 30..) are chosen by the library
+    if t >= 30:
+        d.tile = t
+        return
+    _pick_general(d)
 
 
 def _gemm_cost(d):

@@ -1,0 +1,235 @@
+"""The lean small-M GEMM instances (csrc/gemm_sm.hip, tiles 30..): every epilogue against float64 formulas on the rounded
+operands AND against the general kernel (tile 0) on the same descriptor -- the per-frame step's Linears
+(croco/models/blocks.py:73-79,94-112,149-169) must not change when the dispatcher moves them to the lean family."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+def _ops():
+    from spann3r_amd import ops
+    return ops
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def bf(t):
+    return t.to(BF).float()
+
+
+def _dense(ops, pa, g, M, K):
+    """problem g of a PackedAct.group as a dense [M, K] tensor"""
+    shape = ops.packed_shape(M, K, BF)
+    n = 1
+    for v in shape:
+        n *= v
+    return ops.PackedAct(M, K, BF, DEV, data=pa.data.view(-1)[g * pa.stride: g * pa.stride + n].view(shape)).to_dense()
+
+
+def _plan_of(ops, fn):
+    """runs fn() (which issues exactly one GEMM) with a hook that records the tile the library planned"""
+    seen = []
+    orig = ops._gemm_launch
+
+    def spy(d, what, name):
+        from spann3r_amd import lib as L
+        seen.append(L.load().sp3_gemm_plan(C.byref(d)) if d.tile < 0 else d.tile)
+        return orig(d, what, name)
+    ops._gemm_launch = spy
+    try:
+        fn()
+    finally:
+        ops._gemm_launch = orig
+    return seen
+
+
+@pytest.mark.parametrize("M,N,K,G,res,stats,ln", [
+    (196, 1024, 1024, 1, True, True, False),      # val proj                        -> tile 34
+    (196, 1024, 1024, 1, True, False, True),      # value_out: folded LayerNorm      -> tile 34
+    (196, 1024, 4096, 1, True, True, False),      # val fc2                          -> tile 35
+    (196, 768, 768, 2, True, True, False),        # decoder proj / cproj, both sides -> tile 36
+    (196, 1024, 768, 1, False, True, False),      # pos patch embed                  -> tile 36
+    (196, 768, 3072, 2, True, True, False),       # decoder fc2                      -> tile 37
+    (196, 1024, 1792, 2, False, True, False),     # key MLP out                      -> tile 38
+    (100, 768, 768, 1, True, True, False),        # ragged M
+    (256, 1024, 1024, 1, True, True, False),
+])
+def test_lean_stream(M, N, K, G, res, stats, ln):
+    ops = _ops()
+    A = ops.PackedAct.group(G, M, K, BF, DEV)
+    Ad = [rnd(M, K, seed=1 + g) for g in range(G)]
+    for g in range(G):
+        A.at(g).data.view(-1)[:A.stride].copy_(ops.PackedAct.from_dense(Ad[g].to(DEV).to(BF)).data.view(-1))
+    Wd = [rnd(N, K, seed=10 + g) * 0.05 for g in range(G)]
+    gam, beta = rnd(K, seed=31) * 0.3 + 1, rnd(K, seed=32) * 0.2
+    if ln:
+        Wd = [w * gam[None, :] for w in Wd]
+    Ws = ops.PackedWeightGroup([ops.PackedWeight(w.to(DEV).to(BF)) for w in Wd])
+    bias = rnd(G, N, seed=5)
+    R = rnd(G, M, N, seed=6) * 2 + 0.3
+    lnf = None
+    if ln:
+        # statistics partials of the (fp32) rows whose bf16 copy is A
+        xs = torch.stack(Ad)
+        st = torch.stack((xs.reshape(G, M, K // 32, 32).sum(-1), (xs * xs).reshape(G, M, K // 32, 32).sum(-1)), -1).contiguous().to(DEV)
+        s_n = torch.stack([bf(w).sum(1) for w in Wd]).contiguous().to(DEV)
+        lnf = ops.LnFold(st, K, s_n, 1e-6, sb_stats=M * (K // 32) * 8, sb_s=N * 4)
+    outs = {}
+    for tile in (-1, 0):
+        out = torch.full((G, M, N), float("nan"), device=DEV)
+        so = torch.full((G, M, N // 32, 2), float("nan"), device=DEV) if stats else None
+        c2 = ops.PackedAct.group(G, M, N, BF, DEV) if stats else None
+        kw = dict(M=M, N=N, K=K, lda=K, ldc=N, bias=bias.to(DEV), res1=R.to(DEV) if res else None, ldr1=N if res else 0,
+                  stats_out=so, c2=c2, ln=lnf, tile=tile)
+        sb = {"bias": N * 4}
+        if stats:
+            sb["stats_out"], sb["c2"] = M * (N // 32) * 8, c2.stride * 2
+        if G > 1:
+            kw.update(batch=G, strideA=A.stride, strideW=Ws.stride, strideC=M * N, sb=sb)
+        planned = _plan_of(ops, lambda: ops.gemm(A, Ws, out, **kw))
+        assert (planned[0] >= 30) == (tile < 0), planned
+        outs[tile] = (out, so, c2)
+    out, so, c2 = outs[-1]
+    for g in range(G):
+        x = bf(Ad[g]).double()
+        if ln:
+            xf = Ad[g].double()
+            mu, var = xf.mean(1, keepdim=True), xf.var(1, unbiased=False, keepdim=True)
+            # what the fold computes: rstd * (x_bf16 . W'^T) - rstd * mu * s + b
+            ref = (x @ bf(Wd[g]).double().T) / torch.sqrt(var + 1e-6) - (mu / torch.sqrt(var + 1e-6)) * bf(Wd[g]).double().sum(1)[None] + bias[g].double()
+        else:
+            ref = x @ bf(Wd[g]).double().T + bias[g].double()
+        if res:
+            ref = ref + R[g].double()
+        assert rel_err(out[g].cpu(), ref) < 2e-5, (g, rel_err(out[g].cpu(), ref))
+        assert rel_err(out[g].cpu(), outs[0][0][g].cpu()) < 2e-5            # the general kernel: summation order only
+        if stats:
+            assert torch.equal(_dense(ops, c2, g, M, N), out[g].to(BF))
+            st = so[g].cpu().double()
+            xr = out[g].cpu().double()
+            assert rel_err(st[..., 0], xr.reshape(M, N // 32, 32).sum(-1)) < 1e-5
+            assert rel_err(st[..., 1], (xr * xr).reshape(M, N // 32, 32).sum(-1)) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K,G,act", [(196, 4096, 1024, 1, "gelu"), (196, 3072, 768, 2, "gelu"), (196, 3072, 768, 1, "none"), (60, 4096, 1024, 1, "gelu")])
+def test_lean_packed_fc1(M, N, K, G, act):
+    """norm (folded) + fc1 + GELU into fragment order (croco/models/blocks.py:74-75,129)"""
+    ops = _ops()
+    A = ops.PackedAct.group(G, M, K, BF, DEV)
+    Ad = [rnd(M, K, seed=1 + g) * 2 + 0.1 for g in range(G)]
+    for g in range(G):
+        A.at(g).data.view(-1)[:A.stride].copy_(ops.PackedAct.from_dense(Ad[g].to(DEV).to(BF)).data.view(-1))
+    gam = rnd(K, seed=31) * 0.3 + 1
+    Wd = [rnd(N, K, seed=10 + g) * 0.05 * gam[None, :] for g in range(G)]
+    Ws = ops.PackedWeightGroup([ops.PackedWeight(w.to(DEV).to(BF)) for w in Wd])
+    bias = rnd(G, N, seed=5)
+    xs = torch.stack(Ad)
+    st = torch.stack((xs.reshape(G, M, K // 32, 32).sum(-1), (xs * xs).reshape(G, M, K // 32, 32).sum(-1)), -1).contiguous().to(DEV)
+    s_n = torch.stack([bf(w).sum(1) for w in Wd]).contiguous().to(DEV)
+    lnf = ops.LnFold(st, K, s_n, 1e-6, sb_stats=M * (K // 32) * 8, sb_s=N * 4)
+    outs = {}
+    for tile in (-1, 0):
+        h = ops.PackedAct.group(G, M, N, BF, DEV)
+        kw = dict(M=M, N=N, K=K, lda=K, ldc=N, bias=bias.to(DEV), act=ops.ACT_GELU if act == "gelu" else ops.ACT_NONE, ln=lnf, tile=tile)
+        if G > 1:
+            kw.update(batch=G, strideA=A.stride, strideW=Ws.stride, strideC=h.stride, sb={"bias": N * 4})
+        planned = _plan_of(ops, lambda: ops.gemm(A, Ws, h, **kw))
+        assert (planned[0] >= 30) == (tile < 0), planned
+        outs[tile] = h
+    for g in range(G):
+        xf = Ad[g].double()
+        mu, var = xf.mean(1, keepdim=True), xf.var(1, unbiased=False, keepdim=True)
+        rstd = 1.0 / torch.sqrt(var + 1e-6)
+        ref = rstd * (bf(Ad[g]).double() @ bf(Wd[g]).double().T) - rstd * mu * bf(Wd[g]).double().sum(1)[None] + bias[g].double()
+        if act == "gelu":
+            ref = F.gelu(ref)
+        got, old = _dense(ops, outs[-1], g, M, N).float().cpu(), _dense(ops, outs[0], g, M, N).float().cpu()
+        assert rel_err(got, ref) < 4e-3                       # bf16 output rounding
+        assert rel_err(got, old) < 8e-3 and float((got != old).float().mean()) < 0.02      # same values up to a rare last-bit flip
+
+
+def _pos(B, nh, nw):
+    ys, xs = torch.meshgrid(torch.arange(nh), torch.arange(nw), indexing="ij")
+    return torch.stack((ys.reshape(-1), xs.reshape(-1)), -1)[None].expand(B, -1, -1).contiguous()
+
+
+@pytest.mark.parametrize("B,nh,nw,C,heads,kind", [(1, 14, 14, 1024, 16, "qkv"), (1, 14, 14, 768, 12, "qkv"), (1, 14, 14, 768, 12, "q"),
+                                                   (2, 10, 10, 768, 12, "qkv"), (2, 8, 12, 1024, 16, "kv")])
+def test_lean_rope_vt(B, nh, nw, C, heads, kind):
+    """q/k/v projection with folded LayerNorm, bias, 2-D RoPE and the attention kernel's layouts: lean instance vs general kernel"""
+    from spann3r_amd.engine import _rope_tables
+    ops = _ops()
+    P = nh * nw
+    R, npad = B * P, (P + 63) // 64 * 64
+    N = {"qkv": 3 * C, "kv": 2 * C, "q": C}[kind]
+    rope_cols = {"qkv": 2 * C, "kv": C, "q": C}[kind]
+    x = rnd(R, C, seed=1) * 2 + 0.2
+    gam = rnd(C, seed=31) * 0.3 + 1
+    W, b = rnd(N, C, seed=2) * 0.05 * gam[None, :], rnd(N, seed=3)
+    A = ops.PackedAct.from_dense(x.to(DEV).to(BF))
+    Wp = ops.PackedWeight(W.to(DEV).to(BF))
+    st = torch.stack((x.reshape(R, C // 32, 32).sum(-1), (x * x).reshape(R, C // 32, 32).sum(-1)), -1).contiguous().to(DEV)
+    lnf = ops.LnFold(st, C, bf(W).sum(1).to(DEV), 1e-6)
+    pos = _pos(B, nh, nw).reshape(-1, 2).to(torch.int32).to(DEV)
+    cos, sin = _rope_tables(64, 100.0, DEV)
+    outs = {}
+    for tile in (-1, 0):
+        qkp = ops.PackedAct(B * npad, rope_cols, BF, DEV)
+        vtp = torch.zeros(B * heads * npad * 64, device=DEV, dtype=BF) if kind != "q" else None
+        planned = _plan_of(ops, lambda: ops.proj_rope_vt(A, Wp, b.to(DEV), qkp.data, 0, vtp, npad, M=R, N=N, K=C, lda=C, rope_cols=rope_cols,
+                                                         pos=pos, cos=cos, sin=sin, tokens=P, heads=heads, qkv_packed=True, ln=lnf, tile=tile))
+        assert (planned[0] >= 30) == (tile < 0), planned
+        outs[tile] = (qkp.to_dense().float().cpu(), None if vtp is None else vtp.float().cpu())
+    (q1, v1), (q0, v0) = outs[-1], outs[0]
+    assert float(q1.abs().max()) > 0.1
+    assert rel_err(q1, q0) < 8e-3 and float((q1 != q0).float().mean()) < 0.02
+    pad = q1.reshape(B, npad, rope_cols)[:, P:]
+    assert float(pad.abs().max()) == 0.0
+    if v1 is not None:
+        assert float(v1.abs().max()) > 0.1
+        assert rel_err(v1, v0) < 8e-3 and float((v1 != v0).float().mean()) < 0.02
+
+
+def test_lean_pair_equals_two_launches():
+    """sp3_gemm2 on a lean instance (a decoder layer's q/k/v + cross k/v projections, both sides): bit-identical to the two launches"""
+    from spann3r_amd.engine import _rope_tables
+    ops = _ops()
+    M, K, heads, P, npad, B = 196, 768, 12, 196, 256, 1
+    A = ops.PackedAct.group(2, M, K, BF, DEV)
+    A.data.copy_(rnd(*A.data.shape, seed=1).to(DEV).to(BF))
+    pos = _pos(1, 14, 14).reshape(-1, 2).to(torch.int32).to(DEV)
+    cos, sin = _rope_tables(64, 100.0, DEV)
+    st = (rnd(2, M, K // 32, 2, seed=4).abs() * 30 + 40).to(DEV)
+    st[..., 0] *= 0.05
+    res = {}
+    for mode in ("two", "pair"):
+        outs = []
+        ctx = ops.pair() if mode == "pair" else None
+        if ctx:
+            ctx.__enter__()
+        for j, (N, rc) in enumerate(((3 * K, 2 * K), (2 * K, K))):
+            Ws = ops.PackedWeightGroup([ops.PackedWeight((rnd(N, K, seed=10 * j + z) * 0.05).to(DEV).to(BF)) for z in range(2)])
+            bias, s_n = rnd(2, N, seed=5 + j).to(DEV), rnd(2, N, seed=7 + j).to(DEV)
+            qk = torch.zeros(ops.packed_shape(2 * B * npad, rc, BF), device=DEV, dtype=BF)
+            vt = torch.zeros(2 * B * heads * npad * 64, device=DEV, dtype=BF)
+            ops.proj_rope_vt(A, Ws, bias, qk, 0, vt, npad, M=M, N=N, K=K, lda=K, rope_cols=rc, pos=pos, cos=cos, sin=sin, tokens=P,
+                             heads=heads, qkv_packed=True, batch=2, strideA=A.stride, strideW=Ws.stride, strideC=B * npad * rc,
+                             ln=ops.LnFold(st, K, s_n, 1e-6, sb_stats=M * (K // 32) * 8, sb_s=N * 4),
+                             sb={"bias": N * 4, "vt": B * heads * npad * 64 * 2})
+            outs += [qk, vt]
+        if ctx:
+            ctx.__exit__(None, None, None)
+        res[mode] = outs
+    for a, b in zip(res["two"], res["pair"]):
+        assert torch.equal(a, b) and float(a.float().abs().max()) > 0

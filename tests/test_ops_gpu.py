@@ -781,8 +781,9 @@ def test_paired_launch_equals_two_launches(dt):
             Ws = ops.PackedWeightGroup([ops.PackedWeight((rnd(N, K, seed=10 * j + z) * 0.05).to(DEV).to(dt)) for z in range(2)])
             bias = rnd(2, N, seed=5 + j).to(DEV)
             out = torch.zeros(2, M, N, device=DEV)
+            # (tile 0: the general kernel in both modes -- the lean instances' pairing is tests/test_gemm_lean_gpu.py)
             ops.gemm(A, Ws, out, M=M, N=N, K=K, lda=K, ldc=N, bias=bias, batch=2, strideA=A.stride, strideW=Ws.stride,
-                     strideC=M * N, sb={"bias": N * 4}, act=ops.ACT_GELU if j else ops.ACT_NONE)
+                     strideC=M * N, sb={"bias": N * 4}, act=ops.ACT_GELU if j else ops.ACT_NONE, tile=0)
             res.append(out)
         if ctx:
             ctx.__exit__(None, None, None)
