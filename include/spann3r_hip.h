@@ -158,7 +158,9 @@ int sp3_gemm2(const sp3_gemm_desc* a, const sp3_gemm_desc* b, void* stream);
  * compile time -- 30 / 31: q/k/v projections (K = 1024 / 768, ROPE_VT epilogue with qkv_packed), 32 / 33: fc1 + GELU into
  * fragment order (K = 1024 / 768), 34..38: output projections onto the fp32 residual stream (K = 1024, 4096, 768, 3072, 1792).
  * They serve M <= 256, batch <= 2, bias set, alpha = 1, no split-K / second residual / split A; anything else runs on the general
- * tiles above.  SP3_LEAN_GEMM=0 in the environment switches them off (A/B runs). */
+ * tiles above.  40 / 41: loader CONV3X3 on maps of <= 256 / <= 1024 output pixels (fp32 NHWC map, bf16 fragment-order weights,
+ * K = 9 Cin a multiple of 64, fp32 output, plain epilogue with bias / ReLU / two residuals): the DPT heads' small-map convolutions
+ * (croco/models/dpt_block.py:33-75,95-113) in ONE launch instead of split-K partials + sp3_reduce_ln.  SP3_LEAN_GEMM=0 in the environment switches them off (A/B runs). */
 int sp3_gemm_plan(const sp3_gemm_desc* desc_host);
 
 /* ------------------------------------------------------------------------------------------

@@ -333,6 +333,184 @@ __global__ __launch_bounds__(64 * WK) void sm_kernel(const SmArgs a) {
 #undef OPF
 }
 
+// ------------------------------------------------------------------------------------------------ small-map 3x3 convolutions
+// The DPT heads' 3x3 convolutions on maps of <= 1024 pixels (croco/models/dpt_block.py:33-75,95-113: layer_rn, the
+// ResidualConvUnits of refinenet 2-4, act_postprocess[3] at 7x7 .. 28x28 of a 224x224 frame): M = pixels is tiny, K = 9 Cin is
+// long (2304 .. 6912), N = 256 / 768.  The general kernel ran them as split-K x 4-8 over 32x32 tiles plus a reduce launch
+// (7.7 + 4.7 us at 14x14); here a workgroup owns a SMALL output tile (16x16: 208 workgroups at 196 pixels), splits K over its 12
+// waves, gathers the im2col rows straight from the fp32 NHWC map (ReLU + bf16 rounding on the way into the MFMA, exactly the
+// general loader's arithmetic) and finishes bias / ReLU / both residuals itself: one launch, no partial sums in memory.
+struct ConvSmArgs {
+  const float* x; const char* W; float* out;
+  const float* bias; const float* res1; const float* res2;
+  int M, N, H, Wd, Cin, OH, OW, stride, nkb, relu_in, act;
+  unsigned cin_magic, per_magic, ow_magic;        // floor(2^32 / d) + 1: n / d by one multiply-high (n < 65536)
+};
+
+template <int MF, int NF, int WK, int R>
+__global__ __launch_bounds__(64 * WK) void conv_sm_kernel(const ConvSmArgs a) {
+  constexpr int BM = MF * 16, BN = NF * 16, NT = 64 * WK, LD = BN + 4, CG = BN / 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wk = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile_m = blockIdx.y, tile_n = blockIdx.z * 8 + blockIdx.x;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  if (n0 >= a.N) return;
+  const int g = lane >> 4, r16 = lane & 15;
+
+  // epilogue operands of this thread's (row, 4 columns) first
+  const int ec4 = (tid % CG) * 4, erow = tid / CG;
+  const bool eact = erow < BM && (m0 + erow) < a.M;
+  float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = b4, r2 = b4;
+  if (eact) {
+    const long o = (long)(m0 + erow) * a.N + n0 + ec4;
+    if (a.bias) b4 = *reinterpret_cast<const float4*>(a.bias + n0 + ec4);
+    if (a.res1) r1 = *reinterpret_cast<const float4*>(a.res1 + o);
+    if (a.res2) r2 = *reinterpret_cast<const float4*>(a.res2 + o);
+  }
+
+  // this lane's output pixels (one per row block)
+  const float* img[MF];
+  int iy0[MF], ix0[MF];
+#pragma unroll
+  for (int m = 0; m < MF; ++m) {
+    int r = m0 + m * 16 + r16;
+    r = r < a.M ? r : a.M - 1;
+    const int per = a.OH * a.OW;
+    const int b = (int)__umulhi((unsigned)r, a.per_magic);
+    const int rem = r - b * per;
+    const int oy = (int)__umulhi((unsigned)rem, a.ow_magic), ox = rem - oy * a.OW;
+    img[m] = a.x + (long)b * a.H * a.Wd * a.Cin;
+    iy0[m] = oy * a.stride - 1;
+    ix0[m] = ox * a.stride - 1;
+  }
+  const char* wp[NF];
+#pragma unroll
+  for (int n = 0; n < NF; ++n) wp[n] = a.W + ((long)(tile_n * NF + n) * a.nkb) * 2048 + lane * 16;
+
+  float4 av[R][MF][4];
+  bf16x8 wv[R][NF][2];
+  unsigned am[R][MF];
+  auto load = [&](int slot, int kb) {
+#pragma unroll
+    for (int n = 0; n < NF; ++n) {
+      wv[slot][n][0] = *reinterpret_cast<const bf16x8*>(wp[n] + (long)kb * 2048);
+      wv[slot][n][1] = *reinterpret_cast<const bf16x8*>(wp[n] + (long)kb * 2048 + 1024);
+    }
+    const int k0 = kb * 64 + g * 16;
+    const int tap = (int)__umulhi((unsigned)k0, a.cin_magic), ci = k0 - tap * a.Cin;
+    const int dy = (tap * 11) >> 5, dx = tap - 3 * dy;
+#pragma unroll
+    for (int m = 0; m < MF; ++m) {
+      const int iy = iy0[m] + dy, ix = ix0[m] + dx;
+      const bool inb = iy >= 0 && iy < a.H && ix >= 0 && ix < a.Wd;
+      const float4* p = reinterpret_cast<const float4*>(inb ? img[m] + ((long)iy * a.Wd + ix) * a.Cin + ci : a.x);
+      am[slot][m] = inb ? 0xffffffffu : 0u;                 // unconditional load, masked at consume time (zero padding)
+      av[slot][m][0] = p[0]; av[slot][m][1] = p[1]; av[slot][m][2] = p[2]; av[slot][m][3] = p[3];
+    }
+  };
+  f32x4 acc[MF][NF];
+#pragma unroll
+  for (int m = 0; m < MF; ++m)
+#pragma unroll
+    for (int n = 0; n < NF; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nkw = (a.nkb - wk + WK - 1) / WK;              // k-blocks of this wave: wk, wk + WK, ...
+#pragma unroll
+  for (int i = 0; i < R; ++i)
+    if (i < nkw) load(i, wk + i * WK);
+  const bool relu = a.relu_in != 0;
+  for (int i0 = 0; i0 < nkw; i0 += R) {
+#pragma unroll
+    for (int s = 0; s < R; ++s) {
+      const int i = i0 + s;
+      if (i < nkw) {
+        bf16x8 ab[MF][2];
+#pragma unroll
+        for (int m = 0; m < MF; ++m) {
+          float4 v[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            v[q].x = __uint_as_float(__float_as_uint(av[s][m][q].x) & am[s][m]);
+            v[q].y = __uint_as_float(__float_as_uint(av[s][m][q].y) & am[s][m]);
+            v[q].z = __uint_as_float(__float_as_uint(av[s][m][q].z) & am[s][m]);
+            v[q].w = __uint_as_float(__float_as_uint(av[s][m][q].w) & am[s][m]);
+            if (relu) v[q] = relu4(v[q]);
+          }
+          ab[m][0] = cvt8(v[0], v[1]);
+          ab[m][1] = cvt8(v[2], v[3]);
+        }
+#pragma unroll
+        for (int m = 0; m < MF; ++m)
+#pragma unroll
+          for (int n = 0; n < NF; ++n) {
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[m][0], wv[s][n][0], acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[m][1], wv[s][n][1], acc[m][n], 0, 0, 0);
+          }
+        if (i + R < nkw) load(s, wk + (i + R) * WK);
+      }
+    }
+  }
+  {
+    float* slab = smem + (size_t)wk * BM * LD;
+#pragma unroll
+    for (int m = 0; m < MF; ++m)
+#pragma unroll
+      for (int n = 0; n < NF; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slab[(m * 16 + 4 * g + r) * LD + n * 16 + r16] = acc[m][n][r];
+  }
+  __syncthreads();
+  static_assert(BM * CG <= NT, "one epilogue item per thread");
+  if (eact) {
+    float4 t = *reinterpret_cast<const float4*>(smem + erow * LD + ec4);
+#pragma unroll
+    for (int s = 1; s < WK; ++s) {
+      const float4 u = *reinterpret_cast<const float4*>(smem + (size_t)s * BM * LD + erow * LD + ec4);
+      t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+    }
+    float v[4] = {t.x + b4.x, t.y + b4.y, t.z + b4.z, t.w + b4.w};
+    if (a.act == SP3_ACT_RELU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    v[0] += r1.x + r2.x; v[1] += r1.y + r2.y; v[2] += r1.z + r2.z; v[3] += r1.w + r2.w;
+    *reinterpret_cast<float4*>(a.out + (long)(m0 + erow) * a.N + n0 + ec4) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+template <int MF, int NF, int WK, int R>
+int conv_sm_launch(const ConvSmArgs& a, hipStream_t stream) {
+  constexpr int BM = MF * 16, BN = NF * 16;
+  constexpr size_t lds = (size_t)WK * BM * (BN + 4) * sizeof(float);
+  static_assert(lds <= 64 * 1024, "partial tiles: default dynamic LDS limit");
+  const int mt = (a.M + BM - 1) / BM, ntz = (a.N / BN + 7) / 8;
+  hipLaunchKernelGGL((conv_sm_kernel<MF, NF, WK, R>), dim3(8, mt, ntz), dim3(64 * WK), lds, stream, a);
+  SP3_LAUNCH_CHECK("sp3_gemm (lean conv3x3)");
+  return 0;
+}
+
+// tile 40: 16x16 outputs per workgroup, K over 12 waves (maps of <= 256 pixels); tile 41: 32x32, K over 8 waves (<= 1024 pixels)
+int conv_sm_tile(const sp3_gemm_desc& d) {
+  if (d.loader != SP3_LOAD_CONV3X3 || d.wdtype != SP3_BF16 || !d.w_packed || d.a_bf16 || d.out_bf16 || d.out_packed || d.epi != SP3_EPI_PLAIN ||
+      d.batch > 1 || d.splitk > 1 || d.alpha != 1.0f || d.ln_stats || d.stats_out || d.c2 || d.trace || d.sm_stats_out || d.f32x3)
+    return -1;
+  if (d.K % 64 || d.conv_C % 16 || d.K != 9 * d.conv_C || d.K >= 65536 || d.M > 1024 || d.M < 1 || d.act == SP3_ACT_GELU) return -1;
+  if (d.ldc != d.N || (d.res1 && d.ldr1 != d.N) || (d.res2 && d.ldr2 != d.N) || (d.ldw > 0 && d.ldw != d.K)) return -1;
+  if (d.M <= 256) return d.N % 16 == 0 ? 40 : -1;
+  return d.N % 32 == 0 ? 41 : -1;
+}
+
+int conv_sm_dispatch(const sp3_gemm_desc& d, int tile, hipStream_t stream) {
+  ConvSmArgs a;
+  a.x = d.A; a.W = reinterpret_cast<const char*>(d.W); a.out = reinterpret_cast<float*>(d.C);
+  a.bias = d.bias; a.res1 = d.res1; a.res2 = d.res2;
+  a.M = d.M; a.N = d.N; a.H = d.conv_H; a.Wd = d.conv_W; a.Cin = d.conv_C; a.OH = d.conv_OH; a.OW = d.conv_OW;
+  a.stride = d.conv_stride; a.nkb = d.K / 64; a.relu_in = d.relu_in; a.act = d.act;
+  auto magic = [](int v) { return (unsigned)((1ull << 32) / (unsigned)v + 1); };
+  a.cin_magic = magic(d.conv_C); a.per_magic = magic(d.conv_OH * d.conv_OW); a.ow_magic = magic(d.conv_OW);
+  if (tile == 40) return conv_sm_launch<1, 1, 12, 3>(a, stream);
+  return conv_sm_launch<2, 2, 8, 3>(a, stream);
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 struct SmInst {
   int tile, epi, K, MF, NF, WK;
@@ -437,11 +615,20 @@ void sm_fill(SmOp& o, const sp3_gemm_desc& d, const SmInst& s) {
 }  // namespace
 
 int sp3_gemm_sm_tile(const sp3_gemm_desc& d) {
+  if (d.loader == SP3_LOAD_CONV3X3) return sm_enabled() ? conv_sm_tile(d) : -1;
   const SmInst* s = sm_find(d);
   return s ? s->tile : -1;
 }
 
 int sp3_gemm_sm_launch(const sp3_gemm_desc& d, const sp3_gemm_desc* pair, hipStream_t stream) {
+  if (d.loader == SP3_LOAD_CONV3X3) {
+    const int t = sm_enabled() ? conv_sm_tile(d) : -1;
+    if (t < 0 || pair || (d.tile >= 30 && d.tile != t)) {
+      sp3_set_error("sp3_gemm: no lean conv3x3 instance for this descriptor (tile %d, M=%d N=%d K=%d)", d.tile, d.M, d.N, d.K);
+      return 1;
+    }
+    return conv_sm_dispatch(d, t, stream);
+  }
   const SmInst* s = sm_find(d);
   if (!s || (d.tile >= 30 && d.tile != s->tile)) {
     sp3_set_error("sp3_gemm: no lean small-M instance for this descriptor (tile %d, M=%d N=%d K=%d epi=%d)", d.tile, d.M, d.N, d.K, d.epi);

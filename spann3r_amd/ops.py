@@ -108,7 +108,8 @@ _TILE_NAMES = {0: "32x32xk4", 1: "64x64", 2: "64x128", 3: "64x64xk4", 4: "32x64x
                # lean small-M instances (csrc/gemm_sm.hip): epilogue, K, tile, waves over K
                30: "lean-rope-k1024-48x64xk8", 31: "lean-rope-k768-32x32xk4", 32: "lean-packed-k1024-64x64xk8", 33: "lean-packed-k768-32x32xk4",
                34: "lean-stream-k1024-32x32xk8", 35: "lean-stream-k4096-32x32xk16", 36: "lean-stream-k768-48x32xk6",
-               37: "lean-stream-k3072-48x32xk8", 38: "lean-stream-k1792-64x32xk7"}
+               37: "lean-stream-k3072-48x32xk8", 38: "lean-stream-k1792-64x32xk7",
+               40: "lean-conv-16x16xk12", 41: "lean-conv-32x32xk8"}
 
 
 def pick_tile(M, N, batch=1, splitk=1, conv=False, K=0, packed_bf16=False, plain=False, ln_nt=0, pipe_ok=False, rope=False):
@@ -472,6 +473,23 @@ def conv3x3(x, Wp, out, *, B, H, W_, Cin, Cout, stride=1, bias=None, res1=None, 
     d.out_bf16 = int(out.dtype == torch.bfloat16)
     _w(d, Wp)
     M = B * OH * OW
+    lean = -1
+    if tile < 0 and isinstance(Wp, PackedWeight):
+        # small maps (<= 1024 pixels, bf16 weights): one lean launch, K split inside the workgroup -- no split-K workspace, no reduce launch
+        p = GemmDesc()
+        p.a_bf16, p.out_bf16 = d.a_bf16, d.out_bf16
+        _w(p, Wp)
+        p.A, p.C, p.bias, p.res1, p.res2 = x.data_ptr(), out.data_ptr(), L.ptr(bias), L.ptr(res1), L.ptr(res2)
+        p.M, p.N, p.K, p.batch = M, Cout, 9 * Cin, 1
+        p.lda, p.ldc, p.ldr1, p.ldr2 = Cin, Cout, Cout, Cout
+        p.alpha, p.act, p.relu_in = 1.0, act, int(relu_in)
+        p.loader, p.epi, p.tile = L.LOAD_CONV3X3, L.EPI_PLAIN, -1
+        p.conv_H, p.conv_W, p.conv_C, p.conv_OH, p.conv_OW, p.conv_stride = H, W_, Cin, OH, OW, stride
+        lean = L.load().sp3_gemm_plan(C.byref(p))
+        if lean >= 30:
+            p.tile = lean
+            _gemm_launch(p, "sp3_gemm(conv3x3)", "conv3x3")
+            return out
     S = conv_splitk(M, Cout, 9 * Cin, Wp.dtype) if (splitk_ws is not None and tile < 0 and out.dtype == torch.float32) else 1
     if S > 1 and splitk_ws.numel() < S * M * Cout:
         raise ValueError("conv3x3: splitk_ws holds %d floats, needs %d" % (splitk_ws.numel(), S * M * Cout))
