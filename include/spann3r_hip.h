@@ -173,6 +173,12 @@ int sp3_layernorm(const float* x, int64_t ldx, const float* gamma, const float* 
 /* Same, output in fragment order (see sp3_gemm_desc.a_packed). */
 int sp3_layernorm_packed(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
                          void* out, int out_bf16, int rows, int C, void* stream);
+/* fp32 row-major output (as sp3_layernorm) AND a bf16 fragment-order copy for GEMM consumers in the same launch: rows are taken
+ * in groups of group_rows (one image / one decoder side) and group g starts at packed row g * group_rows_pad (a multiple of 16),
+ * so every group is an a_packed operand of its own.  enc_norm / dec_norm (dust3r/model.py:153,204), whose outputs are both
+ * API-visible (fp32) and the A operands of decoder_embed / the key MLPs (dust3r/model.py:190-191, spann3r/model.py:299-303). */
+int sp3_layernorm_dual(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, float* out, int64_t ldo,
+                       void* out_packed_bf16, int rows, int C, int group_rows, int group_rows_pad, void* stream);
 /* Same, but stores the result TRANSPOSED: out[c * ldo + row] (used to append LN_v(value) columns
  * to the [1024, capacity] V^T bank of the spatial memory). */
 int sp3_layernorm_t(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,

@@ -1786,14 +1786,17 @@ static int gemm_prepare(sp3_gemm_desc& d, int& tile_out) {
   SP3_CHECK((!d.stats_out && !d.c2) || (d.epi == SP3_EPI_PLAIN && d.N % 32 == 0 && !d.out_packed),
             "sp3_gemm: stats_out / c2 need the plain epilogue, N %% 32 == 0");
   SP3_CHECK(!d.out_packed || (d.epi == SP3_EPI_PLAIN && d.N % 4 == 0), "sp3_gemm: out_packed needs the plain epilogue, N %% 4 == 0");
-  SP3_CHECK(!d.a_packed || (d.loader == SP3_LOAD_PLAIN && !d.A2), "sp3_gemm: packed A is plain / unsplit");
+  // (a fragment-order A split along K -- A2 a second packed matrix with K - K1 columns -- is served by the lean instances only)
+  SP3_CHECK(!d.a_packed || d.loader == SP3_LOAD_PLAIN, "sp3_gemm: packed A needs the plain loader");
+  SP3_CHECK(!(d.a_packed && d.A2) || (d.K1 % 64 == 0 && d.K1 > 0 && d.K1 < d.K && d.K % 64 == 0),
+            "sp3_gemm: packed split A needs K1 and K - K1 in whole 64-column blocks");
   SP3_CHECK(d.batch == 1 || ((d.sb_bias | d.sb_ln_stats | d.sb_ln_s | d.sb_stats_out | d.sb_c2 | d.sb_vt | d.sb_A2) & 15) == 0,
             "sp3_gemm: per-batch byte offsets must keep 16-byte alignment");
   SP3_CHECK(!d.a_packed || ((d.a_bf16 != 0) == (d.wdtype == SP3_BF16)), "sp3_gemm: packed A must have the MFMA dtype (its fragment geometry)");
   if (!d.A2) d.K1 = d.K;
   const int aalign = d.a_bf16 ? 8 : 4;    // elements per 16 bytes
   SP3_CHECK(d.ldw >= d.K && d.ldw % 8 == 0, "sp3_gemm: ldw=%lld must be >= K and a multiple of 8", (long long)d.ldw);
-  SP3_CHECK(!d.A2 || (d.loader == SP3_LOAD_PLAIN && d.K1 % 64 == 0 && d.K1 > 0 && d.K1 < d.K && d.lda2 % aalign == 0),
+  SP3_CHECK(!d.A2 || (d.loader == SP3_LOAD_PLAIN && d.K1 % 64 == 0 && d.K1 > 0 && d.K1 < d.K && (d.a_packed || d.lda2 % aalign == 0)),
             "sp3_gemm: bad split-A configuration (K1=%d)", d.K1);
   SP3_CHECK(d.splitk == 1 || d.epi == SP3_EPI_PARTIAL, "sp3_gemm: splitk > 1 needs the PARTIAL epilogue");
   if (d.loader == SP3_LOAD_PLAIN && !d.a_packed) {
@@ -1917,6 +1920,7 @@ extern "C" int sp3_gemm(const sp3_gemm_desc* dp, void* stream_) {
   if (int rc = gemm_prepare(d, tile)) return rc;
   // the 196-row weight-streaming shapes of the per-frame step: lean shape-specialised instances (gemm_sm.hip, tiles 30..)
   if (d.tile >= 30 || (d.tile < 0 && sp3_gemm_sm_tile(d) >= 0)) return sp3_gemm_sm_launch(d, nullptr, reinterpret_cast<hipStream_t>(stream_));
+  SP3_CHECK(!(d.a_packed && d.A2), "sp3_gemm: a fragment-order A split along K runs on the lean instances only (no instance for M=%d N=%d K=%d)", d.M, d.N, d.K);
   return gemm_dispatch(d, tile, reinterpret_cast<hipStream_t>(stream_));
 }
 

@@ -27,11 +27,11 @@ namespace {
 enum { SM_PACKED = 0, SM_STREAM = 1, SM_ROPE = 2 };
 
 struct SmOp {
-  const char* A; const char* W; char* C;
+  const char* A; const char* A2; const char* W; char* C;     // A2: second fragment-order source for k-blocks >= nkb1 (split A), else = A
   const float* bias; const float* res1; const float* ln_stats; const float* ln_s;
   float* stats_out; char* c2; char* vt;
-  long gA, gW, gC, gbias, gres, gstats, gs, gso, gc2, gvt;      // byte strides per group (problem) of a grouped launch
-  int N, ntz, ldc, rope_cols, act;
+  long gA, gA2, gW, gC, gbias, gres, gstats, gs, gso, gc2, gvt;      // byte strides per group (problem) of a grouped launch
+  int N, ntz, ldc, rope_cols, act, nkb1;
 };
 
 struct SmArgs {
@@ -44,7 +44,9 @@ struct SmArgs {
 };
 
 // grid = (8, mt, nz): linear workgroup id = x + 8 (y + mt z) -> XCD x; tile_m = y; z = group * ntz + zt, tile_n = 8 zt + x
-template <int MF, int NF, int WK, int NKB, int RING, int EPI>
+// SPLIT: A = [A | A2] along K (torch.cat(..., dim=-1) without the copy, spann3r/model.py:300): k-blocks [0, nkb1) come from A (a
+// fragment-order [M, 64 nkb1] matrix), the rest from A2 ([M, 64 (NKB - nkb1)])
+template <int MF, int NF, int WK, int NKB, int RING, int EPI, bool SPLIT = false>
 __global__ __launch_bounds__(64 * WK) void sm_kernel(const SmArgs a) {
   constexpr int BM = MF * 16, BN = NF * 16, NT = 64 * WK;
   constexpr int NKW = NKB / WK;                               // k-blocks per wave
@@ -127,7 +129,9 @@ __global__ __launch_bounds__(64 * WK) void sm_kernel(const SmArgs a) {
 
   // ---- operands: wave wk owns k-blocks wk, wk + WK, ...
   const char* ap[MF];
+  const char* ap2[SPLIT ? MF : 1];
   const char* wp[NF];
+  const int nkb1 = SPLIT ? OPF(nkb1) : NKB;
   {
     const char* A = OPF(A) + grp * OPF(gA);
     const char* W = OPF(W) + grp * OPF(gW);
@@ -135,7 +139,8 @@ __global__ __launch_bounds__(64 * WK) void sm_kernel(const SmArgs a) {
     for (int m = 0; m < MF; ++m) {
       int rb = tile_m * MF + m;
       rb = rb < a.rb_max ? rb : a.rb_max;                      // row blocks past M: re-read the last one (masked at the store)
-      ap[m] = A + ((long)rb * NKB + wk) * 2048 + lane * 16;
+      ap[m] = A + ((long)rb * nkb1 + wk) * 2048 + lane * 16;
+      if constexpr (SPLIT) ap2[m] = OPF(A2) + grp * OPF(gA2) + ((long)rb * (NKB - nkb1) + wk - nkb1) * 2048 + lane * 16;
     }
     const int nb_max = (N >> 4) - 1;
 #pragma unroll
@@ -152,10 +157,12 @@ __global__ __launch_bounds__(64 * WK) void sm_kernel(const SmArgs a) {
       wv[slot][n][0] = *reinterpret_cast<const bf16x8*>(wp[n] + (long)i * WK * 2048);
       wv[slot][n][1] = *reinterpret_cast<const bf16x8*>(wp[n] + (long)i * WK * 2048 + 1024);
     }
+    const bool from2 = SPLIT && (wk + i * WK) >= nkb1;         // wave-uniform
 #pragma unroll
     for (int m = 0; m < MF; ++m) {
-      av[slot][m][0] = *reinterpret_cast<const bf16x8*>(ap[m] + (long)i * WK * 2048);
-      av[slot][m][1] = *reinterpret_cast<const bf16x8*>(ap[m] + (long)i * WK * 2048 + 1024);
+      const char* q = (SPLIT && from2 ? ap2[m] : ap[m]) + (long)i * WK * 2048;
+      av[slot][m][0] = *reinterpret_cast<const bf16x8*>(q);
+      av[slot][m][1] = *reinterpret_cast<const bf16x8*>(q + 1024);
     }
   };
   f32x4 acc[MF][NF];
@@ -514,17 +521,18 @@ int conv_sm_dispatch(const sp3_gemm_desc& d, int tile, hipStream_t stream) {
 // ------------------------------------------------------------------------------------------------ host side
 struct SmInst {
   int tile, epi, K, MF, NF, WK;
+  bool split;                       // serves descriptors with a second A source (and only those)
   int min_n;                        // N range this instance is the choice for (per problem)
   int max_n;
   int (*launch)(const SmArgs&, int mt, int nz, hipStream_t);
 };
 
-template <int MF, int NF, int WK, int NKB, int RING, int EPI>
+template <int MF, int NF, int WK, int NKB, int RING, int EPI, bool SPLIT = false>
 int sm_launch(const SmArgs& a, int mt, int nz, hipStream_t stream) {
   constexpr int BM = MF * 16, BN = NF * 16;
   constexpr size_t lds = ((size_t)WK * BM * (BN + 4) + 2 * BM) * sizeof(float);
   static_assert(lds <= 160 * 1024, "partial tiles must fit the LDS");
-  auto kern = sm_kernel<MF, NF, WK, NKB, RING, EPI>;
+  auto kern = sm_kernel<MF, NF, WK, NKB, RING, EPI, SPLIT>;
   if (lds > 64 * 1024) {
     static bool raised = false;
     if (!raised) {
@@ -542,17 +550,19 @@ int sm_launch(const SmArgs& a, int mt, int nz, hipStream_t stream) {
 // tile ids 30.. are what sp3_gemm_desc.tile / the profiles call them.
 const SmInst kInst[] = {
     // ROPE (q/k/v projections): BN % 32 == 0 (the RoPE partner column lies in the tile)
-    {30, SM_ROPE, 1024, 3, 4, 8, 0, 1 << 30, sm_launch<3, 4, 8, 16, 0, SM_ROPE>},      // val / enc-step qkv: 48x64, K over 8 waves
-    {31, SM_ROPE, 768, 2, 2, 4, 0, 1 << 30, sm_launch<2, 2, 4, 12, 0, SM_ROPE>},       // decoder qkv + ckv pair, cross q: 32x32 k4
+    {30, SM_ROPE, 1024, 3, 4, 8, false, 0, 1 << 30, sm_launch<3, 4, 8, 16, 0, SM_ROPE>},      // val / enc-step qkv: 48x64, K over 8 waves
+    {31, SM_ROPE, 768, 2, 2, 4, false, 0, 1 << 30, sm_launch<2, 2, 4, 12, 0, SM_ROPE>},       // decoder qkv + ckv pair, cross q: 32x32 k4
     // PACKED (fc1 + GELU, key MLP hidden)
-    {32, SM_PACKED, 1024, 4, 4, 8, 0, 1 << 30, sm_launch<4, 4, 8, 16, 0, SM_PACKED>},  // val fc1: 64x64 k8
-    {33, SM_PACKED, 768, 2, 2, 4, 0, 1 << 30, sm_launch<2, 2, 4, 12, 0, SM_PACKED>},   // dec fc1 x2: 32x32 k4
+    {32, SM_PACKED, 1024, 4, 4, 8, false, 0, 1 << 30, sm_launch<4, 4, 8, 16, 0, SM_PACKED>},  // val fc1: 64x64 k8
+    {33, SM_PACKED, 768, 2, 4, 4, false, 0, 1 << 30, sm_launch<2, 4, 4, 12, 0, SM_PACKED>},   // dec fc1 x2: 32x64 k4
+    {42, SM_PACKED, 1792, 4, 2, 7, true, 0, 1 << 30, sm_launch<4, 2, 7, 28, 0, SM_PACKED, true>},   // key MLP hidden x2 (split A: feat | dec[-1]): 64x32 k7
     // STREAM (output projections onto the residual stream)
-    {34, SM_STREAM, 1024, 2, 2, 8, 0, 1 << 30, sm_launch<2, 2, 8, 16, 0, SM_STREAM>},  // val proj, value_out: 32x32 k8
-    {35, SM_STREAM, 4096, 2, 2, 16, 0, 1 << 30, sm_launch<2, 2, 16, 64, 0, SM_STREAM>},   // val fc2: 32x32 k16
-    {36, SM_STREAM, 768, 3, 2, 6, 0, 1 << 30, sm_launch<3, 2, 6, 12, 0, SM_STREAM>},   // dec proj / cproj x2, pos patch embed: 48x32 k6
-    {37, SM_STREAM, 3072, 3, 2, 8, 0, 1 << 30, sm_launch<3, 2, 8, 48, 3, SM_STREAM>},  // dec fc2 x2: 48x32 k8, ring of 3
-    {38, SM_STREAM, 1792, 4, 2, 7, 0, 1 << 30, sm_launch<4, 2, 7, 28, 0, SM_STREAM>},  // key MLP out x2: 64x32 k7
+    {39, SM_STREAM, 1024, 3, 2, 8, false, 0, 768, sm_launch<3, 2, 8, 16, 0, SM_STREAM>},      // decoder_embed x2 (N = 768): 48x32 k8
+    {34, SM_STREAM, 1024, 2, 2, 8, false, 769, 1 << 30, sm_launch<2, 2, 8, 16, 0, SM_STREAM>},  // val proj, value_out: 32x32 k8
+    {35, SM_STREAM, 4096, 2, 2, 16, false, 0, 1 << 30, sm_launch<2, 2, 16, 64, 0, SM_STREAM>},   // val fc2: 32x32 k16
+    {36, SM_STREAM, 768, 3, 2, 6, false, 0, 1 << 30, sm_launch<3, 2, 6, 12, 0, SM_STREAM>},   // dec proj / cproj x2, pos patch embed: 48x32 k6
+    {37, SM_STREAM, 3072, 3, 2, 8, false, 0, 1 << 30, sm_launch<3, 2, 8, 48, 3, SM_STREAM>},  // dec fc2 x2: 48x32 k8, ring of 3
+    {38, SM_STREAM, 1792, 4, 2, 7, false, 0, 1 << 30, sm_launch<4, 2, 7, 28, 0, SM_STREAM>},  // key MLP out x2: 64x32 k7
 };
 
 bool sm_enabled() {
@@ -568,7 +578,7 @@ int sm_kind(const sp3_gemm_desc& d) {
 
 const SmInst* sm_find(const sp3_gemm_desc& d) {
   if (!sm_enabled()) return nullptr;
-  if (d.wdtype != SP3_BF16 || !d.a_bf16 || !d.a_packed || !d.w_packed || d.loader != SP3_LOAD_PLAIN || d.A2 || d.res2 || d.relu_in ||
+  if (d.wdtype != SP3_BF16 || !d.a_bf16 || !d.a_packed || !d.w_packed || d.loader != SP3_LOAD_PLAIN || d.res2 || d.relu_in ||
       d.trace || d.sm_stats_out || d.sm_stats || d.alpha != 1.0f || d.f32x3)
     return nullptr;
   if (d.splitk > 1 || d.epi == SP3_EPI_PARTIAL || d.epi == SP3_EPI_PIXSHUF) return nullptr;
@@ -585,8 +595,10 @@ const SmInst* sm_find(const sp3_gemm_desc& d) {
     if ((d.stats_out || d.c2) && d.N % 32) return nullptr;
   }
   if (d.ln_stats && (d.ln_C != d.K || d.K > 1024 || (d.K / 64) % 4)) return nullptr;
+  const bool split = d.A2 != nullptr;
+  if (split && (d.K1 % 64 || d.K1 <= 0 || d.K1 >= d.K)) return nullptr;
   for (const SmInst& s : kInst) {
-    if (s.epi != kind || s.K != d.K) continue;
+    if (s.epi != kind || s.K != d.K || s.split != split) continue;
     if (d.N % (s.NF * 16) || d.N < s.min_n || d.N > s.max_n) continue;
     if (d.ln_stats && s.MF * 16 * 4 > 64 * s.WK) continue;
     return &s;
@@ -597,6 +609,9 @@ const SmInst* sm_find(const sp3_gemm_desc& d) {
 void sm_fill(SmOp& o, const sp3_gemm_desc& d, const SmInst& s) {
   const long G = d.batch > 1 ? 1 : 0;
   o.A = reinterpret_cast<const char*>(d.A);
+  o.A2 = d.A2 ? reinterpret_cast<const char*>(d.A2) : o.A;
+  o.nkb1 = d.A2 ? d.K1 / 64 : d.K / 64;
+  o.gA2 = G * d.sb_A2;
   o.W = reinterpret_cast<const char*>(d.W);
   o.C = reinterpret_cast<char*>(d.C);
   o.bias = d.bias; o.res1 = d.res1; o.ln_stats = d.ln_stats; o.ln_s = d.ln_s;

@@ -51,7 +51,8 @@ __device__ __forceinline__ void ln_row(const float* __restrict__ xr, int C, cons
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t ldx,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         float eps, void* __restrict__ out, int64_t ldo, int out_bf16,
-                                                        int out_packed, int rows, int C) {
+                                                        int out_packed, int rows, int C, __bf16* __restrict__ dual = nullptr,
+                                                        int group_rows = 0, int group_pad = 0) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -59,6 +60,19 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   int nv;
   ln_row(x + (int64_t)row * ldx, C, gamma, beta, eps, lane, v, nv);
   const int c4 = C >> 2;
+  if (dual) {
+    // second output: bf16 fragment-order copy, every group of group_rows rows starting on a 16-row boundary (group_pad)
+    const int gi = row / group_rows, prow = gi * group_pad + (row - gi * group_rows);
+#pragma unroll
+    for (int i = 0; i < LN_MAX_V4; ++i) {
+      const int j = lane + i * 64;
+      if (j < c4) {
+        bf16x4 o;
+        o[0] = (__bf16)v[i].x; o[1] = (__bf16)v[i].y; o[2] = (__bf16)v[i].z; o[3] = (__bf16)v[i].w;
+        *reinterpret_cast<bf16x4*>(dual + packed_off(prow, 4 * j, C, true)) = o;
+      }
+    }
+  }
 #pragma unroll
   for (int i = 0; i < LN_MAX_V4; ++i) {
     const int j = lane + i * 64;
@@ -253,6 +267,19 @@ extern "C" int sp3_layernorm_packed(const float* x, int64_t ldx, const float* ga
   hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, ldx,
                      gamma, beta, eps, out, (int64_t)0, out_bf16, 1, rows, C);
   SP3_LAUNCH_CHECK("sp3_layernorm_packed");
+  return 0;
+}
+
+extern "C" int sp3_layernorm_dual(const float* x, int64_t ldx, const float* gamma, const float* beta, float eps, float* out, int64_t ldo,
+                                  void* out_packed_bf16, int rows, int C, int group_rows, int group_rows_pad, void* stream) {
+  if (ln_check(x, ldx, gamma, beta, out, rows, C)) return 1;
+  SP3_CHECK(ldo % 4 == 0 && out_packed_bf16, "sp3_layernorm_dual: ldo must be a multiple of 4, the packed output non-null");
+  SP3_CHECK(group_rows > 0 && group_rows_pad >= group_rows && group_rows_pad % 16 == 0, "sp3_layernorm_dual: bad row groups %d -> %d",
+            group_rows, group_rows_pad);
+  hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, ldx,
+                     gamma, beta, eps, static_cast<void*>(out), ldo, 0, 0, rows, C, reinterpret_cast<__bf16*>(out_packed_bf16), group_rows,
+                     group_rows_pad);
+  SP3_LAUNCH_CHECK("sp3_layernorm_dual");
   return 0;
 }
 

@@ -271,9 +271,11 @@ class Engine:
             self._block(x, xpA, stA, xpB, stB, R, B, P, E, cfg.enc_heads, prefix + "%d." % i, pos32, tag=tag)
         return x, xpA, stA
 
-    def encode_image(self, img, out=None, tag=""):
+    def encode_image(self, img, out=None, tag="", out_packed=None, group_rows=0):
         """dust3r._encode_image (dust3r/model.py:131-154): patch embed -> enc_depth blocks -> enc_norm.
-        img fp32 [B,3,H,W] on device -> feat [B,P,1024] (written to `out` if given), pos int64 [B,P,2]."""
+        img fp32 [B,3,H,W] on device -> feat [B,P,1024] (written to `out` if given), pos int64 [B,P,2].
+        out_packed (bf16 PackedAct.group): fragment-order copy of the features written by the enc_norm launch, one group per
+        group_rows rows (the rows of one frame) -- the A operand of decoder_embed / the key MLPs."""
         cfg, w = self.cfg, self.w
         B, Cin, H, W_ = img.shape
         p = cfg.patch
@@ -287,7 +289,8 @@ class Engine:
         if out is None:
             out = torch.empty(B, P, E, device=self.device)
         x, _, _ = self._vit(col, R, B, P, "patch", "enc", cfg.enc_depth, pos32, tag=tag)
-        ops.layernorm(x, w["enc_norm.w"], w["enc_norm.b"], 1e-6, out, rows=R, C_=E)     # API-visible: stays a kernel
+        ops.layernorm(x, w["enc_norm.w"], w["enc_norm.b"], 1e-6, out, rows=R, C_=E,     # API-visible: stays a kernel
+                      dual=out_packed, group_rows=group_rows)
         return out, pos64
 
     def side_streams(self):
@@ -423,7 +426,7 @@ class Engine:
             t = self._ws[key] = ops.PackedAct.group(2, R, K, self.adt, self.device)
         return t
 
-    def decoder_grouped(self, f1, f2, B, nh, nw):
+    def decoder_grouped(self, f1, f2, B, nh, nw, f1p=None, f2p=None):
         """dust3r._decoder (dust3r/model.py:186-205) with both sides as problems 0 / 1 of one grouped launch per op:
         8 launches per layer on ONE stream instead of 2 x 10 on two streams with a fork/join per layer (the cross-stream
         dependencies cost ~8 us of idle GPU each).  Same kernels, same arithmetic per side as `decoder`."""
@@ -449,10 +452,17 @@ class Engine:
         sb_st, sb_vt = R * nt * 8, B * Hh * npad * 64 * 2
         Rp = xp[0].rows_pad
         # decoder_embed (dust3r/model.py:190-191): one weight, two inputs that live in different buffers
-        dA = f2.data_ptr() - f1.data_ptr()
-        assert dA % 16 == 0 and f1.dtype == f2.dtype == torch.float32
-        ops.gemm(f1, w["dec_embed.w"], x[0], M=R, N=D, K=E, lda=E, ldc=D, bias=w["dec_embed.b"], stats_out=st[0], c2=xp[0],
-                 batch=2, strideA=dA // 4, strideC=R * D, sb={"stats_out": sb_st, "c2": xp[0].stride * es})
+        if f1p is not None and f2p is not None:
+            # fragment-order bf16 copies of both inputs exist (enc_norm / the memory read wrote them): lean instance
+            dA = f2p.data_ptr() - f1p.data_ptr()
+            assert dA % 16 == 0
+            ops.gemm(f1p, w["dec_embed.w"], x[0], M=R, N=D, K=E, lda=E, ldc=D, bias=w["dec_embed.b"], stats_out=st[0], c2=xp[0],
+                     batch=2, strideA=dA // 2, strideC=R * D, sb={"stats_out": sb_st, "c2": xp[0].stride * es})
+        else:
+            dA = f2.data_ptr() - f1.data_ptr()
+            assert dA % 16 == 0 and f1.dtype == f2.dtype == torch.float32
+            ops.gemm(f1, w["dec_embed.w"], x[0], M=R, N=D, K=E, lda=E, ldc=D, bias=w["dec_embed.b"], stats_out=st[0], c2=xp[0],
+                     batch=2, strideA=dA // 4, strideC=R * D, sb={"stats_out": sb_st, "c2": xp[0].stride * es})
         rope = dict(pos=pos, cos=self.cos, sin=self.sin, tokens=P, heads=Hh, qkv_packed=True, batch=2)
         for i in range(depth):
             cur, nx = i % 2, (i + 1) % 2
@@ -499,7 +509,9 @@ class Engine:
             else:
                 upd(h, Hd, "fc2", xo, st[nx], xp[nx])
         normed = self.ws("decg_normed", (2, R, D))
-        ops.layernorm(x[depth], w["dec_norm.w"], w["dec_norm.b"], 1e-6, normed, rows=2 * R, C_=D)       # API-visible
+        # API-visible (fp32) + the fragment-order copy the key MLPs read
+        ops.layernorm(x[depth], w["dec_norm.w"], w["dec_norm.b"], 1e-6, normed, rows=2 * R, C_=D,
+                      dual=self.wspg("decg_normed_packed", R, D) if self.adt == torch.bfloat16 else None, group_rows=R)
         outs = {}
         for s_ in (0, 1):
             outs[s_] = [(f1, f2)[s_]] + [x[l][s_].view(B, P, D) for l in range(1, depth)] + [normed[s_].view(B, P, D)]
@@ -511,16 +523,25 @@ class Engine:
         E = self.cfg.enc_dim
         return self.wspg("keyg_packed", R, E), self.ws("keyg_stats", (2, R, E // 32, 2))
 
-    def encode_feat_keys_grouped(self, feat1, feat2, normed1, normed2, R, out1, out2):
-        """both key MLPs (spann3r/model.py:299-303) as one grouped launch per layer; normed1/2 = the decoders' last outputs"""
+    def encode_feat_keys_grouped(self, feat1, feat2, normed1, normed2, R, out1, out2, feat1p=None, feat2p=None):
+        """both key MLPs (spann3r/model.py:299-303) as one grouped launch per layer; normed1/2 = the decoders' last outputs.
+        feat1p / feat2p: fragment-order bf16 copies of the features (written by enc_norm): with the packed copy of the decoder
+        outputs (decoder_grouped) the first layer runs on a lean split-A instance instead of converting fp32 rows on load."""
         cfg, w = self.cfg, self.w
         E, D, Kd = cfg.enc_dim, cfg.dec_dim, cfg.key_dim
         dF, dN, dO = feat2.data_ptr() - feat1.data_ptr(), normed2.data_ptr() - normed1.data_ptr(), out2.data_ptr() - out1.data_ptr()
         assert dF % 16 == 0 and dN % 16 == 0 and dO % 16 == 0
         es = 2 if self.adt == torch.bfloat16 else 4
         h = self.wspg("keyg_hidden", R, Kd)
-        ops.gemm(feat1, w["keyg.0.w"], h, M=R, N=Kd, K=Kd, lda=E, ldc=Kd, bias=w["keyg.0.b"], act=ACT_GELU, A2=normed1, lda2=D, K1=E,
-                 batch=2, strideA=dF // 4, strideW=w["keyg.0.w"].stride, strideC=h.stride, sb={"bias": Kd * 4, "A2": dN})
+        if feat1p is not None and feat2p is not None and self.adt == torch.bfloat16 and R <= 256:     # (R: the lean instances' row limit)
+            np_ = self.wspg("decg_normed_packed", R, D)
+            dFp = feat2p.data_ptr() - feat1p.data_ptr()
+            assert dFp % 16 == 0
+            ops.gemm(feat1p, w["keyg.0.w"], h, M=R, N=Kd, K=Kd, lda=E, ldc=Kd, bias=w["keyg.0.b"], act=ACT_GELU, A2=np_, lda2=D, K1=E,
+                     batch=2, strideA=dFp // 2, strideW=w["keyg.0.w"].stride, strideC=h.stride, sb={"bias": Kd * 4, "A2": np_.stride * 2})
+        else:
+            ops.gemm(feat1, w["keyg.0.w"], h, M=R, N=Kd, K=Kd, lda=E, ldc=Kd, bias=w["keyg.0.b"], act=ACT_GELU, A2=normed1, lda2=D, K1=E,
+                     batch=2, strideA=dF // 4, strideW=w["keyg.0.w"].stride, strideC=h.stride, sb={"bias": Kd * 4, "A2": dN})
         kp, kst = self.key_aux(R)
         ops.gemm(h, w["keyg.2.w"], out1, M=R, N=E, K=Kd, lda=Kd, ldc=E, bias=w["keyg.2.b"], stats_out=kst, c2=kp,
                  batch=2, strideA=h.stride, strideW=w["keyg.2.w"].stride, strideC=dO // 4,

@@ -97,6 +97,8 @@ _PROTOS = {
     "sp3_layernorm": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_int,
                       C.c_int, C.c_int, C.c_void_p],
     "sp3_reduce_ln": [C.POINTER(ReduceLnDesc), C.c_void_p],
+    "sp3_layernorm_dual": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int,
+                           C.c_int, C.c_int, C.c_void_p],
     "sp3_layernorm_packed": [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int,
                              C.c_int, C.c_int, C.c_void_p],
     "sp3_attention_ex": [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,

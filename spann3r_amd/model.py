@@ -181,14 +181,17 @@ class SpatialMemory:
         return None if self.M == 0 else self.bank["count"][:, :self.M, None]
 
     # ------------------------------------------------------------------ read (:145-183)
-    def memory_read(self, feat, out, feat_packed=None, feat_stats=None, defer_attn=False):
+    def memory_read(self, feat, out, feat_packed=None, feat_stats=None, defer_attn=False, out_packed=None):
         """feat fp32 [B,P,1024] (the query, feat_k2) -> out = attn . LN_v(mem_v) + feat ; mem_attn += colsum(attn).
         feat_packed / feat_stats: fragment-order copy and row-statistics partials of `feat` when its producer already
         wrote them (B == 1: the key-MLP GEMM's c2 / stats_out); otherwise one sp3_pack_stats launch makes them.
         defer_attn: the column sums of the two-launch read (mem_attn += ..., consumed by nothing before the next prune) are
         not launched here but folded into the launch that commits / drops the staged frame (`commit`, `finish_staged`) --
-        a side stream for them costs more in graph fork/join edges than the launch itself (measured: -8 % frames/s)."""
+        a side stream for them costs more in graph fork/join edges than the launch itself (measured: -8 % frames/s).
+        out_packed (B == 1, two-launch read): receives a fragment-order bf16 copy of `out` from the same epilogue (decoder_embed's A
+        operand); returns whether it was written."""
         self._flush_attn()
+        self.wrote_packed = False
         eng, bk = self.eng, self.bank
         B, P, C, M, kb = self.B, self.P, self.C, self.M, self.kb
         assert M > 0
@@ -219,8 +222,10 @@ class SpatialMemory:
                      bias=bk["b_bank"][b], ln=ops.LnFold(qs[b], C, bk["s_bank"][b], 1e-5), sm_stats_out=st[b] if fused else None)
         if fused:
             for b in range(B):
+                c2 = out_packed if (out_packed is not None and B == 1) else None
                 ops.gemm(S[b], ops.PackedWeight.wrap(bk["v_hat_t"][b], C, self.cap), out[b], M=P, N=C, K=M, lda=ld, ldc=C,
-                         ldw=self.cap, res1=feat[b], ldr1=C, softmax=(st[b], self.attn_thresh, zk[b]))
+                         ldw=self.cap, res1=feat[b], ldr1=C, softmax=(st[b], self.attn_thresh, zk[b]), c2=c2)
+                self.wrote_packed = c2 is not None
             self.note_deferred_read()
             if not defer_attn:
                 self._flush_attn()
@@ -431,6 +436,12 @@ class _SequenceRunner:
         self.featpair = torch.empty(2 * B, self.P, self.E, device=dev)
         self.feat1, self.feat2 = self.featpair[:B], self.featpair[B:]
         self.fuse = torch.empty(B, self.P, self.E, device=dev)
+        # bf16 mode, whole-sequence encoder: fragment-order copies of the features (enc_norm writes them next to the fp32 rows) so
+        # that decoder_embed and the key MLPs run on the lean small-M instances
+        self.packed_feats = eng.packed_attn
+        self.feats_p = None
+        self.featpair_p = ops.PackedAct.group(2, B * self.P, self.E, torch.bfloat16, dev) if self.packed_feats else None
+        self.fuse_p = ops.PackedAct(B * self.P, self.E, torch.bfloat16, dev) if self.packed_feats else None
         self.k1 = torch.empty(B, self.P, self.E, device=dev)
         self.k2 = torch.empty(B, self.P, self.E, device=dev)
         self.v = torch.empty(B, self.P, self.E, device=dev)
@@ -469,6 +480,7 @@ class _SequenceRunner:
         if self.feats is None or self.feats.shape[0] < n * B:
             self.img_all = torch.empty(n * B, 3, self.H, self.W, device=self.eng.device)
             self.feats = torch.empty(n * B, self.P, self.E, device=self.eng.device)
+            self.feats_p = ops.PackedAct.group(n, B * self.P, self.E, torch.bfloat16, self.eng.device) if self.packed_feats else None
             # every graph that baked in the old buffers dies with them: the encoder's AND the deferred head's (reads feats)
             self._drop_graphs(lambda k: k[0] in ("enc", "head2"))
             self.seen = {k for k in self.seen if k[0] not in ("enc", "head2")}
@@ -483,7 +495,9 @@ class _SequenceRunner:
         for c0 in range(0, n, per):
             c1 = min(n, c0 + per)
             img, out = self.img_all[c0 * B:c1 * B], self.feats[c0 * B:c1 * B]
-            self._graphed(("enc", c0, c1), lambda: self.eng.encode_image(img, out=out, tag="_seq"), use_graphs)
+            outp = self.feats_p.at(c0) if self.feats_p is not None else None          # frame f -> group f of the packed copy
+            self._graphed(("enc", c0, c1), lambda: self.eng.encode_image(img, out=out, tag="_seq", out_packed=outp, group_rows=B * self.P),
+                          use_graphs)
         self.batched = True
 
     # ---- deferred view-2 head --------------------------------------------------------------------------------
@@ -531,13 +545,18 @@ class _SequenceRunner:
                 outs.append((pts[j * B:(j + 1) * B], conf[j * B:(j + 1) * B]))
         return outs
 
-    def pair_copy(self, i):
-        """featpair <- (feat of frame i, feat of frame i+1): two adjacent slabs of the sequence buffer, one copy"""
+    def pair_copies(self, i):
+        """featpair <- (feat of frame i, feat of frame i+1): two adjacent slabs of the sequence buffer, one copy (plus the same for
+        the fragment-order bf16 copies)"""
         B = self.B
-        return (self.feats[i * B:(i + 2) * B], self.featpair)
+        pairs = [(self.feats[i * B:(i + 2) * B], self.featpair)]
+        if self.feats_p is not None:
+            st = self.feats_p.stride
+            pairs.append((self.feats_p.data.view(-1)[i * st:(i + 2) * st], self.featpair_p.data.view(-1)[:2 * st]))
+        return pairs
 
     def load_pair(self, i):
-        ops.copy_multi([self.pair_copy(i)])
+        ops.copy_multi(self.pair_copies(i))
 
     def _drop_graphs(self, pred):
         for k in [k for k in self.graphs if pred(k)]:
@@ -583,25 +602,33 @@ class _SequenceRunner:
         eng, mem, B, P, E = self.eng, self.mem, self.B, self.P, self.E
         main = torch.cuda.current_stream()
         st = eng.side_streams()
+        # fragment-order bf16 copies of the features exist when the sequence was encoded up front (encode_sequence)
+        packed = self.packed_feats and self.model.packed_features and self.batched and self.feats_p is not None
+        p1 = p2 = f1p = None
+        if packed:
+            p1, p2 = self.featpair_p.at(0), self.featpair_p.at(1)
         if first:
             if not self.batched:
                 eng.encode_image(self.img_pair, out=self.featpair)
-            f1 = self.feat1
+            f1, f1p = self.feat1, p1
         else:
             if not self.batched:
                 ops.copy2d(self.feat2, E, self.feat1, E, B * P, E)      # feat1 <- previous feat2 (:294)
                 ops.copy2d(self.feat_pre, E, self.feat2, E, B * P, E)   # feat2 <- the frame encoded during the previous step
             # reads k2 (and its fragment-order copy / statistics) before the key MLP of this step overwrites them
-            mem.memory_read(self.k2, self.fuse, *(self.k2_aux if B == 1 else (None, None)), defer_attn=True)
+            mem.memory_read(self.k2, self.fuse, *(self.k2_aux if B == 1 else (None, None)), defer_attn=True,
+                            out_packed=self.fuse_p if packed else None)
             f1 = self.fuse
+            f1p = self.fuse_p if (packed and mem.wrote_packed) else None
         if has_next:
             st[3].wait_stream(main)
             with torch.cuda.stream(st[3]):
                 eng.encode_image(self.img_next, out=self.feat_pre, tag="_pre")
         if eng.packed_attn and self.model.grouped_decoder:
             # both decoder sides and both key MLPs as grouped launches on the main stream: no per-layer fork/join
-            dec1, dec2 = eng.decoder_grouped(f1, self.feat2, B, self.nh, self.nw)
-            self.k2_aux = eng.encode_feat_keys_grouped(self.feat1, self.feat2, dec1[-1], dec2[-1], B * P, self.k1, self.k2)
+            dec1, dec2 = eng.decoder_grouped(f1, self.feat2, B, self.nh, self.nw, f1p=f1p, f2p=p2 if f1p is not None else None)
+            self.k2_aux = eng.encode_feat_keys_grouped(self.feat1, self.feat2, dec1[-1], dec2[-1], B * P, self.k1, self.k2,
+                                                       feat1p=p1, feat2p=p2)
         else:
             if self.model.decoder_streams:
                 dec1, dec2 = eng.decoder(f1, self.feat2, B, self.nh, self.nw, self.nh, self.nw, streams=st)   # joined on return
@@ -650,7 +677,7 @@ class _SequenceRunner:
         (decoder hooks -> sequence slots, the next pair of encoder features): six eager launches per frame became one"""
         mem = self.mem
         has_next = has_next and not self.batched                # nothing to prefetch: the sequence is already encoded
-        key = (mem.M, mem.wm, mem._cur, has_next, self.batched, self.defer2, self.model.grouped_decoder)
+        key = (mem.M, mem.wm, mem._cur, has_next, self.batched, self.defer2, self.model.grouped_decoder, self.model.packed_features)
         if not use_graphs and ops._prof is not None:
             ops._prof.step_begin()
         # two graphs per step: the host fetches the similarity scores (async copy + event) as soon as the first one is
@@ -747,6 +774,7 @@ class Spann3R(nn.Module):
         self.batch_encode = True     # forward(): encode all frames of the sequence together (False: frame by frame)
         self.defer_head2 = True      # with batch_encode: run the view-2 DPT head once for all steps after the loop
         self.grouped_decoder = True  # bf16: the two decoder sides as grouped launches on one stream (False: two streams)
+        self.packed_features = True  # bf16 + batch_encode + grouped_decoder: decoder_embed / key MLPs read fragment-order bf16 copies of the features (lean instances)
         self.decoder_streams = os.environ.get("SP3_DEC_STREAMS", "1") == "1"   # ungrouped decoder (fp32 mode): two streams with a fork/join per layer, or one stream
         self.force_general = False   # True: always take the reference-shaped eager loop (_forward_general; tests)
         self.max_runners = 4         # geometries (batch, H, W, policy, true_shape) kept with their buffers and graphs
@@ -776,7 +804,8 @@ class Spann3R(nn.Module):
         if dev.type != "cuda":
             raise RuntimeError("spann3r_amd.Spann3R runs on an MI355X only: call .to('cuda') first "
                                "(there is no CPU fallback; the CPU reference lives in oracle/ for tests)")
-        key = (dev, self.precision, self._versions())
+        # (ops.WEIGHTS_EPOCH: optimizers that update through raw pointers / a replayed hipGraph do not move the version counters)
+        key = (dev, self.precision, self._versions(), ops.WEIGHTS_EPOCH)
         if self._engine is None or self._engine_key != key:
             self._engine = Engine(self.cfg, dict(self._params), dev, self.precision)
             self._engine_key = key
@@ -1078,7 +1107,7 @@ class Spann3R(nn.Module):
             has_next = i + 2 < n
             def post(i=i):
                 # after this step's kernels: the next step's pair of encoder features, side 2's hook outputs to their slots
-                nxt = [run.pair_copy(i + 1)] if (run.batched and i + 1 < n - 1) else []
+                nxt = run.pair_copies(i + 1) if (run.batched and i + 1 < n - 1) else []
                 return nxt + (run.dec2_copies(i) if run.defer2 else [])
             res1, res2 = run.run(i == 0, has_next, self.use_graphs, post)
             if not run.defer2:

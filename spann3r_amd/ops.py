@@ -109,7 +109,7 @@ _TILE_NAMES = {0: "32x32xk4", 1: "64x64", 2: "64x128", 3: "64x64xk4", 4: "32x64x
                30: "lean-rope-k1024-48x64xk8", 31: "lean-rope-k768-32x32xk4", 32: "lean-packed-k1024-64x64xk8", 33: "lean-packed-k768-32x32xk4",
                34: "lean-stream-k1024-32x32xk8", 35: "lean-stream-k4096-32x32xk16", 36: "lean-stream-k768-48x32xk6",
                37: "lean-stream-k3072-48x32xk8", 38: "lean-stream-k1792-64x32xk7",
-               40: "lean-conv-16x16xk12", 41: "lean-conv-32x32xk8"}
+               39: "lean-stream-k1024-48x32xk8", 40: "lean-conv-16x16xk12", 41: "lean-conv-32x32xk8", 42: "lean-packed-splitA-k1792-64x32xk7"}
 
 
 def pick_tile(M, N, batch=1, splitk=1, conv=False, K=0, packed_bf16=False, plain=False, ln_nt=0, pipe_ok=False, rope=False):
@@ -334,6 +334,7 @@ class PackedWeightGroup(PackedWeight):
         self.stride = items[0].data.numel()
 
 
+WEIGHTS_EPOCH = 0    # bumped by every optimizer step of spann3r_amd.train (train.invalidate_weight_cache): part of Spann3R.engine's key
 F32X3 = False        # fp32 GEMMs through three bf16 MFMAs per k-block (sp3_gemm_desc.f32x3 = 1); set by the model's "f32x3" precision
 F32X6 = False        # fp32 GEMMs through six bf16 MFMAs of a three-way split (f32x3 = 3): fp32-grade products; "f32x6" precision
 F16X3 = False        # fp32 GEMMs through three fp16 MFMAs of a two-way (h, l * 2^-11) split (f32x3 = 4): 22 operand bits; "f16x3" precision
@@ -560,10 +561,20 @@ def proj_rope_vt(A, W, bias, out_qk, ldc, vt, vt_ld, *, M, N, K, lda, rope_cols,
     _gemm_launch(d, "sp3_gemm(rope_vt)", "plain")
 
 
-def layernorm(x, gamma, beta, eps, out, *, rows, C_, ldx=None, ldo=None, transposed=False):
+def layernorm(x, gamma, beta, eps, out, *, rows, C_, ldx=None, ldo=None, transposed=False, dual=None, group_rows=0):
+    """dual: a bf16 PackedAct(.group) that receives a fragment-order copy in the same launch, rows taken in groups of group_rows,
+    each group starting at a multiple of dual.rows_pad packed rows (sp3_layernorm_dual)"""
     _f32(x, "x")
     ldx = C_ if ldx is None else ldx
     ldo = C_ if ldo is None else ldo
+    if dual is not None:
+        assert dual.dtype == torch.bfloat16 and not transposed and not _is_packed(out)
+        pad = getattr(dual, "rows_pad", (group_rows + 15) // 16 * 16)
+        _timed("layernorm", 8.0 * rows * C_, rows * C_ * 10.0,
+               lambda: L.check(L.load().sp3_layernorm_dual(x.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(), eps, out.data_ptr(), ldo,
+                                                           dual.data_ptr(), rows, C_, group_rows or rows, pad, L.stream_ptr()),
+                               "sp3_layernorm_dual"))
+        return out
     if _is_packed(out):
         _timed("layernorm", 8.0 * rows * C_, rows * C_ * 6.0,
                lambda: L.check(L.load().sp3_layernorm_packed(x.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(), eps,

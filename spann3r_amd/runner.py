@@ -196,6 +196,7 @@ class GradReducer:
                 for p in self.buckets[i]:
                     p.grad = None
         self._touched = [False] * len(self.params)
+        self._reset_pending()
         if self.flat:
             self._attach()
 
@@ -205,8 +206,15 @@ class GradReducer:
             return False
         return self.force or dist.get_world_size(self.group) > 1
 
+    def _reset_pending(self):
+        # direct-to-bucket bookkeeping of spann3r_amd.train (_expect / _contributed): contributions owed by a tape whose backward
+        # never ran (skipped step, a forward under grad that missed the loss) must not silence the next step's hooks
+        for p in self.params:
+            p._sp3_pending = 0
+
     def prepare(self):
         """arm the hooks for the backward pass that follows (overlap=True)"""
+        self._reset_pending()
         self._work = [None] * len(self.buckets)
         self._pending = [len(b) for b in self.buckets]
         self._next = 0

@@ -41,7 +41,7 @@ FLASH_ATTENTION = True   # heads of 64: sp3_attention_train_fwd / _bwd (no atten
 ACT_ON_LOAD = True    # bf16: GELU / ReLU in front of a Linear or 3x3 convolution applied by its pack launch (False: separate activation launches)
 CONV_GATHER = True    # bf16 3x3 convolutions: im2col gathered inside the pack launch (False: sp3_im2col3x3 + pack)
 FUSED_HEADS = True    # attention through _MHA (one shuffle launch each way); False: the separate ATen reshapes + _Attention (tests compare the two)
-_wcache = {}          # id(weight) -> (version, packed W, packed W^T): refreshed when the optimizer has stepped
+_wcache = {}          # (id(weight), derivation) -> (stamp, packed W, packed W^T): one entry per weight, see _packed_weight
 
 
 def set_precision(p):
@@ -54,20 +54,33 @@ def set_precision(p):
 
 
 def invalidate_weight_cache():
+    """Every optimizer of this module calls this after it has written the parameters (also through raw pointers or a replayed
+    hipGraph, which leave the version counters alone): the bf16 weight copies are re-packed at their next use and every
+    inference Engine built from the parameters is rebuilt (ops.WEIGHTS_EPOCH is part of Spann3R.engine's key)."""
     _wcache.clear()
+    ops.WEIGHTS_EPOCH += 1
 
 
 def _packed_weight(W, key):
-    """(W, W^T) of a [N, K] fp32 matrix as bf16 fragment-order GEMM operands.  key: identifies the CONTENT (parameter id, its
-    version, what was derived from it) or None (no caching); optimizers call invalidate_weight_cache() after a step."""
-    ent = _wcache.get(key) if key is not None else None
+    """(W, W^T) of a [N, K] fp32 matrix as bf16 fragment-order GEMM operands.  key = (id of the parameter, what was derived from
+    it, *stamp) or None (no caching): ONE entry per (parameter, derivation), replaced when the stamp (version counter, address)
+    has moved -- a torch optimizer bumps the version every step, so stale entries cannot pile up; optimizers that write through
+    raw pointers call invalidate_weight_cache()."""
+    if key is None:
+        slot = stamp = None
+        ent = None
+    else:
+        slot, stamp = key[:2], key[2:]
+        ent = _wcache.get(slot)
+        if ent is not None and ent[0] != stamp:
+            ent = None
     if ent is None:
         a, t = ops.pack_bf16(W.detach(), True, True)
         N, K = W.shape
-        ent = (ops.PackedWeight.wrap(a.data, N, K), ops.PackedWeight.wrap(t.data, K, N))
-        if key is not None:
-            _wcache[key] = ent
-    return ent
+        ent = (stamp, ops.PackedWeight.wrap(a.data, N, K), ops.PackedWeight.wrap(t.data, K, N))
+        if slot is not None:
+            _wcache[slot] = ent
+    return ent[1], ent[2]
 
 
 def _colsum(dy, out=None):
@@ -107,6 +120,13 @@ def _expect(p):
     """forward side of _into_grad: one more contribution to p.grad is owed by a backward of this tape"""
     if isinstance(p, torch.nn.Parameter):
         p._sp3_pending = getattr(p, "_sp3_pending", 0) + 1
+
+
+def reset_pending(params):
+    """forget contributions owed by tapes that never ran their backward (a skipped step, a branch that missed the loss): called by
+    GradReducer.prepare() / zero_grad() so that the hand-run post-accumulate hooks of the NEXT step fire again"""
+    for p in params:
+        p._sp3_pending = 0
 
 
 def _r8(n):
@@ -325,6 +345,9 @@ class _Linear(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if ctx.bf16 and ctx.WT is None:
+            raise RuntimeError("spann3r_amd.train: second backward through a bf16 Linear (its packed operands are released by the "
+                               "first one; retain_graph=True is not supported)")
         dy = dy.contiguous()
         dev = dy.device
         dx = dW = db = None
@@ -1101,6 +1124,7 @@ class AdamW(torch.optim.Optimizer):
                 g = p.grad.contiguous()
                 L.check(lib.sp3_adamw(p.data_ptr(), g.data_ptr(), st["m"].data_ptr(), st["v"].data_ptr(), p.numel(), float(gr["lr"]), b1, b2,
                                       float(gr["eps"]), float(gr["weight_decay"]), st["step"], float(grad_scale), L.stream_ptr()), "sp3_adamw")
+        invalidate_weight_cache()       # sp3_adamw writes through data_ptr(): version counters do not move
 
 
 def parameter_groups(model, weight_decay):
@@ -1142,9 +1166,7 @@ class TrainStep:
 
     def _body(self, frames, gts, monitor):
         self.reducer.zero_grad()
-        self.reducer.prepare()
-        for p in self.reducer.params:
-            p._sp3_pending = 0
+        self.reducer.prepare()                       # (also resets the direct-to-bucket bookkeeping, train.reset_pending)
         preds, preds_all = self.model(frames)
         loss, details, factor = self.crit.compute_frame_loss(gts, preds_all, monitor=monitor)
         total = loss + factor
@@ -1159,9 +1181,12 @@ class TrainStep:
         if self._g is None:
             clone = lambda d: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in d.items()}
             self._static = ([clone(f) for f in frames], [clone(g) for g in gts])
+            # the warm-up steps (allocator pools, caches, chunk tables) and the capture must not move the trajectory: parameters,
+            # both moments and the step count are put back, so the first REPLAY is update number one of this batch, as in eager mode
+            snap = self.opt.snapshot()
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):                # warm-up off the capture: allocator pools, caches, chunk tables
+            with torch.cuda.stream(side):
                 for _ in range(2):
                     self._body(*self._static, monitor=False)
             torch.cuda.current_stream().wait_stream(side)
@@ -1170,6 +1195,8 @@ class TrainStep:
             self._g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._g):
                 self._out = self._body(*self._static, monitor=False)
+            self.opt.restore(snap)
+            del snap
         else:
             for dst, src in zip(self._static[0] + self._static[1], list(frames) + list(gts)):
                 for k, v in src.items():
@@ -1177,6 +1204,8 @@ class TrainStep:
                         dst[k].copy_(v, non_blocking=True)
         self.opt.sync_lr()
         self._g.replay()
+        self.opt.step_count += 1                     # the device-side count advanced inside the replay
+        invalidate_weight_cache()                    # the replay rewrote the parameters: packed copies / inference engines are stale
         return self._out
 
 
@@ -1248,8 +1277,33 @@ class FlatAdamW:
         self._capture = bool(on)
         self._step_dev.fill_(self.step_count)
 
+    def _base_lr(self):
+        """the learning rate every group's lr is a multiple of: group 0's lr over its own scale"""
+        g0 = self.param_groups[0]
+        return float(g0["lr"]) / float(g0.get("lr_scale", 1.0) or 1.0)
+
+    def _lr_ratio(self, g, base):
+        """lr of group g as a multiple of the base lr: its lr_scale when the group carries one (croco/utils/misc.py:404-455 groups
+        do; valid at lr = 0, i.e. at the first iteration of a warm-up), else lr / base"""
+        if "lr_scale" in g:
+            return float(g["lr_scale"])
+        return float(g["lr"]) / base if base else 1.0
+
     def sync_lr(self):
-        self._lr_dev.fill_(float(self.param_groups[0]["lr"]))
+        self._lr_dev.fill_(self._base_lr())
+
+    def snapshot(self):
+        """parameters, moments and step count (TrainStep restores them behind its warm-up / capture steps)"""
+        return ([t.clone() for t in self.flat_p], [t.clone() for t in self.flat_m], [t.clone() for t in self.flat_v], self.step_count)
+
+    @torch.no_grad()
+    def restore(self, snap):
+        ps, ms, vs, n = snap
+        for dst, src in zip(self.flat_p + self.flat_m + self.flat_v, ps + ms + vs):
+            dst.copy_(src)
+        self.step_count = n
+        self._step_dev.fill_(n)
+        invalidate_weight_cache()
 
     def zero_grad(self, set_to_none=False):
         self.reducer.zero_grad()
@@ -1257,8 +1311,8 @@ class FlatAdamW:
     def _chunk_tables(self, skip):
         """(weight decay, lr / lr of group 0; -1 = skip) per 1024-element chunk and bucket; rebuilt only when the groups' lr ratios,
         weight decays or the skipped set change"""
-        base = self.param_groups[0]["lr"] or 1.0
-        key = (tuple((g["weight_decay"], g["lr"] / base) for g in self.param_groups), tuple(sorted(id(p) for p in skip)))
+        base = self._base_lr()
+        key = (tuple((g["weight_decay"], self._lr_ratio(g, base)) for g in self.param_groups), tuple(sorted(id(p) for p in skip)))
         if key == self._table_key:
             return self._tables
         skip_ids = {id(p) for p in skip}
@@ -1270,8 +1324,13 @@ class FlatAdamW:
                 g = self.param_groups[self._group_of[id(p)]]
                 c0, c1 = o // 1024, (o + p.numel() + 1023) // 1024
                 t[c0:c1, 0] = g["weight_decay"]
-                t[c0:c1, 1] = -1.0 if id(p) in skip_ids else g["lr"] / base
+                t[c0:c1, 1] = -1.0 if id(p) in skip_ids else self._lr_ratio(g, base)
             tabs.append(t.to(gbuf.device))
+        if self._capture and self._tables:
+            # a captured step holds the tables' addresses: new scales / weight decays / skips are written INTO them
+            for old_t, new_t in zip(self._tables, tabs):
+                old_t.copy_(new_t)
+            tabs = self._tables
         self._tables, self._table_key = tabs, key
         return tabs
 
@@ -1293,7 +1352,7 @@ class FlatAdamW:
                                       self._coef.data_ptr(), self._step_dev.data_ptr(), L.stream_ptr()), "sp3_clip_coef")
             coef_ptr, gs = self._coef.data_ptr(), 1.0
         tabs = self._chunk_tables(skip)
-        base = self.param_groups[0]["lr"]
+        base = self._base_lr()
         b1, b2 = self.betas
         for (g, _), fp, fm, fv, tab in zip(bufs, self.flat_p, self.flat_m, self.flat_v, tabs):
             L.check(lib.sp3_adamw_flat(fp.data_ptr(), g.data_ptr(), fm.data_ptr(), fv.data_ptr(), g.numel(), tab.data_ptr(), float(base), b1, b2,

@@ -269,3 +269,50 @@ def test_lean_conv3x3_small_maps(B, H, W, Cin, Cout, stride, variant):
         ref = ref + r1.double() + r2.double()
     assert rel_err(outs[-1], nhwc(ref)) < 2e-5
     assert rel_err(outs[-1], outs[0]) < 2e-5
+
+
+def test_lean_split_a_key_mlp():
+    """first layer of the key MLPs (spann3r/model.py:299-303: Linear(1792, 1792) + GELU on cat(feat, dec[-1])) with both halves of the
+    concatenation as fragment-order bf16 matrices, both MLPs in one launch (tile 42), against the row-major split-A path"""
+    ops = _ops()
+    M, E, D, Kd, G = 196, 1024, 768, 1792, 2
+    f = [rnd(M, E, seed=1 + g) for g in range(G)]
+    nrm = [rnd(M, D, seed=5 + g) for g in range(G)]
+    Fp = ops.PackedAct.group(G, M, E, BF, DEV)
+    Np = ops.PackedAct.group(G, M, D, BF, DEV)
+    for g in range(G):
+        Fp.at(g).data.view(-1)[:Fp.stride].copy_(ops.PackedAct.from_dense(f[g].to(DEV).to(BF)).data.view(-1))
+        Np.at(g).data.view(-1)[:Np.stride].copy_(ops.PackedAct.from_dense(nrm[g].to(DEV).to(BF)).data.view(-1))
+    Wd = [rnd(Kd, Kd, seed=10 + g) * 0.05 for g in range(G)]
+    Ws = ops.PackedWeightGroup([ops.PackedWeight(w.to(DEV).to(BF)) for w in Wd])
+    bias = rnd(G, Kd, seed=3)
+    h = ops.PackedAct.group(G, M, Kd, BF, DEV)
+    planned = _plan_of(ops, lambda: ops.gemm(Fp, Ws, h, M=M, N=Kd, K=Kd, lda=E, ldc=Kd, bias=bias.to(DEV), act=ops.ACT_GELU, A2=Np, lda2=D, K1=E,
+                                             batch=G, strideA=Fp.stride, strideW=Ws.stride, strideC=h.stride,
+                                             sb={"bias": Kd * 4, "A2": Np.stride * 2}))
+    assert planned == [42]
+    # the general kernel on the fp32 row-major halves (what the model ran before)
+    fd, nd = torch.stack(f).to(DEV).to(BF).float().contiguous(), torch.stack(nrm).to(DEV).to(BF).float().contiguous()
+    h0 = ops.PackedAct.group(G, M, Kd, BF, DEV)
+    ops.gemm(fd, Ws, h0, M=M, N=Kd, K=Kd, lda=E, ldc=Kd, bias=bias.to(DEV), act=ops.ACT_GELU, A2=nd, lda2=D, K1=E,
+             batch=G, strideA=M * E, strideW=Ws.stride, strideC=h0.stride, sb={"bias": Kd * 4, "A2": M * D * 4})
+    for g in range(G):
+        ref = F.gelu(torch.cat((bf(f[g]), bf(nrm[g])), 1).double() @ bf(Wd[g]).double().T + bias[g].double())
+        got, old = _dense(ops, h, g, M, Kd).float().cpu(), _dense(ops, h0, g, M, Kd).float().cpu()
+        assert rel_err(got, ref) < 4e-3
+        assert rel_err(got, old) < 8e-3 and float((got != old).float().mean()) < 0.02
+
+
+def test_layernorm_dual_groups():
+    """sp3_layernorm_dual: fp32 rows + a bf16 fragment-order copy whose row groups start on 16-row boundaries"""
+    ops = _ops()
+    G, R, C_ = 3, 196, 768
+    x = rnd(G * R, C_, seed=1) * 3 + 0.5
+    g, b = rnd(C_, seed=2) * 0.3 + 1, rnd(C_, seed=3) * 0.2
+    out = torch.empty(G * R, C_, device=DEV)
+    dual = ops.PackedAct.group(G, R, C_, BF, DEV)
+    ops.layernorm(x.to(DEV), g.to(DEV), b.to(DEV), 1e-6, out, rows=G * R, C_=C_, dual=dual, group_rows=R)
+    ref = F.layer_norm(x.double(), (C_,), g.double(), b.double(), 1e-6)
+    assert rel_err(out.cpu(), ref) < 1e-5
+    for k in range(G):
+        assert torch.equal(_dense(ops, dual, k, R, C_), out[k * R:(k + 1) * R].to(BF))

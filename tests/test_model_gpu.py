@@ -203,11 +203,15 @@ def test_batched_encoder_equals_per_frame(tiny_model):
 
 def test_grouped_decoder_equals_two_stream_decoder(tiny_model):
     """bf16: the decoder as grouped launches (both sides = problems 0/1 of one launch per op, one stream) runs the same
-    kernels on the same operands as the two-stream decoder: bit-identical outputs."""
+    kernels on the same operands as the two-stream decoder: bit-identical outputs.  (packed_features off: with it the grouped
+    path's decoder_embed / key MLPs read bf16 fragment-order copies of the features on lean instances -- same products, another
+    summation order; that variant is held to the bf16 tolerance below.)"""
     from spann3r_amd.weights import synth_frames
     m = tiny_model.set_precision("bf16")
     try:
         frames = to_dev(synth_frames(5, 48, 64, seed=9))
+        c = m(frames, return_memory=True)
+        m.packed_features = False
         a = m(frames, return_memory=True)
         m.grouped_decoder = False
         try:
@@ -215,11 +219,15 @@ def test_grouped_decoder_equals_two_stream_decoder(tiny_model):
         finally:
             m.grouped_decoder = True
     finally:
+        m.packed_features = True
         m.set_precision("fp32")
     for x, y in zip(a[0], b[0]):
         for k in x:
             assert torch.equal(x[k], y[k]), k
     assert torch.equal(a[2].mem_k, b[2].mem_k) and torch.equal(a[2].mem_v, b[2].mem_v)
+    for x, y in zip(a[0], c[0]):
+        for k in x:
+            assert rel_err(x[k].cpu(), y[k].cpu()) < 3e-2, k          # TOL_BF16: rounding flips of bf16 operands downstream of another summation order
 
 
 def test_tiny_training_policy(tiny_model):

@@ -726,12 +726,103 @@ def test_train_step_hip_graph_replay_matches_eager(tiny_sd):
     finally:
         T.set_precision("fp32")
         T.invalidate_weight_cache()
-    # the graph path runs two warm-up steps on its first batch before capturing: compare the LAST step's loss given the same
-    # number of updates is not possible -- compare instead that replays are live (loss changes with the batch) and finite,
-    # and that eager steps of the same batches produce the same first-step loss
+    # warm-up and capture are undone (parameters, moments, step count restored): replay i is update i of the same trajectory
     assert all(map(lambda t: t[0] == t[0] and t[1] > 0, traj[True][0]))
     assert abs(traj[True][0][1][0] - traj[True][0][2][0]) > 0            # different batches -> different losses: inputs are refreshed
     assert not torch.equal(traj[True][1], tiny_sd["dust3r.dec_blocks.1.attn.qkv.weight"].cuda())
+    assert traj[True][2] == traj[False][2] == len(batches)               # host-side step count follows the replays
+    for (le, ne), (lg, ng) in zip(traj[False][0], traj[True][0]):
+        assert abs(le - lg) <= 1e-5 * abs(le) and abs(ne - ng) <= 1e-4 * abs(ne), (traj[False][0], traj[True][0])
+    we, wg = traj[False][1].double(), traj[True][1].double()
+    assert float((we - wg).abs().max() / (we - tiny_sd["dust3r.dec_blocks.1.attn.qkv.weight"].cuda().double()).abs().max()) < 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("graph", [False, True])
+def test_inference_after_training_sees_the_new_weights(tiny_sd, graph):
+    """An Engine built before training must not survive an optimizer step (FlatAdamW re-points .data and, under a hipGraph,
+    never touches the version counters): eval forward after TrainStep == eval forward of a fresh model with the trained weights"""
+    from spann3r_amd import Spann3R, TINY
+    from spann3r_amd import train as T
+    from spann3r_amd.weights import synth_frames
+    n, B, H, W = 3, 1, 32, 48
+    fr = [{"img": f["img"].cuda()} for f in synth_frames(n, H, W, batch=B, seed=3)]
+    gt = _synth_gts(n, B, H, W, 41, torch.float32, "cuda")
+    try:
+        m = Spann3R(dus3r_name=None, cfg=TINY, init_weights=False, memory_dropout=0.0)
+        m.load_state_dict(tiny_sd, strict=True)
+        m = m.cuda().eval()
+        with torch.no_grad():
+            before = m(fr)[0][0]["pts3d"].clone()                        # builds (and caches) the inference engine
+        ts = T.TrainStep(m, precision="fp32", lr=1e-4, graph=graph)
+        for _ in range(2):
+            ts.run(fr, gt)
+        m.eval()
+        with torch.no_grad():
+            after = m(fr)[0][0]["pts3d"].clone()
+        fresh = Spann3R(dus3r_name=None, cfg=TINY, init_weights=False, memory_dropout=0.0)
+        fresh.load_state_dict({k: v.clone() for k, v in m.state_dict().items()}, strict=True)
+        with torch.no_grad():
+            want = fresh.cuda().eval()(fr)[0][0]["pts3d"]
+        assert bool(torch.isfinite(after).all())
+        assert not torch.equal(before, after), "eval forward still runs on the pre-training weights"
+        assert rel_err(after.cpu(), want.cpu()) < 1e-6
+    finally:
+        T.set_precision("fp32")
+        T.invalidate_weight_cache()
+
+
+@pytest.mark.gpu
+def test_graph_captured_at_lr_zero_follows_set_lr(tiny_sd):
+    """the reference's warm-up starts at lr = 0 (croco/utils/misc.py:464-479): a step captured there must still move the weights
+    once set_lr raises the rate (chunk tables hold the groups' lr SCALE, not lr / lr0)"""
+    from spann3r_amd import Spann3R, TINY
+    from spann3r_amd import train as T
+    from spann3r_amd.weights import synth_frames
+    n, B, H, W = 3, 1, 32, 48
+    fr = [{"img": f["img"].cuda()} for f in synth_frames(n, H, W, batch=B, seed=3)]
+    gt = _synth_gts(n, B, H, W, 41, torch.float32, "cuda")
+    try:
+        m = Spann3R(dus3r_name=None, cfg=TINY, init_weights=False, memory_dropout=0.0)
+        m.load_state_dict(tiny_sd, strict=True)
+        ts = T.TrainStep(m.cuda(), precision="fp32", lr=0.0, graph=True)
+        key = "dust3r.dec_blocks.1.attn.qkv.weight"
+        ts.run(fr, gt)
+        w0 = m.state_dict()[key].clone()
+        assert torch.equal(w0, tiny_sd[key].cuda())                      # lr = 0: nothing moves
+        ts.set_lr(1e-4)
+        ts.run(fr, gt)
+        assert not torch.equal(m.state_dict()[key], w0)
+    finally:
+        T.set_precision("fp32")
+        T.invalidate_weight_cache()
+
+
+@pytest.mark.gpu
+def test_weight_cache_is_bounded_and_refreshed():
+    """bf16 packed-weight cache: one entry per (weight, derivation); train.AdamW (raw-pointer update) and torch optimizers
+    (version bump) both lead to a re-pack, neither grows the cache"""
+    from spann3r_amd import train as T
+    try:
+        T.set_precision("bf16")
+        T.invalidate_weight_cache()
+        W = torch.nn.Parameter(torch.randn(64, 128, device="cuda") * 0.1)
+        x = torch.randn(32, 128, device="cuda")
+        for opt in (T.AdamW([W], lr=1e-1), torch.optim.SGD([W], lr=1e-1)):
+            outs = []
+            for _ in range(4):
+                y = T.linear(x, W)
+                outs.append(y.detach().clone())
+                y.square().mean().backward()
+                opt.step()
+                opt.zero_grad(set_to_none=True)
+            assert len(T._wcache) <= 1
+            ref = x.to(torch.bfloat16).double() @ W.detach().to(torch.bfloat16).double().T
+            assert rel_err(T.linear(x, W).detach().cpu(), ref.cpu()) < 1e-5     # the product uses the CURRENT weights
+            assert not torch.equal(outs[0], outs[-1])
+    finally:
+        T.set_precision("fp32")
+        T.invalidate_weight_cache()
 
 
 @pytest.mark.gpu

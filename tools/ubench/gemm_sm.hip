@@ -356,6 +356,78 @@ int main(int argc, char** argv) {
       run<4, 2, 7, 28, 0>(p, "64x32 k7 all");
       release(p); }
   }
+  if (want("dc2")) {
+    { Problem p = make(196, 2304, 768, 330, 2);
+      printf("dec qkv 196x2304x768 x2, more tiles (%d weight copies)\n", p.ncopy);
+      run<2, 2, 4, 12, 0>(p, "32x32 k4 all");
+      run<2, 2, 6, 12, 0>(p, "32x32 k6 all");
+      run<2, 2, 12, 12, 0>(p, "32x32 k12 all");
+      run<2, 4, 4, 12, 0>(p, "32x64 k4 all");
+      run<2, 4, 6, 12, 0>(p, "32x64 k6 all");
+      run<2, 4, 12, 12, 0>(p, "32x64 k12 all");
+      run<3, 2, 6, 12, 0>(p, "48x32 k6 all");
+      run<3, 2, 12, 12, 0>(p, "48x32 k12 all");
+      run<3, 4, 6, 12, 0>(p, "48x64 k6 all");
+      run<3, 4, 12, 12, 0>(p, "48x64 k12 all");
+      run<1, 4, 12, 12, 0>(p, "16x64 k12 all");
+      run<1, 2, 12, 12, 0>(p, "16x32 k12 all");
+      release(p); }
+    { Problem p = make(196, 3072, 768, 330, 2);
+      printf("dec fc1 196x3072x768 x2, more tiles (%d weight copies)\n", p.ncopy);
+      run<2, 2, 4, 12, 0>(p, "32x32 k4 all");
+      run<2, 2, 6, 12, 0>(p, "32x32 k6 all");
+      run<2, 4, 4, 12, 0>(p, "32x64 k4 all");
+      run<2, 4, 6, 12, 0>(p, "32x64 k6 all");
+      run<2, 4, 12, 12, 0>(p, "32x64 k12 all");
+      run<3, 2, 6, 12, 0>(p, "48x32 k6 all");
+      run<3, 4, 6, 12, 0>(p, "48x64 k6 all");
+      run<3, 4, 12, 12, 0>(p, "48x64 k12 all");
+      run<4, 2, 6, 12, 0>(p, "64x32 k6 all");
+      release(p); }
+    { Problem p = make(196, 768, 3072, 330, 2);
+      printf("dec fc2 196x768x3072 x2, more tiles (%d weight copies)\n", p.ncopy);
+      run<3, 2, 8, 48, 3>(p, "48x32 k8 ring3");
+      run<3, 2, 8, 48, 2>(p, "48x32 k8 ring2");
+      run<3, 2, 12, 48, 0>(p, "48x32 k12 all");
+      run<3, 2, 12, 48, 2>(p, "48x32 k12 ring2");
+      run<3, 2, 16, 48, 0>(p, "48x32 k16 all");
+      run<3, 2, 6, 48, 4>(p, "48x32 k6 ring4");
+      run<3, 2, 6, 48, 3>(p, "48x32 k6 ring3");
+      run<2, 2, 12, 48, 0>(p, "32x32 k12 all");
+      run<2, 2, 12, 48, 2>(p, "32x32 k12 ring2");
+      run<4, 2, 8, 48, 3>(p, "64x32 k8 ring3");
+      run<4, 2, 12, 48, 2>(p, "64x32 k12 ring2");
+      run<3, 1, 8, 48, 3>(p, "48x16 k8 ring3");
+      release(p); }
+    { Problem p = make(196, 1024, 4096, 330);
+      printf("val fc2 196x1024x4096, more tiles (%d weight copies)\n", p.ncopy);
+      run<2, 2, 16, 64, 0>(p, "32x32 k16 all");
+      run<3, 2, 8, 64, 3>(p, "48x32 k8 ring3");
+      run<3, 2, 16, 64, 0>(p, "48x32 k16 all");
+      run<3, 2, 16, 64, 2>(p, "48x32 k16 ring2");
+      run<2, 2, 8, 64, 4>(p, "32x32 k8 ring4");
+      run<4, 2, 16, 64, 2>(p, "64x32 k16 ring2");
+      run<4, 1, 16, 64, 0>(p, "64x16 k16 all");
+      release(p); }
+    { Problem p = make(196, 1792, 1792, 330, 2);
+      printf("key0 196x1792x1792 x2 (%d weight copies)\n", p.ncopy);
+      run<2, 2, 4, 28, 3>(p, "32x32 k4 ring3");
+      run<2, 2, 7, 28, 0>(p, "32x32 k7 all");
+      run<4, 2, 7, 28, 0>(p, "64x32 k7 all");
+      run<4, 4, 7, 28, 0>(p, "64x64 k7 all");
+      run<4, 4, 14, 28, 0>(p, "64x64 k14 all");
+      run<3, 4, 14, 28, 0>(p, "48x64 k14 all");
+      run<3, 4, 7, 28, 0>(p, "48x64 k7 all");
+      run<2, 4, 7, 28, 0>(p, "32x64 k7 all");
+      run<2, 4, 14, 28, 0>(p, "32x64 k14 all");
+      release(p); }
+    { Problem p = make(196, 768, 1024, 330, 2);
+      printf("dec_embed 196x768x1024 x2 (%d weight copies)\n", p.ncopy);
+      run<2, 2, 8, 16, 0>(p, "32x32 k8 all");
+      run<3, 2, 8, 16, 0>(p, "48x32 k8 all");
+      run<2, 2, 16, 16, 0>(p, "32x32 k16 all");
+      release(p); }
+  }
   if (want("fc1")) {
     Problem p = make(196, 4096, 1024, 330);
     printf("val fc1 196x4096x1024 (%d weight copies)\n", p.ncopy);
