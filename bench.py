@@ -185,7 +185,7 @@ def kernel_profile(model, seq, precision):
     breakdown = [{"kernel": k, "launches": v["launches"], "ms": round(v["ms"], 4), "avg_us": round(1e3 * v["ms"] / v["launches"], 2),
                   "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else None,
                   "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else None}
-                 for k, v in top[:8]]
+                 for k, v in top[:16]]
     memread = None
     reads = [r for r in prof.region_summary() if r["key"] == "memread"]
     if reads:
@@ -318,6 +318,50 @@ def train_measure(dev, steps, warmup, precision, batch, n_frames=5, size=224, wo
     T.set_precision("fp32")
     del ts, model
     torch.cuda.empty_cache()
+    return out
+
+
+def parity_errors(model, dev, precision="f16x3"):
+    """Errors of `precision` against the committed dumps of the unmodified reference (tests/golden/*.npz: data, not code): the config-2
+    fixture on `model`'s weights and the stress fixture on trained-like weights.  Returns {} when the fixtures are absent."""
+    import numpy as np
+    import torch
+    from spann3r_amd import Spann3R, FULL
+    from spann3r_amd.weights import synth_frames, stress_state_dict
+    out = {}
+    keep = model.precision
+    for tag, name, stress in (("config2", "spann3r_cfg2_224x10.npz", False), ("stress", "spann3r_stress_224x6.npz", True)):
+        path = os.path.join(ROOT, "tests", "golden", name)
+        if not os.path.exists(path):
+            continue
+        g = np.load(path)
+        H, W = map(int, g["meta_hw"])
+        S, n = int(g["meta_sub"]), int(g["meta_frames"])
+        m = model
+        if stress:
+            m = Spann3R(dus3r_name=None, cfg=FULL, init_weights=False)
+            m.load_state_dict(stress_state_dict(7, FULL), strict=True)
+            m = m.to(dev).eval()
+        m.set_precision(precision)
+        frames = [{"img": f["img"].to(dev)} for f in synth_frames(n, H, W)]
+        with torch.no_grad():
+            preds, _ = m(frames)
+        e_max = e_conf = 0.0
+        pp = []
+        for j, p in enumerate(preds):
+            pts = p["pts3d" if j == 0 else "pts3d_in_other_view"][:, ::S, ::S].double().cpu()
+            ref = torch.as_tensor(g["pred%d_pts_sub" % j]).double()
+            e_max = max(e_max, float((pts - ref).abs().max() / ref.abs().max()))
+            pp.append(((pts - ref).norm(dim=-1) / ref.norm(dim=-1).clamp_min(1e-30)).reshape(-1))
+            cr = torch.as_tensor(g["pred%d_conf_sub" % j]).double()
+            e_conf = max(e_conf, float((p["conf"][:, ::S, ::S].double().cpu() - cr).abs().max() / cr.abs().max()))
+        pp = torch.cat(pp)
+        out[tag] = {"pts3d_max_norm": e_max, "conf_max_norm": e_conf, "pts3d_per_point_p999": float(torch.quantile(pp, 0.999)),
+                    "pts3d_per_point_max": float(pp.max()), "frames": n}
+        if stress:
+            del m
+            torch.cuda.empty_cache()
+    model.set_precision(keep)
     return out
 
 
@@ -457,10 +501,11 @@ def main():
                        "frac_of_mfma_peak": fl * 6 / f32_s / 1e12 / PEAK_TFLOPS["fp32"]}
         model.set_precision("f32x3")
         x3_frames, x3_s = time_sequences(model, seqs, 6, 3)
-        out["f32x3"] = {"value": x3_frames / x3_s, "unit": "frames/s", "steps": 6,
+        out["f32x3"] = {"value": x3_frames / x3_s, "unit": "frames/s", "steps": 6, "parity_mode": False,
                         "what": "same workload, fp32 operands with every GEMM product through three bf16 MFMAs of a (hi, lo) split (16 "
-                                "mantissa bits per product, fp32 accumulate): the fast parity mode, held to the same <=1e-3 vs the "
-                                "reference as fp32 (tests/test_model_gpu.py)"}
+                                "mantissa bits per product, fp32 accumulate).  NOT a parity mode: it FAILS the 1e-3 bar on the trained-like "
+                                "stress fixture (1.4e-3 pointmaps / 2.0e-3 mem_attn; <= 4e-4 on the reference-initialised fixtures); "
+                                "kept as a throughput data point only -- the parity-carrying modes are fp32, f32x6 and f16x3"}
         model.set_precision("f32x6")
         x6_frames, x6_s = time_sequences(model, seqs, 6, 3)
         out["f32x6"] = {"value": x6_frames / x6_s, "unit": "frames/s", "steps": 6,
@@ -474,6 +519,14 @@ def main():
                                 "x = h + l * 2^-11 (22 operand bits, fp32 accumulate): the fast fp32-grade mode -- pointmaps within 5e-6 of the reference on "
                                 "the config-2 fixture and 1.6e-4 on the trained-like stress fixture, where f32x3 measures 1.4e-3 and exact fp32 1.4e-4 "
                                 "(tests/test_model_gpu.py)"}
+        # the >= 200 frames/s-at-1e-3 claim as ONE record: the fp32-grade mode's rate next to its errors against the reference
+        # dumps (tests/golden: outputs of the unmodified reference), measured here, now, on this build
+        out["parity_mode"] = {"mode": "f16x3", "value": h3_frames / h3_s, "unit": "frames/s", "tolerance": 1e-3,
+                              "errors_vs_reference": parity_errors(model, dev),
+                              "what": "pointmaps / confidences of the f16x3 mode against dumps of the unmodified reference (torch CPU fp32) on the "
+                                      "config-2 fixture (10 x 224x224, synthetic reference-initialised weights) and the stress fixture (6 frames, "
+                                      "trained-like weight statistics): max-norm relative error max|d| / max|ref| and the 99.9th percentile of the "
+                                      "per-point error |d| / |p|; asserted in tests/test_model_gpu.py"}
         model.set_precision("bf16")
         # how the same GPU fills with more independent work per launch: 4 sequences batched into one forward (B = 4).
         # NOT the headline configuration (BASELINE config 2 is batch 1): reported next to it.

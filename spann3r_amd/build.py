@@ -9,13 +9,35 @@ LIB = os.path.join(HERE, "libspann3r_hip.so")
 SOURCES = ["error.cpp", "gemm.hip", "gemm_sm.hip", "norm_rope.hip", "attention.hip", "memory.hip", "dpt.hip", "conv.hip", "preproc.hip", "loss.hip", "train.hip", "train2.hip", "postproc.hip"]
 
 
+STAMP = LIB + ".srchash"
+
+
+def _deps():
+    return [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_sm.h"),
+                                                      os.path.join(HERE, "..", "include", "spann3r_hip.h"), os.path.abspath(__file__)]
+
+
+def source_hash():
+    """SHA-256 over every source the library is built from (and this recipe, flags included)"""
+    import hashlib
+    h = hashlib.sha256()
+    for d in _deps():
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as f:
+            h.update(f.read())
+    h.update(os.environ.get("SP3_HIPCC_EXTRA", "").encode())
+    return h.hexdigest()
+
+
 def needs_build():
-    if not os.path.exists(LIB):
+    """True unless the .so was built from exactly these sources: the hash recorded next to it (not its mtime -- a stale library
+    that merely looks newer than the tree must not pass) equals the tree's."""
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_sm.h"),
-                                                      os.path.join(HERE, "..", "include", "spann3r_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    try:
+        return open(STAMP).read().strip() != source_hash()
+    except OSError:
+        return True
 
 
 # Packed-FP32 VALU ops (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32, formed by the SLP vectoriser in the GEMM epilogues) are
@@ -50,6 +72,8 @@ def build(force=False, verbose=True):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(source_hash() + "\n")
     return LIB
 
 

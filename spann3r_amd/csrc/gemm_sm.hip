@@ -21,6 +21,7 @@
 #include "common.h"
 #include "gemm_sm.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -340,6 +341,373 @@ __global__ __launch_bounds__(64 * WK) void sm_kernel(const SmArgs a) {
 #undef OPF
 }
 
+// ------------------------------------------------------------------------------------------------ many rows (M > 256)
+// The same three epilogues for the many-row Linears (whole-sequence encoder: M = frames x 196; a 512x512 frame: M = 1024; their
+// K = 768 .. 4096): bm_kernel.  Both operand tiles arrive per workgroup by global_load_lds into a ring of fragment-order stages
+// (the pipelined loop of gemm_kernel<LOOP = -1>: a slot is refilled right behind the barrier that publishes the next stage, two
+// fragment sets per wave so the ds_reads of one half fly under the MFMAs of the other), every wave owns a 64 x (16 NF) output
+// tile over the whole K -- and the MFMA operands are SWAPPED (D = W . A^T): a lane then holds 4 consecutive COLUMNS of one output
+// row, so bias / LayerNorm fold / GELU / residual / RoPE partner (column ^ 16 = the neighbouring fragment of the same lane) /
+// per-32-column statistics / fp32 and fragment-order bf16 stores all happen in registers on 8- and 16-byte row segments: no
+// accumulator round trip through LDS (the general kernel's epilogue cost 12-18 k clocks per 256 x 128 workgroup, half of a
+// K = 1024 launch).  Only the V columns of a q/k/v projection cross LDS once (their PV-operand layout wants 4 consecutive
+// TOKENS per store).
+__device__ __forceinline__ void bm_glds16(const char* gsrc, char* lds) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc, (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+#else
+  (void)gsrc; (void)lds;
+#endif
+}
+
+template <int WM, int WN, int NF, int NKB, int NST, int EPI>
+__global__ __launch_bounds__(64 * WM * WN) void bm_kernel(const SmArgs a) {
+  constexpr int MF = 4, NW = WM * WN, NT = 64 * NW;
+  constexpr int BM = WM * MF * 16, BN = WN * NF * 16;
+  constexpr int NBLK = BM / 16 + BN / 16, STAGE_BYTES = NBLK * 2048, NINSTR = 2 * NBLK, PER = (NINSTR + NW - 1) / NW;
+  constexpr int K = NKB * 64;
+  constexpr bool LNOK = NKB % 4 == 0 && NKB <= 16;
+  static_assert(NST >= 2 && NST <= 4 && PER * (NST - 1) < 64 && NST <= NKB, "stage ring: 2..4 stages, vmcnt is a 6-bit count");
+  static_assert(NF % 2 == 0, "RoPE partner / statistics pairs: an even number of column fragments per wave");
+  extern __shared__ __attribute__((aligned(16))) char lds_b[];
+  const int tid = threadIdx.x, lane = tid & 63, wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave_u % WN, wm = wave_u / WN;
+  const int g = lane >> 4, r16 = lane & 15;
+  const bool second = EPI == SM_ROPE && (int)blockIdx.z >= a.z1;
+#define OPF(f) (second ? a.op[1].f : a.op[0].f)
+  int z = (int)blockIdx.z - (second ? a.z1 : 0);
+  const int ntz = OPF(ntz);
+  const int grp = z >= ntz ? 1 : 0;
+  z -= grp * ntz;
+  const int tile_m = blockIdx.y, tile_n = z * 8 + blockIdx.x;
+  const int N = OPF(N);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  if (n0 >= N) return;
+
+  // ---- DMA pieces of this wave: A row blocks first, then W column blocks (surplus slots repeat the last piece)
+  const char* src[PER];
+  int dst[PER];
+  {
+    const char* A = OPF(A) + grp * OPF(gA);
+    const char* W = OPF(W) + grp * OPF(gW);
+    const int nb_max = (N >> 4) - 1;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      int j = wave_u + i * NW;
+      j = j < NINSTR ? j : NINSTR - 1;
+      const int blk = j >> 1;
+      const char* base;
+      if (blk < BM / 16) {
+        int rb = (m0 >> 4) + blk;
+        rb = rb < a.rb_max ? rb : a.rb_max;                   // rows past M: re-read the last block (masked at the store)
+        base = A + (long)rb * NKB * 2048;
+      } else {
+        int nb = (n0 >> 4) + blk - BM / 16;
+        nb = nb < nb_max ? nb : nb_max;
+        base = W + (long)nb * NKB * 2048;
+      }
+      src[i] = base + (j & 1) * 1024 + lane * 16;
+      dst[i] = j * 1024;
+    }
+  }
+  auto issue = [&](int slot, int kb) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) bm_glds16(src[i] + (long)kb * 2048, lds_b + slot * STAGE_BYTES + dst[i]);
+  };
+  auto wait_pending = [&](int pend) {
+    if (pend >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PER) : "memory");
+    else if (pend == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+    else if (pend == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  // ---- per-row / per-column epilogue operands of this lane (rows m0 + wm*64 + m*16 + r16, columns cw0 + 16 n .. +3), requested
+  // BEFORE the first DMA stages: the LayerNorm partials are reduced right behind the DMA prologue (in-order returns: that wait
+  // retires only these older loads, not the stages), bias / column sums / RoPE positions stay in registers through the loop
+  const float* lnst = OPF(ln_stats);
+  const bool ln = LNOK && lnst != nullptr;
+  float mean[MF], rstd[MF];
+  int grow[MF];
+#pragma unroll
+  for (int m = 0; m < MF; ++m) {
+    grow[m] = m0 + wm * 64 + m * 16 + r16;
+    mean[m] = 0.f; rstd[m] = 1.f;
+  }
+  constexpr int NL4 = LNOK ? NKB / 4 : 1;
+  float4 lp[LNOK ? MF : 1][NL4];
+  if constexpr (LNOK) {
+    if (ln) {
+#pragma unroll
+      for (int m = 0; m < MF; ++m) {
+        const int gm = grow[m] < a.M ? grow[m] : a.M - 1;
+        const float4* ps = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(lnst) + grp * OPF(gstats)) + (long)gm * NKB;
+#pragma unroll
+        for (int q = 0; q < NL4; ++q) lp[m][q] = ps[g + 4 * q];
+      }
+    }
+  }
+  const int cw0 = n0 + wn * NF * 16 + 4 * g;
+  const float* biasp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(OPF(bias)) + grp * OPF(gbias));
+  float4 pb4[NF], ps4[NF];
+#pragma unroll
+  for (int n = 0; n < NF; ++n) {
+    pb4[n] = *reinterpret_cast<const float4*>(biasp + cw0 + n * 16);
+    ps4[n] = ln ? *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(OPF(ln_s)) + grp * OPF(gs)) + cw0 + n * 16)
+                : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  int ppos[EPI == SM_ROPE ? MF : 1][2];
+  if constexpr (EPI == SM_ROPE) {
+#pragma unroll
+    for (int m = 0; m < MF; ++m) {
+      const int gm = grow[m] < a.M ? grow[m] : a.M - 1;
+      ppos[m][0] = a.pos[(long)gm * 2];
+      ppos[m][1] = a.pos[(long)gm * 2 + 1];
+    }
+  }
+#pragma unroll
+  for (int s_ = 0; s_ < NST; ++s_) issue(s_, s_);
+  if constexpr (LNOK) {
+    if (ln) {
+#pragma unroll
+      for (int m = 0; m < MF; ++m) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < NL4; ++q) { s1 += lp[m][q].x + lp[m][q].z; s2 += lp[m][q].y + lp[m][q].w; }
+        s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+        mean[m] = s1 * (1.0f / (float)K);
+        const float var = fmaxf(s2 * (1.0f / (float)K) - mean[m] * mean[m], 0.f);
+        rstd[m] = 1.0f / sqrtf(var + a.ln_eps);
+      }
+    }
+  }
+
+  typedef bf16x8 V16;
+  V16 fa[2][MF], fw[2][NF];
+  f32x4 acc[MF][NF];
+#pragma unroll
+  for (int m = 0; m < MF; ++m)
+#pragma unroll
+    for (int n = 0; n < NF; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto read_half = [&](auto buf_tag, int slot, int half) {
+    constexpr int BUF = decltype(buf_tag)::value;
+    const char* st = lds_b + slot * STAGE_BYTES + half * 1024 + lane * 16;
+#pragma unroll
+    for (int m = 0; m < MF; ++m) fa[BUF][m] = *reinterpret_cast<const V16*>(st + (wm * MF + m) * 2048);
+#pragma unroll
+    for (int n = 0; n < NF; ++n) fw[BUF][n] = *reinterpret_cast<const V16*>(st + (BM / 16 + wn * NF + n) * 2048);
+  };
+  // swapped operands: D = W_frag . A_frag^T -> lane (r16, g) holds output row r16 of row block m, columns 4g .. 4g+3 of column block n
+  auto mma_first = [&](auto buf_tag) {
+    constexpr int BUF = decltype(buf_tag)::value;
+    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[BUF][0], fa[BUF][0], acc[0][0], 0, 0, 0);
+  };
+  auto mma_rest = [&](auto buf_tag) {
+    constexpr int BUF = decltype(buf_tag)::value;
+#pragma unroll
+    for (int m = 0; m < MF; ++m)
+#pragma unroll
+      for (int n = 0; n < NF; ++n)
+        if (m + n > 0) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[BUF][n], fa[BUF][m], acc[m][n], 0, 0, 0);
+  };
+  auto sync_stage = [&](int s) {
+    const int newer = NKB - 1 - s;
+    wait_pending(newer < NST - 2 ? newer : NST - 2);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (s + NST - 1 < NKB) issue((s + NST - 1) % NST, s + NST - 1);
+  };
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, 1>;
+  wait_pending(NST - 1);
+  asm volatile("s_barrier" ::: "memory");
+  int slot = 0;
+  read_half(B0{}, 0, 0);
+  for (int i = 0; i < NKB; ++i) {
+    mma_first(B0{});
+    __builtin_amdgcn_sched_barrier(0);
+    read_half(B1{}, slot, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mma_rest(B0{});
+    mma_first(B1{});
+    __builtin_amdgcn_sched_barrier(0);
+    slot = slot + 1 == NST ? 0 : slot + 1;
+    if (i + 1 < NKB) {
+      sync_stage(i + 1);
+      read_half(B0{}, slot, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    mma_rest(B1{});
+  }
+
+  // ---- epilogue, in registers.  Column group of (n, this lane): cw0 + 16 n .. +3
+  // y = rstd * acc - rstd * mean * s + bias (folded LayerNorm), else acc + bias
+  auto finish = [&](int m, int n, float (&v)[4]) {
+    const float4 b4 = pb4[n];
+    v[0] = acc[m][n][0]; v[1] = acc[m][n][1]; v[2] = acc[m][n][2]; v[3] = acc[m][n][3];
+    if (ln) {
+      const float4 s4 = ps4[n];
+      const float rm = rstd[m] * mean[m];
+      v[0] = rstd[m] * v[0] - rm * s4.x; v[1] = rstd[m] * v[1] - rm * s4.y;
+      v[2] = rstd[m] * v[2] - rm * s4.z; v[3] = rstd[m] * v[3] - rm * s4.w;
+    }
+    v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+  };
+
+  if constexpr (EPI == SM_ROPE) {
+    const int rope_cols = OPF(rope_cols);
+    const int c_wave = n0 + wn * NF * 16;                         // first column of this wave (a multiple of 32)
+    if (c_wave >= rope_cols) {
+      // ---- V columns: PV-operand order wants 4 consecutive TOKENS of one column per store -> this wave's tile crosses LDS once
+      __syncthreads();                                            // (the stage ring is dead; every wave of the workgroup gets here: n0 is workgroup-uniform, c_wave is not)
+      constexpr int LDV = NF * 16 + 4;
+      float* tl = reinterpret_cast<float*>(lds_b) + (size_t)wave_u * 64 * LDV;
+#pragma unroll
+      for (int m = 0; m < MF; ++m)
+#pragma unroll
+        for (int n = 0; n < NF; ++n) {
+          float v[4];
+          finish(m, n, v);
+          *reinterpret_cast<float4*>(tl + (m * 16 + r16) * LDV + n * 16 + 4 * g) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // own tile only: no barrier
+      __bf16* vt = reinterpret_cast<__bf16*>(OPF(vt) + grp * OPF(gvt));
+      for (int idx = lane; idx < 16 * NF * 16; idx += 64) {       // 16 row quads x NF*16 columns
+        const int rq = idx & 15, col = idx >> 4;
+        const int gm = m0 + wm * 64 + 4 * rq, gn = c_wave + col;
+        if (gm >= a.M) continue;
+        const int vc = gn - rope_cols;
+        const int h = vc >> 6, dd = vc & 63;
+        const int b = (int)__umulhi((unsigned)gm, a.tok_magic), n_ = gm - b * a.tokens;
+        const int u = n_ >> 5, kk = n_ & 31, w16 = kk & 15;
+        const int e = 4 * (kk >> 4), lane_ = (w16 >> 2) * 16 + (dd & 15);
+        const long nU = a.vt_ld >> 5;
+        const long off = ((((long)(b * a.heads + h) * nU + u) * 4 + (dd >> 4)) * 64 + lane_) * 8 + e;
+        bf16x4 ob;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ob[i] = (__bf16)tl[(4 * rq + i) * LDV + col];
+        *reinterpret_cast<bf16x4*>(vt + off) = ob;
+      }
+      return;
+    }
+    if (n0 + BN > rope_cols) __syncthreads();                     // pairs with the V waves' barrier in a tile that straddles rope_cols
+    // ---- q / k columns: the RoPE partner of column block n is block n ^ 1 (column ^ 16), same lane
+    __bf16* out = reinterpret_cast<__bf16*>(OPF(C) + grp * OPF(gC));
+#pragma unroll
+    for (int m = 0; m < MF; ++m) {
+      const int gm = grow[m];
+      if (gm >= a.M) continue;
+      const int b = (int)__umulhi((unsigned)gm, a.tok_magic), n_ = gm - b * a.tokens;
+      const int prow = b * a.vt_ld + n_;
+      const int py = ppos[m][0], px = ppos[m][1];
+#pragma unroll
+      for (int n = 0; n < NF; n += 2) {
+        const int hc = (c_wave + n * 16) & 63;                    // 0 or 32: axis
+        const int p = (hc >> 5) ? px : py;
+        const float4 cs4 = *reinterpret_cast<const float4*>(a.cos + p * 16 + 4 * g);
+        const float4 sn4 = *reinterpret_cast<const float4*>(a.sin + p * 16 + 4 * g);
+        const float cs[4] = {cs4.x, cs4.y, cs4.z, cs4.w}, sn[4] = {sn4.x, sn4.y, sn4.z, sn4.w};
+        float v0[4], v1[4];
+        finish(m, n, v0);
+        finish(m, n + 1, v1);
+        bf16x4 o0, o1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o0[e] = (__bf16)(v0[e] * cs[e] - v1[e] * sn[e]);       // first half of the pair: x cos - y sin
+          o1[e] = (__bf16)(v1[e] * cs[e] + v0[e] * sn[e]);       // second half:           y cos + x sin
+        }
+        *reinterpret_cast<bf16x4*>(out + packed_off(prow, cw0 + n * 16, rope_cols, true)) = o0;
+        *reinterpret_cast<bf16x4*>(out + packed_off(prow, cw0 + n * 16 + 16, rope_cols, true)) = o1;
+      }
+    }
+  } else if constexpr (EPI == SM_PACKED) {
+    __bf16* out = reinterpret_cast<__bf16*>(OPF(C) + grp * OPF(gC));
+    const bool gelu = OPF(act) == SP3_ACT_GELU;
+#pragma unroll
+    for (int m = 0; m < MF; ++m) {
+      const int gm = grow[m];
+      if (gm >= a.M) continue;
+#pragma unroll
+      for (int n = 0; n < NF; ++n) {
+        float v[4];
+        finish(m, n, v);
+        if (gelu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+        }
+        bf16x4 ob;
+        ob[0] = (__bf16)v[0]; ob[1] = (__bf16)v[1]; ob[2] = (__bf16)v[2]; ob[3] = (__bf16)v[3];
+        *reinterpret_cast<bf16x4*>(out + packed_off(gm, cw0 + n * 16, N, true)) = ob;
+      }
+    }
+  } else {
+    float* out = reinterpret_cast<float*>(OPF(C) + grp * OPF(gC));
+    float* so = OPF(stats_out);
+    __bf16* c2 = reinterpret_cast<__bf16*>(OPF(c2));
+    const float* res = OPF(res1);
+    if (so) so = reinterpret_cast<float*>(reinterpret_cast<char*>(so) + grp * OPF(gso));
+    if (c2) c2 = reinterpret_cast<__bf16*>(reinterpret_cast<char*>(c2) + grp * OPF(gc2));
+    if (res) res = reinterpret_cast<const float*>(reinterpret_cast<const char*>(res) + grp * OPF(gres));
+    const int ldc = OPF(ldc);
+#pragma unroll
+    for (int m = 0; m < MF; ++m) {
+      const int gm = grow[m];
+      const bool ok = gm < a.M;
+      const int gmc = ok ? gm : a.M - 1;
+      float4 r4[NF];
+#pragma unroll
+      for (int n = 0; n < NF; ++n) r4[n] = res ? *reinterpret_cast<const float4*>(res + (long)gmc * N + cw0 + n * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int n = 0; n < NF; n += 2) {
+        float v0[4], v1[4];
+        finish(m, n, v0);
+        finish(m, n + 1, v1);
+        v0[0] += r4[n].x; v0[1] += r4[n].y; v0[2] += r4[n].z; v0[3] += r4[n].w;
+        v1[0] += r4[n + 1].x; v1[1] += r4[n + 1].y; v1[2] += r4[n + 1].z; v1[3] += r4[n + 1].w;
+        if (so) {
+          // per-32-column (sum, sum of squares): column blocks n, n+1 of the 4 lanes that share the row (all lanes take part)
+          float s1 = ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]));
+          float s2 = ((v0[0] * v0[0] + v0[1] * v0[1]) + (v0[2] * v0[2] + v0[3] * v0[3])) + ((v1[0] * v1[0] + v1[1] * v1[1]) + (v1[2] * v1[2] + v1[3] * v1[3]));
+          s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+          s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+          if (ok && g == 0) reinterpret_cast<float2*>(so)[(long)gm * (N >> 5) + ((cw0 + n * 16) >> 5)] = make_float2(s1, s2);
+        }
+        if (ok) {
+          if (c2) {
+            bf16x4 o0, o1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o0[e] = (__bf16)v0[e]; o1[e] = (__bf16)v1[e]; }
+            *reinterpret_cast<bf16x4*>(c2 + packed_off(gm, cw0 + n * 16, N, true)) = o0;
+            *reinterpret_cast<bf16x4*>(c2 + packed_off(gm, cw0 + n * 16 + 16, N, true)) = o1;
+          }
+          *reinterpret_cast<float4*>(out + (long)gm * ldc + cw0 + n * 16) = make_float4(v0[0], v0[1], v0[2], v0[3]);
+          *reinterpret_cast<float4*>(out + (long)gm * ldc + cw0 + n * 16 + 16) = make_float4(v1[0], v1[1], v1[2], v1[3]);
+        }
+      }
+    }
+  }
+#undef OPF
+}
+
+template <int WM, int WN, int NF, int NKB, int NST, int EPI>
+int bm_launch(const SmArgs& a, int mt, int nz, hipStream_t stream) {
+  constexpr int BM = WM * 64, BN = WN * NF * 16;
+  constexpr size_t ring = (size_t)NST * (BM / 16 + BN / 16) * 2048;
+  constexpr size_t vtile = (size_t)WM * WN * 64 * (NF * 16 + 4) * sizeof(float);     // the V columns' transposition (ROPE epilogue)
+  constexpr size_t lds = ring > vtile ? ring : vtile;
+  static_assert(lds <= 160 * 1024, "stage ring must fit the LDS");
+  auto kern = bm_kernel<WM, WN, NF, NKB, NST, EPI>;
+  if (lds > 64 * 1024) {
+    static bool raised = false;
+    if (!raised) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) { sp3_set_error("sp3_gemm (lean, many rows): cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e)); return 2; }
+      raised = true;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(8, mt, nz), dim3(64 * WM * WN), lds, stream, a);
+  SP3_LAUNCH_CHECK("sp3_gemm (lean, many rows)");
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ small-map 3x3 convolutions
 // The DPT heads' 3x3 convolutions on maps of <= 1024 pixels (croco/models/dpt_block.py:33-75,95-113: layer_rn, the
 // ResidualConvUnits of refinenet 2-4, act_postprocess[3] at 7x7 .. 28x28 of a 224x224 frame): M = pixels is tiny, K = 9 Cin is
@@ -520,11 +888,15 @@ int conv_sm_dispatch(const sp3_gemm_desc& d, int tile, hipStream_t stream) {
 
 // ------------------------------------------------------------------------------------------------ host side
 struct SmInst {
-  int tile, epi, K, MF, NF, WK;
+  int tile, epi, K, MF, NF, WK;     // small-M family: tile = 16 MF x 16 NF, K over WK waves; many-row family: see bm / bn
   bool split;                       // serves descriptors with a second A source (and only those)
   int min_n;                        // N range this instance is the choice for (per problem)
   int max_n;
   int (*launch)(const SmArgs&, int mt, int nz, hipStream_t);
+  int min_m = 1, max_m = 256;       // row range (small-M family: M <= 256)
+  int bm = 0, bn = 0;               // many-row family (bm_kernel): workgroup tile
+  int tile_m() const { return bm ? bm : MF * 16; }
+  int tile_n() const { return bn ? bn : NF * 16; }
 };
 
 template <int MF, int NF, int WK, int NKB, int RING, int EPI, bool SPLIT = false>
@@ -563,8 +935,19 @@ const SmInst kInst[] = {
     {36, SM_STREAM, 768, 3, 2, 6, false, 0, 1 << 30, sm_launch<3, 2, 6, 12, 0, SM_STREAM>},   // dec proj / cproj x2, pos patch embed: 48x32 k6
     {37, SM_STREAM, 3072, 3, 2, 8, false, 0, 1 << 30, sm_launch<3, 2, 8, 48, 3, SM_STREAM>},  // dec fc2 x2: 48x32 k8, ring of 3
     {38, SM_STREAM, 1792, 4, 2, 7, false, 0, 1 << 30, sm_launch<4, 2, 7, 28, 0, SM_STREAM>},  // key MLP out x2: 64x32 k7
+    // ---- many rows (bm_kernel<WM, WN, NF, NKB, NST, EPI>): 256x128 (8 waves) from 1536 rows on, else 128x128 / 128x64 (4 waves)
+    {50, SM_ROPE, 1024, 4, 4, 1, false, 0, 1 << 30, bm_launch<4, 2, 4, 16, 3, SM_ROPE>, 1536, 1 << 30, 256, 128},     // encoder q/k/v (M = frames x 196)
+    {51, SM_ROPE, 1024, 4, 4, 1, false, 0, 1 << 30, bm_launch<2, 2, 4, 16, 3, SM_ROPE>, 257, 1535, 128, 128},
+    {52, SM_ROPE, 768, 4, 4, 1, false, 0, 1 << 30, bm_launch<2, 2, 4, 12, 3, SM_ROPE>, 257, 1 << 30, 128, 128},       // decoder q/k/v + cross k/v at 512x512
+    {53, SM_PACKED, 1024, 4, 4, 1, false, 0, 1 << 30, bm_launch<4, 2, 4, 16, 3, SM_PACKED>, 1536, 1 << 30, 256, 128},  // encoder fc1
+    {54, SM_PACKED, 1024, 4, 4, 1, false, 0, 1 << 30, bm_launch<2, 2, 4, 16, 3, SM_PACKED>, 257, 1535, 128, 128},
+    {55, SM_PACKED, 768, 4, 4, 1, false, 0, 1 << 30, bm_launch<2, 2, 4, 12, 3, SM_PACKED>, 257, 1 << 30, 128, 128},
+    {56, SM_STREAM, 1024, 4, 2, 1, false, 0, 1 << 30, bm_launch<2, 2, 2, 16, 3, SM_STREAM>, 257, 1 << 30, 128, 64},    // encoder proj
+    {57, SM_STREAM, 4096, 4, 2, 1, false, 0, 1 << 30, bm_launch<2, 2, 2, 64, 3, SM_STREAM>, 257, 1 << 30, 128, 64},    // encoder fc2
+    {58, SM_STREAM, 768, 4, 2, 1, false, 0, 1 << 30, bm_launch<2, 2, 2, 12, 3, SM_STREAM>, 257, 1 << 30, 128, 64},
+    {59, SM_STREAM, 3072, 4, 2, 1, false, 0, 1 << 30, bm_launch<2, 2, 2, 48, 3, SM_STREAM>, 257, 1 << 30, 128, 64},
+    {60, SM_STREAM, 1792, 4, 2, 1, false, 0, 1 << 30, bm_launch<2, 2, 2, 28, 3, SM_STREAM>, 257, 1 << 30, 128, 64},
 };
-
 bool sm_enabled() {
   static const bool on = [] { const char* e = getenv("SP3_LEAN_GEMM"); return !(e && e[0] == '0'); }();
   return on;
@@ -582,7 +965,8 @@ const SmInst* sm_find(const sp3_gemm_desc& d) {
       d.trace || d.sm_stats_out || d.sm_stats || d.alpha != 1.0f || d.f32x3)
     return nullptr;
   if (d.splitk > 1 || d.epi == SP3_EPI_PARTIAL || d.epi == SP3_EPI_PIXSHUF) return nullptr;
-  if (d.batch > 2 || d.M > 256 || d.M < 1 || (d.ldw > 0 && d.ldw != d.K) || !d.bias) return nullptr;
+  static const bool big_on = [] { const char* e = getenv("SP3_LEAN_BIG"); return !(e && e[0] == '0'); }();
+  if (d.batch > 2 || d.M < 1 || d.M >= 65536 || (d.M > 256 && !big_on) || (d.ldw > 0 && d.ldw != d.K) || !d.bias) return nullptr;
   const int kind = sm_kind(d);
   if (kind == SM_ROPE) {
     if (!d.qkv_packed || d.rope_cols % 64 || d.N % 64 || (d.tokens & 3) || d.tokens <= 0 || d.tokens >= 65536 || d.vt_ld % 64) return nullptr;
@@ -598,9 +982,10 @@ const SmInst* sm_find(const sp3_gemm_desc& d) {
   const bool split = d.A2 != nullptr;
   if (split && (d.K1 % 64 || d.K1 <= 0 || d.K1 >= d.K)) return nullptr;
   for (const SmInst& s : kInst) {
-    if (s.epi != kind || s.K != d.K || s.split != split) continue;
-    if (d.N % (s.NF * 16) || d.N < s.min_n || d.N > s.max_n) continue;
-    if (d.ln_stats && s.MF * 16 * 4 > 64 * s.WK) continue;
+    if (s.epi != kind || s.K != d.K || s.split != split || d.M < s.min_m || d.M > s.max_m) continue;
+    if (d.N % s.tile_n() || d.N < s.min_n || d.N > s.max_n) continue;
+    if (!s.bm && d.ln_stats && s.MF * 16 * 4 > 64 * s.WK) continue;
+    if (s.bm && kind == SM_ROPE && d.rope_cols % 32) continue;
     return &s;
   }
   return nullptr;
@@ -621,7 +1006,7 @@ void sm_fill(SmOp& o, const sp3_gemm_desc& d, const SmInst& s) {
   o.gbias = G * d.sb_bias; o.gres = G * (long)d.M * d.ldr1 * 4; o.gstats = G * d.sb_ln_stats; o.gs = G * d.sb_ln_s;
   o.gso = G * d.sb_stats_out; o.gc2 = G * d.sb_c2; o.gvt = G * d.sb_vt;
   o.N = d.N;
-  o.ntz = (d.N / (s.NF * 16) + 7) / 8;
+  o.ntz = (d.N / s.tile_n() + 7) / 8;
   o.ldc = (int)d.ldc;
   o.rope_cols = d.rope_cols;
   o.act = d.act;
@@ -673,6 +1058,6 @@ int sp3_gemm_sm_launch(const sp3_gemm_desc& d, const sp3_gemm_desc* pair, hipStr
   a.vt_ld = (int)d.vt_ld;
   a.tok_magic = (unsigned)((1ull << 32) / (unsigned)a.tokens + 1);
   a.ln_eps = d.ln_eps;
-  const int mt = (d.M + s->MF * 16 - 1) / (s->MF * 16);
+  const int mt = (d.M + s->tile_m() - 1) / s->tile_m();
   return s->launch(a, mt, nz, stream);
 }

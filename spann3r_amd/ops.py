@@ -109,7 +109,11 @@ _TILE_NAMES = {0: "32x32xk4", 1: "64x64", 2: "64x128", 3: "64x64xk4", 4: "32x64x
                30: "lean-rope-k1024-48x64xk8", 31: "lean-rope-k768-32x32xk4", 32: "lean-packed-k1024-64x64xk8", 33: "lean-packed-k768-32x32xk4",
                34: "lean-stream-k1024-32x32xk8", 35: "lean-stream-k4096-32x32xk16", 36: "lean-stream-k768-48x32xk6",
                37: "lean-stream-k3072-48x32xk8", 38: "lean-stream-k1792-64x32xk7",
-               39: "lean-stream-k1024-48x32xk8", 40: "lean-conv-16x16xk12", 41: "lean-conv-32x32xk8", 42: "lean-packed-splitA-k1792-64x32xk7"}
+               39: "lean-stream-k1024-48x32xk8", 40: "lean-conv-16x16xk12", 41: "lean-conv-32x32xk8", 42: "lean-packed-splitA-k1792-64x32xk7",
+               # many-row lean instances (bm_kernel: LDS-staged operands, epilogue in registers)
+               50: "lean-rope-k1024-256x128", 51: "lean-rope-k1024-128x128", 52: "lean-rope-k768-128x128", 53: "lean-packed-k1024-256x128",
+               54: "lean-packed-k1024-128x128", 55: "lean-packed-k768-128x128", 56: "lean-stream-k1024-128x64", 57: "lean-stream-k4096-128x64",
+               58: "lean-stream-k768-128x64", 59: "lean-stream-k3072-128x64", 60: "lean-stream-k1792-128x64"}
 
 
 def pick_tile(M, N, batch=1, splitk=1, conv=False, K=0, packed_bf16=False, plain=False, ln_nt=0, pipe_ok=False, rope=False):
@@ -459,7 +463,7 @@ def conv3x3(x, Wp, out, *, B, H, W_, Cin, Cout, stride=1, bias=None, res1=None, 
     Wp is the weight packed as [Cout, 9*Cin] with k = (ky*3+kx)*Cin + ci."""
     OH, OW = (H - 1) // stride + 1, (W_ - 1) // stride + 1
     if (tile < 0 and stride == 1 and isinstance(Wp, PackedWeight) and Wp.dtype == torch.bfloat16
-            and Cin % 64 == 0 and Cout % 64 == 0 and Cin <= 768 and (force_tile_kernel or H * W_ >= 2048)):
+            and Cin % 64 == 0 and Cout % 64 == 0 and Cin <= 768 and (force_tile_kernel or B * H * W_ >= 2048)):
         # bf16 weights, stride 1: the LDS-tiled kernel (input halo tile staged once, 9 taps read it from LDS)
         _act(x, "x")
         _timed("conv3x3_tile", 2.0 * B * H * W_ * Cout * 9 * Cin,

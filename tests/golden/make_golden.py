@@ -132,7 +132,7 @@ def run_with_taps(m, frames):
 
 
 def npf(t):
-    return t.detach().cpu().numpy().astype(np.float32)
+    return t.detach().float().cpu().numpy().astype(np.float32)
 
 
 def make_tiny():
@@ -282,6 +282,46 @@ def make_sequence_fixture(name, H, W, NF, train_policy, S, keep=None, stress=Fal
     out["mem_wm_lm"] = np.array([sp.wm, sp.lm])
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
     print("%s: %d arrays" % (name, len(out)))
+
+
+def make_autocast():
+    """The reference ITSELF under torch's bf16 autocast (CPU), on the config-2 and the stress workloads: its max-norm errors against
+    its own fp32 run (the committed fixtures) anchor the bf16 tolerance of tests/test_model_gpu.py -- the bf16 mode of the MI355X
+    build must not be worse than 1.5x what bf16 autocast does to the reference (the DPT heads stay fp32 there too: model.py:327-329)."""
+    out = {}
+    for tag, name, H, W, NF, S, stress in (("cfg2", "spann3r_cfg2_224x10", 224, 224, 10, 4, False),
+                                           ("stress", "spann3r_stress_224x6", 224, 224, 6, 4, True)):
+        g = np.load(os.path.join(HERE, name + ".npz"))
+        sd = stress_state_dict(7, FULL) if stress else synth_state_dict(0, FULL)
+        m = build_reference(FULL, sd, name)
+        frames = synth_frames(NF, H, W)
+        t = time.time()
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            preds, preds_all, sp, steps = run_with_taps(m, frames)
+        print("%s: reference forward under bf16 autocast %.1f s" % (name, time.time() - t))
+
+        def rel(a, b):
+            a, b = torch.as_tensor(np.asarray(a)).double(), torch.as_tensor(np.asarray(b)).double()
+            return float((a - b).abs().max() / b.abs().max())
+        err = {"pts": 0.0, "conf": 0.0, "pts2": 0.0, "fuse": 0.0, "k": 0.0}
+        for j, p in enumerate(preds):
+            pts = p["pts3d" if j == 0 else "pts3d_in_other_view"]
+            err["pts"] = max(err["pts"], rel(npf(pts[:, ::S, ::S]), g["pred%d_pts_sub" % j]))
+            err["conf"] = max(err["conf"], rel(npf(p["conf"][:, ::S, ::S]), g["pred%d_conf_sub" % j]))
+        for i, (_, r2) in enumerate(preds_all):
+            err["pts2"] = max(err["pts2"], rel(npf(r2["pts3d_in_other_view"][:, ::S, ::S]), g["step%d_pts2_sub" % i]),
+                              rel(npf(r2["conf"][:, ::S, ::S]), g["step%d_conf2_sub" % i]))
+        for i, st in enumerate(steps):
+            if i > 0:
+                err["fuse"] = max(err["fuse"], rel(npf(st["feat_fuse"].float()[:, ::7, ::16]), g["s%d_feat_fuse_sub" % i]))
+            err["k"] = max(err["k"], rel(npf(st["feat_k1"].float()[:, ::7, ::16]), g["s%d_feat_k1_sub" % i]),
+                           rel(npf(st["feat_k2"].float()[:, ::7, ::16]), g["s%d_feat_k2_sub" % i]))
+        err["mem_attn"] = rel(npf(sp.mem_attn.float()), g["mem_attn"])
+        print(tag, {k: "%.2e" % v for k, v in err.items()})
+        for k, v in err.items():
+            out["%s_%s" % (tag, k)] = np.array(v)
+    np.savez_compressed(os.path.join(HERE, "reference_bf16_autocast.npz"), **out)
+    print("reference_bf16_autocast: %d arrays" % len(out))
 
 
 def make_trueshape():
@@ -585,6 +625,8 @@ if __name__ == "__main__":
     what = sys.argv[1:] or ["tiny", "full", "memory"]
     if "pnp" in what:
         make_pnp()
+    if "autocast" in what:
+        make_autocast()
     if "crop" in what:
         make_crop()
     if "usefeat" in what:

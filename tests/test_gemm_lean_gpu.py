@@ -64,6 +64,14 @@ def _plan_of(ops, fn):
     (196, 1024, 1792, 2, False, True, False),     # key MLP out                      -> tile 38
     (100, 768, 768, 1, True, True, False),        # ragged M
     (256, 1024, 1024, 1, True, True, False),
+    # many rows (bm_kernel): whole-sequence encoder (10 frames x 196 tokens), a 512x512 frame (1024 tokens)
+    (1960, 1024, 1024, 1, True, True, False),     # encoder proj            -> tile 56
+    (1960, 1024, 4096, 1, True, True, False),     # encoder fc2             -> tile 57
+    (1024, 768, 768, 2, True, True, False),       # decoder proj at 512x512 -> tile 58
+    (1024, 768, 3072, 2, True, True, False),      #         fc2             -> tile 59
+    (1024, 1024, 1792, 2, False, True, False),    # key MLP out             -> tile 60
+    (1024, 1024, 1024, 1, True, False, True),     # value_out at 512x512: folded LayerNorm
+    (300, 1024, 1024, 1, True, True, False),      # ragged: last row block half empty
 ])
 def test_lean_stream(M, N, K, G, res, stats, ln):
     ops = _ops()
@@ -122,7 +130,8 @@ def test_lean_stream(M, N, K, G, res, stats, ln):
             assert rel_err(st[..., 1], (xr * xr).reshape(M, N // 32, 32).sum(-1)) < 1e-5
 
 
-@pytest.mark.parametrize("M,N,K,G,act", [(196, 4096, 1024, 1, "gelu"), (196, 3072, 768, 2, "gelu"), (196, 3072, 768, 1, "none"), (60, 4096, 1024, 1, "gelu")])
+@pytest.mark.parametrize("M,N,K,G,act", [(196, 4096, 1024, 1, "gelu"), (196, 3072, 768, 2, "gelu"), (196, 3072, 768, 1, "none"), (60, 4096, 1024, 1, "gelu"),
+                                         (1960, 4096, 1024, 1, "gelu"), (1024, 4096, 1024, 1, "gelu"), (1024, 3072, 768, 2, "gelu"), (500, 3072, 768, 1, "none")])
 def test_lean_packed_fc1(M, N, K, G, act):
     """norm (folded) + fc1 + GELU into fragment order (croco/models/blocks.py:74-75,129)"""
     ops = _ops()
@@ -165,7 +174,9 @@ def _pos(B, nh, nw):
 
 
 @pytest.mark.parametrize("B,nh,nw,C,heads,kind", [(1, 14, 14, 1024, 16, "qkv"), (1, 14, 14, 768, 12, "qkv"), (1, 14, 14, 768, 12, "q"),
-                                                   (2, 10, 10, 768, 12, "qkv"), (2, 8, 12, 1024, 16, "kv")])
+                                                   (2, 10, 10, 768, 12, "qkv"), (2, 8, 12, 1024, 16, "kv"),
+                                                   (10, 14, 14, 1024, 16, "qkv"), (1, 32, 32, 1024, 16, "qkv"), (1, 32, 32, 768, 12, "qkv"),
+                                                   (1, 32, 32, 768, 12, "kv"), (1, 32, 32, 768, 12, "q"), (3, 14, 14, 768, 12, "qkv")])
 def test_lean_rope_vt(B, nh, nw, C, heads, kind):
     """q/k/v projection with folded LayerNorm, bias, 2-D RoPE and the attention kernel's layouts: lean instance vs general kernel"""
     from spann3r_amd.engine import _rope_tables
@@ -194,25 +205,27 @@ def test_lean_rope_vt(B, nh, nw, C, heads, kind):
     (q1, v1), (q0, v0) = outs[-1], outs[0]
     assert float(q1.abs().max()) > 0.1
     assert rel_err(q1, q0) < 8e-3 and float((q1 != q0).float().mean()) < 0.02
-    pad = q1.reshape(B, npad, rope_cols)[:, P:]
-    assert float(pad.abs().max()) == 0.0
+    if npad > P:
+        pad = q1.reshape(B, npad, rope_cols)[:, P:]
+        assert float(pad.abs().max()) == 0.0
     if v1 is not None:
         assert float(v1.abs().max()) > 0.1
         assert rel_err(v1, v0) < 8e-3 and float((v1 != v0).float().mean()) < 0.02
 
 
-def test_lean_pair_equals_two_launches():
+@pytest.mark.parametrize("M,npad,grid", [(196, 256, 14), (1024, 1024, 32)])
+def test_lean_pair_equals_two_launches(M, npad, grid):
     """sp3_gemm2 on a lean instance (a decoder layer's q/k/v + cross k/v projections, both sides): bit-identical to the two launches"""
     from spann3r_amd.engine import _rope_tables
     ops = _ops()
-    M, K, heads, P, npad, B = 196, 768, 12, 196, 256, 1
+    K, heads, P, B = 768, 12, M, 1
     A = ops.PackedAct.group(2, M, K, BF, DEV)
     A.data.copy_(rnd(*A.data.shape, seed=1).to(DEV).to(BF))
-    pos = _pos(1, 14, 14).reshape(-1, 2).to(torch.int32).to(DEV)
+    pos = _pos(1, grid, grid).reshape(-1, 2).to(torch.int32).to(DEV)
     cos, sin = _rope_tables(64, 100.0, DEV)
     st = (rnd(2, M, K // 32, 2, seed=4).abs() * 30 + 40).to(DEV)
     st[..., 0] *= 0.05
-    res = {}
+    res, keep = {}, []
     for mode in ("two", "pair"):
         outs = []
         ctx = ops.pair() if mode == "pair" else None
@@ -228,8 +241,10 @@ def test_lean_pair_equals_two_launches():
                              ln=ops.LnFold(st, K, s_n, 1e-6, sb_stats=M * (K // 32) * 8, sb_s=N * 4),
                              sb={"bias": N * 4, "vt": B * heads * npad * 64 * 2})
             outs += [qk, vt]
+            keep += [Ws, bias, s_n]              # a paired launch is issued at __exit__: its operands must outlive the loop body
         if ctx:
             ctx.__exit__(None, None, None)
+        torch.cuda.synchronize()
         res[mode] = outs
     for a, b in zip(res["two"], res["pair"]):
         assert torch.equal(a, b) and float(a.float().abs().max()) > 0

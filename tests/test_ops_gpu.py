@@ -771,7 +771,7 @@ def test_paired_launch_equals_two_launches(dt):
     M, K = 196, 768
     A = ops.PackedAct.group(2, M, K, dt, DEV)
     A.data.copy_(rnd(*A.data.shape, seed=1).to(DEV).to(dt))
-    outs = {}
+    outs, keep = {}, []
     for mode in ("two", "pair"):
         res = []
         ctx = ops.pair() if mode == "pair" else None
@@ -785,8 +785,10 @@ def test_paired_launch_equals_two_launches(dt):
             ops.gemm(A, Ws, out, M=M, N=N, K=K, lda=K, ldc=N, bias=bias, batch=2, strideA=A.stride, strideW=Ws.stride,
                      strideC=M * N, sb={"bias": N * 4}, act=ops.ACT_GELU if j else ops.ACT_NONE, tile=0)
             res.append(out)
+            keep += [Ws, bias]                   # a paired launch is issued at __exit__: its operands must outlive the loop body
         if ctx:
             ctx.__exit__(None, None, None)
+        torch.cuda.synchronize()
         outs[mode] = res
     for a, b in zip(outs["two"], outs["pair"]):
         assert torch.equal(a, b) and float(a.abs().max()) > 0
