@@ -875,9 +875,30 @@ class Spann3R(nn.Module):
         hs, ws = true_shape[:, 0], true_shape[:, 1]
         B = dec[-1].shape[0]
         H, W = int(true_shape[0, 0]), int(true_shape[0, 1])
-        if not bool((true_shape == true_shape[0:1]).all()):
-            raise NotImplementedError("mixed portrait/landscape batch")
         p = self.cfg.patch
+        if not bool((true_shape == true_shape[0:1]).all()):
+            # a batch that mixes landscape views and portraits the dataset rotated to landscape (dust3r/utils/misc.py:80-94): the
+            # head runs once per orientation on its share of the batch -- portraits on the (W, H) token grid, results transposed --
+            # and the results are scattered back into batch order
+            H, W = int(true_shape.min()), int(true_shape.max())
+            land = (ws >= hs).to(dec[-1].device)
+            if not bool(((hs == H) & (ws == W) | (hs == W) & (ws == H)).all()):
+                raise ValueError("true_shape: one image size per batch, in either orientation (got %s)" % true_shape.tolist())
+            res = None
+            for mask, (gh, gw), swap in ((land, (H, W), False), (~land, (W, H), True)):
+                nb = int(mask.sum())
+                if nb == 0:
+                    continue
+                sel = [d[mask].contiguous() for d in dec]
+                pts, conf, _ = self.engine.dpt_head(sel, nb, gh // p, gw // p, num)
+                part = {"pts3d": pts.clone(), "conf": conf.clone()}
+                if swap:
+                    part = {k: v.swapaxes(1, 2) for k, v in part.items()}
+                if res is None:
+                    res = {k: v.new_empty((B,) + tuple(v.shape[1:])) for k, v in part.items()}
+                for k in res:
+                    res[k][mask] = part[k]
+            return res
         pts, conf, _ = self.engine.dpt_head(dec, B, H // p, W // p, num)
         res = {"pts3d": pts.clone(), "conf": conf.clone()}
         if bool((ws < hs).all()):        # landscape_only wrapper: portrait results come back axis-swapped

@@ -348,6 +348,28 @@ def make_trueshape():
     print("trueshape: %d arrays" % len(out))
 
 
+def make_mixedshape():
+    """A training-style batch that MIXES orientations (spann3r/training.py:216 batches do): sample 0 landscape, sample 1 a portrait
+    the dataset rotated to landscape -- dust3r/utils/misc.py:80-94 runs the head once per orientation and scatters the results."""
+    cfg, H, W, NF = TINY, 48, 80, 4
+    sd = synth_state_dict(0, cfg)
+    frames = synth_frames(NF, H, W, batch=2, seed=31)
+    out = {"meta_hw": np.array([H, W]), "meta_frames": np.array(NF), "meta_seed": np.array(31), "meta_batch": np.array(2),
+           "fingerprint": np.array(state_dict_fingerprint(sd))}
+    m = build_reference(cfg, sd, "tsM")
+    fr = [dict(f, true_shape=torch.tensor([(H, W), (W, H)], dtype=torch.int32)) for f in frames]
+    with torch.no_grad():
+        preds, preds_all, sp = m(fr, return_memory=True)
+    for j, p in enumerate(preds):
+        out["M_pred%d_pts" % j] = npf(p["pts3d" if j == 0 else "pts3d_in_other_view"])
+        out["M_pred%d_conf" % j] = npf(p["conf"])
+    for i, (r1, r2) in enumerate(preds_all):
+        out["M_step%d_conf2" % i] = npf(r2["conf"])
+    out["M_mem_attn"] = npf(sp.mem_attn)
+    np.savez_compressed(os.path.join(HERE, "spann3r_mixedshape.npz"), **out)
+    print("mixedshape: %d arrays" % len(out))
+
+
 def make_offline():
     """demo.py's offline mode on the tiny model: the DUSt3R pair graph through the reference's own make_pairs / inference
     (complete graph, symmetrised, batch 2) and Spann3R.offline_reconstruction on it."""
@@ -647,6 +669,8 @@ if __name__ == "__main__":
         make_offline()
     if "trueshape" in what:
         make_trueshape()
+    if "mixedshape" in what:
+        make_mixedshape()
     if "cfg2" in what:
         make_sequence_fixture("spann3r_cfg2_224x10", 224, 224, 10, False, 4)
     if "cfg3" in what:

@@ -446,6 +446,28 @@ def test_general_path_matches_reference(tiny_model, tag):
     assert all(torch.isfinite(v).all() for p in pm for v in p.values())
 
 
+def test_mixed_orientation_batch_vs_reference(tiny_model):
+    """A batch that mixes a landscape view and a portrait the dataset rotated to landscape (training batches do,
+    spann3r/training.py:216): dust3r/utils/misc.py:80-94 runs the DPT head once per orientation and scatters the results back.
+    Against a dump of the unmodified reference (tests/golden/make_golden.py mixedshape)."""
+    from spann3r_amd.weights import synth_frames
+    g = load_golden("spann3r_mixedshape.npz")
+    H, W = map(int, g["meta_hw"])
+    m = tiny_model
+    frames = to_dev(synth_frames(int(g["meta_frames"]), H, W, batch=int(g["meta_batch"]), seed=int(g["meta_seed"])))
+    frames = [dict(f, true_shape=torch.tensor([(H, W), (W, H)], dtype=torch.int32)) for f in frames]
+    assert m._uniform_true_hw(frames) is None
+    preds, preds_all, mem = m(frames, return_memory=True)
+    for j, p in enumerate(preds):
+        key = "pts3d" if j == 0 else "pts3d_in_other_view"
+        assert tuple(p[key].shape) == tuple(g["M_pred%d_pts" % j].shape)
+        assert rel_err(p[key].cpu(), g["M_pred%d_pts" % j]) < TOL_FP32, j
+        assert rel_err(p["conf"].cpu(), g["M_pred%d_conf" % j]) < TOL_FP32, j
+    for i, (_, r2) in enumerate(preds_all):
+        assert rel_err(r2["conf"].cpu(), g["M_step%d_conf2" % i]) < TOL_FP32
+    assert rel_err(mem.mem_attn.cpu(), g["M_mem_attn"]) < TOL_FP32
+
+
 # ----------------------------------------------------------------------------- the benched configurations, at their lengths
 def _run_sequence_fixture(name, full_sd, precision):
     from spann3r_amd import Spann3R, FULL
