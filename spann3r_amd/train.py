@@ -1046,10 +1046,49 @@ def encode_cur_value(pts3d, feat_k, P, cfg, dec_last=None, pos1=None):
     return linear(x, P["value_out.weight"], P["value_out.bias"], res=feat_k)
 
 
+def _orientation(view, H, W):
+    """per-sample landscape flags of a view from its `true_shape` (CPU int tensor [B, 2], dust3r/datasets/base/
+    base_stereo_view_dataset.py:89,215-220: the image shape, or its transpose for a portrait the dataset rotated to landscape);
+    None: every sample is a landscape / square image in its own orientation"""
+    ts = view.get("true_shape")
+    if ts is None or H == W:
+        return None
+    ts = torch.as_tensor(ts).reshape(-1, 2).cpu()
+    land = ts[:, 1] >= ts[:, 0]
+    ok = ((ts[:, 0] == H) & (ts[:, 1] == W)) | ((ts[:, 0] == W) & (ts[:, 1] == H))
+    if not bool(ok.all()):
+        raise ValueError("true_shape must be the image shape or its transpose (got %s for %dx%d images)" % (ts.tolist(), H, W))
+    return None if bool(land.all()) else land
+
+
+def head_by_orientation(dec, land, nh, nw, P, cfg, num):
+    """downstream_head through the landscape_only wrapper (dust3r/utils/misc.py:66-94): portrait samples (land[b] False) run the
+    DPT head on the transposed token grid and their results are transposed back, a mixed batch runs the head once per orientation
+    and the results are scattered into batch order (index_put on the tape)."""
+    if land is None:
+        return dpt_head(dec, nh, nw, P, cfg, num)
+    if not bool(land.any()):
+        pts, conf = dpt_head(dec, nw, nh, P, cfg, num)
+        return pts.transpose(1, 2), conf.transpose(1, 2)
+    dev = dec[0].device
+    B = dec[0].shape[0]
+    out = None
+    for mask, (gh, gw), swap in ((land, (nh, nw), False), (~land, (nw, nh), True)):
+        idx = mask.nonzero().reshape(-1).to(dev)
+        pts, conf = dpt_head([d.index_select(0, idx) for d in dec], gh, gw, P, cfg, num)
+        if swap:
+            pts, conf = pts.transpose(1, 2), conf.transpose(1, 2)
+        if out is None:
+            out = [pts.new_zeros((B,) + tuple(pts.shape[1:])), conf.new_zeros((B,) + tuple(conf.shape[1:]))]
+        out = [out[0].index_copy(0, idx, pts.contiguous()), out[1].index_copy(0, idx, conf.contiguous())]
+    return out[0], out[1]
+
+
 def forward_train(P, frames, cfg, dropout_p=0.0, generator=None):
     """-> (preds, preds_all) of Spann3R.forward in train mode.  P: {reference parameter name: tensor} (leaves of the tape);
-    frames: list of dicts with img [B,3,H,W] on the device (landscape or square; `true_shape` is not consulted: training
-    batches are rectified); dropout_p: spann3r/model.py:229 memory_dropout (0.15 in training), drawn from `generator`."""
+    frames: list of dicts with img [B,3,H,W] on the device and, optionally, `true_shape` [B, 2] (portraits the dataset rotated to
+    landscape, also mixed with landscape samples in one batch: head_by_orientation); dropout_p: spann3r/model.py:229
+    memory_dropout (0.15 in training), drawn from `generator`."""
     ops.F32_BF16 = PRECISION == "bf16"       # (an inference call in between may have reset the product mode of the fp32 GEMMs)
     ops.F32X3 = ops.F32X6 = ops.F16X3 = False
     mem_k = mem_v = None
@@ -1083,8 +1122,9 @@ def forward_train(P, frames, cfg, dropout_p=0.0, generator=None):
         dec1, dec2 = decoder(feat_fuse, pos1, feat2, pos2, P, cfg)
         feat_k1 = encode_feat_key(feat1, dec1[-1], P, 1)
         feat_k2 = encode_feat_key(feat2, dec2[-1], P, 2)
-        pts1, conf1 = dpt_head(dec1, grid[0], grid[1], P, cfg, 1)
-        pts2, conf2 = dpt_head(dec2, grid[0], grid[1], P, cfg, 2)
+        Hi, Wi = v1["img"].shape[-2:]
+        pts1, conf1 = head_by_orientation(dec1, _orientation(v1, Hi, Wi), grid[0], grid[1], P, cfg, 1)
+        pts2, conf2 = head_by_orientation(dec2, _orientation(v2, Hi, Wi), grid[0], grid[1], P, cfg, 2)
         v = encode_cur_value(pts1, feat_k1, P, cfg, dec1[-1], pos1)
         mem_k = feat_k1 if mem_k is None else torch.cat((mem_k, feat_k1), 1)
         mem_v = v if mem_v is None else torch.cat((mem_v, v), 1)
@@ -1175,10 +1215,29 @@ class TrainStep:
         norm = self.opt.step(max_norm=self.clip_grad, skip=self.reducer.unused_everywhere() if self.reducer.active() else ())
         return total.detach(), norm
 
+    @staticmethod
+    def _pattern(frames):
+        """orientation pattern of a batch (per view: which samples are rotated portraits): host-side control flow of the forward"""
+        pat = []
+        for f in frames:
+            H, W = f["img"].shape[-2:]
+            land = _orientation(f, H, W)
+            pat.append(None if land is None else tuple(bool(x) for x in land))
+        return tuple(pat)
+
     def run(self, frames, gts):
         if not self.graph:
             return self._body(frames, gts, monitor=False)
+        pat = self._pattern(frames)
+        if self._g is not None and pat != self._captured_pattern:
+            # the captured step holds ONE orientation pattern (the per-orientation head passes are host-side control flow): a batch
+            # with another pattern takes the eager step on the same buffers / optimizer state
+            self.opt.sync_lr()
+            out = self._body(frames, gts, monitor=False)
+            invalidate_weight_cache()
+            return out
         if self._g is None:
+            self._captured_pattern = pat
             clone = lambda d: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in d.items()}
             self._static = ([clone(f) for f in frames], [clone(g) for g in gts])
             # the warm-up steps (allocator pools, caches, chunk tables) and the capture must not move the trajectory: parameters,

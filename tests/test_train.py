@@ -889,3 +889,38 @@ def test_full_geometry_gradients_vs_reference_step(full_sd, precision, flash, to
     assert (num / den) ** 0.5 < tol
     if precision == "fp32":
         assert worst[0] < 2e-3, worst
+
+
+@pytest.mark.gpu
+def test_train_forward_mixed_orientation_batch(tiny_sd):
+    """Training batches mix landscape samples and portraits rotated to landscape (spann3r/training.py:216,
+    dust3r/utils/misc.py:80-94): the train-mode forward of a mixed batch equals the per-sample forwards in their own orientation
+    (samples of a batch are independent), and gradients flow through both head passes."""
+    from spann3r_amd import Spann3R, TINY
+    from spann3r_amd import train as T
+    from spann3r_amd.weights import synth_frames
+    n, H, W = 3, 32, 48
+    try:
+        T.set_precision("fp32")
+        m = Spann3R(dus3r_name=None, cfg=TINY, init_weights=False, memory_dropout=0.0)
+        m.load_state_dict(tiny_sd, strict=True)
+        m = m.cuda().train()
+        base = synth_frames(n, H, W, batch=2, seed=5)
+        ts = torch.tensor([(H, W), (W, H)], dtype=torch.int32)
+        mixed = [{"img": f["img"].cuda(), "true_shape": ts} for f in base]
+        preds, _ = m(mixed)
+        singles = []
+        for b in range(2):
+            fr = [{"img": f["img"][b:b + 1].cuda(), "true_shape": ts[b:b + 1]} for f in base]
+            singles.append(m(fr)[0])
+        for j, p in enumerate(preds):
+            for k in p:
+                for b in range(2):
+                    assert rel_err(p[k][b].detach().cpu(), singles[b][j][k][0].detach().cpu()) < 1e-5, (j, k, b)
+        loss = sum(p[k].square().mean() for p in preds for k in p)
+        loss.backward()
+        gnorm = sum(float(q.grad.abs().sum()) for q in m.parameters() if q.grad is not None)
+        assert gnorm > 0 and gnorm == gnorm
+    finally:
+        T.set_precision("fp32")
+        T.invalidate_weight_cache()
