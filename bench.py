@@ -290,7 +290,8 @@ def train_measure(dev, steps, warmup, precision, batch, n_frames=5, size=224, wo
     model = Spann3R(dus3r_name=None, cfg=FULL, init_weights=False)
     model.load_state_dict(synth_state_dict(0, FULL), strict=True)
     model = model.to(dev)
-    ts = T.TrainStep(model, precision=precision, graph=(world == 1))
+    # one execution mode at every world size: the step (bucket all-reduces included) is captured into a hipGraph and replayed
+    ts = T.TrainStep(model, precision=precision, graph=True)
     rank = int(os.environ.get("RANK", "0"))
     frames, gts = synth_training_batch(rank, n_frames, size, batch, dev)
     torch.cuda.reset_peak_memory_stats()
@@ -313,6 +314,7 @@ def train_measure(dev, steps, warmup, precision, batch, n_frames=5, size=224, wo
            "achieved_tflops": fl / sec / 1e12, "frac_of_mfma_peak": fl / sec / 1e12 / PEAK_TFLOPS["bf16" if precision == "bf16" else "fp32"],
            "peak_memory_gb": torch.cuda.max_memory_allocated() / 2 ** 30, "precision": precision, "batch": batch, "frames": n_frames, "size": size,
            "rccl_ranks": world, "buckets": len(ts.reducer.buckets), "buckets_reduced_inside_backward": ts.reducer.launched_in_backward, "hip_graph": bool(ts.graph),
+           "collectives_in_graph": bool(ts.graph and ts.reducer.active()),
            "what": "one optimisation step: train-mode Spann3R.forward (HIP autograd ops) + ConfLoss_t(Regr3D_t(L21, avg_dis), 0.4) + backward through the "
                    "memory fusion + bucketed gradient all-reduce (RCCL, world %d) + global-norm clip 1.0 + AdamW on flat buckets" % world}
     T.set_precision("fp32")
@@ -437,8 +439,9 @@ def main():
     if args.train:
         # BASELINE config 5: data-parallel training, batch 4 per rank ("scaling": weak); value = frames/s over all ranks
         tr = train_measure(dev, args.steps, args.warmup, args.train_precision, args.train_batch, world=world)
-        stats = gather_stats(args.train_batch * 5 * args.steps, tr["seconds_per_step"] * args.steps, device=dev)
+        stats = gather_stats(args.train_batch * 5 * args.steps, tr["seconds_per_step"] * args.steps, extra=[float(tr["hip_graph"])], device=dev)
         fps, _, max_seconds = aggregate(stats)
+        tr["hip_graph_per_rank"] = [bool(x) for x in stats[:, 2].tolist()]       # every rank reports its own execution mode
         if rank == 0:
             print(json.dumps({"metric": "training frames/sec (batch %d x %d ranks, 5-frame 224px sequences, ConfLoss backward, AdamW)" % (args.train_batch, world),
                               "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -147,6 +147,7 @@ class GradReducer:
         self._flat = [None] * len(self.buckets)
         self._work = [None] * len(self.buckets)
         self._used = None
+        self.capture = False         # True while train.TrainStep captures / replays the step as a hipGraph (no host transfers in start())
         self._used_work = None
         self.launched_in_backward = 0          # (statistics of the last step: buckets whose collective started from a hook)
         self._armed = False
@@ -266,6 +267,13 @@ class GradReducer:
         touched = self._touched
         if not any(touched):
             touched = [p.grad is not None for p in self.params]
+        if self.capture:
+            # inside a hipGraph capture (train.TrainStep(graph=True)): no host -> device upload, no read-back.  Every rank replays
+            # the SAME captured kernel sequence, so the parameters a step touches are the same on every rank: the used-set is the
+            # local one and needs no collective.
+            self._touched_host = list(touched)
+            self._used = self._used_work = None
+            return
         used = torch.tensor([1 if t else 0 for t in touched], dtype=torch.int32, device=self.params[0].device)
         self._used = used
         self._used_work = dist.all_reduce(used, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
@@ -288,13 +296,16 @@ class GradReducer:
                         p.grad = g.clone()
                     else:
                         p.grad.copy_(g)
-        self._used_work.wait()
+        if self._used_work is not None:
+            self._used_work.wait()
         self._work = [None] * len(self.buckets)
         self._next = 0
         self._started = False
 
     def unused_everywhere(self):
         """parameters that received no gradient on any rank in the step just reduced (DDP leaves their .grad None)"""
+        if self.capture and getattr(self, "_touched_host", None) is not None:
+            return [p for p, t in zip(self.params, self._touched_host) if not t]
         if self._used is None:
             return []
         u = self._used.cpu().tolist()

@@ -1183,8 +1183,8 @@ class TrainStep:
     backward with the bucket all-reduces launched from inside it (RCCL when a process group is up), global-norm clip and AdamW on
     the flat buckets.  `run(frames, gts)` returns (loss, gradient norm) as device scalars (no host sync).
 
-    graph=True (single rank): the whole step -- ~35 000 kernel launches at batch 4 -- is captured once into a hipGraph and
-    replayed; the batch is copied into static buffers, the optimizer's step count and learning rate live on the device
+    graph=True: the whole step -- ~16 000 kernel launches at batch 4, the bucket all-reduces of a multi-rank job included -- is
+    captured once into a hipGraph and replayed; the batch is copied into static buffers, the optimizer's step count and learning rate live on the device
     (`set_lr`).  Shapes must not change between steps (training batches of one resolution)."""
 
     def __init__(self, model, lr=5e-5, weight_decay=0.05, betas=(0.9, 0.95), clip_grad=1.0, precision="bf16", bucket_mb=64.0, force_collectives=False,
@@ -1197,7 +1197,10 @@ class TrainStep:
         self.opt = FlatAdamW(parameter_groups(model, weight_decay), self.reducer, lr=lr, betas=betas, weight_decay=weight_decay)
         self.crit = ConfLoss_t(Regr3D_t(L21, norm_mode="avg_dis", fix_first=False), alpha=0.4)      # training.py:37
         self.clip_grad = clip_grad
-        self.graph = bool(graph) and not self.reducer.active()
+        # multi-rank too: the bucket all-reduces (RCCL through torch.distributed's NCCL backend is capturable) are part of the
+        # captured step; SP3_TRAIN_GRAPH=0 forces the eager step
+        import os
+        self.graph = bool(graph) and os.environ.get("SP3_TRAIN_GRAPH", "1") != "0"
         self._g = self._static = self._out = None
 
     def set_lr(self, lr):
@@ -1251,6 +1254,7 @@ class TrainStep:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             self.opt.capture_mode(True)
+            self.reducer.capture = True                  # collectives stay in the graph; the used-parameter exchange is host-free
             self._g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._g):
                 self._out = self._body(*self._static, monitor=False)

@@ -309,6 +309,30 @@ for step in range(2):
     for p, w_ in zip(allp, want):
         assert torch.allclose(p.grad, w_ / world, atol=1e-6), step
     assert red3.unused_everywhere() == []
+# capture mode (train.TrainStep(graph=True) with a process group): the gradient all-reduces still run, the used-parameter bitmap
+# is NOT exchanged (no host -> device upload inside a hipGraph capture): every rank replays the same kernel sequence, so the local
+# used-set is the global one
+torch.manual_seed(3)
+net4 = torch.nn.Sequential(torch.nn.Linear(20, 32), torch.nn.Tanh(), torch.nn.Linear(32, 4))
+spare = torch.nn.Parameter(torch.ones(7))
+red4 = GradReducer(list(net4.parameters()) + [spare], bucket_mb=0.004, overlap=True)
+red4.capture = True
+red4.zero_grad()
+red4.prepare()
+net4(torch.randn(6, 20, generator=torch.Generator().manual_seed(400 + rank))).square().mean().backward()
+red4.finish()
+assert red4._used is None and red4._used_work is None
+assert [q is spare for q in red4.unused_everywhere()] == [True]
+ref4 = torch.nn.Sequential(torch.nn.Linear(20, 32), torch.nn.Tanh(), torch.nn.Linear(32, 4))
+ref4.load_state_dict(net4.state_dict())
+tot4 = [torch.zeros_like(p) for p in ref4.parameters()]
+for r in range(world):
+    ref4.zero_grad()
+    ref4(torch.randn(6, 20, generator=torch.Generator().manual_seed(400 + r))).square().mean().backward()
+    for t, p in zip(tot4, ref4.parameters()):
+        t += p.grad
+for p, t in zip(net4.parameters(), tot4):
+    assert torch.allclose(p.grad, t / world, atol=1e-7)
 if rank == 0:
     print("OK grads", started)
 dist.destroy_process_group()

@@ -924,3 +924,43 @@ def test_train_forward_mixed_orientation_batch(tiny_sd):
     finally:
         T.set_precision("fp32")
         T.invalidate_weight_cache()
+
+
+@pytest.mark.gpu
+def test_captured_step_with_rccl_collectives_matches_eager(tiny_sd):
+    """TrainStep(graph=True) with a process group up (one rank, collectives forced): the bucket all-reduces are captured INTO the
+    step's hipGraph (no silent fall-back to the eager step) and the replayed trajectory equals the eager one."""
+    import torch.distributed as dist
+    from spann3r_amd import Spann3R, TINY
+    from spann3r_amd import train as T
+    from spann3r_amd.weights import synth_frames
+    own = not dist.is_initialized()
+    if own:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29619")
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        n, B, H, W = 3, 2, 32, 48
+        batches = [([{"img": f["img"].cuda()} for f in synth_frames(n, H, W, batch=B, seed=30 + i)], _synth_gts(n, B, H, W, 40 + i, torch.float32, "cuda")) for i in range(3)]
+        traj = {}
+        for mode in (False, True):
+            m = Spann3R(dus3r_name=None, cfg=TINY, init_weights=False, memory_dropout=0.0)
+            m.load_state_dict(tiny_sd, strict=True)
+            ts = T.TrainStep(m.cuda(), precision="fp32", lr=1e-4, graph=mode, bucket_mb=4.0, force_collectives=True)
+            assert ts.reducer.active() and bool(ts.graph) == mode
+            out = []
+            for fr, gt in batches:
+                loss, norm = ts.run(fr, gt)
+                out.append((float(loss), float(norm)))
+            traj[mode] = (out, m.state_dict()["dust3r.dec_blocks.1.attn.qkv.weight"].clone())
+            del ts, m
+            T.invalidate_weight_cache()
+        for (le, ne), (lg, ng) in zip(traj[False][0], traj[True][0]):
+            assert abs(le - lg) <= 1e-5 * abs(le) and abs(ne - ng) <= 1e-4 * abs(ne), traj
+        we, wg = traj[False][1].double(), traj[True][1].double()
+        assert float((we - wg).abs().max() / (we - tiny_sd["dust3r.dec_blocks.1.attn.qkv.weight"].cuda().double()).abs().max()) < 1e-3
+    finally:
+        T.set_precision("fp32")
+        T.invalidate_weight_cache()
+        if own:
+            dist.destroy_process_group()
