@@ -931,7 +931,7 @@ const SmInst kInst[] = {
     // STREAM (output projections onto the residual stream)
     {39, SM_STREAM, 1024, 3, 2, 8, false, 0, 768, sm_launch<3, 2, 8, 16, 0, SM_STREAM>},      // decoder_embed x2 (N = 768): 48x32 k8
     {34, SM_STREAM, 1024, 2, 2, 8, false, 769, 1 << 30, sm_launch<2, 2, 8, 16, 0, SM_STREAM>},  // val proj, value_out: 32x32 k8
-    {35, SM_STREAM, 4096, 2, 2, 16, false, 0, 1 << 30, sm_launch<2, 2, 16, 64, 0, SM_STREAM>},   // val fc2: 32x32 k16
+    {35, SM_STREAM, 4096, 2, 2, 8, false, 0, 1 << 30, sm_launch<2, 2, 8, 64, 4, SM_STREAM>},   // val fc2: 32x32 k8, ring of 4
     {36, SM_STREAM, 768, 3, 2, 6, false, 0, 1 << 30, sm_launch<3, 2, 6, 12, 0, SM_STREAM>},   // dec proj / cproj x2, pos patch embed: 48x32 k6
     {37, SM_STREAM, 3072, 3, 2, 8, false, 0, 1 << 30, sm_launch<3, 2, 8, 48, 3, SM_STREAM>},  // dec fc2 x2: 48x32 k8, ring of 3
     {38, SM_STREAM, 1792, 4, 2, 7, false, 0, 1 << 30, sm_launch<4, 2, 7, 28, 0, SM_STREAM>},  // key MLP out x2: 64x32 k7
@@ -942,6 +942,8 @@ const SmInst kInst[] = {
     {53, SM_PACKED, 1024, 4, 4, 1, false, 0, 1 << 30, bm_launch<4, 2, 4, 16, 3, SM_PACKED>, 1536, 1 << 30, 256, 128},  // encoder fc1
     {54, SM_PACKED, 1024, 4, 4, 1, false, 0, 1 << 30, bm_launch<2, 2, 4, 16, 3, SM_PACKED>, 257, 1535, 128, 128},
     {55, SM_PACKED, 768, 4, 4, 1, false, 0, 1 << 30, bm_launch<2, 2, 4, 12, 3, SM_PACKED>, 257, 1 << 30, 128, 128},
+    {61, SM_STREAM, 1024, 4, 4, 1, false, 0, 1 << 30, bm_launch<4, 2, 4, 16, 3, SM_STREAM>, 4096, 1 << 30, 256, 128},   // 512x512 whole-sequence encoder (M = 16 x 1024)
+    {62, SM_STREAM, 4096, 4, 4, 1, false, 0, 1 << 30, bm_launch<4, 2, 4, 64, 3, SM_STREAM>, 4096, 1 << 30, 256, 128},
     {56, SM_STREAM, 1024, 4, 2, 1, false, 0, 1 << 30, bm_launch<2, 2, 2, 16, 3, SM_STREAM>, 257, 1 << 30, 128, 64},    // encoder proj
     {57, SM_STREAM, 4096, 4, 2, 1, false, 0, 1 << 30, bm_launch<2, 2, 2, 64, 3, SM_STREAM>, 257, 1 << 30, 128, 64},    // encoder fc2
     {58, SM_STREAM, 768, 4, 2, 1, false, 0, 1 << 30, bm_launch<2, 2, 2, 12, 3, SM_STREAM>, 257, 1 << 30, 128, 64},

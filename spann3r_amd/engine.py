@@ -131,6 +131,16 @@ class Engine:
                 w[d_ + "pp%d.w" % i], w[d_ + "pp%d.b" % i] = mat(p[a + "%d.0.weight" % i]), vec(p[a + "%d.0.bias" % i])
                 w[d_ + "rn%d.w" % i] = conv3(p[s + "scratch.layer%d_rn.weight" % (i + 1)])
             w[d_ + "pp0t.w"], w[d_ + "pp0t.b"] = convt(p[a + "0.1.weight"]), vec(p[a + "0.1.bias"])
+            if wdt == torch.bfloat16:
+                # bf16 mode: the 96-channel map of act_postprocess[0] is carried with 128 channels (32 zero channels: zero rows of
+                # the transposed convolution, zero bias, zero input columns of layer1_rn -- the same sums), so that layer1_rn's
+                # K = 9 x 128 is whole 64-wide k-blocks and runs on the LDS-tiled convolution instead of the general loader
+                wt = p[a + "0.1.weight"].detach().to(dev, torch.float32)                        # [Cin, Cout, 4, 4]
+                wt = torch.cat((wt, torch.zeros(wt.shape[0], 32, 4, 4, device=dev)), 1)
+                w[d_ + "pp0t.w"] = convt(wt)
+                w[d_ + "pp0t.b"] = torch.cat((vec(p[a + "0.1.bias"]), torch.zeros(32, device=dev))).contiguous()
+                wr = p[s + "scratch.layer1_rn.weight"].detach().to(dev, torch.float32)          # [256, 96, 3, 3]
+                w[d_ + "rn0.w"] = conv3(torch.cat((wr, torch.zeros(wr.shape[0], 32, 3, 3, device=dev)), 1))
             w[d_ + "pp1t.w"], w[d_ + "pp1t.b"] = convt(p[a + "1.1.weight"]), vec(p[a + "1.1.bias"])
             w[d_ + "pp3c.w"], w[d_ + "pp3c.b"] = conv3(p[a + "3.1.weight"]), vec(p[a + "3.1.bias"])
             for r in (1, 2, 3, 4):
@@ -622,10 +632,11 @@ class Engine:
                 for i in (i0, i0 + 1):
                     ops.gemm(dec[hk[i]], w[pre + "pp%d.w" % i], t[i], M=R, N=ld[i], K=dims[i], lda=dims[i], ldc=ld[i], bias=w[pre + "pp%d.b" % i])
         # act_postprocess tails (croco/models/dpt_block.py:356-410)
-        l0 = self.ws("dpt%d_l0" % num, (B * 16 * nh * nw, ld[0]))
+        c0 = 128 if self.wdt == torch.bfloat16 else ld[0]         # (bf16 mode: 32 zero channels ride along, see _pack)
+        l0 = self.ws("dpt%d_l0" % num, (B * 16 * nh * nw, c0))
         l1 = self.ws("dpt%d_l1" % num, (B * 4 * nh * nw, ld[1]))
         with pair():
-            ops.conv_transpose_ks(t[0], w[pre + "pp0t.w"], l0, B=B, H=nh, W_=nw, Cin=ld[0], Cout=ld[0], ks=4, bias=w[pre + "pp0t.b"])
+            ops.conv_transpose_ks(t[0], w[pre + "pp0t.w"], l0, B=B, H=nh, W_=nw, Cin=ld[0], Cout=c0, ks=4, bias=w[pre + "pp0t.b"])
             ops.conv_transpose_ks(t[1], w[pre + "pp1t.w"], l1, B=B, H=nh, W_=nw, Cin=ld[1], Cout=ld[1], ks=2, bias=w[pre + "pp1t.b"])
         l2 = t[2]
         h3, w3 = (nh - 1) // 2 + 1, (nw - 1) // 2 + 1
@@ -639,7 +650,7 @@ class Engine:
         for i, src in enumerate((l0, l1, l2, l3)):
             Hh, Ww = geo[i]
             o = self.ws("dpt%d_rn%d" % (num, i), (B * Hh * Ww, F))
-            ops.conv3x3(src, w[pre + "rn%d.w" % i], o, B=B, H=Hh, W_=Ww, Cin=ld[i], Cout=F, splitk_ws=sk)
+            ops.conv3x3(src, w[pre + "rn%d.w" % i], o, B=B, H=Hh, W_=Ww, Cin=(c0 if i == 0 else ld[i]), Cout=F, splitk_ws=sk)
             rn.append(o)
         # refinenets; path_4 is cropped to layer 3's size (dust3r/heads/dpt_head.py:57)
         p4, H4, W4 = self._fusion(pre + "ref4.", B, h3, w3, rn[3], None, "%d_4" % num, crop=(nh, nw))

@@ -107,13 +107,14 @@ _TILE_NAMES = {0: "32x32xk4", 1: "64x64", 2: "64x128", 3: "64x64xk4", 4: "32x64x
                20: "256x128pipe", 21: "128x128pipe", 22: "128x64pipe", 23: "64x64pipe", 24: "64x32pipe", 25: "32x32pipe",
                # lean small-M instances (csrc/gemm_sm.hip): epilogue, K, tile, waves over K
                30: "lean-rope-k1024-48x64xk8", 31: "lean-rope-k768-32x32xk4", 32: "lean-packed-k1024-64x64xk8", 33: "lean-packed-k768-32x32xk4",
-               34: "lean-stream-k1024-32x32xk8", 35: "lean-stream-k4096-32x32xk16", 36: "lean-stream-k768-48x32xk6",
+               34: "lean-stream-k1024-32x32xk8", 35: "lean-stream-k4096-32x32xk8r4", 36: "lean-stream-k768-48x32xk6",
                37: "lean-stream-k3072-48x32xk8", 38: "lean-stream-k1792-64x32xk7",
                39: "lean-stream-k1024-48x32xk8", 40: "lean-conv-16x16xk12", 41: "lean-conv-32x32xk8", 42: "lean-packed-splitA-k1792-64x32xk7",
                # many-row lean instances (bm_kernel: LDS-staged operands, epilogue in registers)
                50: "lean-rope-k1024-256x128", 51: "lean-rope-k1024-128x128", 52: "lean-rope-k768-128x128", 53: "lean-packed-k1024-256x128",
                54: "lean-packed-k1024-128x128", 55: "lean-packed-k768-128x128", 56: "lean-stream-k1024-128x64", 57: "lean-stream-k4096-128x64",
-               58: "lean-stream-k768-128x64", 59: "lean-stream-k3072-128x64", 60: "lean-stream-k1792-128x64"}
+               58: "lean-stream-k768-128x64", 59: "lean-stream-k3072-128x64", 60: "lean-stream-k1792-128x64",
+               61: "lean-stream-k1024-256x128", 62: "lean-stream-k4096-256x128"}
 
 
 def pick_tile(M, N, batch=1, splitk=1, conv=False, K=0, packed_bf16=False, plain=False, ln_nt=0, pipe_ok=False, rope=False):
