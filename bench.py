@@ -409,6 +409,16 @@ def main():
     args = parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+    # stdout carries exactly ONE line, the JSON record: anything the model prints on the way (the reference-style
+    # "Similarity detected" / "Memory pruned" notes of the memory policy) goes to stderr
+    real_stdout, sys.stdout = sys.stdout, sys.stderr
+    try:
+        _main(args, real_stdout)
+    finally:
+        sys.stdout = real_stdout
+
+
+def _main(args, real_stdout):
 
     import torch
     import torch.distributed as dist
@@ -443,12 +453,12 @@ def main():
         fps, _, max_seconds = aggregate(stats)
         tr["hip_graph_per_rank"] = [bool(x) for x in stats[:, 2].tolist()]       # every rank reports its own execution mode
         if rank == 0:
-            print(json.dumps({"metric": "training frames/sec (batch %d x %d ranks, 5-frame 224px sequences, ConfLoss backward, AdamW)" % (args.train_batch, world),
+            print(file=real_stdout, flush=True, *[json.dumps({"metric": "training frames/sec (batch %d x %d ranks, 5-frame 224px sequences, ConfLoss backward, AdamW)" % (args.train_batch, world),
                               "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                               "ms_per_step": 1e3 * max_seconds / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                               "dtype": args.train_precision, "data": "synthetic (seeded frames / ground truth, seeded random-init weights)",
                               "config": {"workload": "train step, BASELINE config 5 per rank: batch %d, 5 frames of 224x224" % args.train_batch,
-                                         "parallelism": "dp%d (RCCL bucket all-reduce inside backward)" % world}, "train": tr}))
+                                         "parallelism": "dp%d (RCCL bucket all-reduce inside backward)" % world}, "train": tr})])
         if use_dist:
             dist.destroy_process_group()
         return
@@ -497,6 +507,7 @@ def main():
 
     # ---- secondary measurements on this GPU (N = 1 only): the fp32 parity mode, and BASELINE config 3
     if world == 1 and not args.no_extras and (args.size, args.frames, args.precision, args.train_policy) == (224, 10, "bf16", False):
+        print("bench.py: extras: fp32 mode", file=sys.stderr, flush=True)
         model.set_precision("fp32")
         f32_frames, f32_s = time_sequences(model, seqs, 6, 3)
         out["fp32"] = {"value": f32_frames / f32_s, "unit": "frames/s", "what": "same workload in the fp32 MFMA parity mode "
@@ -515,6 +526,7 @@ def main():
                         "what": "same workload, fp32 operands, every GEMM product through SIX bf16 MFMAs of a three-way (h, m, l) split: 24 operand "
                                 "bits, fp32-grade products, fp32 accumulate; exact-fp32 attention.  The fast parity mode that also holds 1e-3 on "
                                 "trained-like weight statistics (stress fixture), where f32x3 measures 1.4e-3"}
+        print("bench.py: extras: f16x3 mode", file=sys.stderr, flush=True)
         model.set_precision("f16x3")
         h3_frames, h3_s = time_sequences(model, seqs, 6, 3)
         out["f16x3"] = {"value": h3_frames / h3_s, "unit": "frames/s", "steps": 6,
@@ -522,6 +534,7 @@ def main():
                                 "x = h + l * 2^-11 (22 operand bits, fp32 accumulate): the fast fp32-grade mode -- pointmaps within 5e-6 of the reference on "
                                 "the config-2 fixture and 1.6e-4 on the trained-like stress fixture, where f32x3 measures 1.4e-3 and exact fp32 1.4e-4 "
                                 "(tests/test_model_gpu.py)"}
+        print("bench.py: extras: parity errors of f16x3 against the reference dumps", file=sys.stderr, flush=True)
         # the >= 200 frames/s-at-1e-3 claim as ONE record: the fp32-grade mode's rate next to its errors against the reference
         # dumps (tests/golden: outputs of the unmodified reference), measured here, now, on this build
         out["parity_mode"] = {"mode": "f16x3", "value": h3_frames / h3_s, "unit": "frames/s", "tolerance": 1e-3,
@@ -533,6 +546,7 @@ def main():
         model.set_precision("bf16")
         # how the same GPU fills with more independent work per launch: 4 sequences batched into one forward (B = 4).
         # NOT the headline configuration (BASELINE config 2 is batch 1): reported next to it.
+        print("bench.py: extras: batch 4", file=sys.stderr, flush=True)
         seqs_b4 = [make_sequence(200, args.frames, args.size, args.size, batch=4, device=dev)]
         b4_frames, b4_s = time_sequences(model, seqs_b4, 6, 3)
         out["batch4"] = {"value": 4 * b4_frames / b4_s, "unit": "frames/s", "steps": 6,
@@ -540,6 +554,7 @@ def main():
                                  "every launch carries 4x the rows; not the BASELINE configuration"}
         del model
         torch.cuda.empty_cache()
+        print("bench.py: extras: config 3 (512x512, 50 frames)", file=sys.stderr, flush=True)
         m3, _ = build_model("bf16", dev, train_policy=True)
         seq3 = [make_sequence(100, 50, 512, 512, device=dev)]
         c3_frames, c3_s = time_sequences(m3, seq3, 3, 3)
@@ -559,6 +574,8 @@ def main():
                     c3["memread"]["graph_replay"] = rep3
         out["config3"] = c3
         del m3
+        import gc
+        gc.collect()                     # runner <-> model cycles hold hipGraphs: finalise them now, not inside a later capture
         torch.cuda.empty_cache()
 
     # ---- the training step (BASELINE config 5, one rank's share): bf16 products, flat buckets, device-side clip
@@ -567,13 +584,17 @@ def main():
             del model
         except NameError:
             pass
+        import gc
+        gc.collect()
         torch.cuda.empty_cache()
+        print("bench.py: extras: training step", file=sys.stderr, flush=True)
         out["train"] = train_measure(dev, 3, 2, "bf16", 4)
 
     # ---- CPU baseline: the oracle (port of the reference algorithm) on this box's host cores, bounded sample
     if world == 1 and not args.no_cpu_baseline:
+        print("bench.py: cpu baseline", file=sys.stderr, flush=True)
         out["cpu_baseline"] = cpu_baseline(sd, args.size, args.train_policy)
-    print(json.dumps(out))
+    print(json.dumps(out), file=real_stdout, flush=True)
     if use_dist:
         dist.destroy_process_group()
 

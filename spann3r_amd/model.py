@@ -580,8 +580,17 @@ class _SequenceRunner:
                 self._pool = torch.cuda.graph_pool_handle()
             before = torch.cuda.memory_allocated()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=self._pool):
-                fn()
+            # (no cyclic garbage collection during the capture: finalising another runner's hipGraph is not permitted while a
+            # stream captures)
+            import gc
+            gc_was = gc.isenabled()
+            gc.disable()
+            try:
+                with torch.cuda.graph(g, pool=self._pool):
+                    fn()
+            finally:
+                if gc_was:
+                    gc.enable()
             nbytes = max(0, torch.cuda.memory_allocated() - before)
             self.graphs[key] = (g, nbytes)
             self.graph_bytes += nbytes

@@ -1256,8 +1256,18 @@ class TrainStep:
             self.opt.capture_mode(True)
             self.reducer.capture = True                  # collectives stay in the graph; the used-parameter exchange is host-free
             self._g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._g):
-                self._out = self._body(*self._static, monitor=False)
+            # no cyclic garbage collection while the stream captures: the collector may finalise hipGraphs of models dropped
+            # earlier (an inference runner <-> model cycle), and destroying a graph is not permitted during a capture
+            import gc
+            gc.collect()
+            gc_was = gc.isenabled()
+            gc.disable()
+            try:
+                with torch.cuda.graph(self._g):
+                    self._out = self._body(*self._static, monitor=False)
+            finally:
+                if gc_was:
+                    gc.enable()
             self.opt.restore(snap)
             del snap
         else:
