@@ -33,12 +33,14 @@ struct SmOp {
   float* stats_out; char* c2; char* vt;
   long gA, gA2, gW, gC, gbias, gres, gstats, gs, gso, gc2, gvt;      // byte strides per group (problem) of a grouped launch
   int N, ntz, ldc, rope_cols, act, nkb1;
+  int nt;                           // N-tiles per problem (bm_kernel's M-major tile map)
 };
 
 struct SmArgs {
   SmOp op[2];                       // op[1]: second group of problems of a paired launch (blockIdx.z >= z1)
   const float* cos; const float* sin; const int* pos;
   int M, rb_max, z1;
+  int xm;                           // bm_kernel: 1 = M-tiles across the XCDs (grid = (8, N-tiles x groups, ceil(M-tiles / 8))), see bm_kernel
   int tokens, heads, vt_ld;
   unsigned tok_magic;               // floor(2^32 / tokens) + 1: gm / tokens by one multiply-high (gm < 65536)
   float ln_eps;
@@ -375,11 +377,25 @@ __global__ __launch_bounds__(64 * WM * WN) void bm_kernel(const SmArgs a) {
   const int g = lane >> 4, r16 = lane & 15;
   const bool second = EPI == SM_ROPE && (int)blockIdx.z >= a.z1;
 #define OPF(f) (second ? a.op[1].f : a.op[0].f)
-  int z = (int)blockIdx.z - (second ? a.z1 : 0);
-  const int ntz = OPF(ntz);
-  const int grp = z >= ntz ? 1 : 0;
-  z -= grp * ntz;
-  const int tile_m = blockIdx.y, tile_n = z * 8 + blockIdx.x;
+  // Tile map (block b runs on XCD b % 8 = blockIdx.x).  Default: XCD x owns the N-tiles {x, x + 8, ..} of every M-tile -- its L2
+  // fetches A once and 1/8 of W.  a.xm (host: A larger than W, i.e. more rows than columns -- the encoder's proj / fc2): XCD x
+  // owns the M-tiles {x, x + 8, ..} of every N-tile -- 1/8 of A and all of W (PMC: 158 MB -> fetched per fc2 launch with the
+  // default map, the activation panel once per XCD).
+  int tile_m, tile_n, grp;
+  if (EPI != SM_ROPE && a.xm) {
+    const int nt = OPF(nt), y = blockIdx.y;
+    grp = y >= nt ? 1 : 0;
+    tile_n = y - grp * nt;
+    tile_m = blockIdx.z * 8 + blockIdx.x;
+    if (tile_m * BM >= a.M) return;
+  } else {
+    int z = (int)blockIdx.z - (second ? a.z1 : 0);
+    const int ntz = OPF(ntz);
+    grp = z >= ntz ? 1 : 0;
+    z -= grp * ntz;
+    tile_m = blockIdx.y;
+    tile_n = z * 8 + blockIdx.x;
+  }
   const int N = OPF(N);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   if (n0 >= N) return;
@@ -703,7 +719,8 @@ int bm_launch(const SmArgs& a, int mt, int nz, hipStream_t stream) {
       raised = true;
     }
   }
-  hipLaunchKernelGGL(kern, dim3(8, mt, nz), dim3(64 * WM * WN), lds, stream, a);
+  const dim3 grid = a.xm ? dim3(8, a.op[0].nt * (a.z1 / a.op[0].ntz), (mt + 7) / 8) : dim3(8, mt, nz);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, stream, a);
   SP3_LAUNCH_CHECK("sp3_gemm (lean, many rows)");
   return 0;
 }
@@ -1008,7 +1025,8 @@ void sm_fill(SmOp& o, const sp3_gemm_desc& d, const SmInst& s) {
   o.gbias = G * d.sb_bias; o.gres = G * (long)d.M * d.ldr1 * 4; o.gstats = G * d.sb_ln_stats; o.gs = G * d.sb_ln_s;
   o.gso = G * d.sb_stats_out; o.gc2 = G * d.sb_c2; o.gvt = G * d.sb_vt;
   o.N = d.N;
-  o.ntz = (d.N / s.tile_n() + 7) / 8;
+  o.nt = d.N / s.tile_n();
+  o.ntz = (o.nt + 7) / 8;
   o.ldc = (int)d.ldc;
   o.rope_cols = d.rope_cols;
   o.act = d.act;
@@ -1054,6 +1072,7 @@ int sp3_gemm_sm_launch(const sp3_gemm_desc& d, const sp3_gemm_desc* pair, hipStr
   }
   a.cos = d.rope_cos; a.sin = d.rope_sin; a.pos = d.pos;
   a.M = d.M;
+  a.xm = (s->bm && s->epi != SM_ROPE && !pair && d.M > d.N) ? 1 : 0;     // more rows than columns: the activation panel is the larger operand
   a.rb_max = (d.M + 15) / 16 - 1;
   a.tokens = d.tokens > 0 ? d.tokens : 1;
   a.heads = d.heads;

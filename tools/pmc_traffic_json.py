@@ -10,7 +10,43 @@ NAMES = {(2, 2, 1, 1, 4, 3, 0): "32x32xk4", (7, 1, 1, 4, 2, 4, 2): "112x64wreg8"
          (4, 4, 2, 2, 2, 4, -1): "128x128pipe", (4, 4, 2, 1, 2, 3, -1): "128x64pipe", (4, 2, 1, 1, 2, 4, -1): "64x32pipe"}
 
 
+# the lean instances (csrc/gemm_sm.hip): template arguments -> the tile name spann3r_amd/ops.py gives them
+SM = {(3, 4, 8, 16, 0, 2): 30, (2, 2, 4, 12, 0, 2): 31, (4, 4, 8, 16, 0, 0): 32, (2, 4, 4, 12, 0, 0): 33, (2, 2, 8, 16, 0, 1): 34,
+      (2, 2, 8, 64, 4, 1): 35, (3, 2, 6, 12, 0, 1): 36, (3, 2, 8, 48, 3, 1): 37, (4, 2, 7, 28, 0, 1): 38, (3, 2, 8, 16, 0, 1): 39,
+      (4, 2, 7, 28, 0, 0): 42}
+BM = {(4, 2, 4, 16, 3, 2): 50, (2, 2, 4, 16, 3, 2): 51, (2, 2, 4, 12, 3, 2): 52, (4, 2, 4, 16, 3, 0): 53, (2, 2, 4, 16, 3, 0): 54,
+      (2, 2, 4, 12, 3, 0): 55, (2, 2, 2, 16, 3, 1): 56, (2, 2, 2, 64, 3, 1): 57, (2, 2, 2, 12, 3, 1): 58, (2, 2, 2, 48, 3, 1): 59,
+      (2, 2, 2, 28, 3, 1): 60, (4, 2, 4, 16, 3, 1): 61, (4, 2, 4, 64, 3, 1): 62}
+
+
+def lean_key(row):
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from spann3r_amd.ops import _TILE_NAMES
+    n = row["kernel"]
+    m = re.search(r"\b(sm|bm)_kernel<([^>]*)>", n)
+    if m:
+        ints = tuple(int(x) for x in re.findall(r"-?\d+", m.group(2)))[:6]
+        tile = (SM if m.group(1) == "sm" else BM).get(ints)
+        if tile is None:
+            return None
+        # sp3_gemm2 (q/k/v + cross k/v projections of a decoder layer in one launch): the only paired lean launch of the 224x224 step
+        pair = tile == 31 and row["grid"][2] == 30
+        return ("gemm2" if pair else "gemm") + "<Abf16,Wbf16,plain,%s>" % _TILE_NAMES[tile]
+    if "conv3x3_tile_kernel" in n:
+        return "conv3x3_tile"
+    m = re.search(r"conv_sm_kernel<(\d+), (\d+), (\d+)", n)
+    if m:
+        return "gemm<Af32,Wbf16,conv3x3,%s>" % _TILE_NAMES[40 if m.group(1) == "1" else 41]
+    if "attention_packed_kernel" in n:
+        return "attention_packed<bf16>"
+    return None
+
+
 def key_of(row):
+    k = lean_key(row)
+    if k:
+        return k
     m = re.search(r"gemm_kernelIDF16bDF16bLi0E((?:Lin?\d+E)+)", row["kernel"])
     if not m:
         return None
