@@ -319,18 +319,42 @@ class SpatialMemory:
                                % (self.wm * self.P, self.M))
         return True
 
-    def fetch_scores_async(self):
-        """queue the device->host copy of the scores behind the kernels launched so far; sim_verdict() waits for it only"""
+    def _host_scores(self):
         if self._score_host is None:
             self._score_host = torch.empty(self._score.shape, dtype=torch.float32).pin_memory()
             self._score_event = torch.cuda.Event()
-        self._score_host.copy_(self._score, non_blocking=True)
+        return self._score_host
+
+    def fetch_scores_async(self):
+        """queue the device->host copy of the scores behind the kernels launched so far; sim_verdict() waits for it only"""
+        self._host_scores().copy_(self._score, non_blocking=True)
         self._score_event.record()
         self._score_pending = True
 
+    def copy_scores_in_graph(self):
+        """The same copy as a node INSIDE the step's hipGraph (single-graph step): no event can be recorded in the middle of a
+        replay, so the host learns that the copy has landed from the data itself -- arm_score_poll() fills the pinned buffer with
+        NaN before the launch, sim_verdict() spins until the wm valid scores (cosines: never NaN) have replaced them."""
+        self._host_scores().copy_(self._score, non_blocking=True)
+
+    def arm_score_poll(self):
+        self._host_scores().fill_(float("nan"))
+        self._score_pending = "poll"
+
     def sim_verdict(self):
         """Host side of check_sim: reads the scores the cos_sim kernels left in self._score (host sync, as :114)."""
-        if self._score_pending:
+        if self._score_pending == "poll":
+            import time
+            self._score_pending = False
+            view = self._score_host[:, :self.wm]
+            t0 = time.perf_counter()
+            while bool(torch.isnan(view).any()):
+                if time.perf_counter() - t0 > 2.0:           # (never observed: fall back to a stream sync + plain copy)
+                    torch.cuda.current_stream().synchronize()
+                    view = self._score[:, :self.wm].cpu()
+                    break
+            mx = max(view.reshape(-1).tolist())
+        elif self._score_pending:
             self._score_event.synchronize()
             self._score_pending = False
             mx = max(self._score_host[:, :self.wm].reshape(-1).tolist())
@@ -692,13 +716,28 @@ class _SequenceRunner:
         # two graphs per step: the host fetches the similarity scores (async copy + event) as soon as the first one is
         # done and takes the memory decision while the second one (head, value encoder) still runs -> the next step's
         # launches are queued before the GPU runs dry.  The reference syncs at the same point of the data flow (:114).
-        self._graphed(("first" if first else "step",) + key, lambda: self._part1(first, has_next), use_graphs)
-        if not first:
-            mem.note_deferred_read()        # (a replayed graph ran no Python)
         need_sim = not self.training and mem.sim_needed()
-        if need_sim:
-            mem.fetch_scores_async()
-        self._graphed(("tail",) + key, self._part2, use_graphs)
+        if self.model.single_graph_step and use_graphs and ops._prof is None:
+            # ONE graph per step: the score copy is a memcpy node between the two halves and the host polls the pinned buffer for
+            # it while the second half runs (two graph launches per step left ~15 us of launch gaps around the copy)
+            if need_sim:
+                mem.arm_score_poll()
+
+            def whole():
+                self._part1(first, has_next)
+                if need_sim:
+                    mem.copy_scores_in_graph()
+                self._part2()
+            self._graphed(("whole", first, need_sim) + key, whole, use_graphs)
+            if not first:
+                mem.note_deferred_read()        # (a replayed graph ran no Python)
+        else:
+            self._graphed(("first" if first else "step",) + key, lambda: self._part1(first, has_next), use_graphs)
+            if not first:
+                mem.note_deferred_read()        # (a replayed graph ran no Python)
+            if need_sim:
+                mem.fetch_scores_async()
+            self._graphed(("tail",) + key, self._part2, use_graphs)
         pts1, conf1, pts2, conf2 = self.out
         outs = [torch.empty_like(t) for t in (pts1, conf1) + (() if pts2 is None else (pts2, conf2))]
         copies = list(zip((pts1, conf1) + (() if pts2 is None else (pts2, conf2)), outs))
@@ -783,6 +822,7 @@ class Spann3R(nn.Module):
         self.batch_encode = True     # forward(): encode all frames of the sequence together (False: frame by frame)
         self.defer_head2 = True      # with batch_encode: run the view-2 DPT head once for all steps after the loop
         self.grouped_decoder = True  # bf16: the two decoder sides as grouped launches on one stream (False: two streams)
+        self.single_graph_step = True   # one hipGraph per step, the similarity scores polled from pinned memory (False: two graphs + an event)
         self.packed_features = True  # bf16 + batch_encode + grouped_decoder: decoder_embed / key MLPs read fragment-order bf16 copies of the features (lean instances)
         self.decoder_streams = os.environ.get("SP3_DEC_STREAMS", "1") == "1"   # ungrouped decoder (fp32 mode): two streams with a fork/join per layer, or one stream
         self.force_general = False   # True: always take the reference-shaped eager loop (_forward_general; tests)

@@ -166,7 +166,7 @@ def test_graph_replay_equals_eager(tiny_model):
     frames = to_dev(synth_frames(5, 48, 64, seed=5))
     outs = [m(frames, return_memory=True) for _ in range(3)]
     run = [r for k, r in m._runners.items() if k[:3] == (1, 48, 64)][0]
-    assert sum(k[0] in ("first", "step") for k in run.graphs) == 4      # one per step of the 5-frame sequence
+    assert sum(k[0] in ("first", "step", "whole") for k in run.graphs) == 4      # one per step of the 5-frame sequence
     assert ("enc", 0, 5) in run.graphs                                   # + the whole-sequence encoder
     m.use_graphs = False
     try:
@@ -410,7 +410,7 @@ def test_true_shape_takes_graph_path_and_matches_reference(tiny_model, tag):
             assert rel_err(r2["conf"].cpu(), g["%s_step%d_conf2" % (tag, i)]) < TOL_FP32
         assert rel_err(mem.mem_attn.cpu(), g["%s_mem_attn" % tag]) < TOL_FP32
     run = m._runners[(int(g["meta_batch"]), H, W, False, ts)]
-    assert any(k[0] == "step" for k in run.graphs) and any(k[0] == "tail" for k in run.graphs)
+    assert any(k[0] == "whole" for k in run.graphs) or (any(k[0] == "step" for k in run.graphs) and any(k[0] == "tail" for k in run.graphs))
     # a device-resident true_shape and the key-less form give the same thing (landscape only for the latter)
     p_dev, _ = m(_with_true_shape(frames, ts, DEV))
     assert all(torch.equal(a[k], b[k]) for a, b in zip(preds, p_dev) for k in a)
