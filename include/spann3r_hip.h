@@ -158,8 +158,8 @@ int sp3_gemm2(const sp3_gemm_desc* a, const sp3_gemm_desc* b, void* stream);
  * compile time -- 30 / 31: q/k/v projections (K = 1024 / 768, ROPE_VT epilogue with qkv_packed), 32 / 33: fc1 + GELU into
  * fragment order (K = 1024 / 768), 34..38: output projections onto the fp32 residual stream (K = 1024, 4096, 768, 3072, 1792).
  * They serve M <= 256, batch <= 2, bias set, alpha = 1, no split-K / second residual / split A; anything else runs on the general
- * tiles above.  40 / 41: loader CONV3X3 on maps of <= 256 / <= 1024 output pixels (fp32 NHWC map, bf16 fragment-order weights,
- * K = 9 Cin a multiple of 64, fp32 output, plain epilogue with bias / ReLU / two residuals): the DPT heads' small-map convolutions
+ * tiles above.  40 / 41: loader CONV3X3 on maps of <= 256 / <= 2048 output pixels (NHWC map, residuals and output all fp32 or all bf16 --
+ * a_bf16 = out_bf16 --, bf16 fragment-order weights, K = 9 Cin a multiple of 64, plain epilogue with bias / ReLU / two residuals): the DPT heads' small-map convolutions
  * (croco/models/dpt_block.py:33-75,95-113) in ONE launch instead of split-K partials + sp3_reduce_ln.  SP3_LEAN_GEMM=0 in the environment switches them off (A/B runs). */
 int sp3_gemm_plan(const sp3_gemm_desc* desc_host);
 
@@ -332,15 +332,21 @@ int sp3_gather_1d(const float* src, float* dst, const int32_t* sel, int n_sel, v
  *   w_packed fragment order; bias fp32[Cout] / res1 / res2 fp32 NHWC maps of the output shape, all optional;
  *   out fp32 or bf16 (out_bf16).  Cin, Cout multiples of 64; act is SP3_ACT_NONE or SP3_ACT_RELU.
  *   Replaces the Conv2d calls of ResidualConvUnit_custom (croco/models/dpt_block.py:120-142), scratch.layer_rn
- *   (:180-188) and the head convs (:318-324) in bf16 mode; fp32 mode and stride 2 use sp3_gemm's LOAD_CONV3X3. */
+ *   (:180-188) and the head convs (:318-324) in bf16 mode; fp32 mode and stride 2 use sp3_gemm's LOAD_CONV3X3.  out_bf16: bit 0 = the output map is bf16, bit 1 = the residual maps res1 / res2 are bf16 too (else fp32).
+ */
 int sp3_conv3x3_tile(const void* x, int in_bf16, const void* w_packed, const float* bias, const float* res1,
                      const float* res2, void* out, int out_bf16, int B, int H, int W, int Cin, int Cout,
                      int relu_in, int act, void* stream);
 int sp3_im2col_patch(const float* img, int64_t sb, int64_t sc, int64_t sy, int64_t sx, int B, int C, int H, int W,
                      int p, void* out, int out_bf16, int out_packed, void* stream);
 int sp3_upsample2x(const float* in, float* out, int B, int H, int W, int C, int outH, int outW, void* stream);
+/* the same on bf16 NHWC maps (bf16 mode of the DPT heads keeps its feature maps in bf16; interpolation arithmetic in fp32) */
+int sp3_upsample2x_bf16(const void* in, void* out, int B, int H, int W, int C, int outH, int outW, void* stream);
 int sp3_head_final(const float* feat, const float* w, const float* b, int64_t pixels, int C, float* pts,
                    float* conf, float* raw, void* stream);
+/* the same with the feature map stored as bf16 (outputs stay fp32: the API's pointmaps / confidences) */
+int sp3_head_final_bf16(const void* feat, const float* w, const float* b, int64_t pixels, int C, float* pts, float* conf,
+                        float* raw, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Input pipeline: one decoded RGB frame (uint8 HWC, row stride src_row_stride bytes) -> the normalised

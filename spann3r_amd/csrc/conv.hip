@@ -197,9 +197,14 @@ __global__ __launch_bounds__(256) void conv3x3_tile_kernel(const ConvArgs a) {
     if (a.bias) { const float4 b4 = *reinterpret_cast<const float4*>(a.bias + gn); v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
     if (a.act == SP3_ACT_RELU) v = relu4(v);
     const int64_t off = (((int64_t)b * a.H + oy) * a.W + ox) * a.Cout + gn;
-    if (a.res1) { const float4 q = *reinterpret_cast<const float4*>(a.res1 + off); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
-    if (a.res2) { const float4 q = *reinterpret_cast<const float4*>(a.res2 + off); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
-    if (a.out_bf16) {
+    if (a.out_bf16 & 2) {                     // residual maps stored as bf16 (bf16 mode of the DPT heads)
+      if (a.res1) { const bf16x4 q = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(a.res1) + off); v.x += (float)q[0]; v.y += (float)q[1]; v.z += (float)q[2]; v.w += (float)q[3]; }
+      if (a.res2) { const bf16x4 q = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(a.res2) + off); v.x += (float)q[0]; v.y += (float)q[1]; v.z += (float)q[2]; v.w += (float)q[3]; }
+    } else {
+      if (a.res1) { const float4 q = *reinterpret_cast<const float4*>(a.res1 + off); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+      if (a.res2) { const float4 q = *reinterpret_cast<const float4*>(a.res2 + off); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+    }
+    if (a.out_bf16 & 1) {
       bf16x4 o;
       o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
       *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.out) + off) = o;

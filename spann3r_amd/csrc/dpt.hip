@@ -29,7 +29,21 @@ __global__ __launch_bounds__(256) void im2col_patch_kernel(const float* __restri
 
 // F.interpolate(scale_factor=2, bilinear, align_corners=True) on NHWC; optional crop to [outH,outW].
 // Source index as ATen computes it: scale = (in-1)/(out-1) in float, src = scale * dst.
-__global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W,
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4(const __bf16* p) {
+  const bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
+  return make_float4((float)t[0], (float)t[1], (float)t[2], (float)t[3]);
+}
+__device__ __forceinline__ void st4(float* p, const float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4(__bf16* p, const float4 v) {
+  bf16x4 t;
+  t[0] = (__bf16)v.x; t[1] = (__bf16)v.y; t[2] = (__bf16)v.z; t[3] = (__bf16)v.w;
+  *reinterpret_cast<bf16x4*>(p) = t;
+}
+
+// T = float, or __bf16 (bf16 mode of the DPT heads: maps stored as bf16, the interpolation itself in fp32)
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2x_kernel(const T* __restrict__ in, T* __restrict__ out, int H, int W,
                                                          int C, int outH, int outW, int64_t total4) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= total4) return;
@@ -50,22 +64,23 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict
   const int y1 = y0 < H - 1 ? y0 + 1 : y0, x1 = x0 < W - 1 ? x0 + 1 : x0;
   const float ly = fy - (float)y0, lx = fx - (float)x0;
   const float hy = 1.f - ly, hx = 1.f - lx;
-  const float4* base = reinterpret_cast<const float4*>(in + (int64_t)b * H * W * C);
-  const float4 v00 = base[((int64_t)y0 * W + x0) * c4 + cc];
-  const float4 v01 = base[((int64_t)y0 * W + x1) * c4 + cc];
-  const float4 v10 = base[((int64_t)y1 * W + x0) * c4 + cc];
-  const float4 v11 = base[((int64_t)y1 * W + x1) * c4 + cc];
+  const T* base = in + (int64_t)b * H * W * C;
+  const float4 v00 = ld4(base + (((int64_t)y0 * W + x0) * c4 + cc) * 4);
+  const float4 v01 = ld4(base + (((int64_t)y0 * W + x1) * c4 + cc) * 4);
+  const float4 v10 = ld4(base + (((int64_t)y1 * W + x0) * c4 + cc) * 4);
+  const float4 v11 = ld4(base + (((int64_t)y1 * W + x1) * c4 + cc) * 4);
   float4 o;
   // same association as ATen's upsample_bilinear2d: hy*(hx*v00 + lx*v01) + ly*(hx*v10 + lx*v11)
   o.x = hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
   o.y = hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
   o.z = hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
   o.w = hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
-  reinterpret_cast<float4*>(out)[idx] = o;
+  st4(out + idx * 4, o);
 }
 
 // 8 lanes per pixel: each lane dots C/8 channels against the 4 output filters, xor-shuffle reduce.
-__global__ __launch_bounds__(256) void head_final_kernel(const float* __restrict__ feat, const float* __restrict__ w,
+template <typename T>
+__global__ __launch_bounds__(256) void head_final_kernel(const T* __restrict__ feat, const float* __restrict__ w,
                                                          const float* __restrict__ bias, int64_t pixels, int C,
                                                          float* __restrict__ pts, float* __restrict__ conf,
                                                          float* __restrict__ raw) {
@@ -75,9 +90,9 @@ __global__ __launch_bounds__(256) void head_final_kernel(const float* __restrict
   const bool valid = pix < pixels;
   const int64_t pp = valid ? pix : pixels - 1;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  const float* f = feat + pp * C;
+  const T* f = feat + pp * C;
   for (int c = sub * 4; c < C; c += 32) {
-    const float4 x = *reinterpret_cast<const float4*>(f + c);
+    const float4 x = ld4(f + c);
     const float4 w0 = *reinterpret_cast<const float4*>(w + c);
     const float4 w1 = *reinterpret_cast<const float4*>(w + C + c);
     const float4 w2 = *reinterpret_cast<const float4*>(w + 2 * C + c);
@@ -122,9 +137,19 @@ extern "C" int sp3_upsample2x(const float* in, float* out, int B, int H, int W, 
   SP3_CHECK(in && out && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "sp3_upsample2x: bad arguments");
   SP3_CHECK(outH > 0 && outH <= 2 * H && outW > 0 && outW <= 2 * W, "sp3_upsample2x: bad crop");
   const int64_t total4 = (int64_t)B * outH * outW * (C / 4);
-  hipLaunchKernelGGL(upsample2x_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, ST(stream), in, out, H, W, C,
+  hipLaunchKernelGGL(upsample2x_kernel<float>, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, ST(stream), in, out, H, W, C,
                      outH, outW, total4);
   SP3_LAUNCH_CHECK("sp3_upsample2x");
+  return 0;
+}
+
+extern "C" int sp3_upsample2x_bf16(const void* in, void* out, int B, int H, int W, int C, int outH, int outW, void* stream) {
+  SP3_CHECK(in && out && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "sp3_upsample2x_bf16: bad arguments");
+  SP3_CHECK(outH > 0 && outH <= 2 * H && outW > 0 && outW <= 2 * W, "sp3_upsample2x_bf16: bad crop");
+  const int64_t total4 = (int64_t)B * outH * outW * (C / 4);
+  hipLaunchKernelGGL(upsample2x_kernel<__bf16>, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, ST(stream),
+                     reinterpret_cast<const __bf16*>(in), reinterpret_cast<__bf16*>(out), H, W, C, outH, outW, total4);
+  SP3_LAUNCH_CHECK("sp3_upsample2x_bf16");
   return 0;
 }
 
@@ -132,8 +157,18 @@ extern "C" int sp3_head_final(const float* feat, const float* w, const float* b,
                               float* raw, void* stream) {
   SP3_CHECK(feat && w && b && pts && conf && pixels > 0 && C > 0 && C % 32 == 0, "sp3_head_final: bad arguments");
   const int64_t threads = pixels * 8;
-  hipLaunchKernelGGL(head_final_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ST(stream), feat, w, b, pixels, C,
+  hipLaunchKernelGGL(head_final_kernel<float>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ST(stream), feat, w, b, pixels, C,
                      pts, conf, raw);
   SP3_LAUNCH_CHECK("sp3_head_final");
+  return 0;
+}
+
+extern "C" int sp3_head_final_bf16(const void* feat, const float* w, const float* b, int64_t pixels, int C, float* pts, float* conf,
+                                   float* raw, void* stream) {
+  SP3_CHECK(feat && w && b && pts && conf && pixels > 0 && C > 0 && C % 32 == 0, "sp3_head_final_bf16: bad arguments");
+  const int64_t threads = pixels * 8;
+  hipLaunchKernelGGL(head_final_kernel<__bf16>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ST(stream),
+                     reinterpret_cast<const __bf16*>(feat), w, b, pixels, C, pts, conf, raw);
+  SP3_LAUNCH_CHECK("sp3_head_final_bf16");
   return 0;
 }

@@ -733,13 +733,67 @@ int bm_launch(const SmArgs& a, int mt, int nz, hipStream_t stream) {
 // waves, gathers the im2col rows straight from the fp32 NHWC map (ReLU + bf16 rounding on the way into the MFMA, exactly the
 // general loader's arithmetic) and finishes bias / ReLU / both residuals itself: one launch, no partial sums in memory.
 struct ConvSmArgs {
-  const float* x; const char* W; float* out;
-  const float* bias; const float* res1; const float* res2;
+  const void* x; const char* W; void* out;          // x / res1 / res2 / out: NHWC maps in the map dtype TM (fp32, or bf16 in bf16 mode)
+  const float* bias; const void* res1; const void* res2;
   int M, N, H, Wd, Cin, OH, OW, stride, nkb, relu_in, act;
   unsigned cin_magic, per_magic, ow_magic;        // floor(2^32 / d) + 1: n / d by one multiply-high (n < 65536)
 };
 
-template <int MF, int NF, int WK, int R>
+typedef __attribute__((ext_vector_type(4))) unsigned int csm_u32x4;
+
+// one lane's 16 consecutive input channels of one tap, as the two 16-byte MFMA operand halves (ReLU, zero padding, bf16 rounding)
+template <typename TM> struct CsmA;
+template <> struct CsmA<float> {
+  float4 v[4];
+  __device__ __forceinline__ void load(const void* p) {
+    const float4* q = reinterpret_cast<const float4*>(p);
+    v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
+  }
+  __device__ __forceinline__ void halves(unsigned mask, bool relu, bf16x8& h0, bf16x8& h1) const {
+    float4 t[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      t[q].x = __uint_as_float(__float_as_uint(v[q].x) & mask); t[q].y = __uint_as_float(__float_as_uint(v[q].y) & mask);
+      t[q].z = __uint_as_float(__float_as_uint(v[q].z) & mask); t[q].w = __uint_as_float(__float_as_uint(v[q].w) & mask);
+      if (relu) t[q] = relu4(t[q]);
+    }
+    h0 = cvt8(t[0], t[1]);
+    h1 = cvt8(t[2], t[3]);
+  }
+};
+template <> struct CsmA<__bf16> {
+  bf16x8 v[2];
+  __device__ __forceinline__ void load(const void* p) {
+    const bf16x8* q = reinterpret_cast<const bf16x8*>(p);
+    v[0] = q[0]; v[1] = q[1];
+  }
+  __device__ __forceinline__ void halves(unsigned mask, bool relu, bf16x8& h0, bf16x8& h1) const {
+    csm_u32x4 a = __builtin_bit_cast(csm_u32x4, v[0]), b = __builtin_bit_cast(csm_u32x4, v[1]);
+    a &= mask; b &= mask;
+    h0 = __builtin_bit_cast(bf16x8, a);
+    h1 = __builtin_bit_cast(bf16x8, b);
+    if (relu) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        h0[i] = (float)h0[i] > 0.f ? h0[i] : (__bf16)0.f;
+        h1[i] = (float)h1[i] > 0.f ? h1[i] : (__bf16)0.f;
+      }
+    }
+  }
+};
+__device__ __forceinline__ float4 csm_load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 csm_load4(const __bf16* p) {
+  const bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
+  return make_float4((float)t[0], (float)t[1], (float)t[2], (float)t[3]);
+}
+__device__ __forceinline__ void csm_store4(float* p, const float (&v)[4]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ void csm_store4(__bf16* p, const float (&v)[4]) {
+  bf16x4 t;
+  t[0] = (__bf16)v[0]; t[1] = (__bf16)v[1]; t[2] = (__bf16)v[2]; t[3] = (__bf16)v[3];
+  *reinterpret_cast<bf16x4*>(p) = t;
+}
+
+template <typename TM, int MF, int NF, int WK, int R>
 __global__ __launch_bounds__(64 * WK) void conv_sm_kernel(const ConvSmArgs a) {
   constexpr int BM = MF * 16, BN = NF * 16, NT = 64 * WK, LD = BN + 4, CG = BN / 4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -748,6 +802,7 @@ __global__ __launch_bounds__(64 * WK) void conv_sm_kernel(const ConvSmArgs a) {
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   if (n0 >= a.N) return;
   const int g = lane >> 4, r16 = lane & 15;
+  const TM* X = reinterpret_cast<const TM*>(a.x);
 
   // epilogue operands of this thread's (row, 4 columns) first
   const int ec4 = (tid % CG) * 4, erow = tid / CG;
@@ -756,12 +811,12 @@ __global__ __launch_bounds__(64 * WK) void conv_sm_kernel(const ConvSmArgs a) {
   if (eact) {
     const long o = (long)(m0 + erow) * a.N + n0 + ec4;
     if (a.bias) b4 = *reinterpret_cast<const float4*>(a.bias + n0 + ec4);
-    if (a.res1) r1 = *reinterpret_cast<const float4*>(a.res1 + o);
-    if (a.res2) r2 = *reinterpret_cast<const float4*>(a.res2 + o);
+    if (a.res1) r1 = csm_load4(reinterpret_cast<const TM*>(a.res1) + o);
+    if (a.res2) r2 = csm_load4(reinterpret_cast<const TM*>(a.res2) + o);
   }
 
   // this lane's output pixels (one per row block)
-  const float* img[MF];
+  const TM* img[MF];
   int iy0[MF], ix0[MF];
 #pragma unroll
   for (int m = 0; m < MF; ++m) {
@@ -771,7 +826,7 @@ __global__ __launch_bounds__(64 * WK) void conv_sm_kernel(const ConvSmArgs a) {
     const int b = (int)__umulhi((unsigned)r, a.per_magic);
     const int rem = r - b * per;
     const int oy = (int)__umulhi((unsigned)rem, a.ow_magic), ox = rem - oy * a.OW;
-    img[m] = a.x + (long)b * a.H * a.Wd * a.Cin;
+    img[m] = X + (long)b * a.H * a.Wd * a.Cin;
     iy0[m] = oy * a.stride - 1;
     ix0[m] = ox * a.stride - 1;
   }
@@ -779,7 +834,7 @@ __global__ __launch_bounds__(64 * WK) void conv_sm_kernel(const ConvSmArgs a) {
 #pragma unroll
   for (int n = 0; n < NF; ++n) wp[n] = a.W + ((long)(tile_n * NF + n) * a.nkb) * 2048 + lane * 16;
 
-  float4 av[R][MF][4];
+  CsmA<TM> av[R][MF];
   bf16x8 wv[R][NF][2];
   unsigned am[R][MF];
   auto load = [&](int slot, int kb) {
@@ -795,9 +850,8 @@ __global__ __launch_bounds__(64 * WK) void conv_sm_kernel(const ConvSmArgs a) {
     for (int m = 0; m < MF; ++m) {
       const int iy = iy0[m] + dy, ix = ix0[m] + dx;
       const bool inb = iy >= 0 && iy < a.H && ix >= 0 && ix < a.Wd;
-      const float4* p = reinterpret_cast<const float4*>(inb ? img[m] + ((long)iy * a.Wd + ix) * a.Cin + ci : a.x);
       am[slot][m] = inb ? 0xffffffffu : 0u;                 // unconditional load, masked at consume time (zero padding)
-      av[slot][m][0] = p[0]; av[slot][m][1] = p[1]; av[slot][m][2] = p[2]; av[slot][m][3] = p[3];
+      av[slot][m].load(inb ? img[m] + ((long)iy * a.Wd + ix) * a.Cin + ci : X);
     }
   };
   f32x4 acc[MF][NF];
@@ -817,19 +871,7 @@ __global__ __launch_bounds__(64 * WK) void conv_sm_kernel(const ConvSmArgs a) {
       if (i < nkw) {
         bf16x8 ab[MF][2];
 #pragma unroll
-        for (int m = 0; m < MF; ++m) {
-          float4 v[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            v[q].x = __uint_as_float(__float_as_uint(av[s][m][q].x) & am[s][m]);
-            v[q].y = __uint_as_float(__float_as_uint(av[s][m][q].y) & am[s][m]);
-            v[q].z = __uint_as_float(__float_as_uint(av[s][m][q].z) & am[s][m]);
-            v[q].w = __uint_as_float(__float_as_uint(av[s][m][q].w) & am[s][m]);
-            if (relu) v[q] = relu4(v[q]);
-          }
-          ab[m][0] = cvt8(v[0], v[1]);
-          ab[m][1] = cvt8(v[2], v[3]);
-        }
+        for (int m = 0; m < MF; ++m) av[s][m].halves(am[s][m], relu, ab[m][0], ab[m][1]);
 #pragma unroll
         for (int m = 0; m < MF; ++m)
 #pragma unroll
@@ -865,27 +907,28 @@ __global__ __launch_bounds__(64 * WK) void conv_sm_kernel(const ConvSmArgs a) {
       for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
     }
     v[0] += r1.x + r2.x; v[1] += r1.y + r2.y; v[2] += r1.z + r2.z; v[3] += r1.w + r2.w;
-    *reinterpret_cast<float4*>(a.out + (long)(m0 + erow) * a.N + n0 + ec4) = make_float4(v[0], v[1], v[2], v[3]);
+    csm_store4(reinterpret_cast<TM*>(a.out) + (long)(m0 + erow) * a.N + n0 + ec4, v);
   }
 }
 
-template <int MF, int NF, int WK, int R>
+template <typename TM, int MF, int NF, int WK, int R>
 int conv_sm_launch(const ConvSmArgs& a, hipStream_t stream) {
   constexpr int BM = MF * 16, BN = NF * 16;
   constexpr size_t lds = (size_t)WK * BM * (BN + 4) * sizeof(float);
   static_assert(lds <= 64 * 1024, "partial tiles: default dynamic LDS limit");
   const int mt = (a.M + BM - 1) / BM, ntz = (a.N / BN + 7) / 8;
-  hipLaunchKernelGGL((conv_sm_kernel<MF, NF, WK, R>), dim3(8, mt, ntz), dim3(64 * WK), lds, stream, a);
+  hipLaunchKernelGGL((conv_sm_kernel<TM, MF, NF, WK, R>), dim3(8, mt, ntz), dim3(64 * WK), lds, stream, a);
   SP3_LAUNCH_CHECK("sp3_gemm (lean conv3x3)");
   return 0;
 }
 
-// tile 40: 16x16 outputs per workgroup, K over 12 waves (maps of <= 256 pixels); tile 41: 32x32, K over 8 waves (<= 1024 pixels)
+// tile 40: 16x16 outputs per workgroup, K over 12 waves (maps of <= 256 pixels); tile 41: 32x32, K over 8 waves (<= 2048 pixels).
+// The map dtype is fp32, or bf16 for input AND output (bf16 mode of the DPT heads: a_bf16 = out_bf16 = 1; residuals in the same dtype)
 int conv_sm_tile(const sp3_gemm_desc& d) {
-  if (d.loader != SP3_LOAD_CONV3X3 || d.wdtype != SP3_BF16 || !d.w_packed || d.a_bf16 || d.out_bf16 || d.out_packed || d.epi != SP3_EPI_PLAIN ||
+  if (d.loader != SP3_LOAD_CONV3X3 || d.wdtype != SP3_BF16 || !d.w_packed || (d.a_bf16 != 0) != (d.out_bf16 != 0) || d.out_packed || d.epi != SP3_EPI_PLAIN ||
       d.batch > 1 || d.splitk > 1 || d.alpha != 1.0f || d.ln_stats || d.stats_out || d.c2 || d.trace || d.sm_stats_out || d.f32x3)
     return -1;
-  if (d.K % 64 || d.conv_C % 16 || d.K != 9 * d.conv_C || d.K >= 65536 || d.M > 1024 || d.M < 1 || d.act == SP3_ACT_GELU) return -1;
+  if (d.K % 64 || d.conv_C % 16 || d.K != 9 * d.conv_C || d.K >= 65536 || d.M > 2048 || d.M < 1 || d.act == SP3_ACT_GELU) return -1;
   if (d.ldc != d.N || (d.res1 && d.ldr1 != d.N) || (d.res2 && d.ldr2 != d.N) || (d.ldw > 0 && d.ldw != d.K)) return -1;
   if (d.M <= 256) return d.N % 16 == 0 ? 40 : -1;
   return d.N % 32 == 0 ? 41 : -1;
@@ -893,14 +936,18 @@ int conv_sm_tile(const sp3_gemm_desc& d) {
 
 int conv_sm_dispatch(const sp3_gemm_desc& d, int tile, hipStream_t stream) {
   ConvSmArgs a;
-  a.x = d.A; a.W = reinterpret_cast<const char*>(d.W); a.out = reinterpret_cast<float*>(d.C);
+  a.x = d.A; a.W = reinterpret_cast<const char*>(d.W); a.out = d.C;
   a.bias = d.bias; a.res1 = d.res1; a.res2 = d.res2;
   a.M = d.M; a.N = d.N; a.H = d.conv_H; a.Wd = d.conv_W; a.Cin = d.conv_C; a.OH = d.conv_OH; a.OW = d.conv_OW;
   a.stride = d.conv_stride; a.nkb = d.K / 64; a.relu_in = d.relu_in; a.act = d.act;
   auto magic = [](int v) { return (unsigned)((1ull << 32) / (unsigned)v + 1); };
   a.cin_magic = magic(d.conv_C); a.per_magic = magic(d.conv_OH * d.conv_OW); a.ow_magic = magic(d.conv_OW);
-  if (tile == 40) return conv_sm_launch<1, 1, 12, 3>(a, stream);
-  return conv_sm_launch<2, 2, 8, 3>(a, stream);
+  if (d.a_bf16) {
+    if (tile == 40) return conv_sm_launch<__bf16, 1, 1, 12, 3>(a, stream);
+    return conv_sm_launch<__bf16, 2, 2, 8, 3>(a, stream);
+  }
+  if (tile == 40) return conv_sm_launch<float, 1, 1, 12, 3>(a, stream);
+  return conv_sm_launch<float, 2, 2, 8, 3>(a, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ host side

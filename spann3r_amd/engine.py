@@ -9,6 +9,7 @@ Precision: 'fp32' -> fp32 weights, v_mfma_f32_16x16x4_f32 (parity mode, <=1e-3 v
                      fp32 residual stream, LayerNorm, softmax and DPT feature maps (bench mode).
 """
 import math
+import os
 
 import torch
 
@@ -38,6 +39,9 @@ class Engine:
         self.adt = self.wdt          # dtype of activations that only feed GEMMs
         import os
         self.packed_attn = precision == "bf16"      # fragment-order q/k/v + wave-split attention kernel
+        # DPT feature maps: bf16 in bf16 mode (round 4: every map is a GEMM / convolution operand that the MFMA rounds to bf16 anyway;
+        # stored as bf16 they cost half the bytes in the convolutions' loaders, the upsamplers and the residual adds), fp32 otherwise
+        self.mdt = torch.bfloat16 if (precision == "bf16" and os.environ.get("SP3_DPT_FP32_MAPS", "0") != "1") else torch.float32
         self._ws = {}
         self._pos_cache = {}
         # RoPE tables for every grid the build supports, allocated ONCE: captured graphs hold their addresses
@@ -584,7 +588,7 @@ class Engine:
     def _rcu(self, x, pre, B, H, W_, out, extra_res=None, tag=""):
         """ResidualConvUnit_custom (croco/models/dpt_block.py:120-142): conv2(relu(conv1(relu(x)))) + x [+ extra]."""
         w, F = self.w, self.cfg.dpt_feat
-        t = self.ws("rcu_tmp" + tag, (B * H * W_, F))
+        t = self.ws("rcu_tmp" + tag, (B * H * W_, F), self.mdt)
         sk = self._conv_ws(tag[:1])
         ops.conv3x3(x, w[pre + "c1.w"], t, B=B, H=H, W_=W_, Cin=F, Cout=F, bias=w[pre + "c1.b"], relu_in=True, act=ACT_RELU,
                     splitk_ws=sk)
@@ -600,15 +604,15 @@ class Engine:
         M = B * H * W_
         cur = x0
         if x1 is not None:
-            s = self.ws("fus_sum_" + tag, (M, F))
+            s = self.ws("fus_sum_" + tag, (M, F), self.mdt)
             self._rcu(x1, pre + "u1", B, H, W_, s, extra_res=x0, tag=tag)
             cur = s
-        r = self.ws("fus_rcu2_" + tag, (M, F))
+        r = self.ws("fus_rcu2_" + tag, (M, F), self.mdt)
         self._rcu(cur, pre + "u2", B, H, W_, r, tag=tag)
-        oc = self.ws("fus_oc_" + tag, (M, F))
+        oc = self.ws("fus_oc_" + tag, (M, F), self.mdt)
         ops.gemm(r, w[pre + "out.w"], oc, M=M, N=F, K=F, lda=F, ldc=F, bias=w[pre + "out.b"])
         OH, OW = (2 * H, 2 * W_) if crop is None else crop
-        up = self.ws("fus_up_" + tag, (B * OH * OW, F))
+        up = self.ws("fus_up_" + tag, (B * OH * OW, F), self.mdt)
         ops.upsample2x(oc, up, B=B, H=H, W_=W_, C_=F, outH=OH, outW=OW)
         return up, OH, OW
 
@@ -622,7 +626,8 @@ class Engine:
         hk = cfg.hooks
         dims = (cfg.enc_dim, cfg.dec_dim, cfg.dec_dim, cfg.dec_dim)
         ld = (96, 192, 384, 768)
-        t = [self.ws("dpt%d_pp%d" % (num, i), (R, ld[i])) for i in range(4)]
+        mdt = self.mdt
+        t = [self.ws("dpt%d_pp%d" % (num, i), (R, ld[i]), mdt) for i in range(4)]
         pairable = len({dec[hk[i]].dtype for i in range(4)}) == 1          # one kernel instance per pair (same operand dtypes)
         # the four hooks are independent: two launches of two differently shaped problems each (sp3_gemm2)
         import contextlib
@@ -633,14 +638,14 @@ class Engine:
                     ops.gemm(dec[hk[i]], w[pre + "pp%d.w" % i], t[i], M=R, N=ld[i], K=dims[i], lda=dims[i], ldc=ld[i], bias=w[pre + "pp%d.b" % i])
         # act_postprocess tails (croco/models/dpt_block.py:356-410)
         c0 = 128 if self.wdt == torch.bfloat16 else ld[0]         # (bf16 mode: 32 zero channels ride along, see _pack)
-        l0 = self.ws("dpt%d_l0" % num, (B * 16 * nh * nw, c0))
-        l1 = self.ws("dpt%d_l1" % num, (B * 4 * nh * nw, ld[1]))
+        l0 = self.ws("dpt%d_l0" % num, (B * 16 * nh * nw, c0), mdt)
+        l1 = self.ws("dpt%d_l1" % num, (B * 4 * nh * nw, ld[1]), mdt)
         with pair():
             ops.conv_transpose_ks(t[0], w[pre + "pp0t.w"], l0, B=B, H=nh, W_=nw, Cin=ld[0], Cout=c0, ks=4, bias=w[pre + "pp0t.b"])
             ops.conv_transpose_ks(t[1], w[pre + "pp1t.w"], l1, B=B, H=nh, W_=nw, Cin=ld[1], Cout=ld[1], ks=2, bias=w[pre + "pp1t.b"])
         l2 = t[2]
         h3, w3 = (nh - 1) // 2 + 1, (nw - 1) // 2 + 1
-        l3 = self.ws("dpt%d_l3" % num, (B * h3 * w3, ld[3]))
+        l3 = self.ws("dpt%d_l3" % num, (B * h3 * w3, ld[3]), mdt)
         sk = self._conv_ws(num)
         ops.conv3x3(t[3], w[pre + "pp3c.w"], l3, B=B, H=nh, W_=nw, Cin=ld[3], Cout=ld[3], stride=2, bias=w[pre + "pp3c.b"],
                     splitk_ws=sk)
@@ -649,7 +654,7 @@ class Engine:
         rn = []
         for i, src in enumerate((l0, l1, l2, l3)):
             Hh, Ww = geo[i]
-            o = self.ws("dpt%d_rn%d" % (num, i), (B * Hh * Ww, F))
+            o = self.ws("dpt%d_rn%d" % (num, i), (B * Hh * Ww, F), mdt)
             ops.conv3x3(src, w[pre + "rn%d.w" % i], o, B=B, H=Hh, W_=Ww, Cin=(c0 if i == 0 else ld[i]), Cout=F, splitk_ws=sk)
             rn.append(o)
         # refinenets; path_4 is cropped to layer 3's size (dust3r/heads/dpt_head.py:57)
@@ -658,12 +663,12 @@ class Engine:
         p2, H2, W2 = self._fusion(pre + "ref2.", B, H3, W3, p3, rn[1], "%d_2" % num)
         p1, H1, W1 = self._fusion(pre + "ref1.", B, H2, W2, p2, rn[0], "%d_1" % num)
         # head: conv3x3(256->128) -> x2 -> conv3x3(128->128) + ReLU -> 1x1(128->4) + postprocess
-        a = self.ws("dpt%d_h0" % num, (B * H1 * W1, Lc))
+        a = self.ws("dpt%d_h0" % num, (B * H1 * W1, Lc), mdt)
         ops.conv3x3(p1, w[pre + "h0.w"], a, B=B, H=H1, W_=W1, Cin=F, Cout=Lc, bias=w[pre + "h0.b"])
         OH, OW = 2 * H1, 2 * W1
-        u = self.ws("dpt%d_h0up" % num, (B * OH * OW, Lc))
+        u = self.ws("dpt%d_h0up" % num, (B * OH * OW, Lc), mdt)
         ops.upsample2x(a, u, B=B, H=H1, W_=W1, C_=Lc)
-        c = self.ws("dpt%d_h2" % num, (B * OH * OW, Lc))
+        c = self.ws("dpt%d_h2" % num, (B * OH * OW, Lc), mdt)
         ops.conv3x3(u, w[pre + "h2.w"], c, B=B, H=OH, W_=OW, Cin=Lc, Cout=Lc, bias=w[pre + "h2.b"], act=ACT_RELU)
         pts = self.ws("dpt_pts%d" % num, (B, OH, OW, 3))
         conf = self.ws("dpt_conf%d" % num, (B, OH, OW))

@@ -138,6 +138,9 @@ _PROTOS = {
     "sp3_upsample2x": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "sp3_head_final": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                        C.c_void_p],
+    "sp3_upsample2x_bf16": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p],
+    "sp3_head_final_bf16": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                            C.c_void_p],
     "sp3_fill_f32": [C.c_void_p, C.c_float, C.c_int64, C.c_void_p],
     "sp3_cast_f32_to_bf16": [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
     "sp3_copy2d_f32": [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p],

@@ -467,11 +467,15 @@ def conv3x3(x, Wp, out, *, B, H, W_, Cin, Cout, stride=1, bias=None, res1=None, 
             and Cin % 64 == 0 and Cout % 64 == 0 and Cin <= 768 and (force_tile_kernel or B * H * W_ >= 2048)):
         # bf16 weights, stride 1: the LDS-tiled kernel (input halo tile staged once, 9 taps read it from LDS)
         _act(x, "x")
+        rbf = [t.dtype == torch.bfloat16 for t in (res1, res2) if t is not None]
+        if rbf and (any(rbf) != all(rbf) or (any(rbf) and out.dtype != torch.bfloat16)):
+            raise TypeError("conv3x3: residual maps must share one dtype (bf16 only next to a bf16 output)")
+        oflag = int(out.dtype == torch.bfloat16) | (2 if any(rbf) else 0)
         _timed("conv3x3_tile", 2.0 * B * H * W_ * Cout * 9 * Cin,
                B * H * W_ * (x.element_size() * Cin + out.element_size() * Cout) + 2.0 * 9 * Cin * Cout,
                lambda: L.check(L.load().sp3_conv3x3_tile(
                    x.data_ptr(), int(x.dtype == torch.bfloat16), Wp.data_ptr(), L.ptr(bias), L.ptr(res1), L.ptr(res2),
-                   out.data_ptr(), int(out.dtype == torch.bfloat16), B, H, W_, Cin, Cout, int(relu_in), act,
+                   out.data_ptr(), oflag, B, H, W_, Cin, Cout, int(relu_in), act,
                    L.stream_ptr()), "sp3_conv3x3_tile"))
         return out
     d = GemmDesc()
@@ -496,6 +500,9 @@ def conv3x3(x, Wp, out, *, B, H, W_, Cin, Cout, stride=1, bias=None, res1=None, 
             p.tile = lean
             _gemm_launch(p, "sp3_gemm(conv3x3)", "conv3x3")
             return out
+    if any(t is not None and t.dtype == torch.bfloat16 for t in (res1, res2)):
+        raise TypeError("conv3x3: bf16 residual maps are served by the lean small-map and the LDS-tiled kernels only "
+                        "(B*H*W=%d, Cin=%d, Cout=%d, stride %d)" % (B * H * W_, Cin, Cout, stride))
     S = conv_splitk(M, Cout, 9 * Cin, Wp.dtype) if (splitk_ws is not None and tile < 0 and out.dtype == torch.float32) else 1
     if S > 1 and splitk_ws.numel() < S * M * Cout:
         raise ValueError("conv3x3: splitk_ws holds %d floats, needs %d" % (splitk_ws.numel(), S * M * Cout))
@@ -820,16 +827,19 @@ def im2col_patch(img, out, *, B, C_, H, W_, p, strides):
 def upsample2x(x, out, *, B, H, W_, C_, outH=None, outW=None):
     outH = 2 * H if outH is None else outH
     outW = 2 * W_ if outW is None else outW
-    _timed("upsample2x", 8.0 * B * outH * outW * C_, 4.0 * B * C_ * (H * W_ + outH * outW),
-           lambda: L.check(L.load().sp3_upsample2x(x.data_ptr(), out.data_ptr(), B, H, W_, C_, outH, outW, L.stream_ptr()),
-                           "sp3_upsample2x"))
+    if x.dtype != out.dtype or x.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("upsample2x: fp32 or bf16 maps, input and output alike")
+    fn = L.load().sp3_upsample2x_bf16 if x.dtype == torch.bfloat16 else L.load().sp3_upsample2x
+    _timed("upsample2x", 8.0 * B * outH * outW * C_, float(x.element_size()) * B * C_ * (H * W_ + outH * outW),
+           lambda: L.check(fn(x.data_ptr(), out.data_ptr(), B, H, W_, C_, outH, outW, L.stream_ptr()), "sp3_upsample2x"))
     return out
 
 
 def head_final(feat, w, b, pixels, C_, pts, conf, raw=None):
-    _timed("head_final", 8.0 * pixels * C_, 4.0 * pixels * (C_ + 4),
-           lambda: L.check(L.load().sp3_head_final(feat.data_ptr(), w.data_ptr(), b.data_ptr(), pixels, C_, pts.data_ptr(),
-                                                   conf.data_ptr(), L.ptr(raw), L.stream_ptr()), "sp3_head_final"))
+    fn = L.load().sp3_head_final_bf16 if feat.dtype == torch.bfloat16 else L.load().sp3_head_final
+    _timed("head_final", 8.0 * pixels * C_, pixels * (float(feat.element_size()) * C_ + 16.0),
+           lambda: L.check(fn(feat.data_ptr(), w.data_ptr(), b.data_ptr(), pixels, C_, pts.data_ptr(),
+                              conf.data_ptr(), L.ptr(raw), L.stream_ptr()), "sp3_head_final"))
 
 
 def fill(t, v):
