@@ -35,9 +35,10 @@ def lean_key(row):
         return ("gemm2" if pair else "gemm") + "<Abf16,Wbf16,plain,%s>" % _TILE_NAMES[tile]
     if "conv3x3_tile_kernel" in n:
         return "conv3x3_tile"
-    m = re.search(r"conv_sm_kernel<(\d+), (\d+), (\d+)", n)
+    m = re.search(r"conv_sm_kernel<([^,>]*), (\d+),", n) or re.search(r"conv_sm_kernelI(\w+?)Li(\d+)E", n)
     if m:
-        return "gemm<Af32,Wbf16,conv3x3,%s>" % _TILE_NAMES[40 if m.group(1) == "1" else 41]
+        bf = "float" not in m.group(1) and m.group(1) != "f"
+        return "gemm<A%s,Wbf16,conv3x3,%s>" % ("bf16" if bf else "f32", _TILE_NAMES[40 if m.group(2) == "1" else 41])
     if "attention_packed_kernel" in n:
         return "attention_packed<bf16>"
     return None
