@@ -35,10 +35,10 @@ def lean_key(row):
         return ("gemm2" if pair else "gemm") + "<Abf16,Wbf16,plain,%s>" % _TILE_NAMES[tile]
     if "conv3x3_tile_kernel" in n:
         return "conv3x3_tile"
-    m = re.search(r"conv_sm_kernel<([^,>]*), (\d+),", n) or re.search(r"conv_sm_kernelI(\w+?)Li(\d+)E", n)
-    if m:
-        bf = "float" not in m.group(1) and m.group(1) != "f"
-        return "gemm<A%s,Wbf16,conv3x3,%s>" % ("bf16" if bf else "f32", _TILE_NAMES[40 if m.group(2) == "1" else 41])
+    if "conv_sm_kernel" in n:
+        # (the demangler prints __bf16 template arguments as garbage: take the dtype from the spelling, the tile from the workgroup size)
+        bf = "float" not in n and "conv_sm_kernelIf" not in n
+        return "gemm<A%s,Wbf16,conv3x3,%s>" % ("bf16" if bf else "f32", _TILE_NAMES[40 if row["grid"][3] == 768 else 41])
     if "attention_packed_kernel" in n:
         return "attention_packed<bf16>"
     return None
