@@ -28,6 +28,35 @@ def _rope_tables(max_pos, base, device):
     return ang.cos().contiguous().to(device), ang.sin().contiguous().to(device)
 
 
+def _rope_tables_narrow(max_pos, base, head_dim, device):
+    """cos/sin [max_pos, 16] for RoPE2D on heads NARROWER than 64 (use_feat: 16 heads of 48, spann3r/model.py:225-235) in the
+    kernels' 64-slot head layout: per axis D = head_dim / 2 with D / 2 frequencies base^(-2i/D) (croco/models/pos_embed.py:118-129);
+    frequency i of an axis sits in table column i, the unused columns hold the identity rotation (cos 1, sin 0)."""
+    D = head_dim // 2
+    nf = D // 2
+    assert nf <= 16 and head_dim % 4 == 0
+    inv_freq = 1.0 / (base ** (torch.arange(0, D, 2).float() / D))
+    t = torch.arange(max_pos, dtype=torch.float32)
+    ang = torch.einsum("i,j->ij", t, inv_freq)
+    cos, sin = torch.ones(max_pos, 16), torch.zeros(max_pos, 16)
+    cos[:, :nf], sin[:, :nf] = ang.cos(), ang.sin()
+    return cos.contiguous().to(device), sin.contiguous().to(device)
+
+
+def narrow_head_slots(head_dim):
+    """slot (0..63) of every dimension of a head of head_dim < 64 under RoPE2D: dimension d = axis * D + half * D/2 + i lands at
+    axis * 32 + half * 16 + i, which is where the kernels' 64-wide rotary pairing (column c with c ^ 16 inside each 32-wide axis
+    half) expects it; dot products and the attention output do not care about a permutation shared by q and k."""
+    D = head_dim // 2
+    nf = D // 2
+    idx = []
+    for d in range(head_dim):
+        a, j = divmod(d, D)
+        h, i = divmod(j, nf)
+        idx.append(a * 32 + h * 16 + i)
+    return torch.tensor(idx, dtype=torch.long)
+
+
 class Engine:
     def __init__(self, cfg: Spann3RConfig, params: dict, device, precision="fp32"):
         assert precision in ("fp32", "f32x3", "f32x6", "f16x3", "bf16")
@@ -47,6 +76,9 @@ class Engine:
         # RoPE tables for every grid the build supports, allocated ONCE: captured graphs hold their addresses
         self.max_pos = 256
         self.cos, self.sin = _rope_tables(self.max_pos, cfg.rope_base, self.device)
+        self.rope_narrow = None
+        if cfg.use_feat and cfg.mem_pos_enc:
+            self.rope_narrow = _rope_tables_narrow(self.max_pos, cfg.rope_base, cfg.val_dim // cfg.enc_heads, self.device)
         self.w = {}
         self._pack(params)
 
@@ -100,6 +132,12 @@ class Engine:
                 qb = p[src + "attn.qkv.bias"].detach().to(dev, torch.float32).reshape(3, Hh, hd)
                 qwp, qbp = torch.zeros(3, Hh, 64, Cv, device=dev), torch.zeros(3, Hh, 64, device=dev)
                 qwp[:, :, :hd], qbp[:, :, :hd] = qw, qb
+                if cfg.mem_pos_enc:
+                    # RoPE on the 48-wide heads (mem_pos_enc with use_feat): q and k rows go to the slots the 64-wide rotary pairing
+                    # expects (narrow_head_slots); v keeps the plain zero padding (it meets the padded output projection)
+                    slots = narrow_head_slots(hd).to(dev)
+                    qwp[:2], qbp[:2] = 0.0, 0.0
+                    qwp[:2, :, slots], qbp[:2, :, slots] = qw[:2], qb[:2]
                 fold("val%d.qkv" % i, qwp.reshape(3 * Hh * 64, Cv), qbp.reshape(-1), src + "norm1")
                 pw = p[src + "attn.proj.weight"].detach().to(dev, torch.float32).reshape(Cv, Hh, hd)
                 pwp = torch.zeros(Cv, Hh, 64, device=dev)
@@ -209,7 +247,7 @@ class Engine:
     # Activations that only feed a GEMM (LayerNorm outputs, attention outputs, GELU outputs) are stored in `adt`
     # (bf16 in bf16 mode: exactly the rounding the MFMA operand conversion would apply on load, at half the traffic);
     # the residual stream, LayerNorm statistics and everything the API returns stay fp32.
-    def _attn_core(self, xp, st, R, B, P, C, heads, pre, pos32, ao, tag="", head_dim=64):
+    def _attn_core(self, xp, st, R, B, P, C, heads, pre, pos32, ao, tag="", head_dim=64, rope_tab=None):
         """norm1 (folded) + qkv projection with fused bias + 2-D RoPE + per-head V^T store, then softmax(qk^T/sqrt(d))v
         (croco/models/blocks.py:94-109, 128).  xp/st: fragment-order copy and row-statistics partials of the stream x.
         The kernels keep 64-wide heads: narrower ones (head_dim < 64: the 16 x 48 heads of the use_feat value encoder) run on
@@ -220,13 +258,14 @@ class Engine:
         A = heads * 64
         npad = (P + 63) // 64 * 64
         scale = head_dim ** -0.5
+        cos, sin = rope_tab or (self.cos, self.sin)
         ln = ops.LnFold(st, C, w[pre + "qkv.s"], 1e-6)
         if self.packed_attn:
             # fragment-order q/k (+ PV-order V) straight from the projection epilogue; zero pad rows are never written
             qkp = self.ws("qkp" + tag, ops.packed_shape(B * npad, 2 * A, self.wdt), self.wdt, zero=True)
             vtp = self.ws("vtp" + tag, (B * heads * npad * 64,), self.wdt, zero=True)
             ops.proj_rope_vt(xp, w[pre + "qkv.w"], w[pre + "qkv.b"], qkp, 0, vtp, npad, M=R, N=3 * A, K=C, lda=C,
-                             rope_cols=2 * A, pos=pos32, cos=self.cos, sin=self.sin, tokens=P, heads=heads, qkv_packed=True,
+                             rope_cols=2 * A, pos=pos32, cos=cos, sin=sin, tokens=P, heads=heads, qkv_packed=True,
                              ln=ln)
             ops.attention_packed(qkp, 2 * A, 0, npad, qkp, 2 * A, A, npad, vtp, ao, A, B=B, heads=heads, Nq=P, Nk=P,
                                  scale=scale)
@@ -234,7 +273,7 @@ class Engine:
         qk = self.ws("qk" + tag, (R, 2 * A), self.wdt)
         vt = self.ws("vt" + tag, (B * heads * 64, npad), self.wdt, zero=True)
         ops.proj_rope_vt(xp, w[pre + "qkv.w"], w[pre + "qkv.b"], qk, 2 * A, vt, npad, M=R, N=3 * A, K=C, lda=C,
-                         rope_cols=2 * A, pos=pos32, cos=self.cos, sin=self.sin, tokens=P, heads=heads, ln=ln)
+                         rope_cols=2 * A, pos=pos32, cos=cos, sin=sin, tokens=P, heads=heads, ln=ln)
         ops.attention(qk, P * 2 * A, 2 * A, qk[:, A:], P * 2 * A, 2 * A, vt, npad, ao, A, B=B, heads=heads, Nq=P, Nk=P,
                       scale=scale)
 
@@ -259,12 +298,12 @@ class Engine:
         ops.gemm(xp, w[pre + "fc1.w"], h, M=R, N=Hd, K=C, lda=C, ldc=Hd, bias=w[pre + "fc1.b"], act=ACT_GELU,
                  ln=ops.LnFold(st, C, w[pre + "fc1.s"], 1e-6))
 
-    def _block(self, x, xpA, stA, xpB, stB, R, B, P, C, heads, pre, pos32, tag="", last=False, head_dim=64):
+    def _block(self, x, xpA, stA, xpB, stB, R, B, P, C, heads, pre, pos32, tag="", last=False, head_dim=64, rope_tab=None):
         """Pre-LN ViT block on the fp32 stream x (croco/models/blocks.py:127-130): 5 launches, no LayerNorm kernel.
         (xpA, stA) describe x on entry and on exit (unless `last`); (xpB, stB) are scratch for the mid-block state."""
         A = heads * 64                                  # attention width (= C unless the heads are zero-padded, _attn_core)
         ao = self.wsp("attn_out" + tag, R, A)
-        self._attn_core(xpA, stA, R, B, P, C, heads, pre, pos32, ao, tag=tag, head_dim=head_dim)
+        self._attn_core(xpA, stA, R, B, P, C, heads, pre, pos32, ao, tag=tag, head_dim=head_dim, rope_tab=rope_tab)
         self._update(ao, pre + "proj", R, C, A, x, x, xpB, stB)
         Hd = C * self.cfg.mlp_ratio
         h = self.wsp("mlp_hidden" + tag, R, Hd)
@@ -676,15 +715,20 @@ class Engine:
         ops.head_final(c, w[pre + "h4.w"], w[pre + "h4.b"], B * OH * OW, Lc, pts, conf, raw)
         return pts, conf, raw
 
-    def encode_cur_value_feat(self, tok, out, res):
+    def encode_cur_value_feat(self, tok, out, res, pos32=None):
         """spann3r/model.py:312-314 (use_feat=True): value_out(value_norm(value_encoder(dec1[-1]))) -- 6 blocks of width 768 with
-        16 heads of 48 (zero-padded to 64, _attn_core) and no RoPE; `res` (feat_k1) is added by the finishing GEMM if given.
-        tok fp32 [B,P,768]."""
+        16 heads of 48 (zero-padded to 64, _attn_core); no RoPE, or with mem_pos_enc RoPE2D on the 48-wide heads (pos32 = the
+        tokens' int32 (y, x) positions: narrow_head_slots / _rope_tables_narrow); `res` (feat_k1) is added by the finishing GEMM if
+        given.  tok fp32 [B,P,768]."""
         cfg, w = self.cfg, self.w
         B, P, Cv = tok.shape
-        assert Cv == cfg.val_dim and not cfg.mem_pos_enc
+        assert Cv == cfg.val_dim
         R, E = B * P, cfg.enc_dim
         zero_pos = self.ws("valf_zero_pos", (R, 2), torch.int32, zero=True)     # rope=None (:232-234): all-zero positions = identity
+        rope_tab = None
+        if cfg.mem_pos_enc:
+            assert pos32 is not None and self.rope_narrow is not None
+            zero_pos, rope_tab = pos32, self.rope_narrow
         x = self.ws("valf_x", (R, Cv))
         xpA, xpB = self.wsp("valf_xpA", R, Cv), self.wsp("valf_xpB", R, Cv)
         stA, stB = self.stats("valf_stA", R, Cv), self.stats("valf_stB", R, Cv)
@@ -692,7 +736,7 @@ class Engine:
         ops.pack_stats(x, xpA, stA, rows=R, C_=Cv)
         for i in range(cfg.val_depth):
             self._block(x, xpA, stA, xpB, stB, R, B, P, Cv, cfg.enc_heads, "val%d." % i, zero_pos, tag="_valf",
-                        head_dim=Cv // cfg.enc_heads)
+                        head_dim=Cv // cfg.enc_heads, rope_tab=rope_tab)
         ops.gemm(xpA, w["value_out.w"], out, M=R, N=E, K=Cv, lda=Cv, ldc=E, bias=w["value_out.b"], res1=res, ldr1=E,
                  ln=ops.LnFold(stA, Cv, w["value_out.s"], 1e-6))
         return out

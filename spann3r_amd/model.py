@@ -697,7 +697,8 @@ class _SequenceRunner:
         pts1, conf1, _ = eng.dpt_head(dec1, B, self.hh, self.hw, 1)
         # portrait results are handed on axis-swapped (landscape_only wrapper); the value encoder sees that view
         if eng.cfg.use_feat:                    # spann3r/model.py:312-314: the value comes from dec1[-1], not from the pointmap
-            eng.encode_cur_value_feat(dec1[-1], self.v, self.k1)
+            eng.encode_cur_value_feat(dec1[-1], self.v, self.k1,
+                                      pos32=eng.positions(B, self.nh, self.nw)[1] if eng.cfg.mem_pos_enc else None)
         else:
             eng.encode_cur_value(pts1.swapaxes(1, 2) if self.swap else pts1, self.v, self.k1)   # v = cur_v + feat_k1
         mem.stage_write(self.k1, self.v)
@@ -764,10 +765,6 @@ class Spann3R(nn.Module):
                  use_feat=False, mem_pos_enc=False, memory_dropout=0.15, cfg: Spann3RConfig = None,
                  init_weights=True):
         super().__init__()
-        if use_feat and mem_pos_enc:
-            raise NotImplementedError("use_feat=True together with mem_pos_enc=True (RoPE on 48-wide heads inside the value encoder) "
-                                      "is not built: the attention kernels keep 64-wide heads (48-wide ones run zero-padded, which "
-                                      "the rotary pairing does not survive); each option alone is supported")
         self.use_feat = use_feat
         self.mem_pos_enc = mem_pos_enc
         # spann3r/model.py:248: only its .training flag and p matter for the forward-only build
@@ -958,7 +955,10 @@ class Spann3R(nn.Module):
         if self.cfg.use_feat:                                               # :313-314: value from the last decoder output
             tok = dec1[-1]
             out = torch.empty(tok.shape[0], tok.shape[1], self.cfg.enc_dim, device=tok.device)
-            return self.engine.encode_cur_value_feat(tok, out, add)
+            pos32 = None
+            if self.cfg.mem_pos_enc:                                        # pos1: int64 [B, P, 2] token positions (:313)
+                pos32 = pos1.reshape(-1, 2).to(torch.int32).to(tok.device).contiguous()
+            return self.engine.encode_cur_value_feat(tok, out, add, pos32=pos32)
         pts = res1["pts3d"]
         B = pts.shape[0]
         P = (pts.shape[1] // self.cfg.patch) * (pts.shape[2] // self.cfg.patch)

@@ -204,6 +204,27 @@ def make_usefeat():
     print("usefeat: %d arrays" % len(out))
 
 
+def make_usefeat_mpe():
+    """Spann3R(use_feat=True, mem_pos_enc=True): RoPE2D on the 48-wide heads of the 768-wide value encoder (spann3r/model.py:225-235,
+    croco/models/pos_embed.py:112-159 with D = 24 per axis) -- the one constructor combination the MI355X build used to refuse"""
+    import dataclasses
+    cfg = dataclasses.replace(TINY, use_feat=True, mem_pos_enc=True)
+    H, W, NF = 64, 80, 4
+    sd = synth_state_dict(0, cfg)
+    frames = synth_frames(NF, H, W, batch=2, seed=41)
+    out = {"meta_hw": np.array([H, W]), "meta_frames": np.array(NF), "meta_seed": np.array(41), "meta_batch": np.array(2),
+           "fingerprint": np.array(state_dict_fingerprint(sd))}
+    m = build_reference(cfg, sd, "usefeatmpe", use_feat=True, mem_pos_enc=True)
+    with torch.no_grad():
+        preds, preds_all, sp = m(frames, return_memory=True)
+    for j, p in enumerate(preds):
+        out["eval_pred%d_pts" % j] = npf(p["pts3d" if j == 0 else "pts3d_in_other_view"])
+        out["eval_pred%d_conf" % j] = npf(p["conf"])
+    out["eval_mem_v"], out["eval_mem_k"] = npf(sp.mem_v), npf(sp.mem_k)
+    np.savez_compressed(os.path.join(HERE, "spann3r_usefeat_mpe.npz"), **out)
+    print("usefeat_mpe: %d arrays" % len(out))
+
+
 def make_full():
     cfg, H, W, NF = FULL, 224, 224, 5
     sd = synth_state_dict(0, cfg)
@@ -653,6 +674,8 @@ if __name__ == "__main__":
         make_crop()
     if "usefeat" in what:
         make_usefeat()
+    if "usefeatmpe" in what:
+        make_usefeat_mpe()
     if "traingrad" in what:
         make_traingrad()
     if "postprocess" in what:

@@ -119,8 +119,12 @@ def test_constructor_from_reference_checkpoint(tiny_sd):
     assert Spann3RConfig.from_ctor_string(TINY.ctor_string("PatchEmbedDust3R")) == TINY
     with pytest.raises(ValueError):
         Spann3RConfig.from_ctor_string("AsymmetricCroCo3DStereo(enc_embed_dim=768, dec_depth=12)")
-    with pytest.raises(NotImplementedError):                  # the one unsupported combination (RoPE on zero-padded 48-wide heads)
-        Spann3R(dus3r_name=None, cfg=TINY, use_feat=True, mem_pos_enc=True, init_weights=False)
+    both = Spann3R(dus3r_name=None, cfg=TINY, use_feat=True, mem_pos_enc=True, init_weights=False)
+    assert both.cfg.use_feat and both.cfg.mem_pos_enc         # RoPE on the 48-wide heads: engine.narrow_head_slots
+    from spann3r_amd.engine import narrow_head_slots
+    slots = narrow_head_slots(48).tolist()
+    assert len(set(slots)) == 48 and max(slots) < 64 and all((s & 15) < 12 for s in slots)
+    assert all(slots[d] ^ 16 == slots[d + 12] for a in (0, 24) for d in range(a, a + 12))      # rotary partners stay partners
     uf = Spann3R(dus3r_name=None, cfg=TINY, use_feat=True, init_weights=False)       # spann3r/model.py:225,239: 768-wide value encoder
     keys = set(uf.state_dict().keys())
     assert "pos_patch_embed.proj.weight" not in keys and tuple(uf.state_dict()["value_out.weight"].shape) == (1024, 768)

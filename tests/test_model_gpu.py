@@ -154,8 +154,47 @@ def test_tiny_use_feat_vs_golden(precision, tol):
         assert worst < tol, (tag, worst)
         if precision == "fp32":
             assert rel_err(mem.mem_v.cpu(), g[tag + "_mem_v"]) < tol
-    with pytest.raises(NotImplementedError):
-        Spann3R(dus3r_name=None, cfg=TINY, init_weights=False, use_feat=True, mem_pos_enc=True)
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", TOL_FP32), ("bf16", TOL_BF16)])
+def test_tiny_use_feat_mem_pos_enc_vs_golden(precision, tol):
+    """Spann3R(use_feat=True, mem_pos_enc=True): RoPE2D on the 48-wide heads of the 768-wide value encoder (spann3r/model.py:225-235
+    with rope=self.rope, :313 passing pos1) -- q/k head rows scattered into the kernels' 64-slot rotary layout with a 12-frequency
+    table (engine.narrow_head_slots / _rope_tables_narrow) -- against a dump of the reference on the same weights and frames"""
+    import dataclasses
+    from spann3r_amd import Spann3R, TINY
+    from spann3r_amd.weights import synth_frames, synth_state_dict, state_dict_fingerprint
+    g = load_golden("spann3r_usefeat_mpe.npz")
+    cfg = dataclasses.replace(TINY, use_feat=True, mem_pos_enc=True)
+    sd = synth_state_dict(0, cfg)
+    assert state_dict_fingerprint(sd) == float(g["fingerprint"])
+    H, W = map(int, g["meta_hw"])
+    m = Spann3R(dus3r_name=None, cfg=TINY, init_weights=False, use_feat=True, mem_pos_enc=True)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV).eval().set_precision(precision)
+    frames = to_dev(synth_frames(int(g["meta_frames"]), H, W, batch=int(g["meta_batch"]), seed=int(g["meta_seed"])))
+    for rep in range(2):                                     # eager, then the captured graphs
+        preds, _, mem = m(frames, return_memory=True)
+        worst = 0.0
+        for j, p in enumerate(preds):
+            worst = max(worst, rel_err(p["pts3d" if j == 0 else "pts3d_in_other_view"].cpu(), g["eval_pred%d_pts" % j]),
+                        rel_err(p["conf"].cpu(), g["eval_pred%d_conf" % j]))
+        assert worst < tol, (rep, worst)
+        if precision == "fp32":
+            assert rel_err(mem.mem_v.cpu(), g["eval_mem_v"]) < tol
+            assert rel_err(mem.mem_k.cpu(), g["eval_mem_k"]) < tol
+    # the rotary embedding must matter in this dump: with the positions zeroed the values move by far more than the tolerance
+    if precision == "fp32":
+        eng = m.engine
+        keep = eng.rope_narrow
+        eng.rope_narrow = (torch.ones_like(keep[0]), torch.zeros_like(keep[1]))
+        m._runners.clear()
+        try:
+            _, _, mem0 = m(frames, return_memory=True)
+        finally:
+            eng.rope_narrow = keep
+            m._runners.clear()
+        assert rel_err(mem0.mem_v.cpu(), g["eval_mem_v"]) > 10 * tol
 
 
 def test_graph_replay_equals_eager(tiny_model):
