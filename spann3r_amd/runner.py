@@ -213,15 +213,22 @@ class GradReducer:
         for p in self.params:
             p._sp3_pending = 0
 
-    def prepare(self):
-        """arm the hooks for the backward pass that follows (overlap=True)"""
+    def prepare(self, arm=True):
+        """arm the hooks for the backward pass that follows (overlap=True).  arm=False: a backward that only accumulates (gradient
+        accumulation, spann3r/training.py:228-233) -- no collective starts from it, the window's last backward reduces the sums"""
         self._reset_pending()
         self._work = [None] * len(self.buckets)
         self._pending = [len(b) for b in self.buckets]
         self._next = 0
         self._started = False
         self.launched_in_backward = 0
-        self._armed = self.active()
+        self._armed = bool(arm) and self.active()
+
+    def untouched(self):
+        """parameters that got no gradient on THIS rank since zero_grad() (one-rank counterpart of unused_everywhere())"""
+        if not any(self._touched):
+            return []
+        return [p for p, t in zip(self.params, self._touched) if not t]
 
     def _on_grad(self, p):
         self._touched[self._index_of[id(p)]] = True

@@ -29,6 +29,7 @@ dW = dY^T . X are all plain A . W^T launches, no fp32 transposes -- the attentio
 MFMA per product, and the memory read's fp32 GEMMs do the same (sp3_gemm f32x3 = 2).  Master weights, gradients (flat buckets the
 kernels accumulate into directly), LayerNorm, softmax statistics, the residual stream and the optimizer stay fp32."""
 import ctypes
+import math
 
 import torch
 
@@ -1188,7 +1189,7 @@ class TrainStep:
     (`set_lr`).  Shapes must not change between steps (training batches of one resolution)."""
 
     def __init__(self, model, lr=5e-5, weight_decay=0.05, betas=(0.9, 0.95), clip_grad=1.0, precision="bf16", bucket_mb=64.0, force_collectives=False,
-                 graph=False):
+                 graph=False, accum_iter=1):
         from .loss import ConfLoss_t, Regr3D_t, L21
         from .runner import GradReducer
         set_precision(precision)
@@ -1202,20 +1203,53 @@ class TrainStep:
         import os
         self.graph = bool(graph) and os.environ.get("SP3_TRAIN_GRAPH", "1") != "0"
         self._g = self._static = self._out = None
+        # gradient accumulation (spann3r/training.py:228-233): run() is ONE iteration of the loop; the gradients of accum_iter
+        # consecutive iterations (each loss divided by accum_iter) add up in the flat buckets and the last one reduces them over the
+        # ranks, clips and updates.  (DDP all-reduces after every backward; the mean over ranks is linear, so one reduction of the
+        # accumulated buckets gives the same gradient with accum_iter times fewer collectives.)
+        self.accum_iter = int(accum_iter)
+        assert self.accum_iter >= 1
+        self.data_iter_step = 0                      # iterations since the last reset_iteration(): position inside the window
+        self._graphs = {}                            # (first, last) of the window -> (hipGraph, outputs, orientation pattern)
 
     def set_lr(self, lr):
         for g in self.opt.param_groups:
             g["lr"] = lr * g.get("lr_scale", 1.0)
 
-    def _body(self, frames, gts, monitor):
-        self.reducer.zero_grad()
-        self.reducer.prepare()                       # (also resets the direct-to-bucket bookkeeping, train.reset_pending)
+    def adjust_learning_rate(self, epoch, args):
+        """croco/utils/misc.py:464-479 (the per-iteration hook of spann3r/training.py:205-207): linear warm-up over
+        args.warmup_epochs, then half-cycle cosine from args.lr to args.min_lr at args.epochs; every group gets lr * its lr_scale.
+        `epoch` is fractional.  In graph mode the value reaches the captured update kernels through device memory (sync_lr)."""
+        if epoch < args.warmup_epochs:
+            lr = args.lr * epoch / args.warmup_epochs
+        else:
+            lr = args.min_lr + (args.lr - args.min_lr) * 0.5 * (1.0 + math.cos(math.pi * (epoch - args.warmup_epochs) / (args.epochs - args.warmup_epochs)))
+        self.set_lr(lr)
+        return lr
+
+    def reset_iteration(self):
+        """start of an epoch (training.py:200 `optimizer.zero_grad()`): an unfinished accumulation window is dropped"""
+        self.data_iter_step = 0
+
+    def _window(self):
+        i = self.data_iter_step % self.accum_iter
+        return i == 0, i == self.accum_iter - 1
+
+    def _body(self, frames, gts, monitor, first=True, last=True):
+        if first:
+            self.reducer.zero_grad()
+        self.reducer.prepare(arm=last)               # (also resets the direct-to-bucket bookkeeping, train.reset_pending)
         preds, preds_all = self.model(frames)
         loss, details, factor = self.crit.compute_frame_loss(gts, preds_all, monitor=monitor)
         total = loss + factor
-        total.backward()
+        (total if self.accum_iter == 1 else total * (1.0 / self.accum_iter)).backward()          # training.py:228 `loss /= accum_iter`
+        if not last:
+            return total.detach(), None
         self.reducer.finish()
-        norm = self.opt.step(max_norm=self.clip_grad, skip=self.reducer.unused_everywhere() if self.reducer.active() else ())
+        # parameters without a gradient in the whole window keep .grad None in the reference and AdamW passes over them (no weight
+        # decay either): across ranks the used-set exchange of the reducer, on one rank its own bookkeeping
+        skip = self.reducer.unused_everywhere() if self.reducer.active() else self.reducer.untouched()
+        norm = self.opt.step(max_norm=self.clip_grad, skip=skip)
         return total.detach(), norm
 
     @staticmethod
@@ -1229,33 +1263,45 @@ class TrainStep:
         return tuple(pat)
 
     def run(self, frames, gts):
+        """one iteration of the training loop (spann3r/training.py:216-233): returns (loss + factor, gradient norm) as device
+        scalars; the norm is None on iterations that only accumulate (`update_grad=False`, croco/utils/misc.py:268-282)."""
+        first, last = self._window()
+        self.data_iter_step += 1
         if not self.graph:
-            return self._body(frames, gts, monitor=False)
+            return self._body(frames, gts, monitor=False, first=first, last=last)
         pat = self._pattern(frames)
-        if self._g is not None and pat != self._captured_pattern:
-            # the captured step holds ONE orientation pattern (the per-orientation head passes are host-side control flow): a batch
+        key = (first, last)
+        held = self._graphs.get(key)
+        if held is not None and pat != held[2]:
+            # a captured step holds ONE orientation pattern (the per-orientation head passes are host-side control flow): a batch
             # with another pattern takes the eager step on the same buffers / optimizer state
             self.opt.sync_lr()
-            out = self._body(frames, gts, monitor=False)
+            out = self._body(frames, gts, monitor=False, first=first, last=last)
             invalidate_weight_cache()
             return out
-        if self._g is None:
-            self._captured_pattern = pat
+        if held is None:
             clone = lambda d: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in d.items()}
-            self._static = ([clone(f) for f in frames], [clone(g) for g in gts])
+            if self._static is None:
+                self._static = ([clone(f) for f in frames], [clone(g) for g in gts])
+            else:
+                self._copy_in(frames, gts)
             # the warm-up steps (allocator pools, caches, chunk tables) and the capture must not move the trajectory: parameters,
-            # both moments and the step count are put back, so the first REPLAY is update number one of this batch, as in eager mode
+            # both moments, the step count and (inside an accumulation window) the gradients gathered so far are put back, so the
+            # first REPLAY is this iteration, as in eager mode
             snap = self.opt.snapshot()
+            grads = None if first else [g.clone() for g, _ in self.reducer.flat_buffers()]
+            touched = list(self.reducer._touched)
+            invalidate_weight_cache()
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(2):
-                    self._body(*self._static, monitor=False)
+                    self._body(*self._static, monitor=False, first=first, last=last)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             self.opt.capture_mode(True)
             self.reducer.capture = True                  # collectives stay in the graph; the used-parameter exchange is host-free
-            self._g = torch.cuda.CUDAGraph()
+            g = torch.cuda.CUDAGraph()
             # no cyclic garbage collection while the stream captures: the collector may finalise hipGraphs of models dropped
             # earlier (an inference runner <-> model cycle), and destroying a graph is not permitted during a capture
             import gc
@@ -1263,23 +1309,64 @@ class TrainStep:
             gc_was = gc.isenabled()
             gc.disable()
             try:
-                with torch.cuda.graph(self._g):
-                    self._out = self._body(*self._static, monitor=False)
+                with torch.cuda.graph(g):
+                    out = self._body(*self._static, monitor=False, first=first, last=last)
             finally:
                 if gc_was:
                     gc.enable()
+            self._graphs[key] = held = (g, out, pat)
+            self._g, self._out, self._captured_pattern = g, out, pat
             self.opt.restore(snap)
-            del snap
+            if grads is not None:
+                for (dst, _), src in zip(self.reducer.flat_buffers(), grads):
+                    dst.copy_(src)
+                self.reducer._touched = touched
+            del snap, grads
         else:
-            for dst, src in zip(self._static[0] + self._static[1], list(frames) + list(gts)):
-                for k, v in src.items():
-                    if torch.is_tensor(v):
-                        dst[k].copy_(v, non_blocking=True)
+            self._copy_in(frames, gts)
         self.opt.sync_lr()
-        self._g.replay()
-        self.opt.step_count += 1                     # the device-side count advanced inside the replay
-        invalidate_weight_cache()                    # the replay rewrote the parameters: packed copies / inference engines are stale
-        return self._out
+        held[0].replay()
+        if last:
+            self.opt.step_count += 1                 # the device-side count advanced inside the replay
+        invalidate_weight_cache()                    # the replay rewrote the packed copies (and, on `last`, the parameters)
+        return held[1]
+
+    def _copy_in(self, frames, gts):
+        for dst, src in zip(self._static[0] + self._static[1], list(frames) + list(gts)):
+            for k, v in src.items():
+                if torch.is_tensor(v):
+                    dst[k].copy_(v, non_blocking=True)
+
+
+def train_one_epoch(step, data_loader, epoch, args, on_iteration=None):
+    """The iteration schedule of the reference's train_one_epoch (spann3r/training.py:168-262) around TrainStep.run: per-iteration
+    learning rate at the first iteration of every accumulation window (:205-207, fractional epoch = epoch + i / len(loader)), the
+    update on the last one (:229-233), a non-finite loss stops the run (:223-226).  `data_loader` yields batches (lists of view
+    dicts on the device or the host; `img`, `pts3d`, `valid_mask`, `camera_pose` are moved, :209-213); args: accum_iter (must equal
+    step.accum_iter), lr, min_lr, warmup_epochs, epochs.  Returns the averaged statistics {loss, lr, norm}; `on_iteration(i, loss,
+    norm, lr)` sees every iteration.  Data-set curriculum (`set_ratio`), logging and checkpoints are the caller's (out of scope)."""
+    assert int(getattr(args, "accum_iter", 1)) == step.accum_iter, "args.accum_iter and TrainStep(accum_iter=...) differ"
+    step.model.train()
+    step.reset_iteration()
+    dev = next(step.model.parameters()).device
+    n = len(data_loader)
+    losses, norms, lr = [], [], None
+    for i, batch in enumerate(data_loader):
+        if i % step.accum_iter == 0:
+            lr = step.adjust_learning_rate(epoch + i / n, args)
+        batch = [{k: (v.to(dev, non_blocking=True) if torch.is_tensor(v) and k in ("img", "pts3d", "valid_mask", "camera_pose") else v)
+                  for k, v in view.items()} for view in batch]
+        loss, norm = step.run(batch, batch)
+        loss_value = float(loss)
+        if not math.isfinite(loss_value):
+            raise FloatingPointError("Loss is %r, stopping training" % loss_value)
+        losses.append(loss_value)
+        if norm is not None:
+            norms.append(float(norm))
+        if on_iteration is not None:
+            on_iteration(i, loss_value, None if norm is None else norms[-1], step.opt.param_groups[0]["lr"])
+    mean = lambda v: sum(v) / len(v) if v else float("nan")
+    return {"loss": mean(losses), "norm": mean(norms), "lr": lr}
 
 
 class FlatAdamW:

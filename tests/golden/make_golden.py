@@ -564,6 +564,104 @@ def make_traingrad():
     print("train_grad_full.npz: %d parameter gradients" % len(names))
 
 
+def synth_gt_views(frames, H, W, B, g):
+    """ground-truth side of a training batch (pointmaps in front of the camera, 85 % valid, random rigid poses)"""
+    views = []
+    for f in frames:
+        Q, _ = torch.linalg.qr(torch.randn(B, 3, 3, generator=g))
+        pose = torch.eye(4).repeat(B, 1, 1)
+        pose[:, :3, :3] = Q
+        pose[:, :3, 3] = torch.randn(B, 3, generator=g) * 0.3
+        views.append(dict(img=f["img"], true_shape=torch.tensor([[H, W]] * B, dtype=torch.int32),
+                          pts3d=torch.randn(B, H, W, 3, generator=g) + torch.tensor([0.0, 0.0, 3.0]),
+                          valid_mask=torch.rand(B, H, W, generator=g) < 0.85, camera_pose=pose))
+    return views
+
+
+def make_trainloop():
+    """f1, the LOOP around the step: the reference's UNMODIFIED `train_one_epoch` (spann3r/training.py:168-262) run here on the CPU
+    for two epochs of 4 iterations with accum_iter = 2 -- per-iteration learning rate (croco/utils/misc.py:464-479: epoch 0 is the
+    linear warm-up starting at lr = 0, epoch 1 the cosine branch), losses divided by accum_iter and accumulated, clip at 1.0 and
+    AdamW(get_parameter_groups(model, 0.05), betas=(0.9, 0.95)) every second iteration through NativeScalerWithGradNormCount (its
+    GradScaler disables itself without CUDA).  `spann3r.training` imports tensorboard and the data sets (cv2, ...), neither needed
+    by the function: both are stubbed in sys.modules before the module is imported.  Tiny model, memory dropout 0 (deterministic),
+    3 frames of 64x80, batch 2.  Dumped: the ground truth of the 8 batches, per-iteration loss / lr / gradient norm (through a
+    recording wrapper around the loss scaler) and, for every parameter, a strided sample of its value after each epoch."""
+    import types
+    tb = types.ModuleType("torch.utils.tensorboard")
+    tb.SummaryWriter = object
+    sys.modules.setdefault("torch.utils.tensorboard", tb)
+    ds = types.ModuleType("spann3r.datasets")
+    ds.__all__ = []
+    sys.modules.setdefault("spann3r.datasets", ds)
+    import croco.utils.misc as misc
+    import spann3r.training as T
+    from spann3r.loss import Regr3D_t, ConfLoss_t
+    from dust3r.losses import L21
+    cfg, H, W, NF, B, NIT, NEP = TINY, 64, 80, 3, 2, 4, 2
+    sd = synth_state_dict(0, cfg)
+    m = build_reference(cfg, sd, "trainloop")
+    m.train()
+    m.mem_dropout.p = 0.0
+    args = argparse.Namespace(accum_iter=2, epochs=10, warmup_epochs=1, lr=2e-5, min_lr=1e-6, print_freq=1, weight_decay=0.05)
+    g = torch.Generator().manual_seed(91)
+    batches = [synth_gt_views(synth_frames(NF, H, W, batch=B, seed=200 + i), H, W, B, g) for i in range(NIT * NEP)]
+
+    class Loader:
+        class dataset:
+            set_epoch = staticmethod(lambda e: None)
+            set_ratio = staticmethod(lambda r: None)
+
+        def __init__(self, items):
+            self.items = items
+
+        def __len__(self):
+            return len(self.items)
+
+        def __iter__(self):
+            return iter([[dict(v) for v in b] for b in self.items])
+
+    rec = {"loss": [], "norm": [], "lr": [], "untouched": []}
+    inner = misc.NativeScalerWithGradNormCount()
+
+    def scaler(loss, optimizer, **kw):
+        n = inner(loss, optimizer, **kw)
+        rec["loss"].append(float(loss) * args.accum_iter)          # the loop divided it by accum_iter just before (:228)
+        rec["norm"].append(float("nan") if n is None else float(n))
+        rec["lr"].append(optimizer.param_groups[0]["lr"])
+        if n is not None:                                          # parameters AdamW passed over in this update (grad None)
+            rec["untouched"] = [name for name, p in m.named_parameters() if p.requires_grad and p.grad is None]
+        return n
+
+    crit = ConfLoss_t(Regr3D_t(L21, norm_mode="avg_dis", fix_first=False), alpha=0.4)
+    opt = torch.optim.AdamW(misc.get_parameter_groups(m, args.weight_decay), lr=args.lr, betas=(0.9, 0.95))      # training.py:326-327
+    torch.backends.cuda.matmul.allow_tf32 = True                   # asserted at the top of train_one_epoch
+    out = {"meta": np.array([H, W, NF, B, NIT, NEP, 91, 200]), "fingerprint": np.array(state_dict_fingerprint(sd)),
+           "args": np.array([args.accum_iter, args.epochs, args.warmup_epochs, args.lr, args.min_lr, args.weight_decay])}
+    for i, b in enumerate(batches):
+        out["gt%d_pts3d" % i] = np.stack([v["pts3d"].numpy() for v in b]).astype(np.float32)
+        out["gt%d_valid" % i] = np.packbits(np.stack([v["valid_mask"].numpy() for v in b]))
+        out["gt%d_pose" % i] = np.stack([v["camera_pose"].numpy() for v in b]).astype(np.float32)
+    t = time.time()
+    names = [n for n, p in m.named_parameters() if p.requires_grad]
+    for ep in range(NEP):
+        stats = T.train_one_epoch(m, crit, Loader(batches[ep * NIT:(ep + 1) * NIT]), opt, torch.device("cpu"), ep, scaler, args)
+        print("trainloop: epoch %d  %s" % (ep, {k: round(v, 6) for k, v in stats.items()}))
+        for name, p in m.named_parameters():
+            if p.requires_grad:
+                flat = p.detach().reshape(-1)
+                step = max(1, flat.numel() // 64)
+                out["p%d_%s" % (ep, name)] = flat[::step][:64].numpy().astype(np.float64)
+    for k in ("loss", "norm", "lr"):
+        out["it_" + k] = np.array(rec[k], dtype=np.float64)
+    out["names"] = np.array(names)
+    out["untouched"] = np.array(rec["untouched"])
+    print("trainloop: %.1f s; lr %s; loss %s; norms %s; %d of %d parameters without a gradient: %s"
+          % (time.time() - t, rec["lr"], rec["loss"], rec["norm"], len(rec["untouched"]), len(names), rec["untouched"][:8]))
+    np.savez_compressed(os.path.join(HERE, "train_loop_tiny.npz"), **out)
+    print("train_loop_tiny.npz: %d arrays" % len(out))
+
+
 def make_crop():
     """f3 pin: the crop / resize plan of the reference's own functions.  `cropping.py` imports cv2 (used only for the depth map,
     cropping.py:73-75) and `dust3r.utils.image` imports torchvision (ImgNorm); neither is installed here and neither touches the
@@ -678,6 +776,8 @@ if __name__ == "__main__":
         make_usefeat_mpe()
     if "traingrad" in what:
         make_traingrad()
+    if "trainloop" in what:
+        make_trainloop()
     if "postprocess" in what:
         make_postprocess()
     if "loss" in what:

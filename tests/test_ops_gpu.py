@@ -322,10 +322,16 @@ def test_conv3x3_splitk(wdt, B, H, W, Cin, Cout, stride):
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(1, 56, 56, 256, 256), (2, 13, 9, 128, 128), (1, 8, 8, 64, 192), (1, 20, 28, 256, 128),
                                             (1, 3, 5, 384, 64)])
 @pytest.mark.parametrize("variant", ["rcu1", "rcu2", "plain"])
-def test_conv3x3_tile(in_dt, out_dt, B, H, W, Cin, Cout, variant):
-    """sp3_conv3x3_tile (LDS halo tile, packed bf16 weights) vs F.conv2d on the bf16-rounded operands; ragged tiles,
-    input ReLU, bias / ReLU / two residuals, fp32 and bf16 maps."""
+@pytest.mark.parametrize("tile_px", ["8x8", "8x16"])
+def test_conv3x3_tile(in_dt, out_dt, B, H, W, Cin, Cout, variant, tile_px):
+    """sp3_conv3x3_tile (LDS halo tile, packed bf16 weights; 8 x 8 and 8 x 16 pixel tiles) vs F.conv2d on the bf16-rounded operands;
+    ragged tiles, input ReLU, bias / ReLU / two residuals, fp32 and bf16 maps."""
     ops = _ops()
+    if tile_px == "8x16" and Cin % 128:
+        with pytest.raises(RuntimeError, match="Cin"):
+            ops.conv3x3(torch.zeros(B, H, W, Cin, device=DEV), ops.PackedWeight(torch.zeros(Cout, 9 * Cin, device=DEV, dtype=torch.bfloat16)),
+                        torch.zeros(B, H, W, Cout, device=DEV), B=B, H=H, W_=W, Cin=Cin, Cout=Cout, force_tile_kernel=True, tile_px=tile_px)
+        return
     x, w, b = rnd(B, Cin, H, W, seed=1), rnd(Cout, Cin, 3, 3, seed=2) * 0.05, rnd(Cout, seed=3)
     r1, r2 = rnd(B, Cout, H, W, seed=4), rnd(B, Cout, H, W, seed=5)
     nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous()
@@ -333,7 +339,7 @@ def test_conv3x3_tile(in_dt, out_dt, B, H, W, Cin, Cout, variant):
     out = torch.full((B, H, W, Cout), float("nan"), device=DEV, dtype=out_dt)
     xin = nhwc(x).to(DEV).to(in_dt)
     relu_in = variant in ("rcu1", "rcu2")
-    kw = dict(B=B, H=H, W_=W, Cin=Cin, Cout=Cout, relu_in=relu_in, force_tile_kernel=True)
+    kw = dict(B=B, H=H, W_=W, Cin=Cin, Cout=Cout, relu_in=relu_in, force_tile_kernel=True, tile_px=tile_px)
     if variant == "rcu1":
         ops.conv3x3(xin, wp, out, bias=b.to(DEV), act=ops.ACT_RELU, **kw)
     elif variant == "rcu2":
@@ -349,6 +355,27 @@ def test_conv3x3_tile(in_dt, out_dt, B, H, W, Cin, Cout, variant):
         ref = ref + r1.double() + r2.double()
     tol = 2e-5 if out_dt == torch.float32 else 6e-3
     assert rel_err(out.float().cpu(), nhwc(ref)) < tol
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(1, 112, 112, 256, 256), (4, 56, 56, 256, 256), (1, 100, 150, 128, 128)])
+def test_conv3x3_tile_choice_by_size(B, H, W, Cin, Cout):
+    """maps large enough to fill the chip with 8 x 16 tiles take the wide kernel on their own; both tiles give the same result up to
+    the order of the fp32 partial sums, bf16 maps with bf16 residuals as in the DPT head"""
+    ops = _ops()
+    x, w, b = rnd(B, H, W, Cin, seed=1).to(DEV).to(torch.bfloat16), rnd(Cout, 9 * Cin, seed=2) * 0.05, rnd(Cout, seed=3).to(DEV)
+    r1 = rnd(B, H, W, Cout, seed=4).to(DEV).to(torch.bfloat16)
+    wp = ops.PackedWeight(w.to(DEV).to(torch.bfloat16))
+    outs = {}
+    for px in (None, "8x8", "8x16"):
+        out = torch.full((B, H, W, Cout), float("nan"), device=DEV)
+        ops.conv3x3(x, wp, out, B=B, H=H, W_=W, Cin=Cin, Cout=Cout, bias=b, relu_in=True, tile_px=px)
+        outs[px] = out
+    assert torch.isfinite(outs[None]).all()
+    assert rel_err(outs["8x16"].cpu(), outs["8x8"].cpu()) < 2e-6
+    assert torch.equal(outs[None], outs["8x16"])                 # >= 160 wide workgroups: the size rule picks the wide tile
+    ob = torch.empty(B, H, W, Cout, device=DEV, dtype=torch.bfloat16)
+    ops.conv3x3(x, wp, ob, B=B, H=H, W_=W, Cin=Cin, Cout=Cout, bias=b, res1=r1, relu_in=True)
+    assert rel_err(ob.float().cpu(), (outs["8x8"] + r1.float()).cpu()) < 6e-3
 
 
 @pytest.mark.parametrize("wdt", [torch.float32, torch.bfloat16])

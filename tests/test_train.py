@@ -2,6 +2,8 @@
 against the CPU oracle in float64 with autograd; the oracle against the unmodified reference module."""
 import os
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -964,3 +966,85 @@ def test_captured_step_with_rccl_collectives_matches_eager(tiny_sd):
         T.invalidate_weight_cache()
         if own:
             dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("graph", [False, True])
+def test_training_loop_vs_reference_train_one_epoch(tiny_sd, graph):
+    """The loop around the step -- gradient accumulation over accum_iter = 2 iterations, the per-iteration learning-rate hook (warm-up
+    from lr 0, then the cosine branch), clip + AdamW every second iteration, parameters without a gradient passed over -- against the
+    reference's UNMODIFIED train_one_epoch run for two epochs of 4 iterations (tests/golden/make_golden.py trainloop: losses,
+    learning rates, gradient norms per iteration and a strided sample of every parameter after each epoch).  Eager and captured
+    (one hipGraph per position in the accumulation window)."""
+    import argparse
+    from conftest import load_golden
+    from spann3r_amd import Spann3R, TINY
+    from spann3r_amd import train as T
+    from spann3r_amd.weights import synth_frames, state_dict_fingerprint
+    g = load_golden("train_loop_tiny.npz")
+    H, W, NF, B, NIT, NEP, _, seed0 = map(int, g["meta"])
+    assert state_dict_fingerprint(tiny_sd) == float(g["fingerprint"])
+    a = g["args"]
+    args = argparse.Namespace(accum_iter=int(a[0]), epochs=int(a[1]), warmup_epochs=int(a[2]), lr=float(a[3]), min_lr=float(a[4]))
+    batches = []
+    for i in range(NIT * NEP):
+        valid = np.unpackbits(g["gt%d_valid" % i])[:NF * B * H * W].reshape(NF, B, H, W).astype(bool)
+        views = []
+        for j, f in enumerate(synth_frames(NF, H, W, batch=B, seed=seed0 + i)):
+            views.append({"img": f["img"].cuda(), "true_shape": torch.tensor([[H, W]] * B, dtype=torch.int32),
+                          "pts3d": torch.from_numpy(g["gt%d_pts3d" % i][j]).cuda(), "valid_mask": torch.from_numpy(valid[j]).cuda(),
+                          "camera_pose": torch.from_numpy(g["gt%d_pose" % i][j]).cuda()})
+        batches.append(views)
+    rec = []
+    try:
+        m = Spann3R(dus3r_name=None, cfg=TINY, init_weights=False, memory_dropout=0.0)
+        m.load_state_dict(tiny_sd, strict=True)
+        m = m.cuda()
+        ts = T.TrainStep(m, precision="fp32", lr=args.lr, weight_decay=float(a[5]), accum_iter=args.accum_iter, graph=graph)
+        params = dict(m.named_parameters())
+        for ep in range(NEP):
+            stats = T.train_one_epoch(ts, batches[ep * NIT:(ep + 1) * NIT], ep, args, on_iteration=lambda *r: rec.append(r))
+            assert stats["loss"] == stats["loss"]
+            # Adam's first updates are +-lr per element whatever the gradient's size, so an element whose accumulated gradient is
+            # rounding noise (softmax-invariant directions: norm_k.bias, the k third of every qkv bias, ...) moves by an arbitrary
+            # amount up to the sum of the learning rates on either machine.  The comparison is therefore a distribution over all
+            # sampled elements of |p - p_ref| in units of that sum: the bulk must agree closely, outliers must be rare (the
+            # per-iteration losses and gradient norms below pin the trajectory as a whole).
+            lr_sum = float(np.sum(g["it_lr"][1:(ep + 1) * NIT:args.accum_iter]))
+            errs, names_of = [], []
+            untouched = set(map(str, g["untouched"]))
+            for name in g["names"]:
+                name = str(name)
+                flat = params[name].detach().reshape(-1)
+                step = max(1, flat.numel() // 64)
+                mine = flat[::step][:64].double().cpu().numpy()
+                ref, init = g["p%d_%s" % (ep, name)], tiny_sd[name].reshape(-1)[::step][:64].double().numpy()
+                if name in untouched:
+                    assert np.array_equal(mine, init), name                  # no gradient: not even weight decay (AdamW passes over it)
+                    assert np.array_equal(ref, init), name
+                    continue
+                errs.append(np.abs(mine - ref) / lr_sum)
+                names_of += [name] * len(mine)
+            errs = np.concatenate(errs)
+            p50, p95, p99 = np.percentile(errs, [50, 95, 99])
+            out_frac = float((errs > 0.5).mean())
+            bad = sorted({names_of[k] for k in np.nonzero(errs > 0.5)[0]})
+            print("epoch %d (graph=%s): |p - p_ref| / sum(lr) over %d elements: median %.2e p95 %.2e p99 %.2e max %.2e; %.3f%% beyond 0.5: %s"
+                  % (ep, graph, errs.size, p50, p95, p99, errs.max(), 100 * out_frac, bad[:12]))
+            # measured: median <= 7e-5, p95 5e-4, p99 1.2e-3, max 2.1e-2 of the summed learning rates, no outlier
+            assert p50 < 1e-3 and p95 < 5e-3 and out_frac < 1e-3, (ep, p50, p95, out_frac)
+        if graph:
+            assert sorted(ts._graphs) == [(False, True), (True, False)]          # one graph per position in the window
+        assert ts.opt.step_count == NIT * NEP // args.accum_iter
+    finally:
+        T.set_precision("fp32")
+        T.invalidate_weight_cache()
+    assert len(rec) == NIT * NEP
+    for i, (it, loss, norm, lr) in enumerate(rec):
+        assert abs(lr - g["it_lr"][i]) <= 1e-12 + 1e-9 * abs(g["it_lr"][i]), (i, lr, g["it_lr"][i])
+        assert abs(loss - g["it_loss"][i]) <= 2e-3 * abs(g["it_loss"][i]), (i, loss, g["it_loss"][i])
+        if np.isnan(g["it_norm"][i]):
+            assert norm is None                                                  # update_grad=False iterations return no norm
+        else:
+            assert abs(norm - g["it_norm"][i]) <= 2e-3 * g["it_norm"][i], (i, norm, g["it_norm"][i])
+    print("losses", [round(r[1], 4) for r in rec], "ref", np.round(g["it_loss"], 4).tolist())
