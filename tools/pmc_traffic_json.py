@@ -33,7 +33,7 @@ def lean_key(row):
         # sp3_gemm2 (q/k/v + cross k/v projections of a decoder layer in one launch): the only paired lean launch of the 224x224 step
         pair = tile == 31 and row["grid"][2] == 30
         return ("gemm2" if pair else "gemm") + "<Abf16,Wbf16,plain,%s>" % _TILE_NAMES[tile]
-    if "conv3x3_tile_kernel" in n:
+    if "conv3x3_tile_kernel" in n or "conv3x3_wide_kernel" in n:        # both pixel tiles of sp3_conv3x3_tile (bench.py times them as one op)
         return "conv3x3_tile"
     if "conv_sm_kernel" in n:
         # (the demangler prints __bf16 template arguments as garbage: take the dtype from the spelling, the tile from the workgroup size)
