@@ -333,9 +333,10 @@ int sp3_gather_1d(const float* src, float* dst, const int32_t* sel, int n_sel, v
  *   out fp32 or bf16 (out_bf16).  Cin, Cout multiples of 64; act is SP3_ACT_NONE or SP3_ACT_RELU.
  *   Replaces the Conv2d calls of ResidualConvUnit_custom (croco/models/dpt_block.py:120-142), scratch.layer_rn
  *   (:180-188) and the head convs (:318-324) in bf16 mode; fp32 mode and stride 2 use sp3_gemm's LOAD_CONV3X3.  out_bf16: bit 0 = the output map is bf16, bit 1 = the residual maps res1 / res2 are bf16 too (else fp32).
- *   Bits 2-3 choose the workgroup's pixel tile: 0 = by size, 1 = 8 x 8 pixels, 2 = 8 rows x 16 pixels (needs Cin % 128 == 0: the
- *   halo is staged 128 channels at a time; half the weight stream per flop, taken by the size rule once its grid has >= 160
- *   workgroups).  Both tiles cover 64 output channels per workgroup and give the same sums up to fp32 addition order.
+ *   Bits 2-3 choose the workgroup's tile: 0 = by size, 1 = 8 x 8 pixels x 64 channels, 2 = 8 rows x 16 pixels x 64 channels, 3 = 8 x 16
+ *   pixels x 32 channels (2 and 3 need Cin % 128 == 0: the halo is staged 128 channels at a time; half the weight stream per flop).
+ *   By size: the 64-channel wide tile once its grid has >= 256 workgroups, the 32-channel one from 80 (batch-1 56 x 56 maps:
+ *   112 -> 224 workgroups), else 8 x 8.  All tiles give the same sums up to fp32 addition order.
  */
 int sp3_conv3x3_tile(const void* x, int in_bf16, const void* w_packed, const float* bias, const float* res1,
                      const float* res2, void* out, int out_bf16, int B, int H, int W, int Cin, int Cout,

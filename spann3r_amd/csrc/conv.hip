@@ -24,7 +24,7 @@ constexpr int BM = TH * TW, BN = 64;
 constexpr int MF = BM / 16, NF = BN / 16;
 constexpr int SLAB_LD = BN + 4;
 constexpr int DEPTH = 3;                      // W units in flight per wave
-constexpr int SP3_CONV_WIDE_MIN_WGS = 160;    // the 8 x 16 tile is taken when its grid has at least this many workgroups (measured cross-over: 112 loses 12 %, 196 wins 10 %)
+constexpr int SP3_CONV_WIDE_MIN_WGS = 256;    // 8 x 16 x 64-channel tile from this many workgroups up, the 32-channel instance from 80 (measured: profiles/r04_conv_tile_sweep.txt)
 
 struct ConvArgs {
   const void* x; const __bf16* w; const float* bias; const float* res1; const float* res2; void* out;
@@ -230,14 +230,19 @@ __global__ __launch_bounds__(256) void conv3x3_tile_kernel(const ConvArgs a) {
 namespace wide {
 constexpr int TH = 8, TW = 16, HW = TW + 2, HP = (TH + 2) * HW;   // 180 halo pixels
 constexpr int CH = 128, PS = CH * 2 + 16;                          // channels per staged chunk, halo pixel stride (bytes)
-constexpr int MF = 8, NF = 4, BN = 64, SLAB_LD = BN + 4, DEPTH = 3;
-constexpr int HALO_BYTES = HP * PS, SLAB_BYTES = 4 * 64 * SLAB_LD * 4;
-constexpr int LDS_BYTES = HALO_BYTES > SLAB_BYTES ? HALO_BYTES : SLAB_BYTES;
+constexpr int MF = 8, DEPTH = 3;
+constexpr int HALO_BYTES = HP * PS;
+template <int NF> constexpr int lds_bytes() {                     // halo chunk, re-used by the 4 partial tiles of one 64-pixel pass
+  return HALO_BYTES > 4 * 64 * (16 * NF + 4) * 4 ? HALO_BYTES : 4 * 64 * (16 * NF + 4) * 4;
+}
 
 // ABL (tools/ubench/conv_wide.hip only; 0 in the library): ablation bits -- 1 no W refills, 2 no A re-loads per tap, 4 no halo loads
 // from memory, 8 no epilogue (a dummy consumer keeps the MFMAs alive)
-template <typename TIN, int ABL = 0>
+// NF = 16-channel column blocks per workgroup: 4 (64 output channels), or 2 for maps whose grid of 64-channel tiles leaves most CUs idle
+// (batch-1 56 x 56: 112 workgroups) -- twice the workgroups, each with half the W stream, at twice the LDS reads per MFMA.
+template <typename TIN, int NF = 4, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const ConvArgs a) {
+  constexpr int BN = 16 * NF, SLAB_LD = BN + 4;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r = lane & 15;
   const int Cin = a.Cin;
@@ -442,28 +447,32 @@ extern "C" int sp3_conv3x3_tile(const void* x, int in_bf16, const void* w_packed
   a.relu_in = relu_in; a.act = act; a.out_bf16 = out_bf16 & 3;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   {
-    // tile choice (out_bf16 bits 2-3: 0 = by size, 1 = 8 x 8 pixels, 2 = 8 x 16 pixels): the wide tile halves the W stream per flop
-    // and wins once its own grid covers most of the 256 CUs (measured: profiles/r04_conv_tile_sweep.txt)
+    // tile choice (out_bf16 bits 2-3: 0 = by size, 1 = 8 x 8 pixels, 2 = 8 x 16 pixels x 64 channels, 3 = 8 x 16 pixels x 32 channels): the
+    // wide tile halves the W stream per flop and wins once its own grid covers most of the 256 CUs (profiles/r04_conv_tile_sweep.txt);
+    // when the 64-channel grid is too small for that but the 32-channel one is not, the narrow-N instance takes over
     const int want = (out_bf16 >> 2) & 3;
     const int wtx = (W + wide::TW - 1) / wide::TW, wty = (H + wide::TH - 1) / wide::TH;
-    const int64_t wgs = (int64_t)wtx * wty * B * (Cout / wide::BN);
+    const int64_t wgs = (int64_t)wtx * wty * B * (Cout / 64);
     const bool can = Cin % wide::CH == 0;
-    SP3_CHECK(want != 2 || can, "sp3_conv3x3_tile: the 8 x 16 tile needs Cin %% 128 == 0 (Cin=%d)", Cin);
-    SP3_CHECK(want != 3, "sp3_conv3x3_tile: tile choice 3");
-    if (want == 2 || (want == 0 && can && wgs >= SP3_CONV_WIDE_MIN_WGS)) {
+    SP3_CHECK(want < 2 || can, "sp3_conv3x3_tile: the 8 x 16 tile needs Cin %% 128 == 0 (Cin=%d)", Cin);
+    SP3_CHECK((int64_t)H * W * Cin * (in_bf16 ? 2 : 4) < (1ll << 31), "sp3_conv3x3_tile: one image of the map must stay below 2 GiB");
+    const int nf = want == 2 ? 4 : want == 3 ? 2 : (want == 0 && can) ? (wgs >= SP3_CONV_WIDE_MIN_WGS ? 4 : wgs >= 80 ? 2 : 0) : 0;
+    if (nf) {
       a.tiles_x = wtx; a.tiles_y = wty;
-      dim3 grid(wtx * wty * B, Cout / wide::BN);
-      auto launch = [&](auto kern) -> int {
+      dim3 grid(wtx * wty * B, Cout / (16 * nf));
+      auto launch = [&](auto kern, int lds_bytes) -> int {
         static bool raised = false;               // per instantiation: opt in to > 64 KiB of dynamic LDS once
-        if (!raised) {
-          hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, wide::LDS_BYTES);
-          if (e != hipSuccess) { sp3_set_error("sp3_conv3x3_tile: cannot raise dynamic LDS to %d: %s", wide::LDS_BYTES, hipGetErrorString(e)); return 2; }
+        if (!raised && lds_bytes > 64 * 1024) {
+          hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+          if (e != hipSuccess) { sp3_set_error("sp3_conv3x3_tile: cannot raise dynamic LDS to %d: %s", lds_bytes, hipGetErrorString(e)); return 2; }
           raised = true;
         }
-        hipLaunchKernelGGL(kern, grid, dim3(256), wide::LDS_BYTES, st, a);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, st, a);
         return 0;
       };
-      const int rc = in_bf16 ? launch(wide::conv3x3_wide_kernel<__bf16>) : launch(wide::conv3x3_wide_kernel<float>);
+      int rc;
+      if (nf == 4) rc = in_bf16 ? launch(wide::conv3x3_wide_kernel<__bf16, 4>, wide::lds_bytes<4>()) : launch(wide::conv3x3_wide_kernel<float, 4>, wide::lds_bytes<4>());
+      else         rc = in_bf16 ? launch(wide::conv3x3_wide_kernel<__bf16, 2>, wide::lds_bytes<2>()) : launch(wide::conv3x3_wide_kernel<float, 2>, wide::lds_bytes<2>());
       if (rc) return rc;
       SP3_LAUNCH_CHECK("sp3_conv3x3_tile");
       return 0;

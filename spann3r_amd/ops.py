@@ -470,7 +470,7 @@ def conv3x3(x, Wp, out, *, B, H, W_, Cin, Cout, stride=1, bias=None, res1=None, 
         rbf = [t.dtype == torch.bfloat16 for t in (res1, res2) if t is not None]
         if rbf and (any(rbf) != all(rbf) or (any(rbf) and out.dtype != torch.bfloat16)):
             raise TypeError("conv3x3: residual maps must share one dtype (bf16 only next to a bf16 output)")
-        oflag = int(out.dtype == torch.bfloat16) | (2 if any(rbf) else 0) | ({None: 0, "8x8": 1, "8x16": 2}[tile_px] << 2)
+        oflag = int(out.dtype == torch.bfloat16) | (2 if any(rbf) else 0) | ({None: 0, "8x8": 1, "8x16": 2, "8x16n32": 3}[tile_px] << 2)
         _timed("conv3x3_tile", 2.0 * B * H * W_ * Cout * 9 * Cin,
                B * H * W_ * (x.element_size() * Cin + out.element_size() * Cout) + 2.0 * 9 * Cin * Cout,
                lambda: L.check(L.load().sp3_conv3x3_tile(

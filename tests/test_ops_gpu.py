@@ -322,12 +322,12 @@ def test_conv3x3_splitk(wdt, B, H, W, Cin, Cout, stride):
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(1, 56, 56, 256, 256), (2, 13, 9, 128, 128), (1, 8, 8, 64, 192), (1, 20, 28, 256, 128),
                                             (1, 3, 5, 384, 64)])
 @pytest.mark.parametrize("variant", ["rcu1", "rcu2", "plain"])
-@pytest.mark.parametrize("tile_px", ["8x8", "8x16"])
+@pytest.mark.parametrize("tile_px", ["8x8", "8x16", "8x16n32"])
 def test_conv3x3_tile(in_dt, out_dt, B, H, W, Cin, Cout, variant, tile_px):
     """sp3_conv3x3_tile (LDS halo tile, packed bf16 weights; 8 x 8 and 8 x 16 pixel tiles) vs F.conv2d on the bf16-rounded operands;
     ragged tiles, input ReLU, bias / ReLU / two residuals, fp32 and bf16 maps."""
     ops = _ops()
-    if tile_px == "8x16" and Cin % 128:
+    if tile_px != "8x8" and Cin % 128:
         with pytest.raises(RuntimeError, match="Cin"):
             ops.conv3x3(torch.zeros(B, H, W, Cin, device=DEV), ops.PackedWeight(torch.zeros(Cout, 9 * Cin, device=DEV, dtype=torch.bfloat16)),
                         torch.zeros(B, H, W, Cout, device=DEV), B=B, H=H, W_=W, Cin=Cin, Cout=Cout, force_tile_kernel=True, tile_px=tile_px)
@@ -371,8 +371,17 @@ def test_conv3x3_tile_choice_by_size(B, H, W, Cin, Cout):
         ops.conv3x3(x, wp, out, B=B, H=H, W_=W, Cin=Cin, Cout=Cout, bias=b, relu_in=True, tile_px=px)
         outs[px] = out
     assert torch.isfinite(outs[None]).all()
-    assert rel_err(outs["8x16"].cpu(), outs["8x8"].cpu()) < 2e-6
-    assert torch.equal(outs[None], outs["8x16"])                 # >= 160 wide workgroups: the size rule picks the wide tile
+    assert rel_err(outs["8x16"].cpu(), outs["8x8"].cpu()) < 1e-5
+    assert torch.equal(outs[None], outs["8x16"])                 # >= 256 wide workgroups: the size rule picks the wide tile
+    # a batch-1 56 x 56 map (112 wide workgroups of 64 channels): the 32-channel instance of the wide tile
+    xs, outs = x[:1, :56, :56].contiguous(), {}
+    for px in (None, "8x8", "8x16n32"):
+        out = torch.full((1, 56, 56, Cout), float("nan"), device=DEV)
+        ops.conv3x3(xs, wp, out, B=1, H=56, W_=56, Cin=Cin, Cout=Cout, bias=b, relu_in=True, tile_px=px)
+        outs[px] = out
+    assert rel_err(outs["8x16n32"].cpu(), outs["8x8"].cpu()) < 1e-5, rel_err(outs["8x16n32"].cpu(), outs["8x8"].cpu())
+    if Cout == 256:
+        assert torch.equal(outs[None], outs["8x16n32"])
     ob = torch.empty(B, H, W, Cout, device=DEV, dtype=torch.bfloat16)
     ops.conv3x3(x, wp, ob, B=B, H=H, W_=W, Cin=Cin, Cout=Cout, bias=b, res1=r1, relu_in=True)
     assert rel_err(ob.float().cpu(), (outs["8x8"] + r1.float()).cpu()) < 6e-3

@@ -12,14 +12,14 @@
 
 template <int ABL>
 static float run(const ConvArgs& a, dim3 grid, int reps) {
-  auto kern = wide::conv3x3_wide_kernel<__bf16, ABL>;
-  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, wide::LDS_BYTES));
+  auto kern = wide::conv3x3_wide_kernel<__bf16, 4, ABL>;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, wide::lds_bytes<4>()));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   float best = 1e9f;
   for (int it = 0; it < 4; ++it) {
     CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, grid, dim3(256), wide::LDS_BYTES, 0, a);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, grid, dim3(256), wide::lds_bytes<4>(), 0, a);
     CK(hipEventRecord(e1, 0));
     CK(hipEventSynchronize(e1));
     float ms;
@@ -49,7 +49,7 @@ int main() {
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.tiles_x = (W + wide::TW - 1) / wide::TW; a.tiles_y = (H + wide::TH - 1) / wide::TH;
     a.relu_in = 1; a.act = SP3_ACT_NONE; a.out_bf16 = 1;
-    dim3 grid(a.tiles_x * a.tiles_y * B, Cout / wide::BN);
+    dim3 grid(a.tiles_x * a.tiles_y * B, Cout / 64);
     const int reps = 10;
     const float t0 = run<0>(a, grid, reps), t1 = run<1>(a, grid, reps), t2 = run<2>(a, grid, reps), t4 = run<4>(a, grid, reps),
                 t8 = run<8>(a, grid, reps), t3 = run<3>(a, grid, reps), t15 = run<15>(a, grid, reps);
