@@ -374,14 +374,14 @@ def test_conv3x3_tile_choice_by_size(B, H, W, Cin, Cout):
     assert rel_err(outs["8x16"].cpu(), outs["8x8"].cpu()) < 1e-5
     assert torch.equal(outs[None], outs["8x16"])                 # >= 256 wide workgroups: the size rule picks the wide tile
     # a batch-1 56 x 56 map (112 wide workgroups of 64 channels): the 32-channel instance of the wide tile
-    xs, outs = x[:1, :56, :56].contiguous(), {}
+    xs, small = x[:1, :56, :56].contiguous(), {}
     for px in (None, "8x8", "8x16n32"):
         out = torch.full((1, 56, 56, Cout), float("nan"), device=DEV)
         ops.conv3x3(xs, wp, out, B=1, H=56, W_=56, Cin=Cin, Cout=Cout, bias=b, relu_in=True, tile_px=px)
-        outs[px] = out
-    assert rel_err(outs["8x16n32"].cpu(), outs["8x8"].cpu()) < 1e-5, rel_err(outs["8x16n32"].cpu(), outs["8x8"].cpu())
+        small[px] = out
+    assert rel_err(small["8x16n32"].cpu(), small["8x8"].cpu()) < 1e-5, rel_err(small["8x16n32"].cpu(), small["8x8"].cpu())
     if Cout == 256:
-        assert torch.equal(outs[None], outs["8x16n32"])
+        assert torch.equal(small[None], small["8x16n32"])
     ob = torch.empty(B, H, W, Cout, device=DEV, dtype=torch.bfloat16)
     ops.conv3x3(x, wp, ob, B=B, H=H, W_=W, Cin=Cin, Cout=Cout, bias=b, res1=r1, relu_in=True)
     assert rel_err(ob.float().cpu(), (outs["8x8"] + r1.float()).cpu()) < 6e-3
