@@ -1179,6 +1179,14 @@ def parameter_groups(model, weight_decay):
     return [{"params": no_decay, "weight_decay": 0.0, "lr_scale": 1.0}, {"params": decay, "weight_decay": weight_decay, "lr_scale": 1.0}]
 
 
+def scheduled_lr(epoch, args):
+    """learning rate at a (fractional) epoch, croco/utils/misc.py:464-471: linear warm-up over args.warmup_epochs, then a half cosine
+    from args.lr down to args.min_lr at args.epochs"""
+    if epoch < args.warmup_epochs:
+        return args.lr * epoch / args.warmup_epochs
+    return args.min_lr + (args.lr - args.min_lr) * 0.5 * (1.0 + math.cos(math.pi * (epoch - args.warmup_epochs) / (args.epochs - args.warmup_epochs)))
+
+
 class TrainStep:
     """One optimisation step of spann3r/training.py:216-231 on one rank: train-mode forward (HIP autograd ops), ConfLoss_t,
     backward with the bucket all-reduces launched from inside it (RCCL when a process group is up), global-norm clip and AdamW on
@@ -1220,10 +1228,7 @@ class TrainStep:
         """croco/utils/misc.py:464-479 (the per-iteration hook of spann3r/training.py:205-207): linear warm-up over
         args.warmup_epochs, then half-cycle cosine from args.lr to args.min_lr at args.epochs; every group gets lr * its lr_scale.
         `epoch` is fractional.  In graph mode the value reaches the captured update kernels through device memory (sync_lr)."""
-        if epoch < args.warmup_epochs:
-            lr = args.lr * epoch / args.warmup_epochs
-        else:
-            lr = args.min_lr + (args.lr - args.min_lr) * 0.5 * (1.0 + math.cos(math.pi * (epoch - args.warmup_epochs) / (args.epochs - args.warmup_epochs)))
+        lr = scheduled_lr(epoch, args)
         self.set_lr(lr)
         return lr
 

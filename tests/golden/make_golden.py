@@ -662,6 +662,29 @@ def make_trainloop():
     print("train_loop_tiny.npz: %d arrays" % len(out))
 
 
+def make_lrsched():
+    """the reference's per-iteration schedule (croco/utils/misc.py:464-479) sampled through the UNMODIFIED function on a stand-in
+    optimizer with and without per-group lr_scale: 3 argument sets x 64 fractional epochs"""
+    import croco.utils.misc as misc
+
+    class Opt:
+        def __init__(self):
+            self.param_groups = [{"lr": 0.0}, {"lr": 0.0, "lr_scale": 0.65}]
+
+    sets = [(5e-5, 1e-6, 1, 120), (1e-4, 0.0, 5, 40), (2e-5, 1e-6, 0, 10)]
+    out = {"sets": np.array(sets, dtype=np.float64)}
+    for k, (lr, min_lr, warm, epochs) in enumerate(sets):
+        args = argparse.Namespace(lr=lr, min_lr=min_lr, warmup_epochs=warm, epochs=epochs)
+        eps = np.linspace(0.0, epochs, 64)
+        opt, rows = Opt(), []
+        for e in eps:
+            ret = misc.adjust_learning_rate(opt, float(e), args)
+            rows.append((ret, opt.param_groups[0]["lr"], opt.param_groups[1]["lr"]))
+        out["epochs%d" % k], out["lr%d" % k] = eps, np.array(rows, dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "lr_schedule.npz"), **out)
+    print("lr_schedule.npz: %d arrays" % len(out))
+
+
 def make_crop():
     """f3 pin: the crop / resize plan of the reference's own functions.  `cropping.py` imports cv2 (used only for the depth map,
     cropping.py:73-75) and `dust3r.utils.image` imports torchvision (ImgNorm); neither is installed here and neither touches the
@@ -778,6 +801,8 @@ if __name__ == "__main__":
         make_traingrad()
     if "trainloop" in what:
         make_trainloop()
+    if "lrsched" in what:
+        make_lrsched()
     if "postprocess" in what:
         make_postprocess()
     if "loss" in what:

@@ -337,6 +337,37 @@ for r in range(world):
         t += p.grad
 for p, t in zip(net4.parameters(), tot4):
     assert torch.allclose(p.grad, t / world, atol=1e-7)
+# gradient accumulation (train.TrainStep(accum_iter=3), spann3r/training.py:228-233): the first backwards of a window only add into the
+# buckets (prepare(arm=False): no collective may start), the last one reduces the SUMS -- equal to DDP's all-reduce after every
+# backward, since the mean over ranks is linear.  A parameter only an early iteration touches still counts as used.
+torch.manual_seed(4)
+net5 = torch.nn.Sequential(torch.nn.Linear(12, 24), torch.nn.Tanh(), torch.nn.Linear(24, 6))
+early, never = torch.nn.Parameter(torch.ones(3)), torch.nn.Parameter(torch.ones(2))
+red5 = GradReducer(list(net5.parameters()) + [early, never], bucket_mb=0.002, overlap=True)
+assert len(red5.buckets) >= 2 and red5.untouched() == []
+A = 3
+red5.zero_grad()
+for it in range(A):
+    red5.prepare(arm=(it == A - 1))
+    xin = torch.randn(5, 12, generator=torch.Generator().manual_seed(500 + 10 * it + rank))
+    loss = net5(xin).square().mean() + (early.sum() * 0.25 if it == 0 else 0.0)
+    (loss * (1.0 / A)).backward()
+    if it < A - 1:
+        assert red5.launched_in_backward == 0 and not red5._armed and red5._work == [None] * len(red5.buckets)
+red5.finish()
+ref5 = torch.nn.Sequential(torch.nn.Linear(12, 24), torch.nn.Tanh(), torch.nn.Linear(24, 6))
+ref5.load_state_dict(net5.state_dict())
+tot5 = [torch.zeros_like(p) for p in ref5.parameters()]
+for r in range(world):
+    for it in range(A):
+        ref5.zero_grad()
+        (ref5(torch.randn(5, 12, generator=torch.Generator().manual_seed(500 + 10 * it + r))).square().mean() * (1.0 / A)).backward()
+        for t, p in zip(tot5, ref5.parameters()):
+            t += p.grad
+for p, t in zip(net5.parameters(), tot5):
+    assert torch.allclose(p.grad, t / world, atol=1e-7)
+assert torch.allclose(early.grad, torch.full((3,), 0.25 / A)) and torch.equal(never.grad, torch.zeros(2))
+assert [q is never for q in red5.unused_everywhere()] == [True] and [q is never for q in red5.untouched()] == [True]
 if rank == 0:
     print("OK grads", started)
 dist.destroy_process_group()
@@ -384,3 +415,35 @@ def test_curope_shim_is_selected_by_unmodified_reference():
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "shim ok" in out.stdout, out.stdout + out.stderr
     assert "slow pytorch version" not in out.stdout
+
+
+def test_lr_schedule_and_accumulation_window_vs_reference():
+    """host logic of the training loop (spann3r/training.py:205-233): the per-iteration learning rate against samples of the reference's
+    unmodified `adjust_learning_rate` (tests/golden/lr_schedule.npz: warm-up, cosine, warmup_epochs = 0, lr_scale groups), and which
+    iterations of an accumulation window zero / update -- no GPU involved"""
+    import argparse
+    import numpy as np
+    from conftest import load_golden
+    from spann3r_amd import train as T
+    g = load_golden("lr_schedule.npz")
+    for k, (lr, min_lr, warm, epochs) in enumerate(g["sets"]):
+        args = argparse.Namespace(lr=float(lr), min_lr=float(min_lr), warmup_epochs=int(warm), epochs=int(epochs))
+        for e, (ret, lr0, lr1) in zip(g["epochs%d" % k], g["lr%d" % k]):
+            mine = T.scheduled_lr(float(e), args)
+            assert mine == ret == lr0, (k, e, mine, ret)                     # same expression, same doubles
+            assert abs(mine * 0.65 - lr1) <= 1e-18 + 1e-15 * abs(lr1)        # a group's lr_scale multiplies it (misc.py:473-477)
+
+    class Step(T.TrainStep):                                                 # the window bookkeeping without a model
+        def __init__(self, a):
+            self.accum_iter, self.data_iter_step = a, 0
+
+    for a in (1, 2, 3):
+        st, seen = Step(a), []
+        for i in range(7):
+            seen.append(st._window())
+            st.data_iter_step += 1
+        # training.py:229-233: update (and zero_grad afterwards, i.e. the NEXT iteration starts a window) when (i + 1) % accum_iter == 0
+        assert [w[1] for w in seen] == [(i + 1) % a == 0 for i in range(7)]
+        assert [w[0] for w in seen] == [i % a == 0 for i in range(7)]
+        st.reset_iteration()
+        assert st._window() == (True, a == 1)
