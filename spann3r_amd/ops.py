@@ -461,7 +461,9 @@ def reduce_ln(partial, splits, rows, C_, *, bias=None, res=None, ldres=0, x_out=
 def conv3x3(x, Wp, out, *, B, H, W_, Cin, Cout, stride=1, bias=None, res1=None, res2=None, act=ACT_NONE,
             relu_in=False, tile=-1, force_tile_kernel=False, splitk_ws=None, tile_px=None):
     """3x3 Conv2d, padding 1, on an NHWC fp32 map [B,H,W,Cin] -> [B,OH,OW,Cout] (implicit GEMM).
-    Wp is the weight packed as [Cout, 9*Cin] with k = (ky*3+kx)*Cin + ci."""
+    Wp is the weight packed as [Cout, 9*Cin] with k = (ky*3+kx)*Cin + ci.
+    tile_px (LDS-tiled kernel only; tests and tools/bench_conv_tile.py): None = the library's size rule, "8x8" | "8x16" | "8x16n32" = that
+    workgroup tile of sp3_conv3x3_tile (pixels, n32 = 32 instead of 64 output channels)."""
     OH, OW = (H - 1) // stride + 1, (W_ - 1) // stride + 1
     if (tile < 0 and stride == 1 and isinstance(Wp, PackedWeight) and Wp.dtype == torch.bfloat16
             and Cin % 64 == 0 and Cout % 64 == 0 and Cin <= 768 and (force_tile_kernel or B * H * W_ >= 2048)):
