@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Average every counter of a rocprofv3 --pmc CSV (counter_collection.csv) per kernel name.  Usage: pmc_csv.py file.csv"""
+"""Average every counter of a rocprofv3 --pmc CSV (counter_collection.csv) per (kernel name, grid).
+Usage: pmc_csv.py file.csv [substring ...]   -- kernels whose name contains one of the substrings (default: gemm)"""
 import csv
 import re
 import sys
@@ -12,7 +13,7 @@ for r in csv.DictReader(open(sys.argv[1])):
     a[0] += float(r["Counter_Value"])
     a[1] += 1
 for (k, g), cs in sorted(agg.items()):
-    if "gemm" not in k:
+    if not any(w in k for w in (sys.argv[2:] or ["gemm"])):
         continue
     print(k, "grid", g)
     for c, (s, n) in sorted(cs.items()):
