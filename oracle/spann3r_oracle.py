@@ -204,15 +204,25 @@ def postprocess(raw):
 def downstream_head(dec, true_shape, sd, cfg, num):
     """spann3r/model.py:327-331 -> dust3r/model.py:207-211 -> transpose_to_landscape wrapper
     (dust3r/utils/misc.py:54-96, landscape_only=True): all-landscape batches run as is,
-    all-portrait batches run with (H,W) as given and the result is axis-swapped."""
+    all-portrait batches run with (H,W) as given and the result is axis-swapped; a batch that mixes both runs the head
+    once per orientation on the selected samples and scatters the results back (:80-94)."""
     hs, ws = true_shape[:, 0], true_shape[:, 1]
     Hm, Wm = int(true_shape.min()), int(true_shape.max())
-    if bool((ws >= hs).all()):
+    land = ws >= hs
+    if bool(land.all()):
         return postprocess(dpt_raw(dec, (Hm, Wm), sd, cfg, num))
-    if bool((ws < hs).all()):
+    if bool((~land).all()):
         res = postprocess(dpt_raw(dec, (Wm, Hm), sd, cfg, num))
         return {k: v.swapaxes(1, 2) for k, v in res.items()}
-    raise NotImplementedError("mixed portrait/landscape batch")
+    sel = lambda mask: [None if d is None else d[mask] for d in dec]
+    res_l = postprocess(dpt_raw(sel(land), (Hm, Wm), sd, cfg, num))
+    res_p = {k: v.swapaxes(1, 2) for k, v in postprocess(dpt_raw(sel(~land), (Wm, Hm), sd, cfg, num)).items()}
+    out = {}
+    for k in res_l:
+        x = res_l[k].new_empty((true_shape.shape[0],) + tuple(res_l[k].shape[1:]))
+        x[land], x[~land] = res_l[k], res_p[k]
+        out[k] = x
+    return out
 
 
 def encode_cur_value(pts3d, sd, cfg, dec_last=None, pos1=None):

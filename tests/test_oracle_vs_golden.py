@@ -194,3 +194,40 @@ def test_tiny_use_feat():
             assert rel_err(p["pts3d" if j == 0 else "pts3d_in_other_view"], g["%s_pred%d_pts" % (tag, j)]) < TOL
             assert rel_err(p["conf"], g["%s_pred%d_conf" % (tag, j)]) < TOL
         assert rel_err(mem.mem_v, g[tag + "_mem_v"]) < TOL
+
+
+def test_tiny_use_feat_with_mem_pos_enc():
+    """oracle with cfg.use_feat AND cfg.mem_pos_enc (RoPE2D on the 48-wide heads of the 768-wide value encoder, spann3r/model.py:225-235,
+    :313) against the reference dump of Spann3R(use_feat=True, mem_pos_enc=True)"""
+    import dataclasses
+    from spann3r_amd.weights import synth_state_dict
+    g = load_golden("spann3r_usefeat_mpe.npz")
+    cfg = dataclasses.replace(TINY, use_feat=True, mem_pos_enc=True)
+    sd = synth_state_dict(0, cfg)
+    assert state_dict_fingerprint(sd) == float(g["fingerprint"])
+    H, W = map(int, g["meta_hw"])
+    frames = synth_frames(int(g["meta_frames"]), H, W, batch=int(g["meta_batch"]), seed=int(g["meta_seed"]))
+    preds, _, mem = O.forward(frames, sd, cfg, return_memory=True)
+    for j, p in enumerate(preds):
+        assert rel_err(p["pts3d" if j == 0 else "pts3d_in_other_view"], g["eval_pred%d_pts" % j]) < TOL
+        assert rel_err(p["conf"], g["eval_pred%d_conf" % j]) < TOL
+    assert rel_err(mem.mem_v, g["eval_mem_v"]) < TOL and rel_err(mem.mem_k, g["eval_mem_k"]) < TOL
+    # the dump exercises the rotation: without it the stored values move far beyond the tolerance
+    _, _, mem0 = O.forward(frames, sd, dataclasses.replace(cfg, mem_pos_enc=False), return_memory=True)
+    assert rel_err(mem0.mem_v, g["eval_mem_v"]) > 100 * TOL
+
+
+def test_mixed_orientation_batch(tiny_sd):
+    """A batch mixing a landscape view and a portrait the dataset rotated to landscape: the heads run once per orientation and the
+    results are scattered back (dust3r/utils/misc.py:80-94); against the reference dump (make_golden.py mixedshape)"""
+    g = load_golden("spann3r_mixedshape.npz")
+    H, W = map(int, g["meta_hw"])
+    frames = synth_frames(int(g["meta_frames"]), H, W, batch=int(g["meta_batch"]), seed=int(g["meta_seed"]))
+    frames = [dict(f, true_shape=torch.tensor([(H, W), (W, H)], dtype=torch.int32)) for f in frames]
+    preds, preds_all, mem = O.forward(frames, tiny_sd, TINY, return_memory=True)
+    for j, p in enumerate(preds):
+        assert rel_err(p["pts3d" if j == 0 else "pts3d_in_other_view"], g["M_pred%d_pts" % j]) < TOL
+        assert rel_err(p["conf"], g["M_pred%d_conf" % j]) < TOL
+    for i, (_, r2) in enumerate(preds_all):
+        assert rel_err(r2["conf"], g["M_step%d_conf2" % i]) < TOL
+    assert rel_err(mem.mem_attn, g["M_mem_attn"]) < 1e-4
