@@ -175,6 +175,11 @@ __global__ __launch_bounds__(256) void attention_packed_qb_kernel(const __bf16* 
 // v_exp_f32 + range test + two selects + v_ldexp for denormal results, 32 compare / select pairs mask keys >= Nk on EVERY tile,
 // 16 multiplies apply the scale): here exp2 is the bare v_exp_f32 (probabilities below 2^-126 flush to zero), the key mask runs on
 // the last tile only, and the scale rides in the exponent's FMA (max taken on the raw scores: scale > 0).
+// PIN = 1 (v3): a scheduling barrier behind the tile's loads.  The ISA of the product loop (and of v2) shows that the compiler SINKS the
+// next tile's K loads from the top of the iteration to its end -- after loop rotation they sit right in front of the MFMAs that consume
+// them (`s_waitcnt vmcnt(7)` 50 instructions behind the loads): the software prefetch the source spells out does not exist in the
+// binary, every tile starts by waiting one L2 round trip for its K fragments.  The barrier keeps the loads where the source has them.
+template <int PIN>
 __global__ __launch_bounds__(256) void attention_packed_v2_kernel(const __bf16* __restrict__ QP, int q_cols, int q_col0, int npad_q,
                                                                   const __bf16* __restrict__ KP, int k_cols, int k_col0, int npad_k,
                                                                   const __bf16* __restrict__ VTP, void* __restrict__ O, int64_t ldo,
@@ -211,6 +216,7 @@ __global__ __launch_bounds__(256) void attention_packed_v2_kernel(const __bf16* 
       const int nkb = (tile + 4 < ntiles ? tile + 4 : tile) << 6;
 #pragma unroll
       for (int t = 0; t < 4; ++t) kn[t] = load_frag(KP, krow0 + nkb + 16 * t + ql, kcol, k_cols);
+      if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
       f32x4 s[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
@@ -295,9 +301,10 @@ __global__ __launch_bounds__(256) void attention_packed_v2_kernel(const __bf16* 
   }
 }
 
+template <int PIN>
 void launch_v2(const __bf16* q, const __bf16* k, const __bf16* vt, void* o, int cols, int npad_q, int npad_k, int B, int heads, int Nq, int Nk,
                int out_bf16, int out_packed) {
-  hipLaunchKernelGGL(attention_packed_v2_kernel, dim3((Nq + 15) / 16, heads, B), dim3(256), 0, 0, q, cols, 0, npad_q, k, cols, 0, npad_k, vt, o,
+  hipLaunchKernelGGL(attention_packed_v2_kernel<PIN>, dim3((Nq + 15) / 16, heads, B), dim3(256), 0, 0, q, cols, 0, npad_q, k, cols, 0, npad_k, vt, o,
                      (int64_t)cols, out_bf16, out_packed, heads, Nq, Nk, 0.125f, 0, 0);
 }
 
@@ -340,8 +347,8 @@ float time_us(F&& f, int reps) {
 int main() {
   // B, heads, Nq (= Nk): config 3 encoder (2 x 16 x 1024 in the grouped launches), its decoder (12 heads), ragged lengths, config 2
   const int cases[][3] = {{2, 16, 1024}, {2, 12, 1024}, {1, 16, 1000}, {2, 12, 777}, {2, 12, 196}, {10, 16, 196}};
-  printf("%-18s %10s %10s %10s %10s %10s   v2 TFLOP/s   QB bit-identical to the product kernel   v2 max |diff| / max |out| (fp32 rows)\n", "B,heads,tokens",
-         "product us", "QB=2 us", "QB=3 us", "QB=4 us", "v2 us");
+  printf("%-18s %10s %10s %10s %10s %10s %10s   v3 TFLOP/s   QB bit-identical to the product kernel   v3 max |diff| / max |out| (fp32 rows)\n", "B,heads,tokens",
+         "product us", "QB=2 us", "QB=3 us", "QB=4 us", "v2 us", "v3 us");
   for (auto& c : cases) {
     const int B = c[0], heads = c[1], N = c[2];
     const int npad_q = (N + 15) / 16 * 16, npad_k = (N + 63) / 64 * 64, cols = heads * 64;
@@ -378,7 +385,7 @@ int main() {
     // v2 against the product kernel, fp32 rows: not bit-identical by design (FMA in the exponent, flushed denormal probabilities)
     CK(hipMemset(o_ref, 0, no * 4)); CK(hipMemset(o_new, 0, no * 4));
     launch_ref(q, k, vt, o_ref, cols, npad_q, npad_k, B, heads, N, N, 0, 0);
-    launch_v2(q, k, vt, o_new, cols, npad_q, npad_k, B, heads, N, N, 0, 0);
+    launch_v2<1>(q, k, vt, o_new, cols, npad_q, npad_k, B, heads, N, N, 0, 0);
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(a.data(), o_ref, no * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(b2.data(), o_new, no * 4, hipMemcpyDeviceToHost));
     double dmax = 0.0, amax = 0.0;
@@ -393,11 +400,12 @@ int main() {
     const float t2 = time_us([&] { launch_qb<2>(q, k, vt, o_new, cols, npad_q, npad_k, B, heads, N, N, 1, 1); }, reps);
     const float t3 = time_us([&] { launch_qb<3>(q, k, vt, o_new, cols, npad_q, npad_k, B, heads, N, N, 1, 1); }, reps);
     const float t4 = time_us([&] { launch_qb<4>(q, k, vt, o_new, cols, npad_q, npad_k, B, heads, N, N, 1, 1); }, reps);
-    const float t5 = time_us([&] { launch_v2(q, k, vt, o_new, cols, npad_q, npad_k, B, heads, N, N, 1, 1); }, reps);
+    const float t5 = time_us([&] { launch_v2<0>(q, k, vt, o_new, cols, npad_q, npad_k, B, heads, N, N, 1, 1); }, reps);
+    const float t6 = time_us([&] { launch_v2<1>(q, k, vt, o_new, cols, npad_q, npad_k, B, heads, N, N, 1, 1); }, reps);
     char name[64];
     snprintf(name, sizeof name, "%d,%d,%d", B, heads, N);
-    printf("%-18s %10.2f %10.2f %10.2f %10.2f %10.2f   %8.1f     %s                                    %.2e\n", name, t0, t2, t3, t4, t5,
-           4.0 * B * heads * (double)N * N * 64 / t5 / 1e6, same ? "yes" : "NO", dmax / amax);
+    printf("%-18s %10.2f %10.2f %10.2f %10.2f %10.2f %10.2f   %8.1f     %s                                    %.2e\n", name, t0, t2, t3, t4, t5, t6,
+           4.0 * B * heads * (double)N * N * 64 / t6 / 1e6, same ? "yes" : "NO", dmax / amax);
     CK(hipFree(q)); CK(hipFree(k)); CK(hipFree(vt)); CK(hipFree(o_ref)); CK(hipFree(o_new));
   }
   return 0;
