@@ -145,6 +145,11 @@ typedef struct sp3_gemm_desc {
    *   (hi.hi + hi.lo + lo.hi of a bf16 split of both operands: 16 mantissa bits per product, fp32 accumulate) instead of the
    *   fp32 MFMA -- 2-3x the matrix rate, the "f32x3" precision mode of the model.  Ignored for bf16 operands. */
   int32_t f32x3;
+  /* --- dtype of the residual maps res1 / res2 (their pointer type says fp32): 1 = they hold bf16.  Only the lean small-map
+   *   convolutions (tiles 40 / 41) read bf16 residuals, and only next to a bf16 map and output (res_bf16 == out_bf16 == a_bf16);
+   *   sp3_gemm_plan answers -1 for any other combination and the general tiles refuse res_bf16 != 0, so a descriptor whose
+   *   residual dtype differs from its output dtype is never routed to a kernel that would reinterpret the bytes. */
+  int32_t res_bf16;
 } sp3_gemm_desc;
 int sp3_gemm(const sp3_gemm_desc* desc_host, void* stream);
 /* Two differently shaped groups of problems in ONE launch (grid.y = a.batch + b.batch), e.g. a decoder layer's self-attention
@@ -159,7 +164,7 @@ int sp3_gemm2(const sp3_gemm_desc* a, const sp3_gemm_desc* b, void* stream);
  * fragment order (K = 1024 / 768), 34..38: output projections onto the fp32 residual stream (K = 1024, 4096, 768, 3072, 1792).
  * They serve M <= 256, batch <= 2, bias set, alpha = 1, no split-K / second residual / split A; anything else runs on the general
  * tiles above.  40 / 41: loader CONV3X3 on maps of <= 256 / <= 2048 output pixels (NHWC map, residuals and output all fp32 or all bf16 --
- * a_bf16 = out_bf16 --, bf16 fragment-order weights, K = 9 Cin a multiple of 64, plain epilogue with bias / ReLU / two residuals): the DPT heads' small-map convolutions
+ * a_bf16 = out_bf16 = res_bf16 --, bf16 fragment-order weights, K = 9 Cin a multiple of 64, plain epilogue with bias / ReLU / two residuals): the DPT heads' small-map convolutions
  * (croco/models/dpt_block.py:33-75,95-113) in ONE launch instead of split-K partials + sp3_reduce_ln.  SP3_LEAN_GEMM=0 in the environment switches them off (A/B runs). */
 int sp3_gemm_plan(const sp3_gemm_desc* desc_host);
 

@@ -48,17 +48,21 @@ def needs_build():
 DEVICE_FLAGS = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 
 
-def build(force=False, verbose=True):
-    if not force and not needs_build():
+def build(force=False, verbose=True, variant=None, extra=()):
+    """variant (kernel A/B experiments): builds libspann3r_hip.<variant>.so next to the product library with the extra
+    compiler flags; select it with SP3_LIB_PATH (spann3r_amd/lib.py).  The product build ignores it."""
+    if variant is None and not force and not needs_build():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
-    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    bdir = os.path.join(HERE, "build" if variant is None else "build_" + variant)
+    lib_out = LIB if variant is None else os.path.join(HERE, "libspann3r_hip.%s.so" % variant)
+    os.makedirs(bdir, exist_ok=True)
     for s in SOURCES:
-        o = os.path.join(HERE, "build", s.rsplit(".", 1)[0] + ".o")
+        o = os.path.join(bdir, s.rsplit(".", 1)[0] + ".o")
         cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c",
-               os.path.join(CSRC, s), "-o", o] + DEVICE_FLAGS + os.environ.get("SP3_HIPCC_EXTRA", "").split()
+               os.path.join(CSRC, s), "-o", o] + DEVICE_FLAGS + os.environ.get("SP3_HIPCC_EXTRA", "").split() + list(extra)
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -68,15 +72,21 @@ def build(force=False, verbose=True):
         if p.returncode != 0:
             sys.stderr.write(out.decode())
             raise RuntimeError("hipcc failed on %s" % s)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_out] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    with open(STAMP, "w") as f:
-        f.write(source_hash() + "\n")
-    return LIB
+    if variant is None:
+        with open(STAMP, "w") as f:
+            f.write(source_hash() + "\n")
+    return lib_out
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(LIB)
+    # python -m spann3r_amd.build [--force] | --variant NAME [extra hipcc flags ...]
+    if "--variant" in sys.argv:
+        i = sys.argv.index("--variant")
+        print(build(variant=sys.argv[i + 1], extra=sys.argv[i + 2:], verbose=False))
+    else:
+        build(force="--force" in sys.argv)
+        print(LIB)

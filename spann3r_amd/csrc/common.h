@@ -54,24 +54,47 @@ __device__ __forceinline__ float4 relu4(float4 v) {
   return v;
 }
 
-// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute, i.e. at fp32 rounding level for the GELU below): one
-// v_rcp_f32, one v_exp_f32 and six FMAs instead of the ~150-instruction branchy libm erff, which made the GELU epilogue of
-// an fc1 GEMM cost more shader time than its whole K loop.
-__device__ __forceinline__ float erf_fast(float z) {
-  const float a = fabsf(z);
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, a, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float y = fmaf(-p * t, __expf(-a * a), 1.0f);
-  return copysignf(y, z);
+// nn.GELU() (approximate='none') = x Phi(x), by the normal tail of Abramowitz & Stegun 26.2.17:
+//   x Phi(x) = max(x, 0) - |x| Q(|x|),   Q(a) = phi(a) (b1 t + .. + b5 t^5),   t = 1 / (1 + 0.2316419 a),   |error of Q| < 7.5e-8
+// one v_rcp_f32, one v_exp_f32 and ten FMA-class ops: measured against float64 over [-12, 12] the absolute error stays below
+// 3.4e-7 (the 7.1.26 erf form this replaces: 4.7e-7 with four more VALU ops; libm erff is a ~150-instruction branchy routine that
+// made the GELU epilogue of an fc1 GEMM cost more shader time than its K loop).  NaN and +-inf inputs give NaN.
+__device__ __forceinline__ float gelu_erf(float x) {
+  const float a = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.2316419f, a, 1.0f));
+  float p = fmaf(1.330274429f, t, -1.821255978f);
+  p = fmaf(p, t, 1.781477937f);
+  p = fmaf(p, t, -0.356563782f);
+  p = fmaf(p, t, 0.319381530f);
+  const float e = __builtin_amdgcn_exp2f(-0.72134752044448170368f * a * a);      // exp(-a^2 / 2)
+  const float q = (p * t) * (e * 0.3989422804014327f);                           // / sqrt(2 pi)
+  return fmaf(-a, q, fmaxf(x, 0.f));
 }
 
-// nn.GELU() (approximate='none'): 0.5 x (1 + erf(x / sqrt 2))
-__device__ __forceinline__ float gelu_erf(float x) {
-  return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f));
+// Write-through stores for GEMM / convolution epilogues (global_store ... sc1).  Every workgroup of a one-round launch reaches
+// its epilogue at the same time, so with plain stores the whole output (16 MB for an encoder fc1) sits dirty in the XCD L2s
+// when the kernel ends and the release at the launch boundary writes it back while nothing runs: measured 1.9 us of a 25 us
+// launch (tools/ubench/gemm_bm.hip, profiles/r05_gemm_manyrow_structure_probe_*.txt).  sc1 stores go through to the memory side as they are issued --
+// under the epilogue's own VALU work -- and leave nothing to flush; the consumer is another launch (its L2s start clean anyway).
+// -DSP3_NO_WT_STORES builds the plain form (A/B).
+#ifndef SP3_NO_WT_STORES
+__device__ __forceinline__ void st_out(bf16x4* p, bf16x4 v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ void st_out(float2* p, float2 v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_out(float4* p, float4 v) {
+  // (no builtin for a 16-byte sc1 store without a buffer descriptor; s_nop 1: the data registers may be reused right behind it)
+  const f32x4 t = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
+}
+__device__ __forceinline__ void st_out(bf16x8* p, bf16x8 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+#else
+template <typename T> __device__ __forceinline__ void st_out(T* p, T v) { *p = v; }
+#endif
 
 // Fragment-order ("packed") operand layout shared by sp3_gemm's a_packed / w_packed and every producer's
 // out_packed option: [ceil(rows/16)][ceil(K/KB)][2 halves h][4 lane groups g][16 rows r][CH/2], KB/CH = 64/16 (bf16),

@@ -1921,6 +1921,7 @@ extern "C" int sp3_gemm(const sp3_gemm_desc* dp, void* stream_) {
   // the 196-row weight-streaming shapes of the per-frame step: lean shape-specialised instances (gemm_sm.hip, tiles 30..)
   if (d.tile >= 30 || (d.tile < 0 && sp3_gemm_sm_tile(d) >= 0)) return sp3_gemm_sm_launch(d, nullptr, reinterpret_cast<hipStream_t>(stream_));
   SP3_CHECK(!(d.a_packed && d.A2), "sp3_gemm: a fragment-order A split along K runs on the lean instances only (no instance for M=%d N=%d K=%d)", d.M, d.N, d.K);
+  SP3_CHECK(!(d.res_bf16 && (d.res1 || d.res2)), "sp3_gemm: bf16 residual maps are read by the lean small-map convolutions only (res_bf16 = out_bf16 = a_bf16; M=%d N=%d K=%d)", d.M, d.N, d.K);
   return gemm_dispatch(d, tile, reinterpret_cast<hipStream_t>(stream_));
 }
 
@@ -1948,13 +1949,16 @@ extern "C" int sp3_gemm2(const sp3_gemm_desc* ap, const sp3_gemm_desc* bp, void*
     a0.tile = b0.tile = -1;
     if (gemm_prepare(a0, t0) == 0 && gemm_prepare(b0, t1) == 0) {
       const int la = sp3_gemm_sm_tile(a0), lb = sp3_gemm_sm_tile(b0);
-      if (la >= 30 && la == lb && (want < 0 || want == la)) return sp3_gemm_sm_launch(a0, &b0, reinterpret_cast<hipStream_t>(stream_));
+      // (only the q/k/v projections' ROPE instances take a second group; two STREAM / PACKED problems that share an instance
+      //  pair on the general tiles below, as they did before the lean families existed)
+      if (la >= 30 && la == lb && sp3_gemm_sm_pairs(a0) && (want < 0 || want == la)) return sp3_gemm_sm_launch(a0, &b0, reinterpret_cast<hipStream_t>(stream_));
     }
-    SP3_CHECK(want < 30, "sp3_gemm2: tile %d asks for a lean instance the two groups do not share", want);
+    SP3_CHECK(want < 30, "sp3_gemm2: tile %d asks for a lean instance that does not take this pair", want);
   }
   if (int rc = gemm_prepare(a, ta)) return rc;
   if (b.tile < 0) b.tile = ta;                   // the second group runs on the first one's kernel instance
   if (int rc = gemm_prepare(b, tb)) return rc;
+  SP3_CHECK(!(a.res_bf16 && (a.res1 || a.res2)) && !(b.res_bf16 && (b.res1 || b.res2)), "sp3_gemm2: bf16 residual maps are read by the lean small-map convolutions only");
   SP3_CHECK(ta == tb && a.wdtype == b.wdtype && a.a_bf16 == b.a_bf16 && a.loader == b.loader && a.loader != SP3_LOAD_SOFTMAX,
             "sp3_gemm2: both groups must use one kernel instance (tile %d / %d, same dtypes and loader)", ta, tb);
   SP3_CHECK(a.splitk == 1 && b.splitk == 1 && !a.trace && !b.trace, "sp3_gemm2: no split-K, no trace");

@@ -267,7 +267,7 @@ __global__ __launch_bounds__(64 * WK) void sm_kernel(const SmArgs a) {
         const long off = ((((long)(b * a.heads + h) * nU + u) * 4 + (dd >> 4)) * 64 + lane_) * 8 + e;
         bf16x4 ob;
         ob[0] = (__bf16)v[0]; ob[1] = (__bf16)v[1]; ob[2] = (__bf16)v[2]; ob[3] = (__bf16)v[3];
-        *reinterpret_cast<bf16x4*>(vt + off) = ob;
+        st_out(reinterpret_cast<bf16x4*>(vt + off), ob);
       }
       return;
     }
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(64 * WK) void sm_kernel(const SmArgs a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) ob[e] = (__bf16)(is_v ? (v[e] * cs[e] + pv[e] * sn[e]) : (v[e] * cs[e] - pv[e] * sn[e]));
       const int b = (int)__umulhi((unsigned)gm, a.tok_magic), n = gm - b * a.tokens;
-      *reinterpret_cast<bf16x4*>(out + packed_off(b * a.vt_ld + n, gn, rope_cols, true)) = ob;
+      st_out(reinterpret_cast<bf16x4*>(out + packed_off(b * a.vt_ld + n, gn, rope_cols, true)), ob);
     }
     return;
   } else if constexpr (EPI == SM_PACKED) {
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(64 * WK) void sm_kernel(const SmArgs a) {
       }
       bf16x4 ob;
       ob[0] = (__bf16)v[0]; ob[1] = (__bf16)v[1]; ob[2] = (__bf16)v[2]; ob[3] = (__bf16)v[3];
-      *reinterpret_cast<bf16x4*>(out + packed_off(gm, gn, N, true)) = ob;
+      st_out(reinterpret_cast<bf16x4*>(out + packed_off(gm, gn, N, true)), ob);
     }
   } else {
     float* out = reinterpret_cast<float*>(OPF(C) + grp * OPF(gC));
@@ -330,14 +330,14 @@ __global__ __launch_bounds__(64 * WK) void sm_kernel(const SmArgs a) {
         float s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
 #pragma unroll
         for (int o_ = 1; o_ < 8; o_ <<= 1) { s1 += __shfl_xor(s1, o_); s2 += __shfl_xor(s2, o_); }
-        if (((gn >> 2) & 7) == 0) reinterpret_cast<float2*>(so)[(long)gm * (N >> 5) + (gn >> 5)] = make_float2(s1, s2);
+        if (((gn >> 2) & 7) == 0) st_out(reinterpret_cast<float2*>(so) + ((long)gm * (N >> 5) + (gn >> 5)), make_float2(s1, s2));
       }
       if (c2) {
         bf16x4 ob;
         ob[0] = (__bf16)v[0]; ob[1] = (__bf16)v[1]; ob[2] = (__bf16)v[2]; ob[3] = (__bf16)v[3];
-        *reinterpret_cast<bf16x4*>(c2 + packed_off(gm, gn, N, true)) = ob;
+        st_out(reinterpret_cast<bf16x4*>(c2 + packed_off(gm, gn, N, true)), ob);
       }
-      *reinterpret_cast<float4*>(out + (long)gm * ldc + gn) = make_float4(v[0], v[1], v[2], v[3]);
+      st_out(reinterpret_cast<float4*>(out + (long)gm * ldc + gn), make_float4(v[0], v[1], v[2], v[3]));
     }
   }
 #undef OPF
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(64 * WM * WN) void bm_kernel(const SmArgs a) {
         bf16x4 ob;
 #pragma unroll
         for (int i = 0; i < 4; ++i) ob[i] = (__bf16)tl[(4 * rq + i) * LDV + col];
-        *reinterpret_cast<bf16x4*>(vt + off) = ob;
+        st_out(reinterpret_cast<bf16x4*>(vt + off), ob);
       }
       return;
     }
@@ -630,8 +630,8 @@ __global__ __launch_bounds__(64 * WM * WN) void bm_kernel(const SmArgs a) {
           o0[e] = (__bf16)(v0[e] * cs[e] - v1[e] * sn[e]);       // first half of the pair: x cos - y sin
           o1[e] = (__bf16)(v1[e] * cs[e] + v0[e] * sn[e]);       // second half:           y cos + x sin
         }
-        *reinterpret_cast<bf16x4*>(out + packed_off(prow, cw0 + n * 16, rope_cols, true)) = o0;
-        *reinterpret_cast<bf16x4*>(out + packed_off(prow, cw0 + n * 16 + 16, rope_cols, true)) = o1;
+        st_out(reinterpret_cast<bf16x4*>(out + packed_off(prow, cw0 + n * 16, rope_cols, true)), o0);
+        st_out(reinterpret_cast<bf16x4*>(out + packed_off(prow, cw0 + n * 16 + 16, rope_cols, true)), o1);
       }
     }
   } else if constexpr (EPI == SM_PACKED) {
@@ -651,7 +651,7 @@ __global__ __launch_bounds__(64 * WM * WN) void bm_kernel(const SmArgs a) {
         }
         bf16x4 ob;
         ob[0] = (__bf16)v[0]; ob[1] = (__bf16)v[1]; ob[2] = (__bf16)v[2]; ob[3] = (__bf16)v[3];
-        *reinterpret_cast<bf16x4*>(out + packed_off(gm, cw0 + n * 16, N, true)) = ob;
+        st_out(reinterpret_cast<bf16x4*>(out + packed_off(gm, cw0 + n * 16, N, true)), ob);
       }
     }
   } else {
@@ -684,18 +684,18 @@ __global__ __launch_bounds__(64 * WM * WN) void bm_kernel(const SmArgs a) {
           float s2 = ((v0[0] * v0[0] + v0[1] * v0[1]) + (v0[2] * v0[2] + v0[3] * v0[3])) + ((v1[0] * v1[0] + v1[1] * v1[1]) + (v1[2] * v1[2] + v1[3] * v1[3]));
           s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
           s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-          if (ok && g == 0) reinterpret_cast<float2*>(so)[(long)gm * (N >> 5) + ((cw0 + n * 16) >> 5)] = make_float2(s1, s2);
+          if (ok && g == 0) st_out(reinterpret_cast<float2*>(so) + ((long)gm * (N >> 5) + ((cw0 + n * 16) >> 5)), make_float2(s1, s2));
         }
         if (ok) {
           if (c2) {
             bf16x4 o0, o1;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { o0[e] = (__bf16)v0[e]; o1[e] = (__bf16)v1[e]; }
-            *reinterpret_cast<bf16x4*>(c2 + packed_off(gm, cw0 + n * 16, N, true)) = o0;
-            *reinterpret_cast<bf16x4*>(c2 + packed_off(gm, cw0 + n * 16 + 16, N, true)) = o1;
+            st_out(reinterpret_cast<bf16x4*>(c2 + packed_off(gm, cw0 + n * 16, N, true)), o0);
+            st_out(reinterpret_cast<bf16x4*>(c2 + packed_off(gm, cw0 + n * 16 + 16, N, true)), o1);
           }
-          *reinterpret_cast<float4*>(out + (long)gm * ldc + cw0 + n * 16) = make_float4(v0[0], v0[1], v0[2], v0[3]);
-          *reinterpret_cast<float4*>(out + (long)gm * ldc + cw0 + n * 16 + 16) = make_float4(v1[0], v1[1], v1[2], v1[3]);
+          st_out(reinterpret_cast<float4*>(out + (long)gm * ldc + cw0 + n * 16), make_float4(v0[0], v0[1], v0[2], v0[3]));
+          st_out(reinterpret_cast<float4*>(out + (long)gm * ldc + cw0 + n * 16 + 16), make_float4(v1[0], v1[1], v1[2], v1[3]));
         }
       }
     }
@@ -930,6 +930,9 @@ int conv_sm_tile(const sp3_gemm_desc& d) {
     return -1;
   if (d.K % 64 || d.conv_C % 16 || d.K != 9 * d.conv_C || d.K >= 65536 || d.M > 2048 || d.M < 1 || d.act == SP3_ACT_GELU) return -1;
   if (d.ldc != d.N || (d.res1 && d.ldr1 != d.N) || (d.res2 && d.ldr2 != d.N) || (d.ldw > 0 && d.ldw != d.K)) return -1;
+  // the instances read res1 / res2 in the map dtype: a descriptor that says otherwise (fp32 residuals next to a bf16 map, the
+  // contract the general tiles serve) is not theirs
+  if ((d.res1 || d.res2) && (d.res_bf16 != 0) != (d.out_bf16 != 0)) return -1;
   if (d.M <= 256) return d.N % 16 == 0 ? 40 : -1;
   return d.N % 32 == 0 ? 41 : -1;
 }
@@ -1085,6 +1088,12 @@ int sp3_gemm_sm_tile(const sp3_gemm_desc& d) {
   if (d.loader == SP3_LOAD_CONV3X3) return sm_enabled() ? conv_sm_tile(d) : -1;
   const SmInst* s = sm_find(d);
   return s ? s->tile : -1;
+}
+
+bool sp3_gemm_sm_pairs(const sp3_gemm_desc& d) {
+  if (d.loader == SP3_LOAD_CONV3X3) return false;
+  const SmInst* s = sm_find(d);
+  return s && s->epi == SM_ROPE;
 }
 
 int sp3_gemm_sm_launch(const sp3_gemm_desc& d, const sp3_gemm_desc* pair, hipStream_t stream) {

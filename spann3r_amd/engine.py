@@ -70,7 +70,9 @@ class Engine:
         self.packed_attn = precision == "bf16"      # fragment-order q/k/v + wave-split attention kernel
         # DPT feature maps: bf16 in bf16 mode (round 4: every map is a GEMM / convolution operand that the MFMA rounds to bf16 anyway;
         # stored as bf16 they cost half the bytes in the convolutions' loaders, the upsamplers and the residual adds), fp32 otherwise
-        self.mdt = torch.bfloat16 if (precision == "bf16" and os.environ.get("SP3_DPT_FP32_MAPS", "0") != "1") else torch.float32
+        # bf16 DPT maps carry bf16 residuals, which only the lean small-map convolutions (and the LDS-tiled kernel) read: with
+        # SP3_LEAN_GEMM=0 (the documented A/B switch) the maps stay fp32, as with SP3_DPT_FP32_MAPS=1
+        self.mdt = torch.bfloat16 if (precision == "bf16" and os.environ.get("SP3_DPT_FP32_MAPS", "0") != "1" and ops.LEAN) else torch.float32
         self._ws = {}
         self._pos_cache = {}
         # RoPE tables for every grid the build supports, allocated ONCE: captured graphs hold their addresses
@@ -586,7 +588,7 @@ class Engine:
         assert dF % 16 == 0 and dN % 16 == 0 and dO % 16 == 0
         es = 2 if self.adt == torch.bfloat16 else 4
         h = self.wspg("keyg_hidden", R, Kd)
-        if feat1p is not None and feat2p is not None and self.adt == torch.bfloat16 and R <= 256:     # (R: the lean instances' row limit)
+        if feat1p is not None and feat2p is not None and self.adt == torch.bfloat16 and R <= 256 and ops.LEAN:     # (R: the lean instances' row limit; a packed split A has no general tile)
             np_ = self.wspg("decg_normed_packed", R, D)
             dFp = feat2p.data_ptr() - feat1p.data_ptr()
             assert dFp % 16 == 0

@@ -42,7 +42,7 @@ class GemmDesc(C.Structure):
         ("sb_stats_out", C.c_int64), ("sb_c2", C.c_int64), ("sb_vt", C.c_int64),
         ("trace", C.c_void_p),
         ("sm_stats_out", C.c_void_p), ("sm_stats", C.c_void_p), ("sm_nt", C.c_int32), ("sm_thresh", C.c_float), ("sm_zout", C.c_void_p),
-        ("f32x3", C.c_int32),
+        ("f32x3", C.c_int32), ("res_bf16", C.c_int32),
     ]
 
 

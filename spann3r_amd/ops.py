@@ -149,6 +149,8 @@ def pick_tile(M, N, batch=1, splitk=1, conv=False, K=0, packed_bf16=False, plain
 
 import os as _os
 PIPE_TILES = _os.environ.get("SP3_PIPE_TILES", "1")[:1] != "0"     # mirrors the switch in csrc/gemm.hip (A/B runs)
+LEAN = _os.environ.get("SP3_LEAN_GEMM", "1")[:1] != "0"          # mirrors sm_enabled() in csrc/gemm_sm.hip: with the lean instances off the
+                                                                  # engine must not pick the layouts only they serve (packed split-A, bf16 DPT maps)
 
 _pair = None
 
@@ -173,8 +175,8 @@ class pair:
         (a, na), (b, _) = descs
         if a.tile < 0 and b.tile < 0:
             ta, tb = L.load().sp3_gemm_plan(C.byref(a)), L.load().sp3_gemm_plan(C.byref(b))
-            if ta >= 30 and ta == tb:               # both groups on one lean instance
-                a.tile = b.tile = ta
+            if ta >= 30 and ta == tb and a.epi == L.EPI_ROPE_VT and b.epi == L.EPI_ROPE_VT:   # both groups on one lean q/k/v instance (the only
+                a.tile = b.tile = ta                # family that takes a second group; others pair on the general tiles)
         if a.tile < 0:
             _pick_general(a)                        # (a lean instance for one group only: both take the general tiles)
         if b.tile < 0:
@@ -497,6 +499,10 @@ def conv3x3(x, Wp, out, *, B, H, W_, Cin, Cout, stride=1, bias=None, res1=None, 
         p.alpha, p.act, p.relu_in = 1.0, act, int(relu_in)
         p.loader, p.epi, p.tile = L.LOAD_CONV3X3, L.EPI_PLAIN, -1
         p.conv_H, p.conv_W, p.conv_C, p.conv_OH, p.conv_OW, p.conv_stride = H, W_, Cin, OH, OW, stride
+        rbf = [t.dtype == torch.bfloat16 for t in (res1, res2) if t is not None]
+        if rbf and any(rbf) != all(rbf):
+            raise TypeError("conv3x3: residual maps must share one dtype")
+        p.res_bf16 = int(any(rbf))                  # the lean instances read the residuals in the map dtype: the plan refuses a mismatch
         lean = L.load().sp3_gemm_plan(C.byref(p))
         if lean >= 30:
             p.tile = lean
