@@ -417,9 +417,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const typename AttnT<TT>
     if (out_bf16) {
       bf16x4 ob;
       ob[0] = (__bf16)(acc.x * inv); ob[1] = (__bf16)(acc.y * inv); ob[2] = (__bf16)(acc.z * inv); ob[3] = (__bf16)(acc.w * inv);
-      *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(O) + off) = ob;
+      st_out(reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(O) + off), ob);
     } else {
-      *reinterpret_cast<float4*>(reinterpret_cast<float*>(O) + off) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+      st_out(reinterpret_cast<float4*>(reinterpret_cast<float*>(O) + off), make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv));
     }
   }
 }
@@ -562,9 +562,9 @@ __global__ __launch_bounds__(256) void attention_packed_kernel(const __bf16* __r
     if (out_bf16) {
       bf16x4 ob;
       ob[0] = (__bf16)(acc.x * inv); ob[1] = (__bf16)(acc.y * inv); ob[2] = (__bf16)(acc.z * inv); ob[3] = (__bf16)(acc.w * inv);
-      *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(O) + off) = ob;
+      st_out(reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(O) + off), ob);
     } else {
-      *reinterpret_cast<float4*>(reinterpret_cast<float*>(O) + off) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+      st_out(reinterpret_cast<float4*>(reinterpret_cast<float*>(O) + off), make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv));
     }
   }
 }

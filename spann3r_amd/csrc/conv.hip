@@ -209,9 +209,9 @@ __global__ __launch_bounds__(256) void conv3x3_tile_kernel(const ConvArgs a) {
     if (a.out_bf16 & 1) {
       bf16x4 o;
       o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
-      *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.out) + off) = o;
+      st_out(reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.out) + off), o);
     } else {
-      *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + off) = v;
+      st_out(reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + off), v);
     }
   }
 }
@@ -421,9 +421,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const ConvArgs a) 
       if (a.out_bf16 & 1) {
         bf16x4 o;
         o[0] = (__bf16)v.x; o[1] = (__bf16)v.y; o[2] = (__bf16)v.z; o[3] = (__bf16)v.w;
-        *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.out) + off) = o;
+        st_out(reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.out) + off), o);
       } else {
-        *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + off) = v;
+        st_out(reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + off), v);
       }
     }
   }

@@ -34,11 +34,11 @@ __device__ __forceinline__ float4 ld4(const __bf16* p) {
   const bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
   return make_float4((float)t[0], (float)t[1], (float)t[2], (float)t[3]);
 }
-__device__ __forceinline__ void st4(float* p, const float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4(float* p, const float4 v) { st_out(reinterpret_cast<float4*>(p), v); }
 __device__ __forceinline__ void st4(__bf16* p, const float4 v) {
   bf16x4 t;
   t[0] = (__bf16)v.x; t[1] = (__bf16)v.y; t[2] = (__bf16)v.z; t[3] = (__bf16)v.w;
-  *reinterpret_cast<bf16x4*>(p) = t;
+  st_out(reinterpret_cast<bf16x4*>(p), t);
 }
 
 // T = float, or __bf16 (bf16 mode of the DPT heads: maps stored as bf16, the interpolation itself in fp32)

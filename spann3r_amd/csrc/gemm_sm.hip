@@ -786,11 +786,11 @@ __device__ __forceinline__ float4 csm_load4(const __bf16* p) {
   const bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
   return make_float4((float)t[0], (float)t[1], (float)t[2], (float)t[3]);
 }
-__device__ __forceinline__ void csm_store4(float* p, const float (&v)[4]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ void csm_store4(float* p, const float (&v)[4]) { st_out(reinterpret_cast<float4*>(p), make_float4(v[0], v[1], v[2], v[3])); }
 __device__ __forceinline__ void csm_store4(__bf16* p, const float (&v)[4]) {
   bf16x4 t;
   t[0] = (__bf16)v[0]; t[1] = (__bf16)v[1]; t[2] = (__bf16)v[2]; t[3] = (__bf16)v[3];
-  *reinterpret_cast<bf16x4*>(p) = t;
+  st_out(reinterpret_cast<bf16x4*>(p), t);
 }
 
 template <typename TM, int MF, int NF, int WK, int R>
