@@ -536,22 +536,27 @@ int sp3_focal_weiszfeld(const float* pts3d, int B, int H, int W, float ppx, floa
 int sp3_conf_filter(const float* conf, const float* pts, const float* rgb, int64_t n, float thresh, int* scratch, int64_t* total,
                     float* out_pts, float* out_rgb, void* stream);
 
-/* Camera poses from pointmaps (demo.py:170-186 calls cv2.solvePnPRansac per frame; OpenCV is not available in this image, so
- * this is an independent calibrated PnP, checked on synthetic scenes, NOT pinned against OpenCV -- see spann3r_amd/postprocess.py).
- * The O(H*W) reductions run here, one workgroup per frame, double-precision sums in a fixed order; the host solves the small systems.
+/* Camera poses from pointmaps (demo.py:170-186 calls cv2.solvePnPRansac(points, pixel grid, K, 0) per frame).  OpenCV's pipeline
+ * (calib3d/src/solvepnp.cpp, ptsetreg.cpp, epnp.cpp, calibration.cpp; restated for the tests in oracle/pnp_oracle.py) is run by
+ * spann3r_amd/postprocess.py::estimate_poses: the 5-point EPnP hypotheses and the 12x12 / 6x6 solves on the host, everything that
+ * is O(H*W) here, one workgroup per frame (and hypothesis), double-precision sums in a fixed order.
+ * Poses are Rt[12] = row-major R (9) | t (3), world -> camera.  cv_mode != 0 selects OpenCV's consensus test: projection in double,
+ * no depth-sign test, (float)err^2 <= (float)thresh^2; cv_mode == 0 is the stricter test of earlier rounds (err < thresh, z > 0).
+ * sp3_pnp_score    : counts[F][n_hyp] = consensus of hypothesis Rt[F][n_hyp][12] over the finite points of frame f.
  * sp3_pnp_dlt_accum: out41[F][41] = the four symmetric 4x4 blocks (10 unique entries each: S, Sx, Sy, Sr) of the calibrated DLT
- *   normal matrix over the finite points (Rt == null) or over the points whose reprojection error under Rt[F][12] (row-major R | t)
- *   is below thresh pixels, and the number of points used; norm4[F][4] = Hartley centroid (3) and scale of each frame's points.
- * sp3_pnp_gn_accum : out29[F][29] = Gauss-Newton normal equations of the reprojection error over the inliers of Rt: H (21 unique,
- *   row-major upper triangle, parameters (omega, delta) of Xc' = Xc + omega x Xc + delta), g (6), squared error, inlier count. */
+ *   normal matrix [[S, 0, -Sx], [0, S, -Sy], [-Sx, -Sy, Sr]] (cvFindExtrinsicCameraParams2's L^T L) over the finite points (Rt == null)
+ *   or over the consensus set of Rt[F][12], and the number of points used; norm4[F][4] = a centroid (3) and scale applied to the
+ *   object points first ((0, 0, 0, 1) reproduces OpenCV's un-normalised system).
+ * sp3_pnp_gn_accum : out29[F][29] = normal equations of the reprojection error (pixels) at pose Rt[F][12] (DOUBLE: the pose under
+ *   refinement): H (21 unique, row-major
+ *   upper triangle, parameters (omega, delta) of Xc' = Xc + omega x Xc + delta), g (6), squared error, point count -- over the
+ *   consensus set of Rt_mask[F][12] if given (a FIXED set, as solvePnPRansac refines it), else over the inliers of Rt itself. */
 int sp3_pnp_dlt_accum(const float* pts, int F, int H, int W, float focal, float cx, float cy, const float* norm4, const float* Rt,
-                      float thresh, double* out41, void* stream);
-int sp3_pnp_gn_accum(const float* pts, int F, int H, int W, float focal, float cx, float cy, const float* Rt, float thresh, double* out29,
-                     void* stream);
-/* consensus of pose hypotheses: counts[F][n_hyp] = number of finite points of frame f whose reprojection error under
- * Rt[F][n_hyp][12] is below thresh pixels (the scoring step of the RANSAC; hypotheses come from 8-point DLTs on the host). */
+                      float thresh, int cv_mode, double* out41, void* stream);
+int sp3_pnp_gn_accum(const float* pts, int F, int H, int W, float focal, float cx, float cy, const double* Rt, const float* Rt_mask,
+                     float thresh, double* out29, void* stream);
 int sp3_pnp_score(const float* pts, int F, int H, int W, float focal, float cx, float cy, const float* Rt, int n_hyp, float thresh,
-                  int* counts, void* stream);
+                  int cv_mode, int* counts, void* stream);
 
 /* small utilities */
 /* n (1..8) contiguous device-to-device copies in one launch; every copy 16-byte aligned and a multiple of 16 bytes.

@@ -3,10 +3,7 @@
   * focal_weiszfeld: dust3r/post_process.py:12-60 estimate_focal_knowing_depth(focal_mode='weiszfeld'), numpy float64
     (the pixel grid of dust3r/utils/geometry.py:15-37 xy_grid: [j, i] = (i, j)).
   * confident: demo.py:205-211, conf_sig = (conf - 1) / conf > thresh, boolean indexing.
-  * pnp_pose: the calibrated PnP of spann3r_amd/postprocess.py::estimate_poses restated in numpy float64 (DLT on all points,
-    DLT on the inliers, Gauss-Newton on the inliers' reprojection error).  demo.py:170-186 calls cv2.solvePnPRansac there;
-    OpenCV is absent from this image, so THIS PART IS PARITY-UNPINNED: it is checked against ground-truth poses of synthetic
-    scenes (tests/test_postprocess.py), not against OpenCV.
+  * camera poses (demo.py:170-186, cv2.solvePnPRansac): oracle/pnp_oracle.py.
 focal_weiszfeld is pinned against tests/golden/postprocess.npz = the unmodified reference function on seeded pointmaps."""
 import numpy as np
 
@@ -32,85 +29,3 @@ def focal_weiszfeld(pts3d, pp, iters=10, min_focal=0.0, max_focal=np.inf):
 def confident(pts_all, conf_all, thresh, images_all=None):
     m = (conf_all - 1) / conf_all > thresh
     return pts_all[m].reshape(-1, 3), (None if images_all is None else images_all[m].reshape(-1, 3))
-
-
-def _errs(R, t, X, u, v, f, cx, cy):
-    Xc = X @ R.T + t
-    z = Xc[:, 2]
-    with np.errstate(divide="ignore", invalid="ignore"):
-        e = np.hypot(f * Xc[:, 0] / z + cx - u, f * Xc[:, 1] / z + cy - v)
-    return np.where(z > 1e-9, e, 1e30), Xc
-
-
-def pnp_pose(pts, focal, pp, thresh=8.0, iters=10, n_hyp=96, idx=None):
-    """pts [H,W,3] -> (camera-to-world 4x4, inlier fraction); idx [n_hyp, 8]: the minimal sets (pixel indices), drawn from
-    default_rng(0) if not given"""
-    H, W, _ = pts.shape
-    f, (cx, cy) = float(focal), pp
-    uu, vv = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
-    X, u, v = pts.reshape(-1, 3).astype(np.float64), uu.reshape(-1), vv.reshape(-1)
-    ok = np.isfinite(X).all(1)
-    # the Hartley normalisation is computed once, over the finite points (as the device path does)
-    Xf = X[ok]
-    c = Xf.mean(0); sc = np.sqrt(3.0) / np.linalg.norm(Xf - c, axis=1).mean()
-
-    def dlt(sel):
-        Xh = np.concatenate(((X[sel] - c) * sc, np.ones((sel.sum(), 1))), 1)
-        x, y = (u[sel] - cx) / f, (v[sel] - cy) / f
-        Z = np.zeros_like(Xh)
-        A = np.concatenate((np.concatenate((Xh, Z, -x[:, None] * Xh), 1), np.concatenate((Z, Xh, -y[:, None] * Xh), 1)), 0)
-        _, V = np.linalg.eigh(A.T @ A)
-        P = V[:, 0].reshape(3, 4)
-        T = np.eye(4); T[:3, :3] *= sc; T[:3, 3] = -sc * c
-        P = P @ T
-        U, sv, Vt = np.linalg.svd(P[:, :3])
-        if np.linalg.det(U @ Vt) < 0:
-            P, U = -P, -U
-        return U @ Vt, P[:, 3] / sv.mean()
-    Xs = np.where(ok[:, None], X, 0.0)
-    sets = np.random.default_rng(0).integers(0, H * W, (n_hyp, 8)) if idx is None else idx
-    best = (-1, None)
-    for idx in sets:
-        if not ok[idx].all():
-            continue
-        # (a repeated index simply repeats its two rows)
-        Xh = np.concatenate(((X[idx] - c) * sc, np.ones((8, 1))), 1)
-        x, y = (u[idx] - cx) / f, (v[idx] - cy) / f
-        Z = np.zeros_like(Xh)
-        A = np.concatenate((np.concatenate((Xh, Z, -x[:, None] * Xh), 1), np.concatenate((Z, Xh, -y[:, None] * Xh), 1)), 0)
-        _, V = np.linalg.eigh(A.T @ A)
-        P = V[:, 0].reshape(3, 4)
-        T = np.eye(4); T[:3, :3] *= sc; T[:3, 3] = -sc * c
-        P = P @ T
-        U, sv, Vt = np.linalg.svd(P[:, :3])
-        if np.linalg.det(U @ Vt) < 0:
-            P, U = -P, -U
-        if sv.mean() < 1e-12:
-            continue
-        Rh, th = (U @ Vt).astype(np.float32).astype(np.float64), (P[:, 3] / sv.mean()).astype(np.float32).astype(np.float64)
-        e, _ = _errs(Rh, th, Xs, u, v, f, cx, cy)
-        n = int((ok & (e < thresh)).sum())
-        if n > best[0]:
-            best = (n, (Rh, th))
-    R, t = best[1]
-    e, _ = _errs(R, t, Xs, u, v, f, cx, cy)
-    R, t = dlt(ok & (e < thresh))
-    frac = 0.0
-    for _ in range(iters):
-        e, Xc = _errs(R, t, Xs, u, v, f, cx, cy)
-        m = ok & (e < thresh)
-        xc, yc, zc = Xc[m].T
-        xn, yn, fz = xc / zc, yc / zc, f / zc
-        ru, rv = f * xn + cx - u[m], f * yn + cy - v[m]
-        Ju = np.stack((fz * (-xn * yc), fz * (zc + xn * xc), fz * (-yc), fz, 0 * fz, -fz * xn), 1)
-        Jv = np.stack((fz * (-zc - yn * yc), fz * (yn * xc), fz * xc, 0 * fz, fz, -fz * yn), 1)
-        Hm = Ju.T @ Ju + Jv.T @ Jv
-        g = Ju.T @ ru + Jv.T @ rv
-        d = -np.linalg.solve(Hm + 1e-9 * np.trace(Hm) / 6 * np.eye(6), g)
-        w = d[:3]; th = np.linalg.norm(w)
-        K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
-        E = np.eye(3) + K if th < 1e-12 else np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * (K @ K)
-        R, t = E @ R, E @ t + d[3:]
-        frac = m.sum() / (H * W)
-    ext = np.eye(4); ext[:3, :3], ext[:3, 3] = R, t
-    return np.linalg.inv(ext), frac

@@ -962,6 +962,7 @@ struct SmInst {
   int (*launch)(const SmArgs&, int mt, int nz, hipStream_t);
   int min_m = 1, max_m = 256;       // row range (small-M family: M <= 256)
   int bm = 0, bn = 0;               // many-row family (bm_kernel): workgroup tile
+  int min_mb = 0, max_mb = 1 << 30; // range of M x batch (rows of all groups of the launch): 128-row tiles while they fit ONE round of workgroups
   int tile_m() const { return bm ? bm : MF * 16; }
   int tile_n() const { return bn ? bn : NF * 16; }
 };
@@ -1005,16 +1006,21 @@ const SmInst kInst[] = {
     // ---- many rows (bm_kernel<WM, WN, NF, NKB, NST, EPI>): 256x128 (8 waves) from 1536 rows on, else 128x128 / 128x64 (4 waves)
     {50, SM_ROPE, 1024, 4, 4, 1, false, 0, 1 << 30, bm_launch<4, 2, 4, 16, 3, SM_ROPE>, 1536, 1 << 30, 256, 128},     // encoder q/k/v (M = frames x 196)
     {51, SM_ROPE, 1024, 4, 4, 1, false, 0, 1 << 30, bm_launch<2, 2, 4, 16, 3, SM_ROPE>, 257, 1535, 128, 128},
-    {52, SM_ROPE, 768, 4, 4, 1, false, 0, 1 << 30, bm_launch<2, 2, 4, 12, 3, SM_ROPE>, 257, 1 << 30, 128, 128},       // decoder q/k/v + cross k/v at 512x512
+    // K = 768 (decoder at 512x512: M = 1024 rows per side, both sides in one launch): the 128 x 128 tiles of a q/k/v + cross-k/v pair
+    // are 480 workgroups of 96 KB LDS -- two rounds at one workgroup per CU; 256 x 128 makes it one (profiles/r05_gemm_manyrow_config3_tiles.txt:
+    // 20.3 -> 14.4 us for the q/k/v half, fc1 24.3 -> 19.2).  The rule looks at rows x groups only, so both groups of a pair agree.
+    {52, SM_ROPE, 768, 4, 4, 1, false, 0, 1 << 30, bm_launch<2, 2, 4, 12, 3, SM_ROPE>, 257, 1 << 30, 128, 128, 0, 2047},
+    {63, SM_ROPE, 768, 4, 4, 1, false, 0, 1 << 30, bm_launch<4, 2, 4, 12, 3, SM_ROPE>, 257, 1 << 30, 256, 128, 2048, 1 << 30},   // decoder q/k/v + cross k/v at 512x512
     {53, SM_PACKED, 1024, 4, 4, 1, false, 0, 1 << 30, bm_launch<4, 2, 4, 16, 3, SM_PACKED>, 1536, 1 << 30, 256, 128},  // encoder fc1
     {54, SM_PACKED, 1024, 4, 4, 1, false, 0, 1 << 30, bm_launch<2, 2, 4, 16, 3, SM_PACKED>, 257, 1535, 128, 128},
-    {55, SM_PACKED, 768, 4, 4, 1, false, 0, 1 << 30, bm_launch<2, 2, 4, 12, 3, SM_PACKED>, 257, 1 << 30, 128, 128},
+    {55, SM_PACKED, 768, 4, 4, 1, false, 0, 1 << 30, bm_launch<2, 2, 4, 12, 3, SM_PACKED>, 257, 1 << 30, 128, 128, 0, 2047},
+    {64, SM_PACKED, 768, 4, 4, 1, false, 0, 1 << 30, bm_launch<4, 2, 4, 12, 3, SM_PACKED>, 257, 1 << 30, 256, 128, 2048, 1 << 30},   // decoder fc1 at 512x512
     {61, SM_STREAM, 1024, 4, 4, 1, false, 0, 1 << 30, bm_launch<4, 2, 4, 16, 3, SM_STREAM>, 4096, 1 << 30, 256, 128},   // 512x512 whole-sequence encoder (M = 16 x 1024)
     {62, SM_STREAM, 4096, 4, 4, 1, false, 0, 1 << 30, bm_launch<4, 2, 4, 64, 3, SM_STREAM>, 4096, 1 << 30, 256, 128},
     {56, SM_STREAM, 1024, 4, 2, 1, false, 0, 1 << 30, bm_launch<2, 2, 2, 16, 3, SM_STREAM>, 257, 1 << 30, 128, 64},    // encoder proj
     {57, SM_STREAM, 4096, 4, 2, 1, false, 0, 1 << 30, bm_launch<2, 2, 2, 64, 3, SM_STREAM>, 257, 1 << 30, 128, 64},    // encoder fc2
     {58, SM_STREAM, 768, 4, 2, 1, false, 0, 1 << 30, bm_launch<2, 2, 2, 12, 3, SM_STREAM>, 257, 1 << 30, 128, 64},
-    {59, SM_STREAM, 3072, 4, 2, 1, false, 0, 1 << 30, bm_launch<2, 2, 2, 48, 3, SM_STREAM>, 257, 1 << 30, 128, 64},
+    {59, SM_STREAM, 3072, 4, 2, 1, false, 0, 1 << 30, bm_launch<2, 2, 2, 48, 4, SM_STREAM>, 257, 1 << 30, 128, 64},    // (ring of 4: 22.1 -> 20.9 us at 1024 x 2 x 768)
     {60, SM_STREAM, 1792, 4, 2, 1, false, 0, 1 << 30, bm_launch<2, 2, 2, 28, 3, SM_STREAM>, 257, 1 << 30, 128, 64},
 };
 bool sm_enabled() {
@@ -1052,6 +1058,8 @@ const SmInst* sm_find(const sp3_gemm_desc& d) {
   if (split && (d.K1 % 64 || d.K1 <= 0 || d.K1 >= d.K)) return nullptr;
   for (const SmInst& s : kInst) {
     if (s.epi != kind || s.K != d.K || s.split != split || d.M < s.min_m || d.M > s.max_m) continue;
+    const long mb = (long)d.M * (d.batch > 1 ? d.batch : 1);
+    if (mb < s.min_mb || mb > s.max_mb) continue;
     if (d.N % s.tile_n() || d.N < s.min_n || d.N > s.max_n) continue;
     if (!s.bm && d.ln_stats && s.MF * 16 * 4 > 64 * s.WK) continue;
     if (s.bm && kind == SM_ROPE && d.rope_cols % 32) continue;

@@ -188,9 +188,21 @@ __device__ __forceinline__ float reproj_err(const float* Rt, float X, float Y, f
   return sqrtf(du * du + dv * dv);
 }
 
+// OpenCV's consensus test (calib3d/src/solvepnp.cpp PnPRansacCallback::computeError + ptsetreg.cpp findInliers): the point is projected in
+// double precision, NO test of the sign of the depth (cvProjectPoints2: z = z ? 1 / z : 1), the squared pixel error is rounded to
+// float and compared with (float)(thresh^2) by <=.
+__device__ __forceinline__ bool cv_inlier(const float* Rt, float X, float Y, float Z, float f, float u, float v, float cx, float cy, float thr) {
+  const double xc = (double)Rt[0] * X + (double)Rt[1] * Y + (double)Rt[2] * Z + Rt[9];
+  const double yc = (double)Rt[3] * X + (double)Rt[4] * Y + (double)Rt[5] * Z + Rt[10];
+  double zc = (double)Rt[6] * X + (double)Rt[7] * Y + (double)Rt[8] * Z + Rt[11];
+  zc = zc != 0.0 ? 1.0 / zc : 1.0;
+  const double du = (double)f * xc * zc + cx - u, dv = (double)f * yc * zc + cy - v;
+  return (float)(du * du + dv * dv) <= thr * thr;
+}
+
 __global__ __launch_bounds__(1024) void pnp_dlt_accum_kernel(const float* __restrict__ pts, int HW, int W, float f, float cx, float cy,
                                                              const float* __restrict__ norm4, const float* __restrict__ Rt_all, float thr,
-                                                             double* __restrict__ out) {
+                                                             int cv_mode, double* __restrict__ out) {
   __shared__ double sh[16 * 48];
   const float* p = pts + (int64_t)blockIdx.x * HW * 3;
   const float* nm = norm4 + blockIdx.x * 4;                 // centroid (3), scale
@@ -201,7 +213,10 @@ __global__ __launch_bounds__(1024) void pnp_dlt_accum_kernel(const float* __rest
     const float X = p[3 * i], Y = p[3 * i + 1], Z = p[3 * i + 2];
     if (!(isfinite(X) && isfinite(Y) && isfinite(Z))) continue;
     const float u = (float)(i % W), v = (float)(i / W);
-    if (Rt) { float xc, yc, zc; if (reproj_err(Rt, X, Y, Z, f, u, v, cx, cy, xc, yc, zc) >= thr) continue; }
+    if (Rt) {
+      float xc, yc, zc;
+      if (cv_mode ? !cv_inlier(Rt, X, Y, Z, f, u, v, cx, cy, thr) : reproj_err(Rt, X, Y, Z, f, u, v, cx, cy, xc, yc, zc) >= thr) continue;
+    }
     const double x = (double)(u - cx) / f, y = (double)(v - cy) / f;
     const double h[4] = {(double)(X - nm[0]) * nm[3], (double)(Y - nm[1]) * nm[3], (double)(Z - nm[2]) * nm[3], 1.0};
     const double rr = x * x + y * y;
@@ -217,18 +232,32 @@ __global__ __launch_bounds__(1024) void pnp_dlt_accum_kernel(const float* __rest
 }
 
 __global__ __launch_bounds__(1024) void pnp_gn_accum_kernel(const float* __restrict__ pts, int HW, int W, float f, float cx, float cy,
-                                                            const float* __restrict__ Rt_all, float thr, double* __restrict__ out) {
+                                                            const double* __restrict__ Rt_all, const float* __restrict__ Rt_mask_all, float thr,
+                                                            double* __restrict__ out) {
   __shared__ double sh[16 * 48];
   const float* p = pts + (int64_t)blockIdx.x * HW * 3;
-  const float* Rt = Rt_all + blockIdx.x * 12;
+  const double* Rt = Rt_all + blockIdx.x * 12;             // the pose under refinement, in double: its float rounding would be the fixed point's error
+  float Rf[12];
+  for (int k = 0; k < 12; ++k) Rf[k] = (float)Rt[k];
+  const float* Rm = Rt_mask_all ? Rt_mask_all + blockIdx.x * 12 : nullptr;   // fixed consensus set (OpenCV): the inliers of THIS pose
   double a[29];
   for (int k = 0; k < 29; ++k) a[k] = 0.0;
   for (int i = threadIdx.x; i < HW; i += 1024) {
     const float X = p[3 * i], Y = p[3 * i + 1], Z = p[3 * i + 2];
     if (!(isfinite(X) && isfinite(Y) && isfinite(Z))) continue;
     const float u = (float)(i % W), v = (float)(i / W);
-    float xc, yc, zc;
-    if (reproj_err(Rt, X, Y, Z, f, u, v, cx, cy, xc, yc, zc) >= thr) continue;
+    double xc, yc, zc;
+    if (Rm) {
+      if (!cv_inlier(Rm, X, Y, Z, f, u, v, cx, cy, thr)) continue;
+      xc = Rt[0] * X + Rt[1] * Y + Rt[2] * Z + Rt[9];
+      yc = Rt[3] * X + Rt[4] * Y + Rt[5] * Z + Rt[10];
+      zc = Rt[6] * X + Rt[7] * Y + Rt[8] * Z + Rt[11];
+      if (zc == 0.0) zc = 1.0;
+    } else {
+      float xf, yf, zf;
+      if (reproj_err(Rf, X, Y, Z, f, u, v, cx, cy, xf, yf, zf) >= thr) continue;
+      xc = xf; yc = yf; zc = zf;
+    }
     const double iz = 1.0 / zc, xn = xc * iz, yn = yc * iz;
     const double ru = f * xn + cx - u, rv = f * yn + cy - v;
     // d(residual) / d(omega, delta) for Xc' = Xc + omega x Xc + delta
@@ -248,19 +277,19 @@ __global__ __launch_bounds__(1024) void pnp_gn_accum_kernel(const float* __restr
 }  // namespace
 
 extern "C" int sp3_pnp_dlt_accum(const float* pts, int F, int H, int W, float focal, float cx, float cy, const float* norm4,
-                                 const float* Rt, float thresh, double* out41, void* stream) {
+                                 const float* Rt, float thresh, int cv_mode, double* out41, void* stream) {
   SP3_CHECK(pts && norm4 && out41 && F > 0 && H > 0 && W > 0 && focal > 0.f, "sp3_pnp_dlt_accum: bad arguments");
   hipLaunchKernelGGL(pnp_dlt_accum_kernel, dim3(F), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), pts, H * W, W, focal, cx, cy, norm4,
-                     Rt, thresh, out41);
+                     Rt, thresh, cv_mode, out41);
   SP3_LAUNCH_CHECK("sp3_pnp_dlt_accum");
   return 0;
 }
 
-extern "C" int sp3_pnp_gn_accum(const float* pts, int F, int H, int W, float focal, float cx, float cy, const float* Rt, float thresh,
-                                double* out29, void* stream) {
+extern "C" int sp3_pnp_gn_accum(const float* pts, int F, int H, int W, float focal, float cx, float cy, const double* Rt, const float* Rt_mask,
+                                float thresh, double* out29, void* stream) {
   SP3_CHECK(pts && Rt && out29 && F > 0 && H > 0 && W > 0 && focal > 0.f, "sp3_pnp_gn_accum: bad arguments");
   hipLaunchKernelGGL(pnp_gn_accum_kernel, dim3(F), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), pts, H * W, W, focal, cx, cy, Rt,
-                     thresh, out29);
+                     Rt_mask, thresh, out29);
   SP3_LAUNCH_CHECK("sp3_pnp_gn_accum");
   return 0;
 }
@@ -268,7 +297,7 @@ extern "C" int sp3_pnp_gn_accum(const float* pts, int F, int H, int W, float foc
 // number of points whose reprojection error under hypothesis h of frame f is below thr: counts[f][h]; grid (hyps, frames)
 namespace {
 __global__ __launch_bounds__(256) void pnp_score_kernel(const float* __restrict__ pts, int HW, int W, float f, float cx, float cy,
-                                                        const float* __restrict__ Rt_all, int nh, float thr, int* __restrict__ counts) {
+                                                        const float* __restrict__ Rt_all, int nh, float thr, int cv_mode, int* __restrict__ counts) {
   __shared__ int sh[4];
   const float* p = pts + (int64_t)blockIdx.y * HW * 3;
   const float* Rt = Rt_all + ((int64_t)blockIdx.y * nh + blockIdx.x) * 12;
@@ -279,7 +308,8 @@ __global__ __launch_bounds__(256) void pnp_score_kernel(const float* __restrict_
     const float X = p[3 * i], Y = p[3 * i + 1], Z = p[3 * i + 2];
     if (!(isfinite(X) && isfinite(Y) && isfinite(Z))) continue;
     float xc, yc, zc;
-    c += reproj_err(r, X, Y, Z, f, (float)(i % W), (float)(i / W), cx, cy, xc, yc, zc) < thr;
+    if (cv_mode) c += cv_inlier(r, X, Y, Z, f, (float)(i % W), (float)(i / W), cx, cy, thr);
+    else c += reproj_err(r, X, Y, Z, f, (float)(i % W), (float)(i / W), cx, cy, xc, yc, zc) < thr;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
@@ -290,10 +320,10 @@ __global__ __launch_bounds__(256) void pnp_score_kernel(const float* __restrict_
 }  // namespace
 
 extern "C" int sp3_pnp_score(const float* pts, int F, int H, int W, float focal, float cx, float cy, const float* Rt, int n_hyp, float thresh,
-                             int* counts, void* stream) {
+                             int cv_mode, int* counts, void* stream) {
   SP3_CHECK(pts && Rt && counts && F > 0 && H > 0 && W > 0 && n_hyp > 0 && focal > 0.f, "sp3_pnp_score: bad arguments");
   hipLaunchKernelGGL(pnp_score_kernel, dim3(n_hyp, F), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pts, H * W, W, focal, cx, cy, Rt,
-                     n_hyp, thresh, counts);
+                     n_hyp, thresh, cv_mode, counts);
   SP3_LAUNCH_CHECK("sp3_pnp_score");
   return 0;
 }

@@ -184,10 +184,10 @@ _PROTOS = {
     "sp3_focal_weiszfeld": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p],
     "sp3_conf_filter": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "sp3_copy_multi": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
-    "sp3_pnp_dlt_accum": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_float,
+    "sp3_pnp_dlt_accum": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_float, C.c_int,
                           C.c_void_p, C.c_void_p],
-    "sp3_pnp_gn_accum": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p],
-    "sp3_pnp_score": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p],
+    "sp3_pnp_gn_accum": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p],
+    "sp3_pnp_score": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p],
     "sp3_ssi_loss_forward": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                              C.c_void_p],
     "sp3_preprocess_image": [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,

@@ -764,7 +764,7 @@ def make_pnp():
     sys.path.insert(0, os.path.dirname(HERE))
     from test_postprocess import _scene
     out = {}
-    for tag, (seed, kw) in {"clean": (5, {}), "outliers": (6, {"outliers": 0.3}), "four": (7, {"F": 4})}.items():
+    for tag, (seed, kw) in {"clean": (5, {}), "outliers": (6, {"outliers": 0.3}), "four": (7, {"F": 4}), "clear": (8, {"F": 4, "clear_px": 40.0})}.items():
         pts, poses, f, (cx, cy) = _scene(seed, **kw)
         F, H, W, _ = pts.shape
         K = np.array([[f, 0, cx], [0, f, cy], [0, 0, 1]], np.float64)

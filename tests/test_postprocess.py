@@ -10,6 +10,7 @@ import torch
 
 from conftest import load_golden, rel_err
 from oracle import postprocess_oracle as PO
+from oracle import pnp_oracle as CV
 from spann3r_amd.weights import synth_pointmaps
 
 
@@ -73,9 +74,11 @@ def test_ply_and_transforms_writers(tmp_path):
     assert json.load(open(os.path.join(tmp_path, "transforms.json")))["ply_file_path"] == "c.ply"
 
 
-def _scene(seed, F=3, H=48, W=64, f=60.0, noise=0.004, outliers=0.1):
+def _scene(seed, F=3, H=48, W=64, f=60.0, noise=0.004, outliers=0.1, clear_px=0.0):
     """F views of one smooth surface: every frame's pointmap expressed in the world (= first camera) frame, with known
-    camera-to-world poses, Gaussian noise, gross outliers and a few non-finite entries"""
+    camera-to-world poses, Gaussian noise, gross outliers and a few non-finite entries.  clear_px > 0: outliers are redrawn until
+    they reproject at least that far from their pixel, so that every good hypothesis has the SAME consensus set at 8 px (a
+    consensus estimator is only reproducible to the last digit when no point sits on its threshold)"""
     rng = np.random.default_rng(seed)
     uu, vv = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
     cx, cy = W / 2, H / 2
@@ -91,6 +94,14 @@ def _scene(seed, F=3, H=48, W=64, f=60.0, noise=0.004, outliers=0.1):
         Xw = Xc @ R.T + t + rng.normal(0, noise, Xc.shape)                 # camera-to-world = (R, t)
         m = rng.random((H, W)) < outliers
         Xw[m] = rng.normal(0, 2.0, (int(m.sum()), 3)) + np.array([0, 0, 2.5])
+        while clear_px > 0:
+            Xo = (Xw - t) @ R                                               # back into this camera: where do the outliers reproject?
+            with np.errstate(divide="ignore", invalid="ignore"):
+                d = np.hypot(f * Xo[..., 0] / Xo[..., 2] + cx - uu, f * Xo[..., 1] / Xo[..., 2] + cy - vv)
+            bad = m & ~(d > clear_px)
+            if not bad.any():
+                break
+            Xw[bad] = rng.normal(0, 2.0, (int(bad.sum()), 3)) + np.array([0, 0, 2.5])
         Xw[3, 4] = np.nan
         Xw[5, 6, 1] = np.inf
         P = np.eye(4); P[:3, :3], P[:3, 3] = R, t
@@ -105,15 +116,101 @@ def _pose_err(A, B):
 
 
 def test_pnp_oracle_recovers_ground_truth_poses():
+    """oracle/pnp_oracle.py (OpenCV's solvePnPRansac pipeline restated) against the poses the scenes were rendered with"""
     pts, poses, f, pp = _scene(5)
     for j in range(len(pts)):
-        P, frac = PO.pnp_pose(pts[j], f, pp)
+        P, frac = CV.pose_c2w(pts[j], f, pp)
         ang, dt = _pose_err(P, poses[j])
         assert ang < 0.25 and dt < 1.5e-2 and 0.8 < frac < 0.95, (j, ang, dt, frac)
     pts, poses, f, pp = _scene(6, outliers=0.3)                           # 30 % gross outliers: the consensus step matters
-    P, frac = PO.pnp_pose(pts[1], f, pp)
+    P, frac = CV.pose_c2w(pts[1], f, pp)
     ang, dt = _pose_err(P, poses[1])
     assert ang < 0.4 and dt < 2e-2 and 0.6 < frac < 0.8, (ang, dt, frac)
+
+
+def test_pnp_oracle_pieces():
+    """the restated OpenCV pieces one by one: cv::RNG / getSubset, Rodrigues and its Jacobian, EPnP and the iterative solver on exact data,
+    the adaptive iteration count"""
+    r = CV.CvRNG()
+    first = [r.next() for _ in range(3)]
+    s0 = 0xFFFFFFFFFFFFFFFF
+    exp = []
+    for _ in range(3):
+        s0 = ((s0 & 0xFFFFFFFF) * 4164903690 + (s0 >> 32)) & 0xFFFFFFFFFFFFFFFF
+        exp.append(s0 & 0xFFFFFFFF)
+    assert first == exp and first[0] == (0xFFFFFFFF * 4164903690 + 0xFFFFFFFF) & 0xFFFFFFFF
+    rv = np.array([0.3, -0.5, 0.2])
+    R, dR = CV.rodrigues(rv)
+    assert np.abs(R @ R.T - np.eye(3)).max() < 1e-14 and np.abs(CV.rodrigues_inv(R) - rv).max() < 1e-14
+    for i in range(3):
+        d = np.zeros(3); d[i] = 1e-6
+        num = (CV.rodrigues(rv + d)[0] - CV.rodrigues(rv - d)[0]) / 2e-6
+        assert np.abs(num - dR[i]).max() < 1e-9
+    rng = np.random.default_rng(0)
+    K = np.array([[60.0, 0, 32], [0, 60.0, 24], [0, 0, 1]])
+    t = np.array([0.1, -0.2, 0.3])
+    X = rng.normal(0, 1, (40, 3)) + np.array([0, 0, 4.0])
+    px = CV.project(X, rv, t, K)
+    for n in (5, 6, 40):                                                    # exact correspondences: EPnP is exact up to round-off
+        Re, te = CV.epnp(X[:n], px[:n], K)
+        assert np.abs(Re - R).max() < 1e-6 and np.abs(te - t).max() < 1e-6, n
+    r2, t2 = CV.solve_pnp_iterative(X, px + rng.normal(0, 0.05, px.shape), K)
+    assert np.abs(r2 - rv).max() < 2e-3 and np.abs(t2 - t).max() < 5e-3
+    r3, t3 = CV.solve_pnp_iterative(X, px, K)
+    assert np.abs(r3 - rv).max() < 1e-8 and np.abs(t3 - t).max() < 1e-8
+    p, J = CV.project(X, rv, t, K, jac=True)
+    for i in range(6):
+        d = np.zeros(6); d[i] = 1e-6
+        num = (CV.project(X, rv + d[:3], t + d[3:], K) - CV.project(X, rv - d[:3], t - d[3:], K)).reshape(-1) / 2e-6
+        assert np.abs(num - J[:, i]).max() < 1e-5
+    assert CV.ransac_update_num_iters(0.99, 0.1, 5, 100) == 5 and CV.ransac_update_num_iters(0.99, 0.0, 5, 100) == 0
+    assert CV.ransac_update_num_iters(0.99, 0.9, 5, 100) == 100
+
+
+def test_pnp_product_host_pieces_match_oracle():
+    """the product's host side (spann3r_amd/postprocess.py: sampler, batched EPnP) against the oracle, no GPU involved"""
+    from spann3r_amd import postprocess as PP
+    pts, _, f, (cx, cy) = _scene(5, clear_px=40.0)
+    H, W = pts.shape[1:3]
+    X = pts[1].reshape(-1, 3)
+    ok = np.isfinite(X).all(1)
+    Xf = X[ok].astype(np.float64)
+    uu, vv = np.meshgrid(np.arange(W), np.arange(H))
+    px = np.stack((uu, vv), -1).reshape(-1, 2)[ok].astype(np.float64)
+    sets = PP._cv_subsets(len(Xf), 10)
+    r = CV.CvRNG()
+    for k in range(10):
+        idx = []
+        for _ in range(5):
+            i = r.uniform(0, len(Xf))
+            while i in idx:
+                i = r.uniform(0, len(Xf))
+            idx.append(i)
+        assert list(sets[k]) == idx
+    K = np.array([[f, 0, cx], [0, f, cy], [0, 0, 1]], np.float64)
+    R, t = PP._epnp_batch(Xf[sets], px[sets], f, cx, cy)
+    agree = 0
+    for k in range(10):
+        Ro, to = CV.epnp(Xf[sets[k]], px[sets[k]], K)
+        e = np.hypot(*(CV.project(Xf, CV.rodrigues_inv(Ro), to, K) - px).T)
+        if (e <= 8).mean() > 0.8:                                           # an all-inlier subset: the pose is determined, both must find it
+            eb = np.hypot(*(CV.project(Xf, CV.rodrigues_inv(R[k]), t[k], K) - px).T)
+            assert np.array_equal(e <= 8, eb <= 8), k                       # same consensus set (no point near the threshold in this scene)
+            agree += 1
+    assert agree >= 4
+
+
+def test_pnp_oracle_vs_opencv():
+    """the last link: the restatement against cv2 itself, on a machine that could run tests/golden/make_golden.py pnp"""
+    path = os.path.join(os.path.dirname(__file__), "golden", "pnp_cv2.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/pnp_cv2.npz not generated (needs OpenCV): oracle/pnp_oracle.py is parity-unpinned against cv2")
+    g = np.load(path)
+    pts, _, f, pp = _scene(8, F=4, clear_px=40.0)
+    for j in range(len(pts)):
+        P, _ = CV.pose_c2w(pts[j], f, pp)
+        ang, dt = _pose_err(P, g["clear_poses"][j])
+        assert ang < 1e-3 and dt < 1e-5, (j, ang, dt)
 
 
 @pytest.mark.gpu
@@ -125,26 +222,37 @@ def test_estimate_poses_vs_opencv():
         pytest.skip("tests/golden/pnp_cv2.npz not generated (needs OpenCV): f4 parity unpinned")
     from spann3r_amd.postprocess import estimate_poses
     g = np.load(path)
-    for tag, (seed, kw) in {"clean": (5, {}), "outliers": (6, {"outliers": 0.3}), "four": (7, {"F": 4})}.items():
+    for tag, (seed, kw) in {"clean": (5, {}), "outliers": (6, {"outliers": 0.3}), "four": (7, {"F": 4}), "clear": (8, {"F": 4, "clear_px": 40.0})}.items():
         pts, _, f, pp = _scene(seed, **kw)
-        got, _ = estimate_poses(torch.from_numpy(pts).cuda(), f, pp, seed=3)
+        got, _ = estimate_poses(torch.from_numpy(pts).cuda(), f, pp)
         for j in range(len(pts)):
             ang, dt = _pose_err(got[j], g[tag + "_poses"][j])
-            assert ang < 0.3 and dt < 2e-2, (tag, j, ang, dt)
+            assert (ang < 1e-3 and dt < 1e-5) if tag == "clear" else (ang < 0.3 and dt < 2e-2), (tag, j, ang, dt)
 
 
 @pytest.mark.gpu
-def test_estimate_poses_kernels():
+def test_estimate_poses_pinned_to_opencv_restatement():
+    """the product (device reductions + batched host solves) against oracle/pnp_oracle.py.  Scenes without points near the 8 px
+    threshold: every good hypothesis has the same consensus set, so the two must agree to the digits of the float32 pose hand-over;
+    scenes with threshold points: the consensus sets may differ by those points and the poses by what they weigh (noise level)."""
     from spann3r_amd.postprocess import estimate_poses
-    pts, poses, f, pp = _scene(7, F=4)
-    got, inl = estimate_poses(torch.from_numpy(pts).cuda(), f, pp, seed=3)
+    pts, poses, f, pp = _scene(8, F=4, clear_px=40.0)
+    got, inl = estimate_poses(torch.from_numpy(pts).cuda(), f, pp)
     F, H, W, _ = pts.shape
-    sets = np.random.default_rng(3).integers(0, H * W, (F, 96, 8))        # the same minimal sets the product draws
     for j in range(F):
-        ang, dt = _pose_err(got[j], poses[j])
-        assert ang < 0.25 and dt < 1.5e-2 and 0.8 < inl[j] < 0.95, (j, ang, dt, inl[j])
-        ref, _ = PO.pnp_pose(pts[j], f, pp, idx=sets[j])
+        ref, frac = CV.pose_c2w(pts[j], f, pp)
         ang, dt = _pose_err(got[j], ref)
-        assert ang < 5e-3 and dt < 2e-4, (j, ang, dt)
-    again, _ = estimate_poses(torch.from_numpy(pts).cuda(), f, pp, seed=3)
-    assert np.array_equal(got, again)                                     # seeded sampling, fixed-order sums: deterministic
+        assert ang < 2e-4 and dt < 1e-5 and abs(inl[j] - frac) < 1e-12, (j, ang, dt, inl[j], frac)
+        ang, dt = _pose_err(got[j], poses[j])
+        assert ang < 0.1 and dt < 5e-3, (j, ang, dt)
+    again, _ = estimate_poses(torch.from_numpy(pts).cuda(), f, pp)
+    assert np.array_equal(got, again)                                     # OpenCV's fixed-seed sampler, fixed-order sums: deterministic
+    for seed, kw in ((5, {}), (6, {"outliers": 0.3}), (7, {"F": 4})):
+        pts, poses, f, pp = _scene(seed, **kw)
+        got, inl = estimate_poses(torch.from_numpy(pts).cuda(), f, pp)
+        for j in range(len(pts)):
+            ref, frac = CV.pose_c2w(pts[j], f, pp)
+            ang, dt = _pose_err(got[j], ref)
+            assert ang < 0.35 and dt < 2e-2 and abs(inl[j] - frac) < 2e-3, (seed, j, ang, dt, inl[j], frac)
+            ang, dt = _pose_err(got[j], poses[j])
+            assert ang < 0.45 and dt < 2.5e-2, (seed, j, ang, dt)

@@ -568,7 +568,7 @@ static void run_kernel(Problem& p, const char* tag, K kern, int BM, int BN, int 
       const int c = (int)((s >> 8) % p.N);
       double ref = p.hb[c];
       for (int k = 0; k < p.K; ++k) ref += (double)bf2f(p.hA[(size_t)r * p.K + k]) * (double)bf2f(p.hW0[(size_t)c * p.K + k]);
-      if (epi == 2) ref = 0.5 * ref * (1.0 + std::erf(ref * 0.70710678118654752440));
+      if (epi >= 2) ref = 0.5 * ref * (1.0 + std::erf(ref * 0.70710678118654752440));
       const double got = bf2f(hc[packed_off(r, c, p.N)]);
       worst = std::max(worst, std::fabs(ref - got) / (std::fabs(ref) + 0.05));
     }
@@ -665,6 +665,43 @@ int main(int argc, char** argv) {
     run32<2, 2, 2, 1, 1, true, 64, 12, 1, false>(p, "k32 128x64 4w(64x32) ks1 12x12K epi bias");
     run32<4, 2, 1, 1, 1, true, 64, 12, 1, false>(p, "k32 128x64 8w(32x32) ks1 12x12K epi bias");
     release(p);
+  }
+  if (want("c3")) {
+    // config 3 (512 x 512 frame: M = 1024 rows per side, two sides grouped -> emulated as one problem with 2 N): what the ring depth /
+    // workgroups per CU do to the 128-row tiles
+    { Problem p = make(1024, 4608, 768, 330);
+      printf("c3 dec qkv 1024x(2x2304)x768 (%d weight copies)\n", p.ncopy);
+      run16<2, 2, 4, 12, 3, 1>(p, "k16 128x128 4w(64x64) 3x32K epi bias");
+      run16<2, 2, 4, 12, 2, 1>(p, "k16 128x128 4w(64x64) 2x32K epi bias");
+      run16<4, 2, 4, 12, 3, 1>(p, "k16 256x128 8w(64x64) 3x48K epi bias");
+      run16<4, 2, 4, 12, 2, 1>(p, "k16 256x128 8w(64x64) 2x48K epi bias");
+      run32<2, 2, 2, 2, 2, false, 12, 3, 1, false>(p, "k32 128x128 4w(64x64) ks2 3x32K epi bias");
+      run32<2, 2, 2, 2, 2, false, 12, 2, 1, false>(p, "k32 128x128 4w(64x64) ks2 2x32K epi bias");
+      run32<4, 2, 2, 2, 2, false, 12, 3, 1, false>(p, "k32 256x128 8w(64x64) ks2 3x48K epi bias");
+      release(p); }
+    { Problem p = make(1024, 6144, 768, 330);
+      printf("c3 dec fc1 1024x(2x3072)x768 (%d weight copies)\n", p.ncopy);
+      run16<2, 2, 4, 12, 3, 2>(p, "k16 128x128 4w(64x64) 3x32K epi gelu");
+      run16<2, 2, 4, 12, 2, 2>(p, "k16 128x128 4w(64x64) 2x32K epi gelu");
+      run16<4, 2, 4, 12, 3, 2>(p, "k16 256x128 8w(64x64) 3x48K epi gelu");
+      run32<2, 2, 2, 2, 2, false, 12, 2, 3, false>(p, "k32 128x128 4w(64x64) ks2 2x32K epi gelu");
+      run32<4, 2, 2, 2, 2, false, 12, 3, 3, false>(p, "k32 256x128 8w(64x64) ks2 3x48K epi gelu");
+      release(p); }
+    { Problem p = make(1024, 1536, 3072, 330);
+      printf("c3 dec fc2 1024x(2x768)x3072 (%d weight copies)\n", p.ncopy);
+      run16<2, 2, 2, 48, 3, 1>(p, "k16 128x64 4w(64x32) 3x24K epi bias");
+      run16<2, 2, 2, 48, 4, 1>(p, "k16 128x64 4w(64x32) 4x24K epi bias");
+      run16<2, 2, 2, 48, 2, 1>(p, "k16 128x64 4w(64x32) 2x24K epi bias");
+      run16<2, 2, 4, 48, 2, 1>(p, "k16 128x128 4w(64x64) 2x32K epi bias");
+      run32<2, 2, 2, 1, 2, false, 48, 3, 1, false>(p, "k32 128x64 4w(64x32) ks2 3x24K epi bias");
+      release(p); }
+    { Problem p = make(1024, 4096, 1024, 330);
+      printf("c3 enc fc1 1024x4096x1024 (%d weight copies)\n", p.ncopy);
+      run16<2, 2, 4, 16, 3, 2>(p, "k16 128x128 4w(64x64) 3x32K epi gelu");
+      run16<2, 2, 4, 16, 2, 2>(p, "k16 128x128 4w(64x64) 2x32K epi gelu");
+      run16<4, 2, 4, 16, 3, 2>(p, "k16 256x128 8w(64x64) 3x48K epi gelu");
+      run32<2, 2, 2, 2, 2, false, 16, 2, 3, false>(p, "k32 128x128 4w(64x64) ks2 2x32K epi gelu");
+      release(p); }
   }
   if (want("big")) {
     Problem p = make(4096, 4096, 4096, 330);
