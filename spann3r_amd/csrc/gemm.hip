@@ -1809,7 +1809,7 @@ static int gemm_prepare(sp3_gemm_desc& d, int& tile_out) {
     SP3_CHECK(d.sm_stats && d.sm_nt == (d.K + 31) / 32 && d.lda % 4 == 0 && d.lda >= (d.K + 15) / 16 * 16 && d.K % 4 == 0,
               "sp3_gemm: softmax loader needs sm_stats[M][ceil(K/32)][2], K %% 4 == 0 and score rows padded to 16 (lda=%lld K=%d)",
               (long long)d.lda, d.K);
-    SP3_CHECK(d.tile <= 1, "sp3_gemm: the softmax loader runs on the 16x64 tile (tile <= 0) or the 32x32 one (tile 1)");
+    SP3_CHECK(d.tile <= 1 || d.tile == 44, "sp3_gemm: the softmax loader runs on the 16x64 tile (tile <= 0), the 32x32 one (tile 1) or the lean instance (44)");
   } else if (d.loader == SP3_LOAD_CONV3X3) {
     SP3_CHECK(d.conv_C % 16 == 0, "sp3_gemm: conv Cin=%d must be a multiple of 16", d.conv_C);
     SP3_CHECK(d.K == 9 * d.conv_C, "sp3_gemm: conv K=%d != 9*Cin", d.K);

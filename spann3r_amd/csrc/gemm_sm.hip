@@ -16,6 +16,8 @@
 //       SM_PACKED  bias (+ folded LayerNorm) (+ GELU) -> fragment-order bf16           (fc1, key MLP hidden)
 //       SM_STREAM  bias (+ folded LayerNorm) (+ residual) -> fp32 rows (+ per-32-column statistics + packed bf16 copy)
 //       SM_ROPE    folded LayerNorm + bias + 2-D RoPE -> fragment-order q / k, V in PV-operand order  (q/k/v projections)
+//       SM_SCORE   alpha x, folded LayerNorm, bias -> fp32 rows with ANY N (a multiple of 4: the bank grows by a frame per step) + the
+//                  (max, sum exp) of every 32-column group: the score GEMM of the spatial-memory read (spann3r/model.py:159-166)
 // Operands: A and W bf16 in fragment order (include/spann3r_hip.h a_packed / w_packed), fp32 accumulation.  Same arithmetic per
 // output element as gemm_kernel up to the summation order over K (WK partial sums instead of 4).
 #include "common.h"
@@ -25,7 +27,7 @@
 
 namespace {
 
-enum { SM_PACKED = 0, SM_STREAM = 1, SM_ROPE = 2 };
+enum { SM_PACKED = 0, SM_STREAM = 1, SM_ROPE = 2, SM_SCORE = 3 };
 
 struct SmOp {
   const char* A; const char* A2; const char* W; char* C;     // A2: second fragment-order source for k-blocks >= nkb1 (split A), else = A
@@ -34,6 +36,7 @@ struct SmOp {
   long gA, gA2, gW, gC, gbias, gres, gstats, gs, gso, gc2, gvt;      // byte strides per group (problem) of a grouped launch
   int N, ntz, ldc, rope_cols, act, nkb1;
   int nt;                           // N-tiles per problem (bm_kernel's M-major tile map)
+  float alpha;                      // SM_SCORE: scale of the accumulator (the other epilogues serve alpha = 1 only)
 };
 
 struct SmArgs {
@@ -82,12 +85,14 @@ __global__ __launch_bounds__(64 * WK) void sm_kernel(const SmArgs a) {
   const float* lnst = OPF(ln_stats);
   const bool ln = lnst != nullptr;
   const float* biasp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(OPF(bias)) + grp * OPF(gbias));
-  const float4 b4 = *reinterpret_cast<const float4*>(biasp + n0 + ec4);
+  // (SM_SCORE: N is any multiple of 4 -- column groups past it re-read the last one, masked at the store)
+  const int ecl = EPI == SM_SCORE ? ((n0 + ec4 < N - 4) ? n0 + ec4 : N - 4) : n0 + ec4;
+  const float4 b4 = *reinterpret_cast<const float4*>(biasp + ecl);
   float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 lp[NL4];
   if constexpr (LNOK) {
     if (ln) {
-      s4 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(OPF(ln_s)) + grp * OPF(gs)) + n0 + ec4);
+      s4 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(OPF(ln_s)) + grp * OPF(gs)) + ecl);
       const int srow = tid >> 2, sj = tid & 3;
       if (srow < BM) {
         int gm = m0 + srow;
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(64 * WK) void sm_kernel(const SmArgs a) {
       ap[m] = A + ((long)rb * nkb1 + wk) * 2048 + lane * 16;
       if constexpr (SPLIT) ap2[m] = OPF(A2) + grp * OPF(gA2) + ((long)rb * (NKB - nkb1) + wk - nkb1) * 2048 + lane * 16;
     }
-    const int nb_max = (N >> 4) - 1;
+    const int nb_max = ((N + 15) >> 4) - 1;                   // (the last 16-row block of W may be partial: zero rows in the packed layout)
 #pragma unroll
     for (int n = 0; n < NF; ++n) {
       int nb = tile_n * NF + n;
@@ -228,6 +233,10 @@ __global__ __launch_bounds__(64 * WK) void sm_kernel(const SmArgs a) {
       t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
     }
     v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    if constexpr (EPI == SM_SCORE) {
+      const float al = OPF(alpha);
+      v[0] *= al; v[1] *= al; v[2] *= al; v[3] *= al;
+    }
     if (LNOK && ln) {
       const float mean = rowstat[2 * row], rstd = rowstat[2 * row + 1], rm = rstd * mean;
       v[0] = rstd * v[0] - rm * ss.x; v[1] = rstd * v[1] - rm * ss.y;
@@ -309,6 +318,31 @@ __global__ __launch_bounds__(64 * WK) void sm_kernel(const SmArgs a) {
       bf16x4 ob;
       ob[0] = (__bf16)v[0]; ob[1] = (__bf16)v[1]; ob[2] = (__bf16)v[2]; ob[3] = (__bf16)v[3];
       st_out(reinterpret_cast<bf16x4*>(out + packed_off(gm, gn, N, true)), ob);
+    }
+  } else if constexpr (EPI == SM_SCORE) {
+    // scores of the memory read: fp32 rows, and per row and 32-column group (max, sum exp(x - max)) over the columns < N --
+    // the softmax statistics leave with the scores (the P.V launch merges the groups; no pass over the score matrix)
+    static_assert(BN == 32, "one statistics group per tile row");
+    float* out = reinterpret_cast<float*>(OPF(C));
+    float2* so = reinterpret_cast<float2*>(OPF(stats_out));
+    const int ldc = OPF(ldc), ng = (N + 31) >> 5;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int row = row_e0 + it * (NT / CG), gm = m0 + row, gn = n0 + ec4;
+      if (row >= BM || gm >= a.M) continue;                   // (the 8 lanes of a group share the row)
+      float v[4];
+      finish4(row, ec4, b4, s4, v);
+      const int nvalid = N - gn;                              // >= 4, or <= 0 (N % 4 == 0)
+      float mx = -INFINITY;
+      if (nvalid > 0) mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+#pragma unroll
+      for (int o_ = 1; o_ < 8; o_ <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o_));
+      float se = 0.f;
+      if (nvalid > 0) se = (__expf(v[0] - mx) + __expf(v[1] - mx)) + (__expf(v[2] - mx) + __expf(v[3] - mx));
+#pragma unroll
+      for (int o_ = 1; o_ < 8; o_ <<= 1) se += __shfl_xor(se, o_);
+      if (((gn >> 2) & 7) == 0) so[(long)gm * ng + (gn >> 5)] = make_float2(mx, se);
+      if (nvalid > 0) *reinterpret_cast<float4*>(out + (long)gm * ldc + gn) = make_float4(v[0], v[1], v[2], v[3]);
     }
   } else {
     float* out = reinterpret_cast<float*>(OPF(C) + grp * OPF(gC));
@@ -725,6 +759,216 @@ int bm_launch(const SmArgs& a, int mt, int nz, hipStream_t stream) {
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ memory read, second launch
+// out = softmax_thresh(S) . V_hat + q of the spatial-memory read (spann3r/model.py:159-183) for short banks (every per-frame read of
+// the 224 x 224 demo): A is the fp32 score matrix the SCORE instance above left, W = V_hat^T in fragment order with K = bank tokens --
+// a RUN-TIME k-block count.  Same shell as sm_kernel (3-D grid, K over all waves, every load of a wave's first R k-blocks requested
+// up front, one LDS reduction); per workgroup 16 query rows x 64 output columns:
+//   * the (max, sum exp) partials of the rows' 32-key groups (<= 8 per thread, 32 threads per row) are merged to (m, Z) while the
+//     first operand loads fly;
+//   * a lane turns the 8 fp32 scores behind its MFMA operand into p = exp2(s log2e - m log2e - log2 Z), drops p < thresh and keys
+//     past the bank's end, adds the kept mass (the renormalisation of model.py:170-172) -- no probability matrix in memory;
+//   * epilogue: sum of the WK partial tiles / kept mass + q -> fp32 rows (+ fragment-order bf16 copy), (kept mass, m, 1/Z) per row
+//     for the column sums that follow (sp3_colsum_softmax).
+struct PvArgs {
+  const float* S; const float2* stats; const char* W; float* out; const float* res; char* c2; float* zout;
+  int M, Mk, N, ld, ng, nkbw, ldc, ldr;
+  float thr;
+};
+
+template <int NF, int WK, int R>
+__global__ __launch_bounds__(64 * WK) void pv_kernel(const PvArgs a) {
+  constexpr int BM = 16, BN = NF * 16, NT = 64 * WK, LD = BN + 4, TPR = NT / BM;    // TPR threads merge one row's statistics
+  constexpr float L2E = 1.44269504088896341f;
+  static_assert(TPR == 32 || TPR == 64, "statistics merge: 32 or 64 threads per row");
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [WK][BM][LD] partial tiles (kept mass in column BN), then crow[BM][4]
+  float* crow = smem + (size_t)WK * BM * LD;
+  const int tid = threadIdx.x, lane = tid & 63, wk = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, r16 = lane & 15;
+  const int tile_m = blockIdx.y, tile_n = blockIdx.z * 8 + blockIdx.x;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  if (n0 >= a.N) return;
+  const int nkb = (a.Mk + 63) >> 6;
+  const int nkw = wk < nkb ? (nkb - wk + WK - 1) / WK : 0;       // k-blocks of this wave: wk, wk + WK, ...
+  // ---- operand loads of the first R k-blocks
+  int row = m0 + r16;
+  row = row < a.M ? row : a.M - 1;
+  const float* srow = a.S + (long)row * a.ld + g * 16;
+  const char* wp[NF];
+#pragma unroll
+  for (int n = 0; n < NF; ++n) wp[n] = a.W + ((long)((n0 >> 4) + n) * a.nkbw) * 2048 + lane * 16;
+  float4 sv[R][2][2];
+  bf16x8 wv[R][NF][2];
+  auto load = [&](int slot, int kb) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      sv[slot][h][0] = *reinterpret_cast<const float4*>(srow + kb * 64 + h * 8);
+      sv[slot][h][1] = *reinterpret_cast<const float4*>(srow + kb * 64 + h * 8 + 4);
+    }
+#pragma unroll
+    for (int n = 0; n < NF; ++n) {
+      wv[slot][n][0] = *reinterpret_cast<const bf16x8*>(wp[n] + (long)kb * 2048);
+      wv[slot][n][1] = *reinterpret_cast<const bf16x8*>(wp[n] + (long)kb * 2048 + 1024);
+    }
+  };
+  // ---- the 32-key groups' (max, sum exp) of this thread's row FIRST: the merge below then waits for these (older) loads only,
+  // not for the operand loads behind them
+  const int rowi = tid / TPR, st_t = tid % TPR;
+  float2 stv[8];
+  {
+    int gm = m0 + rowi;
+    gm = gm < a.M ? gm : a.M - 1;
+    const float2* st = a.stats + (long)gm * a.ng;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int j = st_t + q * TPR;
+      stv[q] = j < a.ng ? st[j] : make_float2(-INFINITY, 0.f);
+    }
+  }
+#pragma unroll
+  for (int s_ = 0; s_ < R; ++s_)
+    if (s_ < nkw) load(s_, wk + s_ * WK);
+  // epilogue operand: the residual (q) quad of this thread
+  constexpr int CG = BN / 4;
+  const int erow = tid / CG, ec4 = (tid % CG) * 4;
+  float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (tid < BM * CG && a.res) {
+    int gm = m0 + erow;
+    gm = gm < a.M ? gm : a.M - 1;
+    r4 = *reinterpret_cast<const float4*>(a.res + (long)gm * a.ldr + n0 + ec4);
+  }
+  // ---- (m, Z) of the rows
+  {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) mx = fmaxf(mx, stv[q].x);
+#pragma unroll
+    for (int o_ = 1; o_ < TPR; o_ <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o_));
+    float z = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) z += stv[q].y * __expf(stv[q].x - mx);          // (empty groups: 0 * exp(-inf) = 0)
+#pragma unroll
+    for (int o_ = 1; o_ < TPR; o_ <<= 1) z += __shfl_xor(z, o_);
+    if (st_t == 0) {
+      crow[4 * rowi] = -mx * L2E - __log2f(z);
+      crow[4 * rowi + 1] = mx;
+      crow[4 * rowi + 2] = 1.0f / z;
+    }
+  }
+  __syncthreads();
+  const float c = crow[4 * r16];
+  // ---- K loop
+  f32x4 acc[NF];
+#pragma unroll
+  for (int n = 0; n < NF; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float zk = 0.f;
+  for (int i0 = 0; i0 < nkw; i0 += R) {
+#pragma unroll
+    for (int s_ = 0; s_ < R; ++s_) {
+      const int i = i0 + s_;
+      if (i < nkw) {
+        const int kb = wk + i * WK;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int left = a.Mk - (kb * 64 + g * 16 + h * 8);
+          float p[8];
+          const float4 s0 = sv[s_][h][0], s1 = sv[s_][h][1];
+          const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float q = __builtin_amdgcn_exp2f(fmaf(sc[e], L2E, c));
+            p[e] = (q < a.thr || e >= left) ? 0.f : q;
+            zk += p[e];
+          }
+          const bf16x8 af = cvt8(make_float4(p[0], p[1], p[2], p[3]), make_float4(p[4], p[5], p[6], p[7]));
+#pragma unroll
+          for (int n = 0; n < NF; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, wv[s_][n][h], acc[n], 0, 0, 0);
+        }
+        if (i + R < nkw) load(s_, kb + R * WK);
+      }
+    }
+  }
+  // ---- partial tiles and kept mass -> LDS (C layout: col = lane & 15, row = 4 (lane >> 4) + reg)
+  {
+    float* slab = smem + (size_t)wk * BM * LD;
+#pragma unroll
+    for (int n = 0; n < NF; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) slab[(4 * g + r) * LD + n * 16 + r16] = acc[n][r];
+    zk += __shfl_xor(zk, 16);
+    zk += __shfl_xor(zk, 32);
+    if (g == 0) slab[r16 * LD + BN] = zk;
+  }
+  __syncthreads();
+  if (tid < BM * CG) {
+    const int gm = m0 + erow, gn = n0 + ec4;
+    if (gm < a.M) {
+      float4 t = *reinterpret_cast<const float4*>(smem + erow * LD + ec4);
+      float zs = smem[erow * LD + BN];
+#pragma unroll
+      for (int s_ = 1; s_ < WK; ++s_) {
+        const float4 u = *reinterpret_cast<const float4*>(smem + (size_t)s_ * BM * LD + erow * LD + ec4);
+        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+        zs += smem[(size_t)s_ * BM * LD + erow * LD + BN];
+      }
+      const float izs = 1.0f / zs;
+      const float4 o = make_float4(t.x * izs + r4.x, t.y * izs + r4.y, t.z * izs + r4.z, t.w * izs + r4.w);
+      st_out(reinterpret_cast<float4*>(a.out + (long)gm * a.ldc + gn), o);
+      if (a.c2) {
+        bf16x4 ob;
+        ob[0] = (__bf16)o.x; ob[1] = (__bf16)o.y; ob[2] = (__bf16)o.z; ob[3] = (__bf16)o.w;
+        st_out(reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(a.c2) + packed_off(gm, gn, a.N, true)), ob);
+      }
+      if (a.zout && gn == 0) *reinterpret_cast<float4*>(a.zout + 4 * (long)gm) = make_float4(zs, crow[4 * erow + 1], crow[4 * erow + 2], 0.f);
+    }
+  }
+}
+
+// loader SOFTMAX descriptors this kernel serves (tile 44); anything else stays on the general tiles
+bool pv_ok(const sp3_gemm_desc& d) {
+  return d.loader == SP3_LOAD_SOFTMAX && d.wdtype == SP3_BF16 && d.w_packed && !d.a_bf16 && !d.a_packed && d.sm_stats && d.epi == SP3_EPI_PLAIN &&
+         !d.out_bf16 && !d.out_packed && !d.bias && !d.res2 && d.act == SP3_ACT_NONE && d.alpha == 1.0f && d.batch <= 1 && d.splitk <= 1 &&
+         !d.ln_stats && !d.stats_out && !d.trace && !d.sm_stats_out && !d.A2 && d.N % 64 == 0 && d.K % 4 == 0 && d.K >= 4 &&
+         d.sm_nt == (d.K + 31) / 32 && d.sm_nt <= 8 * 32 && d.M >= 1 && d.M < 65536 * 16 && d.ldw % 64 == 0 && d.ldw >= d.K && (d.lda & 3) == 0 &&
+         d.lda >= ((d.K + 63) & ~63) && (d.ldc & 3) == 0 && d.ldc >= d.N && (!d.res1 || (d.ldr1 & 3) == 0) && (!d.c2 || d.N % 64 == 0);
+}
+
+template <int NF, int WK, int R>
+int pv_launch(const PvArgs& a, int M, int N, hipStream_t stream) {
+  constexpr size_t lds = ((size_t)WK * 16 * (NF * 16 + 4) + 16 * 4) * sizeof(float);
+  static_assert(lds <= 160 * 1024, "partial tiles must fit the LDS");
+  auto kern = pv_kernel<NF, WK, R>;
+  if (lds > 64 * 1024) {
+    static bool raised = false;
+    if (!raised) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) { sp3_set_error("sp3_gemm (lean, softmax P.V): cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e)); return 2; }
+      raised = true;
+    }
+  }
+  const int nt = N / (NF * 16);
+  hipLaunchKernelGGL(kern, dim3(8, (M + 15) / 16, (nt + 7) / 8), dim3(64 * WK), lds, stream, a);
+  SP3_LAUNCH_CHECK("sp3_gemm (lean, softmax P.V)");
+  return 0;
+}
+
+int pv_dispatch(const sp3_gemm_desc& d, hipStream_t stream) {
+  PvArgs a;
+  a.S = reinterpret_cast<const float*>(d.A); a.stats = reinterpret_cast<const float2*>(d.sm_stats); a.W = reinterpret_cast<const char*>(d.W);
+  a.out = reinterpret_cast<float*>(d.C); a.res = d.res1; a.c2 = reinterpret_cast<char*>(d.c2); a.zout = d.sm_zout;
+  a.M = d.M; a.Mk = d.K; a.N = d.N; a.ld = (int)d.lda; a.ng = d.sm_nt; a.nkbw = (int)(d.ldw / 64); a.ldc = (int)d.ldc; a.ldr = (int)d.ldr1;
+  a.thr = d.sm_thresh;
+  static const int variant = [] { const char* e = getenv("SP3_PV_VARIANT"); return e ? atoi(e) : 0; }();    // (tile / wave-count A/B: tools/bench_memread.py)
+  switch (variant) {
+    case 1: return pv_launch<4, 16, 2>(a, d.M, d.N, stream);
+    case 2: return pv_launch<2, 8, 4>(a, d.M, d.N, stream);
+    case 3: return pv_launch<2, 16, 2>(a, d.M, d.N, stream);
+    case 4: return pv_launch<4, 8, 3>(a, d.M, d.N, stream);
+    case 5: return pv_launch<4, 8, 4>(a, d.M, d.N, stream);
+    default: return pv_launch<4, 8, 2>(a, d.M, d.N, stream);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ small-map 3x3 convolutions
 // The DPT heads' 3x3 convolutions on maps of <= 1024 pixels (croco/models/dpt_block.py:33-75,95-113: layer_rn, the
 // ResidualConvUnits of refinenet 2-4, act_postprocess[3] at 7x7 .. 28x28 of a 224x224 frame): M = pixels is tiny, K = 9 Cin is
@@ -1003,6 +1247,8 @@ const SmInst kInst[] = {
     {36, SM_STREAM, 768, 3, 2, 6, false, 0, 1 << 30, sm_launch<3, 2, 6, 12, 0, SM_STREAM>},   // dec proj / cproj x2, pos patch embed: 48x32 k6
     {37, SM_STREAM, 3072, 3, 2, 8, false, 0, 1 << 30, sm_launch<3, 2, 8, 48, 3, SM_STREAM>},  // dec fc2 x2: 48x32 k8, ring of 3
     {38, SM_STREAM, 1792, 4, 2, 7, false, 0, 1 << 30, sm_launch<4, 2, 7, 28, 0, SM_STREAM>},  // key MLP out x2: 64x32 k7
+    // SCORE (the memory read's S = LN_q(q) . K_hat^T / 32 with the softmax statistics of its 32-key groups; N = bank tokens, any multiple of 4)
+    {43, SM_SCORE, 1024, 2, 2, 8, false, 0, 1 << 30, sm_launch<2, 2, 8, 16, 0, SM_SCORE>},
     // ---- many rows (bm_kernel<WM, WN, NF, NKB, NST, EPI>): 256x128 (8 waves) from 1536 rows on, else 128x128 / 128x64 (4 waves)
     {50, SM_ROPE, 1024, 4, 4, 1, false, 0, 1 << 30, bm_launch<4, 2, 4, 16, 3, SM_ROPE>, 1536, 1 << 30, 256, 128},     // encoder q/k/v (M = frames x 196)
     {51, SM_ROPE, 1024, 4, 4, 1, false, 0, 1 << 30, bm_launch<2, 2, 4, 16, 3, SM_ROPE>, 257, 1535, 128, 128},
@@ -1029,6 +1275,7 @@ bool sm_enabled() {
 }
 
 int sm_kind(const sp3_gemm_desc& d) {
+  if (d.sm_stats_out) return SM_SCORE;
   if (d.epi == SP3_EPI_ROPE_VT) return SM_ROPE;
   if (d.out_packed) return SM_PACKED;
   return SM_STREAM;
@@ -1037,13 +1284,18 @@ int sm_kind(const sp3_gemm_desc& d) {
 const SmInst* sm_find(const sp3_gemm_desc& d) {
   if (!sm_enabled()) return nullptr;
   if (d.wdtype != SP3_BF16 || !d.a_bf16 || !d.a_packed || !d.w_packed || d.loader != SP3_LOAD_PLAIN || d.res2 || d.relu_in ||
-      d.trace || d.sm_stats_out || d.sm_stats || d.alpha != 1.0f || d.f32x3)
+      d.trace || d.sm_stats || (d.alpha != 1.0f && !d.sm_stats_out) || d.f32x3)
     return nullptr;
   if (d.splitk > 1 || d.epi == SP3_EPI_PARTIAL || d.epi == SP3_EPI_PIXSHUF) return nullptr;
   static const bool big_on = [] { const char* e = getenv("SP3_LEAN_BIG"); return !(e && e[0] == '0'); }();
   if (d.batch > 2 || d.M < 1 || d.M >= 65536 || (d.M > 256 && !big_on) || (d.ldw > 0 && d.ldw != d.K) || !d.bias) return nullptr;
   const int kind = sm_kind(d);
-  if (kind == SM_ROPE) {
+  if (kind == SM_SCORE) {
+    // (sp3_gemm's own checks: plain fp32 epilogue, N % 4 == 0, one problem)
+    if (d.epi != SP3_EPI_PLAIN || d.out_bf16 || d.out_packed || d.batch > 1 || d.res1 || d.stats_out || d.c2 || d.act != SP3_ACT_NONE ||
+        d.N % 4 || d.N < 4 || (d.ldc & 3) || d.ldc < d.N || d.M > 256)
+      return nullptr;
+  } else if (kind == SM_ROPE) {
     if (!d.qkv_packed || d.rope_cols % 64 || d.N % 64 || (d.tokens & 3) || d.tokens <= 0 || d.tokens >= 65536 || d.vt_ld % 64) return nullptr;
     if (d.rope_cols < d.N && !d.vt) return nullptr;
   } else if (kind == SM_PACKED) {
@@ -1060,7 +1312,7 @@ const SmInst* sm_find(const sp3_gemm_desc& d) {
     if (s.epi != kind || s.K != d.K || s.split != split || d.M < s.min_m || d.M > s.max_m) continue;
     const long mb = (long)d.M * (d.batch > 1 ? d.batch : 1);
     if (mb < s.min_mb || mb > s.max_mb) continue;
-    if (d.N % s.tile_n() || d.N < s.min_n || d.N > s.max_n) continue;
+    if ((kind != SM_SCORE && d.N % s.tile_n()) || d.N < s.min_n || d.N > s.max_n) continue;
     if (!s.bm && d.ln_stats && s.MF * 16 * 4 > 64 * s.WK) continue;
     if (s.bm && kind == SM_ROPE && d.rope_cols % 32) continue;
     return &s;
@@ -1083,7 +1335,9 @@ void sm_fill(SmOp& o, const sp3_gemm_desc& d, const SmInst& s) {
   o.gbias = G * d.sb_bias; o.gres = G * (long)d.M * d.ldr1 * 4; o.gstats = G * d.sb_ln_stats; o.gs = G * d.sb_ln_s;
   o.gso = G * d.sb_stats_out; o.gc2 = G * d.sb_c2; o.gvt = G * d.sb_vt;
   o.N = d.N;
-  o.nt = d.N / s.tile_n();
+  o.alpha = d.alpha;
+  if (s.epi == SM_SCORE) o.stats_out = d.sm_stats_out;
+  o.nt = (d.N + s.tile_n() - 1) / s.tile_n();
   o.ntz = (o.nt + 7) / 8;
   o.ldc = (int)d.ldc;
   o.rope_cols = d.rope_cols;
@@ -1094,17 +1348,25 @@ void sm_fill(SmOp& o, const sp3_gemm_desc& d, const SmInst& s) {
 
 int sp3_gemm_sm_tile(const sp3_gemm_desc& d) {
   if (d.loader == SP3_LOAD_CONV3X3) return sm_enabled() ? conv_sm_tile(d) : -1;
+  if (d.loader == SP3_LOAD_SOFTMAX) return (sm_enabled() && pv_ok(d)) ? 44 : -1;
   const SmInst* s = sm_find(d);
   return s ? s->tile : -1;
 }
 
 bool sp3_gemm_sm_pairs(const sp3_gemm_desc& d) {
-  if (d.loader == SP3_LOAD_CONV3X3) return false;
+  if (d.loader != SP3_LOAD_PLAIN) return false;
   const SmInst* s = sm_find(d);
   return s && s->epi == SM_ROPE;
 }
 
 int sp3_gemm_sm_launch(const sp3_gemm_desc& d, const sp3_gemm_desc* pair, hipStream_t stream) {
+  if (d.loader == SP3_LOAD_SOFTMAX) {
+    if (!sm_enabled() || !pv_ok(d) || pair || (d.tile >= 30 && d.tile != 44)) {
+      sp3_set_error("sp3_gemm: no lean softmax-loader instance for this descriptor (tile %d, M=%d N=%d K=%d)", d.tile, d.M, d.N, d.K);
+      return 1;
+    }
+    return pv_dispatch(d, stream);
+  }
   if (d.loader == SP3_LOAD_CONV3X3) {
     const int t = sm_enabled() ? conv_sm_tile(d) : -1;
     if (t < 0 || pair || (d.tile >= 30 && d.tile != t)) {

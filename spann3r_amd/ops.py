@@ -109,7 +109,7 @@ _TILE_NAMES = {0: "32x32xk4", 1: "64x64", 2: "64x128", 3: "64x64xk4", 4: "32x64x
                30: "lean-rope-k1024-48x64xk8", 31: "lean-rope-k768-32x32xk4", 32: "lean-packed-k1024-64x64xk8", 33: "lean-packed-k768-32x32xk4",
                34: "lean-stream-k1024-32x32xk8", 35: "lean-stream-k4096-32x32xk8r4", 36: "lean-stream-k768-48x32xk6",
                37: "lean-stream-k3072-48x32xk8", 38: "lean-stream-k1792-64x32xk7",
-               39: "lean-stream-k1024-48x32xk8", 40: "lean-conv-16x16xk12", 41: "lean-conv-32x32xk8", 42: "lean-packed-splitA-k1792-64x32xk7",
+               39: "lean-stream-k1024-48x32xk8", 40: "lean-conv-16x16xk12", 41: "lean-conv-32x32xk8", 42: "lean-packed-splitA-k1792-64x32xk7", 43: "lean-score-k1024-32x32xk8", 44: "lean-softmax-pv-16x64xk8",
                # many-row lean instances (bm_kernel: LDS-staged operands, epilogue in registers)
                50: "lean-rope-k1024-256x128", 51: "lean-rope-k1024-128x128", 52: "lean-rope-k768-128x128", 53: "lean-packed-k1024-256x128",
                54: "lean-packed-k1024-128x128", 55: "lean-packed-k768-128x128", 56: "lean-stream-k1024-128x64", 57: "lean-stream-k4096-128x64",
@@ -227,7 +227,11 @@ def _gemm_launch(d, what, loader_name):
         _pair.append((d, loader_name))
         return
     if d.loader == L.LOAD_SOFTMAX:
-        d.tile = 1 if d.tile == 1 else 0
+        if d.tile < 0:
+            t = L.load().sp3_gemm_plan(C.byref(d))          # 44: the lean P.V instance of the memory read
+            d.tile = t if t >= 30 else 0
+        elif d.tile < 30:
+            d.tile = 1 if d.tile == 1 else 0
     if d.tile < 0:
         _pick(d)
     if _prof is None:
@@ -242,7 +246,7 @@ def _gemm_launch(d, what, loader_name):
     a_elems = d.M * d.K if d.loader != L.LOAD_CONV3X3 else d.M * d.conv_stride * d.conv_stride * d.conv_C   # conv: the map, once
     nbytes = b * (asz * a_elems + wsz * d.N * d.K + csz * d.M * d.N)      # algorithmic: every operand once
     adt = "bf16" if d.a_bf16 else "f32"
-    tname = ("16x64xk4" if d.tile == 0 else "32x32xk4") if d.loader == L.LOAD_SOFTMAX else _TILE_NAMES[d.tile]
+    tname = ("16x64xk4" if d.tile == 0 else "32x32xk4") if (d.loader == L.LOAD_SOFTMAX and d.tile < 30) else _TILE_NAMES[d.tile]
     _prof.end("gemm<A%s,W%s,%s,%s>" % (adt, "f32" if d.wdtype == F32 else "bf16", loader_name, tname),
               e0, flops, nbytes)
 
