@@ -1256,7 +1256,8 @@ const SmInst kInst[] = {
     // are 480 workgroups of 96 KB LDS -- two rounds at one workgroup per CU; 256 x 128 makes it one (profiles/r05_gemm_manyrow_config3_tiles.txt:
     // 20.3 -> 14.4 us for the q/k/v half, fc1 24.3 -> 19.2).  The rule looks at rows x groups only, so both groups of a pair agree.
     {52, SM_ROPE, 768, 4, 4, 1, false, 0, 1 << 30, bm_launch<2, 2, 4, 12, 3, SM_ROPE>, 257, 1 << 30, 128, 128, 0, 2047},
-    {63, SM_ROPE, 768, 4, 4, 1, false, 0, 1 << 30, bm_launch<4, 2, 4, 12, 3, SM_ROPE>, 257, 1 << 30, 256, 128, 2048, 1 << 30},   // decoder q/k/v + cross k/v at 512x512
+    {63, SM_ROPE, 768, 4, 4, 1, false, 1536, 1 << 30, bm_launch<4, 2, 4, 12, 3, SM_ROPE>, 257, 1 << 30, 256, 128, 2048, 1 << 30},   // decoder q/k/v + cross k/v at 512x512 (N = 2304 / 1536)
+    {65, SM_ROPE, 768, 4, 2, 1, false, 0, 1535, bm_launch<2, 2, 2, 12, 3, SM_ROPE>, 257, 1 << 30, 128, 64, 2048, 1 << 30},         // its cross-attention q projection (N = 768: 192 workgroups instead of 48)
     {53, SM_PACKED, 1024, 4, 4, 1, false, 0, 1 << 30, bm_launch<4, 2, 4, 16, 3, SM_PACKED>, 1536, 1 << 30, 256, 128},  // encoder fc1
     {54, SM_PACKED, 1024, 4, 4, 1, false, 0, 1 << 30, bm_launch<2, 2, 4, 16, 3, SM_PACKED>, 257, 1535, 128, 128},
     {55, SM_PACKED, 768, 4, 4, 1, false, 0, 1 << 30, bm_launch<2, 2, 4, 12, 3, SM_PACKED>, 257, 1 << 30, 128, 128, 0, 2047},

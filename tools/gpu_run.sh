@@ -32,7 +32,7 @@ for stage in "$@"; do
                   n=$(echo $C | cut -d" " -f1); (cd /tmp && timeout 300 rocprofv3 --pmc $C -d "$OLDPWD/$OUT/pmc_$n" -o run --output-format csv -- python "$OLDPWD/tools/bench_gemm2.py" --big --only "enc16 fc2,enc fc1" --tiles 20,5 > "$OLDPWD/$OUT/pmc_$n.log" 2>&1); F=$(find "$OUT/pmc_$n" -name "*counter_collection.csv" | head -1); python tools/pmc_csv.py "$F" > "$OUT/pmc_$n.txt" 2>&1; rm -rf "$OUT/pmc_$n"; cat "$OUT/pmc_$n.txt"; done ;;
     pmcattn)    # SQ / LDS / TA counters of the packed attention at long sequences (product kernel, QB variants, v2): what the launch waits for
                 for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS" "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "TA_BUSY_avr TA_TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum TCC_HIT_sum TCC_MISS_sum" ; do
-                  n=$(echo $C | cut -d" " -f1); (cd /tmp && timeout 200 rocprofv3 --pmc $C -d "$OLDPWD/$OUT/pmca_$n" -o run --output-format csv -- "$OLDPWD/tools/ubench/attn_qb.bin" > "$OLDPWD/$OUT/pmca_$n.log" 2>&1); F=$(find "$OUT/pmca_$n" -name "*counter_collection.csv" | head -1); python tools/pmc_csv.py "$F" attention > "$OUT/pmca_$n.txt" 2>&1; rm -rf "$OUT/pmca_$n"; cat "$OUT/pmca_$n.txt" | cut -c1-220; done ;;
+                  n=$(echo $C | cut -d" " -f1); (cd /tmp && timeout 200 rocprofv3 --pmc $C -d "$OLDPWD/$OUT/pmca_$n" -o run --output-format csv -- "$OLDPWD/tools/ubench/attn_qb.bin" > "$OLDPWD/$OUT/pmca_$n.log" 2>&1); F=$(find "$OUT/pmca_$n" -name "*counter_collection.csv" | head -1); python tools/pmc_csv.py "$F" attention > "$OUT/pmca_$n.txt" 2>&1; cp "$F" "$OUT/pmca_$n.csv"; rm -rf "$OUT/pmca_$n"; cat "$OUT/pmca_$n.txt" | cut -c1-220; done ;;
     tracegemm)  for t in 20 22; do for a in gelu noact; do timeout 120 python tools/trace_gemm.py $t $a >> "$OUT/tracegemm.txt" 2>&1; done; done; cat "$OUT/tracegemm.txt" ;;
     bench)      timeout 900 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; head -c 1500 "$OUT/bench.json"; tail -3 "$OUT/bench.err" ;;
     benchfast)  timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > "$OUT/benchfast.json" 2> "$OUT/benchfast.err"; head -c 1200 "$OUT/benchfast.json"; tail -3 "$OUT/benchfast.err" ;;

@@ -8,7 +8,7 @@ from collections import defaultdict
 
 agg = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
 for r in csv.DictReader(open(sys.argv[1])):
-    k = re.sub(r"\(.*", "", r.get("Kernel_Name", "?"))[:90]
+    k = re.sub(r"\(.*", "", r.get("Kernel_Name", "?").replace("(anonymous namespace)::", "").replace("void ", ""))[:90]
     a = agg[(k, r.get("Grid_Size", ""))][r["Counter_Name"]]
     a[0] += float(r["Counter_Value"])
     a[1] += 1
