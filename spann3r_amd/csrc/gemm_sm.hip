@@ -1177,6 +1177,8 @@ int conv_sm_tile(const sp3_gemm_desc& d) {
   // the instances read res1 / res2 in the map dtype: a descriptor that says otherwise (fp32 residuals next to a bf16 map, the
   // contract the general tiles serve) is not theirs
   if ((d.res1 || d.res2) && (d.res_bf16 != 0) != (d.out_bf16 != 0)) return -1;
+  // the kernel divides by conv_C, OH * OW and OW with floor(2^32 / d) + 1 multiply-highs: d = 1 overflows the 32-bit magic
+  if (d.conv_OW < 2 || d.conv_OH * d.conv_OW < 2 || d.conv_C < 2) return -1;
   if (d.M <= 256) return d.N % 16 == 0 ? 40 : -1;
   return d.N % 32 == 0 ? 41 : -1;
 }

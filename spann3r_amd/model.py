@@ -334,11 +334,14 @@ class SpatialMemory:
     def copy_scores_in_graph(self):
         """The same copy as a node INSIDE the step's hipGraph (single-graph step): no event can be recorded in the middle of a
         replay, so the host learns that the copy has landed from the data itself -- arm_score_poll() fills the pinned buffer with
-        NaN before the launch, sim_verdict() spins until the wm valid scores (cosines: never NaN) have replaced them."""
+        a sentinel no cosine can take (2.0; a NaN sentinel could not tell "not landed" from a genuinely NaN score of degenerate
+        features) before the launch, sim_verdict() spins until the wm scores have replaced it."""
         self._host_scores().copy_(self._score, non_blocking=True)
 
+    _SENTINEL = 2.0                       # outside [-1, 1]: never a mean cosine (NaN scores pass through and compare False below)
+
     def arm_score_poll(self):
-        self._host_scores().fill_(float("nan"))
+        self._host_scores().fill_(self._SENTINEL)
         self._score_pending = "poll"
 
     def sim_verdict(self):
@@ -348,8 +351,8 @@ class SpatialMemory:
             self._score_pending = False
             view = self._score_host[:, :self.wm]
             t0 = time.perf_counter()
-            while bool(torch.isnan(view).any()):
-                if time.perf_counter() - t0 > 2.0:           # (never observed: fall back to a stream sync + plain copy)
+            while bool((view == self._SENTINEL).any()):
+                if time.perf_counter() - t0 > 0.25:          # (never observed: fall back to a stream sync + plain copy)
                     torch.cuda.current_stream().synchronize()
                     view = self._score[:, :self.wm].cpu()
                     break
@@ -826,6 +829,8 @@ class Spann3R(nn.Module):
         self.max_runners = 4         # geometries (batch, H, W, policy, true_shape) kept with their buffers and graphs
 
     # ------------------------------------------------------------------ engine management
+    f16x3_range_guard = True              # 'f16x3': raise if an activation left the fp16 range (non-finite outputs), see _forward_inference
+
     def set_precision(self, precision):
         """'fp32': fp32 operands, fp32 MFMA (exact fp32 products; the strictest parity mode).  'f32x3': fp32 operands, every
         GEMM product through three bf16 MFMAs of a (hi, lo) split (16 mantissa bits per product -- TF32, which the reference
@@ -1105,9 +1110,19 @@ class Spann3R(nn.Module):
         eng = self.engine
         self._pinned = eng
         try:                                 # (the engine fetch above set the product mode of the fp32 GEMMs from self.precision)
-            return self._forward(eng, frames, return_memory)
+            out = self._forward(eng, frames, return_memory)
         finally:
             self._pinned = None
+        if self.precision == "f16x3" and self.f16x3_range_guard:
+            # the fp16 planes of the f16x3 products hold |x| < 65504: a larger activation converts to inf and
+            # the products to NaN -- loud in the numbers, and made loud HERE: one device reduction over the last frame's outputs, read
+            # back once per sequence (the sequence has already synchronised on its similarity verdicts)
+            last = out[0][-1]
+            ok = torch.isfinite(last["conf"]).all() & torch.isfinite(next(v for k, v in last.items() if k.startswith("pts3d"))).all()
+            if not bool(ok):
+                raise FloatingPointError("f16x3: non-finite outputs -- an activation left the fp16 range (|x| >= 65504) of the split "
+                                         "products; run this checkpoint with set_precision('f32x6') or 'fp32'")
+        return out
 
     def _uniform_true_hw(self, frames):
         """(true_h, true_w) if every frame carries the same image shape and the same true_shape for the whole batch

@@ -563,21 +563,38 @@ def _run_sequence_fixture(name, full_sd, precision):
     err["mem_attn"] = rel_err(mem.mem_attn.cpu(), g["mem_attn"])
     # 99.9th percentile of the per-point relative error of the pointmaps (reported with the max-norm numbers, asserted with them)
     err["pts_pp999"] = float(torch.quantile(torch.cat(per_point)[::max(1, sum(map(len, per_point)) // 2000000)], 0.999))
+    err["pts_ppmax"] = float(torch.cat(per_point).max())          # worst single point (asserted for the fp32-grade modes)
     assert np.array_equal(mem.mem_count.cpu().numpy(), g["mem_count"])
     assert [mem.wm, mem.lm] == list(g["mem_wm_lm"])
     print("%s %s: %s" % (name, precision, {k: "%.2e" % v for k, v in err.items()}))
     return err
 
 
-def _bf16_bound(tag):
+def _bf16_bounds(tag, cap):
     """The bf16 tolerance is anchored on the REFERENCE under torch's bf16 autocast (tests/golden/reference_bf16_autocast.npz,
-    make_golden.py autocast): the bf16 mode here may be at most 1.5x as far from the fp32 reference as the reference's own bf16 run
-    (worst quantity vs worst quantity).  Without the fixture: the constant TOL_BF16."""
+    make_golden.py autocast), QUANTITY BY QUANTITY: each of pts / conf / pts2 / fuse / k / mem_attn may be at most 1.5x as far from
+    the fp32 reference as the reference's own bf16 run is on that quantity, and never beyond the absolute `cap` (a regression of
+    one quantity cannot hide behind the worst of the others).  A quantity whose anchor already exceeds the cap carries no
+    information (the stress fixture's mem_attn: the reference's own autocast run is off by 172 %) and is reported, not asserted.
+    Without the fixture: the cap for every quantity."""
     path = os.path.join(os.path.dirname(__file__), "golden", "reference_bf16_autocast.npz")
+    keys = ("pts", "conf", "pts2", "fuse", "k", "mem_attn")
     if not os.path.exists(path):
-        return TOL_BF16 if tag == "cfg2" else None
+        return {k: cap for k in keys}
     a = np.load(path)
-    return 1.5 * max(float(a[k]) for k in a.files if k.startswith(tag + "_"))
+    out = {}
+    for k in keys:
+        anchor = float(a["%s_%s" % (tag, k)])
+        if 1.5 * anchor <= cap:
+            out[k] = 1.5 * anchor
+        elif anchor <= cap:
+            out[k] = cap
+    return out
+
+
+def _assert_bf16(err, bounds):
+    bad = {k: (err[k], b) for k, b in bounds.items() if k in err and not err[k] < b}
+    assert not bad, (bad, err)
 
 
 @pytest.mark.parametrize("precision,tol", [("fp32", TOL_FP32), ("f32x3", TOL_FP32), ("f32x6", 2e-4), ("f16x3", 2e-4), ("bf16", TOL_BF16)])
@@ -586,9 +603,11 @@ def test_cfg2_224x10_vs_reference(full_sd, precision, tol):
     every view-2 result, every memory read (feat_fuse), the keys and the final mem_attn against the reference dump."""
     err = _run_sequence_fixture("spann3r_cfg2_224x10.npz", full_sd, precision)
     if precision == "bf16":
-        tol = _bf16_bound("cfg2")
-        err.pop("pts_pp999")        # per-point percentile: reported; the autocast anchor holds max-norm errors only (measured 4.4e-2)
+        _assert_bf16(err, _bf16_bounds("cfg2", TOL_BF16))     # (per-point percentile / max: reported; the anchor holds max-norm errors only)
+        return
+    ppmax = err.pop("pts_ppmax")
     assert max(err.values()) < tol, err
+    assert ppmax < 5 * tol, (ppmax, err)                      # the worst single point too (measured f16x3: 3.6e-5)
 
 
 @pytest.mark.parametrize("precision,tol", [("fp32", TOL_FP32), ("f32x3", TOL_FP32), ("bf16", TOL_BF16)])
@@ -596,8 +615,11 @@ def test_cfg3_512x13_vs_reference(full_sd, precision, tol):
     """BASELINE config 3: 512x512, growing bank (train policy, dropout off), 13 frames = 11 memory reads over up to
     11264 bank tokens, against the reference dump."""
     err = _run_sequence_fixture("spann3r_cfg3_512x13.npz", full_sd, precision)
+    ppmax = err.pop("pts_ppmax")
     if precision == "bf16":
         err.pop("pts_pp999")        # reported only (bf16: ~4e-2 per point at the 99.9th percentile)
+    else:
+        assert ppmax < 5 * tol, (ppmax, err)
     assert max(err.values()) < tol, err
 
 
@@ -610,8 +632,11 @@ def test_cfg3_512x50_vs_reference(full_sd, precision, tol):
     if not os.path.exists(os.path.join(os.path.dirname(__file__), "golden", "spann3r_cfg3_512x50.npz")):
         pytest.skip("fixture not generated (tests/golden/make_golden.py cfg3long)")
     err = _run_sequence_fixture("spann3r_cfg3_512x50.npz", full_sd, precision)
+    ppmax = err.pop("pts_ppmax")
     if precision == "bf16":
         err.pop("pts_pp999")        # reported only (bf16: ~4e-2 per point at the 99.9th percentile)
+    else:
+        assert ppmax < 5 * tol, (ppmax, err)
     assert max(err.values()) < tol, err
 
 
@@ -631,10 +656,13 @@ def test_stress_weights_224x6_vs_reference(precision, tol):
     from spann3r_amd.weights import stress_state_dict
     err = _run_sequence_fixture("spann3r_stress_224x6.npz", stress_state_dict(7, FULL), precision)
     if precision == "bf16":
-        tol = _bf16_bound("stress")             # the reference's own bf16 autocast run on these statistics (0.7 / 1.7): asserted when the fixture exists
-        err.pop("pts_pp999")
-    if tol is not None:
-        assert max(err.values()) < tol, err
+        # quantity by quantity against the reference's own autocast run, capped at 50 % (pts 0.71 / mem_attn 1.72 there: no information,
+        # reported only; conf, pts2, fuse, k: asserted)
+        _assert_bf16(err, _bf16_bounds("stress", 0.5))
+        return
+    ppmax = err.pop("pts_ppmax")
+    assert max(err.values()) < tol, err
+    assert ppmax < 5 * tol, (ppmax, err)                      # (measured f16x3: 2.0e-4)
 
 
 def test_stats_gather_through_rccl_world1():
