@@ -58,18 +58,54 @@ def aggregate(stats):
     return frames / seconds, frames, seconds
 
 
-def pair_graph(dust3r, frames, batch_size=2, scene_graph="complete"):
+def pair_indices(n, scene_graph="complete", prefilter=None, symmetrize=True):
+    """dust3r/image_pairs.py:11-46 make_pairs on indices: the (i, j) list for n images in the reference's order.
+    scene_graph: 'complete' | 'swin[-W]' (window W = 3 with loop closure) | 'oneref[-R]' (every image against image R) | 'prev'
+    (every image against all earlier ones, earlier first); prefilter 'seqN' / 'cycN' keeps pairs at most N frames apart
+    (cyclically for 'cyc'), applied after the symmetrisation as there."""
+    pairs = []
+    if scene_graph == "complete":
+        pairs = [(i, j) for i in range(n) for j in range(i)]
+    elif scene_graph.startswith("swin"):
+        win = int(scene_graph.split("-")[1]) if "-" in scene_graph else 3
+        ids = set()                                          # (the reference iterates this set: same construction, same order)
+        for i in range(n):
+            for j in range(1, win + 1):
+                k = (i + j) % n
+                ids.add((i, k) if i < k else (k, i))
+        pairs = list(ids)
+    elif scene_graph.startswith("oneref"):
+        ref = int(scene_graph.split("-")[1]) if "-" in scene_graph else 0
+        pairs = [(ref, j) for j in range(n) if j != ref]
+    elif scene_graph.startswith("prev"):
+        pairs = [(j, i) for i in range(1, n) for j in range(i)]
+    else:
+        raise ValueError("pair_indices: unknown scene_graph %r" % (scene_graph,))
+    if symmetrize:
+        pairs = pairs + [(b, a) for a, b in pairs]
+    if isinstance(prefilter, str) and (prefilter.startswith("seq") or prefilter.startswith("cyc")):
+        thr, cyc = int(prefilter[3:]), prefilter.startswith("cyc")
+        m = max(max(e) for e in pairs) + 1 if pairs else 0   # (the reference counts images from the surviving edges)
+        keep = []
+        for a, b in pairs:
+            d = abs(a - b)
+            if cyc:
+                d = min(d, abs(a + m - b), abs(a - m - b))
+            if d <= thr:
+                keep.append((a, b))
+        pairs = keep
+    return pairs
+
+
+def pair_graph(dust3r, frames, batch_size=2, scene_graph="complete", prefilter=None):
     """The DUSt3R pair graph offline_reconstruction starts from, built the way demo.py:100-117 does it with
     dust3r.image_pairs.make_pairs(symmetrize=True) + dust3r.inference.inference(): every frame becomes a view dict
-    (img, true_shape, idx, instance), the pair list is symmetrised, and each batch of pairs is run in both orders
+    (img, true_shape, idx, instance), the pair list (`pair_indices`: every scene_graph / prefilter of make_pairs) is symmetrised, and each batch of pairs is run in both orders
     (inference.py:27-37 make_batch_symmetric), so the result holds 4 entries per unordered pair.  Returns
     dict(view1, view2, pred1, pred2) with tensors on the CPU, lists chained."""
     views = [dict(img=f["img"], true_shape=torch.tensor(f["img"].shape[-2:])[None], idx=j, instance=str(j)) for j, f in enumerate(frames)]
     n = len(views)
-    if scene_graph != "complete":
-        raise NotImplementedError("pair_graph builds the complete graph (demo.py default)")
-    pairs = [(i, j) for i in range(n) for j in range(i)]
-    pairs += [(j, i) for i, j in pairs]
+    pairs = pair_indices(n, scene_graph, prefilter, symmetrize=True)
 
     def batch_of(ids):                                      # collate + interleave the two orders of every pair
         v1, v2 = [], []

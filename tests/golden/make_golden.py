@@ -755,6 +755,26 @@ def make_crop():
     print("crop_plan.npz:", len(cases), "shapes")
 
 
+def make_pairs_fixture():
+    """missing #6 of VERDICT r4: dust3r/image_pairs.py:11-46 make_pairs for every scene_graph / prefilter it knows, on index-only
+    "images" (the function only reads img['idx']): the pair lists spann3r_amd.runner.pair_indices must reproduce, order included."""
+    import json
+    from dust3r.image_pairs import make_pairs
+    out = {}
+    for n in (2, 3, 5, 8):
+        imgs = [dict(idx=i) for i in range(n)]
+        for sg in ("complete", "swin", "swin-2", "swin-5", "oneref", "oneref-2", "prev"):
+            if sg == "oneref-2" and n < 3:
+                continue
+            for pf in (None, "seq1", "seq3", "cyc1", "cyc2"):
+                for sym in (True, False):
+                    pr = make_pairs(imgs, scene_graph=sg, prefilter=pf, symmetrize=sym)
+                    out["%d|%s|%s|%d" % (n, sg, pf, sym)] = [[a["idx"], b["idx"]] for a, b in pr]
+    with open(os.path.join(HERE, "pairs.json"), "w") as f:
+        json.dump(out, f, separators=(",", ":"))
+    print("pairs.json:", len(out), "graphs")
+
+
 def make_pnp():
     """f4: the poses demo.py:170-186 computes -- cv2.solvePnPRansac(points, pixel grid, K, zeros(4)) with OpenCV's defaults,
     Rodrigues, inverse -- on the synthetic scenes of tests/test_postprocess.py.  Needs OpenCV,
@@ -787,6 +807,8 @@ def make_pnp():
 
 if __name__ == "__main__":
     what = sys.argv[1:] or ["tiny", "full", "memory"]
+    if "pairs" in what:
+        make_pairs_fixture()
     if "pnp" in what:
         make_pnp()
     if "autocast" in what:

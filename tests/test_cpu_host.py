@@ -447,3 +447,18 @@ def test_lr_schedule_and_accumulation_window_vs_reference():
         assert [w[0] for w in seen] == [i % a == 0 for i in range(7)]
         st.reset_iteration()
         assert st._window() == (True, a == 1)
+
+
+def test_pair_indices_vs_reference_make_pairs():
+    """runner.pair_indices against dust3r/image_pairs.py make_pairs run on the unmodified reference (tests/golden/make_golden.py pairs):
+    every scene graph (complete, swin[-W], oneref[-R], prev), prefilter (seqN, cycN) and symmetrize, pair ORDER included"""
+    import json
+    from spann3r_amd.runner import pair_indices
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "pairs.json")))
+    assert len(g) > 200
+    for key, ref in g.items():
+        n, sg, pf, sym = key.split("|")
+        got = pair_indices(int(n), sg, None if pf == "None" else pf, bool(int(sym)))
+        assert [list(p) for p in got] == ref, key
+    with pytest.raises(ValueError):
+        pair_indices(4, "star")
