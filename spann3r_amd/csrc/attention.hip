@@ -438,133 +438,167 @@ __device__ __forceinline__ KFrag load_frag(const __bf16* base, int row, int col,
   return f;
 }
 
-// One workgroup = 16 query rows of one head; its 4 waves split the key tiles (tile t goes to wave t & 3), each running
-// an independent online softmax; the four partial (m, l, O^T) states are merged through LDS (wave w merges d-block w).
+// One workgroup = QB blocks of 16 query rows of one head; its 4 waves split the key tiles (tile t goes to wave t & 3), each running
+// an independent online softmax per query block; the four partial (m, l, O^T) states are merged through LDS (wave w merges d-block w).
 // At N = 196 (4 tiles) every wave handles ONE tile: the dependent chain is 1 tile instead of 4.
-__global__ __launch_bounds__(256) void attention_packed_kernel(const __bf16* __restrict__ QP, int q_cols, int q_col0, int npad_q,
-                                                               const __bf16* __restrict__ KP, int k_cols, int k_col0, int npad_k,
-                                                               const __bf16* __restrict__ VTP, void* __restrict__ O, int64_t ldo,
-                                                               int out_bf16, int out_packed, int heads, int Nq, int Nk, float scale,
-                                                               int o_group, int o_group_rows) {
-  __shared__ float sh_o[4][4][64][4];   // [wave][db][lane][r]
-  __shared__ float sh_m[4][64], sh_l[4][64];
+//
+// Round 5 (profiles/r05_attn_long_pmc.md, r05_attn_long_variants.txt): the round-4 loop was VALU-bound -- 385 VALU instructions per 64-key
+// tile next to 16 MFMAs (libm-style exp2f with its denormal fix-up, a key mask on every tile, 64-bit fragment addressing, a 32-register
+// copy of the prefetched K fragments, 16-deep max / sum chains), 48 % of the wave cycles in issue stalls at 4 waves per SIMD.  Now:
+//   * QB = 2 query blocks per wave from 512 query rows on: the K / V^T fragments of a tile are loaded once for both (half the vector-
+//     memory traffic per query) and the two softmax chains are independent work the compiler interleaves under each other's latencies;
+//   * bare v_exp_f32 (probabilities below 2^-126 flush to zero), the scale folded into the exponent's FMA (max on the raw scores),
+//     the key mask on the ragged last tile only, tree-shaped reductions (four chains of four);
+//   * one pointer per lane with constant strides per tile; K and V^T of a tile requested together at its top (no register copy: the
+//     other resident waves cover the latency -- the explicit prefetch cost more registers than it hid).
+// 2 x 16 heads x 1024 tokens: 28.4 -> 21.5 us; 2 x 12 x 1024: 22.3 -> 16.7; 2 x 12 x 196: 4.26 -> 3.93.  Against the round-4 kernel the
+// outputs differ by <= 2.5e-4 of their maximum (the last bit of a probability before its bf16 rounding).
+template <int QB, int MINW>
+__global__ __launch_bounds__(256, MINW) void attention_packed_kernel(const __bf16* __restrict__ QP, int q_cols, int q_col0, int npad_q,
+                                                                     const __bf16* __restrict__ KP, int k_cols, int k_col0, int npad_k,
+                                                                     const __bf16* __restrict__ VTP, void* __restrict__ O, int64_t ldo,
+                                                                     int out_bf16, int out_packed, int heads, int Nq, int Nk, float scale,
+                                                                     int o_group, int o_group_rows) {
+  extern __shared__ __attribute__((aligned(16))) float sh[];
+  float* sh_o = sh;                                  // [wave][qb][db][lane][4]
+  float* sh_m = sh + 4 * QB * 4 * 64 * 4;            // [wave][qb][lane]
+  float* sh_l = sh_m + 4 * QB * 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, ql = lane & 15;
   const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-  const int q0 = qt * 16;
-  const KFrag qf = load_frag(QP, b * npad_q + q0 + ql, q_col0 + h * 64 + 16 * g, q_cols);
-  const int krow0 = b * npad_k;
-  const int kcol = k_col0 + h * 64 + 16 * g;
-  const int64_t nU = npad_k >> 5;
-  const __bf16* vbase = VTP + ((int64_t)(b * heads + h) * nU * 4 * 64 + lane) * 8;
+  const int q0 = qt * 16 * QB;
+  const int last_qrow = npad_q - 16;                 // query blocks past the padded rows re-read the last block (their results are dropped)
+  KFrag qf[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const int r0 = q0 + 16 * qb < last_qrow ? q0 + 16 * qb : last_qrow;
+    qf[qb] = load_frag(QP, b * npad_q + r0 + ql, q_col0 + h * 64 + 16 * g, q_cols);
+  }
   const int ntiles = (Nk + 63) >> 6;
   const float sl2 = scale * 1.4426950408889634f;     // softmax in base 2: exp(x) = exp2(x * log2 e), v_exp_f32
+  // K fragment of key block t of a tile: rows krow0 + 64 tile + 16 t + ql; a 16-row block's column blocks are contiguous, so one
+  // pointer per lane and a constant stride per 16-row block
+  const __bf16* kbase = KP + packed_off(b * npad_k + ql, k_col0 + h * 64 + 16 * g, k_cols, true);
+  const int64_t kblk = (int64_t)((k_cols + 63) >> 6) * 1024;        // elements per 16-row block
+  const int64_t nU = npad_k >> 5;
+  const __bf16* vbase = VTP + ((int64_t)(b * heads + h) * nU * 4 * 64 + lane) * 8;
 
-  f32x4 o[4];
+  f32x4 o[QB][4];
+  float m_run[QB], l_run[QB];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m_run = -INFINITY, l_run = 0.f;
-
+  for (int qb = 0; qb < QB; ++qb) {
+    m_run[qb] = -INFINITY; l_run[qb] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[qb][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   if (wave < ntiles) {
-    KFrag kc[4], kn[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) kc[t] = load_frag(KP, krow0 + (wave << 6) + 16 * t + ql, kcol, k_cols);
     for (int tile = wave; tile < ntiles; tile += 4) {
       const int kb = tile << 6;
-      // V of this tile and K of this wave's next tile are requested before any arithmetic (unconditional loads: the
-      // last iteration re-reads its own tile)
+      KFrag kc[4];
       bf16x8 vv[2][4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const __bf16* p = kbase + (int64_t)(4 * tile + t) * kblk;
+        kc[t].v[0] = *reinterpret_cast<const bf16x8*>(p);
+        kc[t].v[1] = *reinterpret_cast<const bf16x8*>(p + 64 * 8);
+      }
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int db = 0; db < 4; ++db)
           vv[u][db] = *reinterpret_cast<const bf16x8*>(vbase + (((int64_t)(2 * tile + u)) * 4 + db) * 64 * 8);
-      const int nkb = (tile + 4 < ntiles ? tile + 4 : tile) << 6;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) kn[t] = load_frag(KP, krow0 + nkb + 16 * t + ql, kcol, k_cols);
-
-      f32x4 s[4];
+      for (int qb = 0; qb < QB; ++qb) {
+        f32x4 s[4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc[t].v[0], qf.v[0], s[t], 0, 0, 0);
-        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc[t].v[1], qf.v[1], s[t], 0, 0, 0);
-      }
-      float mx = -INFINITY;
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = kb + 16 * t + 4 * g + r;
-          const float v = key < Nk ? s[t][r] * sl2 : -INFINITY;
-          s[t][r] = v;
-          mx = fmaxf(mx, v);
+        for (int t = 0; t < 4; ++t) {
+          s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+          s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc[t].v[0], qf[qb].v[0], s[t], 0, 0, 0);
+          s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc[t].v[1], qf[qb].v[1], s[t], 0, 0, 0);
         }
-      mx = fmaxf(mx, __shfl_xor(mx, 16));
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = exp2f(m_run - m_new);
-      float ps = 0.f;
+        if (kb + 64 > Nk) {                    // the ragged last tile (wave-uniform): keys past Nk drop out of the softmax
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+          for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float e = exp2f(s[t][r] - m_new);
-          s[t][r] = e;
-          ps += e;
+            for (int r = 0; r < 4; ++r)
+              if (kb + 16 * t + 4 * g + r >= Nk) s[t][r] = -INFINITY;
         }
-      l_run = l_run * alpha + ps;
-      m_run = m_new;
+        float mt[4];
 #pragma unroll
-      for (int db = 0; db < 4; ++db)
+        for (int t = 0; t < 4; ++t) mt[t] = fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3]));
+        float mx = fmaxf(fmaxf(mt[0], mt[1]), fmaxf(mt[2], mt[3]));
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run[qb], mx * sl2);          // (scale > 0: the max of the raw scores is the max of the scaled ones)
+        const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new);
+        float pt[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[db][r] *= alpha;
+        for (int t = 0; t < 4; ++t) {
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        bf16x8 pb;
+          for (int r = 0; r < 4; ++r) s[t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], sl2, -m_new));
+          pt[t] = (s[t][0] + s[t][1]) + (s[t][2] + s[t][3]);
+        }
+        l_run[qb] = l_run[qb] * alpha + ((pt[0] + pt[1]) + (pt[2] + pt[3]));
+        m_run[qb] = m_new;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pb[j] = (__bf16)s[2 * u + (j >> 2)][j & 3];
+        for (int db = 0; db < 4; ++db)
 #pragma unroll
-        for (int db = 0; db < 4; ++db) o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vv[u][db], pb, o[db], 0, 0, 0);
+          for (int r = 0; r < 4; ++r) o[qb][db][r] *= alpha;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          bf16x8 pb;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pb[j] = (__bf16)s[2 * u + (j >> 2)][j & 3];
+#pragma unroll
+          for (int db = 0; db < 4; ++db) o[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vv[u][db], pb, o[qb][db], 0, 0, 0);
+        }
       }
-#pragma unroll
-      for (int t = 0; t < 4; ++t) kc[t] = kn[t];
     }
-    l_run += __shfl_xor(l_run, 16);
-    l_run += __shfl_xor(l_run, 32);
-  }
-  // ---- merge the four per-wave states (base-2 running max m, sum l, O^T)
-  sh_m[wave][lane] = m_run;
-  sh_l[wave][lane] = l_run;
 #pragma unroll
-  for (int db = 0; db < 4; ++db)
-    *reinterpret_cast<float4*>(&sh_o[wave][db][lane][0]) = make_float4(o[db][0], o[db][1], o[db][2], o[db][3]);
+    for (int qb = 0; qb < QB; ++qb) {
+      l_run[qb] += __shfl_xor(l_run[qb], 16);
+      l_run[qb] += __shfl_xor(l_run[qb], 32);
+    }
+  }
+  // ---- merge the four per-wave states of every query block (base-2 running max m, sum l, O^T): wave w merges d-block w
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    sh_m[(wave * QB + qb) * 64 + lane] = m_run[qb];
+    sh_l[(wave * QB + qb) * 64 + lane] = l_run[qb];
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+      *reinterpret_cast<float4*>(sh_o + ((((wave * QB + qb) * 4 + db) * 64 + lane) << 2)) = make_float4(o[qb][db][0], o[qb][db][1], o[qb][db][2], o[qb][db][3]);
+  }
   __syncthreads();
-  float M = sh_m[0][lane];
+  const int db = wave;
 #pragma unroll
-  for (int w = 1; w < 4; ++w) M = fmaxf(M, sh_m[w][lane]);
-  float L = 0.f;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  const int db = wave;                       // this wave merges d-block `wave`
+  for (int qb = 0; qb < QB; ++qb) {
+    float M = sh_m[(0 * QB + qb) * 64 + lane];
 #pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    const float sc = exp2f(sh_m[w][lane] - M);            // 0 for a wave that saw no tile (m = -inf)
-    L += sh_l[w][lane] * sc;
-    const float4 ow = *reinterpret_cast<const float4*>(&sh_o[w][db][lane][0]);
-    acc.x += ow.x * sc; acc.y += ow.y * sc; acc.z += ow.z * sc; acc.w += ow.w * sc;
-  }
-  const float inv = 1.0f / L;
-  if (q0 + ql < Nq) {
-    // output row: images are consecutive, except that every o_group of them may start at a multiple of o_group_rows
-    // (grouped launches keep each problem's packed rows 16-aligned)
-    const int row = o_group > 0 ? (b / o_group) * o_group_rows + (b % o_group) * Nq + q0 + ql : b * Nq + q0 + ql;
-    const int col = h * 64 + db * 16 + 4 * g;
-    const int64_t off = out_packed ? packed_off(row, col, heads * 64, out_bf16 != 0) : (int64_t)row * ldo + col;
-    if (out_bf16) {
-      bf16x4 ob;
-      ob[0] = (__bf16)(acc.x * inv); ob[1] = (__bf16)(acc.y * inv); ob[2] = (__bf16)(acc.z * inv); ob[3] = (__bf16)(acc.w * inv);
-      st_out(reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(O) + off), ob);
-    } else {
-      st_out(reinterpret_cast<float4*>(reinterpret_cast<float*>(O) + off), make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv));
+    for (int w = 1; w < 4; ++w) M = fmaxf(M, sh_m[(w * QB + qb) * 64 + lane]);
+    float L = 0.f;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float sc = __builtin_amdgcn_exp2f(sh_m[(w * QB + qb) * 64 + lane] - M);     // 0 for a wave that saw no tile (m = -inf)
+      L += sh_l[(w * QB + qb) * 64 + lane] * sc;
+      const float4 ow = *reinterpret_cast<const float4*>(sh_o + ((((w * QB + qb) * 4 + db) * 64 + lane) << 2));
+      acc.x += ow.x * sc; acc.y += ow.y * sc; acc.z += ow.z * sc; acc.w += ow.w * sc;
+    }
+    const float inv = 1.0f / L;
+    const int q = q0 + 16 * qb + ql;
+    if (q < Nq) {
+      // output row: images are consecutive, except that every o_group of them may start at a multiple of o_group_rows
+      // (grouped launches keep each problem's packed rows 16-aligned)
+      const int row = o_group > 0 ? (b / o_group) * o_group_rows + (b % o_group) * Nq + q : b * Nq + q;
+      const int col = h * 64 + db * 16 + 4 * g;
+      const int64_t off = out_packed ? packed_off(row, col, heads * 64, out_bf16 != 0) : (int64_t)row * ldo + col;
+      if (out_bf16) {
+        bf16x4 ob;
+        ob[0] = (__bf16)(acc.x * inv); ob[1] = (__bf16)(acc.y * inv); ob[2] = (__bf16)(acc.z * inv); ob[3] = (__bf16)(acc.w * inv);
+        st_out(reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(O) + off), ob);
+      } else {
+        st_out(reinterpret_cast<float4*>(reinterpret_cast<float*>(O) + off), make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv));
+      }
     }
   }
 }
@@ -800,10 +834,19 @@ extern "C" int sp3_attention_packed(const void* qp, int q_cols, int q_col0, int 
   SP3_CHECK(q_cols % 64 == 0 && k_cols % 64 == 0 && q_col0 % 64 == 0 && k_col0 % 64 == 0, "sp3_attention_packed: column geometry");
   SP3_CHECK(out_packed || ldo % 4 == 0, "sp3_attention_packed: ldo");
   SP3_CHECK(o_group == 0 || (o_group > 0 && B % o_group == 0 && o_group_rows >= o_group * Nq), "sp3_attention_packed: output grouping");
-  hipLaunchKernelGGL(attention_packed_kernel, dim3((Nq + 15) / 16, heads, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     reinterpret_cast<const __bf16*>(qp), q_cols, q_col0, npad_q, reinterpret_cast<const __bf16*>(kp), k_cols, k_col0,
-                     npad_k, reinterpret_cast<const __bf16*>(vtp), out, ldo, out_bf16, out_packed, heads, Nq, Nk, scale, o_group,
-                     o_group_rows);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  // two query blocks per workgroup once the grid still fills the chip that way (profiles/r05_attn_long_variants.txt)
+  if (Nq >= 512) {
+    constexpr int QB = 2, lds = (4 * QB * 4 * 64 * 4 + 2 * 4 * QB * 64) * 4;
+    hipLaunchKernelGGL((attention_packed_kernel<QB, 3>), dim3((Nq + 16 * QB - 1) / (16 * QB), heads, B), dim3(256), lds, st,
+                       reinterpret_cast<const __bf16*>(qp), q_cols, q_col0, npad_q, reinterpret_cast<const __bf16*>(kp), k_cols, k_col0,
+                       npad_k, reinterpret_cast<const __bf16*>(vtp), out, ldo, out_bf16, out_packed, heads, Nq, Nk, scale, o_group, o_group_rows);
+  } else {
+    constexpr int QB = 1, lds = (4 * QB * 4 * 64 * 4 + 2 * 4 * QB * 64) * 4;
+    hipLaunchKernelGGL((attention_packed_kernel<QB, 4>), dim3((Nq + 15) / 16, heads, B), dim3(256), lds, st,
+                       reinterpret_cast<const __bf16*>(qp), q_cols, q_col0, npad_q, reinterpret_cast<const __bf16*>(kp), k_cols, k_col0,
+                       npad_k, reinterpret_cast<const __bf16*>(vtp), out, ldo, out_bf16, out_packed, heads, Nq, Nk, scale, o_group, o_group_rows);
+  }
   SP3_LAUNCH_CHECK("sp3_attention_packed");
   return 0;
 }

@@ -397,11 +397,36 @@ class SpatialMemory:
         if self.wm > self.work_mem_size:
             self.wm -= 1
             if self.long_mem_size == 0:
-                raise NotImplementedError("long_mem_size == 0 (sliding window) is not used by Spann3R.forward")
-            self.lm += self.P
+                self._drop_oldest()                              # sliding window (spann3r/model.py:132-137)
+            else:
+                self.lm += self.P
         if self.lm > self.long_mem_size:
             self.memory_prune()
             self.lm = self.top_k - self.wm * self.P
+
+    def _drop_oldest(self):
+        """long_mem_size == 0 (spann3r/model.py:132-137): the bank is a sliding window of work_mem_size frames -- the oldest frame's
+        P tokens leave.  P is not a multiple of the 16-row fragment blocks, so the fragment-order copies are re-gathered like a
+        prune with the selection [P, M) (same kernels, other arena half)."""
+        self._flush_attn()
+        B, C, M, P = self.B, self.C, self.M, self.P
+        k = M - P
+        src = self.bank
+        if self._banks[1 - self._cur] is None:
+            self._banks[1 - self._cur] = self._alloc(self.eng.device, self.eng.wdt)
+        dst = self._banks[1 - self._cur]
+        sel = torch.arange(P, M, dtype=torch.int32, device=self.eng.device)
+        for b in range(B):
+            ops.gather_rows(src["k_raw"][b], dst["k_raw"][b], sel, k, C)
+            ops.gather_rows(src["v_raw"][b], dst["v_raw"][b], sel, k, C)
+            ops.gather_packed_rows(src["k_hat"][b], dst["k_hat"][b], sel, k, C)
+            ops.gather_packed_cols(src["v_hat_t"][b], dst["v_hat_t"][b], sel, k, self.cap, C, self.cap)
+            for name in ("s_bank", "b_bank", "attn", "count"):
+                ops.gather_1d(src[name][b], dst[name][b], sel, k)
+        print("Memory pruned:", (B, k, C))
+        self.events.append("window %d->%d" % (M, k))
+        self._cur = 1 - self._cur
+        self.M = k
 
     # ------------------------------------------------------------------ prune (:185-210)
     def memory_prune(self):

@@ -149,6 +149,7 @@ def pick_tile(M, N, batch=1, splitk=1, conv=False, K=0, packed_bf16=False, plain
 
 import os as _os
 PIPE_TILES = _os.environ.get("SP3_PIPE_TILES", "1")[:1] != "0"     # mirrors the switch in csrc/gemm.hip (A/B runs)
+PROF_SHAPES = _os.environ.get("SP3_PROF_SHAPES", "0")[:1] == "1"
 LEAN = _os.environ.get("SP3_LEAN_GEMM", "1")[:1] != "0"          # mirrors sm_enabled() in csrc/gemm_sm.hip: with the lean instances off the
                                                                   # engine must not pick the layouts only they serve (packed split-A, bf16 DPT maps)
 
@@ -247,8 +248,10 @@ def _gemm_launch(d, what, loader_name):
     nbytes = b * (asz * a_elems + wsz * d.N * d.K + csz * d.M * d.N)      # algorithmic: every operand once
     adt = "bf16" if d.a_bf16 else "f32"
     tname = ("16x64xk4" if d.tile == 0 else "32x32xk4") if (d.loader == L.LOAD_SOFTMAX and d.tile < 30) else _TILE_NAMES[d.tile]
-    _prof.end("gemm<A%s,W%s,%s,%s>" % (adt, "f32" if d.wdtype == F32 else "bf16", loader_name, tname),
-              e0, flops, nbytes)
+    key = "gemm<A%s,W%s,%s,%s>" % (adt, "f32" if d.wdtype == F32 else "bf16", loader_name, tname)
+    if PROF_SHAPES:                                 # (tools: one profile line per GEMM shape)
+        key += " %dx%dx%d x%d%s" % (d.M, d.N, d.K, b, " splitA" if d.A2 else "")
+    _prof.end(key, e0, flops, nbytes)
 
 
 def _timed(key, flops, nbytes, fn, *args):

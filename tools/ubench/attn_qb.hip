@@ -301,6 +301,197 @@ __global__ __launch_bounds__(256) void attention_packed_v2_kernel(const __bf16* 
   }
 }
 
+
+// v5: what the counters of profiles/r05_attn_long_pmc.md ask for -- more independent work per wave at (about) the product kernel's
+// register budget: QB query blocks per wave on the same K / V^T registers (independent softmax chains the compiler interleaves), v2's
+// trimmed softmax, tree-shaped max / sum reductions (4 chains of 4 instead of one of 16), and the two K buffers used alternately by
+// a loop unrolled x2 instead of a 32-register copy per tile.  MINW: minimum waves per SIMD for the register allocator; PF: prefetch
+// the next tile's K fragments (0: request K and V of a tile together at its top and rely on the other waves).
+template <int QB, int MINW, int PF>
+__global__ __launch_bounds__(256, MINW) void attention_packed_v5_kernel(const __bf16* __restrict__ QP, int q_cols, int q_col0, int npad_q,
+                                                                        const __bf16* __restrict__ KP, int k_cols, int k_col0, int npad_k,
+                                                                        const __bf16* __restrict__ VTP, void* __restrict__ O, int64_t ldo,
+                                                                        int out_bf16, int out_packed, int heads, int Nq, int Nk, float scale,
+                                                                        int o_group, int o_group_rows) {
+  extern __shared__ __attribute__((aligned(16))) float sh[];
+  float* sh_o = sh;                                  // [wave][qb][db][lane][4]
+  float* sh_m = sh + 4 * QB * 4 * 64 * 4;            // [wave][qb][lane]
+  float* sh_l = sh_m + 4 * QB * 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, ql = lane & 15;
+  const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int q0 = qt * 16 * QB;
+  const int last_qrow = npad_q - 16;
+  KFrag qf[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const int r0 = q0 + 16 * qb < last_qrow ? q0 + 16 * qb : last_qrow;
+    qf[qb] = load_frag(QP, b * npad_q + r0 + ql, q_col0 + h * 64 + 16 * g, q_cols);
+  }
+  const int ntiles = (Nk + 63) >> 6;
+  const float sl2 = scale * 1.4426950408889634f;
+  // K fragment of key block t of tile `tile`: rows krow0 + 64 tile + 16 t + ql -> fragment blocks are 16 rows x 64 columns = 2 KB, a row block's
+  // column blocks are contiguous: one pointer per lane, constant strides per tile / per key block
+  const int nkbk = (k_cols + 63) >> 6;
+  const __bf16* kbase = KP + packed_off(b * npad_k + ql, k_col0 + h * 64 + 16 * g, k_cols, true);
+  const int64_t kblk = (int64_t)nkbk * 1024;          // elements per 16-row block
+  const int64_t nU = npad_k >> 5;
+  const __bf16* vbase = VTP + ((int64_t)(b * heads + h) * nU * 4 * 64 + lane) * 8;
+  auto load_k = [&](KFrag (&kf)[4], int tile) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const __bf16* p = kbase + (int64_t)(4 * tile + t) * kblk;
+      kf[t].v[0] = *reinterpret_cast<const bf16x8*>(p);
+      kf[t].v[1] = *reinterpret_cast<const bf16x8*>(p + 64 * 8);
+    }
+  };
+  f32x4 o[QB][4];
+  float m_run[QB], l_run[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    m_run[qb] = -INFINITY; l_run[qb] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[qb][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  auto tile_body = [&](const KFrag (&kc)[4], const bf16x8 (&vv)[2][4], int tile) {
+    const int kb = tile << 6;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      f32x4 s[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc[t].v[0], qf[qb].v[0], s[t], 0, 0, 0);
+        s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kc[t].v[1], qf[qb].v[1], s[t], 0, 0, 0);
+      }
+      if (kb + 64 > Nk) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (kb + 16 * t + 4 * g + r >= Nk) s[t][r] = -INFINITY;
+      }
+      float mt[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) mt[t] = fmaxf(fmaxf(s[t][0], s[t][1]), fmaxf(s[t][2], s[t][3]));
+      float mx = fmaxf(fmaxf(mt[0], mt[1]), fmaxf(mt[2], mt[3]));
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m_run[qb], mx * sl2);
+      const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new);
+      float pt[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[t][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], sl2, -m_new));
+        pt[t] = (s[t][0] + s[t][1]) + (s[t][2] + s[t][3]);
+      }
+      l_run[qb] = l_run[qb] * alpha + ((pt[0] + pt[1]) + (pt[2] + pt[3]));
+      m_run[qb] = m_new;
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[qb][db][r] *= alpha;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        bf16x8 pb;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pb[j] = (__bf16)s[2 * u + (j >> 2)][j & 3];
+#pragma unroll
+        for (int db = 0; db < 4; ++db) o[qb][db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vv[u][db], pb, o[qb][db], 0, 0, 0);
+      }
+    }
+  };
+  auto load_v = [&](bf16x8 (&vv)[2][4], int tile) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int db = 0; db < 4; ++db) vv[u][db] = *reinterpret_cast<const bf16x8*>(vbase + (((int64_t)(2 * tile + u)) * 4 + db) * 64 * 8);
+  };
+  if (wave < ntiles) {
+    if constexpr (PF) {
+      KFrag ka[4], kb_[4];
+      load_k(ka, wave);
+      for (int tile = wave; tile < ntiles; tile += 8) {
+        {
+          bf16x8 vv[2][4];
+          load_v(vv, tile);
+          load_k(kb_, tile + 4 < ntiles ? tile + 4 : tile);
+          tile_body(ka, vv, tile);
+        }
+        if (tile + 4 < ntiles) {
+          bf16x8 vv[2][4];
+          load_v(vv, tile + 4);
+          load_k(ka, tile + 8 < ntiles ? tile + 8 : tile + 4);
+          tile_body(kb_, vv, tile + 4);
+        }
+      }
+    } else {
+      for (int tile = wave; tile < ntiles; tile += 4) {
+        KFrag kc[4];
+        bf16x8 vv[2][4];
+        load_k(kc, tile);
+        load_v(vv, tile);
+        tile_body(kc, vv, tile);
+      }
+    }
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      l_run[qb] += __shfl_xor(l_run[qb], 16);
+      l_run[qb] += __shfl_xor(l_run[qb], 32);
+    }
+  }
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    sh_m[(wave * QB + qb) * 64 + lane] = m_run[qb];
+    sh_l[(wave * QB + qb) * 64 + lane] = l_run[qb];
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+      *reinterpret_cast<float4*>(sh_o + ((((wave * QB + qb) * 4 + db) * 64 + lane) << 2)) = make_float4(o[qb][db][0], o[qb][db][1], o[qb][db][2], o[qb][db][3]);
+  }
+  __syncthreads();
+  const int db = wave;
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    float M = sh_m[(0 * QB + qb) * 64 + lane];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) M = fmaxf(M, sh_m[(w * QB + qb) * 64 + lane]);
+    float L = 0.f;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float sc = __builtin_amdgcn_exp2f(sh_m[(w * QB + qb) * 64 + lane] - M);
+      L += sh_l[(w * QB + qb) * 64 + lane] * sc;
+      const float4 ow = *reinterpret_cast<const float4*>(sh_o + ((((w * QB + qb) * 4 + db) * 64 + lane) << 2));
+      acc.x += ow.x * sc; acc.y += ow.y * sc; acc.z += ow.z * sc; acc.w += ow.w * sc;
+    }
+    const float inv = 1.0f / L;
+    const int q = q0 + 16 * qb + ql;
+    if (q < Nq) {
+      const int row = o_group > 0 ? (b / o_group) * o_group_rows + (b % o_group) * Nq + q : b * Nq + q;
+      const int col = h * 64 + db * 16 + 4 * g;
+      const int64_t off = out_packed ? packed_off(row, col, heads * 64, out_bf16 != 0) : (int64_t)row * ldo + col;
+      if (out_bf16) {
+        bf16x4 ob;
+        ob[0] = (__bf16)(acc.x * inv); ob[1] = (__bf16)(acc.y * inv); ob[2] = (__bf16)(acc.z * inv); ob[3] = (__bf16)(acc.w * inv);
+        *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(O) + off) = ob;
+      } else {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(O) + off) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+      }
+    }
+  }
+}
+
+template <int QB, int MINW, int PF>
+void launch_v5(const __bf16* q, const __bf16* k, const __bf16* vt, void* o, int cols, int npad_q, int npad_k, int B, int heads, int Nq, int Nk,
+               int out_bf16, int out_packed) {
+  const int lds = (4 * QB * 4 * 64 * 4 + 2 * 4 * QB * 64) * 4;
+  auto kern = attention_packed_v5_kernel<QB, MINW, PF>;
+  static bool raised = false;
+  if (!raised && lds > 64 * 1024) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds)); raised = true; }
+  hipLaunchKernelGGL(kern, dim3((Nq + 16 * QB - 1) / (16 * QB), heads, B), dim3(256), lds, 0, q, cols, 0, npad_q, k, cols, 0, npad_k, vt, o,
+                     (int64_t)cols, out_bf16, out_packed, heads, Nq, Nk, 0.125f, 0, 0);
+}
+
 template <int PIN>
 void launch_v2(const __bf16* q, const __bf16* k, const __bf16* vt, void* o, int cols, int npad_q, int npad_k, int B, int heads, int Nq, int Nk,
                int out_bf16, int out_packed) {
@@ -321,8 +512,8 @@ void launch_qb(const __bf16* q, const __bf16* k, const __bf16* vt, void* o, int 
 
 void launch_ref(const __bf16* q, const __bf16* k, const __bf16* vt, void* o, int cols, int npad_q, int npad_k, int B, int heads, int Nq, int Nk,
                 int out_bf16, int out_packed) {
-  hipLaunchKernelGGL(attention_packed_kernel, dim3((Nq + 15) / 16, heads, B), dim3(256), 0, 0, q, cols, 0, npad_q, k, cols, 0, npad_k, vt, o,
-                     (int64_t)cols, out_bf16, out_packed, heads, Nq, Nk, 0.125f, 0, 0);
+  // (the product entry point: since round 5 it runs the v5 loop -- QB = 2 from 512 query rows on; the round-4 loop survives here as v2's ancestor)
+  sp3_attention_packed(q, cols, 0, npad_q, k, cols, 0, npad_k, vt, o, (int64_t)cols, out_bf16, out_packed, B, heads, Nq, Nk, 0.125f, 0, 0, nullptr);
 }
 
 template <typename F>
@@ -402,6 +593,22 @@ int main() {
     const float t4 = time_us([&] { launch_qb<4>(q, k, vt, o_new, cols, npad_q, npad_k, B, heads, N, N, 1, 1); }, reps);
     const float t5 = time_us([&] { launch_v2<0>(q, k, vt, o_new, cols, npad_q, npad_k, B, heads, N, N, 1, 1); }, reps);
     const float t6 = time_us([&] { launch_v2<1>(q, k, vt, o_new, cols, npad_q, npad_k, B, heads, N, N, 1, 1); }, reps);
+    {
+      struct V { const char* n; void (*f)(const __bf16*, const __bf16*, const __bf16*, void*, int, int, int, int, int, int, int, int, int); };
+      const V vs[] = {{"v5 qb1 w4 pf1", launch_v5<1, 4, 1>}, {"v5 qb1 w3 pf1", launch_v5<1, 3, 1>}, {"v5 qb1 w4 pf0", launch_v5<1, 4, 0>},
+                      {"v5 qb2 w2 pf1", launch_v5<2, 2, 1>}, {"v5 qb2 w3 pf1", launch_v5<2, 3, 1>}, {"v5 qb2 w4 pf1", launch_v5<2, 4, 1>},
+                      {"v5 qb2 w3 pf0", launch_v5<2, 3, 0>}, {"v5 qb2 w4 pf0", launch_v5<2, 4, 0>}, {"v5 qb4 w2 pf0", launch_v5<4, 2, 0>}};
+      for (const V& v : vs) {
+        CK(hipMemset(o_new, 0, no * 4));
+        v.f(q, k, vt, o_new, cols, npad_q, npad_k, B, heads, N, N, 0, 0);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(b2.data(), o_new, no * 4, hipMemcpyDeviceToHost));
+        double dm = 0.0;
+        for (size_t i = 0; i < (size_t)B * N * cols; ++i) { const double d = fabs((double)a[i] - (double)b2[i]); dm = d > dm ? d : dm; if (!(b2[i] == b2[i])) dm = 1e30; }
+        const float t = time_us([&] { v.f(q, k, vt, o_new, cols, npad_q, npad_k, B, heads, N, N, 1, 1); }, reps);
+        printf("    %-16s %8.2f us  (%5.1f TFLOP/s)  max |diff| / max |out| %.2e\n", v.n, t, 4.0 * B * heads * (double)N * N * 64 / t / 1e6, dm / amax);
+      }
+    }
     char name[64];
     snprintf(name, sizeof name, "%d,%d,%d", B, heads, N);
     printf("%-18s %10.2f %10.2f %10.2f %10.2f %10.2f %10.2f   %8.1f     %s                                    %.2e\n", name, t0, t2, t3, t4, t5, t6,
