@@ -209,7 +209,12 @@ def kernel_profile(model, seq, precision):
     # doubled as MI355X_MICROARCH.md prescribes for gfx950.  Only reported when the committed file names THIS kernel.
     try:
         pm_all = json.load(open(os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")))
-        pm = pm_all["kernels"].get(key) or next((pm_all["kernels"][k] for k in a["keys"] if k in pm_all["kernels"]), None)
+        # (an instance booked from several profiler keys -- paired and single launches -- gets the launch-weighted mean of their entries)
+        pms = [pm_all["kernels"][k] for k in a["keys"] if k in pm_all["kernels"]]
+        pm = None
+        if pms:
+            n = sum(max(q.get("launches", 1), 1) for q in pms)
+            pm = {"traffic_bytes": int(round(sum(q["traffic_bytes"] * max(q.get("launches", 1), 1) for q in pms) / n))}
         if pm and precision == "bf16":
             common["traffic"] = pm["traffic_bytes"]
             common["traffic_build"] = pm_all.get("build", "unknown")

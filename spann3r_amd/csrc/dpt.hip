@@ -78,6 +78,38 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const T* __restrict__ i
   st4(out + idx * 4, o);
 }
 
+// bf16 maps with C % 8 == 0 (every map of the DPT heads): 8 channels = 16 bytes per thread, one output row per blockIdx.y (no
+// per-thread divisions by the image size), the same fp32 arithmetic per element as above (bit-identical results).  A pure
+// bandwidth kernel in front of a convolution: 224 x 224 x 128 went from 11.2 us (8-byte accesses) to the time below.
+__global__ __launch_bounds__(256) void upsample2x_bf16x8_kernel(const __bf16* __restrict__ in, __bf16* __restrict__ out, int H, int W,
+                                                                int C, int outH, int outW) {
+  const int c8 = C >> 3;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= outW * c8) return;
+  const int ox = t / c8, cg = t - ox * c8;
+  const int oy = blockIdx.y, b = blockIdx.z;
+  const int OH = 2 * H, OW = 2 * W;
+  const float sh = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
+  const float sw = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
+  const float fy = sh * (float)oy, fx = sw * (float)ox;
+  int y0 = (int)fy, x0 = (int)fx;
+  y0 = y0 < H - 1 ? y0 : H - 1;
+  x0 = x0 < W - 1 ? x0 : W - 1;
+  const int y1 = y0 < H - 1 ? y0 + 1 : y0, x1 = x0 < W - 1 ? x0 + 1 : x0;
+  const float ly = fy - (float)y0, lx = fx - (float)x0;
+  const float hy = 1.f - ly, hx = 1.f - lx;
+  const __bf16* base = in + (int64_t)b * H * W * C + cg * 8;
+  const bf16x8 v00 = *reinterpret_cast<const bf16x8*>(base + ((int64_t)y0 * W + x0) * C);
+  const bf16x8 v01 = *reinterpret_cast<const bf16x8*>(base + ((int64_t)y0 * W + x1) * C);
+  const bf16x8 v10 = *reinterpret_cast<const bf16x8*>(base + ((int64_t)y1 * W + x0) * C);
+  const bf16x8 v11 = *reinterpret_cast<const bf16x8*>(base + ((int64_t)y1 * W + x1) * C);
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    o[e] = (__bf16)(hy * (hx * (float)v00[e] + lx * (float)v01[e]) + ly * (hx * (float)v10[e] + lx * (float)v11[e]));
+  st_out(reinterpret_cast<bf16x8*>(out + (((int64_t)b * outH + oy) * outW + ox) * C + cg * 8), o);
+}
+
 // 8 lanes per pixel: each lane dots C/8 channels against the 4 output filters, xor-shuffle reduce.
 template <typename T>
 __global__ __launch_bounds__(256) void head_final_kernel(const T* __restrict__ feat, const float* __restrict__ w,
@@ -117,6 +149,56 @@ __global__ __launch_bounds__(256) void head_final_kernel(const T* __restrict__ f
   }
 }
 
+// bf16 maps, C = 8 LP with LP a power of two <= 64 (the heads' 128-channel map: 16 lanes per pixel): a lane keeps its 8 channels of the
+// four filters in registers and walks PPT pixels with 16-byte loads (the kernel above re-loads 64 bytes of weights next to every 8
+// bytes of features); the channel sums meet by xor-shuffles inside the LP-lane group.  224 x 224 x 128: 11.7 us -> see profiles/.
+template <int LP, int PPT>
+__global__ __launch_bounds__(256) void head_final_bf16x8_kernel(const __bf16* __restrict__ feat, const float* __restrict__ w,
+                                                                const float* __restrict__ bias, int64_t pixels, float* __restrict__ pts,
+                                                                float* __restrict__ conf, float* __restrict__ raw) {
+  constexpr int C = 8 * LP, PPB = 256 / LP;                       // pixels per workgroup per step
+  const int li = threadIdx.x % LP, pl = threadIdx.x / LP;
+  float wr[4][8];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    const float4 a = *reinterpret_cast<const float4*>(w + f * C + li * 8), b = *reinterpret_cast<const float4*>(w + f * C + li * 8 + 4);
+    wr[f][0] = a.x; wr[f][1] = a.y; wr[f][2] = a.z; wr[f][3] = a.w; wr[f][4] = b.x; wr[f][5] = b.y; wr[f][6] = b.z; wr[f][7] = b.w;
+  }
+  const float b0 = bias[0], b1 = bias[1], b2 = bias[2], b3 = bias[3];
+  const int64_t p0 = (int64_t)blockIdx.x * PPB * PPT + pl;
+  bf16x8 x[PPT];
+#pragma unroll
+  for (int q = 0; q < PPT; ++q) {
+    int64_t pix = p0 + (int64_t)q * PPB;
+    pix = pix < pixels ? pix : pixels - 1;
+    x[q] = *reinterpret_cast<const bf16x8*>(feat + pix * C + li * 8);
+  }
+#pragma unroll
+  for (int q = 0; q < PPT; ++q) {
+    const int64_t pix = p0 + (int64_t)q * PPB;
+    float a[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { t0 = fmaf((float)x[q][e], wr[f][e], t0); t1 = fmaf((float)x[q][4 + e], wr[f][4 + e], t1); }
+      a[f] = t0 + t1;
+    }
+#pragma unroll
+    for (int o = 1; o < LP; o <<= 1) {
+      a[0] += __shfl_xor(a[0], o); a[1] += __shfl_xor(a[1], o); a[2] += __shfl_xor(a[2], o); a[3] += __shfl_xor(a[3], o);
+    }
+    if (li == 0 && pix < pixels) {
+      const float X = a[0] + b0, Y = a[1] + b1, Z = a[2] + b2, Cc = a[3] + b3;
+      if (raw) *reinterpret_cast<float4*>(raw + pix * 4) = make_float4(X, Y, Z, Cc);
+      const float d = sqrtf(X * X + Y * Y + Z * Z);
+      const float sc = expm1f(d) / fmaxf(d, 1e-8f);
+      pts[pix * 3 + 0] = X * sc; pts[pix * 3 + 1] = Y * sc; pts[pix * 3 + 2] = Z * sc;
+      conf[pix] = 1.0f + expf(Cc);
+    }
+  }
+}
+
 }  // namespace
 
 #define ST(s) reinterpret_cast<hipStream_t>(s)
@@ -146,6 +228,12 @@ extern "C" int sp3_upsample2x(const float* in, float* out, int B, int H, int W, 
 extern "C" int sp3_upsample2x_bf16(const void* in, void* out, int B, int H, int W, int C, int outH, int outW, void* stream) {
   SP3_CHECK(in && out && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "sp3_upsample2x_bf16: bad arguments");
   SP3_CHECK(outH > 0 && outH <= 2 * H && outW > 0 && outW <= 2 * W, "sp3_upsample2x_bf16: bad crop");
+  if (C % 8 == 0 && outH <= 65535 && B <= 65535) {
+    hipLaunchKernelGGL(upsample2x_bf16x8_kernel, dim3((unsigned)((outW * (C / 8) + 255) / 256), outH, B), dim3(256), 0, ST(stream),
+                       reinterpret_cast<const __bf16*>(in), reinterpret_cast<__bf16*>(out), H, W, C, outH, outW);
+    SP3_LAUNCH_CHECK("sp3_upsample2x_bf16");
+    return 0;
+  }
   const int64_t total4 = (int64_t)B * outH * outW * (C / 4);
   hipLaunchKernelGGL(upsample2x_kernel<__bf16>, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, ST(stream),
                      reinterpret_cast<const __bf16*>(in), reinterpret_cast<__bf16*>(out), H, W, C, outH, outW, total4);
@@ -166,6 +254,13 @@ extern "C" int sp3_head_final(const float* feat, const float* w, const float* b,
 extern "C" int sp3_head_final_bf16(const void* feat, const float* w, const float* b, int64_t pixels, int C, float* pts, float* conf,
                                    float* raw, void* stream) {
   SP3_CHECK(feat && w && b && pts && conf && pixels > 0 && C > 0 && C % 32 == 0, "sp3_head_final_bf16: bad arguments");
+  if (C == 128 && (reinterpret_cast<uintptr_t>(feat) & 15) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0 && (!raw || (reinterpret_cast<uintptr_t>(raw) & 15) == 0)) {
+    constexpr int LP = 16, PPT = 4, PPB = 256 / LP;
+    hipLaunchKernelGGL((head_final_bf16x8_kernel<LP, PPT>), dim3((unsigned)((pixels + PPB * PPT - 1) / (PPB * PPT))), dim3(256), 0, ST(stream),
+                       reinterpret_cast<const __bf16*>(feat), w, b, pixels, pts, conf, raw);
+    SP3_LAUNCH_CHECK("sp3_head_final_bf16");
+    return 0;
+  }
   const int64_t threads = pixels * 8;
   hipLaunchKernelGGL(head_final_kernel<__bf16>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ST(stream),
                      reinterpret_cast<const __bf16*>(feat), w, b, pixels, C, pts, conf, raw);

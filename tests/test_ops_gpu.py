@@ -993,6 +993,16 @@ def test_im2col_upsample_headfinal():
     ops.upsample2x(x.permute(0, 2, 3, 1).contiguous().to(DEV), up, B=B, H=4, W_=3, C_=8, outH=7, outW=5)
     ref = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)[:, :, :7, :5]
     assert rel_err(up.cpu(), ref.permute(0, 2, 3, 1)) < 1e-6
+    # bf16 maps: the 16-byte kernel (C % 8 == 0) and the 8-byte one (C = 12) do the fp32 arithmetic of the fp32 kernel on the rounded input
+    for C_ in (16, 12):
+        xb = rnd(B, C_, 9, 6, seed=7).to(torch.bfloat16)
+        nh = xb.permute(0, 2, 3, 1).contiguous().to(DEV)
+        ub = torch.empty(B, 17, 11, C_, device=DEV, dtype=torch.bfloat16)
+        uf = torch.empty(B, 17, 11, C_, device=DEV)
+        ops.upsample2x(nh, ub, B=B, H=9, W_=6, C_=C_, outH=17, outW=11)
+        ops.upsample2x(nh.float(), uf, B=B, H=9, W_=6, C_=C_, outH=17, outW=11)
+        assert torch.equal(ub, uf.to(torch.bfloat16)), C_
+        assert rel_err(uf.cpu(), F.interpolate(xb.float(), scale_factor=2, mode="bilinear", align_corners=True)[:, :, :17, :11].permute(0, 2, 3, 1)) < 1e-6
     # final 1x1 conv + postprocess
     pix, C = 1000, 128
     f, w, b = F.relu(rnd(pix, C, seed=3)), rnd(4, C, seed=4) * 0.1, rnd(4, seed=5)
@@ -1003,3 +1013,12 @@ def test_im2col_upsample_headfinal():
     post = O.postprocess(r.T.reshape(1, 4, 1, pix))
     assert rel_err(pts.cpu(), post["pts3d"].reshape(pix, 3)) < 1e-5
     assert rel_err(conf.cpu(), post["conf"].reshape(pix)) < 1e-5
+    # bf16 feature map (C = 128: the 16-byte kernel; 1003 pixels: ragged last workgroup) against float64 on the rounded features
+    pix = 1003
+    fb = F.relu(rnd(pix, C, seed=6)).to(torch.bfloat16)
+    pts, conf, raw = torch.empty(pix, 3, device=DEV), torch.empty(pix, device=DEV), torch.empty(pix, 4, device=DEV)
+    ops.head_final(fb.to(DEV), w.to(DEV), b.to(DEV), pix, C, pts, conf, raw)
+    r = (fb.double() @ w.double().T + b.double()).float()
+    assert rel_err(raw.cpu(), r) < 1e-5
+    post = O.postprocess(r.T.reshape(1, 4, 1, pix))
+    assert rel_err(pts.cpu(), post["pts3d"].reshape(pix, 3)) < 1e-5 and rel_err(conf.cpu(), post["conf"].reshape(pix)) < 1e-5

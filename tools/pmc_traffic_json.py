@@ -13,10 +13,11 @@ NAMES = {(2, 2, 1, 1, 4, 3, 0): "32x32xk4", (7, 1, 1, 4, 2, 4, 2): "112x64wreg8"
 # the lean instances (csrc/gemm_sm.hip): template arguments -> the tile name spann3r_amd/ops.py gives them
 SM = {(3, 4, 8, 16, 0, 2): 30, (2, 2, 4, 12, 0, 2): 31, (4, 4, 8, 16, 0, 0): 32, (2, 4, 4, 12, 0, 0): 33, (2, 2, 8, 16, 0, 1): 34,
       (2, 2, 8, 64, 4, 1): 35, (3, 2, 6, 12, 0, 1): 36, (3, 2, 8, 48, 3, 1): 37, (4, 2, 7, 28, 0, 1): 38, (3, 2, 8, 16, 0, 1): 39,
-      (4, 2, 7, 28, 0, 0): 42}
+      (4, 2, 7, 28, 0, 0): 42, (2, 2, 8, 16, 0, 3): 43}
 BM = {(4, 2, 4, 16, 3, 2): 50, (2, 2, 4, 16, 3, 2): 51, (2, 2, 4, 12, 3, 2): 52, (4, 2, 4, 16, 3, 0): 53, (2, 2, 4, 16, 3, 0): 54,
       (2, 2, 4, 12, 3, 0): 55, (2, 2, 2, 16, 3, 1): 56, (2, 2, 2, 64, 3, 1): 57, (2, 2, 2, 12, 3, 1): 58, (2, 2, 2, 48, 3, 1): 59,
-      (2, 2, 2, 28, 3, 1): 60, (4, 2, 4, 16, 3, 1): 61, (4, 2, 4, 64, 3, 1): 62}
+      (2, 2, 2, 28, 3, 1): 60, (4, 2, 4, 16, 3, 1): 61, (4, 2, 4, 64, 3, 1): 62, (2, 2, 2, 48, 4, 1): 59, (4, 2, 4, 12, 3, 2): 63,
+      (4, 2, 4, 12, 3, 0): 64}
 
 
 def lean_key(row):
