@@ -404,7 +404,9 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
 
 // ------------------------------------------------------------------ memory write (spann3r/model.py:80-95 + the LayerNorms of :154,174)
 // One launch per stored frame.  A workgroup owns TG consecutive bank tokens (TG = 8 bf16 / 4 fp32 = the tokens that share
-// a 16-byte piece of the fragment-order V^T), aligned to the absolute token index; its 4 waves take the tokens in turn:
+// a 16-byte piece of the fragment-order V^T), aligned to the absolute token index; it has 2 TG waves, ONE per (token, key | value) row
+// -- a frame is only 25 workgroups, so the launch is as long as one wave's dependent chain: with 4 waves taking two tokens' key
+// and value rows in turn it was 15 us, one row per wave brings it to a third (round 5):
 //   k row: raw copy; k_hat = LN_k(k); K' = k_hat (.) gamma_q stored in fragment order (row = token);
 //          s = alpha * sum_c K'_c (of the ROUNDED operand), b = alpha * sum_c beta_q,c k_hat_c  -> fold LN_q into the S GEMM
 //   v row: raw copy; v_hat = LN_v(v) staged in LDS, then written TRANSPOSED in fragment order (row = channel, k = token):
@@ -420,20 +422,22 @@ struct BankWriteArgs {
 };
 
 template <typename TW>
-__global__ __launch_bounds__(256) void bank_write_kernel(const BankWriteArgs a) {
-  constexpr int TG = 16 / (int)sizeof(TW);
+__global__ __launch_bounds__(128 * (16 / (int)sizeof(TW))) void bank_write_kernel(const BankWriteArgs a) {
+  constexpr int TG = 16 / (int)sizeof(TW), NTH = 128 * TG;
   constexpr bool BF = sizeof(TW) == 2;
   extern __shared__ __attribute__((aligned(16))) unsigned char raw_[];
   TW* stage = reinterpret_cast<TW*>(raw_);                 // [TG][C]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int t0 = (a.M / TG + blockIdx.x) * TG;             // first token of this group (absolute bank row)
   const int C = a.C;
-  for (int j = wave; j < TG; j += 4) {
+  {
+    const int j = wave % TG;
+    const bool is_key = wave < TG;                         // waves [0, TG): key rows, [TG, 2 TG): value rows
     const int t = t0 + j;
-    if (t < a.M || t >= a.M + a.P) continue;               // wave-uniform
+    const bool live = t >= a.M && t < a.M + a.P;           // wave-uniform
     const int pr = t - a.M;
     // ---- key row
-    {
+    if (live && is_key) {
       const float* x = a.fk + (int64_t)pr * C;
       float s1 = 0.f, s2 = 0.f;
       for (int c = lane * 4; c < C; c += 256) {
@@ -461,14 +465,20 @@ __global__ __launch_bounds__(256) void bank_write_kernel(const BankWriteArgs a) 
           sb += bqa[e] * kh[e];
         }
         TW* dst = reinterpret_cast<TW*>(a.k_hat) + packed_off(t, c, C, BF);
+        if constexpr (BF) {
+          bf16x4 o4;
+          o4[0] = w[0]; o4[1] = w[1]; o4[2] = w[2]; o4[3] = w[3];
+          *reinterpret_cast<bf16x4*>(dst) = o4;                      // (4 consecutive k stay contiguous in the fragment order)
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dst[e] = w[e];
+          for (int e = 0; e < 4; ++e) dst[e] = w[e];
+        }
       }
       ss = wave_sum(ss); sb = wave_sum(sb);
       if (lane == 0) { a.s_bank[t] = a.alpha * ss; a.b_bank[t] = a.alpha * sb; }
     }
     // ---- value row
-    {
+    if (live && !is_key) {
       const float* x = a.fv + (int64_t)pr * C;
       float s1 = 0.f, s2 = 0.f;
       for (int c = lane * 4; c < C; c += 256) {
@@ -492,7 +502,7 @@ __global__ __launch_bounds__(256) void bank_write_kernel(const BankWriteArgs a) 
   __syncthreads();
   // ---- transposed store of the staged value rows: channel c, tokens t0 .. t0+TG-1 = one 16-byte piece
   const bool whole = t0 >= a.M && t0 + TG <= a.M + a.P;
-  for (int c = threadIdx.x; c < C; c += 256) {
+  for (int c = threadIdx.x; c < C; c += NTH) {
     TW* dst = reinterpret_cast<TW*>(a.v_hat_t) + packed_off(c, t0, a.cap, BF);
     if (whole) {
       TW o[TG];
@@ -631,8 +641,8 @@ extern "C" int sp3_bank_write(const sp3_bank_write_desc* dp, void* stream) {
   const int TG = d.wdtype == SP3_BF16 ? 8 : 4;
   const int groups = (d.M + d.P + TG - 1) / TG - d.M / TG;
   const size_t lds = (size_t)TG * d.C * (d.wdtype == SP3_BF16 ? 2 : 4);
-  if (d.wdtype == SP3_BF16) hipLaunchKernelGGL(bank_write_kernel<__bf16>, dim3(groups), dim3(256), lds, ST(stream), a);
-  else hipLaunchKernelGGL(bank_write_kernel<float>, dim3(groups), dim3(256), lds, ST(stream), a);
+  if (d.wdtype == SP3_BF16) hipLaunchKernelGGL(bank_write_kernel<__bf16>, dim3(groups), dim3(1024), lds, ST(stream), a);
+  else hipLaunchKernelGGL(bank_write_kernel<float>, dim3(groups), dim3(512), lds, ST(stream), a);
   SP3_LAUNCH_CHECK("sp3_bank_write");
   return 0;
 }
