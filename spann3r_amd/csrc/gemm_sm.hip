@@ -396,7 +396,9 @@ __device__ __forceinline__ void bm_glds16(const char* gsrc, char* lds) {
 #endif
 }
 
-template <int WM, int WN, int NF, int NKB, int NST, int EPI>
+// SPLIT (the key MLP's first layer at > 256 rows, spann3r/model.py:300): A = [A | A2] along K as two fragment-order matrices -- the A
+// pieces of k-block kb come from A (kb < nkb1, nkb1 k-blocks per row block) or from A2 (NKB - nkb1 per row block).
+template <int WM, int WN, int NF, int NKB, int NST, int EPI, bool SPLIT = false>
 __global__ __launch_bounds__(64 * WM * WN) void bm_kernel(const SmArgs a) {
   constexpr int MF = 4, NW = WM * WN, NT = 64 * NW;
   constexpr int BM = WM * MF * 16, BN = WN * NF * 16;
@@ -436,7 +438,9 @@ __global__ __launch_bounds__(64 * WM * WN) void bm_kernel(const SmArgs a) {
 
   // ---- DMA pieces of this wave: A row blocks first, then W column blocks (surplus slots repeat the last piece)
   const char* src[PER];
+  const char* src2[SPLIT ? PER : 1];
   int dst[PER];
+  const int nkb1 = SPLIT ? OPF(nkb1) : NKB;
   {
     const char* A = OPF(A) + grp * OPF(gA);
     const char* W = OPF(W) + grp * OPF(gW);
@@ -447,10 +451,12 @@ __global__ __launch_bounds__(64 * WM * WN) void bm_kernel(const SmArgs a) {
       j = j < NINSTR ? j : NINSTR - 1;
       const int blk = j >> 1;
       const char* base;
+      if constexpr (SPLIT) src2[i] = nullptr;
       if (blk < BM / 16) {
         int rb = (m0 >> 4) + blk;
         rb = rb < a.rb_max ? rb : a.rb_max;                   // rows past M: re-read the last block (masked at the store)
-        base = A + (long)rb * NKB * 2048;
+        base = A + (long)rb * nkb1 * 2048;
+        if constexpr (SPLIT) src2[i] = OPF(A2) + grp * OPF(gA2) + ((long)rb * (NKB - nkb1) - nkb1) * 2048 + (j & 1) * 1024 + lane * 16;
       } else {
         int nb = (n0 >> 4) + blk - BM / 16;
         nb = nb < nb_max ? nb : nb_max;
@@ -462,7 +468,11 @@ __global__ __launch_bounds__(64 * WM * WN) void bm_kernel(const SmArgs a) {
   }
   auto issue = [&](int slot, int kb) {
 #pragma unroll
-    for (int i = 0; i < PER; ++i) bm_glds16(src[i] + (long)kb * 2048, lds_b + slot * STAGE_BYTES + dst[i]);
+    for (int i = 0; i < PER; ++i) {
+      const char* p = src[i];
+      if constexpr (SPLIT) p = (kb >= nkb1 && src2[i]) ? src2[i] : p;     // (wave-uniform: a piece is an A piece or a W piece for all lanes)
+      bm_glds16(p + (long)kb * 2048, lds_b + slot * STAGE_BYTES + dst[i]);
+    }
   };
   auto wait_pending = [&](int pend) {
     if (pend >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PER) : "memory");
@@ -737,14 +747,14 @@ __global__ __launch_bounds__(64 * WM * WN) void bm_kernel(const SmArgs a) {
 #undef OPF
 }
 
-template <int WM, int WN, int NF, int NKB, int NST, int EPI>
+template <int WM, int WN, int NF, int NKB, int NST, int EPI, bool SPLIT = false>
 int bm_launch(const SmArgs& a, int mt, int nz, hipStream_t stream) {
   constexpr int BM = WM * 64, BN = WN * NF * 16;
   constexpr size_t ring = (size_t)NST * (BM / 16 + BN / 16) * 2048;
   constexpr size_t vtile = (size_t)WM * WN * 64 * (NF * 16 + 4) * sizeof(float);     // the V columns' transposition (ROPE epilogue)
   constexpr size_t lds = ring > vtile ? ring : vtile;
   static_assert(lds <= 160 * 1024, "stage ring must fit the LDS");
-  auto kern = bm_kernel<WM, WN, NF, NKB, NST, EPI>;
+  auto kern = bm_kernel<WM, WN, NF, NKB, NST, EPI, SPLIT>;
   if (lds > 64 * 1024) {
     static bool raised = false;
     if (!raised) {
@@ -1266,6 +1276,8 @@ const SmInst kInst[] = {
     {64, SM_PACKED, 768, 4, 4, 1, false, 0, 1 << 30, bm_launch<4, 2, 4, 12, 3, SM_PACKED>, 257, 1 << 30, 256, 128, 2048, 1 << 30},   // decoder fc1 at 512x512
     {61, SM_STREAM, 1024, 4, 4, 1, false, 0, 1 << 30, bm_launch<4, 2, 4, 16, 3, SM_STREAM>, 4096, 1 << 30, 256, 128},   // 512x512 whole-sequence encoder (M = 16 x 1024)
     {62, SM_STREAM, 4096, 4, 4, 1, false, 0, 1 << 30, bm_launch<4, 2, 4, 64, 3, SM_STREAM>, 4096, 1 << 30, 256, 128},
+    {66, SM_PACKED, 1792, 4, 4, 1, true, 0, 1 << 30, bm_launch<2, 2, 4, 28, 3, SM_PACKED, true>, 257, 1 << 30, 128, 128, 0, 2047},      // key MLP hidden (split A) above 256 rows: batch 4, 512x512
+    {67, SM_PACKED, 1792, 4, 4, 1, true, 0, 1 << 30, bm_launch<4, 2, 4, 28, 3, SM_PACKED, true>, 257, 1 << 30, 256, 128, 2048, 1 << 30},
     {56, SM_STREAM, 1024, 4, 2, 1, false, 0, 1 << 30, bm_launch<2, 2, 2, 16, 3, SM_STREAM>, 257, 1 << 30, 128, 64},    // encoder proj
     {57, SM_STREAM, 4096, 4, 2, 1, false, 0, 1 << 30, bm_launch<2, 2, 2, 64, 3, SM_STREAM>, 257, 1 << 30, 128, 64},    // encoder fc2
     {58, SM_STREAM, 768, 4, 2, 1, false, 0, 1 << 30, bm_launch<2, 2, 2, 12, 3, SM_STREAM>, 257, 1 << 30, 128, 64},

@@ -588,7 +588,7 @@ class Engine:
         assert dF % 16 == 0 and dN % 16 == 0 and dO % 16 == 0
         es = 2 if self.adt == torch.bfloat16 else 4
         h = self.wspg("keyg_hidden", R, Kd)
-        if feat1p is not None and feat2p is not None and self.adt == torch.bfloat16 and R <= 256 and ops.LEAN:     # (R: the lean instances' row limit; a packed split A has no general tile)
+        if feat1p is not None and feat2p is not None and self.adt == torch.bfloat16 and ops.LEAN:     # (a packed split A has no general tile: tiles 42 / 66 / 67)
             np_ = self.wspg("decg_normed_packed", R, D)
             dFp = feat2p.data_ptr() - feat1p.data_ptr()
             assert dFp % 16 == 0

@@ -243,6 +243,11 @@ class SpatialMemory:
                     ops.gemm(A, Wv, part, M=P, N=C, K=Kp, lda=Kp, ldc=C, ldw=self.cap, splitk=S_k)
                     ops.reduce_ln(part, S_k, P, C, res=feat[b], ldres=C, x_out=out[b], ldx=C)
                 ops.colsum_packed(pk[b], P, M, bk["attn"][b])
+            if out_packed is not None and B == 1:
+                # the long-bank compositions end in fp32 rows: one small launch makes the fragment-order copy decoder_embed reads
+                # (otherwise that GEMM and the key MLP's first layer fall back to fp32 rows on the general kernel)
+                ops.pack_stats(out[0], out_packed, eng.ws("mem_out_stats", (P, C // 32, 2)), rows=P, C_=C)
+                self.wrote_packed = True
         if prof is not None:
             es = bk["k_hat"].element_size()
             # algorithmic bytes of one read: K_hat + V_hat once, plus the query in and the fused features out

@@ -114,7 +114,7 @@ _TILE_NAMES = {0: "32x32xk4", 1: "64x64", 2: "64x128", 3: "64x64xk4", 4: "32x64x
                50: "lean-rope-k1024-256x128", 51: "lean-rope-k1024-128x128", 52: "lean-rope-k768-128x128", 53: "lean-packed-k1024-256x128",
                54: "lean-packed-k1024-128x128", 55: "lean-packed-k768-128x128", 56: "lean-stream-k1024-128x64", 57: "lean-stream-k4096-128x64",
                58: "lean-stream-k768-128x64", 59: "lean-stream-k3072-128x64", 60: "lean-stream-k1792-128x64",
-               61: "lean-stream-k1024-256x128", 62: "lean-stream-k4096-256x128", 63: "lean-rope-k768-256x128", 64: "lean-packed-k768-256x128", 65: "lean-rope-k768-128x64"}
+               61: "lean-stream-k1024-256x128", 62: "lean-stream-k4096-256x128", 63: "lean-rope-k768-256x128", 64: "lean-packed-k768-256x128", 65: "lean-rope-k768-128x64", 66: "lean-packed-splitA-k1792-128x128", 67: "lean-packed-splitA-k1792-256x128"}
 
 
 def pick_tile(M, N, batch=1, splitk=1, conv=False, K=0, packed_bf16=False, plain=False, ln_nt=0, pipe_ok=False, rope=False):

@@ -291,11 +291,13 @@ def test_lean_conv3x3_small_maps(B, H, W, Cin, Cout, stride, variant, maps):
         assert rel_err(outs[-1], outs[0]) < 2e-5
 
 
-def test_lean_split_a_key_mlp():
+@pytest.mark.parametrize("M,tile", [(196, 42), (784, 66), (1024, 67), (1000, 66)])
+def test_lean_split_a_key_mlp(M, tile):
     """first layer of the key MLPs (spann3r/model.py:299-303: Linear(1792, 1792) + GELU on cat(feat, dec[-1])) with both halves of the
-    concatenation as fragment-order bf16 matrices, both MLPs in one launch (tile 42), against the row-major split-A path"""
+    concatenation as fragment-order bf16 matrices, both MLPs in one launch (tile 42; the many-row instances 66 / 67 above 256 rows:
+    batch 4 and 512x512 frames), against the row-major split-A path"""
     ops = _ops()
-    M, E, D, Kd, G = 196, 1024, 768, 1792, 2
+    E, D, Kd, G = 1024, 768, 1792, 2
     f = [rnd(M, E, seed=1 + g) for g in range(G)]
     nrm = [rnd(M, D, seed=5 + g) for g in range(G)]
     Fp = ops.PackedAct.group(G, M, E, BF, DEV)
@@ -310,7 +312,7 @@ def test_lean_split_a_key_mlp():
     planned = _plan_of(ops, lambda: ops.gemm(Fp, Ws, h, M=M, N=Kd, K=Kd, lda=E, ldc=Kd, bias=bias.to(DEV), act=ops.ACT_GELU, A2=Np, lda2=D, K1=E,
                                              batch=G, strideA=Fp.stride, strideW=Ws.stride, strideC=h.stride,
                                              sb={"bias": Kd * 4, "A2": Np.stride * 2}))
-    assert planned == [42]
+    assert planned == [tile]
     # the general kernel on the fp32 row-major halves (what the model ran before)
     fd, nd = torch.stack(f).to(DEV).to(BF).float().contiguous(), torch.stack(nrm).to(DEV).to(BF).float().contiguous()
     h0 = ops.PackedAct.group(G, M, Kd, BF, DEV)
