@@ -12,6 +12,7 @@
 // bf16: v_mfma_f32_16x16x32_bf16; fp32: v_mfma_f32_16x16x4_f32 (exact fp32, parity mode).
 #include "common.h"
 #include <math.h>
+#include <cstdlib>
 
 namespace {
 
@@ -316,18 +317,42 @@ template <> struct AttnT<BF16X1> {
   }
 };
 
+// Workgroup -> (query tile, head, batch).  xcd_map = heads x B (0: the plain (query tiles, heads, B) grid).  Workgroup L of the dispatch
+// order runs on XCD L % 8: hand every XCD WHOLE (head, batch) pairs {x, x + 8, ..} with all their query tiles, so a pair's K / V^T are
+// fetched by one L2 instead of by all eight (the plain grid spreads the query tiles of a pair over the XCDs).  The grid is then (query
+// tiles, pairs rounded up to a multiple of 8); the surplus pairs exit (returns false).  Measured with cold operands
+// (tools/bench_attention_long.py, packed bf16 kernel): 2 x 12 heads x 196 tokens 5.09 -> 3.85 us, 10 x 16 x 196 14.97 -> 11.04,
+// 2 x 16 x 1024 23.3 -> 21.8, 16 x 16 x 1024 142 -> 131 us.
+__device__ __forceinline__ bool attn_tile_of(int xcd_map, int heads, int& qt, int& h, int& b) {
+  qt = blockIdx.x; h = blockIdx.y; b = blockIdx.z;
+  if (xcd_map) {
+    const unsigned L = blockIdx.x + gridDim.x * blockIdx.y, xc = L & 7, jj = L >> 3, pq = jj / gridDim.x;
+    const unsigned pair = xc + 8 * pq;
+    if (pair >= (unsigned)xcd_map) return false;
+    qt = (int)(jj - pq * gridDim.x);
+    b = (int)(pair / (unsigned)heads);
+    h = (int)(pair - (unsigned)b * heads);
+  }
+  return true;
+}
+static bool attn_xcd_on() {
+  static const bool on = [] { const char* e = getenv("SP3_ATTN_XCD"); return !(e && e[0] == '0'); }();    // (A/B switch: 0 = the plain grid)
+  return on;
+}
+
 template <typename TT>
 __global__ __launch_bounds__(256) void attention_kernel(const typename AttnT<TT>::Store* __restrict__ Q, int64_t sq, int64_t ldq,
                                                        const typename AttnT<TT>::Store* __restrict__ K, int64_t sk, int64_t ldk,
                                                        const typename AttnT<TT>::Store* __restrict__ VT, int64_t vt_ld, void* __restrict__ O,
                                                        int64_t ldo, int out_bf16, int out_packed, int heads, int Nq, int Nk,
-                                                       float scale, float* __restrict__ lse) {
+                                                       float scale, float* __restrict__ lse, int xcd_map) {
   using A = AttnT<TT>;
   using T = typename A::Store;
   __shared__ float sh_o[4][4][64][4];   // [wave][db][lane][r]
   __shared__ float sh_m[4][64], sh_l[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, ql = lane & 15;
-  const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  int qt, h, b;
+  if (!attn_tile_of(xcd_map, heads, qt, h, b)) return;
   const int q0 = qt * 16;
   int qrow = q0 + ql;
   qrow = qrow < Nq ? qrow : Nq - 1;
@@ -458,13 +483,14 @@ __global__ __launch_bounds__(256, MINW) void attention_packed_kernel(const __bf1
                                                                      const __bf16* __restrict__ KP, int k_cols, int k_col0, int npad_k,
                                                                      const __bf16* __restrict__ VTP, void* __restrict__ O, int64_t ldo,
                                                                      int out_bf16, int out_packed, int heads, int Nq, int Nk, float scale,
-                                                                     int o_group, int o_group_rows) {
+                                                                     int o_group, int o_group_rows, int xcd_map) {
   extern __shared__ __attribute__((aligned(16))) float sh[];
   float* sh_o = sh;                                  // [wave][qb][db][lane][4]
   float* sh_m = sh + 4 * QB * 4 * 64 * 4;            // [wave][qb][lane]
   float* sh_l = sh_m + 4 * QB * 64;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, ql = lane & 15;
-  const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  int qt, h, b;
+  if (!attn_tile_of(xcd_map, heads, qt, h, b)) return;
   const int q0 = qt * 16 * QB;
   const int last_qrow = npad_q - 16;                 // query blocks past the padded rows re-read the last block (their results are dropped)
   KFrag qf[QB];
@@ -796,24 +822,25 @@ extern "C" int sp3_attention_ex(const void* q, int64_t sq, int64_t ldq, const vo
   SP3_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && (out_packed || ldo % 4 == 0), "sp3_attention: row strides must keep 16-byte alignment");
   SP3_CHECK(dtype == SP3_F32 || dtype == SP3_BF16 || dtype == 2 || dtype == 3,
             "sp3_attention: bad dtype %d (0 fp32, 1 bf16, 2 / 3: fp32 operands with bf16x3 / fp16x3 split products)", dtype);
-  dim3 grid((Nq + 15) / 16, heads, B);
+  const int xcd_map = attn_xcd_on() ? heads * B : 0;
+  dim3 grid((Nq + 15) / 16, xcd_map ? (heads * B + 7) / 8 * 8 : heads, xcd_map ? 1 : B);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == SP3_BF16)
     hipLaunchKernelGGL(attention_kernel<__bf16>, grid, dim3(256), 0, st, reinterpret_cast<const __bf16*>(q), sq, ldq,
                        reinterpret_cast<const __bf16*>(k), sk, ldk, reinterpret_cast<const __bf16*>(vt), vt_ld, out, ldo,
-                       out_bf16, out_packed, heads, Nq, Nk, scale, (float*)nullptr);
+                       out_bf16, out_packed, heads, Nq, Nk, scale, (float*)nullptr, xcd_map);
   else if (dtype == 3)
     hipLaunchKernelGGL(attention_kernel<F16X3>, grid, dim3(256), 0, st, reinterpret_cast<const float*>(q), sq, ldq,
                        reinterpret_cast<const float*>(k), sk, ldk, reinterpret_cast<const float*>(vt), vt_ld, out, ldo, out_bf16,
-                       out_packed, heads, Nq, Nk, scale, (float*)nullptr);
+                       out_packed, heads, Nq, Nk, scale, (float*)nullptr, xcd_map);
   else if (dtype == 2)
     hipLaunchKernelGGL(attention_kernel<F32X3>, grid, dim3(256), 0, st, reinterpret_cast<const float*>(q), sq, ldq,
                        reinterpret_cast<const float*>(k), sk, ldk, reinterpret_cast<const float*>(vt), vt_ld, out, ldo, out_bf16,
-                       out_packed, heads, Nq, Nk, scale, (float*)nullptr);
+                       out_packed, heads, Nq, Nk, scale, (float*)nullptr, xcd_map);
   else
     hipLaunchKernelGGL(attention_kernel<float>, grid, dim3(256), 0, st, reinterpret_cast<const float*>(q), sq, ldq,
                        reinterpret_cast<const float*>(k), sk, ldk, reinterpret_cast<const float*>(vt), vt_ld, out, ldo, out_bf16,
-                       out_packed, heads, Nq, Nk, scale, (float*)nullptr);
+                       out_packed, heads, Nq, Nk, scale, (float*)nullptr, xcd_map);
   SP3_LAUNCH_CHECK("sp3_attention");
   return 0;
 }
@@ -835,17 +862,21 @@ extern "C" int sp3_attention_packed(const void* qp, int q_cols, int q_col0, int 
   SP3_CHECK(out_packed || ldo % 4 == 0, "sp3_attention_packed: ldo");
   SP3_CHECK(o_group == 0 || (o_group > 0 && B % o_group == 0 && o_group_rows >= o_group * Nq), "sp3_attention_packed: output grouping");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int np = heads * B, xcd_map = attn_xcd_on() ? np : 0;
+  const dim3 tail = xcd_map ? dim3((np + 7) / 8 * 8, 1) : dim3(heads, B);
   // two query blocks per workgroup once the grid still fills the chip that way (profiles/r05_attn_long_variants.txt)
   if (Nq >= 512) {
     constexpr int QB = 2, lds = (4 * QB * 4 * 64 * 4 + 2 * 4 * QB * 64) * 4;
-    hipLaunchKernelGGL((attention_packed_kernel<QB, 3>), dim3((Nq + 16 * QB - 1) / (16 * QB), heads, B), dim3(256), lds, st,
+    hipLaunchKernelGGL((attention_packed_kernel<QB, 3>), dim3((Nq + 16 * QB - 1) / (16 * QB), tail.x, tail.y), dim3(256), lds, st,
                        reinterpret_cast<const __bf16*>(qp), q_cols, q_col0, npad_q, reinterpret_cast<const __bf16*>(kp), k_cols, k_col0,
-                       npad_k, reinterpret_cast<const __bf16*>(vtp), out, ldo, out_bf16, out_packed, heads, Nq, Nk, scale, o_group, o_group_rows);
+                       npad_k, reinterpret_cast<const __bf16*>(vtp), out, ldo, out_bf16, out_packed, heads, Nq, Nk, scale, o_group, o_group_rows,
+                       xcd_map);
   } else {
     constexpr int QB = 1, lds = (4 * QB * 4 * 64 * 4 + 2 * 4 * QB * 64) * 4;
-    hipLaunchKernelGGL((attention_packed_kernel<QB, 4>), dim3((Nq + 15) / 16, heads, B), dim3(256), lds, st,
+    hipLaunchKernelGGL((attention_packed_kernel<QB, 4>), dim3((Nq + 15) / 16, tail.x, tail.y), dim3(256), lds, st,
                        reinterpret_cast<const __bf16*>(qp), q_cols, q_col0, npad_q, reinterpret_cast<const __bf16*>(kp), k_cols, k_col0,
-                       npad_k, reinterpret_cast<const __bf16*>(vtp), out, ldo, out_bf16, out_packed, heads, Nq, Nk, scale, o_group, o_group_rows);
+                       npad_k, reinterpret_cast<const __bf16*>(vtp), out, ldo, out_bf16, out_packed, heads, Nq, Nk, scale, o_group, o_group_rows,
+                       xcd_map);
   }
   SP3_LAUNCH_CHECK("sp3_attention_packed");
   return 0;
@@ -858,12 +889,13 @@ extern "C" int sp3_attention_train_fwd(const float* q, int64_t sq, int64_t ldq, 
   SP3_CHECK(B > 0 && heads > 0 && Nq > 0 && Nk > 0 && B <= 65535 && heads <= 65535, "sp3_attention_train_fwd: bad shape");
   SP3_CHECK(vt_ld >= ((Nk + 63) / 64) * 64 && vt_ld % 8 == 0, "sp3_attention_train_fwd: vt_ld=%lld must be >= Nk padded to 64", (long long)vt_ld);
   SP3_CHECK(ldq % 4 == 0 && ldk % 4 == 0 && ldo % 4 == 0 && sq % 4 == 0 && sk % 4 == 0, "sp3_attention_train_fwd: strides must keep 16-byte alignment");
-  dim3 grid((Nq + 15) / 16, heads, B);
+  const int xcd_map = attn_xcd_on() ? heads * B : 0;
+  dim3 grid((Nq + 15) / 16, xcd_map ? (heads * B + 7) / 8 * 8 : heads, xcd_map ? 1 : B);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (bf16_products)
-    hipLaunchKernelGGL(attention_kernel<BF16X1>, grid, dim3(256), 0, st, q, sq, ldq, k, sk, ldk, vt, vt_ld, (void*)out, ldo, 0, 0, heads, Nq, Nk, scale, lse);
+    hipLaunchKernelGGL(attention_kernel<BF16X1>, grid, dim3(256), 0, st, q, sq, ldq, k, sk, ldk, vt, vt_ld, (void*)out, ldo, 0, 0, heads, Nq, Nk, scale, lse, xcd_map);
   else
-    hipLaunchKernelGGL(attention_kernel<float>, grid, dim3(256), 0, st, q, sq, ldq, k, sk, ldk, vt, vt_ld, (void*)out, ldo, 0, 0, heads, Nq, Nk, scale, lse);
+    hipLaunchKernelGGL(attention_kernel<float>, grid, dim3(256), 0, st, q, sq, ldq, k, sk, ldk, vt, vt_ld, (void*)out, ldo, 0, 0, heads, Nq, Nk, scale, lse, xcd_map);
   SP3_LAUNCH_CHECK("sp3_attention_train_fwd");
   return 0;
 }

@@ -15,6 +15,7 @@
 // Reference ops: croco/models/dpt_block.py:33-75 (ResidualConvUnit), 95-113 (head convs), 180-188 (layer_rn).
 #include "common.h"
 #include <type_traits>
+#include <cstdlib>
 
 namespace {
 
@@ -29,7 +30,23 @@ constexpr int SP3_CONV_WIDE_MIN_WGS = 256;    // 8 x 16 x 64-channel tile from t
 struct ConvArgs {
   const void* x; const __bf16* w; const float* bias; const float* res1; const float* res2; void* out;
   int B, H, W, Cin, Cout, tiles_x, tiles_y, relu_in, act, out_bf16;
+  int xcd_nb;      // > 0: 1-D grid, XCD x (= workgroup id % 8) owns the pixel tiles {x, x + 8, ..} with all their xcd_nb output-channel blocks
 };
+
+// workgroup -> (pixel tile, output-channel block).  Plain grid: x = pixel tile, y = channel block -- the channel blocks of a pixel tile
+// are gridDim.x apart in dispatch order and land on different XCDs, so every L2 fetches the tile's halo (PMC: 2.6 x the algorithmic
+// bytes per launch).  xcd_nb: the channel blocks of a tile are consecutive workgroups of ONE XCD; returns false for the padding
+// workgroups of the last group of 8 tiles.
+__device__ __forceinline__ bool conv_tile_of(const ConvArgs& a, int& t, int& nblk) {
+  t = blockIdx.x; nblk = blockIdx.y;
+  if (a.xcd_nb) {
+    const unsigned L = blockIdx.x, xc = L & 7, jj = L >> 3, q = jj / (unsigned)a.xcd_nb;
+    nblk = (int)(jj - q * a.xcd_nb);
+    t = (int)(q * 8 + xc);
+    if (t >= a.tiles_x * a.tiles_y * a.B) return false;
+  }
+  return true;
+}
 
 __device__ __forceinline__ bf16x8 ld_frag_lds(const char* p) { return *reinterpret_cast<const bf16x8*>(p); }
 
@@ -39,11 +56,12 @@ __global__ __launch_bounds__(256) void conv3x3_tile_kernel(const ConvArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r = lane & 15;
   const int Cin = a.Cin;
   const int PS = Cin * 2 + 16;                // halo pixel stride in bytes
-  int t = blockIdx.x;
+  int t, nblk;
+  if (!conv_tile_of(a, t, nblk)) return;
   const int tx = t % a.tiles_x; t /= a.tiles_x;
   const int ty = t % a.tiles_y;
   const int b = t / a.tiles_y;
-  const int y0 = ty * TH, x0 = tx * TW, n0 = blockIdx.y * BN;
+  const int y0 = ty * TH, x0 = tx * TW, n0 = nblk * BN;
 
   // ---- W stream set-up: unit u = (tap, 32-channel group); fragment-order weight [Cout/16][K/64][2 halves][64 lanes][8]
   const int upt = Cin >> 5;                   // units per tap
@@ -246,11 +264,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const ConvArgs a) 
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, r = lane & 15;
   const int Cin = a.Cin;
-  int t = blockIdx.x;
+  int t, nblk;
+  if (!conv_tile_of(a, t, nblk)) return;
   const int tx = t % a.tiles_x; t /= a.tiles_x;
   const int ty = t % a.tiles_y;
   const int b = t / a.tiles_y;
-  const int y0 = ty * TH, x0 = tx * TW, n0 = blockIdx.y * BN;
+  const int y0 = ty * TH, x0 = tx * TW, n0 = nblk * BN;
   const int nchunk = Cin / CH, upt = Cin >> 5;                     // chunks; 32-deep units per tap in the weight's K order
   const int total = 9 * nchunk;                                    // units of this wave: (chunk, tap), tap fastest
 
@@ -445,6 +464,8 @@ extern "C" int sp3_conv3x3_tile(const void* x, int in_bf16, const void* w_packed
   a.x = x; a.w = reinterpret_cast<const __bf16*>(w_packed); a.bias = bias; a.res1 = res1; a.res2 = res2; a.out = out;
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
   a.relu_in = relu_in; a.act = act; a.out_bf16 = out_bf16 & 3;
+  a.xcd_nb = 0;
+  static const bool xcd_on = [] { const char* e = getenv("SP3_CONV_XCD"); return !(e && e[0] == '0'); }();      // (A/B switch)
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   {
     // tile choice (out_bf16 bits 2-3: 0 = by size, 1 = 8 x 8 pixels, 2 = 8 x 16 pixels x 64 channels, 3 = 8 x 16 pixels x 32 channels): the
@@ -460,6 +481,7 @@ extern "C" int sp3_conv3x3_tile(const void* x, int in_bf16, const void* w_packed
     if (nf) {
       a.tiles_x = wtx; a.tiles_y = wty;
       dim3 grid(wtx * wty * B, Cout / (16 * nf));
+      if (xcd_on) { a.xcd_nb = Cout / (16 * nf); grid = dim3((unsigned)(((wtx * wty * B + 7) / 8) * 8 * a.xcd_nb), 1); }
       auto launch = [&](auto kern, int lds_bytes) -> int {
         static bool raised = false;               // per instantiation: opt in to > 64 KiB of dynamic LDS once
         if (!raised && lds_bytes > 64 * 1024) {
@@ -483,6 +505,7 @@ extern "C" int sp3_conv3x3_tile(const void* x, int in_bf16, const void* w_packed
   const size_t lds = halo > slabs ? halo : slabs;
   SP3_CHECK(lds <= 160 * 1024, "sp3_conv3x3_tile: Cin=%d needs %zu bytes of LDS", Cin, lds);
   dim3 grid(a.tiles_x * a.tiles_y * B, Cout / BN);
+  if (xcd_on) { a.xcd_nb = Cout / BN; grid = dim3((unsigned)(((a.tiles_x * a.tiles_y * B + 7) / 8) * 8 * a.xcd_nb), 1); }
   auto launch = [&](auto kern) -> int {
     static size_t raised = 0;                 // per instantiation: opt in to > 64 KiB of dynamic LDS once per size
     if (lds > 64 * 1024 && lds > raised) {

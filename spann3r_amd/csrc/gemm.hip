@@ -36,6 +36,7 @@ struct GemmArgs {
   sp3_gemm_desc d;
   sp3_gemm_desc d2;
   int nb1;
+  int xcd_slices;        // split-K slices mapped to XCDs (see the tile map)
 };
 
 // ------------------------------------------------------------------ per-dtype operand handling
@@ -486,9 +487,19 @@ void gemm_kernel(const GemmArgs args) {
 
   const int mt = (d.M + BM - 1) / BM, nt = (d.N + BN - 1) / BN;
   // XCD-aware tile mapping (block b -> XCD b & 7); grid is padded, out-of-range tiles exit.
+  // Split-K over a multiple of 8 slices (the long-bank P.V GEMM of the memory read: 16 slices x 32 tiles): XCD x takes the slices
+  // {x, x + 8, ..} with ALL their tiles, so the two operand slabs of a slice are fetched by ONE L2 instead of by all eight (PMC,
+  // profiles/r05_memread_long_bank_launch_breakdown.txt: 904 MB fetched for 206 MB of operands with the slices spread over the XCDs).
+  // Dispatch order L = x + gridDim.x * z (gridDim.x % 8 == 0, gridDim.y == 1) -> XCD L % 8.
   int tile_m, tile_n;
+  int bx = blockIdx.x, kz = blockIdx.z;
+  if (args.xcd_slices) {
+    const unsigned L = blockIdx.x + gridDim.x * blockIdx.z, xc = L & 7, jj = L >> 3, q = jj / gridDim.x;
+    kz = (int)(xc + 8 * q);
+    bx = (int)(jj - q * gridDim.x);
+  }
   {
-    const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
+    const int b = bx, xcd = b & 7, j = b >> 3;
     if (mt >= nt) {          // large M: the tiles that share an A panel sit on one XCD
       tile_n = j % nt;
       tile_m = (j / nt) * 8 + xcd;
@@ -503,7 +514,6 @@ void gemm_kernel(const GemmArgs args) {
   const int wk = wave % WK, wn = (wave / WK) % WN, wm = wave / (WK * WN);
   const int g = lane >> 4;
   const int bz = second ? (int)blockIdx.y - args.nb1 : (int)blockIdx.y;
-  const int kz = blockIdx.z;
   if (d.batch > 1) {                         // grouped launch: problem bz (wave-uniform pointer arithmetic)
     auto shift = [&](auto*& p, int64_t bytes) {
       using P = std::remove_reference_t<decltype(p)>;
@@ -1671,6 +1681,8 @@ int launch(const sp3_gemm_desc& d, hipStream_t stream) {
   } else {
     a.d2 = d;
   }
+  static const bool xs_on = [] { const char* e = getenv("SP3_SPLITK_XCD"); return !(e && e[0] == '0'); }();      // (A/B switch)
+  a.xcd_slices = (xs_on && gy == 1 && d.splitk >= 8 && d.splitk % 8 == 0 && blocks % 8 == 0) ? 1 : 0;
   hipLaunchKernelGGL(kern, dim3(blocks, gy, d.splitk), dim3(NT), lds, stream, a);
   SP3_LAUNCH_CHECK("sp3_gemm");
   return 0;

@@ -199,6 +199,24 @@ def test_gemm_bf16_activations(M, N, K, tile):
     assert rel_err(out32.cpu(), Ab.double() @ bf(W).double().T) < TOL[torch.bfloat16]
 
 
+@pytest.mark.parametrize("M,N,K,S,tile", [(300, 384, 8 * 192, 8, -1), (520, 512, 16 * 256, 16, -1), (520, 512, 16 * 256, 16, 23), (130, 640, 16 * 128, 16, 20)])
+def test_splitk_slices_on_xcds(M, N, K, S, tile):
+    """Split-K over a multiple of 8 slices: the launch hands whole K slices to the XCDs (gemm_kernel's tile map).  Every partial is
+    checked against ITS slice of the product, so a slice that lands in the wrong partial (or is computed twice) shows."""
+    ops = _ops()
+    wdt = torch.bfloat16
+    A, W = rnd(M, K, seed=11), rnd(N, K, seed=12) * 0.05
+    Ap = ops.PackedAct.from_dense(A.to(DEV).to(wdt))
+    Wp = ops.PackedWeight(W.to(DEV).to(wdt))
+    part = torch.full((S, M, N), float("nan"), device=DEV)
+    ops.gemm(Ap, Wp, part, M=M, N=N, K=K, lda=K, ldc=N, splitk=S, tile=tile)
+    Ar, Wr = bf(A).double(), bf(W).double()
+    per = K // S
+    for s_ in range(S):
+        ref = Ar[:, s_ * per:(s_ + 1) * per] @ Wr[:, s_ * per:(s_ + 1) * per].T
+        assert rel_err(part[s_].cpu(), ref) < 1e-5, s_
+
+
 @pytest.mark.parametrize("wdt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,N,K,S", [(196, 1024, 4096, 4), (196, 768, 768, 1), (392, 1024, 1024, 2), (20, 768, 3080, 3)])
 def test_splitk_reduce_ln(wdt, M, N, K, S):
@@ -538,7 +556,8 @@ def _pack_v_for_pv(v, npad):
 
 
 @pytest.mark.parametrize("B,heads,Nq,Nk", [(1, 16, 196, 196), (2, 12, 20, 20), (1, 12, 50, 300), (2, 3, 17, 65),
-                                           (1, 4, 1024, 1024), (2, 3, 100, 700), (1, 2, 70, 513)])     # (long sequences: up to 16 key tiles, 4 per wave)
+                                           (1, 4, 1024, 1024), (2, 3, 100, 700), (1, 2, 70, 513),      # (long sequences: up to 16 key tiles, 4 per wave)
+                                           (2, 4, 530, 530), (4, 2, 100, 600), (3, 8, 33, 520), (2, 12, 1024, 1024)])   # heads x B % 8 == 0 at >= 512 keys: whole (head, batch) pairs per XCD
 def test_attention_packed(B, heads, Nq, Nk):
     """bf16 attention on fragment-order q/k + PV-order V == softmax(qk^T/8)v on the bf16-rounded operands."""
     ops = _ops()

@@ -156,6 +156,14 @@ def test_pnp_oracle_pieces():
         assert np.abs(Re - R).max() < 1e-6 and np.abs(te - t).max() < 1e-6, n
     r2, t2 = CV.solve_pnp_iterative(X, px + rng.normal(0, 0.05, px.shape), K)
     assert np.abs(r2 - rv).max() < 2e-3 and np.abs(t2 - t).max() < 5e-3
+    # independent anchor for the refinement: scipy's MINPACK Levenberg-Marquardt on the same reprojection residual must land on the
+    # same minimiser (the restated CvLevMarq stops at |dx| / |x| < eps = 2.2e-16 or 20 iterations, like OpenCV)
+    from scipy.optimize import least_squares
+    pxn = px + np.random.default_rng(5).normal(0, 0.05, px.shape)
+    r2n, t2n = CV.solve_pnp_iterative(X, pxn, K)
+    sol = least_squares(lambda p: (CV.project(X, p[:3], p[3:], K) - pxn).reshape(-1), np.concatenate((r2n, t2n)) + 1e-3, method="lm",
+                        xtol=1e-15, ftol=1e-15, gtol=1e-15)
+    assert np.abs(sol.x - np.concatenate((r2n, t2n))).max() < 1e-6, np.abs(sol.x - np.concatenate((r2n, t2n))).max()
     r3, t3 = CV.solve_pnp_iterative(X, px, K)
     assert np.abs(r3 - rv).max() < 1e-8 and np.abs(t3 - t).max() < 1e-8
     p, J = CV.project(X, rv, t, K, jac=True)

@@ -1,5 +1,7 @@
 #!/usr/bin/env python
-"""us per launch of sp3_attention_packed at long sequences (config 3: 1024 tokens per frame)."""
+"""us per launch of sp3_attention_packed (config 3: 1024 tokens per frame; the 196-token launches of the headline), rotating operand
+copies so that no launch finds its K / V^T in the L2 a previous one left them in.  SP3_ATTN_XCD=0/1/2 selects the workgroup -> (head,
+batch) map (csrc/attention.hip): run once per value for an A/B."""
 import os
 import sys
 
@@ -9,21 +11,33 @@ import torch  # noqa: E402
 from spann3r_amd import ops  # noqa: E402
 
 dev = "cuda"
-for B, heads, N in ((1, 16, 1024), (2, 12, 1024)):
+print("SP3_ATTN_XCD =", os.environ.get("SP3_ATTN_XCD", "(default)"))
+for B, heads, N in ((2, 16, 1024), (2, 12, 1024), (16, 16, 1024), (2, 12, 196), (10, 16, 196), (2, 16, 196)):
     C = heads * 64
-    qp = ops.PackedAct.from_dense(torch.randn(B * N, C, device=dev).to(torch.bfloat16))
-    kp = ops.PackedAct.from_dense(torch.randn(B * N, C, device=dev).to(torch.bfloat16))
-    vp = torch.randn(B * heads * (N // 32) * 4 * 64 * 8, device=dev).to(torch.bfloat16)
-    out = ops.PackedAct(B * N, C, torch.bfloat16, dev)
-    fn = lambda: ops.attention_packed(qp, C, 0, N, kp, C, 0, N, vp, out, C, B=B, heads=heads, Nq=N, Nk=N, scale=0.125)
-    for _ in range(5):
-        fn()
+    Np = (N + 63) // 64 * 64
+    copies = []
+    for _ in range(6):
+        qp = ops.PackedAct.from_dense(torch.randn(B * Np, C, device=dev).to(torch.bfloat16))
+        kp = ops.PackedAct.from_dense(torch.randn(B * Np, C, device=dev).to(torch.bfloat16))
+        vp = torch.randn(B * heads * (Np // 32) * 4 * 64 * 8, device=dev).to(torch.bfloat16)
+        copies.append((qp, kp, vp))
+    out = ops.PackedAct(B * Np, C, torch.bfloat16, dev)
+    fn = lambda c: ops.attention_packed(c[0], C, 0, Np, c[1], C, 0, Np, c[2], out, C, B=B, heads=heads, Nq=N, Nk=N, scale=0.125)
+    for c in copies:
+        fn(c)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(5):
+            for c in copies:
+                fn(c)
+    g.replay()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(200):
-        fn()
+    for _ in range(10):
+        g.replay()
     e1.record()
     torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / 200
-    print("attention_packed B %d heads %d N %d: %.1f us = %.0f TFLOP/s" % (B, heads, N, us, 4.0 * B * heads * N * N * 64 / us / 1e6))
+    us = e0.elapsed_time(e1) * 1e3 / (10 * 5 * len(copies))
+    print("attention_packed B %2d heads %2d N %4d: %6.2f us = %4.0f TFLOP/s" % (B, heads, N, us, 4.0 * B * heads * N * N * 64 / us / 1e6))

@@ -10,6 +10,7 @@
 #   trainprof rocprofv3 --kernel-trace --stats of the training step       traintests tests/test_train.py + test_loss.py
 #   trainsweep tile sweep of the training step's ~800-row GEMM shapes     f16x3      the fp16-split mode: parity tests + bench
 #   pmcbench  rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the bench (then tools/pmc_traffic_json.py)
+#   prof3     rocprofv3 kernel stats of config 3 (512 x 512, 50 frames)  pmcmemlong FETCH / WRITE of the long-bank memory read
 #   pmcattn   SQ / LDS / TA counters of tools/ubench/attn_qb.bin (long-sequence attention and its candidate variants)
 set -u
 cd "$(dirname "$0")/.."
@@ -40,6 +41,10 @@ for stage in "$@"; do
     bench3)     timeout 600 python bench.py --size 512 --frames 50 --train-policy --steps 3 --warmup 2 --no-cpu-baseline --no-extras > "$OUT/bench3.json" 2> "$OUT/bench3.err"; head -c 1500 "$OUT/bench3.json"; tail -3 "$OUT/bench3.err" ;;
     prof)       (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/prof" -o run -- python "$OLDPWD/bench.py" --steps 6 --warmup 3 --no-cpu-baseline --no-profile --no-extras > "$OLDPWD/$OUT/prof.log" 2>&1); DB=$(find "$OUT/prof" -name "*results.db" | head -1); python tools/rocpd_stats.py "$DB" > "$OUT/prof_stats.md" 2>&1; python tools/rocpd_lastseq.py "$DB" > "$OUT/prof_lastseq.txt" 2>&1; rm -rf "$OUT/prof"; head -40 "$OUT/prof_stats.md" ;;
     pmcbench)   for C in FETCH_SIZE WRITE_SIZE; do (cd /tmp && timeout 600 rocprofv3 --pmc $C -d "$OLDPWD/$OUT/pmcb_$C" -o run -- python "$OLDPWD/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-profile --no-extras --no-graphs > "$OLDPWD/$OUT/pmcb_$C.log" 2>&1); DB=$(find "$OUT/pmcb_$C" -name "*results.db" | head -1); python tools/rocpd_pmc_grid.py "$DB" --json "$OUT/pmc_$C.json" > "$OUT/pmc_${C}_by_grid.md" 2>&1; rm -rf "$OUT/pmcb_$C"; head -12 "$OUT/pmc_${C}_by_grid.md" | cut -c1-200; done ;;
+    prof3)      # rocprofv3 kernel stats of BASELINE config 3 (512 x 512, 50 frames, growing bank)
+                (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/prof3" -o run -- python "$OLDPWD/bench.py" --size 512 --frames 50 --train-policy --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-extras > "$OLDPWD/$OUT/prof3.log" 2>&1); DB=$(find "$OUT/prof3" -name "*results.db" | head -1); python tools/rocpd_stats.py "$DB" > "$OUT/prof3_stats.md" 2>&1; rm -rf "$OUT/prof3"; head -30 "$OUT/prof3_stats.md" | cut -c1-180 ;;
+    pmcmemlong) # HBM traffic of the long-bank memory read (50 176 tokens x 1024 queries), launch by launch: FETCH_SIZE / WRITE_SIZE passes
+                for C in FETCH_SIZE WRITE_SIZE; do (cd /tmp && timeout 300 rocprofv3 --pmc $C -d "$OLDPWD/$OUT/pmcm_$C" -o run --output-format csv -- python "$OLDPWD/tools/bench_memread.py" --tokens 50176 --rows 1024 --copies 3 > "$OLDPWD/$OUT/pmcm_$C.log" 2>&1); F=$(find "$OUT/pmcm_$C" -name "*counter_collection.csv" | head -1); python tools/pmc_csv.py "$F" > "$OUT/pmcmemlong_$C.txt" 2>&1; rm -rf "$OUT/pmcm_$C"; cat "$OUT/pmcmemlong_$C.txt" | cut -c1-200; done ;;
     trainbf)    timeout 900 python tools/train_step_time.py --precision bf16 >> "$OUT/train.txt" 2>&1; tail -12 "$OUT/train.txt" ;;
     train)      for pr in bf16 fp32; do timeout 900 python tools/train_step_time.py --precision $pr >> "$OUT/train.txt" 2>&1; done; tail -20 "$OUT/train.txt" ;;
     trainprof)  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/tprof" -o run -- python "$OLDPWD/tools/train_step_time.py" --precision bf16 --steps 2 > "$OLDPWD/$OUT/trainprof.log" 2>&1); DB=$(find "$OUT/tprof" -name "*results.db" | head -1); python tools/rocpd_stats.py "$DB" > "$OUT/trainprof_stats.md" 2>&1; rm -rf "$OUT/tprof"; head -45 "$OUT/trainprof_stats.md" | cut -c1-200 ;;

@@ -48,7 +48,7 @@ int main() {
     a.x = x; a.w = reinterpret_cast<const __bf16*>(w); a.bias = bias; a.res1 = nullptr; a.res2 = nullptr; a.out = o;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.tiles_x = (W + wide::TW - 1) / wide::TW; a.tiles_y = (H + wide::TH - 1) / wide::TH;
-    a.relu_in = 1; a.act = SP3_ACT_NONE; a.out_bf16 = 1;
+    a.relu_in = 1; a.act = SP3_ACT_NONE; a.out_bf16 = 1; a.xcd_nb = 0;
     dim3 grid(a.tiles_x * a.tiles_y * B, Cout / 64);
     const int reps = 10;
     const float t0 = run<0>(a, grid, reps), t1 = run<1>(a, grid, reps), t2 = run<2>(a, grid, reps), t4 = run<4>(a, grid, reps),
