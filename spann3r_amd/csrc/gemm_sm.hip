@@ -35,7 +35,8 @@ struct SmOp {
   float* stats_out; char* c2; char* vt;
   long gA, gA2, gW, gC, gbias, gres, gstats, gs, gso, gc2, gvt;      // byte strides per group (problem) of a grouped launch
   int N, ntz, ldc, rope_cols, act, nkb1;
-  int nt;                           // N-tiles per problem (bm_kernel's M-major tile map)
+  int nt;                           // N-tiles per problem (bm_kernel's tile maps)
+  int ngrp, nzb;                    // bm_kernel: problems of this op (1 or 2), z-slots of its default map = ceil(ngrp x nt / 8)
   float alpha;                      // SM_SCORE: scale of the accumulator (the other epilogues serve alpha = 1 only)
 };
 
@@ -425,12 +426,15 @@ __global__ __launch_bounds__(64 * WM * WN) void bm_kernel(const SmArgs a) {
     tile_m = blockIdx.z * 8 + blockIdx.x;
     if (tile_m * BM >= a.M) return;
   } else {
-    int z = (int)blockIdx.z - (second ? a.z1 : 0);
-    const int ntz = OPF(ntz);
-    grp = z >= ntz ? 1 : 0;
-    z -= grp * ntz;
+    // the (problem, N-tile) pairs of an op are numbered through (problem 0's tiles, then problem 1's) and dealt to the XCDs round robin:
+    // pair p = 8 z + x.  (Per-problem z-slots left the XCDs 0 .. nt % 8 - 1 with one more N-tile PER PROBLEM: at N = 2304 / 1536 / 768 --
+    // 18 / 12 / 12 tiles -- two XCDs ran 40 workgroups of a q/k/v + cross-k/v pair on their 32 CUs while four ran 24.)
+    const int z = (int)blockIdx.z - (second ? a.z1 : 0);
+    const int nt = OPF(nt), p = z * 8 + (int)blockIdx.x;
+    if (p >= nt * OPF(ngrp)) return;
+    grp = p >= nt ? 1 : 0;
     tile_m = blockIdx.y;
-    tile_n = z * 8 + blockIdx.x;
+    tile_n = p - grp * nt;
   }
   const int N = OPF(N);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -781,12 +785,15 @@ __global__ __launch_bounds__(64 * WM * WN) void bm32_kernel(const SmArgs a) {
     tile_m = blockIdx.z * 8 + blockIdx.x;
     if (tile_m * BM >= a.M) return;
   } else {
-    int z = (int)blockIdx.z - (second ? a.z1 : 0);
-    const int ntz = OPF(ntz);
-    grp = z >= ntz ? 1 : 0;
-    z -= grp * ntz;
+    // the (problem, N-tile) pairs of an op are numbered through (problem 0's tiles, then problem 1's) and dealt to the XCDs round robin:
+    // pair p = 8 z + x.  (Per-problem z-slots left the XCDs 0 .. nt % 8 - 1 with one more N-tile PER PROBLEM: at N = 2304 / 1536 / 768 --
+    // 18 / 12 / 12 tiles -- two XCDs ran 40 workgroups of a q/k/v + cross-k/v pair on their 32 CUs while four ran 24.)
+    const int z = (int)blockIdx.z - (second ? a.z1 : 0);
+    const int nt = OPF(nt), p = z * 8 + (int)blockIdx.x;
+    if (p >= nt * OPF(ngrp)) return;
+    grp = p >= nt ? 1 : 0;
     tile_m = blockIdx.y;
-    tile_n = z * 8 + blockIdx.x;
+    tile_n = p - grp * nt;
   }
   const int N = OPF(N);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -1141,7 +1148,7 @@ int bm_launch(const SmArgs& a, int mt, int nz, hipStream_t stream) {
       raised = true;
     }
   }
-  const dim3 grid = a.xm ? dim3(8, a.op[0].nt * (a.z1 / a.op[0].ntz), (mt + 7) / 8) : dim3(8, mt, nz);
+  const dim3 grid = a.xm ? dim3(8, a.op[0].nt * a.op[0].ngrp, (mt + 7) / 8) : dim3(8, mt, nz);
   hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, stream, a);
   SP3_LAUNCH_CHECK("sp3_gemm (lean, many rows)");
   return 0;
@@ -1732,6 +1739,8 @@ void sm_fill(SmOp& o, const sp3_gemm_desc& d, const SmInst& s) {
   if (s.epi == SM_SCORE) o.stats_out = d.sm_stats_out;
   o.nt = (d.N + s.tile_n() - 1) / s.tile_n();
   o.ntz = (o.nt + 7) / 8;
+  o.ngrp = d.batch > 1 ? d.batch : 1;
+  o.nzb = (o.ngrp * o.nt + 7) / 8;
   o.ldc = (int)d.ldc;
   o.rope_cols = d.rope_cols;
   o.act = d.act;
@@ -1777,7 +1786,7 @@ int sp3_gemm_sm_launch(const sp3_gemm_desc& d, const sp3_gemm_desc* pair, hipStr
   sm_fill(a.op[0], d, *s);
   a.op[1] = a.op[0];
   const int G0 = d.batch > 1 ? d.batch : 1;
-  int nz = a.op[0].ntz * G0;
+  int nz = s->bm ? a.op[0].nzb : a.op[0].ntz * G0;        // (many-row family: z-slots over the op's (problem, N-tile) pairs, see bm_kernel)
   a.z1 = nz;
   if (pair) {
     const SmInst* s2 = sm_find(*pair);
@@ -1787,7 +1796,7 @@ int sp3_gemm_sm_launch(const sp3_gemm_desc& d, const sp3_gemm_desc* pair, hipStr
       return 1;
     }
     sm_fill(a.op[1], *pair, *s);
-    nz += a.op[1].ntz * (pair->batch > 1 ? pair->batch : 1);
+    nz += s->bm ? a.op[1].nzb : a.op[1].ntz * (pair->batch > 1 ? pair->batch : 1);
   }
   a.cos = d.rope_cos; a.sin = d.rope_sin; a.pos = d.pos;
   a.M = d.M;
