@@ -462,3 +462,72 @@ def test_pair_indices_vs_reference_make_pairs():
         assert [list(p) for p in got] == ref, key
     with pytest.raises(ValueError):
         pair_indices(4, "star")
+
+
+def test_xcd_maps_are_bijections():
+    """The round-5 workgroup -> tile maps (csrc/gemm.hip GemmArgs.xcd_slices, csrc/attention.hip attn_tile_of, csrc/conv.hip conv_tile_of,
+    csrc/gemm_sm.hip bm_kernel's (problem, N-tile) pairs) restated in Python: over the launch's grid every tile is produced exactly
+    once, surplus workgroups exit, and the property each map exists for holds (the sharers of an operand run on ONE XCD = workgroup
+    id % 8; the many-row GEMM's workgroups per XCD differ by at most one N-tile's worth)."""
+    # split-K: grid (gx, 1, S), S % 8 == 0, gx % 8 == 0 -> (tile b, slice kz); XCD x owns slices {x, x + 8, ..}
+    for gx, S in ((32, 16), (8, 8), (40, 24)):
+        seen = {}
+        for z in range(S):
+            for x in range(gx):
+                L = x + gx * z
+                xc, jj = L & 7, L >> 3
+                q = jj // gx
+                kz, b = xc + 8 * q, jj - q * gx
+                assert (b, kz) not in seen and 0 <= b < gx and 0 <= kz < S
+                seen[(b, kz)] = L % 8
+        assert len(seen) == gx * S and all(xcd == kz % 8 for (_, kz), xcd in seen.items())
+    # attention: grid (gx, pairs padded to 8, 1) -> (query tile, head, batch); a pair's query tiles on one XCD
+    for gx, heads, B in ((13, 12, 2), (13, 16, 1), (32, 16, 2), (7, 3, 5), (1, 1, 1), (64, 12, 1)):
+        NP = heads * B
+        gy = (NP + 7) // 8 * 8
+        seen = {}
+        for y in range(gy):
+            for x in range(gx):
+                L = x + gx * y
+                xc, jj = L & 7, L >> 3
+                pq = jj // gx
+                pair = xc + 8 * pq
+                if pair >= NP:
+                    continue
+                qt, b = jj - pq * gx, pair // heads
+                h = pair - b * heads
+                assert (qt, h, b) not in seen and 0 <= qt < gx and 0 <= h < heads and 0 <= b < B
+                seen[(qt, h, b)] = L % 8
+        assert len(seen) == gx * NP
+        for h in range(heads):
+            for b in range(B):
+                assert len({seen[(qt, h, b)] for qt in range(gx)}) == 1
+    # 3x3 convolution tiles: 1-D grid of ceil(T / 8) * 8 * NB -> (pixel tile, channel block); a tile's channel blocks on one XCD
+    for T, NB in ((98, 4), (392, 2), (28, 8), (1, 4), (9, 1)):
+        seen = {}
+        for L in range((T + 7) // 8 * 8 * NB):
+            xc, jj = L & 7, L >> 3
+            q = jj // NB
+            nb, t = jj - q * NB, q * 8 + xc
+            if t >= T:
+                continue
+            assert (t, nb) not in seen and 0 <= nb < NB
+            seen[(t, nb)] = L % 8
+        assert len(seen) == T * NB
+        for t in range(T):
+            assert len({seen[(t, nb)] for nb in range(NB)}) == 1
+    # many-row GEMM: grid (8, mt, nzb), pair p = 8 z + x over (problem, N-tile); per XCD the N-tile counts differ by at most one
+    for nt, G in ((18, 2), (12, 2), (24, 1), (12, 1), (7, 2)):
+        nzb = (G * nt + 7) // 8
+        seen, per_xcd = set(), [0] * 8
+        for z in range(nzb):
+            for x in range(8):
+                p = z * 8 + x
+                if p >= nt * G:
+                    continue
+                grp = 1 if p >= nt else 0
+                tile_n = p - grp * nt
+                assert (grp, tile_n) not in seen and 0 <= tile_n < nt and grp < G
+                seen.add((grp, tile_n))
+                per_xcd[x] += 1
+        assert len(seen) == nt * G and max(per_xcd) - min(per_xcd) <= 1
