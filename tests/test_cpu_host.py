@@ -531,3 +531,28 @@ def test_xcd_maps_are_bijections():
                 seen.add((grp, tile_n))
                 per_xcd[x] += 1
         assert len(seen) == nt * G and max(per_xcd) - min(per_xcd) <= 1
+
+
+def test_bench_kernel_symbols():
+    """bench.py books every profiler key under the __global__ template it instantiates (roofline.family): the lean tile names of
+    spann3r_amd/ops.py against the kernel families of csrc/gemm_sm.hip; paired and single launches of one instance share a key"""
+    import bench
+    from spann3r_amd.ops import _TILE_NAMES
+    want = {}
+    for t, n in _TILE_NAMES.items():
+        if t < 30:
+            want[n] = "gemm_kernel"
+        elif t in (40, 41):
+            want[n] = "conv_sm_kernel"
+        elif t == 44:
+            want[n] = "pv_kernel"
+        elif t < 50:
+            want[n] = "sm_kernel"
+        else:
+            want[n] = "bm_kernel"
+    for n, sym in want.items():
+        for form in ("gemm", "gemm2"):
+            assert bench.kernel_symbol("%s<Abf16,Wbf16,plain,%s>" % (form, n)) == sym, n
+    assert bench.instance_key("gemm2<Abf16,Wbf16,plain,lean-rope-k768-32x32xk4>") == "gemm<Abf16,Wbf16,plain,lean-rope-k768-32x32xk4>"
+    assert bench.instance_key("attention_packed<bf16>") == "attention_packed<bf16>"
+    assert bench.kernel_symbol("attention_packed<bf16>") == "attention_packed_kernel" and bench.kernel_symbol("conv3x3_tile") == "conv3x3_tile_kernel"
