@@ -10,6 +10,7 @@ What is dumped (SURVEY.md §8c "recommended dumps"):
   spann3r_full224.npz 24/12 model, 5 frames of 224x224 (BASELINE config 1), outputs subsampled
   memory_bank.npz     reference SpatialMemory driven stand-alone for 32 frames of P=196:
                       similarity skip, working->long-term hand-over and one prune (5096->4000)
+  memory_bank_sliding.npz  the same class with long_mem_size == 0 (the sliding window of spann3r/model.py:132-137), 10 frames (`memory_sliding`)
   spann3r_offline.npz  tiny model, 5 frames of 48x64: DUSt3R pair graph (reference make_pairs + inference) and
                       Spann3R.offline_reconstruction on it (demo.py offline mode): visiting order, outputs
   spann3r_trueshape.npz  tiny model, batch 2, 4 frames of 48x80 WITH `true_shape` (landscape, and dataset-rotated portrait)
@@ -453,6 +454,35 @@ def make_memory():
     print("memory: events\n", np.array(events))
 
 
+def make_memory_sliding():
+    """memory_bank_sliding.npz: the reference SpatialMemory with long_mem_size == 0 (spann3r/model.py:132-137: the bank keeps the last
+    work_mem_size frames), 10 frames of P = 196, every read and the final bank"""
+    from spann3r.model import SpatialMemory
+    sd = synth_state_dict(0, TINY)
+    norms = {}
+    for n in ("norm_q", "norm_k", "norm_v"):
+        ln = torch.nn.LayerNorm(1024)
+        ln.weight.data.copy_(sd[n + ".weight"])
+        ln.bias.data.copy_(sd[n + ".bias"])
+        norms[n] = ln
+    sp = SpatialMemory(norms["norm_q"], norms["norm_k"], norms["norm_v"], long_mem_size=0, work_mem_size=3, sim_thresh=1.0)
+    out = {"n_steps": np.array(10)}
+    events = []
+    with torch.no_grad():
+        for step in range(10):
+            k, v, q = memory_inputs(step)
+            if sp.mem_k is not None:
+                o = sp.memory_read(q, res=True)
+                out["read%d_sub" % step] = npf(o[:, ::7, ::16])
+            sp.add_mem_check(k, v)
+            events.append([step, sp.mem_k.shape[1], sp.wm, sp.lm])
+    out["events"] = np.array(events)
+    out["mem_count"], out["mem_attn"] = npf(sp.mem_count), npf(sp.mem_attn)
+    out["mem_k_sub"], out["mem_v_sub"] = npf(sp.mem_k[:, :, ::64]), npf(sp.mem_v[:, :, ::64])
+    np.savez_compressed(os.path.join(HERE, "memory_bank_sliding.npz"), **out)
+    print("memory (sliding window): events\n", np.array(events))
+
+
 def make_loss():
     """spann3r/loss.py ConfLoss_t(Regr3D_t(L21, norm_mode='avg_dis', fix_first=...), alpha) on seeded inputs: loss, details,
     factor loss and the autograd gradients of (loss + factor loss) w.r.t. every predicted pointmap / confidence."""
@@ -833,6 +863,8 @@ if __name__ == "__main__":
         make_tiny()
     if "memory" in what:
         make_memory()
+    if "memory_sliding" in what:
+        make_memory_sliding()
     if "full" in what:
         make_full()
     if "offline" in what:

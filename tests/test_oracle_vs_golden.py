@@ -94,6 +94,30 @@ def test_memory_bank(tiny_sd):
     assert rel_err(mem.mem_k[:, :, ::64], g["mem_k_sub"]) < 1e-6
 
 
+def test_memory_bank_sliding_window(tiny_sd):
+    """long_mem_size == 0 (spann3r/model.py:132-137): the bank keeps the last work_mem_size frames.  The oracle against a dump of the
+    reference's own SpatialMemory (tests/golden/make_golden.py memory_sliding); tests/test_model_gpu.py pins the HIP path to the oracle"""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location(
+        "make_golden_inputs", os.path.join(os.path.dirname(__file__), "golden", "memory_inputs.py"))
+    mi = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mi)
+    g = load_golden("memory_bank_sliding.npz")
+    mem = O.SpatialMemoryOracle(tiny_sd, long_mem_size=0, work_mem_size=3, sim_thresh=1.0)
+    events = []
+    for step in range(int(g["n_steps"])):
+        k, v, q = mi.memory_inputs(step)
+        if mem.mem_k is not None:
+            o = mem.memory_read(q)
+            assert rel_err(o[:, ::7, ::16], g["read%d_sub" % step]) < 1e-4, step
+        mem.add_mem_check(k, v)
+        events.append([step, mem.mem_k.shape[1], mem.wm, mem.lm])
+    assert np.array_equal(np.array(events), g["events"])
+    assert np.array_equal(mem.mem_count.numpy(), g["mem_count"])
+    assert rel_err(mem.mem_attn, g["mem_attn"]) < 1e-4
+    assert rel_err(mem.mem_k[:, :, ::64], g["mem_k_sub"]) < 1e-6 and rel_err(mem.mem_v[:, :, ::64], g["mem_v_sub"]) < 1e-6
+
+
 @pytest.mark.slow
 def test_full224(full_sd):
     g = load_golden("spann3r_full224.npz")
