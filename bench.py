@@ -413,6 +413,43 @@ def parity_errors(model, dev, precision="f16x3"):
     return out
 
 
+def cold_path(dev, precision, frames, size, steady_fps):
+    """demo.py:123-127 calls forward ONCE per scene: the first call of a fresh model (weights packed -- a per-checkpoint cost -- but no
+    workspace, no memory arena, no hipGraph yet; torch's allocator cache emptied first), the second call, and the eager steady state
+    (use_graphs = False: the same kernels launched one by one).  Frames resident in HBM, wall clock incl. the final synchronise."""
+    import gc
+    import torch
+    from spann3r_amd.runner import make_sequence
+    seqs = [make_sequence(300 + i, frames, size, size, device=dev) for i in range(4)]
+    m, _ = build_model(precision, dev)
+    m.engine                                              # weight packing
+    gc.collect()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+
+    def timed(seq):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        m(seq)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+    t1, t2, t3 = timed(seqs[0]), timed(seqs[1]), timed(seqs[2])
+    run = next(iter(m._runners.values()))
+    n_graphs = len(run.graphs)
+    m.use_graphs = False
+    timed(seqs[3])
+    te = min(timed(seqs[0]), timed(seqs[1]))
+    del m, run
+    gc.collect()
+    torch.cuda.empty_cache()
+    return ({"value": frames / t1, "unit": "frames/s", "ms": 1e3 * t1, "frac_of_steady": frames / t1 / steady_fps,
+             "second_call_frames_per_s": frames / t2, "third_call_frames_per_s": frames / t3, "hip_graphs_after_three_calls": n_graphs,
+             "what": "first forward() of a fresh model on one %d-frame %dx%d sequence (engine built, everything else cold: workspaces, memory "
+                     "arena, hipGraph capture inside the call), then the second and third call" % (frames, size, size)},
+            {"value": frames / te, "unit": "frames/s", "frac_of_steady": frames / te / steady_fps,
+             "what": "steady state with use_graphs = False: every kernel of the sequence launched eagerly through the C-ABI"})
+
+
 def cpu_baseline(sd, size, train_policy):
     """The CPU oracle on this box's host cores: warm-up, a thread-count sweep on a short sequence, then the median of 3
     runs of the bounded sample at the best count."""
@@ -421,7 +458,7 @@ def cpu_baseline(sd, size, train_policy):
     from spann3r_amd import FULL
     from spann3r_amd.runner import make_sequence
     cores = len(os.sched_getaffinity(0))
-    nfr = 3 if size > 224 else 5
+    nfr = 3 if size > 224 else 10            # the benched 10-frame sequence itself at 224 x 224
     short = make_sequence(0, 3, size, size)
     sample = make_sequence(0, nfr, size, size)
 
@@ -593,6 +630,8 @@ def _main(args, real_stdout):
                                       "trained-like weight statistics): max-norm relative error max|d| / max|ref| and the 99.9th percentile of the "
                                       "per-point error |d| / |p|; asserted in tests/test_model_gpu.py"}
         model.set_precision("bf16")
+        print("bench.py: extras: cold path (first call of a fresh model, eager steady state)", file=sys.stderr, flush=True)
+        out["cold_first_call"], out["eager"] = cold_path(dev, "bf16", args.frames, args.size, fps)
         # how the same GPU fills with more independent work per launch: 4 sequences batched into one forward (B = 4).
         # NOT the headline configuration (BASELINE config 2 is batch 1): reported next to it.
         print("bench.py: extras: batch 4", file=sys.stderr, flush=True)

@@ -150,6 +150,13 @@ typedef struct sp3_gemm_desc {
    *   sp3_gemm_plan answers -1 for any other combination and the general tiles refuse res_bf16 != 0, so a descriptor whose
    *   residual dtype differs from its output dtype is never routed to a kernel that would reinterpret the bytes. */
   int32_t res_bf16;
+  /* --- the growing extent of the spatial-memory read as DEVICE state (round 6): if non-null, the score GEMM of the read (tile 43:
+   *   sm_stats_out set) takes its column count N from dyn_n[0] and its P.V GEMM (tile 44: loader SP3_LOAD_SOFTMAX) its contraction
+   *   length K (and sm_nt = ceil(K / 32)) -- the bank's current token count, spann3r/model.py:80-95 grows it by a frame per step.
+   *   The descriptor's N / K then only bound what the launch can serve (grid size, argument checks; dyn_n[0] <= that bound,
+   *   dyn_n[0] % 4 == 0), so ONE captured hipGraph serves every bank length up to it.  Lean instances only: the general tiles
+   *   refuse a descriptor with dyn_n set. */
+  const int32_t* dyn_n;
 } sp3_gemm_desc;
 int sp3_gemm(const sp3_gemm_desc* desc_host, void* stream);
 /* Two differently shaped groups of problems in ONE launch (grid.y = a.batch + b.batch), e.g. a decoder layer's self-attention
@@ -291,6 +298,8 @@ typedef struct sp3_bank_write_desc {
   float alpha;            /* 1 / sqrt(C): the S GEMM's scale, folded into s_bank / b_bank */
   int32_t M, P, C, cap;   /* cap % 64 == 0, C % 256 == 0 */
   int32_t wdtype;         /* SP3_F32 | SP3_BF16 */
+  const int32_t* state;   /* round 6: if non-null, the first row M is read from state[0] on the device (sp3_bank_state_set) and the M
+                           * field is ignored: one captured launch serves every fill level; rows >= cap are not written */
 } sp3_bank_write_desc;
 int sp3_bank_write(const sp3_bank_write_desc* desc_host, void* stream);
 int sp3_softmax_thresh(const float* S, float* P, int64_t ld, int64_t strideS, int rows, int M, int Mpad,
@@ -311,6 +320,14 @@ int sp3_gather_packed_rows(const void* src, void* dst, const int32_t* sel, int n
 int sp3_gather_packed_cols(const void* src, void* dst, const int32_t* sel, int n_sel, int n_fill, int C, int cap,
                            int elem_size, void* stream);
 int sp3_cos_sim(const float* k, const float* wm, int T, int P, int C, float* scratch, float* score, void* stream);
+/* Device-resident fill state of a bank (round 6): state[0] = M (tokens stored), state[1] = wm (frames of working memory,
+ * spann3r/model.py:120-143).  The host owns the policy (commit / skip / prune are its decisions, as in the reference) and pushes the
+ * values after every change; the kernels of a step read them from the device, so the step's hipGraph does not depend on them.
+ * sp3_cos_sim_state = sp3_cos_sim against the last state[1] frames of k_raw [cap, C] (rows [M - wm P, M)), wm <= Tmax: launched
+ * for Tmax frames, surplus workgroups exit; score[t] for t >= wm is left untouched. */
+int sp3_bank_state_set(int32_t* state, int M, int wm, void* stream);
+int sp3_cos_sim_state(const float* k, const float* k_raw, int Tmax, int P, int C, const int32_t* state, float* scratch, float* score,
+                      void* stream);
 int sp3_mem_append(float* count, float* attn, int M, int P, void* stream);
 int sp3_prune_select(const float* attn, const float* count, int M, float protect, int top_k,
                      int32_t* sel, void* stream);

@@ -335,10 +335,9 @@ __device__ __forceinline__ bool attn_tile_of(int xcd_map, int heads, int& qt, in
   }
   return true;
 }
-static bool attn_xcd_on() {
-  static const bool on = [] { const char* e = getenv("SP3_ATTN_XCD"); return !(e && e[0] == '0'); }();    // (A/B switch: 0 = the plain grid)
-  return on;
-}
+// the XCD map needs its (head, batch) pairs, padded to a multiple of 8, in grid.y (<= 65535); beyond that the plain (q tiles, heads, B)
+// grid serves (heads and B are checked against 65535 separately)
+static bool attn_xcd_ok(int heads, int B) { return ((long)heads * B + 7) / 8 * 8 <= 65535; }
 
 template <typename TT>
 __global__ __launch_bounds__(256) void attention_kernel(const typename AttnT<TT>::Store* __restrict__ Q, int64_t sq, int64_t ldq,
@@ -822,7 +821,7 @@ extern "C" int sp3_attention_ex(const void* q, int64_t sq, int64_t ldq, const vo
   SP3_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && (out_packed || ldo % 4 == 0), "sp3_attention: row strides must keep 16-byte alignment");
   SP3_CHECK(dtype == SP3_F32 || dtype == SP3_BF16 || dtype == 2 || dtype == 3,
             "sp3_attention: bad dtype %d (0 fp32, 1 bf16, 2 / 3: fp32 operands with bf16x3 / fp16x3 split products)", dtype);
-  const int xcd_map = attn_xcd_on() ? heads * B : 0;
+  const int xcd_map = attn_xcd_ok(heads, B) ? heads * B : 0;
   dim3 grid((Nq + 15) / 16, xcd_map ? (heads * B + 7) / 8 * 8 : heads, xcd_map ? 1 : B);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (dtype == SP3_BF16)
@@ -862,7 +861,7 @@ extern "C" int sp3_attention_packed(const void* qp, int q_cols, int q_col0, int 
   SP3_CHECK(out_packed || ldo % 4 == 0, "sp3_attention_packed: ldo");
   SP3_CHECK(o_group == 0 || (o_group > 0 && B % o_group == 0 && o_group_rows >= o_group * Nq), "sp3_attention_packed: output grouping");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const int np = heads * B, xcd_map = attn_xcd_on() ? np : 0;
+  const int np = heads * B, xcd_map = attn_xcd_ok(heads, B) ? np : 0;
   const dim3 tail = xcd_map ? dim3((np + 7) / 8 * 8, 1) : dim3(heads, B);
   // two query blocks per workgroup once the grid still fills the chip that way (profiles/r05_attn_long_variants.txt)
   if (Nq >= 512) {
@@ -889,7 +888,7 @@ extern "C" int sp3_attention_train_fwd(const float* q, int64_t sq, int64_t ldq, 
   SP3_CHECK(B > 0 && heads > 0 && Nq > 0 && Nk > 0 && B <= 65535 && heads <= 65535, "sp3_attention_train_fwd: bad shape");
   SP3_CHECK(vt_ld >= ((Nk + 63) / 64) * 64 && vt_ld % 8 == 0, "sp3_attention_train_fwd: vt_ld=%lld must be >= Nk padded to 64", (long long)vt_ld);
   SP3_CHECK(ldq % 4 == 0 && ldk % 4 == 0 && ldo % 4 == 0 && sq % 4 == 0 && sk % 4 == 0, "sp3_attention_train_fwd: strides must keep 16-byte alignment");
-  const int xcd_map = attn_xcd_on() ? heads * B : 0;
+  const int xcd_map = attn_xcd_ok(heads, B) ? heads * B : 0;
   dim3 grid((Nq + 15) / 16, xcd_map ? (heads * B + 7) / 8 * 8 : heads, xcd_map ? 1 : B);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (bf16_products)

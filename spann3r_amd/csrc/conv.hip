@@ -465,7 +465,7 @@ extern "C" int sp3_conv3x3_tile(const void* x, int in_bf16, const void* w_packed
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
   a.relu_in = relu_in; a.act = act; a.out_bf16 = out_bf16 & 3;
   a.xcd_nb = 0;
-  static const bool xcd_on = [] { const char* e = getenv("SP3_CONV_XCD"); return !(e && e[0] == '0'); }();      // (A/B switch)
+  constexpr bool xcd_on = true;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   {
     // tile choice (out_bf16 bits 2-3: 0 = by size, 1 = 8 x 8 pixels, 2 = 8 x 16 pixels x 64 channels, 3 = 8 x 16 pixels x 32 channels): the

@@ -1681,8 +1681,7 @@ int launch(const sp3_gemm_desc& d, hipStream_t stream) {
   } else {
     a.d2 = d;
   }
-  static const bool xs_on = [] { const char* e = getenv("SP3_SPLITK_XCD"); return !(e && e[0] == '0'); }();      // (A/B switch)
-  a.xcd_slices = (xs_on && gy == 1 && d.splitk >= 8 && d.splitk % 8 == 0 && blocks % 8 == 0) ? 1 : 0;
+  a.xcd_slices = (gy == 1 && d.splitk >= 8 && d.splitk % 8 == 0 && blocks % 8 == 0) ? 1 : 0;
   hipLaunchKernelGGL(kern, dim3(blocks, gy, d.splitk), dim3(NT), lds, stream, a);
   SP3_LAUNCH_CHECK("sp3_gemm");
   return 0;
@@ -1851,8 +1850,7 @@ static int gemm_prepare(sp3_gemm_desc& d, int& tile_out) {
     const long t128 = (long)((d.M + 63) / 64) * ((d.N + 127) / 128) * d.batch;
     const bool lds_ok = d.loader == SP3_LOAD_PLAIN && !d.sm_stats_out && sk == 1 && d.a_packed && d.w_packed && d.a_bf16 && !d.A2 &&
                         d.epi != SP3_EPI_PARTIAL && d.K % 64 == 0;
-    // SP3_PIPE_TILES=0 switches the pipelined LDS tiles (20-23) off: A/B runs against the round-2 tile choice
-    static const bool pipe_on = [] { const char* e = getenv("SP3_PIPE_TILES"); return !(e && e[0] == '0'); }();
+    constexpr bool pipe_on = true;
     // (split-K partials too: the PARTIAL epilogue is tile-agnostic; every K slice must hold whole k-blocks)
     const bool pipe_ok = d.loader == SP3_LOAD_PLAIN && !d.sm_stats_out && d.a_packed && d.w_packed && d.a_bf16 && !d.A2 && d.K % 64 == 0 &&
                          (sk == 1 || d.epi == SP3_EPI_PARTIAL);
@@ -1934,6 +1932,7 @@ extern "C" int sp3_gemm(const sp3_gemm_desc* dp, void* stream_) {
   if (d.tile >= 30 || (d.tile < 0 && sp3_gemm_sm_tile(d) >= 0)) return sp3_gemm_sm_launch(d, nullptr, reinterpret_cast<hipStream_t>(stream_));
   SP3_CHECK(!(d.a_packed && d.A2), "sp3_gemm: a fragment-order A split along K runs on the lean instances only (no instance for M=%d N=%d K=%d)", d.M, d.N, d.K);
   SP3_CHECK(!(d.res_bf16 && (d.res1 || d.res2)), "sp3_gemm: bf16 residual maps are read by the lean small-map convolutions only (res_bf16 = out_bf16 = a_bf16; M=%d N=%d K=%d)", d.M, d.N, d.K);
+  SP3_CHECK(!d.dyn_n, "sp3_gemm: a device-side extent (dyn_n) is served by the lean memory-read instances only (tiles 43 / 44; M=%d N=%d K=%d)", d.M, d.N, d.K);
   return gemm_dispatch(d, tile, reinterpret_cast<hipStream_t>(stream_));
 }
 
@@ -1973,7 +1972,7 @@ extern "C" int sp3_gemm2(const sp3_gemm_desc* ap, const sp3_gemm_desc* bp, void*
   SP3_CHECK(!(a.res_bf16 && (a.res1 || a.res2)) && !(b.res_bf16 && (b.res1 || b.res2)), "sp3_gemm2: bf16 residual maps are read by the lean small-map convolutions only");
   SP3_CHECK(ta == tb && a.wdtype == b.wdtype && a.a_bf16 == b.a_bf16 && a.loader == b.loader && a.loader != SP3_LOAD_SOFTMAX,
             "sp3_gemm2: both groups must use one kernel instance (tile %d / %d, same dtypes and loader)", ta, tb);
-  SP3_CHECK(a.splitk == 1 && b.splitk == 1 && !a.trace && !b.trace, "sp3_gemm2: no split-K, no trace");
+  SP3_CHECK(a.splitk == 1 && b.splitk == 1 && !a.trace && !b.trace && !a.dyn_n && !b.dyn_n, "sp3_gemm2: no split-K, no trace, no device-side extent");
   g_pair = &b;
   const int rc = gemm_dispatch(a, ta, reinterpret_cast<hipStream_t>(stream_));
   g_pair = nullptr;

@@ -48,6 +48,7 @@ struct SmArgs {
   int tokens, heads, vt_ld;
   unsigned tok_magic;               // floor(2^32 / tokens) + 1: gm / tokens by one multiply-high (gm < 65536)
   float ln_eps;
+  const int* dyn;                   // SM_SCORE: if set, N = dyn[0] (the bank's token count lives on the device; op[0].N bounds the grid)
 };
 
 // grid = (8, mt, nz): linear workgroup id = x + 8 (y + mt z) -> XCD x; tile_m = y; z = group * ntz + zt, tile_n = 8 zt + x
@@ -76,7 +77,10 @@ __global__ __launch_bounds__(64 * WK) void sm_kernel(const SmArgs a) {
   const int grp = z >= ntz ? 1 : 0;
   z -= grp * ntz;
   const int tile_m = blockIdx.y, tile_n = z * 8 + blockIdx.x;
-  const int N = OPF(N);
+  int N = OPF(N);
+  if constexpr (EPI == SM_SCORE) {
+    if (a.dyn) N = __builtin_amdgcn_readfirstlane(*a.dyn);     // (uniform: a scalar load; the grid was sized for op[0].N >= this)
+  }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   if (n0 >= N) return;
 
@@ -751,395 +755,17 @@ __global__ __launch_bounds__(64 * WM * WN) void bm_kernel(const SmArgs a) {
 #undef OPF
 }
 
-// ------------------------------------------------------------------------------------------------ many rows, 32x32x16 fragments
-// bm_kernel's shell (tile map, stage DMA, swapped operands, epilogues in registers) with the K loop on v_mfma_f32_32x32x16_bf16
-// (round 5; tools/ubench/gemm_bm.hip).  The fragment-order bytes are the same: a 32-row operand of k16-step t is two 16-row blocks --
-// lanes 0..15 / 16..31 read rows of block b / b + 1, lanes >= 32 the other 8 k of the step (piece h = 1) -- still ONE conflict-free
-// ds_read_b128 per operand; half the MFMA instructions per FLOP, 16 accumulator registers per 32 x 32 tile.  A wave owns 64 rows x
-// (32 TN) columns; a register set holds two k16-steps (the wait for a set sits in front of its first MFMA, the next set's reads
-// behind it).  D = W_frag . A_frag^T puts output row (lane & 31) of row tile tm into a lane, with the columns 8 q + 4 (lane >> 5) +
-// (0..3) of column tile tn in registers 4 q .. 4 q + 3: the RoPE partner (column ^ 16) is quad q ^ 2 of the same lane, a 32-column
-// statistics group is the four quads of the lane and of lane ^ 32.  Measured (1960 x 4096 x 1024, no epilogue): 1507 clocks per
-// k-block against 1625 for the 16x16x32 loop -- but with the real epilogues the kernel LOSES in the model (32-byte row segments per
-// store instead of 64, 16 more operand registers per 32 columns): SP3_BM32=1 selects it, the default stays bm_kernel.
-template <int WM, int WN, int TN, int NKB, int NST, int EPI, bool SPLIT = false>
-__global__ __launch_bounds__(64 * WM * WN) void bm32_kernel(const SmArgs a) {
-  constexpr int TM = 2, NW = WM * WN, NT = 64 * NW;
-  constexpr int BM = WM * 64, BN = WN * TN * 32;
-  constexpr int NBLK = BM / 16 + BN / 16, STAGE_BYTES = NBLK * 2048, NINSTR = 2 * NBLK, PER = (NINSTR + NW - 1) / NW;
-  constexpr int K = NKB * 64;
-  constexpr bool LNOK = NKB % 4 == 0 && NKB <= 16;
-  static_assert(NST >= 2 && NST <= 4 && PER * (NST - 1) < 64 && NST <= NKB, "stage ring: 2..4 stages, vmcnt is a 6-bit count");
-  (void)NT;
-  extern __shared__ __attribute__((aligned(16))) char lds_b[];
-  const int tid = threadIdx.x, lane = tid & 63, wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wn = wave_u % WN, wm = wave_u / WN;
-  const int ml = lane & 31, hi = lane >> 5;
-  const bool second = EPI == SM_ROPE && (int)blockIdx.z >= a.z1;
-#define OPF(f) (second ? a.op[1].f : a.op[0].f)
-  int tile_m, tile_n, grp;
-  if (EPI != SM_ROPE && a.xm) {
-    const int nt = OPF(nt), y = blockIdx.y;
-    grp = y >= nt ? 1 : 0;
-    tile_n = y - grp * nt;
-    tile_m = blockIdx.z * 8 + blockIdx.x;
-    if (tile_m * BM >= a.M) return;
-  } else {
-    // the (problem, N-tile) pairs of an op are numbered through (problem 0's tiles, then problem 1's) and dealt to the XCDs round robin:
-    // pair p = 8 z + x.  (Per-problem z-slots left the XCDs 0 .. nt % 8 - 1 with one more N-tile PER PROBLEM: at N = 2304 / 1536 / 768 --
-    // 18 / 12 / 12 tiles -- two XCDs ran 40 workgroups of a q/k/v + cross-k/v pair on their 32 CUs while four ran 24.)
-    const int z = (int)blockIdx.z - (second ? a.z1 : 0);
-    const int nt = OPF(nt), p = z * 8 + (int)blockIdx.x;
-    if (p >= nt * OPF(ngrp)) return;
-    grp = p >= nt ? 1 : 0;
-    tile_m = blockIdx.y;
-    tile_n = p - grp * nt;
-  }
-  const int N = OPF(N);
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
-  if (n0 >= N) return;
-
-  // ---- DMA pieces of this wave (as bm_kernel)
-  const char* src[PER];
-  const char* src2[SPLIT ? PER : 1];
-  int dst[PER];
-  const int nkb1 = SPLIT ? OPF(nkb1) : NKB;
-  {
-    const char* A = OPF(A) + grp * OPF(gA);
-    const char* W = OPF(W) + grp * OPF(gW);
-    const int nb_max = (N >> 4) - 1;
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      int j = wave_u + i * NW;
-      j = j < NINSTR ? j : NINSTR - 1;
-      const int blk = j >> 1;
-      const char* base;
-      if constexpr (SPLIT) src2[i] = nullptr;
-      if (blk < BM / 16) {
-        int rb = (m0 >> 4) + blk;
-        rb = rb < a.rb_max ? rb : a.rb_max;
-        base = A + (long)rb * nkb1 * 2048;
-        if constexpr (SPLIT) src2[i] = OPF(A2) + grp * OPF(gA2) + ((long)rb * (NKB - nkb1) - nkb1) * 2048 + (j & 1) * 1024 + lane * 16;
-      } else {
-        int nb = (n0 >> 4) + blk - BM / 16;
-        nb = nb < nb_max ? nb : nb_max;
-        base = W + (long)nb * NKB * 2048;
-      }
-      src[i] = base + (j & 1) * 1024 + lane * 16;
-      dst[i] = j * 1024;
-    }
-  }
-  auto issue = [&](int slot, int kb) {
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const char* p = src[i];
-      if constexpr (SPLIT) p = (kb >= nkb1 && src2[i]) ? src2[i] : p;
-      bm_glds16(p + (long)kb * 2048, lds_b + slot * STAGE_BYTES + dst[i]);
-    }
-  };
-  auto wait_pending = [&](int pend) {
-    if (pend >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PER) : "memory");
-    else if (pend == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
-    else if (pend == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  };
-  // ---- per-row / per-column epilogue operands, requested before the first DMA stages
-  const float* lnst = OPF(ln_stats);
-  const bool ln = LNOK && lnst != nullptr;
-  float mean[TM], rstd[TM];
-  int grow[TM];
-#pragma unroll
-  for (int m = 0; m < TM; ++m) {
-    grow[m] = m0 + wm * 64 + m * 32 + ml;
-    mean[m] = 0.f; rstd[m] = 1.f;
-  }
-  constexpr int NL2 = LNOK ? NKB / 2 : 1;               // float4 partials per lane of a 2-lane row team
-  float4 lp[LNOK ? TM : 1][NL2];
-  if constexpr (LNOK) {
-    if (ln) {
-#pragma unroll
-      for (int m = 0; m < TM; ++m) {
-        const int gm = grow[m] < a.M ? grow[m] : a.M - 1;
-        const float4* ps = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(lnst) + grp * OPF(gstats)) + (long)gm * NKB;
-#pragma unroll
-        for (int q = 0; q < NL2; ++q) lp[m][q] = ps[hi + 2 * q];
-      }
-    }
-  }
-  const int c_wave = n0 + wn * TN * 32;                 // first column of this wave (a multiple of 32)
-  const float* biasp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(OPF(bias)) + grp * OPF(gbias));
-  float4 pb4[TN][4], ps4[TN][4];
-#pragma unroll
-  for (int n = 0; n < TN; ++n)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int c = c_wave + n * 32 + 8 * q + 4 * hi;
-      pb4[n][q] = *reinterpret_cast<const float4*>(biasp + c);
-      ps4[n][q] = ln ? *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(OPF(ln_s)) + grp * OPF(gs)) + c)
-                     : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  int ppos[EPI == SM_ROPE ? TM : 1][2];
-  if constexpr (EPI == SM_ROPE) {
-#pragma unroll
-    for (int m = 0; m < TM; ++m) {
-      const int gm = grow[m] < a.M ? grow[m] : a.M - 1;
-      ppos[m][0] = a.pos[(long)gm * 2];
-      ppos[m][1] = a.pos[(long)gm * 2 + 1];
-    }
-  }
-#pragma unroll
-  for (int s_ = 0; s_ < NST; ++s_) issue(s_, s_);
-  if constexpr (LNOK) {
-    if (ln) {
-#pragma unroll
-      for (int m = 0; m < TM; ++m) {
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int q = 0; q < NL2; ++q) { s1 += lp[m][q].x + lp[m][q].z; s2 += lp[m][q].y + lp[m][q].w; }
-        s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-        mean[m] = s1 * (1.0f / (float)K);
-        const float var = fmaxf(s2 * (1.0f / (float)K) - mean[m] * mean[m], 0.f);
-        rstd[m] = 1.0f / sqrtf(var + a.ln_eps);
-      }
-    }
-  }
-
-  typedef bf16x8 V16;
-  typedef __attribute__((ext_vector_type(16))) float f32x16;
-  V16 fa[2][2][TM], fw[2][2][TN];
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int m = 0; m < TM; ++m)
-#pragma unroll
-    for (int n = 0; n < TN; ++n)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-  const int lane_off = ((lane >> 4) & 1) * 2048 + hi * 1024 + (lane & 15) * 16;
-  auto read_unit = [&](auto buf_tag, int slot, int u) {
-    constexpr int BUF = decltype(buf_tag)::value;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const char* st = lds_b + slot * STAGE_BYTES + (u * 2 + ks) * 256 + lane_off;
-#pragma unroll
-      for (int m = 0; m < TM; ++m) fa[BUF][ks][m] = *reinterpret_cast<const V16*>(st + (wm * TM + m) * 4096);
-#pragma unroll
-      for (int n = 0; n < TN; ++n) fw[BUF][ks][n] = *reinterpret_cast<const V16*>(st + (BM / 16 + (wn * TN + n) * 2) * 2048);
-    }
-  };
-  auto mma_first = [&](auto buf_tag) {
-    constexpr int BUF = decltype(buf_tag)::value;
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[BUF][0][0], fa[BUF][0][0], acc[0][0], 0, 0, 0);
-  };
-  auto mma_rest = [&](auto buf_tag) {
-    constexpr int BUF = decltype(buf_tag)::value;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int m = 0; m < TM; ++m)
-#pragma unroll
-        for (int n = 0; n < TN; ++n)
-          if (ks + m + n > 0) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[BUF][ks][n], fa[BUF][ks][m], acc[m][n], 0, 0, 0);
-  };
-  using B0 = std::integral_constant<int, 0>;
-  using B1 = std::integral_constant<int, 1>;
-  wait_pending(NST - 1);
-  asm volatile("s_barrier" ::: "memory");
-  int slot = 0;
-  read_unit(B0{}, 0, 0);
-  for (int i = 0; i < NKB; ++i) {
-    // unit 0 of the stage: set 0, prefetch unit 1 into set 1
-    mma_first(B0{});
-    __builtin_amdgcn_sched_barrier(0);
-    read_unit(B1{}, slot, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    mma_rest(B0{});
-    // unit 1: set 1; publish the next stage, refill the slot every wave has finished reading, prefetch its unit 0 into set 0
-    mma_first(B1{});
-    __builtin_amdgcn_sched_barrier(0);
-    const int cur = slot;
-    slot = slot + 1 == NST ? 0 : slot + 1;
-    if (i + 1 < NKB) {
-      const int s = i + 1, newer = NKB - 1 - s;
-      wait_pending(newer < NST - 2 ? newer : NST - 2);
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      if (s + NST - 1 < NKB) issue(cur, s + NST - 1);
-      read_unit(B0{}, slot, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    mma_rest(B1{});
-  }
-
-  // ---- epilogue, in registers.  Quad (tm, tn, q) of this lane: row grow[tm], columns c_wave + 32 tn + 8 q + 4 hi .. + 3
-  auto finish = [&](int m, int n, int q, float (&v)[4]) {
-    const float4 b4 = pb4[n][q];
-    v[0] = acc[m][n][4 * q]; v[1] = acc[m][n][4 * q + 1]; v[2] = acc[m][n][4 * q + 2]; v[3] = acc[m][n][4 * q + 3];
-    if (ln) {
-      const float4 s4 = ps4[n][q];
-      const float rm = rstd[m] * mean[m];
-      v[0] = rstd[m] * v[0] - rm * s4.x; v[1] = rstd[m] * v[1] - rm * s4.y;
-      v[2] = rstd[m] * v[2] - rm * s4.z; v[3] = rstd[m] * v[3] - rm * s4.w;
-    }
-    v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-  };
-
-  if constexpr (EPI == SM_ROPE) {
-    const int rope_cols = OPF(rope_cols);
-    if (c_wave >= rope_cols) {
-      // ---- V columns: PV-operand order wants 4 consecutive TOKENS of one column per store -> this wave's tile crosses LDS once
-      __syncthreads();                                            // (the stage ring is dead; every wave of the workgroup gets here)
-      constexpr int LDV = TN * 32 + 4;
-      float* tl = reinterpret_cast<float*>(lds_b) + (size_t)wave_u * 64 * LDV;
-#pragma unroll
-      for (int m = 0; m < TM; ++m)
-#pragma unroll
-        for (int n = 0; n < TN; ++n)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            float v[4];
-            finish(m, n, q, v);
-            *reinterpret_cast<float4*>(tl + (m * 32 + ml) * LDV + n * 32 + 8 * q + 4 * hi) = make_float4(v[0], v[1], v[2], v[3]);
-          }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // own tile only: no barrier
-      __bf16* vt = reinterpret_cast<__bf16*>(OPF(vt) + grp * OPF(gvt));
-      for (int idx = lane; idx < 16 * TN * 32; idx += 64) {       // 16 row quads x TN*32 columns
-        const int rq = idx & 15, col = idx >> 4;
-        const int gm = m0 + wm * 64 + 4 * rq, gn = c_wave + col;
-        if (gm >= a.M) continue;
-        const int vc = gn - rope_cols;
-        const int h = vc >> 6, dd = vc & 63;
-        const int b = (int)__umulhi((unsigned)gm, a.tok_magic), n_ = gm - b * a.tokens;
-        const int u = n_ >> 5, kk = n_ & 31, w16 = kk & 15;
-        const int e = 4 * (kk >> 4), lane_ = (w16 >> 2) * 16 + (dd & 15);
-        const long nU = a.vt_ld >> 5;
-        const long off = ((((long)(b * a.heads + h) * nU + u) * 4 + (dd >> 4)) * 64 + lane_) * 8 + e;
-        bf16x4 ob;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) ob[i] = (__bf16)tl[(4 * rq + i) * LDV + col];
-        st_out(reinterpret_cast<bf16x4*>(vt + off), ob);
-      }
-      return;
-    }
-    if (n0 + BN > rope_cols) __syncthreads();                     // pairs with the V waves' barrier in a tile that straddles rope_cols
-    // ---- q / k columns: the RoPE partner of quad q (column c) is quad q ^ 2 (column c ^ 16), same lane
-    __bf16* out = reinterpret_cast<__bf16*>(OPF(C) + grp * OPF(gC));
-#pragma unroll
-    for (int m = 0; m < TM; ++m) {
-      const int gm = grow[m];
-      if (gm >= a.M) continue;
-      const int b = (int)__umulhi((unsigned)gm, a.tok_magic), n_ = gm - b * a.tokens;
-      const int prow = b * a.vt_ld + n_;
-      const int py = ppos[m][0], px = ppos[m][1];
-#pragma unroll
-      for (int n = 0; n < TN; ++n) {
-        const int hc = (c_wave + n * 32) & 63;                    // 0 or 32: axis
-        const int p = (hc >> 5) ? px : py;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {                             // pairs (q, q + 2): table entries 8 q + 4 hi .. + 3
-          const float4 cs4 = *reinterpret_cast<const float4*>(a.cos + p * 16 + 8 * q + 4 * hi);
-          const float4 sn4 = *reinterpret_cast<const float4*>(a.sin + p * 16 + 8 * q + 4 * hi);
-          const float cs[4] = {cs4.x, cs4.y, cs4.z, cs4.w}, sn[4] = {sn4.x, sn4.y, sn4.z, sn4.w};
-          float v0[4], v1[4];
-          finish(m, n, q, v0);
-          finish(m, n, q + 2, v1);
-          bf16x4 o0, o1;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            o0[e] = (__bf16)(v0[e] * cs[e] - v1[e] * sn[e]);      // first half of the pair: x cos - y sin
-            o1[e] = (__bf16)(v1[e] * cs[e] + v0[e] * sn[e]);      // second half:           y cos + x sin
-          }
-          const int c = c_wave + n * 32 + 8 * q + 4 * hi;
-          st_out(reinterpret_cast<bf16x4*>(out + packed_off(prow, c, rope_cols, true)), o0);
-          st_out(reinterpret_cast<bf16x4*>(out + packed_off(prow, c + 16, rope_cols, true)), o1);
-        }
-      }
-    }
-  } else if constexpr (EPI == SM_PACKED) {
-    __bf16* out = reinterpret_cast<__bf16*>(OPF(C) + grp * OPF(gC));
-    const bool gelu = OPF(act) == SP3_ACT_GELU;
-#pragma unroll
-    for (int m = 0; m < TM; ++m) {
-      const int gm = grow[m];
-      if (gm >= a.M) continue;
-#pragma unroll
-      for (int n = 0; n < TN; ++n)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float v[4];
-          finish(m, n, q, v);
-          if (gelu) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-          }
-          bf16x4 ob;
-          ob[0] = (__bf16)v[0]; ob[1] = (__bf16)v[1]; ob[2] = (__bf16)v[2]; ob[3] = (__bf16)v[3];
-          st_out(reinterpret_cast<bf16x4*>(out + packed_off(gm, c_wave + n * 32 + 8 * q + 4 * hi, N, true)), ob);
-        }
-    }
-  } else {
-    float* out = reinterpret_cast<float*>(OPF(C) + grp * OPF(gC));
-    float* so = OPF(stats_out);
-    __bf16* c2 = reinterpret_cast<__bf16*>(OPF(c2));
-    const float* res = OPF(res1);
-    if (so) so = reinterpret_cast<float*>(reinterpret_cast<char*>(so) + grp * OPF(gso));
-    if (c2) c2 = reinterpret_cast<__bf16*>(reinterpret_cast<char*>(c2) + grp * OPF(gc2));
-    if (res) res = reinterpret_cast<const float*>(reinterpret_cast<const char*>(res) + grp * OPF(gres));
-    const int ldc = OPF(ldc);
-#pragma unroll
-    for (int m = 0; m < TM; ++m) {
-      const int gm = grow[m];
-      const bool ok = gm < a.M;
-      const int gmc = ok ? gm : a.M - 1;
-#pragma unroll
-      for (int n = 0; n < TN; ++n) {
-        const int cg = c_wave + n * 32;                            // the 32-column group of this tile
-        float4 r4[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) r4[q] = res ? *reinterpret_cast<const float4*>(res + (long)gmc * N + cg + 8 * q + 4 * hi) : make_float4(0.f, 0.f, 0.f, 0.f);
-        float v[4][4];
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          finish(m, n, q, v[q]);
-          v[q][0] += r4[q].x; v[q][1] += r4[q].y; v[q][2] += r4[q].z; v[q][3] += r4[q].w;
-          s1 += (v[q][0] + v[q][1]) + (v[q][2] + v[q][3]);
-          s2 += (v[q][0] * v[q][0] + v[q][1] * v[q][1]) + (v[q][2] * v[q][2] + v[q][3] * v[q][3]);
-        }
-        if (so) {
-          // per-32-column (sum, sum of squares): the two lanes that share the row (all lanes take part)
-          s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
-          if (ok && hi == 0) st_out(reinterpret_cast<float2*>(so) + ((long)gm * (N >> 5) + (cg >> 5)), make_float2(s1, s2));
-        }
-        if (ok) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int c = cg + 8 * q + 4 * hi;
-            if (c2) {
-              bf16x4 o;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[q][e];
-              st_out(reinterpret_cast<bf16x4*>(c2 + packed_off(gm, c, N, true)), o);
-            }
-            st_out(reinterpret_cast<float4*>(out + (long)gm * ldc + c), make_float4(v[q][0], v[q][1], v[q][2], v[q][3]));
-          }
-        }
-      }
-    }
-  }
-#undef OPF
-}
+// (round 5 also built this shell on v_mfma_f32_32x32x16_bf16 fragments -- bm32_kernel: loop 7 % faster in the probe, kernel 1-4 % slower in the
+//  model, profiles/r05_bm32_in_model_ab.txt; removed in round 6, the probe keeps its loop: tools/ubench/gemm_bm.hip)
 
 template <int WM, int WN, int NF, int NKB, int NST, int EPI, bool SPLIT = false>
 int bm_launch(const SmArgs& a, int mt, int nz, hipStream_t stream) {
   constexpr int BM = WM * 64, BN = WN * NF * 16;
   constexpr size_t ring = (size_t)NST * (BM / 16 + BN / 16) * 2048;
-  constexpr size_t vtile = (size_t)WM * WN * 64 * (NF * 16 + 4) * sizeof(float);     // the V columns' transposition (ROPE epilogue; same size in both kernels)
+  constexpr size_t vtile = (size_t)WM * WN * 64 * (NF * 16 + 4) * sizeof(float);     // the V columns' transposition (ROPE epilogue)
   constexpr size_t lds = ring > vtile ? ring : vtile;
   static_assert(lds <= 160 * 1024, "stage ring must fit the LDS");
-  // (A/B in the model, same box, profiles/r05_bm32_in_model_ab.txt: the 32x32x16 kernel is 1-4 % SLOWER end to end -- 609 vs 617 frames/s,
-  //  batch 4 927 vs 955, config 3 202.5 vs 210.8 -- so it is opt-in: SP3_BM32=1)
-  static const bool use32 = [] { const char* e = getenv("SP3_BM32"); return e && e[0] == '1'; }();
-  static_assert(NF % 2 == 0, "a wave's columns: whole 32-column tiles");
-  auto kern = use32 ? bm32_kernel<WM, WN, NF / 2, NKB, NST, EPI, SPLIT> : bm_kernel<WM, WN, NF, NKB, NST, EPI, SPLIT>;
+  auto kern = bm_kernel<WM, WN, NF, NKB, NST, EPI, SPLIT>;
   if (lds > 64 * 1024) {
     static bool raised = false;
     if (!raised) {
@@ -1169,6 +795,7 @@ struct PvArgs {
   const float* S; const float2* stats; const char* W; float* out; const float* res; char* c2; float* zout;
   int M, Mk, N, ld, ng, nkbw, ldc, ldr;
   float thr;
+  const int* dyn;                   // if set: Mk = dyn[0], ng = ceil(Mk / 32) (the bank's token count lives on the device)
 };
 
 template <int NF, int WK, int R>
@@ -1183,7 +810,9 @@ __global__ __launch_bounds__(64 * WK) void pv_kernel(const PvArgs a) {
   const int tile_m = blockIdx.y, tile_n = blockIdx.z * 8 + blockIdx.x;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   if (n0 >= a.N) return;
-  const int nkb = (a.Mk + 63) >> 6;
+  const int Mk = a.dyn ? __builtin_amdgcn_readfirstlane(*a.dyn) : a.Mk;
+  const int ng = a.dyn ? (Mk + 31) >> 5 : a.ng;
+  const int nkb = (Mk + 63) >> 6;
   const int nkw = wk < nkb ? (nkb - wk + WK - 1) / WK : 0;       // k-blocks of this wave: wk, wk + WK, ...
   // ---- operand loads of the first R k-blocks
   int row = m0 + r16;
@@ -1213,11 +842,11 @@ __global__ __launch_bounds__(64 * WK) void pv_kernel(const PvArgs a) {
   {
     int gm = m0 + rowi;
     gm = gm < a.M ? gm : a.M - 1;
-    const float2* st = a.stats + (long)gm * a.ng;
+    const float2* st = a.stats + (long)gm * ng;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int j = st_t + q * TPR;
-      stv[q] = j < a.ng ? st[j] : make_float2(-INFINITY, 0.f);
+      stv[q] = j < ng ? st[j] : make_float2(-INFINITY, 0.f);
     }
   }
 #pragma unroll
@@ -1265,7 +894,7 @@ __global__ __launch_bounds__(64 * WK) void pv_kernel(const PvArgs a) {
         const int kb = wk + i * WK;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const int left = a.Mk - (kb * 64 + g * 16 + h * 8);
+          const int left = Mk - (kb * 64 + g * 16 + h * 8);
           float p[8];
           const float4 s0 = sv[s_][h][0], s1 = sv[s_][h][1];
           const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
@@ -1353,15 +982,8 @@ int pv_dispatch(const sp3_gemm_desc& d, hipStream_t stream) {
   a.out = reinterpret_cast<float*>(d.C); a.res = d.res1; a.c2 = reinterpret_cast<char*>(d.c2); a.zout = d.sm_zout;
   a.M = d.M; a.Mk = d.K; a.N = d.N; a.ld = (int)d.lda; a.ng = d.sm_nt; a.nkbw = (int)(d.ldw / 64); a.ldc = (int)d.ldc; a.ldr = (int)d.ldr1;
   a.thr = d.sm_thresh;
-  static const int variant = [] { const char* e = getenv("SP3_PV_VARIANT"); return e ? atoi(e) : 0; }();    // (tile / wave-count A/B: tools/bench_memread.py)
-  switch (variant) {
-    case 1: return pv_launch<4, 16, 2>(a, d.M, d.N, stream);
-    case 2: return pv_launch<2, 8, 4>(a, d.M, d.N, stream);
-    case 3: return pv_launch<2, 16, 2>(a, d.M, d.N, stream);
-    case 4: return pv_launch<4, 8, 3>(a, d.M, d.N, stream);
-    case 5: return pv_launch<4, 8, 4>(a, d.M, d.N, stream);
-    default: return pv_launch<4, 8, 2>(a, d.M, d.N, stream);
-  }
+  a.dyn = d.dyn_n;
+  return pv_launch<4, 8, 2>(a, d.M, d.N, stream);      // (16 x 32 tiles, 16 waves, deeper rings: measured slower, profiles/r05_memread_short_bank_launch_breakdown.txt)
 }
 
 // ------------------------------------------------------------------------------------------------ small-map 3x3 convolutions
@@ -1687,9 +1309,9 @@ const SmInst* sm_find(const sp3_gemm_desc& d) {
       d.trace || d.sm_stats || (d.alpha != 1.0f && !d.sm_stats_out) || d.f32x3)
     return nullptr;
   if (d.splitk > 1 || d.epi == SP3_EPI_PARTIAL || d.epi == SP3_EPI_PIXSHUF) return nullptr;
-  static const bool big_on = [] { const char* e = getenv("SP3_LEAN_BIG"); return !(e && e[0] == '0'); }();
-  if (d.batch > 2 || d.M < 1 || d.M >= 65536 || (d.M > 256 && !big_on) || (d.ldw > 0 && d.ldw != d.K) || !d.bias) return nullptr;
+  if (d.batch > 2 || d.M < 1 || d.M >= 65536 || (d.ldw > 0 && d.ldw != d.K) || !d.bias) return nullptr;
   const int kind = sm_kind(d);
+  if (d.dyn_n && kind != SM_SCORE) return nullptr;        // (device-side extent: the score instance only)
   if (kind == SM_SCORE) {
     // (sp3_gemm's own checks: plain fp32 epilogue, N % 4 == 0, one problem)
     if (d.epi != SP3_EPI_PLAIN || d.out_bf16 || d.out_packed || d.batch > 1 || d.res1 || d.stats_out || d.c2 || d.act != SP3_ACT_NONE ||
@@ -1807,6 +1429,7 @@ int sp3_gemm_sm_launch(const sp3_gemm_desc& d, const sp3_gemm_desc* pair, hipStr
   a.vt_ld = (int)d.vt_ld;
   a.tok_magic = (unsigned)((1ull << 32) / (unsigned)a.tokens + 1);
   a.ln_eps = d.ln_eps;
+  a.dyn = d.dyn_n;
   const int mt = (d.M + s->tile_m() - 1) / s->tile_m();
   return s->launch(a, mt, nz, stream);
 }

@@ -271,9 +271,15 @@ __global__ __launch_bounds__(256) void colsum_accum_kernel(const float* __restri
 }
 
 // cos_sim, stage 1: one wave per (stored frame t, patch p) pair -> cosv[t*P + p] = cos(k[p], wm[t,p]).
+// state != nullptr (sp3_cos_sim_state): wm is the bank's k_raw, the frames are its last state[1] ones (rows [M - T P, M), M = state[0])
 __global__ __launch_bounds__(256) void cos_pair_kernel(const float* __restrict__ k, const float* __restrict__ wm, int TP, int P, int C,
-                                                       float* __restrict__ cosv) {
+                                                       float* __restrict__ cosv, const int* __restrict__ state) {
   const int lane = threadIdx.x & 63, j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (state) {
+    const int M = state[0], T = state[1];
+    TP = T * P < TP ? T * P : TP;
+    wm += (int64_t)(M - TP) * C;
+  }
   if (j >= TP) return;
   const float* a = k + (int64_t)(j % P) * C;
   const float* b = wm + (int64_t)j * C;
@@ -291,15 +297,20 @@ __global__ __launch_bounds__(256) void cos_pair_kernel(const float* __restrict__
 }
 
 // cos_sim, stage 2: one block per stored frame t: mean over patches, fixed reduction order.
-__global__ __launch_bounds__(256) void cos_mean_kernel(const float* __restrict__ cosv, int P, float* __restrict__ score) {
+__global__ __launch_bounds__(256) void cos_mean_kernel(const float* __restrict__ cosv, int P, float* __restrict__ score, const int* __restrict__ state) {
   __shared__ float sh[4];
   const int t = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (state && t >= state[1]) return;
   float acc = 0.f;
   for (int p = threadIdx.x; p < P; p += 256) acc += cosv[(int64_t)t * P + p];
   acc = wave_sum(acc);
   if (lane == 0) sh[w] = acc;
   __syncthreads();
   if (threadIdx.x == 0) score[t] = ((sh[0] + sh[1]) + (sh[2] + sh[3])) / (float)P;
+}
+
+__global__ void bank_state_kernel(int* __restrict__ state, int M, int wm) {
+  if (threadIdx.x == 0) { state[0] = M; state[1] = wm; }
 }
 
 __global__ __launch_bounds__(256) void mem_append_kernel(float* __restrict__ count, float* __restrict__ attn, int M, int P) {
@@ -419,6 +430,7 @@ struct BankWriteArgs {
   const float *gk, *bk, *gv, *bv, *gq, *bq;
   float eps, alpha;
   int M, P, C, cap;
+  const int* state;                                         // if set: the first row comes from state[0] (device-resident fill level)
 };
 
 template <typename TW>
@@ -428,14 +440,15 @@ __global__ __launch_bounds__(128 * (16 / (int)sizeof(TW))) void bank_write_kerne
   extern __shared__ __attribute__((aligned(16))) unsigned char raw_[];
   TW* stage = reinterpret_cast<TW*>(raw_);                 // [TG][C]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int t0 = (a.M / TG + blockIdx.x) * TG;             // first token of this group (absolute bank row)
+  const int M0 = a.state ? __builtin_amdgcn_readfirstlane(a.state[0]) : a.M;    // first row of the frame (device-resident fill level, or the launch argument)
+  const int t0 = (M0 / TG + blockIdx.x) * TG;              // first token of this group (absolute bank row)
   const int C = a.C;
   {
     const int j = wave % TG;
     const bool is_key = wave < TG;                         // waves [0, TG): key rows, [TG, 2 TG): value rows
     const int t = t0 + j;
-    const bool live = t >= a.M && t < a.M + a.P;           // wave-uniform
-    const int pr = t - a.M;
+    const bool live = t >= M0 && t < M0 + a.P;             // wave-uniform
+    const int pr = t - M0;
     // ---- key row
     if (live && is_key) {
       const float* x = a.fk + (int64_t)pr * C;
@@ -501,7 +514,7 @@ __global__ __launch_bounds__(128 * (16 / (int)sizeof(TW))) void bank_write_kerne
   }
   __syncthreads();
   // ---- transposed store of the staged value rows: channel c, tokens t0 .. t0+TG-1 = one 16-byte piece
-  const bool whole = t0 >= a.M && t0 + TG <= a.M + a.P;
+  const bool whole = t0 >= M0 && t0 + TG <= M0 + a.P;
   for (int c = threadIdx.x; c < C; c += NTH) {
     TW* dst = reinterpret_cast<TW*>(a.v_hat_t) + packed_off(c, t0, a.cap, BF);
     if (whole) {
@@ -513,7 +526,7 @@ __global__ __launch_bounds__(128 * (16 / (int)sizeof(TW))) void bank_write_kerne
     } else {
 #pragma unroll
       for (int j = 0; j < TG; ++j)
-        if (t0 + j >= a.M && t0 + j < a.M + a.P) dst[j] = stage[j * C + c];
+        if (t0 + j >= M0 && t0 + j < M0 + a.P) dst[j] = stage[j * C + c];
     }
   }
 }
@@ -633,13 +646,14 @@ extern "C" int sp3_bank_write(const sp3_bank_write_desc* dp, void* stream) {
   const sp3_bank_write_desc& d = *dp;
   SP3_CHECK(d.feat_k && d.feat_v && d.k_raw && d.v_raw && d.k_hat && d.v_hat_t && d.s_bank && d.b_bank, "sp3_bank_write: null pointer");
   SP3_CHECK(d.gamma_k && d.beta_k && d.gamma_v && d.beta_v && d.gamma_q && d.beta_q, "sp3_bank_write: null LayerNorm parameter");
-  SP3_CHECK(d.P > 0 && d.M >= 0 && d.C > 0 && d.C % 256 == 0 && d.cap % 64 == 0 && d.M + d.P <= d.cap,
+  SP3_CHECK(d.P > 0 && d.C > 0 && d.C % 256 == 0 && d.cap % 64 == 0 && (d.state ? d.P <= d.cap : (d.M >= 0 && d.M + d.P <= d.cap)),
             "sp3_bank_write: bad geometry M=%d P=%d C=%d cap=%d", d.M, d.P, d.C, d.cap);
   SP3_CHECK(d.wdtype == SP3_F32 || d.wdtype == SP3_BF16, "sp3_bank_write: bad wdtype %d", d.wdtype);
   BankWriteArgs a{d.feat_k, d.feat_v, d.k_raw, d.v_raw, d.k_hat, d.v_hat_t, d.s_bank, d.b_bank, d.gamma_k, d.beta_k,
-                  d.gamma_v, d.beta_v, d.gamma_q, d.beta_q, d.eps, d.alpha, d.M, d.P, d.C, d.cap};
+                  d.gamma_v, d.beta_v, d.gamma_q, d.beta_q, d.eps, d.alpha, d.M, d.P, d.C, d.cap, d.state};
   const int TG = d.wdtype == SP3_BF16 ? 8 : 4;
-  const int groups = (d.M + d.P + TG - 1) / TG - d.M / TG;
+  // (device-resident first row: the frame may start anywhere inside a token group -- one group more than the aligned case; idle if not needed)
+  const int groups = d.state ? (d.P + TG - 1) / TG + 1 : (d.M + d.P + TG - 1) / TG - d.M / TG;
   const size_t lds = (size_t)TG * d.C * (d.wdtype == SP3_BF16 ? 2 : 4);
   if (d.wdtype == SP3_BF16) hipLaunchKernelGGL(bank_write_kernel<__bf16>, dim3(groups), dim3(1024), lds, ST(stream), a);
   else hipLaunchKernelGGL(bank_write_kernel<float>, dim3(groups), dim3(512), lds, ST(stream), a);
@@ -686,9 +700,25 @@ extern "C" int sp3_colsum_accum(const float* P, int64_t ld, int rows, int M, flo
 
 extern "C" int sp3_cos_sim(const float* k, const float* wm, int T, int P, int C, float* scratch, float* score, void* stream) {
   SP3_CHECK(k && wm && scratch && score && T > 0 && P > 0 && C > 0 && C % 4 == 0, "sp3_cos_sim: bad arguments");
-  hipLaunchKernelGGL(cos_pair_kernel, dim3((T * P + 3) / 4), dim3(256), 0, ST(stream), k, wm, T * P, P, C, scratch);
-  hipLaunchKernelGGL(cos_mean_kernel, dim3(T), dim3(256), 0, ST(stream), scratch, P, score);
+  hipLaunchKernelGGL(cos_pair_kernel, dim3((T * P + 3) / 4), dim3(256), 0, ST(stream), k, wm, T * P, P, C, scratch, (const int*)nullptr);
+  hipLaunchKernelGGL(cos_mean_kernel, dim3(T), dim3(256), 0, ST(stream), scratch, P, score, (const int*)nullptr);
   SP3_LAUNCH_CHECK("sp3_cos_sim");
+  return 0;
+}
+
+extern "C" int sp3_cos_sim_state(const float* k, const float* k_raw, int Tmax, int P, int C, const int32_t* state, float* scratch, float* score,
+                                 void* stream) {
+  SP3_CHECK(k && k_raw && state && scratch && score && Tmax > 0 && P > 0 && C > 0 && C % 4 == 0, "sp3_cos_sim_state: bad arguments");
+  hipLaunchKernelGGL(cos_pair_kernel, dim3((Tmax * P + 3) / 4), dim3(256), 0, ST(stream), k, k_raw, Tmax * P, P, C, scratch, state);
+  hipLaunchKernelGGL(cos_mean_kernel, dim3(Tmax), dim3(256), 0, ST(stream), scratch, P, score, state);
+  SP3_LAUNCH_CHECK("sp3_cos_sim_state");
+  return 0;
+}
+
+extern "C" int sp3_bank_state_set(int32_t* state, int M, int wm, void* stream) {
+  SP3_CHECK(state && M >= 0 && wm >= 0, "sp3_bank_state_set: bad arguments");
+  hipLaunchKernelGGL(bank_state_kernel, dim3(1), dim3(64), 0, ST(stream), state, M, wm);
+  SP3_LAUNCH_CHECK("sp3_bank_state_set");
   return 0;
 }
 

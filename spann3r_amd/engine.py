@@ -63,7 +63,9 @@ class Engine:
         self.cfg = cfg
         self.device = torch.device(device)
         self.precision = precision
-        # "f32x3": fp32 weights and activations, GEMM products through three bf16 MFMAs (ops.F32X3, set by the model)
+        # "f32x3" / "f32x6" / "f16x3": fp32 weights and activations, GEMM products through split bf16 / fp16 MFMAs -- the product mode
+        # belongs to THIS engine and is activated (per thread) at each of its entry points, see activate()
+        self.f32_mode = ops.PRODUCT_MODES[precision]
         self.wdt = torch.bfloat16 if precision == "bf16" else torch.float32
         self.adt = self.wdt          # dtype of activations that only feed GEMMs
         import os
@@ -71,9 +73,11 @@ class Engine:
         # DPT feature maps: bf16 in bf16 mode (round 4: every map is a GEMM / convolution operand that the MFMA rounds to bf16 anyway;
         # stored as bf16 they cost half the bytes in the convolutions' loaders, the upsamplers and the residual adds), fp32 otherwise
         # bf16 DPT maps carry bf16 residuals, which only the lean small-map convolutions (and the LDS-tiled kernel) read: with
-        # SP3_LEAN_GEMM=0 (the documented A/B switch) the maps stay fp32, as with SP3_DPT_FP32_MAPS=1
-        self.mdt = torch.bfloat16 if (precision == "bf16" and os.environ.get("SP3_DPT_FP32_MAPS", "0") != "1" and ops.LEAN) else torch.float32
+        # SP3_LEAN_GEMM=0 (the one documented A/B switch: the whole default path against the general kernels) the maps stay fp32
+        self.mdt = torch.bfloat16 if (precision == "bf16" and ops.LEAN) else torch.float32
         self._ws = {}
+        self._arena, self._arena_off, self._arenas = None, 0, []
+        self._splitA_plan = {}       # rows -> does the library hold a lean instance for the packed split-A key MLP (encode_feat_keys_grouped)
         self._pos_cache = {}
         # RoPE tables for every grid the build supports, allocated ONCE: captured graphs hold their addresses
         self.max_pos = 256
@@ -83,6 +87,13 @@ class Engine:
             self.rope_narrow = _rope_tables_narrow(self.max_pos, cfg.rope_base, cfg.val_dim // cfg.enc_heads, self.device)
         self.w = {}
         self._pack(params)
+
+    def activate(self):
+        """Every entry point of the engine (and of the SpatialMemory built on it) calls this first: the fp32-operand GEMMs launched
+        by this thread from here on use this engine's product mode (ops.set_product_mode is per thread -- two models of
+        different precision in one process do not share it)."""
+        ops.set_product_mode(self.f32_mode)
+        return self
 
     # ------------------------------------------------------------------ weights
     def _pack(self, p):
@@ -219,16 +230,40 @@ class Engine:
         key = ("packed", name, rows, K, self.adt)
         t = self._ws.get(key)
         if t is None:
-            t = ops.PackedAct(rows, K, self.adt, self.device)
+            t = ops.PackedAct(rows, K, self.adt, self.device, data=self._alloc(ops.packed_shape(rows, K, self.adt), self.adt, zero=True))
             self._ws[key] = t
         return t
 
     # ------------------------------------------------------------------ workspace
+    ARENA_CHUNK = 128 << 20        # bytes per arena chunk (one device allocation)
+    ARENA_DIRECT = 32 << 20        # requests from this size on get an allocation of their own
+
+    def _alloc(self, shape, dtype, zero=False):
+        """Workspace memory comes out of a few large chunks (bump allocation, 256-byte aligned, never freed: the buffers are static --
+        captured hipGraphs hold their addresses -- and live as long as the engine).  A geometry's first forward creates ~150
+        workspaces; as ~150 device allocations that was 25 ms of the 69 ms a first 10-frame call took (tools/cold_start.py)."""
+        n = 1
+        for d in shape:
+            n *= int(d)
+        nbytes = n * dtype.itemsize
+        if nbytes >= self.ARENA_DIRECT or nbytes == 0:
+            return (torch.zeros if zero else torch.empty)(tuple(shape), dtype=dtype, device=self.device)
+        off = (self._arena_off + 255) // 256 * 256
+        if self._arena is None or off + nbytes > self._arena.numel():
+            self._arena = torch.empty(self.ARENA_CHUNK, dtype=torch.uint8, device=self.device)
+            self._arenas.append(self._arena)
+            off = 0
+        t = self._arena[off:off + nbytes].view(dtype).view(tuple(shape))
+        self._arena_off = off + nbytes
+        if zero:
+            t.zero_()
+        return t
+
     def ws(self, name, shape, dtype=torch.float32, zero=False):
         key = (name, tuple(shape), dtype)
         t = self._ws.get(key)
         if t is None:
-            t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
+            t = self._alloc(shape, dtype, zero)
             self._ws[key] = t
         return t
 
@@ -331,6 +366,7 @@ class Engine:
         img fp32 [B,3,H,W] on device -> feat [B,P,1024] (written to `out` if given), pos int64 [B,P,2].
         out_packed (bf16 PackedAct.group): fragment-order copy of the features written by the enc_norm launch, one group per
         group_rows rows (the rows of one frame) -- the A operand of decoder_embed / the key MLPs."""
+        self.activate()
         cfg, w = self.cfg, self.w
         B, Cin, H, W_ = img.shape
         p = cfg.patch
@@ -371,6 +407,7 @@ class Engine:
         """dust3r._decoder (dust3r/model.py:186-205).  f1, f2 fp32 [B,P,1024].
         Returns two lists of dec_depth+1 tensors ([B,P,1024] then [B,P,768] ...), last one dec_norm'ed.
         `streams` = {1: stream, 2: stream}: run the two sides concurrently (caller forks / joins)."""
+        self.activate()
         cfg, w = self.cfg, self.w
         E, D, Hh = cfg.enc_dim, cfg.dec_dim, cfg.dec_heads
         P1, P2 = nh1 * nw1, nh2 * nw2
@@ -478,13 +515,14 @@ class Engine:
         key = ("packed2", name, R, K, self.adt)
         t = self._ws.get(key)
         if t is None:
-            t = self._ws[key] = ops.PackedAct.group(2, R, K, self.adt, self.device)
+            t = self._ws[key] = ops.PackedAct.group(2, R, K, self.adt, self.device, alloc=self._alloc)
         return t
 
     def decoder_grouped(self, f1, f2, B, nh, nw, f1p=None, f2p=None):
         """dust3r._decoder (dust3r/model.py:186-205) with both sides as problems 0 / 1 of one grouped launch per op:
         8 launches per layer on ONE stream instead of 2 x 10 on two streams with a fork/join per layer (the cross-stream
         dependencies cost ~8 us of idle GPU each).  Same kernels, same arithmetic per side as `decoder`."""
+        self.activate()
         cfg, w = self.cfg, self.w
         E, D, Hh = cfg.enc_dim, cfg.dec_dim, cfg.dec_heads
         P = nh * nw
@@ -582,18 +620,30 @@ class Engine:
         """both key MLPs (spann3r/model.py:299-303) as one grouped launch per layer; normed1/2 = the decoders' last outputs.
         feat1p / feat2p: fragment-order bf16 copies of the features (written by enc_norm): with the packed copy of the decoder
         outputs (decoder_grouped) the first layer runs on a lean split-A instance instead of converting fp32 rows on load."""
+        self.activate()
         cfg, w = self.cfg, self.w
         E, D, Kd = cfg.enc_dim, cfg.dec_dim, cfg.key_dim
         dF, dN, dO = feat2.data_ptr() - feat1.data_ptr(), normed2.data_ptr() - normed1.data_ptr(), out2.data_ptr() - out1.data_ptr()
         assert dF % 16 == 0 and dN % 16 == 0 and dO % 16 == 0
         es = 2 if self.adt == torch.bfloat16 else 4
         h = self.wspg("keyg_hidden", R, Kd)
-        if feat1p is not None and feat2p is not None and self.adt == torch.bfloat16 and ops.LEAN:     # (a packed split A has no general tile: tiles 42 / 66 / 67)
+        packed = None
+        if feat1p is not None and feat2p is not None and self.adt == torch.bfloat16 and ops.LEAN:
+            # a packed split A runs on lean instances only (tiles 42 / 66 / 67; no general tile): ask the library whether it has one
+            # for THIS descriptor (SP3_LEAN_BIG=0 with R > 256, or a batch the families do not take, answer no) before taking the layout
             np_ = self.wspg("decg_normed_packed", R, D)
             dFp = feat2p.data_ptr() - feat1p.data_ptr()
             assert dFp % 16 == 0
-            ops.gemm(feat1p, w["keyg.0.w"], h, M=R, N=Kd, K=Kd, lda=E, ldc=Kd, bias=w["keyg.0.b"], act=ACT_GELU, A2=np_, lda2=D, K1=E,
-                     batch=2, strideA=dFp // 2, strideW=w["keyg.0.w"].stride, strideC=h.stride, sb={"bias": Kd * 4, "A2": np_.stride * 2})
+            packed = dict(A2=np_, lda2=D, K1=E, batch=2, strideA=dFp // 2, strideW=w["keyg.0.w"].stride, strideC=h.stride,
+                          sb={"bias": Kd * 4, "A2": np_.stride * 2})
+            ok = self._splitA_plan.get(R)
+            if ok is None:
+                ok = self._splitA_plan[R] = ops.gemm(feat1p, w["keyg.0.w"], h, M=R, N=Kd, K=Kd, lda=E, ldc=Kd, bias=w["keyg.0.b"],
+                                                     act=ACT_GELU, plan_only=True, **packed) >= 30
+            if not ok:
+                packed = None
+        if packed is not None:
+            ops.gemm(feat1p, w["keyg.0.w"], h, M=R, N=Kd, K=Kd, lda=E, ldc=Kd, bias=w["keyg.0.b"], act=ACT_GELU, **packed)
         else:
             ops.gemm(feat1, w["keyg.0.w"], h, M=R, N=Kd, K=Kd, lda=E, ldc=Kd, bias=w["keyg.0.b"], act=ACT_GELU, A2=normed1, lda2=D, K1=E,
                      batch=2, strideA=dF // 4, strideW=w["keyg.0.w"].stride, strideC=h.stride, sb={"bias": Kd * 4, "A2": dN})
@@ -607,6 +657,7 @@ class Engine:
         """spann3r/model.py:299-303: Linear(1792,1792) -> GELU -> Linear(1792,1024) on cat(feat, dec[-1]);
         the concatenation is never materialised (split-A GEMM).  aux: also write the fragment-order copy and the
         row-statistics partials of the key (returned; see key_aux)."""
+        self.activate()
         cfg, w = self.cfg, self.w
         E, D, Kd = cfg.enc_dim, cfg.dec_dim, cfg.key_dim
         h = self.wsp("key_hidden%d" % num, R, Kd)
@@ -660,6 +711,7 @@ class Engine:
     def dpt_head(self, dec, B, nh, nw, num, want_raw=False):
         """DPTOutputAdapter_fix.forward + postprocess (dust3r/heads/dpt_head.py:34-65, postprocess.py:10-58).
         dec: list of dec_depth+1 token tensors; tokens ARE the NHWC map [B,nh,nw,C]."""
+        self.activate()
         cfg, w = self.cfg, self.w
         F, Lc = cfg.dpt_feat, cfg.dpt_last
         pre = "dpt%d." % num
@@ -722,6 +774,7 @@ class Engine:
         16 heads of 48 (zero-padded to 64, _attn_core); no RoPE, or with mem_pos_enc RoPE2D on the 48-wide heads (pos32 = the
         tokens' int32 (y, x) positions: narrow_head_slots / _rope_tables_narrow); `res` (feat_k1) is added by the finishing GEMM if
         given.  tok fp32 [B,P,768]."""
+        self.activate()
         cfg, w = self.cfg, self.w
         B, P, Cv = tok.shape
         assert Cv == cfg.val_dim
@@ -747,6 +800,7 @@ class Engine:
         """spann3r/model.py:305-320 (use_feat=False): pos_patch_embed(pts3d as a 3-channel image) -> 6 blocks without
         RoPE -> value_norm -> value_out; `res` (feat_k1) is added by the finishing kernel (:519/:521 `cur_v+feat_k1`)
         only if given.  pts3d fp32 [B,H,W,3] (any strides)."""
+        self.activate()
         cfg, w = self.cfg, self.w
         B, H, W_, _ = pts3d.shape
         p, E = cfg.patch, cfg.enc_dim

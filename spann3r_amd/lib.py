@@ -42,7 +42,7 @@ class GemmDesc(C.Structure):
         ("sb_stats_out", C.c_int64), ("sb_c2", C.c_int64), ("sb_vt", C.c_int64),
         ("trace", C.c_void_p),
         ("sm_stats_out", C.c_void_p), ("sm_stats", C.c_void_p), ("sm_nt", C.c_int32), ("sm_thresh", C.c_float), ("sm_zout", C.c_void_p),
-        ("f32x3", C.c_int32), ("res_bf16", C.c_int32),
+        ("f32x3", C.c_int32), ("res_bf16", C.c_int32), ("dyn_n", C.c_void_p),
     ]
 
 
@@ -84,7 +84,7 @@ class BankWriteDesc(C.Structure):
         ("gamma_k", C.c_void_p), ("beta_k", C.c_void_p), ("gamma_v", C.c_void_p), ("beta_v", C.c_void_p),
         ("gamma_q", C.c_void_p), ("beta_q", C.c_void_p),
         ("eps", C.c_float), ("alpha", C.c_float),
-        ("M", C.c_int32), ("P", C.c_int32), ("C", C.c_int32), ("cap", C.c_int32), ("wdtype", C.c_int32),
+        ("M", C.c_int32), ("P", C.c_int32), ("C", C.c_int32), ("cap", C.c_int32), ("wdtype", C.c_int32), ("state", C.c_void_p),
     ]
 
 
@@ -126,6 +126,8 @@ _PROTOS = {
     "sp3_colsum_accum": [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
     "sp3_cos_sim": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
     "sp3_mem_append": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p],
+    "sp3_bank_state_set": [C.c_void_p, C.c_int, C.c_int, C.c_void_p],
+    "sp3_cos_sim_state": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "sp3_prune_select": [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p],
     "sp3_gather_rows": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p],
     "sp3_gather_cols": [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int,
@@ -231,8 +233,16 @@ def check(rc, what):
         raise RuntimeError("%s failed (%d): %s" % (what, rc, msg))
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream_ptr():
-    """The caller's CURRENT HIP stream (also the capturing stream under torch.cuda.graph)."""
+    """The caller's CURRENT HIP stream (also the capturing stream under torch.cuda.graph).  Every launch asks for it, so it goes
+    through torch's raw C accessors where they exist: torch.cuda.current_stream() builds a Stream object and resolves the device
+    index in Python -- 8 us per call, a third of the host time of an eagerly launched step (tools/cold_start.py --profile)."""
+    if _raw_stream is not None and _raw_device is not None:
+        return _raw_stream(_raw_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -103,8 +103,16 @@ class SpatialMemory:
     """
     FUSED_READ_MAX = 2_000_000        # queries x bank tokens: fp32 scores <= 8 MB (L2 / MALL resident for the 32 column tiles)
 
+    STATE_BUCKET = 2048               # device-state mode: a step's hipGraph serves every bank length up to the next multiple of this
+                                      # (the score launch carries <= 2048 / 32 x 7 idle workgroups for it: ~1 us at 196 tokens)
+    STATE_READ_MAX = 8192             # ... on the two-launch read, whose statistics merge holds <= 256 groups of 32 keys per row
+
     def __init__(self, engine: Engine, batch, num_patches, capacity, attn_thresh=5e-4, long_mem_size=4000,
-                 work_mem_size=5, sim_thresh=0.95):
+                 work_mem_size=5, sim_thresh=0.95, device_state=False):
+        """device_state (round 6; the static hipGraph runner in bf16 mode): the fill level (M, wm) also lives in a device int32 block
+        that the step's kernels read -- score GEMM N, P.V GEMM K, the row a frame is written to, the working-memory window of the
+        similarity gate -- so the captured step does not depend on it: one graph per step KIND (and grid bucket)
+        instead of one per bank length.  The host still owns the policy and pushes the values after every change (_push_state)."""
         self.eng = engine
         self.B, self.P, self.C = batch, num_patches, engine.cfg.enc_dim
         self.attn_thresh = attn_thresh
@@ -129,6 +137,12 @@ class SpatialMemory:
         w = engine.w
         self._norms = (w["norm_k.w"], w["norm_k.b"], w["norm_v.w"], w["norm_v.b"], w["norm_q.w"], w["norm_q.b"])
         self._pending_attn = None
+        self.state = torch.zeros(4, dtype=torch.int32, device=dev) if (device_state and wdt == torch.bfloat16 and ops.LEAN) else None
+        self._state_pushed = (0, 0)
+        # the read takes its extent from the device where its lean instances serve it (gemm_sm.hip sm_find / pv_ok: <= 256 query rows,
+        # 1024-wide keys); elsewhere (512 x 512 frames) the read's launches keep the token count as an argument and stay keyed by it
+        self.read_dyn = self.state is not None and num_patches <= 256 and self.C == 1024
+        self._window_sel = {}            # (P, M) -> the selection [P, M) of the sliding-window policy (_drop_oldest)
 
     def _alloc(self, dev, wdt):
         B, cap, C = self.B, self.cap, self.C
@@ -152,6 +166,27 @@ class SpatialMemory:
         """Start a new sequence on the same arena (stale rows are never read: every read is bounded by M)."""
         self._cur, self.M, self.wm, self.lm, self.events = 0, 0, 0, 0, []
         self._pending_attn = None
+        self._push_state()
+
+    def _push_state(self):
+        """device copy of (M, wm) <- the host's values, if they changed (one tiny launch; nothing waits for it but the next step)"""
+        if self.state is not None and self._state_pushed != (self.M, self.wm):
+            ops.bank_state_set(self.state, self.M, self.wm)
+            self._state_pushed = (self.M, self.wm)
+
+    def _bucket(self):
+        """device-state mode: the token count the read's launches are SIZED for (grid, argument checks); the kernels take the real
+        count from the device"""
+        return min(self.cap, (self.M + self.STATE_BUCKET - 1) // self.STATE_BUCKET * self.STATE_BUCKET)
+
+    def graph_key(self):
+        """what a captured step depends on: (M, wm) when the launches carry them as arguments; the grid bucket of the two-launch read
+        in device-state mode (long banks: their launch list still depends on M)"""
+        if self.state is None:
+            return (self.M, self.wm)
+        if self.M == 0:
+            return ("s", 0)
+        return ("s", self._bucket()) if (self.read_dyn and self._read_plan()[1]) else ("l", self.M)
 
     def snapshot(self):
         """Detached copy of the reference-visible state (what `return_memory=True` hands out)."""
@@ -192,7 +227,7 @@ class SpatialMemory:
         operand); returns whether it was written."""
         self._flush_attn()
         self.wrote_packed = False
-        eng, bk = self.eng, self.bank
+        eng, bk = self.eng.activate(), self.bank
         B, P, C, M, kb = self.B, self.P, self.C, self.M, self.kb
         assert M > 0
         prof = ops._prof
@@ -216,15 +251,18 @@ class SpatialMemory:
         # Long banks (split K; the scores no longer sit in L2 for 32 column tiles to re-read) keep a materialised P.
         st = eng.ws("mem_sm_stats", (B, P, (self.cap + 31) // 32, 2)) if fused else None
         zk = eng.ws("mem_sm_rowz", (B, P, 4)) if fused else None
+        # device-state mode: the two launches are sized for the bucket and read the token count from the device (dyn_n)
+        dyn = self.state if (fused and self.read_dyn) else None
+        Mg = self._bucket() if dyn is not None else M
         for b in range(B):
             # S = LN_q(q) . K_hat^T / 32: raw q (fragment order) x (gamma_q (.) K_hat), LN_q folded through s_bank / b_bank
-            ops.gemm(qp[b], ops.PackedWeight.wrap(bk["k_hat"][b], M, C), S[b], M=P, N=M, K=C, lda=C, ldc=ld, alpha=alpha,
-                     bias=bk["b_bank"][b], ln=ops.LnFold(qs[b], C, bk["s_bank"][b], 1e-5), sm_stats_out=st[b] if fused else None)
+            ops.gemm(qp[b], ops.PackedWeight.wrap(bk["k_hat"][b], Mg, C), S[b], M=P, N=Mg, K=C, lda=C, ldc=ld, alpha=alpha,
+                     bias=bk["b_bank"][b], ln=ops.LnFold(qs[b], C, bk["s_bank"][b], 1e-5), sm_stats_out=st[b] if fused else None, dyn_n=dyn)
         if fused:
             for b in range(B):
                 c2 = out_packed if (out_packed is not None and B == 1) else None
-                ops.gemm(S[b], ops.PackedWeight.wrap(bk["v_hat_t"][b], C, self.cap), out[b], M=P, N=C, K=M, lda=ld, ldc=C,
-                         ldw=self.cap, res1=feat[b], ldr1=C, softmax=(st[b], self.attn_thresh, zk[b]), c2=c2)
+                ops.gemm(S[b], ops.PackedWeight.wrap(bk["v_hat_t"][b], C, self.cap), out[b], M=P, N=C, K=Mg, lda=ld, ldc=C,
+                         ldw=self.cap, res1=feat[b], ldr1=C, softmax=(st[b], self.attn_thresh, zk[b]), c2=c2, dyn_n=dyn)
                 self.wrote_packed = c2 is not None
             self.note_deferred_read()
             if not defer_attn:
@@ -263,7 +301,7 @@ class SpatialMemory:
         B, P, C, M = self.B, self.P, self.C, self.M
         assert M + P <= self.cap, "spatial memory capacity exceeded"
         for b in range(B):
-            ops.bank_write(feat_k[b], feat_v[b], self._bank_of(bk, b), M, P, C, self.cap, self._norms, 1.0 / (C ** 0.5))
+            ops.bank_write(feat_k[b], feat_v[b], self._bank_of(bk, b), M, P, C, self.cap, self._norms, 1.0 / (C ** 0.5), state=self.state)
 
     def _read_plan(self):
         """(split-K factor of the P.V GEMM, two-launch read?) at the current bank length"""
@@ -273,7 +311,10 @@ class SpatialMemory:
         S_k = 1
         while Kp // (2 * S_k) >= 2048 and S_k < 16:
             S_k *= 2
-        return S_k, (S_k == 1 and self.P * M <= self.FUSED_READ_MAX and M % 4 == 0)
+        fused = S_k == 1 and self.P * M <= self.FUSED_READ_MAX and M % 4 == 0
+        if self.read_dyn:
+            fused = fused and self._bucket() <= self.STATE_READ_MAX
+        return S_k, fused
 
     def note_deferred_read(self):
         """A two-launch read of the current bank was issued (directly or by replaying the step's hipGraph, which runs no
@@ -305,6 +346,7 @@ class SpatialMemory:
     def add_mem(self, feat_k, feat_v):
         self.stage_write(feat_k, feat_v)
         self.commit()
+        self._push_state()
 
     # ------------------------------------------------------------------ similarity gate (:97-118)
     def sim_scores(self, feat_k):
@@ -312,7 +354,10 @@ class SpatialMemory:
         B, P, C = self.B, self.P, self.C
         n = self.wm * P
         for b in range(B):
-            ops.cos_sim(feat_k[b], self.bank["k_raw"][b, self.M - n:self.M], self.wm, P, C, self._score[b], self._cos_scratch)
+            if self.state is not None:       # the window [M - wm P, M) comes from the device: the launch is sized for work_mem_size frames
+                ops.cos_sim_state(feat_k[b], self.bank["k_raw"][b], max(self.work_mem_size, 1), P, C, self.state, self._score[b], self._cos_scratch)
+            else:
+                ops.cos_sim(feat_k[b], self.bank["k_raw"][b, self.M - n:self.M], self.wm, P, C, self._score[b], self._cos_scratch)
         return self._score[:, :self.wm]
 
     def sim_needed(self):
@@ -343,7 +388,7 @@ class SpatialMemory:
         features) before the launch, sim_verdict() spins until the wm scores have replaced it."""
         self._host_scores().copy_(self._score, non_blocking=True)
 
-    _SENTINEL = 2.0                       # outside [-1, 1]: never a mean cosine (NaN scores pass through and compare False below)
+    _SENTINEL = 2.0                       # outside [-1, 1]: never a mean cosine (NaN scores pass through: a NaN maximum compares False below)
 
     def arm_score_poll(self):
         self._host_scores().fill_(self._SENTINEL)
@@ -361,13 +406,13 @@ class SpatialMemory:
                     torch.cuda.current_stream().synchronize()
                     view = self._score[:, :self.wm].cpu()
                     break
-            mx = max(view.reshape(-1).tolist())
+            mx = float(view.max())                 # (torch's max propagates NaN, as the reference's mean_corr.max() does: never 'similar')
         elif self._score_pending:
             self._score_event.synchronize()
             self._score_pending = False
-            mx = max(self._score_host[:, :self.wm].reshape(-1).tolist())
+            mx = float(self._score_host[:, :self.wm].max())
         else:
-            mx = max(self._score[:, :self.wm].cpu().reshape(-1).tolist())
+            mx = float(self._score[:, :self.wm].max())
         if mx > self.sim_thresh:
             print("Similarity detected:", mx)
             return True
@@ -386,6 +431,7 @@ class SpatialMemory:
             return
         self.add_mem(feat_k, feat_v)
         self._after_write()
+        self._push_state()
 
     def finish_staged(self, similar):
         """Second half of add_mem_check when the similarity kernel and the speculative write were already launched
@@ -396,6 +442,7 @@ class SpatialMemory:
             return
         self.commit()
         self._after_write()
+        self._push_state()
 
     def _after_write(self):
         self.wm += 1
@@ -420,7 +467,9 @@ class SpatialMemory:
         if self._banks[1 - self._cur] is None:
             self._banks[1 - self._cur] = self._alloc(self.eng.device, self.eng.wdt)
         dst = self._banks[1 - self._cur]
-        sel = torch.arange(P, M, dtype=torch.int32, device=self.eng.device)
+        sel = self._window_sel.get((P, M))
+        if sel is None:
+            sel = self._window_sel[(P, M)] = torch.arange(P, M, dtype=torch.int32, device=self.eng.device)
         for b in range(B):
             ops.gather_rows(src["k_raw"][b], dst["k_raw"][b], sel, k, C)
             ops.gather_rows(src["v_raw"][b], dst["v_raw"][b], sel, k, C)
@@ -428,7 +477,7 @@ class SpatialMemory:
             ops.gather_packed_cols(src["v_hat_t"][b], dst["v_hat_t"][b], sel, k, self.cap, C, self.cap)
             for name in ("s_bank", "b_bank", "attn", "count"):
                 ops.gather_1d(src[name][b], dst[name][b], sel, k)
-        print("Memory pruned:", (B, k, C))
+        print("Memory pruned:", torch.Size((B, k, C)))              # (spann3r/model.py:137 prints mem_k.shape)
         self.events.append("window %d->%d" % (M, k))
         self._cur = 1 - self._cur
         self.M = k
@@ -518,7 +567,7 @@ class _SequenceRunner:
     def ensure_memory(self, n_frames):
         need = (n_frames - 1) * self.P if self.training else 4000 + 8 * self.P
         if self.mem is None or self.mem.cap < need:
-            self.mem = SpatialMemory(self.eng, self.B, self.P, capacity=need, attn_thresh=0.0 if self.training else 5e-4)
+            self.mem = SpatialMemory(self.eng, self.B, self.P, capacity=need, attn_thresh=0.0 if self.training else 5e-4, device_state=True)
             self.graphs.clear()
             self.graph_bytes = 0
             self.seen.clear()
@@ -601,6 +650,20 @@ class _SequenceRunner:
             for j in range(c1 - c0):
                 outs.append((pts[j * B:(j + 1) * B], conf[j * B:(j + 1) * B]))
         return outs
+
+    def begin_outputs(self, n_steps):
+        """The results of a sequence are handed out as views into ONE fresh allocation per tensor kind (made here, once per forward
+        call), not four torch.empty per step: the caller still owns fresh tensors, the caching allocator is out
+        of the step loop."""
+        self._out_slabs, self._out_steps, self._out_i = None, n_steps, 0
+
+    def _step_outputs(self, srcs):
+        if getattr(self, "_out_steps", 0) <= 0 or self._out_i >= self._out_steps:
+            return [torch.empty_like(t) for t in srcs]               # (a step outside a begin_outputs() window)
+        if self._out_slabs is None or len(self._out_slabs) != len(srcs):
+            self._out_slabs = [t.new_empty((self._out_steps,) + tuple(t.shape)) for t in srcs]
+        i, self._out_i = self._out_i, self._out_i + 1
+        return [slab[i] for slab in self._out_slabs]
 
     def pair_copies(self, i):
         """featpair <- (feat of frame i, feat of frame i+1): two adjacent slabs of the sequence buffer, one copy (plus the same for
@@ -744,7 +807,7 @@ class _SequenceRunner:
         (decoder hooks -> sequence slots, the next pair of encoder features): six eager launches per frame became one"""
         mem = self.mem
         has_next = has_next and not self.batched                # nothing to prefetch: the sequence is already encoded
-        key = (mem.M, mem.wm, mem._cur, has_next, self.batched, self.defer2, self.model.grouped_decoder, self.model.packed_features)
+        key = mem.graph_key() + (mem._cur, has_next, self.batched, self.defer2, self.model.grouped_decoder, self.model.packed_features)
         if not use_graphs and ops._prof is not None:
             ops._prof.step_begin()
         # two graphs per step: the host fetches the similarity scores (async copy + event) as soon as the first one is
@@ -773,8 +836,9 @@ class _SequenceRunner:
                 mem.fetch_scores_async()
             self._graphed(("tail",) + key, self._part2, use_graphs)
         pts1, conf1, pts2, conf2 = self.out
-        outs = [torch.empty_like(t) for t in (pts1, conf1) + (() if pts2 is None else (pts2, conf2))]
-        copies = list(zip((pts1, conf1) + (() if pts2 is None else (pts2, conf2)), outs))
+        srcs = (pts1, conf1) + (() if pts2 is None else (pts2, conf2))
+        outs = self._step_outputs(srcs)
+        copies = list(zip(srcs, outs))
         copies += list(post_copies() if callable(post_copies) else post_copies)     # (callable: the hook buffers exist only now)
         for c0 in range(0, len(copies), 8):
             ops.copy_multi(copies[c0:c0 + 8])
@@ -786,6 +850,7 @@ class _SequenceRunner:
         # memory policy (:518-521): the frame was staged inside the step; commit or drop it here
         if self.training:
             mem.commit()
+            mem._push_state()
         else:
             mem.finish_staged(mem.sim_verdict() if need_sim else False)
         return res1, res2
@@ -854,7 +919,7 @@ class Spann3R(nn.Module):
         self.grouped_decoder = True  # bf16: the two decoder sides as grouped launches on one stream (False: two streams)
         self.single_graph_step = True   # one hipGraph per step, the similarity scores polled from pinned memory (False: two graphs + an event)
         self.packed_features = True  # bf16 + batch_encode + grouped_decoder: decoder_embed / key MLPs read fragment-order bf16 copies of the features (lean instances)
-        self.decoder_streams = os.environ.get("SP3_DEC_STREAMS", "1") == "1"   # ungrouped decoder (fp32 mode): two streams with a fork/join per layer, or one stream
+        self.decoder_streams = True  # ungrouped decoder (the fp32-operand modes): two streams with a fork/join per layer (False: one stream, side after side)
         self.force_general = False   # True: always take the reference-shaped eager loop (_forward_general; tests)
         self.max_runners = 4         # geometries (batch, H, W, policy, true_shape) kept with their buffers and graphs
 
@@ -877,10 +942,10 @@ class Spann3R(nn.Module):
     @property
     def engine(self) -> Engine:
         # every entry point (forward, the reference-shaped stage methods, offline_reconstruction, model.dust3r) fetches the
-        # engine first: the product mode of the fp32 GEMMs follows the model's precision from here
-        ops.F32X3, ops.F32X6, ops.F16X3, ops.F32_BF16 = self.precision == "f32x3", self.precision == "f32x6", self.precision == "f16x3", False
+        # engine first; the product mode of the fp32 GEMMs is the ENGINE's (Engine.activate: per engine and per thread, so two
+        # models of different precision in one process never share it)
         if self._pinned is not None:          # inside forward(): weights cannot change, skip the version scan
-            return self._pinned
+            return self._pinned.activate()
         dev = self._params["norm_q.weight"].device
         if dev.type != "cuda":
             raise RuntimeError("spann3r_amd.Spann3R runs on an MI355X only: call .to('cuda') first "
@@ -891,7 +956,7 @@ class Spann3R(nn.Module):
             self._engine = Engine(self.cfg, dict(self._params), dev, self.precision)
             self._engine_key = key
             self._runners = {}
-        return self._engine
+        return self._engine.activate()
 
     def _runner(self, key, make):
         """LRU over geometries: a runner owns the static buffers, the memory arena and the hipGraphs of one geometry."""
@@ -1115,27 +1180,21 @@ class Spann3R(nn.Module):
 
     # ------------------------------------------------------------------ forward (:473-539)
     def forward(self, frames, return_memory=False):
-        if self.training and self.mem_dropout.training and torch.is_grad_enabled():
-            # a training step (train.py / spann3r/training.py:216): the autograd-recording forward of spann3r_amd/train.py --
-            # memory attn_thresh = 0, dropout on the read, unconditional add_mem; HIP forward AND backward kernels.
+        if self.training and self.mem_dropout.training and (torch.is_grad_enabled() or self.mem_dropout.p > 0):
+            # train mode (spann3r/model.py:474-475: attn_thresh = 0, dropout on the read, unconditional add_mem) through the
+            # autograd-recording forward of spann3r_amd/train.py -- HIP forward AND backward kernels.  With gradients enabled it is
+            # a training step (spann3r/training.py:216); under torch.no_grad() with active memory dropout (a validation pass that left
+            # the model in train mode) the same ops run without a tape: the forward-only runner has no dropout mask.
             # (model.train() with model.mem_dropout.eval() keeps selecting the forward-only growing-bank policy below.)
-            if return_memory:
-                raise NotImplementedError("return_memory in a training step (the memory is a list of tape tensors there)")
             if not frames[0]["img"].is_cuda:
                 raise RuntimeError("spann3r_amd runs on an MI355X (HIP kernels); there is no CPU path -- move the frames to the GPU")
             from . import train as T
             P = {k: v for k, v in self.state_dict(keep_vars=True).items() if v.is_floating_point()}
-            p_drop = self.mem_dropout.p if self.mem_dropout.training else 0.0
-            return T.forward_train(P, frames, self.cfg, dropout_p=p_drop)
+            return T.forward_train(P, frames, self.cfg, dropout_p=self.mem_dropout.p, return_memory=return_memory)
         with torch.no_grad():
             return self._forward_inference(frames, return_memory)
 
     def _forward_inference(self, frames, return_memory):
-        if self.training and self.mem_dropout.training and self.mem_dropout.p > 0:
-            # train-mode memory policy needs a dropout mask on the attention (spann3r/model.py:167-168); the
-            # forward-only build runs it with dropout disabled, the same idiom the survey probe used on the reference
-            raise NotImplementedError("training-mode forward with active memory dropout (backward is a §8f 'next' row); "
-                                      "call model.mem_dropout.eval() for the deterministic growing-bank policy")
         self._pinned = None
         eng = self.engine
         self._pinned = eng
@@ -1201,6 +1260,7 @@ class Spann3R(nn.Module):
         mem = run.ensure_memory(len(frames))
         preds, preds_all = None, []
         n = len(frames)
+        run.begin_outputs(n - 1)
         if self.batch_encode and n > 2:
             run.encode_sequence(frames, self.use_graphs)
             if self.defer_head2:

@@ -148,7 +148,8 @@ def pick_tile(M, N, batch=1, splitk=1, conv=False, K=0, packed_bf16=False, plain
 
 
 import os as _os
-PIPE_TILES = _os.environ.get("SP3_PIPE_TILES", "1")[:1] != "0"     # mirrors the switch in csrc/gemm.hip (A/B runs)
+import threading as _threading
+PIPE_TILES = True                                               # (the pipelined LDS tiles 20-23 of csrc/gemm.hip: always on since round 6)
 PROF_SHAPES = _os.environ.get("SP3_PROF_SHAPES", "0")[:1] == "1"
 LEAN = _os.environ.get("SP3_LEAN_GEMM", "1")[:1] != "0"          # mirrors sm_enabled() in csrc/gemm_sm.hip: with the lean instances off the
                                                                   # engine must not pick the layouts only they serve (packed split-A, bf16 DPT maps)
@@ -295,12 +296,13 @@ class PackedAct:
         return self.data.data_ptr()
 
     @staticmethod
-    def group(G, M, K, dtype, device):
+    def group(G, M, K, dtype, device, alloc=None):
         """G fragment-order [M, K] matrices in one allocation, each starting on a 16-row boundary (grouped launches):
-        .stride = elements between consecutive problems, .rows_pad = padded rows per problem."""
+        .stride = elements between consecutive problems, .rows_pad = padded rows per problem.
+        alloc(shape, dtype, zero=True) -> tensor: where the storage comes from (Engine._alloc: the workspace arena)."""
         KB = 64 if dtype == torch.bfloat16 else 32
         Mp, Kp = (M + 15) // 16 * 16, (K + KB - 1) // KB * KB
-        t = PackedAct(G * Mp, K, dtype, device)
+        t = PackedAct(G * Mp, K, dtype, device, data=None if alloc is None else alloc(packed_shape(G * Mp, K, dtype), dtype, zero=True))
         t.M, t.G, t.rows_pad, t.stride = M, G, Mp, Mp * Kp
         return t
 
@@ -349,10 +351,45 @@ class PackedWeightGroup(PackedWeight):
 
 
 WEIGHTS_EPOCH = 0    # bumped by every optimizer step of spann3r_amd.train (train.invalidate_weight_cache): part of Spann3R.engine's key
-F32X3 = False        # fp32 GEMMs through three bf16 MFMAs per k-block (sp3_gemm_desc.f32x3 = 1); set by the model's "f32x3" precision
-F32X6 = False        # fp32 GEMMs through six bf16 MFMAs of a three-way split (f32x3 = 3): fp32-grade products; "f32x6" precision
-F16X3 = False        # fp32 GEMMs through three fp16 MFMAs of a two-way (h, l * 2^-11) split (f32x3 = 4): 22 operand bits; "f16x3" precision
-F32_BF16 = False     # fp32 operands rounded to bf16 inside the GEMM, one bf16 MFMA per k-block (f32x3 = 2): bf16 training step
+
+# Product mode of the GEMMs on fp32 operands (sp3_gemm_desc.f32x3).  It belongs to whoever launches: an Engine activates ITS mode
+# at every entry point (Engine.activate), the training ops theirs -- and it is kept per THREAD, so two models of different
+# precision in one process (one after the other, or one per thread) never see each other's setting.
+#   0 "fp32": exact fp32 products (v_mfma_f32_16x16x4_f32)          1 "f32x3": three bf16 MFMAs of a (hi, lo) split
+#   2 "f32_bf16": operands rounded to bf16 inside the GEMM (bf16 training step)
+#   3 "f32x6": six bf16 MFMAs of a three-way split (fp32-grade)      4 "f16x3": three fp16 MFMAs of a (h, l * 2^-11) split
+PRODUCT_MODES = {"fp32": 0, "bf16": 0, "f32x3": 1, "f32_bf16": 2, "f32x6": 3, "f16x3": 4}
+_tls = _threading.local()
+_default_mode = 0        # what a thread without its own setting sees: the training ops' mode (autograd runs backward on its own threads)
+
+
+def set_product_mode(mode, process_default=False):
+    """mode of the calling thread; process_default=True (spann3r_amd.train): also of every thread that never set one -- the
+    autograd engine executes backward nodes on its device threads"""
+    global _default_mode
+    _tls.f32_mode = PRODUCT_MODES[mode] if isinstance(mode, str) else int(mode)
+    if process_default:
+        _default_mode = _tls.f32_mode
+
+
+def get_product_mode():
+    return getattr(_tls, "f32_mode", _default_mode)
+
+
+class product_mode:
+    """`with ops.product_mode("f32x3"): ...` -- the fp32-operand GEMMs launched inside (by this thread) use that product mode"""
+
+    def __init__(self, mode):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = get_product_mode()
+        set_product_mode(self.mode)
+        return self
+
+    def __exit__(self, et, ev, tb):
+        set_product_mode(self.prev)
+        return False
 
 
 def _w(d, W):
@@ -360,7 +397,7 @@ def _w(d, W):
     d.W = W.data_ptr()
     d.w_packed = int(isinstance(W, PackedWeight))
     d.wdtype = wdtype_of(W)
-    d.f32x3 = (2 if F32_BF16 else 3 if F32X6 else 4 if F16X3 else int(F32X3)) if d.wdtype == F32 else 0
+    d.f32x3 = get_product_mode() if d.wdtype == F32 else 0
 
 
 class LnFold:
@@ -411,8 +448,12 @@ def _act(t, name):
 def gemm(A, W, out, *, M, N, K, lda, ldc, bias=None, res1=None, ldr1=0, res2=None, ldr2=0, act=ACT_NONE, alpha=1.0,
          relu_in=False, tile=-1, batch=1, strideA=0, strideW=0, strideC=0, ldw=0,
          A2=None, lda2=0, K1=0, splitk=0, ln=None, stats_out=None, c2=None, sb=None, trace=None,
-         sm_stats_out=None, softmax=None):
+         sm_stats_out=None, softmax=None, plan_only=False, dyn_n=None):
     """out[M,N] = act(alpha * A[M,K] @ W[N,K]^T + bias) (+ res1 + res2).  nn.Linear / 1x1 conv / einsum.
+    dyn_n (int32 device tensor): the memory read's growing extent as device state -- the score GEMM (sm_stats_out) reads its N, the
+    softmax-loader GEMM its K from dyn_n[0]; the N / K passed here only bound the launch (include/spann3r_hip.h dyn_n).
+    plan_only: nothing is launched; returns the tile the library would take for this descriptor (sp3_gemm_plan: >= 30 = a lean
+    instance, < 30 = the general kernel's tiles, which not every operand layout has).
     `out` may be fp32 or bf16.  splitk >= 1 selects the PARTIAL epilogue: out is an fp32 [splitk, M, ldc] workspace
     that sp3_reduce_ln finishes.
     sm_stats_out: fp32 [M, ceil(N/32), 2] gets the (max, sum exp) partials of the finished rows (score GEMM of the memory
@@ -437,11 +478,14 @@ def gemm(A, W, out, *, M, N, K, lda, ldc, bias=None, res1=None, ldr1=0, res2=Non
     d.stats_out, d.c2 = L.ptr(stats_out), L.ptr(c2)
     d.trace = L.ptr(trace)
     d.sm_stats_out = L.ptr(sm_stats_out)
+    d.dyn_n = L.ptr(dyn_n)
     if softmax is not None:
         st, thresh, zout = softmax
         d.loader, d.sm_stats, d.sm_nt, d.sm_thresh, d.sm_zout = L.LOAD_SOFTMAX, st.data_ptr(), (K + 31) // 32, float(thresh), L.ptr(zout)
     if sb:
         _group(d, batch, strideA, strideW, strideC, sb)
+    if plan_only:
+        return int(L.load().sp3_gemm_plan(C.byref(d)))
     _gemm_launch(d, "sp3_gemm", "softmax" if softmax is not None else "plain")
     return out
 
@@ -648,7 +692,7 @@ def attention(q, sq, ldq, k, sk, ldk, vt, vt_ld, out, ldo, *, B, heads, Nq, Nk, 
            B * heads * 64.0 * (es * (Nq + 2 * Nk) + 4 * Nq),
            lambda: L.check(L.load().sp3_attention_ex(q.data_ptr(), sq, ldq, k.data_ptr(), sk, ldk, vt.data_ptr(), vt_ld,
                                                      out.data_ptr(), ldo, int(out.dtype == torch.bfloat16), _is_packed(out),
-                                                     B, heads, Nq, Nk, float(scale), (2 if (F32X3 and es == 4) else 3 if (F16X3 and es == 4) else wdtype_of(vt)),
+                                                     B, heads, Nq, Nk, float(scale), (2 if (get_product_mode() == 1 and es == 4) else 3 if (get_product_mode() == 4 and es == 4) else wdtype_of(vt)),
                                                      L.stream_ptr()),
                            "sp3_attention"))
     return out
@@ -716,9 +760,11 @@ def colsum_softmax(S, ld, rows, M, rowz, thresh, mem_attn, mem_count=None, appen
                                                        L.ptr(mem_count), append_P, L.stream_ptr()), "sp3_colsum_softmax"))
 
 
-def bank_write(feat_k, feat_v, bank, M, P, C_, cap, norms, alpha, eps=1e-5):
-    """bank: dict with k_raw, v_raw, k_hat, v_hat_t, s_bank, b_bank (one batch element); norms: (gk, bk, gv, bv, gq, bq)"""
+def bank_write(feat_k, feat_v, bank, M, P, C_, cap, norms, alpha, eps=1e-5, state=None):
+    """bank: dict with k_raw, v_raw, k_hat, v_hat_t, s_bank, b_bank (one batch element); norms: (gk, bk, gv, bv, gq, bq).
+    state (int32 device tensor, bank_state_set): the first row is read from state[0] on the device instead of M."""
     d = L.BankWriteDesc()
+    d.state = L.ptr(state)
     d.feat_k, d.feat_v = feat_k.data_ptr(), feat_v.data_ptr()
     d.k_raw, d.v_raw, d.k_hat, d.v_hat_t = bank["k_raw"].data_ptr(), bank["v_raw"].data_ptr(), bank["k_hat"].data_ptr(), bank["v_hat_t"].data_ptr()
     d.s_bank, d.b_bank = bank["s_bank"].data_ptr(), bank["b_bank"].data_ptr()
@@ -799,6 +845,18 @@ def gather_packed_rows(src, dst, sel, n_sel, C_):
 def gather_packed_cols(src, dst, sel, n_sel, n_fill, C_, cap):
     L.check(L.load().sp3_gather_packed_cols(src.data_ptr(), dst.data_ptr(), sel.data_ptr(), n_sel, n_fill, C_, cap, src.element_size(),
                                             L.stream_ptr()), "sp3_gather_packed_cols")
+
+
+def bank_state_set(state, M, wm):
+    """state[0] = M, state[1] = wm on the device (the fill level the kernels of a step read: their hipGraph does not depend on it)"""
+    L.check(L.load().sp3_bank_state_set(state.data_ptr(), int(M), int(wm), L.stream_ptr()), "sp3_bank_state_set")
+
+
+def cos_sim_state(k, k_raw, Tmax, P, C_, state, score, scratch):
+    """cos_sim against the last state[1] (<= Tmax) frames of the bank's k_raw, rows [state[0] - state[1] P, state[0])"""
+    assert scratch.numel() >= Tmax * P and scratch.dtype == torch.float32 and state.dtype == torch.int32
+    L.check(L.load().sp3_cos_sim_state(k.data_ptr(), k_raw.data_ptr(), Tmax, P, C_, state.data_ptr(), scratch.data_ptr(), score.data_ptr(),
+                                       L.stream_ptr()), "sp3_cos_sim_state")
 
 
 def cos_sim(k, wm, T, P, C_, score, scratch):

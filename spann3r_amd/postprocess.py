@@ -191,7 +191,11 @@ def estimate_poses(pts_all, focal, pp, reproj_thresh=8.0, iterations=100, confid
     """pts_all fp32 [F,H,W,3] on the device (every frame's pointmap in the first camera's frame), focal, pp = (cx, cy) ->
     poses float64 [F,4,4] camera-to-world (= inv(extrinsic), what demo.py:186 appends) and the consensus fractions [F].
     Stands where `cv2.solvePnPRansac(pts, pixel_grid, K, 0)` + Rodrigues + inv stand in demo.py:170-186 and follows OpenCV's
-    pipeline step by step (see the block comment above); non-finite points are left out, as a caller of OpenCV would have to."""
+    pipeline stage by stage (see the block comment above): the same subsets, hypotheses, consensus test and iteration count, then a
+    Levenberg-Marquardt refinement that reaches the same MINIMUM on the fixed consensus set but not through the same iterates --
+    the pose is perturbed on the left (omega, delta) here, CvLevMarq damps (rvec, tvec), so the stopping point differs at the
+    1e-5 level.  Parity with cv2 itself is unpinned (no OpenCV in the image: oracle/pnp_oracle.py is the anchor, DESIGN.md section 1);
+    non-finite points are left out, as a caller of OpenCV would have to."""
     if not pts_all.is_cuda:
         raise RuntimeError("estimate_poses runs on the GPU (HIP kernels); there is no CPU path")
     F, H, W, _ = pts_all.shape

@@ -51,7 +51,7 @@ def set_precision(p):
     if p not in ("fp32", "bf16"):
         raise ValueError("training precision must be 'fp32' or 'bf16'")
     PRECISION = p
-    ops.F32_BF16 = p == "bf16"
+    ops.set_product_mode("f32_bf16" if p == "bf16" else "fp32", process_default=True)
 
 
 def invalidate_weight_cache():
@@ -169,7 +169,7 @@ class _MemoryReadTrain(torch.autograd.Function):
     """one batch element: feat [P,C], mem_k / mem_v [T,C], mask [P,T] or None"""
 
     @staticmethod
-    def forward(ctx, feat, mem_k, mem_v, gq, bq, gk, bk, gv, bv, mask, eps):
+    def forward(ctx, feat, mem_k, mem_v, gq, bq, gk, bk, gv, bv, mask, eps, attn_accum=None):
         P, C = feat.shape
         T = mem_k.shape[0]
         Tp = _r8(T)
@@ -196,6 +196,8 @@ class _MemoryReadTrain(torch.autograd.Function):
             mask = mp
         out = f32(P, C)
         ops.gemm(Ad, vht, out, M=P, N=C, K=Tp, lda=Tp, ldc=C, res1=feat, ldr1=C)
+        if attn_accum is not None:             # spann3r/model.py:180-181: mem_attn += column sums of the (dropped-out) attention
+            ops.colsum_accum(Ad, Tp, P, T, attn_accum)
         ctx.save_for_backward(feat, mem_k, mem_v, gq, gk, gv, qh, kh, vht, A, Ad, mask if mask is not None else torch.empty(0, device=dev))
         ctx.eps, ctx.alpha = eps, alpha
         return out
@@ -234,19 +236,21 @@ class _MemoryReadTrain(torch.autograd.Function):
         dfeat, dgq, dbq = _ln_bwd(feat, gq, dqh, dO, ctx.eps)
         dk, dgk, dbk = _ln_bwd(mem_k, gk, dKh, None, ctx.eps)
         dv, dgv, dbv = _ln_bwd(mem_v, gv, dVh, None, ctx.eps)
-        return dfeat, dk, dv, dgq, dbq, dgk, dbk, dgv, dbv, None, None
+        return dfeat, dk, dv, dgq, dbq, dgk, dbk, dgv, dbv, None, None, None
 
 
-def memory_read_train(feat, mem_k, mem_v, norm_q, norm_k, norm_v, mask=None, eps=1e-5):
+def memory_read_train(feat, mem_k, mem_v, norm_q, norm_k, norm_v, mask=None, eps=1e-5, attn_accum=None):
     """feat [B,P,C], mem_k / mem_v [B,T,C] (fp32, device); norm_* = (weight, bias) of the three LayerNorms; mask [B,P,T]
-    float32 dropout mask (0 or 1/(1-p)) or None.  -> out [B,P,C] = memory_read(feat, res=True) of the reference in train mode."""
+    float32 dropout mask (0 or 1/(1-p)) or None.  -> out [B,P,C] = memory_read(feat, res=True) of the reference in train mode.
+    attn_accum fp32 [B,T] (contiguous; no gradient): += the column sums of the attention after dropout (the reference's mem_attn)."""
     if not feat.is_cuda:
         raise RuntimeError("memory_read_train runs on the GPU (HIP kernels); there is no CPU path")
     outs = []
     for b in range(feat.shape[0]):
         outs.append(_MemoryReadTrain.apply(feat[b].contiguous().float(), mem_k[b].contiguous().float(), mem_v[b].contiguous().float(),
                                            norm_q[0], norm_q[1], norm_k[0], norm_k[1], norm_v[0], norm_v[1],
-                                           None if mask is None else mask[b].contiguous(), eps))
+                                           None if mask is None else mask[b].contiguous(), eps,
+                                           None if attn_accum is None else attn_accum[b]))
     return torch.stack(outs)
 
 
@@ -1085,14 +1089,21 @@ def head_by_orientation(dec, land, nh, nw, P, cfg, num):
     return out[0], out[1]
 
 
-def forward_train(P, frames, cfg, dropout_p=0.0, generator=None):
-    """-> (preds, preds_all) of Spann3R.forward in train mode.  P: {reference parameter name: tensor} (leaves of the tape);
+class TrainMemory:
+    """What forward(..., return_memory=True) hands out in train mode: the visible fields of the reference's SpatialMemory after the
+    sequence (spann3r/model.py:80-95,180-181) -- mem_k / mem_v are the tape tensors themselves."""
+    mem_k = mem_v = mem_attn = mem_count = None
+    wm = lm = 0
+    num_patches = None
+
+
+def forward_train(P, frames, cfg, dropout_p=0.0, generator=None, return_memory=False):
+    """-> (preds, preds_all[, memory]) of Spann3R.forward in train mode.  P: {reference parameter name: tensor} (leaves of the tape);
     frames: list of dicts with img [B,3,H,W] on the device and, optionally, `true_shape` [B, 2] (portraits the dataset rotated to
     landscape, also mixed with landscape samples in one batch: head_by_orientation); dropout_p: spann3r/model.py:229
     memory_dropout (0.15 in training), drawn from `generator`."""
-    ops.F32_BF16 = PRECISION == "bf16"       # (an inference call in between may have reset the product mode of the fp32 GEMMs)
-    ops.F32X3 = ops.F32X6 = ops.F16X3 = False
-    mem_k = mem_v = None
+    ops.set_product_mode("f32_bf16" if PRECISION == "bf16" else "fp32", process_default=True)   # (an inference call in between activated its engine's own on this thread)
+    mem_k = mem_v = mem_attn = mem_count = None
     feat2 = pos2 = feat_k2 = None
     preds, preds_all = None, []
     nq, nk, nv = (P["norm_q.weight"], P["norm_q.bias"]), (P["norm_k.weight"], P["norm_k.bias"]), (P["norm_v.weight"], P["norm_v.bias"])
@@ -1117,7 +1128,7 @@ def forward_train(P, frames, cfg, dropout_p=0.0, generator=None):
             if dropout_p > 0:
                 keep = torch.rand(feat_k2.shape[0], feat_k2.shape[1], mem_k.shape[1], device=feat_k2.device, generator=generator) >= dropout_p
                 mask = keep.float() / (1.0 - dropout_p)
-            feat_fuse = memory_read_train(feat_k2, mem_k, mem_v, nq, nk, nv, mask)
+            feat_fuse = memory_read_train(feat_k2, mem_k, mem_v, nq, nk, nv, mask, attn_accum=mem_attn if return_memory else None)
         else:
             feat_fuse = feat1
         dec1, dec2 = decoder(feat_fuse, pos1, feat2, pos2, P, cfg)
@@ -1129,6 +1140,10 @@ def forward_train(P, frames, cfg, dropout_p=0.0, generator=None):
         v = encode_cur_value(pts1, feat_k1, P, cfg, dec1[-1], pos1)
         mem_k = feat_k1 if mem_k is None else torch.cat((mem_k, feat_k1), 1)
         mem_v = v if mem_v is None else torch.cat((mem_v, v), 1)
+        if return_memory:                                             # add_mem's bookkeeping (spann3r/model.py:84-90)
+            z = torch.zeros(feat_k1.shape[0], feat_k1.shape[1], device=feat_k1.device)
+            mem_count = z if mem_count is None else torch.cat((mem_count + 1, z), 1)
+            mem_attn = z.clone() if mem_attn is None else torch.cat((mem_attn, z), 1).contiguous()
         res2 = {"pts3d_in_other_view": pts2, "conf": conf2}
         if preds is None:
             res1 = {"pts3d": pts1, "conf": conf1}
@@ -1138,6 +1153,11 @@ def forward_train(P, frames, cfg, dropout_p=0.0, generator=None):
             preds.append(res1)
         preds_all.append((res1, res2))
     preds.append(res2)
+    if return_memory:
+        mem = TrainMemory()
+        mem.mem_k, mem.mem_v, mem.mem_attn, mem.mem_count = mem_k, mem_v, mem_attn[..., None], mem_count[..., None]
+        mem.num_patches = mem_k.shape[1] // (len(frames) - 1)
+        return preds, preds_all, mem
     return preds, preds_all
 
 
@@ -1209,7 +1229,7 @@ class TrainStep:
         # multi-rank too: the bucket all-reduces (RCCL through torch.distributed's NCCL backend is capturable) are part of the
         # captured step; SP3_TRAIN_GRAPH=0 forces the eager step
         import os
-        self.graph = bool(graph) and os.environ.get("SP3_TRAIN_GRAPH", "1") != "0"
+        self.graph = bool(graph)
         self._g = self._static = self._out = None
         # gradient accumulation (spann3r/training.py:228-233): run() is ONE iteration of the loop; the gradients of accum_iter
         # consecutive iterations (each loss divided by accum_iter) add up in the flat buckets and the last one reduces them over the

@@ -338,3 +338,86 @@ def test_layernorm_dual_groups():
     assert rel_err(out.cpu(), ref) < 1e-5
     for k in range(G):
         assert torch.equal(_dense(ops, dual, k, R, C_), out[k * R:(k + 1) * R].to(BF))
+
+
+# ----------------------------------------------------------------------------- the bank's fill level as device state (round 6)
+@pytest.mark.parametrize("M", [196, 1764, 2044, 4000, 8192])
+def test_memory_read_with_the_extent_on_the_device(M):
+    """The two launches of the short-bank memory read (tiles 43 / 44, spann3r/model.py:159-183) sized for a BUCKET of bank tokens,
+    with the real count read from a device int32 (sp3_gemm_desc.dyn_n): scores, softmax statistics, fused output and the kept
+    mass are bit-identical to the launches that carry the count as an argument -- for several counts through the SAME bucket
+    descriptor, which is what lets one captured hipGraph serve a growing bank."""
+    ops = _ops()
+    P, C, thr = 196, 1024, 5e-4
+    bucket = (M + 2047) // 2048 * 2048
+    cap = bucket + 64
+    q = rnd(P, C, seed=1) * 1.5 + 0.1
+    qp, qs = ops.PackedAct(P, C, BF, DEV), torch.zeros(P, C // 32, 2, device=DEV)
+    ops.pack_stats(q.to(DEV), qp, qs, rows=P, C_=C)
+    Kh = ops.PackedAct.from_dense((rnd(cap, C, seed=2) * 2).to(DEV).to(BF))           # rows past M hold stale (non-zero) tokens
+    Vt = ops.PackedAct.from_dense(rnd(C, cap, seed=3).to(DEV).to(BF))
+    sb, bb = (rnd(cap, seed=4) * 0.1).to(DEV), (rnd(cap, seed=5) * 0.1).to(DEV)
+    state = torch.zeros(4, dtype=torch.int32, device=DEV)
+    nt_cap = (cap + 31) // 32
+
+    def read(n_arg, dyn):
+        S = torch.full((P, cap), float("nan"), device=DEV)
+        st = torch.full((P * nt_cap * 2,), float("nan"), device=DEV)
+        out, zk = torch.full((P, C), float("nan"), device=DEV), torch.full((P, 4), float("nan"), device=DEV)
+        tiles = _plan_of(ops, lambda: ops.gemm(qp, ops.PackedWeight.wrap(Kh.data, n_arg, C), S, M=P, N=n_arg, K=C, lda=C, ldc=cap, alpha=1 / 32.,
+                                               bias=bb, ln=ops.LnFold(qs, C, sb, 1e-5), sm_stats_out=st, dyn_n=dyn))
+        tiles += _plan_of(ops, lambda: ops.gemm(S, ops.PackedWeight.wrap(Vt.data, C, cap), out, M=P, N=C, K=n_arg, lda=cap, ldc=C, ldw=cap,
+                                                res1=q.to(DEV), ldr1=C, softmax=(st, thr, zk), dyn_n=dyn))
+        assert tiles == [43, 44], tiles
+        return S, st, out, zk
+    ref = read(M, None)
+    ops.bank_state_set(state, M, 3)
+    got = read(bucket, state)
+    ng = (M + 31) // 32
+    assert torch.equal(ref[0][:, :M], got[0][:, :M]) and torch.isnan(got[0][:, M:]).all()       # nothing written past the bank's end
+    assert torch.equal(ref[1][:P * ng * 2], got[1][:P * ng * 2])
+    assert torch.equal(ref[2], got[2]) and torch.equal(ref[3], got[3])
+    assert not torch.isnan(got[2]).any()
+    # a smaller count through the same (bucket-sized) descriptor
+    M2 = max(4, (M // 2) // 4 * 4)
+    ref2 = read(M2, None)
+    ops.bank_state_set(state, M2, 1)
+    got2 = read(bucket, state)
+    assert torch.equal(ref2[0][:, :M2], got2[0][:, :M2]) and torch.equal(ref2[2], got2[2]) and torch.equal(ref2[3], got2[3])
+    # the general kernels do not take a device-side extent
+    with pytest.raises(RuntimeError, match="dyn_n"):
+        ops.gemm(qp, ops.PackedWeight.wrap(Kh.data, bucket, C), torch.empty(P, cap, device=DEV), M=P, N=bucket, K=C, lda=C, ldc=cap, dyn_n=state, tile=0)
+
+
+@pytest.mark.parametrize("wdt", [BF, torch.float32])
+def test_bank_write_and_similarity_window_from_device_state(wdt):
+    """sp3_bank_write with the first row read from the device state and sp3_cos_sim_state (the working-memory window [M - wm P, M) of
+    spann3r/model.py:97-118 from the same state): identical to the launches that carry M / wm as arguments, at fill levels that
+    start inside and on a token-group boundary."""
+    ops = _ops()
+    P, C, cap, Tmax = 196, 1024, 1024, 5
+    names = ("gk", "bk", "gv", "bv", "gq", "bq")
+    norms = tuple((rnd(C, seed=20 + i) * 0.2 + (1.0 if n[0] == "g" else 0.0)).to(DEV) for i, n in enumerate(names))
+
+    def bank():
+        return dict(k_raw=torch.zeros(cap, C, device=DEV), v_raw=torch.zeros(cap, C, device=DEV),
+                    k_hat=torch.zeros(ops.packed_shape(cap, C, wdt), dtype=wdt, device=DEV),
+                    v_hat_t=torch.zeros(ops.packed_shape(C, cap, wdt), dtype=wdt, device=DEV),
+                    s_bank=torch.zeros(cap, device=DEV), b_bank=torch.zeros(cap, device=DEV))
+    a, b = bank(), bank()
+    state = torch.zeros(4, dtype=torch.int32, device=DEV)
+    for f in range(4):                                   # M = 0, 196, 392, 588: 196 % 8 = 4 -> aligned and unaligned starts
+        k, v = (rnd(P, C, seed=10 + f) * 2).to(DEV), (rnd(P, C, seed=30 + f) * 2).to(DEV)
+        ops.bank_write(k, v, a, f * P, P, C, cap, norms, 1 / 32.)
+        ops.bank_state_set(state, f * P, min(f, Tmax))
+        ops.bank_write(k, v, b, -12345, P, C, cap, norms, 1 / 32., state=state)
+    for n in a:
+        assert torch.equal(a[n], b[n]), n
+    M = 4 * P
+    probe = (rnd(P, C, seed=99)).to(DEV)
+    for wm in (1, 3, 4):
+        s1, s2 = torch.full((Tmax,), 7.0, device=DEV), torch.full((Tmax,), 7.0, device=DEV)
+        ops.cos_sim(probe, a["k_raw"][M - wm * P:M], wm, P, C, s1, torch.empty(Tmax * P, device=DEV))
+        ops.bank_state_set(state, M, wm)
+        ops.cos_sim_state(probe, a["k_raw"], Tmax, P, C, state, s2, torch.empty(Tmax * P, device=DEV))
+        assert torch.equal(s1, s2) and float(s2[wm:].min() if wm < Tmax else 7.0) == 7.0      # entries past wm untouched

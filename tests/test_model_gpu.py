@@ -198,8 +198,8 @@ def test_tiny_use_feat_mem_pos_enc_vs_golden(precision, tol):
 
 
 def test_graph_replay_equals_eager(tiny_model):
-    """1st call of a geometry runs eagerly, 2nd captures + replays hipGraphs, 3rd replays: all bit-identical,
-    and identical to use_graphs=False (same kernels, same order)."""
+    """1st call of a geometry runs eagerly, later calls capture + replay hipGraphs: all bit-identical, and identical to
+    use_graphs=False (same kernels, same order).  fp32 operands: the step graphs are keyed by the bank length (one per step)."""
     from spann3r_amd.weights import synth_frames
     m = tiny_model
     frames = to_dev(synth_frames(5, 48, 64, seed=5))
@@ -220,6 +220,98 @@ def test_graph_replay_equals_eager(tiny_model):
     # a different sequence through the captured graphs must differ (inputs are copied into the static buffers)
     other, _ = m(to_dev(synth_frames(5, 48, 64, seed=6)))
     assert not torch.equal(other[0]["pts3d"], outs[0][0][0]["pts3d"])
+
+
+@pytest.mark.parametrize("policy", ["eval", "growing"])
+def test_one_step_graph_serves_a_growing_bank(tiny_sd, policy):
+    """bf16 (the bench mode): the bank's fill level is device state (SpatialMemory(device_state=True)), so ONE captured hipGraph per
+    step kind serves every bank length -- replay starts at the third step of the FIRST forward call, the graph count does not
+    grow with the sequence, and replays are bit-identical to eager launches of the same kernels.  Both memory policies: eval (similarity
+    gate, skips) and the growing bank of BASELINE config 3."""
+    from spann3r_amd import Spann3R, TINY
+    from spann3r_amd.weights import synth_frames
+    m = Spann3R(dus3r_name=None, cfg=TINY, init_weights=False)
+    m.load_state_dict(tiny_sd, strict=True)
+    m = m.to(DEV).eval().set_precision("bf16")
+    if policy == "growing":
+        m.train()
+        m.mem_dropout.eval()
+    n = 12
+    frames = to_dev(synth_frames(n, 48, 64, seed=11))
+    first = m(frames, return_memory=True)                 # call 1: step graphs are captured INSIDE it (second sight of their key)
+    run = [r for k, r in m._runners.items() if k[:3] == (1, 48, 64)][0]
+    assert run.mem.state is not None
+    steps = [k for k in run.graphs if k[0] in ("first", "step", "whole")]
+    assert 1 <= len(steps) <= 3, steps                    # (eval: the similarity gate switches on once -> a second step kind)
+    again = m(frames, return_memory=True)                 # call 2: every key replays or is captured now
+    n_graphs = len(run.graphs)
+    third = m(frames, return_memory=True)
+    assert len(run.graphs) == n_graphs <= 6, list(run.graphs)
+    longer = to_dev(synth_frames(n + 6, 48, 64, seed=11))
+    m.use_graphs = False
+    try:
+        eager = m(frames, return_memory=True)
+        eager_long = m(longer, return_memory=True)
+    finally:
+        m.use_graphs = True
+    for o in (again, third, eager):
+        for a, b in zip(first[0], o[0]):
+            for k in a:
+                assert torch.equal(a[k], b[k]), k
+        assert torch.equal(first[2].mem_k, o[2].mem_k) and torch.equal(first[2].mem_attn, o[2].mem_attn)
+        assert torch.equal(first[2].mem_count, o[2].mem_count) and first[2].events == o[2].events
+    # a LONGER sequence through the same step graphs (the growing-bank arena is re-made at its new capacity, eval keeps its own)
+    got_long = m(longer, return_memory=True)
+    got_long = m(longer, return_memory=True)
+    for a, b in zip(eager_long[0], got_long[0]):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+    assert torch.equal(eager_long[2].mem_attn, got_long[2].mem_attn)
+    run = [r for k, r in m._runners.items() if k[:3] == (1, 48, 64)][0]
+    assert sum(k[0] in ("first", "step", "whole") for k in run.graphs) <= 3
+
+
+def test_two_models_of_different_precision_in_one_process(tiny_sd):
+    """The product mode of the fp32-operand GEMMs belongs to the ENGINE and is activated per thread at each of its entry points
+    (Engine.activate): a second model of another precision -- used in between, or concurrently from another thread -- does not
+    change what the first one computes (round 5 kept it in module globals of spann3r_amd.ops: last writer wins)."""
+    import threading
+    from spann3r_amd import Spann3R, TINY
+    from spann3r_amd.weights import synth_frames
+
+    def make(prec):
+        m = Spann3R(dus3r_name=None, cfg=TINY, init_weights=False)
+        m.load_state_dict(tiny_sd, strict=True)
+        return m.to(DEV).eval().set_precision(prec)
+    a, b = make("fp32"), make("f32x3")
+    view = to_dev(synth_frames(1, 48, 64, seed=3))[0]
+    alone_a, alone_b = a.encode_image(view)[0].clone(), b.encode_image(view)[0].clone()
+    assert not torch.equal(alone_a, alone_b)                       # the two modes do differ (three bf16 MFMAs vs exact fp32)
+    # interleaved on one thread, holding the engines across each other's calls
+    ea, eb = a.engine, b.engine                                    # b's engine was fetched LAST
+    fa = ea.encode_image(view["img"].float())[0].clone()
+    fb = eb.encode_image(view["img"].float())[0].clone()
+    fa2 = ea.encode_image(view["img"].float())[0].clone()
+    assert torch.equal(fa, alone_a) and torch.equal(fa2, alone_a) and torch.equal(fb, alone_b)
+    # one model per thread, several rounds each
+    out, err = {}, []
+
+    def work(name, m, ref):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for _ in range(6):
+                    f = m.encode_image(view)[0]
+                    s.synchronize()
+                    if not torch.equal(f, ref):
+                        err.append(name)
+            out[name] = True
+        except Exception as e:                                      # noqa: BLE001 -- reported through the assertion below
+            err.append("%s: %r" % (name, e))
+    ts = [threading.Thread(target=work, args=("fp32", a, alone_a)), threading.Thread(target=work, args=("f32x3", b, alone_b))]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not err and len(out) == 2, err
 
 
 def test_batched_encoder_equals_per_frame(tiny_model):
@@ -535,7 +627,9 @@ def test_mixed_orientation_batch_vs_reference(tiny_model):
 
 
 # ----------------------------------------------------------------------------- the benched configurations, at their lengths
-def _run_sequence_fixture(name, full_sd, precision):
+def _run_sequence_fixture(name, full_sd, precision, switches_off=(), warm_calls=0):
+    """switches_off: scheduling attributes of the model set to False for the run; warm_calls: forwards before the measured one (0: the
+    measured call is a geometry's first = eager launches; 2: it replays the hipGraphs the second call captured)"""
     from spann3r_amd import Spann3R, FULL
     from spann3r_amd.weights import synth_frames, state_dict_fingerprint
     g = load_golden(name)
@@ -550,6 +644,11 @@ def _run_sequence_fixture(name, full_sd, precision):
         m.train()
         m.mem_dropout.eval()
     frames = _with_true_shape(to_dev(synth_frames(n, H, W)), (H, W))
+    for sw in switches_off:
+        assert getattr(m, sw) is True, sw
+        setattr(m, sw, False)
+    for _ in range(warm_calls):
+        m(frames)
     taps = []
     from spann3r_amd.model import _SequenceRunner
     orig = _SequenceRunner.run
@@ -635,6 +734,33 @@ def test_cfg2_224x10_vs_reference(full_sd, precision, tol):
     ppmax = err.pop("pts_ppmax")
     assert max(err.values()) < tol, err
     assert ppmax < 5 * tol, (ppmax, err)                      # the worst single point too (measured f16x3: 3.6e-5)
+
+
+@pytest.mark.parametrize("switch,precision", [("batch_encode", "bf16"), ("defer_head2", "bf16"), ("grouped_decoder", "bf16"),
+                                              ("single_graph_step", "bf16"), ("packed_features", "bf16"), ("use_graphs", "bf16"),
+                                              ("decoder_streams", "fp32"), ("batch_encode", "fp32"), ("single_graph_step", "fp32")])
+def test_cfg2_schedule_switches_vs_reference(full_sd, switch, precision):
+    """Every scheduling attribute the model keeps, with its NON-default value, on the config-2 reference dump (each switch
+    is a path of its own; the defaults alone were pinned to the BASELINE fixtures).  The measured call is the third of its geometry,
+    i.e. it replays the graphs that schedule captured (use_graphs off: eager by definition)."""
+    err = _run_sequence_fixture("spann3r_cfg2_224x10.npz", full_sd, precision, switches_off=(switch,), warm_calls=2)
+    if precision == "bf16":
+        _assert_bf16(err, _bf16_bounds("cfg2", TOL_BF16))
+        return
+    ppmax = err.pop("pts_ppmax")
+    assert max(err.values()) < TOL_FP32 and ppmax < 5 * TOL_FP32, (ppmax, err)
+
+
+def test_cfg2_with_lean_instances_off():
+    """SP3_LEAN_GEMM=0 (the library's one environment switch: general kernels instead of the lean families, fp32 DPT maps, row-major
+    split A) is read when the library loads, so the config-2 parity run with it happens in a process of its own."""
+    import subprocess
+    import sys
+    env = dict(os.environ, SP3_LEAN_GEMM="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(root, "tests", "test_model_gpu.py"),
+                        "-k", "test_cfg2_224x10_vs_reference and bf16"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 @pytest.mark.parametrize("precision,tol", [("fp32", TOL_FP32), ("f32x3", TOL_FP32), ("bf16", TOL_BF16)])

@@ -865,14 +865,14 @@ def test_attention_f32x3():
     ref = torch.einsum("bhqk,bkhd->bqhd", a, v.double()).reshape(B * Nq, C)
     errs = {}
     for x3 in (False, True):
-        ops.F32X3 = x3
+        ops.set_product_mode("f32x3" if x3 else "fp32")
         try:
             out = torch.empty(B * Nq, C, device=DEV)
             ops.attention(q.reshape(B, Nq, C).to(DEV), Nq * C, C, k.reshape(B, Nk, C).to(DEV), Nk * C, C, vt.to(DEV), npk, out, C,
                           B=B, heads=heads, Nq=Nq, Nk=Nk, scale=0.125)
             errs[x3] = rel_err(out.cpu(), ref)
         finally:
-            ops.F32X3 = False
+            ops.set_product_mode("fp32")
     assert errs[False] < 2e-6 and 1e-6 < errs[True] < 5e-5, errs
 
 
@@ -890,7 +890,7 @@ def test_attention_and_gemm_f16x3():
     M, N, K = 196, 768, 1024
     A, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2) * 0.05, rnd(N, seed=3)
     gref = A.double() @ W.double().T + b.double()
-    ops.F16X3 = True
+    ops.set_product_mode("f16x3")
     try:
         out = torch.empty(B * Nq, C, device=DEV)
         ops.attention(q.reshape(B, Nq, C).to(DEV), Nq * C, C, k.reshape(B, Nk, C).to(DEV), Nk * C, C, vt.to(DEV), npk, out, C,
@@ -902,7 +902,7 @@ def test_attention_and_gemm_f16x3():
             ops.gemm(A.to(DEV), W.to(DEV), o, M=M, N=N, K=K, lda=K, ldc=N, bias=b.to(DEV), tile=tile)
             eg.append(rel_err(o.cpu(), gref))
     finally:
-        ops.F16X3 = False
+        ops.set_product_mode("fp32")
     assert ea < 3e-6 and max(eg) < 3e-6, (ea, eg)
 
 
@@ -914,25 +914,25 @@ def test_gemm_f32x3_products():
     ref = A.double() @ W.double().T + b.double()
     outs = {}
     for x3 in (False, True):
-        ops.F32X3 = x3
+        ops.set_product_mode("f32x3" if x3 else "fp32")
         try:
             for tile in (0, 1):
                 out = torch.empty(M, N, device=DEV)
                 ops.gemm(A.to(DEV), W.to(DEV), out, M=M, N=N, K=K, lda=K, ldc=N, bias=b.to(DEV), tile=tile)
                 outs[(x3, tile)] = rel_err(out.cpu(), ref)
         finally:
-            ops.F32X3 = False
+            ops.set_product_mode("fp32")
     assert max(outs[(False, 0)], outs[(False, 1)]) < 2e-6                      # exact fp32 products
     assert 2e-6 < max(outs[(True, 0)], outs[(True, 1)]) < 3e-5, outs            # 2^-16-class products, far inside TF32's 5e-4
     # bf16 operands are untouched by the switch
-    ops.F32X3 = True
+    ops.set_product_mode("f32x3")
     try:
         o1, o2 = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
         ops.gemm(A.to(DEV).to(torch.bfloat16), W.to(DEV).to(torch.bfloat16), o1, M=M, N=N, K=K, lda=K, ldc=N)
-        ops.F32X3 = False
+        ops.set_product_mode("fp32")
         ops.gemm(A.to(DEV).to(torch.bfloat16), W.to(DEV).to(torch.bfloat16), o2, M=M, N=N, K=K, lda=K, ldc=N)
     finally:
-        ops.F32X3 = False
+        ops.set_product_mode("fp32")
     assert torch.equal(o1, o2)
 
 

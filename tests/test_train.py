@@ -415,6 +415,44 @@ def test_model_train_mode_runs_a_step(tiny_sd):
 
 
 @pytest.mark.gpu
+def test_train_mode_forward_without_grad_and_return_memory(tiny_sd):
+    """spann3r/model.py:474-477,536-539 allow both: (a) model.train() under torch.no_grad() with ACTIVE memory dropout (a validation
+    pass that leaves the model in train mode) -- the train-mode ops run without a tape; (b) return_memory=True in train mode -- the
+    reference hands out its SpatialMemory (mem_k / mem_v / mem_attn / mem_count).  With dropout p = 0 the train-mode ops and the
+    forward-only growing-bank runner (model.train() + mem_dropout.eval()) are the same function: outputs and memory must agree."""
+    from spann3r_amd import Spann3R, TINY
+    from spann3r_amd import train as T
+    from spann3r_amd.weights import synth_frames
+    m = Spann3R(dus3r_name=None, cfg=TINY, init_weights=False, memory_dropout=0.15)
+    m.load_state_dict(tiny_sd, strict=True)
+    m = m.cuda().train()
+    T.set_precision("fp32")
+    n, B, H, W = 4, 1, 32, 48
+    frames = [{"img": f["img"].cuda()} for f in synth_frames(n, H, W, batch=B, seed=3)]
+    with torch.no_grad():                                   # (a): dropout active, no tape
+        preds, preds_all, mem = m(frames, return_memory=True)
+    assert len(preds) == n and not preds[0]["pts3d"].requires_grad and torch.isfinite(preds[-1]["pts3d_in_other_view"]).all()
+    P = (H // 16) * (W // 16)
+    assert tuple(mem.mem_k.shape) == (B, (n - 1) * P, TINY.enc_dim) and tuple(mem.mem_attn.shape) == (B, (n - 1) * P, 1)
+    # (b): p = 0 -> same function as the forward-only growing-bank policy
+    m.mem_dropout.p = 0.0
+    preds_t, _, mem_t = m(frames, return_memory=True)       # grad enabled: the training forward
+    assert preds_t[0]["pts3d"].requires_grad
+    m.mem_dropout.eval()
+    with torch.no_grad():
+        preds_f, _, mem_f = m(frames, return_memory=True)   # forward-only runner, train-mode memory policy
+    for a, b in zip(preds_t, preds_f):
+        for k in a:
+            assert (a[k].detach() - b[k]).abs().max() <= 2e-4 * b[k].abs().max(), k
+    for name in ("mem_k", "mem_v", "mem_attn"):
+        x, y = getattr(mem_t, name).detach(), getattr(mem_f, name)
+        assert (x - y).abs().max() <= 2e-4 * y.abs().max(), name
+    assert torch.equal(mem_t.mem_count, mem_f.mem_count)
+    # the read counts of the reference's add_mem: frame j of the bank has been read (n - 2 - j) times
+    assert mem_t.mem_count[0, ::P, 0].tolist() == [float(n - 2 - j) for j in range(n - 1)]
+
+
+@pytest.mark.gpu
 def test_adamw_kernel_matches_torch():
     from spann3r_amd.train import AdamW
     g = torch.Generator().manual_seed(0)

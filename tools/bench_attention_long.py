@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """us per launch of sp3_attention_packed (config 3: 1024 tokens per frame; the 196-token launches of the headline), rotating operand
-copies so that no launch finds its K / V^T in the L2 a previous one left them in.  SP3_ATTN_XCD=0/1/2 selects the workgroup -> (head,
-batch) map (csrc/attention.hip): run once per value for an A/B."""
+copies so that no launch finds its K / V^T in the L2 a previous one left them in.  (Round 5 A/B'd the workgroup -> (head, batch) map
+with it, profiles/r05_xcd_locality_ab.txt; the XCD map is the only one since round 6.)"""
 import os
 import sys
 
@@ -11,7 +11,6 @@ import torch  # noqa: E402
 from spann3r_amd import ops  # noqa: E402
 
 dev = "cuda"
-print("SP3_ATTN_XCD =", os.environ.get("SP3_ATTN_XCD", "(default)"))
 for B, heads, N in ((2, 16, 1024), (2, 12, 1024), (16, 16, 1024), (2, 12, 196), (10, 16, 196), (2, 16, 196)):
     C = heads * 64
     Np = (N + 63) // 64 * 64

@@ -5,7 +5,7 @@
 #   optests   kernel-level parity tests (tests/test_ops_gpu.py)          gemmsweep  tile sweep of the many-row GEMMs
 #   modeltests tests/test_model_gpu.py                                    alltests   the whole -m gpu suite
 #   bench     python bench.py (default line)                              benchfast  bench.py without extras / CPU baseline
-#   benchab   benchfast with SP3_PIPE_TILES=1 and =0                      prof       rocprofv3 --kernel-trace --stats of benchfast
+#   cold      tools/cold_start.py (first call / later calls / eager)      prof       rocprofv3 --kernel-trace --stats of benchfast
 #   train     tools/train_step_time.py (bf16, fp32; trainbf: bf16 only)   memread    tools/bench_memread.py
 #   trainprof rocprofv3 --kernel-trace --stats of the training step       traintests tests/test_train.py + test_loss.py
 #   trainsweep tile sweep of the training step's ~800-row GEMM shapes     f16x3      the fp16-split mode: parity tests + bench
@@ -37,7 +37,7 @@ for stage in "$@"; do
     tracegemm)  for t in 20 22; do for a in gelu noact; do timeout 120 python tools/trace_gemm.py $t $a >> "$OUT/tracegemm.txt" 2>&1; done; done; cat "$OUT/tracegemm.txt" ;;
     bench)      timeout 900 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; head -c 1500 "$OUT/bench.json"; tail -3 "$OUT/bench.err" ;;
     benchfast)  timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > "$OUT/benchfast.json" 2> "$OUT/benchfast.err"; head -c 1200 "$OUT/benchfast.json"; tail -3 "$OUT/benchfast.err" ;;
-    benchab)    for v in 1 0; do SP3_PIPE_TILES=$v timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --no-profile > "$OUT/bench_pipe$v.json" 2> "$OUT/bench_pipe$v.err"; echo "PIPE=$v"; head -c 400 "$OUT/bench_pipe$v.json"; echo; tail -2 "$OUT/bench_pipe$v.err"; done ;;
+    cold)       timeout 400 python tools/cold_start.py > "$OUT/cold.txt" 2>&1; tail -12 "$OUT/cold.txt"; timeout 400 python tools/cold_start.py --size 512 --frames 50 --train-policy --calls 4 > "$OUT/cold512.txt" 2>&1; tail -9 "$OUT/cold512.txt" ;;
     bench3)     timeout 600 python bench.py --size 512 --frames 50 --train-policy --steps 3 --warmup 2 --no-cpu-baseline --no-extras > "$OUT/bench3.json" 2> "$OUT/bench3.err"; head -c 1500 "$OUT/bench3.json"; tail -3 "$OUT/bench3.err" ;;
     prof)       (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/prof" -o run -- python "$OLDPWD/bench.py" --steps 6 --warmup 3 --no-cpu-baseline --no-profile --no-extras > "$OLDPWD/$OUT/prof.log" 2>&1); DB=$(find "$OUT/prof" -name "*results.db" | head -1); python tools/rocpd_stats.py "$DB" > "$OUT/prof_stats.md" 2>&1; python tools/rocpd_lastseq.py "$DB" > "$OUT/prof_lastseq.txt" 2>&1; rm -rf "$OUT/prof"; head -40 "$OUT/prof_stats.md" ;;
     pmcbench)   for C in FETCH_SIZE WRITE_SIZE; do (cd /tmp && timeout 600 rocprofv3 --pmc $C -d "$OLDPWD/$OUT/pmcb_$C" -o run -- python "$OLDPWD/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-profile --no-extras --no-graphs > "$OLDPWD/$OUT/pmcb_$C.log" 2>&1); DB=$(find "$OUT/pmcb_$C" -name "*results.db" | head -1); python tools/rocpd_pmc_grid.py "$DB" --json "$OUT/pmc_$C.json" > "$OUT/pmc_${C}_by_grid.md" 2>&1; rm -rf "$OUT/pmcb_$C"; head -12 "$OUT/pmc_${C}_by_grid.md" | cut -c1-200; done ;;
