@@ -1779,8 +1779,9 @@ static int gemm_prepare(sp3_gemm_desc& d, int& tile_out) {
   SP3_CHECK(d.A && d.W && d.C, "sp3_gemm: null A/W/C");
   SP3_CHECK(d.M > 0 && d.N > 0 && d.K > 0, "sp3_gemm: bad shape M=%d N=%d K=%d", d.M, d.N, d.K);
   SP3_CHECK(d.K % 8 == 0 || (d.loader == SP3_LOAD_SOFTMAX && d.K % 4 == 0), "sp3_gemm: K=%d must be a multiple of 8", d.K);
-  SP3_CHECK(!d.sm_stats_out || (d.epi == SP3_EPI_PLAIN && d.N % 4 == 0 && !d.out_packed && !d.out_bf16 && d.batch == 1),
-            "sp3_gemm: sm_stats_out needs the plain fp32 epilogue, N %% 4 == 0, one problem");
+  // (sm_stats_out next to a fragment-order bf16 output = the score stage of the long-bank read, probabilities instead of scores: lean tile 45)
+  SP3_CHECK(!d.sm_stats_out || (d.epi == SP3_EPI_PLAIN && d.N % 4 == 0 && (!d.out_packed == !d.out_bf16) && d.batch == 1),
+            "sp3_gemm: sm_stats_out needs the plain epilogue (fp32 rows, or fragment-order bf16), N %% 4 == 0, one problem");
   SP3_CHECK(d.wdtype == SP3_F32 || d.wdtype == SP3_BF16, "sp3_gemm: bad wdtype %d", d.wdtype);
   SP3_CHECK(!d.a_bf16 || d.wdtype == SP3_BF16, "sp3_gemm: a_bf16 needs wdtype bf16");
   SP3_CHECK((reinterpret_cast<uintptr_t>(d.A) & 15) == 0 && (reinterpret_cast<uintptr_t>(d.W) & 15) == 0,
@@ -1798,7 +1799,7 @@ static int gemm_prepare(sp3_gemm_desc& d, int& tile_out) {
             "sp3_gemm: stats_out / c2 need the plain epilogue, N %% 32 == 0");
   SP3_CHECK(!d.out_packed || (d.epi == SP3_EPI_PLAIN && d.N % 4 == 0), "sp3_gemm: out_packed needs the plain epilogue, N %% 4 == 0");
   // (a fragment-order A split along K -- A2 a second packed matrix with K - K1 columns -- is served by the lean instances only)
-  SP3_CHECK(!d.a_packed || d.loader == SP3_LOAD_PLAIN, "sp3_gemm: packed A needs the plain loader");
+  SP3_CHECK(!d.a_packed || d.loader == SP3_LOAD_PLAIN || (d.loader == SP3_LOAD_SOFTMAX && d.a_bf16), "sp3_gemm: packed A needs the plain loader (or the softmax loader's probability form)");
   SP3_CHECK(!(d.a_packed && d.A2) || (d.K1 % 64 == 0 && d.K1 > 0 && d.K1 < d.K && d.K % 64 == 0),
             "sp3_gemm: packed split A needs K1 and K - K1 in whole 64-column blocks");
   SP3_CHECK(d.batch == 1 || ((d.sb_bias | d.sb_ln_stats | d.sb_ln_s | d.sb_stats_out | d.sb_c2 | d.sb_vt | d.sb_A2) & 15) == 0,
@@ -1814,6 +1815,10 @@ static int gemm_prepare(sp3_gemm_desc& d, int& tile_out) {
     SP3_CHECK(d.lda % aalign == 0 && d.lda >= d.K1, "sp3_gemm: lda=%lld must be >= K and keep 16-byte rows", (long long)d.lda);
   } else if (d.loader == SP3_LOAD_PLAIN) {
     /* packed A: geometry is implied by M, K */
+  } else if (d.loader == SP3_LOAD_SOFTMAX && d.a_packed) {
+    // probability form (long-bank read, lean tile 46): A = fragment-order bf16 p~ with the group scales in sm_stats, split-K partials
+    SP3_CHECK(d.a_bf16 && !d.A2 && d.epi == SP3_EPI_PARTIAL && d.batch == 1 && !d.ln_stats && !d.relu_in && d.sm_stats && d.K % 4 == 0,
+              "sp3_gemm: the softmax loader's probability form takes fragment-order bf16 p~, group scales (sm_stats) and the PARTIAL epilogue");
   } else if (d.loader == SP3_LOAD_SOFTMAX) {
     SP3_CHECK(!d.a_bf16 && !d.a_packed && !d.A2 && d.epi == SP3_EPI_PLAIN && d.splitk == 1 && d.batch == 1 && !d.ln_stats && !d.relu_in,
               "sp3_gemm: the softmax loader takes row-major fp32 scores, plain epilogue, one problem, no split-K");

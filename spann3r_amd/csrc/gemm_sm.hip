@@ -18,6 +18,8 @@
 //       SM_ROPE    folded LayerNorm + bias + 2-D RoPE -> fragment-order q / k, V in PV-operand order  (q/k/v projections)
 //       SM_SCORE   alpha x, folded LayerNorm, bias -> fp32 rows with ANY N (a multiple of 4: the bank grows by a frame per step) + the
 //                  (max, sum exp) of every 32-column group: the score GEMM of the spatial-memory read (spann3r/model.py:159-166)
+//       SM_PROB    (many-row family only, round 6) the same scores, never stored: exp(s - max of the row's 64-key group) -> fragment-order
+//                  bf16 (the A operand of the P.V GEMM, pvs_kernel) + (max, sum) per group: the long-bank read without a score matrix
 // Operands: A and W bf16 in fragment order (include/spann3r_hip.h a_packed / w_packed), fp32 accumulation.  Same arithmetic per
 // output element as gemm_kernel up to the summation order over K (WK partial sums instead of 4).
 #include "common.h"
@@ -27,7 +29,7 @@
 
 namespace {
 
-enum { SM_PACKED = 0, SM_STREAM = 1, SM_ROPE = 2, SM_SCORE = 3 };
+enum { SM_PACKED = 0, SM_STREAM = 1, SM_ROPE = 2, SM_SCORE = 3, SM_PROB = 4 };
 
 struct SmOp {
   const char* A; const char* A2; const char* W; char* C;     // A2: second fragment-order source for k-blocks >= nkb1 (split A), else = A
@@ -440,7 +442,10 @@ __global__ __launch_bounds__(64 * WM * WN) void bm_kernel(const SmArgs a) {
     tile_m = blockIdx.y;
     tile_n = p - grp * nt;
   }
-  const int N = OPF(N);
+  int N = OPF(N);
+  if constexpr (EPI == SM_PROB) {
+    if (a.dyn) N = __builtin_amdgcn_readfirstlane(*a.dyn);        // the bank's token count lives on the device; op[0].N sized the grid
+  }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   if (n0 >= N) return;
 
@@ -452,7 +457,7 @@ __global__ __launch_bounds__(64 * WM * WN) void bm_kernel(const SmArgs a) {
   {
     const char* A = OPF(A) + grp * OPF(gA);
     const char* W = OPF(W) + grp * OPF(gW);
-    const int nb_max = (N >> 4) - 1;
+    const int nb_max = ((N + 15) >> 4) - 1;                       // (N % 16 != 0 only for SM_PROB: the bank's last, partly filled row block)
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       int j = wave_u + i * NW;
@@ -611,6 +616,10 @@ __global__ __launch_bounds__(64 * WM * WN) void bm_kernel(const SmArgs a) {
   auto finish = [&](int m, int n, float (&v)[4]) {
     const float4 b4 = pb4[n];
     v[0] = acc[m][n][0]; v[1] = acc[m][n][1]; v[2] = acc[m][n][2]; v[3] = acc[m][n][3];
+    if constexpr (EPI == SM_PROB) {
+      const float al = OPF(alpha);
+      v[0] *= al; v[1] *= al; v[2] *= al; v[3] *= al;
+    }
     if (ln) {
       const float4 s4 = ps4[n];
       const float rm = rstd[m] * mean[m];
@@ -705,6 +714,48 @@ __global__ __launch_bounds__(64 * WM * WN) void bm_kernel(const SmArgs a) {
         ob[0] = (__bf16)v[0]; ob[1] = (__bf16)v[1]; ob[2] = (__bf16)v[2]; ob[3] = (__bf16)v[3];
         st_out(reinterpret_cast<bf16x4*>(out + packed_off(gm, cw0 + n * 16, N, true)), ob);
       }
+    }
+  } else if constexpr (EPI == SM_PROB) {
+    // The long-bank memory read without a score matrix (spann3r/model.py:159-183 at attn_thresh = 0): a wave's 64 columns are one
+    // 64-key GROUP of its rows.  Per row: group maximum m_g, p~ = exp(s - m_g) as bf16 in fragment order [rows][ldc keys] -- the A
+    // operand of pvs_kernel, which rescales each group's partial product by exp(m_g - m_row) / Z_row (sp3_prob_merge) -- and
+    // (m_g, sum of p~) into stats[group][row] (rows contiguous: the merge and the P.V stage's DMA read them along the rows).
+    static_assert(NF * 16 == 64, "SM_PROB: one 64-key group per wave");
+    __bf16* out = reinterpret_cast<__bf16*>(OPF(C));
+    float2* so = reinterpret_cast<float2*>(OPF(stats_out));
+    const int ldk = OPF(ldc);
+    const long rows_pad = (long)((a.M + 255) & ~255);
+    const int grp64 = (n0 + wn * 64) >> 6;
+#pragma unroll
+    for (int m = 0; m < MF; ++m) {
+      const int gm = grow[m];
+      const bool ok = gm < a.M;
+      float vv[NF][4];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int n = 0; n < NF; ++n) {
+        finish(m, n, vv[n]);
+        if (cw0 + n * 16 >= N) { vv[n][0] = vv[n][1] = vv[n][2] = vv[n][3] = -INFINITY; }     // keys past the bank's end (N % 4 == 0)
+        mx = fmaxf(mx, fmaxf(fmaxf(vv[n][0], vv[n][1]), fmaxf(vv[n][2], vv[n][3])));
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float mref = mx == -INFINITY ? 0.f : mx;               // (a group entirely past the end: p~ = 0, statistics (-inf, 0))
+      float se = 0.f;
+#pragma unroll
+      for (int n = 0; n < NF; ++n) {
+        bf16x4 ob;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float pe = __expf(vv[n][e] - mref);
+          se += pe;
+          ob[e] = (__bf16)pe;
+        }
+        if (ok) st_out(reinterpret_cast<bf16x4*>(out + packed_off(gm, cw0 + n * 16, ldk, true)), ob);
+      }
+      se += __shfl_xor(se, 16);
+      se += __shfl_xor(se, 32);
+      if (ok && g == 0) st_out(so + ((long)grp64 * rows_pad + gm), make_float2(mx, se));
     }
   } else {
     float* out = reinterpret_cast<float*>(OPF(C) + grp * OPF(gC));
@@ -946,6 +997,209 @@ __global__ __launch_bounds__(64 * WK) void pv_kernel(const PvArgs a) {
       if (a.zout && gn == 0) *reinterpret_cast<float4*>(a.zout + 4 * (long)gm) = make_float4(zs, crow[4 * erow + 1], crow[4 * erow + 2], 0.f);
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------ long-bank read, P.V stage (round 6)
+// out_partial[s] = sum over the key groups of slice s of  scale[row, group] * (P~[rows, group] . V_hat[group, :])   -- split K over S_k
+// workgroup slices of the bank (sp3_reduce_ln adds the slices and q).  A = the fragment-order bf16 p~ = exp(s - m_group) that the
+// SM_PROB score stage left, W = V_hat^T in fragment order (both with the bank's CAPACITY as their k-extent: one k-block = one 64-key
+// group), scale[group][row] = exp(m_group - m_row) / Z_row from sp3_prob_merge.  The loop is bm_kernel's (LDS ring filled by
+// global_load_lds, two fragment sets per wave, one barrier per k-block, swapped operands), with two differences: the k-block range
+// [kb0, kb1) of a slice is a RUN-TIME quantity (the bank's token count may live on the device: dyn), and every k-block's product
+// goes through a temporary accumulator (its first MFMA takes a zero C) that is folded into the running sum with the row's scale of
+// that group -- 64 FMAs per wave next to 32 MFMAs.  The 256 scales of a stage (one per row of the tile) are its 49th DMA piece.
+// No score or probability matrix in fp32 ever exists; the bf16 p~ is written once and read once per column tile.
+struct PvsArgs {
+  const char* A; const char* W; const float* scale; float* part;
+  int M, N, Mk, nkbc, S_k, ldc;
+  long rows_pad;
+  const int* dyn;
+};
+
+template <int WM, int WN, int NF, int NST>
+__global__ __launch_bounds__(64 * WM * WN) void pvs_kernel(const PvsArgs a) {
+  constexpr int MF = 4, NW = WM * WN;
+  constexpr int BM = WM * MF * 16, BN = WN * NF * 16;
+  constexpr int NBLK = BM / 16 + BN / 16, STAGE_BYTES = NBLK * 2048 + BM * 4, NINSTR = 2 * NBLK + BM / 256, PER = (NINSTR + NW - 1) / NW;
+  static_assert(BM == 256, "the stage's scale piece is one 1 KB DMA: 256 rows");
+  static_assert(NST >= 2 && NST <= 4 && PER * (NST - 1) < 64, "stage ring: 2..4 stages, vmcnt is a 6-bit count");
+  extern __shared__ __attribute__((aligned(16))) char lds_b[];
+  const int tid = threadIdx.x, lane = tid & 63, wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave_u % WN, wm = wave_u / WN;
+  const int g = lane >> 4, r16 = lane & 15;
+  // grid = (8, M-tiles x N-tiles, S_k / 8): XCD x owns the slices {x, x + 8, ..} with all their tiles (a slice's operand slabs enter one L2)
+  const int slice = blockIdx.z * 8 + blockIdx.x;
+  const int mt = (a.M + BM - 1) / BM;
+  const int tile_m = (int)blockIdx.y % mt, tile_n = (int)blockIdx.y / mt;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int Mk = a.dyn ? __builtin_amdgcn_readfirstlane(*a.dyn) : a.Mk;
+  const int nkb_all = (Mk + 63) >> 6, per = (nkb_all + a.S_k - 1) / a.S_k;
+  const int kb0 = slice * per;
+  int nkb = nkb_all - kb0;
+  nkb = nkb < per ? nkb : per;
+  float* part = a.part + ((long)slice * a.M) * a.ldc;
+  const int cw0 = n0 + wn * NF * 16 + 4 * g;
+  int grow[MF];
+#pragma unroll
+  for (int m = 0; m < MF; ++m) grow[m] = m0 + wm * 64 + m * 16 + r16;
+  if (nkb <= 0) {                                                 // an empty slice (short bank, many slices): its partial is zero
+#pragma unroll
+    for (int m = 0; m < MF; ++m)
+      if (grow[m] < a.M)
+#pragma unroll
+        for (int n = 0; n < NF; ++n) st_out(reinterpret_cast<float4*>(part + (long)grow[m] * a.ldc + cw0 + n * 16), make_float4(0.f, 0.f, 0.f, 0.f));
+    return;
+  }
+  // ---- DMA pieces of this wave: A row blocks, W column blocks, the scale piece (surplus slots repeat the last piece)
+  const char* src[PER];
+  int dst[PER];
+  long kstep[PER];
+  {
+    const int rb_max = ((a.M + 15) >> 4) - 1;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      int j = wave_u + i * NW;
+      j = j < NINSTR ? j : NINSTR - 1;
+      if (j < 2 * NBLK) {
+        const int blk = j >> 1;
+        const char* base;
+        if (blk < BM / 16) {
+          int rb = (m0 >> 4) + blk;
+          rb = rb < rb_max ? rb : rb_max;
+          base = a.A + (long)rb * a.nkbc * 2048;
+        } else {
+          base = a.W + (long)((n0 >> 4) + blk - BM / 16) * a.nkbc * 2048;
+        }
+        src[i] = base + (j & 1) * 1024 + lane * 16;
+        dst[i] = j * 1024;
+        kstep[i] = 2048;
+      } else {
+        src[i] = reinterpret_cast<const char*>(a.scale + m0) + lane * 16;      // scale[group][rows_pad]: the tile's 256 rows of one group
+        dst[i] = NBLK * 2048;
+        kstep[i] = a.rows_pad * 4;
+      }
+    }
+  }
+  auto issue = [&](int slot, int kb) {                            // kb: absolute k-block (= key group); clamped, so every call issues PER pieces
+    const int kc = kb < kb0 + nkb ? kb : kb0 + nkb - 1;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) bm_glds16(src[i] + kc * kstep[i], lds_b + slot * STAGE_BYTES + dst[i]);
+  };
+  auto wait_pending = [&](int pend) {
+    if (pend >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PER) : "memory");
+    else if (pend == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+    else if (pend == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+#pragma unroll
+  for (int s_ = 0; s_ < NST; ++s_) issue(s_, kb0 + s_);           // (always NST stages: the counts below do not depend on nkb)
+
+  typedef bf16x8 V16;
+  V16 fa[2][MF], fw[2][NF];
+  f32x4 acc[MF][NF], tmp[MF][NF];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int m = 0; m < MF; ++m)
+#pragma unroll
+    for (int n = 0; n < NF; ++n) acc[m][n] = zero4;
+  auto read_half = [&](auto buf_tag, int slot, int half) {
+    constexpr int BUF = decltype(buf_tag)::value;
+    const char* st = lds_b + slot * STAGE_BYTES + half * 1024 + lane * 16;
+#pragma unroll
+    for (int m = 0; m < MF; ++m) fa[BUF][m] = *reinterpret_cast<const V16*>(st + (wm * MF + m) * 2048);
+#pragma unroll
+    for (int n = 0; n < NF; ++n) fw[BUF][n] = *reinterpret_cast<const V16*>(st + (BM / 16 + wn * NF + n) * 2048);
+  };
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, 1>;
+  auto sync_stage = [&](int s) {                                  // stage s (slice-relative) becomes readable; its predecessor's slot is refilled
+    const int newer = NST - 1;                                    // (NST stages were always issued ahead: see issue())
+    (void)newer;
+    wait_pending(NST - 2);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    issue((s + NST - 1) % NST, kb0 + s + NST - 1);
+  };
+  wait_pending(NST - 1);
+  asm volatile("s_barrier" ::: "memory");
+  int slot = 0;
+  read_half(B0{}, 0, 0);
+  for (int i = 0; i < nkb; ++i) {
+    // the row scales of this group (4 rows of this lane), from the stage's scale piece
+    float sc[MF];
+    {
+      const float* sp = reinterpret_cast<const float*>(lds_b + slot * STAGE_BYTES + NBLK * 2048) + wm * 64 + r16;
+#pragma unroll
+      for (int m = 0; m < MF; ++m) sc[m] = sp[m * 16];
+    }
+    // first k16-pair of the block: C = 0
+    tmp[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[0][0], fa[0][0], zero4, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    read_half(B1{}, slot, 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < MF; ++m)
+#pragma unroll
+      for (int n = 0; n < NF; ++n)
+        if (m + n > 0) tmp[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[0][n], fa[0][m], zero4, 0, 0, 0);
+    tmp[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[1][0], fa[1][0], tmp[0][0], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    slot = slot + 1 == NST ? 0 : slot + 1;
+    if (i + 1 < nkb) {
+      sync_stage(i + 1);
+      read_half(B0{}, slot, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < MF; ++m)
+#pragma unroll
+      for (int n = 0; n < NF; ++n)
+        if (m + n > 0) tmp[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[1][n], fa[1][m], tmp[m][n], 0, 0, 0);
+    // fold the group's product into the running sum with the rows' scales
+#pragma unroll
+    for (int m = 0; m < MF; ++m)
+#pragma unroll
+      for (int n = 0; n < NF; ++n)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[m][n][e] = fmaf(sc[m], tmp[m][n][e], acc[m][n][e]);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // (the clamped surplus stages of a short slice are still landing in LDS)
+#pragma unroll
+  for (int m = 0; m < MF; ++m)
+    if (grow[m] < a.M)
+#pragma unroll
+      for (int n = 0; n < NF; ++n)
+        st_out(reinterpret_cast<float4*>(part + (long)grow[m] * a.ldc + cw0 + n * 16), make_float4(acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]));
+}
+
+// loader SOFTMAX descriptors in their PROBABILITY form (tile 46): A = fragment-order bf16 p~ [M][ldw keys], sm_stats = the group scales
+// [ldw / 64][M rounded up to 256], PARTIAL epilogue with splitk slices (a multiple of 8), W = V_hat^T [N][ldw]
+bool pvs_ok(const sp3_gemm_desc& d) {
+  return d.loader == SP3_LOAD_SOFTMAX && d.wdtype == SP3_BF16 && d.w_packed && d.a_bf16 && d.a_packed && d.sm_stats && d.epi == SP3_EPI_PARTIAL &&
+         !d.out_bf16 && !d.out_packed && !d.bias && !d.res1 && !d.res2 && d.act == SP3_ACT_NONE && d.alpha == 1.0f && d.batch <= 1 &&
+         d.splitk >= 8 && d.splitk % 8 == 0 && !d.ln_stats && !d.stats_out && !d.c2 && !d.trace && !d.sm_stats_out && !d.A2 && d.N % 128 == 0 &&
+         d.K % 4 == 0 && d.K >= 4 && d.M >= 1 && d.M < 65536 && d.ldw % 64 == 0 && d.ldw >= d.K && (d.ldc & 3) == 0 && d.ldc >= d.N;
+}
+
+int pvs_dispatch(const sp3_gemm_desc& d, hipStream_t stream) {
+  PvsArgs a;
+  a.A = reinterpret_cast<const char*>(d.A); a.W = reinterpret_cast<const char*>(d.W); a.scale = d.sm_stats; a.part = reinterpret_cast<float*>(d.C);
+  a.M = d.M; a.N = d.N; a.Mk = d.K; a.nkbc = (int)(d.ldw / 64); a.S_k = d.splitk; a.ldc = (int)d.ldc;
+  a.rows_pad = (long)((d.M + 255) & ~255);
+  a.dyn = d.dyn_n;
+  constexpr int WM = 4, WN = 2, NF = 4, NST = 3, BM = 256, BN = 128;
+  constexpr size_t lds = (size_t)NST * ((BM / 16 + BN / 16) * 2048 + BM * 4);
+  static_assert(lds <= 160 * 1024, "stage ring must fit the LDS");
+  auto kern = pvs_kernel<WM, WN, NF, NST>;
+  static bool raised = false;
+  if (!raised) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { sp3_set_error("sp3_gemm (long-bank P.V): cannot raise dynamic LDS to %zu: %s", lds, hipGetErrorString(e)); return 2; }
+    raised = true;
+  }
+  const int mt = (d.M + BM - 1) / BM, nt = d.N / BN;
+  hipLaunchKernelGGL(kern, dim3(8, mt * nt, d.splitk / 8), dim3(64 * WM * WN), lds, stream, a);
+  SP3_LAUNCH_CHECK("sp3_gemm (long-bank P.V)");
+  return 0;
 }
 
 // loader SOFTMAX descriptors this kernel serves (tile 44); anything else stays on the general tiles
@@ -1268,6 +1522,8 @@ const SmInst kInst[] = {
     {38, SM_STREAM, 1792, 4, 2, 7, false, 0, 1 << 30, sm_launch<4, 2, 7, 28, 0, SM_STREAM>},  // key MLP out x2: 64x32 k7
     // SCORE (the memory read's S = LN_q(q) . K_hat^T / 32 with the softmax statistics of its 32-key groups; N = bank tokens, any multiple of 4)
     {43, SM_SCORE, 1024, 2, 2, 8, false, 0, 1 << 30, sm_launch<2, 2, 8, 16, 0, SM_SCORE>},
+    // PROB (round 6: the long-bank read's score stage for > 256 query rows -- a 512 x 512 frame -- without a score matrix)
+    {45, SM_PROB, 1024, 4, 4, 1, false, 0, 1 << 30, bm_launch<4, 2, 4, 16, 3, SM_PROB>, 257, 1 << 30, 256, 128},
     // ---- many rows (bm_kernel<WM, WN, NF, NKB, NST, EPI>): 256x128 (8 waves) from 1536 rows on, else 128x128 / 128x64 (4 waves)
     {50, SM_ROPE, 1024, 4, 4, 1, false, 0, 1 << 30, bm_launch<4, 2, 4, 16, 3, SM_ROPE>, 1536, 1 << 30, 256, 128},     // encoder q/k/v (M = frames x 196)
     {51, SM_ROPE, 1024, 4, 4, 1, false, 0, 1 << 30, bm_launch<2, 2, 4, 16, 3, SM_ROPE>, 257, 1535, 128, 128},
@@ -1297,7 +1553,7 @@ bool sm_enabled() {
 }
 
 int sm_kind(const sp3_gemm_desc& d) {
-  if (d.sm_stats_out) return SM_SCORE;
+  if (d.sm_stats_out) return (d.out_packed && d.out_bf16) ? SM_PROB : SM_SCORE;
   if (d.epi == SP3_EPI_ROPE_VT) return SM_ROPE;
   if (d.out_packed) return SM_PACKED;
   return SM_STREAM;
@@ -1311,7 +1567,14 @@ const SmInst* sm_find(const sp3_gemm_desc& d) {
   if (d.splitk > 1 || d.epi == SP3_EPI_PARTIAL || d.epi == SP3_EPI_PIXSHUF) return nullptr;
   if (d.batch > 2 || d.M < 1 || d.M >= 65536 || (d.ldw > 0 && d.ldw != d.K) || !d.bias) return nullptr;
   const int kind = sm_kind(d);
-  if (d.dyn_n && kind != SM_SCORE) return nullptr;        // (device-side extent: the score instance only)
+  if (d.dyn_n && kind != SM_SCORE && kind != SM_PROB) return nullptr;        // (device-side extent: the memory read's score instances only)
+  if (kind == SM_PROB) {
+    // C = fragment-order bf16 [M][ldc keys] (ldc = the bank's capacity: the layout must not move as the bank grows), statistics
+    // [ldc / 64][M rounded up to 256] float2
+    if (d.epi != SP3_EPI_PLAIN || d.batch > 1 || d.res1 || d.stats_out || d.c2 || d.act != SP3_ACT_NONE || d.N % 4 || d.N < 4 ||
+        d.ldc % 64 || d.ldc < d.N || !d.ln_stats)
+      return nullptr;
+  } else
   if (kind == SM_SCORE) {
     // (sp3_gemm's own checks: plain fp32 epilogue, N % 4 == 0, one problem)
     if (d.epi != SP3_EPI_PLAIN || d.out_bf16 || d.out_packed || d.batch > 1 || d.res1 || d.stats_out || d.c2 || d.act != SP3_ACT_NONE ||
@@ -1334,7 +1597,7 @@ const SmInst* sm_find(const sp3_gemm_desc& d) {
     if (s.epi != kind || s.K != d.K || s.split != split || d.M < s.min_m || d.M > s.max_m) continue;
     const long mb = (long)d.M * (d.batch > 1 ? d.batch : 1);
     if (mb < s.min_mb || mb > s.max_mb) continue;
-    if ((kind != SM_SCORE && d.N % s.tile_n()) || d.N < s.min_n || d.N > s.max_n) continue;
+    if ((kind != SM_SCORE && kind != SM_PROB && d.N % s.tile_n()) || d.N < s.min_n || d.N > s.max_n) continue;
     if (!s.bm && d.ln_stats && s.MF * 16 * 4 > 64 * s.WK) continue;
     if (s.bm && kind == SM_ROPE && d.rope_cols % 32) continue;
     return &s;
@@ -1358,7 +1621,7 @@ void sm_fill(SmOp& o, const sp3_gemm_desc& d, const SmInst& s) {
   o.gso = G * d.sb_stats_out; o.gc2 = G * d.sb_c2; o.gvt = G * d.sb_vt;
   o.N = d.N;
   o.alpha = d.alpha;
-  if (s.epi == SM_SCORE) o.stats_out = d.sm_stats_out;
+  if (s.epi == SM_SCORE || s.epi == SM_PROB) o.stats_out = d.sm_stats_out;
   o.nt = (d.N + s.tile_n() - 1) / s.tile_n();
   o.ntz = (o.nt + 7) / 8;
   o.ngrp = d.batch > 1 ? d.batch : 1;
@@ -1372,7 +1635,7 @@ void sm_fill(SmOp& o, const sp3_gemm_desc& d, const SmInst& s) {
 
 int sp3_gemm_sm_tile(const sp3_gemm_desc& d) {
   if (d.loader == SP3_LOAD_CONV3X3) return sm_enabled() ? conv_sm_tile(d) : -1;
-  if (d.loader == SP3_LOAD_SOFTMAX) return (sm_enabled() && pv_ok(d)) ? 44 : -1;
+  if (d.loader == SP3_LOAD_SOFTMAX) return !sm_enabled() ? -1 : pv_ok(d) ? 44 : pvs_ok(d) ? 46 : -1;
   const SmInst* s = sm_find(d);
   return s ? s->tile : -1;
 }
@@ -1384,6 +1647,7 @@ bool sp3_gemm_sm_pairs(const sp3_gemm_desc& d) {
 }
 
 int sp3_gemm_sm_launch(const sp3_gemm_desc& d, const sp3_gemm_desc* pair, hipStream_t stream) {
+  if (d.loader == SP3_LOAD_SOFTMAX && sm_enabled() && pvs_ok(d) && !pair && (d.tile < 30 || d.tile == 46)) return pvs_dispatch(d, stream);
   if (d.loader == SP3_LOAD_SOFTMAX) {
     if (!sm_enabled() || !pv_ok(d) || pair || (d.tile >= 30 && d.tile != 44)) {
       sp3_set_error("sp3_gemm: no lean softmax-loader instance for this descriptor (tile %d, M=%d N=%d K=%d)", d.tile, d.M, d.N, d.K);
