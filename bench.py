@@ -150,6 +150,8 @@ def kernel_symbol(key):
             return "conv_sm_kernel"
         if tile.startswith("lean-softmax-pv"):
             return "pv_kernel"
+        if tile.startswith("lean-prob-pv"):
+            return "pvs_kernel"
         if tile.startswith("lean-"):
             return "bm_kernel" if tile.rsplit("-", 1)[-1] in ("256x128", "128x128", "128x64") else "sm_kernel"
         return "gemm_kernel"

@@ -326,6 +326,16 @@ int sp3_cos_sim(const float* k, const float* wm, int T, int P, int C, float* scr
  * sp3_cos_sim_state = sp3_cos_sim against the last state[1] frames of k_raw [cap, C] (rows [M - wm P, M)), wm <= Tmax: launched
  * for Tmax frames, surplus workgroups exit; score[t] for t >= wm is left untouched. */
 int sp3_bank_state_set(int32_t* state, int M, int wm, void* stream);
+/* The long-bank read without a score matrix (round 6; spann3r/model.py:159-183 at attn_thresh = 0, > 256 query rows).  Stage 1 =
+ * sp3_gemm with sm_stats_out AND a fragment-order bf16 output (lean tile 45): C = p~ = exp(s - m_g) per 64-key group g of a row,
+ * [M rows][ldc = bank capacity], sm_stats_out[ldc / 64][M rounded up to 256] = (m_g, sum_g p~) as float2.  sp3_prob_merge turns the
+ * statistics into scale[g][row] = exp(m_g - m_row) / Z_row (same [ldc / 64][rows_pad] layout, fp32).  Stage 2 = sp3_gemm with loader
+ * SP3_LOAD_SOFTMAX in its probability form (lean tile 46: A = p~ a_packed bf16, sm_stats = scale, PARTIAL epilogue, splitk a multiple of
+ * 8, ldw = the capacity): partial[s] = sum over the groups of slice s of scale[g] * (p~_g . V_hat_g); sp3_reduce_ln adds the slices and
+ * q.  sp3_colsum_prob: mem_attn[key] += sum_rows p~[row, key] * scale[key / 64][row] (:180-181).  M = bank tokens (N of stage 1, K of
+ * stage 2), or dyn_n[0] if dyn_n is set (then M only sizes the launch). */
+int sp3_prob_merge(const float* stats, float* scale, int rows, int M, int cap, const int32_t* dyn_n, void* stream);
+int sp3_colsum_prob(const void* P_packed, const float* scale, int rows, int M, int cap, const int32_t* dyn_n, float* mem_attn, void* stream);
 int sp3_cos_sim_state(const float* k, const float* k_raw, int Tmax, int P, int C, const int32_t* state, float* scratch, float* score,
                       void* stream);
 int sp3_mem_append(float* count, float* attn, int M, int P, void* stream);

@@ -309,6 +309,86 @@ __global__ __launch_bounds__(256) void cos_mean_kernel(const float* __restrict__
   if (threadIdx.x == 0) score[t] = ((sh[0] + sh[1]) + (sh[2] + sh[3])) / (float)P;
 }
 
+// ------------------------------------------------------------------ long-bank read without a score matrix (round 6), the two small kernels
+// between / behind its GEMM stages (gemm_sm.hip: SM_PROB score stage, pvs_kernel P.V stage).
+// prob_merge: stats[group][rows_pad] = (m_g, sum_g exp(s - m_g)) of every row's 64-key groups -> scale[group][row] =
+// exp(m_g - m_row) / Z_row with m_row = max_g m_g, Z_row = sum_g sum_g exp(m_g - m_row): softmax(s)[row, key] = p~[row, key] * scale[key / 64][row]
+// (spann3r/model.py:160 at attn_thresh = 0).  One workgroup per 16 rows, 64 lanes over the groups; rows >= rows get scale 0.
+__global__ __launch_bounds__(1024) void prob_merge_kernel(const float2* __restrict__ stats, float* __restrict__ scale, int rows, long rows_pad,
+                                                          int Mk, const int* __restrict__ dyn) {
+  __shared__ float red[64][17];
+  __shared__ float rowm[16], rowiz[16];
+  const int r = threadIdx.x & 15, gl = threadIdx.x >> 4, row = blockIdx.x * 16 + r;
+  if (dyn) Mk = dyn[0];
+  const int ng = (Mk + 63) >> 6;
+  const float2* st = stats + row;
+  float mx = -INFINITY;
+  for (int gq = gl; gq < ng; gq += 64) mx = fmaxf(mx, st[(long)gq * rows_pad].x);
+  red[gl][r] = mx;
+  __syncthreads();
+  if (gl == 0) {
+    float m = red[0][r];
+#pragma unroll 8
+    for (int j = 1; j < 64; ++j) m = fmaxf(m, red[j][r]);
+    rowm[r] = m;
+  }
+  __syncthreads();
+  const float m = rowm[r];
+  float z = 0.f;
+  for (int gq = gl; gq < ng; gq += 64) {
+    const float2 v = st[(long)gq * rows_pad];
+    z += v.y * __expf(v.x - m);                                   // (an empty group: 0 * exp(-inf) = 0)
+  }
+  __syncthreads();
+  red[gl][r] = z;
+  __syncthreads();
+  if (gl == 0) {
+    float t = 0.f;
+#pragma unroll 8
+    for (int j = 0; j < 64; ++j) t += red[j][r];                  // fixed order
+    rowiz[r] = 1.0f / t;
+  }
+  __syncthreads();
+  const float iz = row < rows ? rowiz[r] : 0.f;
+  for (int gq = gl; gq < ng; gq += 64) scale[(long)gq * rows_pad + row] = row < rows ? __expf(st[(long)gq * rows_pad].x - m) * iz : 0.f;
+}
+
+// colsum_prob: mem_attn[key] += sum_rows p~[row, key] * scale[key / 64][row]  (spann3r/model.py:180-181) from the fragment-order bf16 p~
+// [rows][cap keys]: one workgroup per 64-key group, a wave walks every fourth 16-row block (two 1 KB pieces each), fixed order.
+__global__ __launch_bounds__(256) void colsum_prob_kernel(const __bf16* __restrict__ P, const float* __restrict__ scale, int rows, long rows_pad,
+                                                          int nkbc, int Mk, const int* __restrict__ dyn, float* __restrict__ mem_attn) {
+  __shared__ float part[4][64];
+  if (dyn) Mk = dyn[0];
+  const int kb = blockIdx.x;
+  if (kb * 64 >= Mk) return;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, g = lane >> 4, r = lane & 15;
+  const int nrb = (rows + 15) >> 4;
+  float sum[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) sum[e] = 0.f;
+  for (int rb = w; rb < nrb; rb += 4) {
+    const __bf16* piece = P + ((long)rb * nkbc + kb) * 1024 + lane * 8;      // 2 halves x 512 bf16 each
+    const bf16x8 p0 = *reinterpret_cast<const bf16x8*>(piece), p1 = *reinterpret_cast<const bf16x8*>(piece + 512);
+    const float sc = scale[(long)kb * rows_pad + rb * 16 + r];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      sum[e] = fmaf(sc, (float)p0[e], sum[e]);
+      sum[8 + e] = fmaf(sc, (float)p1[e], sum[8 + e]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    float v = sum[e];
+    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+    if (r == 0) part[w][g * 16 + e] = v;                          // key g*16 + (half e >> 3)*8 + (e & 7) = g*16 + e
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int key = kb * 64 + threadIdx.x;
+    if (key < Mk) mem_attn[key] += (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+  }
+}
+
 __global__ void bank_state_kernel(int* __restrict__ state, int M, int wm) {
   if (threadIdx.x == 0) { state[0] = M; state[1] = wm; }
 }
@@ -712,6 +792,24 @@ extern "C" int sp3_cos_sim_state(const float* k, const float* k_raw, int Tmax, i
   hipLaunchKernelGGL(cos_pair_kernel, dim3((Tmax * P + 3) / 4), dim3(256), 0, ST(stream), k, k_raw, Tmax * P, P, C, scratch, state);
   hipLaunchKernelGGL(cos_mean_kernel, dim3(Tmax), dim3(256), 0, ST(stream), scratch, P, score, state);
   SP3_LAUNCH_CHECK("sp3_cos_sim_state");
+  return 0;
+}
+
+extern "C" int sp3_prob_merge(const float* stats, float* scale, int rows, int M, int cap, const int32_t* dyn_n, void* stream) {
+  SP3_CHECK(stats && scale && rows > 0 && M > 0 && cap % 64 == 0 && M <= cap, "sp3_prob_merge: bad arguments");
+  const long rows_pad = (long)((rows + 255) & ~255);
+  hipLaunchKernelGGL(prob_merge_kernel, dim3((unsigned)(rows_pad / 16)), dim3(1024), 0, ST(stream), reinterpret_cast<const float2*>(stats), scale, rows,
+                     rows_pad, M, dyn_n);
+  SP3_LAUNCH_CHECK("sp3_prob_merge");
+  return 0;
+}
+
+extern "C" int sp3_colsum_prob(const void* P_packed, const float* scale, int rows, int M, int cap, const int32_t* dyn_n, float* mem_attn, void* stream) {
+  SP3_CHECK(P_packed && scale && mem_attn && rows > 0 && M > 0 && cap % 64 == 0 && M <= cap, "sp3_colsum_prob: bad arguments");
+  const long rows_pad = (long)((rows + 255) & ~255);
+  hipLaunchKernelGGL(colsum_prob_kernel, dim3((unsigned)((M + 63) / 64)), dim3(256), 0, ST(stream), reinterpret_cast<const __bf16*>(P_packed), scale, rows,
+                     rows_pad, cap / 64, M, dyn_n, mem_attn);
+  SP3_LAUNCH_CHECK("sp3_colsum_prob");
   return 0;
 }
 

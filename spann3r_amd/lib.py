@@ -127,6 +127,8 @@ _PROTOS = {
     "sp3_cos_sim": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
     "sp3_mem_append": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p],
     "sp3_bank_state_set": [C.c_void_p, C.c_int, C.c_int, C.c_void_p],
+    "sp3_prob_merge": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p],
+    "sp3_colsum_prob": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
     "sp3_cos_sim_state": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "sp3_prune_select": [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p],
     "sp3_gather_rows": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p],

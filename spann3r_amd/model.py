@@ -121,7 +121,8 @@ class SpatialMemory:
         self.top_k = long_mem_size
         self.sim_thresh = sim_thresh
         self.num_patches = num_patches
-        self.cap = (capacity + 63) // 64 * 64
+        # (> 256 query rows: the long-bank read's score stage works in 128-key tiles -- capacity in whole tiles)
+        self.cap = (capacity + 127) // 128 * 128 if num_patches > 256 else (capacity + 63) // 64 * 64
         dev, wdt = engine.device, engine.wdt
         self.kb = 64 if wdt == torch.bfloat16 else 32           # k-block of the MFMA dtype
         self._banks = [self._alloc(dev, wdt), None]   # second bank allocated on first prune
@@ -174,10 +175,11 @@ class SpatialMemory:
             ops.bank_state_set(self.state, self.M, self.wm)
             self._state_pushed = (self.M, self.wm)
 
-    def _bucket(self):
+    def _bucket(self, step=None):
         """device-state mode: the token count the read's launches are SIZED for (grid, argument checks); the kernels take the real
         count from the device"""
-        return min(self.cap, (self.M + self.STATE_BUCKET - 1) // self.STATE_BUCKET * self.STATE_BUCKET)
+        step = step or self.STATE_BUCKET
+        return min(self.cap, (self.M + step - 1) // step * step)
 
     def graph_key(self):
         """what a captured step depends on: (M, wm) when the launches carry them as arguments; the grid bucket of the two-launch read
@@ -186,7 +188,19 @@ class SpatialMemory:
             return (self.M, self.wm)
         if self.M == 0:
             return ("s", 0)
-        return ("s", self._bucket()) if (self.read_dyn and self._read_plan()[1]) else ("l", self.M)
+        if self.read_dyn and self._read_plan()[1]:
+            return ("s", self._bucket())
+        if self._prob_read():
+            return ("p", self._bucket(self.PROB_BUCKET))
+        return ("l", self.M)
+
+    PROB_BUCKET = 8192                # device-state mode, long banks: grid bucket of the score-matrix-free read (<= 64 idle N-tiles)
+
+    def _prob_read(self):
+        """Long bank, > 256 query rows (a 512 x 512 frame), bf16, no attention threshold (the growing-bank policy of BASELINE config 3):
+        the read runs without a score matrix -- score stage writes bf16 p~ = exp(s - group max) + group statistics (lean tile 45), a
+        small merge launch, P.V stage with the groups' rescale in its loop (tile 46), split-K reduce, column sums."""
+        return (self.kb == 64 and ops.LEAN and self.attn_thresh == 0.0 and self.P > 256 and self.C == 1024 and not self._read_plan()[1])
 
     def snapshot(self):
         """Detached copy of the reference-visible state (what `return_memory=True` hands out)."""
@@ -235,7 +249,6 @@ class SpatialMemory:
         Kp = (M + kb - 1) // kb * kb
         ld = self.cap
         Pp = (P + 15) // 16 * 16
-        S = eng.ws("mem_S", (B, P, ld))
         if feat_packed is None or B > 1:
             qp = [eng.wsp("mem_q_packed%d" % b, P, C) for b in range(B)]
             qs = eng.ws("mem_q_stats", (B, P, C // 32, 2))
@@ -245,6 +258,10 @@ class SpatialMemory:
             qp, qs = [feat_packed], feat_stats.view(1, P, C // 32, 2)
         alpha = 1.0 / (C ** 0.5)
         S_k, fused = self._read_plan()
+        if not fused and self._prob_read():
+            self._memory_read_prob(feat, out, qp, qs, alpha)
+            return self._read_tail(feat, out, out_packed, prof, e0)
+        S = eng.ws("mem_S", (B, P, ld))
         # Two launches while the bank is short (every per-frame read of the 224x224 demo): the score GEMM leaves the softmax
         # statistics of its 32-key groups behind, the P.V GEMM turns scores into thresholded probabilities as it loads
         # them and renormalises in its epilogue; the column sums (mem_attn, only read by the next prune) follow.
@@ -281,17 +298,49 @@ class SpatialMemory:
                     ops.gemm(A, Wv, part, M=P, N=C, K=Kp, lda=Kp, ldc=C, ldw=self.cap, splitk=S_k)
                     ops.reduce_ln(part, S_k, P, C, res=feat[b], ldres=C, x_out=out[b], ldx=C)
                 ops.colsum_packed(pk[b], P, M, bk["attn"][b])
-            if out_packed is not None and B == 1:
-                # the long-bank compositions end in fp32 rows: one small launch makes the fragment-order copy decoder_embed reads
-                # (otherwise that GEMM and the key MLP's first layer fall back to fp32 rows on the general kernel)
-                ops.pack_stats(out[0], out_packed, eng.ws("mem_out_stats", (P, C // 32, 2)), rows=P, C_=C)
-                self.wrote_packed = True
+            return self._read_tail(feat, out, out_packed, prof, e0)
+        return self._read_tail(feat, out, None, prof, e0)
+
+    def _read_tail(self, feat, out, out_packed, prof, e0):
+        eng, bk = self.eng, self.bank
+        B, P, C, M = self.B, self.P, self.C, self.M
+        if out_packed is not None and B == 1:
+            # the long-bank compositions end in fp32 rows: one small launch makes the fragment-order copy decoder_embed reads
+            # (otherwise that GEMM and the key MLP's first layer fall back to fp32 rows on the general kernel)
+            ops.pack_stats(out[0], out_packed, eng.ws("mem_out_stats", (P, C // 32, 2)), rows=P, C_=C)
+            self.wrote_packed = True
         if prof is not None:
             es = bk["k_hat"].element_size()
             # algorithmic bytes of one read: K_hat + V_hat once, plus the query in and the fused features out
             prof.region_end("memread", e0, B * (2.0 * M * C * es + 2.0 * P * C * 4),
                             info={"M": M, "tokens_per_frame": P, "flops": 4.0 * B * P * M * C})
         return out
+
+    def _memory_read_prob(self, feat, out, qp, qs, alpha):
+        """the long-bank read without a score matrix (see _prob_read; include/spann3r_hip.h sp3_prob_merge)"""
+        eng, bk = self.eng, self.bank
+        B, P, C, M, cap = self.B, self.P, self.C, self.M, self.cap
+        dyn = self.state
+        Mg = self._bucket(self.PROB_BUCKET) if dyn is not None else M
+        S_k = 8 if Mg <= 16384 else 16
+        Pp = (P + 15) // 16 * 16
+        rows_pad = (P + 255) // 256 * 256
+        ngc = cap // 64
+        pk = eng.ws("mem_P_packed", (B, Pp * cap), eng.adt, zero=True)
+        stats = eng.ws("mem_prob_stats", (B, ngc * rows_pad * 2))
+        scale = eng.ws("mem_prob_scale", (B, ngc * rows_pad))
+        part = eng.ws("mem_pv_partial", (16 * P * C,))
+        for b in range(B):
+            pt = ops.PackedAct(P, cap, eng.adt, eng.device, data=pk[b])
+            # stage 1: p~ = exp(s - group max), s = LN_q(q) . K_hat^T / 32 (LN_q folded through s_bank / b_bank), + (max, sum) per 64-key group
+            ops.gemm(qp[b], ops.PackedWeight.wrap(bk["k_hat"][b], Mg, C), pt, M=P, N=Mg, K=C, lda=C, ldc=cap, alpha=alpha,
+                     bias=bk["b_bank"][b], ln=ops.LnFold(qs[b], C, bk["s_bank"][b], 1e-5), sm_stats_out=stats[b], dyn_n=dyn)
+            ops.prob_merge(stats[b], scale[b], P, Mg, cap, dyn_n=dyn)
+            # stage 2: split-K partials of sum_g scale_g (p~_g . V_hat_g), then slices + q
+            ops.gemm(pt, ops.PackedWeight.wrap(bk["v_hat_t"][b], C, cap), part, M=P, N=C, K=Mg, lda=cap, ldc=C, ldw=cap, splitk=S_k,
+                     softmax=(scale[b], 0.0, None), dyn_n=dyn)
+            ops.reduce_ln(part, S_k, P, C, res=feat[b], ldres=C, x_out=out[b], ldx=C)
+            ops.colsum_prob(pk[b], scale[b], P, Mg, cap, bk["attn"][b], dyn_n=dyn)
 
     # ------------------------------------------------------------------ write (:80-95)
     def stage_write(self, feat_k, feat_v):

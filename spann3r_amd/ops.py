@@ -110,6 +110,7 @@ _TILE_NAMES = {0: "32x32xk4", 1: "64x64", 2: "64x128", 3: "64x64xk4", 4: "32x64x
                34: "lean-stream-k1024-32x32xk8", 35: "lean-stream-k4096-32x32xk8r4", 36: "lean-stream-k768-48x32xk6",
                37: "lean-stream-k3072-48x32xk8", 38: "lean-stream-k1792-64x32xk7",
                39: "lean-stream-k1024-48x32xk8", 40: "lean-conv-16x16xk12", 41: "lean-conv-32x32xk8", 42: "lean-packed-splitA-k1792-64x32xk7", 43: "lean-score-k1024-32x32xk8", 44: "lean-softmax-pv-16x64xk8",
+               45: "lean-prob-k1024-256x128", 46: "lean-prob-pv-256x128",
                # many-row lean instances (bm_kernel: LDS-staged operands, epilogue in registers)
                50: "lean-rope-k1024-256x128", 51: "lean-rope-k1024-128x128", 52: "lean-rope-k768-128x128", 53: "lean-packed-k1024-256x128",
                54: "lean-packed-k1024-128x128", 55: "lean-packed-k768-128x128", 56: "lean-stream-k1024-128x64", 57: "lean-stream-k4096-128x64",
@@ -845,6 +846,18 @@ def gather_packed_rows(src, dst, sel, n_sel, C_):
 def gather_packed_cols(src, dst, sel, n_sel, n_fill, C_, cap):
     L.check(L.load().sp3_gather_packed_cols(src.data_ptr(), dst.data_ptr(), sel.data_ptr(), n_sel, n_fill, C_, cap, src.element_size(),
                                             L.stream_ptr()), "sp3_gather_packed_cols")
+
+
+def prob_merge(stats, scale, rows, M, cap, dyn_n=None):
+    """group statistics of the long-bank read's score stage -> scale[group][row] = exp(m_g - m_row) / Z_row (include/spann3r_hip.h)"""
+    L.check(L.load().sp3_prob_merge(stats.data_ptr(), scale.data_ptr(), rows, M, cap, L.ptr(dyn_n), L.stream_ptr()), "sp3_prob_merge")
+
+
+def colsum_prob(p_packed, scale, rows, M, cap, mem_attn, dyn_n=None):
+    """mem_attn[:M] += column sums of softmax = p~ * scale (long-bank read without a score matrix)"""
+    _timed("colsum_prob", 2.0 * rows * M, 2.0 * rows * M,
+           lambda: L.check(L.load().sp3_colsum_prob(p_packed.data_ptr(), scale.data_ptr(), rows, M, cap, L.ptr(dyn_n), mem_attn.data_ptr(), L.stream_ptr()),
+                           "sp3_colsum_prob"))
 
 
 def bank_state_set(state, M, wm):

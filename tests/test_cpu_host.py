@@ -546,6 +546,10 @@ def test_bench_kernel_symbols():
             want[n] = "conv_sm_kernel"
         elif t == 44:
             want[n] = "pv_kernel"
+        elif t == 45:
+            want[n] = "bm_kernel"
+        elif t == 46:
+            want[n] = "pvs_kernel"
         elif t < 50:
             want[n] = "sm_kernel"
         else:

@@ -421,3 +421,62 @@ def test_bank_write_and_similarity_window_from_device_state(wdt):
         ops.bank_state_set(state, M, wm)
         ops.cos_sim_state(probe, a["k_raw"], Tmax, P, C, state, s2, torch.empty(Tmax * P, device=DEV))
         assert torch.equal(s1, s2) and float(s2[wm:].min() if wm < Tmax else 7.0) == 7.0      # entries past wm untouched
+
+
+@pytest.mark.parametrize("rows,M,S_k", [(320, 2240, 8), (1024, 4096, 8), (300, 2244, 16), (257, 640, 8)])
+def test_long_bank_read_without_a_score_matrix(rows, M, S_k):
+    """The long-bank memory read of a > 256-row frame (spann3r/model.py:159-183 at attn_thresh = 0) as: score stage that writes
+    bf16 p~ = exp(s - group max) + (max, sum) per 64-key group (tile 45), sp3_prob_merge, P.V stage with the groups' rescale in its loop
+    (tile 46, split-K partials), reduce + q, column sums -- against float64 softmax on the fp32 scores of the general kernel.  Ragged
+    ends (M not a multiple of 128 / 64, rows not a multiple of 256), stale tokens past the bank's end, and the same launches with the
+    token count read from the device through a larger bucket."""
+    ops = _ops()
+    C = 1024
+    cap = (M + 127) // 128 * 128 + 256
+    rows_pad, ngc = (rows + 255) // 256 * 256, cap // 64
+    q = rnd(rows, C, seed=1) * 1.5 + 0.1
+    qp, qs = ops.PackedAct(rows, C, BF, DEV), torch.zeros(rows, C // 32, 2, device=DEV)
+    ops.pack_stats(q.to(DEV), qp, qs, rows=rows, C_=C)
+    Kd = rnd(cap, C, seed=2) * 2
+    Kh = ops.PackedAct.from_dense(Kd.to(DEV).to(BF))                          # rows past M: stale tokens
+    Vd = rnd(C, cap, seed=3)
+    Vd[:, M:] = 3.0
+    Vt = ops.PackedAct.from_dense(Vd.to(DEV).to(BF))
+    sb, bb = (rnd(cap, seed=4) * 0.1).to(DEV), (rnd(cap, seed=5) * 0.1).to(DEV)
+    alpha = 1 / 32.
+    # reference scores: the general kernel's fp32 S (same folded LayerNorm), then float64 softmax / products on the bf16-rounded V_hat
+    S = torch.empty(rows, cap, device=DEV)
+    ops.gemm(qp, ops.PackedWeight.wrap(Kh.data, M, C), S, M=rows, N=M, K=C, lda=C, ldc=cap, alpha=alpha, bias=bb, ln=ops.LnFold(qs, C, sb, 1e-5), tile=0)
+    p = torch.softmax(S[:, :M].double().cpu(), -1)
+    ref = p @ bf(Vd[:, :M]).double().T + q.double()
+    state = torch.zeros(4, dtype=torch.int32, device=DEV)
+
+    def read(n_arg, dyn):
+        pk = torch.zeros(ops.packed_shape(rows, cap, BF), dtype=BF, device=DEV)
+        pt = ops.PackedAct(rows, cap, BF, DEV, data=pk)
+        stats = torch.full((ngc * rows_pad * 2,), float("nan"), device=DEV)
+        scale = torch.full((ngc * rows_pad,), float("nan"), device=DEV)
+        part = torch.full((S_k * rows * C,), float("nan"), device=DEV)
+        out = torch.empty(rows, C, device=DEV)
+        attn = torch.ones(cap, device=DEV)
+        t = _plan_of(ops, lambda: ops.gemm(qp, ops.PackedWeight.wrap(Kh.data, n_arg, C), pt, M=rows, N=n_arg, K=C, lda=C, ldc=cap, alpha=alpha, bias=bb,
+                                           ln=ops.LnFold(qs, C, sb, 1e-5), sm_stats_out=stats, dyn_n=dyn))
+        ops.prob_merge(stats, scale, rows, n_arg, cap, dyn_n=dyn)
+        t += _plan_of(ops, lambda: ops.gemm(pt, ops.PackedWeight.wrap(Vt.data, C, cap), part, M=rows, N=C, K=n_arg, lda=cap, ldc=C, ldw=cap, splitk=S_k,
+                                            softmax=(scale, 0.0, None), dyn_n=dyn))
+        assert t == [45, 46], t
+        ops.reduce_ln(part, S_k, rows, C, res=q.to(DEV), ldres=C, x_out=out, ldx=C)
+        ops.colsum_prob(pk, scale, rows, n_arg, cap, attn, dyn_n=dyn)
+        return out, attn, pt, scale
+    out, attn, pt, scale = read(M, None)
+    assert rel_err(out.cpu(), ref) < 6e-3, rel_err(out.cpu(), ref)
+    assert rel_err((attn[:M] - 1).cpu(), p.sum(0)) < 6e-3 and torch.equal(attn[M:], torch.ones(cap - M, device=DEV))
+    # p~ * scale is the softmax itself (bf16 rounding of p~)
+    ng = (M + 63) // 64
+    sc = scale.view(ngc, rows_pad)[:ng, :rows].T.repeat_interleave(64, 1)[:, :M].cpu().double()
+    assert rel_err(pt.to_dense()[:, :M].double().cpu() * sc, p) < 6e-3
+    assert float(pt.to_dense()[:, M:ng * 64].abs().max() if ng * 64 > M else 0.0) == 0.0           # keys past the end inside the last group
+    # the token count on the device, launches sized for a larger bucket: bit-identical
+    ops.bank_state_set(state, M, 0)
+    out2, attn2, _, _ = read(min(cap, (M + 1023) // 1024 * 1024 + 128), state)
+    assert torch.equal(out, out2) and torch.equal(attn, attn2)

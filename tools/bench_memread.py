@@ -13,7 +13,7 @@ def main():
     ap.add_argument("--copies", type=int, default=24)
     a = ap.parse_args()
     dev, wdt, C, P, M = "cuda", torch.bfloat16, 1024, a.rows, a.tokens
-    cap = (M + 63) // 64 * 64
+    cap = (M + 127) // 128 * 128
     Kp = cap
     nt = (M + 31) // 32
     g = torch.Generator().manual_seed(0)
@@ -34,6 +34,11 @@ def main():
     part = torch.zeros(16 * P * C, device=dev)
     rowstat = torch.zeros(P * 4, device=dev)
     long_bank = M > 8192
+    # the score-matrix-free composition (round 6; > 256 query rows): p~ + group statistics, merge, rescaling P.V stage, reduce, column sums
+    rows_pad, ngc = (P + 255) // 256 * 256, cap // 64
+    pstats, pscale = torch.zeros(ngc * rows_pad * 2, device=dev), torch.zeros(ngc * rows_pad, device=dev)
+    pt = ops.PackedAct(P, cap, wdt, dev, data=pk) if P > 256 else None
+    Sk = 8 if M <= 16384 else 16
     steps = {
         "S gemm": lambda b: ops.gemm(qp, ops.PackedWeight.wrap(b[0].data, M, C), S, M=P, N=M, K=C, lda=C, ldc=cap, alpha=1 / 32., bias=b_bank, ln=ln),
         "S gemm + stats": lambda b: ops.gemm(qp, ops.PackedWeight.wrap(b[0].data, M, C), S, M=P, N=M, K=C, lda=C, ldc=cap, alpha=1 / 32., bias=b_bank, ln=ln, sm_stats_out=st),
@@ -49,10 +54,18 @@ def main():
         "PV gemm (softmax loader, 32x32)": lambda b: ops.gemm(S, ops.PackedWeight.wrap(b[1].data, C, cap), out, M=P, N=C, K=M, lda=cap, ldc=C, ldw=cap, res1=q, ldr1=C, softmax=(st, 5e-4, zk), tile=1),
         "colsum_softmax": lambda b: ops.colsum_softmax(S, cap, P, M, zk, 5e-4, attn),
     }
+    if P > 256:
+        steps.update({
+            "prob: score stage (p~ + group stats)": lambda b: ops.gemm(qp, ops.PackedWeight.wrap(b[0].data, M, C), pt, M=P, N=M, K=C, lda=C, ldc=cap, alpha=1 / 32., bias=b_bank, ln=ln, sm_stats_out=pstats),
+            "prob: merge": lambda b: ops.prob_merge(pstats, pscale, P, M, cap),
+            "prob: P.V stage (split-K %d, rescale)" % Sk: lambda b: ops.gemm(pt, ops.PackedWeight.wrap(b[1].data, C, cap), part, M=P, N=C, K=M, lda=cap, ldc=C, ldw=cap, splitk=Sk, softmax=(pscale, 0.0, None)),
+            "prob: reduce (+ q)": lambda b: ops.reduce_ln(part, Sk, P, C, res=q, ldres=C, x_out=out, ldx=C),
+            "prob: colsum": lambda b: ops.colsum_prob(pk, pscale, P, M, cap, attn),
+        })
     for name, fn in steps.items():
         if long_bank and ("tile 2" in name or "softmax loader" in name or "stats" in name or name == "colsum_softmax" or name == "PV gemm (packed P)"):
             continue                                   # long banks run: S gemm, softmax_thresh, split-K PV, reduce, colsum_packed
-        if not long_bank and ("split-K" in name or "reduce" in name):
+        if not long_bank and ("split-K" in name or "reduce" in name) and not name.startswith("prob"):
             continue
         for b in banks[:3]: fn(b)
         torch.cuda.synchronize()
