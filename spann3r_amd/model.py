@@ -322,7 +322,7 @@ class SpatialMemory:
         B, P, C, M, cap = self.B, self.P, self.C, self.M, self.cap
         dyn = self.state
         Mg = self._bucket(self.PROB_BUCKET) if dyn is not None else M
-        S_k = 8 if Mg <= 16384 else 16
+        S_k = 8        # one slice per XCD (256 workgroups at 1024 rows: one round); 16 slices measured 4-20 % slower at 8 k .. 50 k tokens and double the reduce
         Pp = (P + 15) // 16 * 16
         rows_pad = (P + 255) // 256 * 256
         ngc = cap // 64
@@ -731,18 +731,24 @@ class _SequenceRunner:
         for k in [k for k in self.graphs if pred(k)]:
             self.graph_bytes -= self.graphs.pop(k)[1]
 
-    MAX_GRAPHS = 256                     # per geometry: a 50-frame growing-bank sequence uses ~100 (one per bank length and step kind)
+    MAX_GRAPHS = 16                      # per geometry.  bf16: the bank's fill level is device state, a 50-frame growing-bank sequence holds
+                                         # ~15 (encoder / head chunks, one step graph per grid bucket); round 5 held ~100 (one per bank length)
     MAX_GRAPH_BYTES = 1 << 30            # device memory the captures of one geometry may pin in their pool
 
-    def _graphed(self, key, fn, use_graphs):
+    def _graphed(self, key, fn, use_graphs, per_length=False):
         """eager the first time a key is seen (creates the workspaces), captured the second time, replayed afterwards.
         The captured graphs are an LRU bounded in count and in the device bytes their captures allocated (all captures of a
-        runner share one memory pool); an evicted key is simply captured again when it comes back."""
+        runner share one memory pool); an evicted key is simply captured again when it comes back.
+        per_length: the key carries the bank length (the fp32-operand modes, whose launches take it as an argument): such a step is
+        captured only while the runner has room -- a long sequence would otherwise evict and re-capture one graph per step, which
+        costs more than launching eagerly (these modes are GPU-bound: eager launches keep up)."""
         if not use_graphs:
             fn()
         elif key in self.graphs:
             self.graphs.move_to_end(key)
             self.graphs[key][0].replay()
+        elif per_length and len(self.graphs) >= self.MAX_GRAPHS:
+            fn()
         elif key in self.seen:
             torch.cuda.synchronize()
             if getattr(self, "_pool", None) is None:
@@ -856,7 +862,9 @@ class _SequenceRunner:
         (decoder hooks -> sequence slots, the next pair of encoder features): six eager launches per frame became one"""
         mem = self.mem
         has_next = has_next and not self.batched                # nothing to prefetch: the sequence is already encoded
-        key = mem.graph_key() + (mem._cur, has_next, self.batched, self.defer2, self.model.grouped_decoder, self.model.packed_features)
+        gk = mem.graph_key()
+        per_length = gk[0] not in ("s", "p")               # (the bank length itself is in the key: see _graphed)
+        key = gk + (mem._cur, has_next, self.batched, self.defer2, self.model.grouped_decoder, self.model.packed_features)
         if not use_graphs and ops._prof is not None:
             ops._prof.step_begin()
         # two graphs per step: the host fetches the similarity scores (async copy + event) as soon as the first one is
@@ -874,16 +882,16 @@ class _SequenceRunner:
                 if need_sim:
                     mem.copy_scores_in_graph()
                 self._part2()
-            self._graphed(("whole", first, need_sim) + key, whole, use_graphs)
+            self._graphed(("whole", first, need_sim) + key, whole, use_graphs, per_length)
             if not first:
                 mem.note_deferred_read()        # (a replayed graph ran no Python)
         else:
-            self._graphed(("first" if first else "step",) + key, lambda: self._part1(first, has_next), use_graphs)
+            self._graphed(("first" if first else "step",) + key, lambda: self._part1(first, has_next), use_graphs, per_length)
             if not first:
                 mem.note_deferred_read()        # (a replayed graph ran no Python)
             if need_sim:
                 mem.fetch_scores_async()
-            self._graphed(("tail",) + key, self._part2, use_graphs)
+            self._graphed(("tail",) + key, self._part2, use_graphs, per_length)
         pts1, conf1, pts2, conf2 = self.out
         srcs = (pts1, conf1) + (() if pts2 is None else (pts2, conf2))
         outs = self._step_outputs(srcs)

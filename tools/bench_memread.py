@@ -58,12 +58,12 @@ def main():
         steps.update({
             "prob: score stage (p~ + group stats)": lambda b: ops.gemm(qp, ops.PackedWeight.wrap(b[0].data, M, C), pt, M=P, N=M, K=C, lda=C, ldc=cap, alpha=1 / 32., bias=b_bank, ln=ln, sm_stats_out=pstats),
             "prob: merge": lambda b: ops.prob_merge(pstats, pscale, P, M, cap),
-            "prob: P.V stage (split-K %d, rescale)" % Sk: lambda b: ops.gemm(pt, ops.PackedWeight.wrap(b[1].data, C, cap), part, M=P, N=C, K=M, lda=cap, ldc=C, ldw=cap, splitk=Sk, softmax=(pscale, 0.0, None)),
-            "prob: reduce (+ q)": lambda b: ops.reduce_ln(part, Sk, P, C, res=q, ldres=C, x_out=out, ldx=C),
+            **{"prob: P.V stage (split-K %d, rescale)" % k: (lambda b, k=k: ops.gemm(pt, ops.PackedWeight.wrap(b[1].data, C, cap), part, M=P, N=C, K=M, lda=cap, ldc=C, ldw=cap, splitk=k, softmax=(pscale, 0.0, None))) for k in (8, 16)},
+            **{"prob: reduce (%d partials + q)" % k: (lambda b, k=k: ops.reduce_ln(part, k, P, C, res=q, ldres=C, x_out=out, ldx=C)) for k in (8, 16)},
             "prob: colsum": lambda b: ops.colsum_prob(pk, pscale, P, M, cap, attn),
         })
     for name, fn in steps.items():
-        if long_bank and ("tile 2" in name or "softmax loader" in name or "stats" in name or name == "colsum_softmax" or name == "PV gemm (packed P)"):
+        if long_bank and not name.startswith("prob") and ("tile 2" in name or "softmax loader" in name or "stats" in name or name == "colsum_softmax" or name == "PV gemm (packed P)"):
             continue                                   # long banks run: S gemm, softmax_thresh, split-K PV, reduce, colsum_packed
         if not long_bank and ("split-K" in name or "reduce" in name) and not name.startswith("prob"):
             continue
