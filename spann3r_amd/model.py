@@ -605,6 +605,7 @@ class _SequenceRunner:
         self.graphs = collections.OrderedDict()        # key -> (hipGraph, device bytes its capture allocated), least recently used first
         self.graph_bytes = 0
         self.seen = set()
+        self.length_keys, self.length_keys_eager = set(), False    # keys that carry the bank length; True: they run eagerly (see _graphed)
         self.out = None
         self.batched = False          # True: the frames of the sequence were encoded up front (encode_sequence)
         self.img_all = self.feats = None
@@ -620,6 +621,7 @@ class _SequenceRunner:
             self.graphs.clear()
             self.graph_bytes = 0
             self.seen.clear()
+            self.length_keys, self.length_keys_eager = set(), False
         self.mem.reset()
         return self.mem
 
@@ -705,6 +707,13 @@ class _SequenceRunner:
         call), not four torch.empty per step: the caller still owns fresh tensors, the caching allocator is out
         of the step loop."""
         self._out_slabs, self._out_steps, self._out_i = None, n_steps, 0
+        # step graphs that carry the bank length (fp32-operand modes): decided for the WHOLE sequence before its first step -- if one
+        # graph (or two, two-graph steps) per step does not fit next to the encoder / head graphs, every step launches eagerly
+        if self.mem is not None and self.mem.state is None and not self.length_keys_eager:
+            per_step = 1 if self.model.single_graph_step else 2
+            if n_steps * per_step > self.MAX_GRAPHS - 4:
+                self.length_keys_eager = True
+                self._drop_graphs(lambda k: k in self.length_keys)
 
     def _step_outputs(self, srcs):
         if getattr(self, "_out_steps", 0) <= 0 or self._out_i >= self._out_steps:
@@ -739,16 +748,24 @@ class _SequenceRunner:
         """eager the first time a key is seen (creates the workspaces), captured the second time, replayed afterwards.
         The captured graphs are an LRU bounded in count and in the device bytes their captures allocated (all captures of a
         runner share one memory pool); an evicted key is simply captured again when it comes back.
-        per_length: the key carries the bank length (the fp32-operand modes, whose launches take it as an argument): such a step is
-        captured only while the runner has room -- a long sequence would otherwise evict and re-capture one graph per step, which
-        costs more than launching eagerly (these modes are GPU-bound: eager launches keep up)."""
-        if not use_graphs:
+        per_length: the key carries the bank length (the fp32-operand modes, whose launches take it as an argument).  Such steps are
+        captured only if ALL of a sequence's fit next to the runner's other graphs: a long sequence would otherwise evict and
+        re-capture one graph per step, which costs more than launching eagerly (these modes are GPU-bound: eager launches keep up).
+        The decision is per runner, never per step (`length_keys_eager`): one sequence is either replayed or launched eagerly
+        throughout."""
+        if per_length and use_graphs and not self.length_keys_eager and key not in self.graphs and key in self.seen \
+                and len(self.graphs) >= self.MAX_GRAPHS - 2:
+            # no room for this sequence's per-length steps (two slots stay free for the encoder / deferred-head graphs): from
+            # here on they all run eagerly, and the ones captured so far go
+            self.length_keys_eager = True
+            self._drop_graphs(lambda k: k in self.length_keys)
+        if per_length:
+            self.length_keys.add(key)
+        if not use_graphs or (per_length and self.length_keys_eager):
             fn()
         elif key in self.graphs:
             self.graphs.move_to_end(key)
             self.graphs[key][0].replay()
-        elif per_length and len(self.graphs) >= self.MAX_GRAPHS:
-            fn()
         elif key in self.seen:
             torch.cuda.synchronize()
             if getattr(self, "_pool", None) is None:
