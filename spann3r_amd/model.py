@@ -575,7 +575,11 @@ class _SequenceRunner:
 
     def __init__(self, model, eng, B, H, W, training, true_hw=None):
         cfg = model.cfg
-        self.model, self.eng, self.B, self.H, self.W, self.training = model, eng, B, H, W, training
+        # (a weak reference: model -> runner -> model would be a cycle, and the hipGraphs of a dropped model would then be destroyed
+        # whenever the cyclic collector runs -- inside some later model's capture or replay; round 6 saw that as a segfault in
+        # hipGraphLaunch.  Without the cycle they go when the model goes.)
+        self._model_ref = weakref.ref(model)
+        self.eng, self.B, self.H, self.W, self.training = eng, B, H, W, training
         p = cfg.patch
         self.nh, self.nw = H // p, W // p                 # token raster of the image (PatchEmbedDust3R ignores true_shape)
         # The heads see the tokens as a (true_h/p, true_w/p) grid and portrait results come back axis-swapped
@@ -613,6 +617,13 @@ class _SequenceRunner:
         self.seq_dec2 = None          # per hook: [steps*B*P, D] copies of the side-2 decoder tokens of every step
         self.dec2_hooks = None
         self.head2_out = {}
+
+    @property
+    def model(self):
+        m = self._model_ref()
+        if m is None:
+            raise RuntimeError("the Spann3R model this runner belongs to is gone")
+        return m
 
     def ensure_memory(self, n_frames):
         need = (n_frames - 1) * self.P if self.training else 4000 + 8 * self.P

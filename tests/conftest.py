@@ -38,3 +38,21 @@ def rel_err(a, b):
     import torch
     a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.fixture(autouse=True)
+def _release_gpu_state_between_tests(request):
+    """A GPU test builds models whose runners hold hipGraphs and GBs of workspaces in reference cycles (runner <-> model): finalise
+    them at a defined point -- after the test, outside any capture -- instead of whenever the cyclic collector happens to run
+    inside a later test."""
+    yield
+    if request.node.get_closest_marker("gpu") is not None and os.environ.get("SP3_TEST_NO_GC") != "1":
+        import gc
+        gc.collect()
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()
+        except ImportError:
+            pass
