@@ -155,6 +155,8 @@ def kernel_symbol(key):
         if tile.startswith("lean-"):
             return "bm_kernel" if tile.rsplit("-", 1)[-1] in ("256x128", "128x128", "128x64") else "sm_kernel"
         return "gemm_kernel"
+    if key.startswith("attention_packed_qproj"):
+        return "attention_packed_kernel"                    # (the same template with the q projection switched on)
     return key.split("<", 1)[0] + "_kernel"
 
 

@@ -257,6 +257,26 @@ int sp3_attention_packed(const void* qp, int q_cols, int q_col0, int npad_q, con
                          const void* vtp, void* out, int64_t ldo, int out_bf16, int out_packed,
                          int B, int heads, int Nq, int Nk, float scale, int o_group, int o_group_rows, void* stream);
 
+/* sp3_attention_packed with the QUERY PROJECTION inside the launch (round 6): a decoder layer's cross-attention
+ * (croco/models/blocks.py:149-169) reads q = RoPE2D(projq(norm2(x))) of its own side; instead of a 196 x 768 x 768 GEMM launch in front
+ * of the attention launch, every attention workgroup (16 query rows x one head) computes its [16 x 64] q tile from the fragment-order
+ * bf16 copy of x, the producer's LayerNorm partials (folded norm2: ln_s = column sums of gamma (.) Wq, bias = bq + Wq beta) and the
+ * fragment-order weight.  Images come in groups (the two decoder sides of a grouped launch): image b belongs to group b / o_group;
+ * its rows are (b % o_group) * Nq + token inside the group's x / statistics / positions; the *_group_stride fields step from group
+ * to group (elements of bf16, floats).  k / v / out arguments as sp3_attention_packed.  D = 768 (12 heads), Nq < 512. */
+typedef struct sp3_attn_qproj_desc {
+  const void* x_packed; int64_t x_group_stride;
+  const float* ln_stats; int64_t stats_group_stride;   /* [rows][D / 32][2] */
+  const void* w_packed; int64_t w_group_stride;         /* [D][D] fragment order */
+  const float* ln_s; const float* bias; int64_t vec_group_stride;
+  const int32_t* pos; const float* rope_cos; const float* rope_sin;   /* [rows of one group][2] (y, x); tables [max_pos][16] */
+  float ln_eps; int32_t D;
+  const void* kp; int32_t k_cols, k_col0, npad_k; const void* vtp;
+  void* out; int64_t ldo; int32_t out_bf16, out_packed;
+  int32_t B, heads, Nq, Nk; float scale; int32_t o_group, o_group_rows;
+} sp3_attn_qproj_desc;
+int sp3_attention_packed_qproj(const sp3_attn_qproj_desc* desc_host, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Spatial-memory kernels (spann3r/model.py:97-210).
  * The bank (spann3r_amd/model.py SpatialMemory) keeps, next to the reference's mem_k / mem_v / mem_attn / mem_count, the

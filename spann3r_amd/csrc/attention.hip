@@ -462,6 +462,113 @@ __device__ __forceinline__ KFrag load_frag(const __bf16* base, int row, int col,
   return f;
 }
 
+// ---- the cross-attention q projection INSIDE the attention launch (round 6; croco/models/blocks.py:149-169: q = projq(norm2(x)))
+// A decoder layer's cross-attention reads q = RoPE(LN(x) Wq^T + b) of its own side; as a launch of its own that 196 x 768 x 768 GEMM
+// is 6.7 us in front of a 5 us attention launch.  Here every attention workgroup (16 query rows x one head) computes its own
+// [16 x 64] q tile first: K = 768 over the 4 waves exactly as sm_kernel<2, 2, 4, 12> splits it (wave w owns k-blocks w, w + 4, w + 8,
+// every operand byte requested up front), partial tiles meet in LDS, then folded LayerNorm (row statistics of the producer's
+// epilogue), bias and 2-D RoPE with the partner column in lane ^ 16 -- the arithmetic of the SM_ROPE epilogue, operation for
+// operation -- straight into the MFMA fragment the attention loop wants.  Costs 96 KB of L2-resident weight reads per workgroup.
+struct QProjArgs {
+  const __bf16* X; int64_t x_gs;                     // fragment-order [rows][D] per group (decoder side), elements between groups
+  const float* st; int64_t st_gs;                    // LayerNorm partials [rows][D / 32][2], floats between groups
+  const __bf16* W; int64_t w_gs;                     // fragment-order [D][D]
+  const float* ln_s; const float* bias; int64_t v_gs;
+  const int* pos; const float* cos; const float* sin;
+  float eps;
+  int group_imgs, img_tokens;
+};
+
+template <int NKB>
+__device__ __forceinline__ KFrag attn_qproj(const QProjArgs& qa, float* sh, int q0, int Nq, int h, int b, int lane, int wave, int g, int ql) {
+  constexpr int D = NKB * 64, NL4 = NKB / 4, KW = NKB / 4, LD = 68;
+  static_assert(NKB % 4 == 0 && NKB <= 16, "K over the 4 waves; LayerNorm partials: NKB / 4 float4 per lane of a 4-lane row team");
+  const int grp = b / qa.group_imgs, img = b - grp * qa.group_imgs;
+  int tok = q0 + ql;
+  tok = tok < Nq ? tok : Nq - 1;                    // query rows past the image: re-read the last one (their results are dropped)
+  const int xrow = img * qa.img_tokens + tok;
+  const __bf16* X = qa.X + grp * qa.x_gs;
+  const __bf16* W = qa.W + grp * qa.w_gs;
+  // epilogue operands first: LayerNorm partials of this lane's row (the 4 lanes g of a row share them), column sums / bias / RoPE table
+  // rows of this lane's 16 head dimensions d = 16 g .. 16 g + 15
+  const float4* ps = reinterpret_cast<const float4*>(qa.st + grp * qa.st_gs + (int64_t)xrow * (2 * NKB) * 2);
+  float4 lp[NL4];
+#pragma unroll
+  for (int q = 0; q < NL4; ++q) lp[q] = ps[g + 4 * q];
+  const float* sv = qa.ln_s + grp * qa.v_gs + h * 64 + 16 * g;
+  const float* bv = qa.bias + grp * qa.v_gs + h * 64 + 16 * g;
+  const int p = qa.pos[(int64_t)xrow * 2 + (g >> 1)];                       // axis: y for d < 32, x above
+  float4 s4[4], b4[4], c4[4], n4[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    s4[j] = *reinterpret_cast<const float4*>(sv + 4 * j);
+    b4[j] = *reinterpret_cast<const float4*>(bv + 4 * j);
+    c4[j] = *reinterpret_cast<const float4*>(qa.cos + p * 16 + 4 * j);
+    n4[j] = *reinterpret_cast<const float4*>(qa.sin + p * 16 + 4 * j);
+  }
+  KFrag xf[KW], wf[KW][4];
+#pragma unroll
+  for (int i = 0; i < KW; ++i) {
+    const int kb = wave + 4 * i;
+    xf[i] = load_frag(X, xrow, kb * 64 + 16 * g, D);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) wf[i][t] = load_frag(W, h * 64 + 16 * t + ql, kb * 64 + 16 * g, D);
+  }
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < KW; ++i)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i].v[0], wf[i][t].v[0], acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[i].v[1], wf[i][t].v[1], acc[t], 0, 0, 0);
+    }
+  // partial tiles -> LDS (C layout: column = lane & 15 = head dimension 16 t + ql, row = 4 (lane >> 4) + reg = token)
+  {
+    float* slab = sh + wave * 16 * LD;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) slab[(4 * g + r) * LD + 16 * t + ql] = acc[t][r];
+  }
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int q = 0; q < NL4; ++q) { s1 += lp[q].x + lp[q].z; s2 += lp[q].y + lp[q].w; }
+  s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+  s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+  const float mean = s1 * (1.0f / (float)D);
+  const float var = fmaxf(s2 * (1.0f / (float)D) - mean * mean, 0.f);
+  const float rstd = 1.0f / sqrtf(var + qa.eps), rm = rstd * mean;
+  __syncthreads();
+  float v[16];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float4 t4 = *reinterpret_cast<const float4*>(sh + ql * LD + 16 * g + 4 * j);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const float4 u = *reinterpret_cast<const float4*>(sh + w * 16 * LD + ql * LD + 16 * g + 4 * j);
+      t4.x += u.x; t4.y += u.y; t4.z += u.z; t4.w += u.w;
+    }
+    v[4 * j] = rstd * t4.x - rm * s4[j].x; v[4 * j + 1] = rstd * t4.y - rm * s4[j].y;
+    v[4 * j + 2] = rstd * t4.z - rm * s4[j].z; v[4 * j + 3] = rstd * t4.w - rm * s4[j].w;
+    v[4 * j] += b4[j].x; v[4 * j + 1] += b4[j].y; v[4 * j + 2] += b4[j].z; v[4 * j + 3] += b4[j].w;
+  }
+  const bool second = (g & 1) != 0;                                        // dimension d & 16: the y of its (x, y) pair
+  KFrag qf;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const float pv = __shfl_xor(v[j], 16);                                 // partner dimension d ^ 16: lane g ^ 1 of the same row
+    const float4 cq = c4[j >> 2], sq = n4[j >> 2];
+    const float cs = (j & 3) == 0 ? cq.x : (j & 3) == 1 ? cq.y : (j & 3) == 2 ? cq.z : cq.w;
+    const float sn = (j & 3) == 0 ? sq.x : (j & 3) == 1 ? sq.y : (j & 3) == 2 ? sq.z : sq.w;
+    const float o = second ? (v[j] * cs + pv * sn) : (v[j] * cs - pv * sn);
+    qf.v[j >> 3][j & 7] = (__bf16)o;
+  }
+  __syncthreads();                                   // the partial tiles' LDS is the merge scratch of the attention loop below
+  return qf;
+}
+
 // One workgroup = QB blocks of 16 query rows of one head; its 4 waves split the key tiles (tile t goes to wave t & 3), each running
 // an independent online softmax per query block; the four partial (m, l, O^T) states are merged through LDS (wave w merges d-block w).
 // At N = 196 (4 tiles) every wave handles ONE tile: the dependent chain is 1 tile instead of 4.
@@ -477,12 +584,12 @@ __device__ __forceinline__ KFrag load_frag(const __bf16* base, int row, int col,
 //     other resident waves cover the latency -- the explicit prefetch cost more registers than it hid).
 // 2 x 16 heads x 1024 tokens: 28.4 -> 21.5 us; 2 x 12 x 1024: 22.3 -> 16.7; 2 x 12 x 196: 4.26 -> 3.93.  Against the round-4 kernel the
 // outputs differ by <= 2.5e-4 of their maximum (the last bit of a probability before its bf16 rounding).
-template <int QB, int MINW>
+template <int QB, int MINW, int QNKB = 0>
 __global__ __launch_bounds__(256, MINW) void attention_packed_kernel(const __bf16* __restrict__ QP, int q_cols, int q_col0, int npad_q,
                                                                      const __bf16* __restrict__ KP, int k_cols, int k_col0, int npad_k,
                                                                      const __bf16* __restrict__ VTP, void* __restrict__ O, int64_t ldo,
                                                                      int out_bf16, int out_packed, int heads, int Nq, int Nk, float scale,
-                                                                     int o_group, int o_group_rows, int xcd_map) {
+                                                                     int o_group, int o_group_rows, int xcd_map, const QProjArgs qa) {
   extern __shared__ __attribute__((aligned(16))) float sh[];
   float* sh_o = sh;                                  // [wave][qb][db][lane][4]
   float* sh_m = sh + 4 * QB * 4 * 64 * 4;            // [wave][qb][lane]
@@ -493,10 +600,15 @@ __global__ __launch_bounds__(256, MINW) void attention_packed_kernel(const __bf1
   const int q0 = qt * 16 * QB;
   const int last_qrow = npad_q - 16;                 // query blocks past the padded rows re-read the last block (their results are dropped)
   KFrag qf[QB];
+  if constexpr (QNKB > 0) {
+    static_assert(QB == 1, "the fused q projection serves one query block per workgroup");
+    qf[0] = attn_qproj<QNKB>(qa, sh, q0, Nq, h, b, lane, wave, g, ql);
+  } else {
 #pragma unroll
-  for (int qb = 0; qb < QB; ++qb) {
-    const int r0 = q0 + 16 * qb < last_qrow ? q0 + 16 * qb : last_qrow;
-    qf[qb] = load_frag(QP, b * npad_q + r0 + ql, q_col0 + h * 64 + 16 * g, q_cols);
+    for (int qb = 0; qb < QB; ++qb) {
+      const int r0 = q0 + 16 * qb < last_qrow ? q0 + 16 * qb : last_qrow;
+      qf[qb] = load_frag(QP, b * npad_q + r0 + ql, q_col0 + h * 64 + 16 * g, q_cols);
+    }
   }
   const int ntiles = (Nk + 63) >> 6;
   const float sl2 = scale * 1.4426950408889634f;     // softmax in base 2: exp(x) = exp2(x * log2 e), v_exp_f32
@@ -869,15 +981,49 @@ extern "C" int sp3_attention_packed(const void* qp, int q_cols, int q_col0, int 
     hipLaunchKernelGGL((attention_packed_kernel<QB, 3>), dim3((Nq + 16 * QB - 1) / (16 * QB), tail.x, tail.y), dim3(256), lds, st,
                        reinterpret_cast<const __bf16*>(qp), q_cols, q_col0, npad_q, reinterpret_cast<const __bf16*>(kp), k_cols, k_col0,
                        npad_k, reinterpret_cast<const __bf16*>(vtp), out, ldo, out_bf16, out_packed, heads, Nq, Nk, scale, o_group, o_group_rows,
-                       xcd_map);
+                       xcd_map, QProjArgs{});
   } else {
     constexpr int QB = 1, lds = (4 * QB * 4 * 64 * 4 + 2 * 4 * QB * 64) * 4;
     hipLaunchKernelGGL((attention_packed_kernel<QB, 4>), dim3((Nq + 15) / 16, tail.x, tail.y), dim3(256), lds, st,
                        reinterpret_cast<const __bf16*>(qp), q_cols, q_col0, npad_q, reinterpret_cast<const __bf16*>(kp), k_cols, k_col0,
                        npad_k, reinterpret_cast<const __bf16*>(vtp), out, ldo, out_bf16, out_packed, heads, Nq, Nk, scale, o_group, o_group_rows,
-                       xcd_map);
+                       xcd_map, QProjArgs{});
   }
   SP3_LAUNCH_CHECK("sp3_attention_packed");
+  return 0;
+}
+
+extern "C" int sp3_attention_packed_qproj(const sp3_attn_qproj_desc* dp, void* stream) {
+  SP3_CHECK(dp != nullptr, "sp3_attention_packed_qproj: null descriptor");
+  const sp3_attn_qproj_desc& d = *dp;
+  SP3_CHECK(d.x_packed && d.ln_stats && d.w_packed && d.ln_s && d.bias && d.pos && d.rope_cos && d.rope_sin && d.kp && d.vtp && d.out,
+            "sp3_attention_packed_qproj: null pointer");
+  SP3_CHECK(d.D == 768 && d.heads * 64 == d.D, "sp3_attention_packed_qproj: the decoder width (D = 768 = heads x 64) only, got D=%d heads=%d", d.D, d.heads);
+  SP3_CHECK(d.B > 0 && d.Nq > 0 && d.Nk > 0 && d.Nq < 512, "sp3_attention_packed_qproj: bad shape (one query block per workgroup: Nq < 512)");
+  SP3_CHECK(d.npad_k % 64 == 0 && d.npad_k >= ((d.Nk + 63) / 64) * 64 && d.k_cols % 64 == 0 && d.k_col0 % 64 == 0, "sp3_attention_packed_qproj: key geometry");
+  SP3_CHECK(d.out_packed || d.ldo % 4 == 0, "sp3_attention_packed_qproj: ldo");
+  SP3_CHECK(d.o_group > 0 && d.B % d.o_group == 0 && d.o_group_rows >= d.o_group * d.Nq, "sp3_attention_packed_qproj: groups (images per decoder side)");
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  SP3_CHECK(al16(d.x_packed) && al16(d.w_packed) && al16(d.ln_stats) && al16(d.ln_s) && al16(d.bias) && al16(d.rope_cos) && al16(d.rope_sin) &&
+            (d.x_group_stride & 7) == 0 && (d.w_group_stride & 7) == 0 && (d.stats_group_stride & 3) == 0 && (d.vec_group_stride & 3) == 0,
+            "sp3_attention_packed_qproj: 16-byte alignment");
+  QProjArgs qa;
+  qa.X = reinterpret_cast<const __bf16*>(d.x_packed); qa.x_gs = d.x_group_stride;
+  qa.st = d.ln_stats; qa.st_gs = d.stats_group_stride;
+  qa.W = reinterpret_cast<const __bf16*>(d.w_packed); qa.w_gs = d.w_group_stride;
+  qa.ln_s = d.ln_s; qa.bias = d.bias; qa.v_gs = d.vec_group_stride;
+  qa.pos = d.pos; qa.cos = d.rope_cos; qa.sin = d.rope_sin;
+  qa.eps = d.ln_eps; qa.group_imgs = d.o_group; qa.img_tokens = d.Nq;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int np = d.heads * d.B, xcd_map = attn_xcd_ok(d.heads, d.B) ? np : 0;
+  const dim3 tail = xcd_map ? dim3((np + 7) / 8 * 8, 1) : dim3(d.heads, d.B);
+  constexpr int QB = 1, lds = (4 * QB * 4 * 64 * 4 + 2 * 4 * QB * 64) * 4;
+  static_assert(lds >= 4 * 16 * 68 * 4, "the q projection's partial tiles fit the merge scratch");
+  hipLaunchKernelGGL((attention_packed_kernel<QB, 2, 12>), dim3((d.Nq + 15) / 16, tail.x, tail.y), dim3(256), lds, st,
+                     (const __bf16*)nullptr, 0, 0, 16, reinterpret_cast<const __bf16*>(d.kp), d.k_cols, d.k_col0, d.npad_k,
+                     reinterpret_cast<const __bf16*>(d.vtp), d.out, d.ldo, d.out_bf16, d.out_packed, d.heads, d.Nq, d.Nk, d.scale, d.o_group,
+                     d.o_group_rows, xcd_map, qa);
+  SP3_LAUNCH_CHECK("sp3_attention_packed_qproj");
   return 0;
 }
 

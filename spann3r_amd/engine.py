@@ -76,6 +76,7 @@ class Engine:
         # SP3_LEAN_GEMM=0 (the one documented A/B switch: the whole default path against the general kernels) the maps stay fp32
         self.mdt = torch.bfloat16 if (precision == "bf16" and ops.LEAN) else torch.float32
         self._ws = {}
+        self.fuse_cross_q = True     # grouped decoder (bf16): the cross-attention's q projection runs inside its attention launch
         self._arena, self._arena_off, self._arenas = None, 0, []
         self._splitA_plan = {}       # rows -> does the library hold a lean instance for the packed split-A key MLP (encode_feat_keys_grouped)
         self._pos_cache = {}
@@ -474,12 +475,18 @@ class Engine:
                         ops.proj_rope_vt(xp[o][cur], w[pre + "ckv.w"], w[pre + "ckv.b"], kbuf, 0, vt, npk, M=Ro, N=2 * D, K=D,
                                          lda=D, rope_cols=D, pos=pos[o], cos=self.cos, sin=self.sin, tokens=Po, heads=Hh,
                                          qkv_packed=True, ln=lnk)
-                        qbuf = self.ws("cqp" + tag, ops.packed_shape(B * npq, D, self.wdt), self.wdt, zero=True)
-                        ops.proj_rope_vt(xq, w[pre + "cq.w"], w[pre + "cq.b"], qbuf, 0, None, npq, M=R, N=D, K=D, lda=D,
-                                         rope_cols=D, pos=pos[s], cos=self.cos, sin=self.sin, tokens=P, heads=Hh,
-                                         qkv_packed=True, ln=lnq)
-                        ops.attention_packed(qbuf, D, 0, npq, kbuf, D, 0, npk, vt, ao, D, B=B, heads=Hh, Nq=P, Nk=Po,
-                                             scale=64 ** -0.5)
+                        if self.fuse_cross_q and P < 512 and D == 768 and ops.LEAN:
+                            # (the q projection inside the attention launch, as in decoder_grouped: one group of B images)
+                            ops.attention_packed_qproj(xq, stq, w[pre + "cq.w"], w[pre + "cq.s"], w[pre + "cq.b"], pos[s], self.cos, self.sin,
+                                                       kbuf, D, 0, npk, vt, ao, D, B=B, heads=Hh, Nq=P, Nk=Po, scale=64 ** -0.5,
+                                                       o_group=B, o_group_rows=R, eps=1e-6)
+                        else:
+                            qbuf = self.ws("cqp" + tag, ops.packed_shape(B * npq, D, self.wdt), self.wdt, zero=True)
+                            ops.proj_rope_vt(xq, w[pre + "cq.w"], w[pre + "cq.b"], qbuf, 0, None, npq, M=R, N=D, K=D, lda=D,
+                                             rope_cols=D, pos=pos[s], cos=self.cos, sin=self.sin, tokens=P, heads=Hh,
+                                             qkv_packed=True, ln=lnq)
+                            ops.attention_packed(qbuf, D, 0, npq, kbuf, D, 0, npk, vt, ao, D, B=B, heads=Hh, Nq=P, Nk=Po,
+                                                 scale=64 ** -0.5)
                     else:
                         kbuf = self.ws("ck" + tag, (Ro, D), self.wdt)
                         vt = self.ws("cvt" + tag, (B * Hh * 64, (Pmax + 63) // 64 * 64), self.wdt, zero=True)
@@ -586,11 +593,17 @@ class Engine:
                                  scale=64 ** -0.5, o_group=B, o_group_rows=Rp)
             upd(ao, D, "proj", xi, stq, xq)
             # cross attention (:188-189): q from this side (norm2); k/v of the OTHER side's previous layer were projected above
-            ops.proj_rope_vt(xq, w[g + "cq.w"], w[g + "cq.b"], cqp, 0, None, npad, M=R, N=D, K=D, lda=D, rope_cols=D,
-                             ln=ops.LnFold(stq, D, w[g + "cq.s"], 1e-6, sb_stats=sb_st, sb_s=D * 4),
-                             strideA=xq.stride, strideW=w[g + "cq.w"].stride, strideC=B * npad * D, sb={"bias": D * 4}, **rope)
-            ops.attention_packed(cqp, D, 0, npad, ckp, D, 0, npad, cvtp, ao, D, B=2 * B, heads=Hh, Nq=P, Nk=P,
-                                 scale=64 ** -0.5, o_group=B, o_group_rows=Rp)
+            if self.fuse_cross_q and P < 512 and D == 768 and ops.LEAN:
+                # the q projection inside the attention launch: one launch less per layer (csrc/attention.hip attn_qproj)
+                ops.attention_packed_qproj(xq, stq, w[g + "cq.w"], w[g + "cq.s"], w[g + "cq.b"], pos, self.cos, self.sin, ckp, D, 0, npad, cvtp,
+                                           ao, D, B=2 * B, heads=Hh, Nq=P, Nk=P, scale=64 ** -0.5, o_group=B, o_group_rows=Rp, eps=1e-6,
+                                           stats_group_stride=sb_st // 4, vec_group_stride=D)
+            else:
+                ops.proj_rope_vt(xq, w[g + "cq.w"], w[g + "cq.b"], cqp, 0, None, npad, M=R, N=D, K=D, lda=D, rope_cols=D,
+                                 ln=ops.LnFold(stq, D, w[g + "cq.s"], 1e-6, sb_stats=sb_st, sb_s=D * 4),
+                                 strideA=xq.stride, strideW=w[g + "cq.w"].stride, strideC=B * npad * D, sb={"bias": D * 4}, **rope)
+                ops.attention_packed(cqp, D, 0, npad, ckp, D, 0, npad, cvtp, ao, D, B=2 * B, heads=Hh, Nq=P, Nk=P,
+                                     scale=64 ** -0.5, o_group=B, o_group_rows=Rp)
             upd(ao, D, "cproj", xo, stq, xq)
             # MLP (:190), norm3 folded into fc1
             Hd = D * cfg.mlp_ratio

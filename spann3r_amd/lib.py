@@ -65,6 +65,19 @@ class AttnBwdDesc(C.Structure):
                 + [("B", C.c_int32), ("heads", C.c_int32), ("Nq", C.c_int32), ("Nk", C.c_int32), ("scale", C.c_float), ("bf16_products", C.c_int32)])
 
 
+class AttnQProjDesc(C.Structure):
+    """sp3_attn_qproj_desc (include/spann3r_hip.h)"""
+    _fields_ = [
+        ("x_packed", C.c_void_p), ("x_group_stride", C.c_int64), ("ln_stats", C.c_void_p), ("stats_group_stride", C.c_int64),
+        ("w_packed", C.c_void_p), ("w_group_stride", C.c_int64), ("ln_s", C.c_void_p), ("bias", C.c_void_p), ("vec_group_stride", C.c_int64),
+        ("pos", C.c_void_p), ("rope_cos", C.c_void_p), ("rope_sin", C.c_void_p), ("ln_eps", C.c_float), ("D", C.c_int32),
+        ("kp", C.c_void_p), ("k_cols", C.c_int32), ("k_col0", C.c_int32), ("npad_k", C.c_int32), ("vtp", C.c_void_p),
+        ("out", C.c_void_p), ("ldo", C.c_int64), ("out_bf16", C.c_int32), ("out_packed", C.c_int32),
+        ("B", C.c_int32), ("heads", C.c_int32), ("Nq", C.c_int32), ("Nk", C.c_int32), ("scale", C.c_float),
+        ("o_group", C.c_int32), ("o_group_rows", C.c_int32),
+    ]
+
+
 class ReduceLnDesc(C.Structure):
     _fields_ = [
         ("partial", C.c_void_p), ("split_stride", C.c_int64), ("bias", C.c_void_p), ("res", C.c_void_p),
@@ -113,6 +126,7 @@ _PROTOS = {
     "sp3_attention_packed": [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                              C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
                              C.c_void_p],
+    "sp3_attention_packed_qproj": [C.POINTER(AttnQProjDesc), C.c_void_p],
     "sp3_softmax_thresh": [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float,
                            C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p],
     "sp3_softmax_pack": [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_void_p,

@@ -711,6 +711,28 @@ def attention_packed(qp, q_cols, q_col0, npad_q, kp, k_cols, k_col0, npad_k, vtp
     return out
 
 
+def attention_packed_qproj(xq, stats, Wq, ln_s, bias, pos, cos, sin, kp, k_cols, k_col0, npad_k, vtp, out, ldo, *, B, heads, Nq, Nk, scale,
+                           o_group, o_group_rows, eps=1e-6, stats_group_stride=0, vec_group_stride=0):
+    """Cross-attention with its query projection inside the launch (include/spann3r_hip.h sp3_attention_packed_qproj):
+    q = RoPE2D(LN(x) Wq^T + b) per (16 query rows, head) workgroup from xq (PackedAct.group: fragment-order bf16 x of both decoder
+    sides), the producer's LayerNorm partials `stats`, the fragment-order weight group Wq with its folded column sums / bias."""
+    d = L.AttnQProjDesc()
+    D = heads * 64
+    d.x_packed, d.x_group_stride = xq.data_ptr(), getattr(xq, "stride", 0)
+    d.ln_stats, d.stats_group_stride = stats.data_ptr(), stats_group_stride
+    d.w_packed, d.w_group_stride = Wq.data_ptr(), getattr(Wq, "stride", 0)
+    d.ln_s, d.bias, d.vec_group_stride = ln_s.data_ptr(), bias.data_ptr(), vec_group_stride
+    d.pos, d.rope_cos, d.rope_sin, d.ln_eps, d.D = pos.data_ptr(), cos.data_ptr(), sin.data_ptr(), eps, D
+    d.kp, d.k_cols, d.k_col0, d.npad_k, d.vtp = kp.data_ptr(), k_cols, k_col0, npad_k, vtp.data_ptr()
+    d.out, d.ldo, d.out_bf16, d.out_packed = out.data_ptr(), ldo, int(out.dtype == torch.bfloat16), _is_packed(out)
+    d.B, d.heads, d.Nq, d.Nk, d.scale, d.o_group, d.o_group_rows = B, heads, Nq, Nk, float(scale), o_group, o_group_rows
+    # algorithmic work: the attention's + the projection GEMM's (2 Nq D D per image); bytes: q is never materialised
+    _timed("attention_packed_qproj<bf16>", 4.0 * B * heads * Nq * Nk * 64 + 2.0 * B * Nq * D * D,
+           B * heads * 64.0 * (2 * (2 * Nk) + 4 * Nq) + 2.0 * B * Nq * D + 2.0 * (B // max(o_group, 1)) * D * D,
+           lambda: L.check(L.load().sp3_attention_packed_qproj(C.byref(d), L.stream_ptr()), "sp3_attention_packed_qproj"))
+    return out
+
+
 def softmax_thresh(S, P, *, ld, rows, M, Mpad, thresh, batch=1, strideS=0, packed=None, stride_packed=0):
     """P: optional fp32 row-major output; packed: optional bf16 / fp32 buffer that receives the probabilities in fragment
     order [rows, M rounded up to a k-block] (the P.V GEMM's packed A)"""

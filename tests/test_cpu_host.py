@@ -37,7 +37,8 @@ def test_ctypes_structs_match_the_header():
     """sizeof / offsetof of the descriptor structs, as gcc sees include/spann3r_hip.h, equal the ctypes mirror."""
     from spann3r_amd import lib
     pairs = [("sp3_gemm_desc", lib.GemmDesc), ("sp3_reduce_ln_desc", lib.ReduceLnDesc), ("sp3_head_part", lib.HeadPart),
-             ("sp3_attn_bwd_desc", lib.AttnBwdDesc), ("sp3_bank_write_desc", lib.BankWriteDesc)]
+             ("sp3_attn_bwd_desc", lib.AttnBwdDesc), ("sp3_bank_write_desc", lib.BankWriteDesc),
+             ("sp3_attn_qproj_desc", lib.AttnQProjDesc)]
     lines = ['#include "%s"' % os.path.join(REPO, "include", "spann3r_hip.h"), "#include <stdio.h>", "#include <stddef.h>", "int main(){"]
     exp = []
     for cname, cls in pairs:

@@ -480,3 +480,49 @@ def test_long_bank_read_without_a_score_matrix(rows, M, S_k):
     ops.bank_state_set(state, M, 0)
     out2, attn2, _, _ = read(min(cap, (M + 1023) // 1024 * 1024 + 128), state)
     assert torch.equal(out, out2) and torch.equal(attn, attn2)
+
+
+@pytest.mark.parametrize("B,nh,nw", [(1, 14, 14), (2, 10, 10), (1, 3, 4)])
+def test_cross_attention_with_the_q_projection_inside(B, nh, nw):
+    """The decoder's cross-attention with its query projection computed per attention workgroup (sp3_attention_packed_qproj,
+    croco/models/blocks.py:149-169) against the two launches it replaces: q/k-style projection GEMM (folded norm2, bias, 2-D RoPE,
+    lean tile 31) + sp3_attention_packed -- two decoder sides as the two groups of a grouped launch, images per side = B."""
+    from spann3r_amd.engine import _rope_tables
+    ops = _ops()
+    D, heads = 768, 12
+    P = nh * nw
+    R, npad = B * P, (P + 63) // 64 * 64
+    xg = ops.PackedAct.group(2, R, D, BF, DEV)
+    stg = torch.zeros(2, R, D // 32, 2, device=DEV)
+    Ws, ss, bs = [], [], []
+    for s_ in (0, 1):
+        x = rnd(R, D, seed=1 + s_) * 2 + 0.2
+        ops.pack_stats(x.to(DEV), xg.at(s_), stg[s_], rows=R, C_=D)
+        gam = rnd(D, seed=31 + s_) * 0.3 + 1
+        W = rnd(D, D, seed=2 + s_) * 0.05 * gam[None, :]
+        Ws.append(ops.PackedWeight(W.to(DEV).to(BF)))
+        ss.append(bf(W).sum(1))
+        bs.append(rnd(D, seed=3 + s_))
+    Wg = ops.PackedWeightGroup(Ws)
+    sg, bg = torch.stack(ss).to(DEV).contiguous(), torch.stack(bs).to(DEV).contiguous()
+    pos = _pos(B, nh, nw).reshape(-1, 2).to(torch.int32).to(DEV)
+    cos, sin = _rope_tables(64, 100.0, DEV)
+    kp = ops.PackedAct.from_dense((rnd(2 * B * npad, D, seed=9) * 1.5).to(DEV).to(BF))
+    vtp = (rnd(2 * B * heads * npad * 64, seed=10)).to(DEV).to(BF)
+    Rp = xg.rows_pad
+    # the two launches
+    cqp = torch.zeros(ops.packed_shape(2 * B * npad, D, BF), dtype=BF, device=DEV)
+    ops.proj_rope_vt(xg, Wg, bg, cqp, 0, None, npad, M=R, N=D, K=D, lda=D, rope_cols=D, pos=pos, cos=cos, sin=sin, tokens=P, heads=heads, qkv_packed=True,
+                     ln=ops.LnFold(stg, D, sg, 1e-6, sb_stats=R * (D // 32) * 8, sb_s=D * 4), batch=2, strideA=xg.stride, strideW=Wg.stride,
+                     strideC=B * npad * D, sb={"bias": D * 4})
+    ref = ops.PackedAct.group(2, R, D, BF, DEV)
+    ops.attention_packed(cqp, D, 0, npad, kp, D, 0, npad, vtp, ref, D, B=2 * B, heads=heads, Nq=P, Nk=P, scale=0.125, o_group=B, o_group_rows=Rp)
+    got = ops.PackedAct.group(2, R, D, BF, DEV)
+    ops.attention_packed_qproj(xg, stg, Wg, sg, bg, pos, cos, sin, kp, D, 0, npad, vtp, got, D, B=2 * B, heads=heads, Nq=P, Nk=P, scale=0.125,
+                               o_group=B, o_group_rows=Rp, eps=1e-6, stats_group_stride=R * (D // 32) * 2, vec_group_stride=D)
+    for s_ in (0, 1):
+        a, b = _dense(ops, got, s_, R, D).float().cpu(), _dense(ops, ref, s_, R, D).float().cpu()
+        assert float(b.abs().max()) > 0.05
+        frac = float((a != b).float().mean())
+        print("side %d: rel diff %.2e, differing elements %.4f" % (s_, rel_err(a, b), frac))
+        assert rel_err(a, b) < 8e-3 and frac < 0.05
