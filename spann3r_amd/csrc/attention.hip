@@ -600,10 +600,7 @@ __global__ __launch_bounds__(256, MINW) void attention_packed_kernel(const __bf1
   const int q0 = qt * 16 * QB;
   const int last_qrow = npad_q - 16;                 // query blocks past the padded rows re-read the last block (their results are dropped)
   KFrag qf[QB];
-  if constexpr (QNKB > 0) {
-    static_assert(QB == 1, "the fused q projection serves one query block per workgroup");
-    qf[0] = attn_qproj<QNKB>(qa, sh, q0, Nq, h, b, lane, wave, g, ql);
-  } else {
+  if constexpr (QNKB == 0) {
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
       const int r0 = q0 + 16 * qb < last_qrow ? q0 + 16 * qb : last_qrow;
@@ -627,22 +624,32 @@ __global__ __launch_bounds__(256, MINW) void attention_packed_kernel(const __bf1
 #pragma unroll
     for (int i = 0; i < 4; ++i) o[qb][i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
+  KFrag kc[4];
+  bf16x8 vv[2][4];
+  auto load_tile = [&](int tile) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const __bf16* p = kbase + (int64_t)(4 * tile + t) * kblk;
+      kc[t].v[0] = *reinterpret_cast<const bf16x8*>(p);
+      kc[t].v[1] = *reinterpret_cast<const bf16x8*>(p + 64 * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+        vv[u][db] = *reinterpret_cast<const bf16x8*>(vbase + (((int64_t)(2 * tile + u)) * 4 + db) * 64 * 8);
+  };
+  if constexpr (QNKB > 0) {
+    // the q projection in front of the loop: this wave's first key tile is requested BEFORE it (independent of q), so the K / V^T
+    // round trip and the projection's operand round trip overlap
+    static_assert(QB == 1, "the fused q projection serves one query block per workgroup");
+    load_tile(wave < ntiles ? wave : ntiles - 1);
+    qf[0] = attn_qproj<QNKB>(qa, sh, q0, Nq, h, b, lane, wave, g, ql);
+  }
   if (wave < ntiles) {
     for (int tile = wave; tile < ntiles; tile += 4) {
       const int kb = tile << 6;
-      KFrag kc[4];
-      bf16x8 vv[2][4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const __bf16* p = kbase + (int64_t)(4 * tile + t) * kblk;
-        kc[t].v[0] = *reinterpret_cast<const bf16x8*>(p);
-        kc[t].v[1] = *reinterpret_cast<const bf16x8*>(p + 64 * 8);
-      }
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int db = 0; db < 4; ++db)
-          vv[u][db] = *reinterpret_cast<const bf16x8*>(vbase + (((int64_t)(2 * tile + u)) * 4 + db) * 64 * 8);
+      if (QNKB == 0 || tile != wave) load_tile(tile);
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) {
         f32x4 s[4];
