@@ -242,7 +242,9 @@ def kernel_profile(model, seq, precision):
         big = max(reads, key=lambda r: r["info"]["M"])
         gbs = big["bytes"] / (big["ms"] * 1e-3) / 1e9
         memread = {"what": "spatial-memory read: score GEMM (LN_q folded, softmax statistics in its epilogue) -> P.V_hat + q with the "
-                           "thresholded probabilities built on load (short banks) or softmax launch + split-K P.V (long banks); column sums",
+                           "thresholded probabilities built on load (short banks); long banks of a 512x512 frame: score stage that writes bf16 "
+                           "exp(s - group max) + group statistics, merge, P.V stage with the groups' rescale in its loop, split-K reduce + q "
+                           "(no score matrix; round 5: fp32 scores + softmax launch + split-K P.V); column sums",
                    "bank_tokens": big["info"]["M"], "queries": big["info"]["tokens_per_frame"], "algorithmic_bytes": big["bytes"],
                    "us": 1e3 * big["ms"], "launches": big["launches"], "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                    "frac": gbs / PEAK_HBM_GBS, "gflop": big["info"].get("flops", 0.0) / 1e9,
@@ -264,6 +266,24 @@ def _promote_replay(memread, rep):
         memread["launches"] = 3
     memread["timing"] = rep["timing"]
     memread.pop("all_reads_us", None)
+    _memread_roofline(memread)
+
+
+def _memread_roofline(memread, precision="bf16"):
+    """which roof binds THIS read (few queries, short bank: HBM bytes of K_hat + V_hat; 1024 queries over a long bank: 963 FLOP/B,
+    the matrix pipe) and how far the replayed read is from it"""
+    us = memread.get("us")
+    if not us:
+        return
+    flops = 4.0 * memread["queries"] * memread["bank_tokens"] * 1024
+    t_mfma, t_hbm = flops / (PEAK_TFLOPS[precision] * 1e12), memread["algorithmic_bytes"] / (PEAK_HBM_GBS * 1e9)
+    bound = "mfma" if t_mfma >= t_hbm else "hbm"
+    if bound == "mfma":
+        memread["roofline"] = {"bound": "mfma", "achieved": flops / (us * 1e-6) / 1e12, "peak": PEAK_TFLOPS[precision], "unit": "TFLOP/s",
+                               "frac": t_mfma / (us * 1e-6)}
+    else:
+        memread["roofline"] = {"bound": "hbm", "achieved": memread["algorithmic_bytes"] / (us * 1e-6) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                               "frac": t_hbm / (us * 1e-6)}
 
 
 def memread_replay(model, reps=20):
