@@ -17,7 +17,7 @@ SM = {(3, 4, 8, 16, 0, 2): 30, (2, 2, 4, 12, 0, 2): 31, (4, 4, 8, 16, 0, 0): 32,
 BM = {(4, 2, 4, 16, 3, 2): 50, (2, 2, 4, 16, 3, 2): 51, (2, 2, 4, 12, 3, 2): 52, (4, 2, 4, 16, 3, 0): 53, (2, 2, 4, 16, 3, 0): 54,
       (2, 2, 4, 12, 3, 0): 55, (2, 2, 2, 16, 3, 1): 56, (2, 2, 2, 64, 3, 1): 57, (2, 2, 2, 12, 3, 1): 58, (2, 2, 2, 48, 3, 1): 59,
       (2, 2, 2, 28, 3, 1): 60, (4, 2, 4, 16, 3, 1): 61, (4, 2, 4, 64, 3, 1): 62, (2, 2, 2, 48, 4, 1): 59, (4, 2, 4, 12, 3, 2): 63,
-      (4, 2, 4, 12, 3, 0): 64}
+      (4, 2, 4, 12, 3, 0): 64, (4, 2, 4, 16, 3, 4): 45}
 
 
 def lean_key(row):
@@ -41,7 +41,13 @@ def lean_key(row):
         bf = "float" not in n and "conv_sm_kernelIf" not in n
         return "gemm<A%s,Wbf16,conv3x3,%s>" % ("bf16" if bf else "f32", _TILE_NAMES[40 if row["grid"][3] == 768 else 41])
     if "attention_packed_kernel" in n:
-        return "attention_packed<bf16>"
+        # (the third template argument = k-blocks of the q projection computed inside the launch: the decoder's cross-attention)
+        m = re.search(r"attention_packed_kernel<\s*\d+,\s*\d+,\s*(\d+)", n) or re.search(r"attention_packed_kernelILi\d+ELi\d+ELi(\d+)E", n)
+        return "attention_packed_qproj<bf16>" if (m and int(m.group(1)) > 0) else "attention_packed<bf16>"
+    if "pvs_kernel" in n:
+        return "gemm<Abf16,Wbf16,softmax,lean-prob-pv-256x128>"
+    if re.search(r"\bpv_kernel", n):
+        return "gemm<Af32,Wbf16,softmax,lean-softmax-pv-16x64xk8>"
     return None
 
 
@@ -83,7 +89,13 @@ def main():
                    "(tools/rocpd_pmc_grid.py) so sp3_gemm2 pairs are separate",
            "kernels": {}}
     for k, (f, n) in fetch.items():
-        w = write.get(k, (0.0, 0))[0]
+        if k not in write:
+            # (the WRITE_SIZE pass did not see this kernel -- a pass that ended early, a name the demangler spelled differently: no number
+            #  is better than an understated one; bench.py skips entries without traffic_bytes)
+            print("pmc_traffic_json: %s has no WRITE_SIZE row: traffic left out" % k, file=sys.stderr)
+            out["kernels"][k] = {"fetch_kib_per_launch": f, "write_kib_per_launch": None, "traffic_bytes": None, "launches": n}
+            continue
+        w = write[k][0]
         out["kernels"][k] = {"fetch_kib_per_launch": f, "write_kib_per_launch": w, "traffic_bytes": int(round(2 * f * 1024 + w * 1024)), "launches": n}
     json.dump(out, sys.stdout, indent=1)
     print()
