@@ -44,7 +44,7 @@ for stage in "$@"; do
     prof3)      # rocprofv3 kernel stats of BASELINE config 3 (512 x 512, 50 frames, growing bank)
                 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/prof3" -o run -- python "$OLDPWD/bench.py" --size 512 --frames 50 --train-policy --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-extras > "$OLDPWD/$OUT/prof3.log" 2>&1); DB=$(find "$OUT/prof3" -name "*results.db" | head -1); python tools/rocpd_stats.py "$DB" > "$OUT/prof3_stats.md" 2>&1; rm -rf "$OUT/prof3"; head -30 "$OUT/prof3_stats.md" | cut -c1-180 ;;
     pmcmemlong) # HBM traffic of the long-bank memory read (50 176 tokens x 1024 queries), launch by launch: FETCH_SIZE / WRITE_SIZE passes
-                for C in FETCH_SIZE WRITE_SIZE; do (cd /tmp && timeout 300 rocprofv3 --pmc $C -d "$OLDPWD/$OUT/pmcm_$C" -o run --output-format csv -- python "$OLDPWD/tools/bench_memread.py" --tokens 50176 --rows 1024 --copies 3 > "$OLDPWD/$OUT/pmcm_$C.log" 2>&1); F=$(find "$OUT/pmcm_$C" -name "*counter_collection.csv" | head -1); python tools/pmc_csv.py "$F" > "$OUT/pmcmemlong_$C.txt" 2>&1; rm -rf "$OUT/pmcm_$C"; cat "$OUT/pmcmemlong_$C.txt" | cut -c1-200; done ;;
+                for C in FETCH_SIZE WRITE_SIZE; do (cd /tmp && timeout 300 rocprofv3 --pmc $C -d "$OLDPWD/$OUT/pmcm_$C" -o run --output-format csv -- python "$OLDPWD/tools/bench_memread.py" --tokens 50176 --rows 1024 --copies 3 > "$OLDPWD/$OUT/pmcm_$C.log" 2>&1); F=$(find "$OUT/pmcm_$C" -name "*counter_collection.csv" | head -1); python tools/pmc_csv.py "$F" gemm bm_kernel pvs_kernel prob_merge colsum_prob softmax_ reduce_ln colsum_packed > "$OUT/pmcmemlong_$C.txt" 2>&1; rm -rf "$OUT/pmcm_$C"; cat "$OUT/pmcmemlong_$C.txt" | cut -c1-200; done ;;
     trainbf)    timeout 900 python tools/train_step_time.py --precision bf16 >> "$OUT/train.txt" 2>&1; tail -12 "$OUT/train.txt" ;;
     train)      for pr in bf16 fp32; do timeout 900 python tools/train_step_time.py --precision $pr >> "$OUT/train.txt" 2>&1; done; tail -20 "$OUT/train.txt" ;;
     trainprof)  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/tprof" -o run -- python "$OLDPWD/tools/train_step_time.py" --precision bf16 --steps 2 > "$OLDPWD/$OUT/trainprof.log" 2>&1); DB=$(find "$OUT/tprof" -name "*results.db" | head -1); python tools/rocpd_stats.py "$DB" > "$OUT/trainprof_stats.md" 2>&1; rm -rf "$OUT/tprof"; head -45 "$OUT/trainprof_stats.md" | cut -c1-200 ;;
