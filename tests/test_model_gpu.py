@@ -424,6 +424,43 @@ def test_memory_bank_fixture(tiny_model):
     assert rel_err(np.sort(mem.mem_attn.cpu().numpy().ravel()), np.sort(g["mem_attn"].ravel())) < TOL_FP32
 
 
+def test_memory_policy_with_the_fill_level_on_the_device(tiny_model):
+    """bf16: the stand-alone spatial memory over the 32-frame policy fixture (similarity skips, working -> long-term hand-over, one
+    prune with its bank switch) with (M, wm) as device state (round 6: reads, similarity window and bank writes take them from the
+    device) against the same memory with the counts as launch arguments: every read bit-identical, identical events and final
+    bank."""
+    import importlib.util
+    from spann3r_amd.model import SpatialMemory
+    spec = importlib.util.spec_from_file_location("memory_inputs", os.path.join(os.path.dirname(__file__), "golden", "memory_inputs.py"))
+    mi = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mi)
+    g = load_golden("memory_bank.npz")
+    m = tiny_model.set_precision("bf16")
+    try:
+        eng = m.engine
+        mems = [SpatialMemory(eng, 1, 196, capacity=4000 + 8 * 196, device_state=ds) for ds in (False, True)]
+        assert mems[0].state is None and mems[1].state is not None and mems[1].read_dyn
+        mems[1].reset()
+        events = [[], []]
+        for step in range(int(g["n_steps"])):
+            k, v, q = (t.to(DEV) for t in mi.memory_inputs(step))
+            outs = []
+            for i, mem in enumerate(mems):
+                if mem.M > 0:
+                    outs.append(mem.memory_read(q, torch.empty_like(q)).clone())
+                before = -1 if mem.M == 0 else mem.M
+                mem.add_mem_check(k, v)
+                events[i].append([step, before, mem.M, mem.wm, mem.lm])
+            if outs:
+                assert torch.equal(outs[0], outs[1]), step
+            assert mems[1].state[:2].tolist() == [mems[1].M, mems[1].wm]
+        assert events[0] == events[1] and np.array_equal(np.array(events[1]), g["events"])      # (fp32 similarity gate: the reference's decisions)
+        for name in ("mem_k", "mem_v", "mem_attn", "mem_count"):
+            assert torch.equal(getattr(mems[0], name), getattr(mems[1], name)), name
+    finally:
+        m.set_precision("fp32")
+
+
 def test_memory_sliding_window_vs_oracle(tiny_model):
     """long_mem_size == 0 (spann3r/model.py:132-137): the bank keeps the last work_mem_size frames; every read and the final bank
     against the CPU oracle's SpatialMemory on the same inputs"""
