@@ -778,22 +778,34 @@ class _SequenceRunner:
             self.graphs.move_to_end(key)
             self.graphs[key][0].replay()
         elif key in self.seen:
-            torch.cuda.synchronize()
             if getattr(self, "_pool", None) is None:
                 self._pool = torch.cuda.graph_pool_handle()
+                self._capture_stream = torch.cuda.Stream()
             before = torch.cuda.memory_allocated()
             g = torch.cuda.CUDAGraph()
+            # capture_begin / capture_end directly instead of the torch.cuda.graph context manager, which opens with a device
+            # synchronise and torch.cuda.empty_cache(): a capture records launches, it does not need an idle GPU -- the eager step
+            # queued before it keeps running while the host records this one (a first forward call captures its step graph between
+            # two steps), and the allocator keeps the blocks the next call's outputs will want.
             # (no cyclic garbage collection during the capture: finalising another runner's hipGraph is not permitted while a
             # stream captures)
             import gc
             gc_was = gc.isenabled()
             gc.disable()
+            main = torch.cuda.current_stream()
+            cap = self._capture_stream
+            cap.wait_stream(main)
             try:
-                with torch.cuda.graph(g, pool=self._pool):
-                    fn()
+                with torch.cuda.stream(cap):
+                    g.capture_begin(self._pool, capture_error_mode="thread_local")
+                    try:
+                        fn()
+                    finally:
+                        g.capture_end()
             finally:
                 if gc_was:
                     gc.enable()
+            main.wait_stream(cap)
             nbytes = max(0, torch.cuda.memory_allocated() - before)
             self.graphs[key] = (g, nbytes)
             self.graph_bytes += nbytes
