@@ -778,8 +778,11 @@ class _SequenceRunner:
             self.graphs.move_to_end(key)
             self.graphs[key][0].replay()
         elif key in self.seen:
-            if getattr(self, "_pool", None) is None:
+            if getattr(self, "_pool", None) is None or not self.graphs:
+                # a pool whose last graph is gone is retired by the allocator (its blocks are freed at the next empty_cache / OOM
+                # retry) and must not be captured into again: a runner that dropped all of its graphs starts a new pool
                 self._pool = torch.cuda.graph_pool_handle()
+            if getattr(self, "_capture_stream", None) is None:
                 self._capture_stream = torch.cuda.Stream()
             before = torch.cuda.memory_allocated()
             g = torch.cuda.CUDAGraph()

@@ -41,6 +41,8 @@ for stage in "$@"; do
     bench3)     timeout 600 python bench.py --size 512 --frames 50 --train-policy --steps 3 --warmup 2 --no-cpu-baseline --no-extras > "$OUT/bench3.json" 2> "$OUT/bench3.err"; head -c 1500 "$OUT/bench3.json"; tail -3 "$OUT/bench3.err" ;;
     prof)       (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/prof" -o run -- python "$OLDPWD/bench.py" --steps 6 --warmup 3 --no-cpu-baseline --no-profile --no-extras > "$OLDPWD/$OUT/prof.log" 2>&1); DB=$(find "$OUT/prof" -name "*results.db" | head -1); python tools/rocpd_stats.py "$DB" > "$OUT/prof_stats.md" 2>&1; python tools/rocpd_lastseq.py "$DB" > "$OUT/prof_lastseq.txt" 2>&1; rm -rf "$OUT/prof"; head -40 "$OUT/prof_stats.md" ;;
     pmcbench)   for C in FETCH_SIZE WRITE_SIZE; do (cd /tmp && timeout 600 rocprofv3 --pmc $C -d "$OLDPWD/$OUT/pmcb_$C" -o run -- python "$OLDPWD/bench.py" --steps 3 --warmup 2 --no-cpu-baseline --no-profile --no-extras --no-graphs > "$OLDPWD/$OUT/pmcb_$C.log" 2>&1); DB=$(find "$OUT/pmcb_$C" -name "*results.db" | head -1); python tools/rocpd_pmc_grid.py "$DB" --json "$OUT/pmc_$C.json" > "$OUT/pmc_${C}_by_grid.md" 2>&1; rm -rf "$OUT/pmcb_$C"; head -12 "$OUT/pmc_${C}_by_grid.md" | cut -c1-200; done ;;
+    proff16)    # rocprofv3 kernel stats of the f16x3 parity mode on the headline workload
+                (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/proff16" -o run -- python "$OLDPWD/bench.py" --precision f16x3 --steps 3 --warmup 2 --no-cpu-baseline --no-profile --no-extras > "$OLDPWD/$OUT/proff16.log" 2>&1); DB=$(find "$OUT/proff16" -name "*results.db" | head -1); python tools/rocpd_stats.py "$DB" > "$OUT/proff16_stats.md" 2>&1; python tools/rocpd_lastseq.py "$DB" > "$OUT/proff16_lastseq.txt" 2>&1; rm -rf "$OUT/proff16"; head -40 "$OUT/proff16_stats.md" | cut -c1-200 ;;
     prof3)      # rocprofv3 kernel stats of BASELINE config 3 (512 x 512, 50 frames, growing bank)
                 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$OUT/prof3" -o run -- python "$OLDPWD/bench.py" --size 512 --frames 50 --train-policy --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-extras > "$OLDPWD/$OUT/prof3.log" 2>&1); DB=$(find "$OUT/prof3" -name "*results.db" | head -1); python tools/rocpd_stats.py "$DB" > "$OUT/prof3_stats.md" 2>&1; rm -rf "$OUT/prof3"; head -30 "$OUT/prof3_stats.md" | cut -c1-180 ;;
     pmcmemlong) # HBM traffic of the long-bank memory read (50 176 tokens x 1024 queries), launch by launch: FETCH_SIZE / WRITE_SIZE passes
