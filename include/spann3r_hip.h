@@ -115,7 +115,9 @@ typedef struct sp3_gemm_desc {
   int32_t out_packed;     /* plain epilogue: store C in fragment order (it is the next GEMM's packed A; dims M x N) */
   int32_t w_packed;       /* W is in MFMA-fragment order [ceil(N/16)][ceil(K/KB)][2 halves][64 lanes][CH/2], zero padded; KB/CH =
                              64/16 (bf16) or 32/8 (fp32); lane = 16*g + r holds row 16*nb + r, k = kb*KB + g*CH + e: e < CH/2 in the first 1 KB
-                             half of the 2 KB block, the rest in the second (every wave access is one contiguous KB) */
+                             half of the 2 KB block, the rest in the second (every wave access is one contiguous KB).
+                             2 (fp32 W, product mode f16x3 only): same blocks, but a lane's 32 bytes hold the fp16 planes of its 8 k --
+                             first half h = fp16(w), second half l = fp16((w - h) * 2^11), the split the kernel would take per use */
   /* --- grouped launches (batch > 1, grid.y): `batch` independent problems of one shape in one launch, e.g. the two
    *   sides of a DUSt3R decoder layer (different weights, dust3r/model.py:196-198).  A / W / C advance by strideA /
    *   strideW / strideC ELEMENTS per batch index (C in its own dtype, any epilogue, also the packed layouts), res1 /

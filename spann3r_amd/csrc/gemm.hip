@@ -275,11 +275,21 @@ template <> struct MM<float, float> {
       l[e] = (_Float16)((x[e] - (float)hh) * 2048.0f);
     }
   }
-  template <int MF, int NF>
+  // WPRE (sp3_gemm_desc.w_packed == 2): the weight already IS its two fp16 planes -- the first 16-byte half of a lane's fragment holds
+  // h of its 8 k, the second half l (split once at pack time, ops.PackedWeight(halves=True): the same two conversions, so the same
+  // bits) -- and the split of W leaves the K loop (a third of the loop's VALU work on the 32x32 wave tile)
+  template <int MF, int NF, bool WPRE = false>
   static __device__ __forceinline__ void mma_h3(f32x4 (&acc)[MF][NF], f32x4 (&accx)[MF][NF], const AReg (&a)[MF], const WReg (&w)[NF]) {
     f16x8 wh[NF], wl[NF];
 #pragma unroll
-    for (int n = 0; n < NF; ++n) split8h(w[n].v[0], w[n].v[1], wh[n], wl[n]);
+    for (int n = 0; n < NF; ++n) {
+      if constexpr (WPRE) {
+        wh[n] = __builtin_bit_cast(f16x8, w[n].v[0]);
+        wl[n] = __builtin_bit_cast(f16x8, w[n].v[1]);
+      } else {
+        split8h(w[n].v[0], w[n].v[1], wh[n], wl[n]);
+      }
+    }
 #pragma unroll
     for (int m = 0; m < MF; ++m) {
       f16x8 ah, al;
@@ -470,7 +480,8 @@ constexpr int kMaxKb = 64;                 // k-blocks per K slice the role loop
 
 // XM (fp32 operands, register-ring tiles): how a k-block's products are formed -- 0: fp32 MFMAs; 1 / 3: three / six bf16 MFMAs of a
 // two- / three-way split (f32x3 / f32x6); 2: one bf16 MFMA of the rounded operands.  A compile-time choice: as a run-time branch the
-// six-product code cost every mode its second wave per SIMD (187 -> 209 registers).
+// six-product code cost every mode its second wave per SIMD (187 -> 209 registers).  4: three fp16 MFMAs of the two-way split x = h + l 2^-11
+// ("f16x3"); 5: the same with W already split into its (h, l) planes at pack time (w_packed == 2).
 template <typename TA, typename TW, int LOADER, int MF, int NF, int WM, int WN, int WK, int STAGES, int LOOP = 0, int XM = 0>
 __global__ __launch_bounds__(64 * (WM * WN * WK + (LOOP >= 2 ? LOOP : 0)), (gemm_min_waves<TA, LOADER, MF, NF, WK>()))
 void gemm_kernel(const GemmArgs args) {
@@ -559,7 +570,7 @@ void gemm_kernel(const GemmArgs args) {
   }
 
   f32x4 acc[MF][NF];
-  constexpr bool XACC = sizeof(TA) == 4 && sizeof(TW) == 4 && XM == 4;      // f16x3: the cross terms' accumulator
+  constexpr bool XACC = sizeof(TA) == 4 && sizeof(TW) == 4 && (XM == 4 || XM == 5);      // f16x3: the cross terms' accumulator
   f32x4 accx[XACC ? MF : 1][XACC ? NF : 1];
 #pragma unroll
   for (int m = 0; m < MF; ++m)
@@ -677,6 +688,7 @@ void gemm_kernel(const GemmArgs args) {
       if constexpr (XM == 1) M_::template mma_x3<MF, NF>(acc, a[st], w[st]);
       else if constexpr (XM == 2) M_::template mma_x1<MF, NF>(acc, a[st], w[st]);
       else if constexpr (XM == 4) M_::template mma_h3<MF, NF>(acc, accx, a[st], w[st]);
+      else if constexpr (XM == 5) M_::template mma_h3<MF, NF, true>(acc, accx, a[st], w[st]);
       else M_::template mma_x6<MF, NF>(acc, a[st], w[st]);
     } else {
       M_::template mma<MF, NF>(acc, a[st], w[st]);
@@ -1701,6 +1713,7 @@ int dispatch_tile(const sp3_gemm_desc& d, int tile, hipStream_t stream) {
       }
       if (xm == 1) { SP3_XM_TILES(1) }
       if (xm == 2) { SP3_XM_TILES(2) }
+      if (xm == 4 && d.w_packed == 2) { SP3_XM_TILES(5) }
       if (xm == 4) { SP3_XM_TILES(4) }
       SP3_XM_TILES(3)
 #undef SP3_XM_TILES

@@ -100,18 +100,20 @@ class Engine:
     def _pack(self, p):
         cfg, dev, wdt = self.cfg, self.device, self.wdt
         w = self.w
+        # f16x3: every product is three fp16 MFMAs of x = h + l 2^-11; the weights' (h, l) planes are taken ONCE, here (ops.PackedWeight)
+        hv = self.precision == "f16x3"
 
         def mat(t):      # MFMA operand: [N, K] in the compute dtype, re-ordered once into fragment order
-            return ops.PackedWeight(t.detach().to(dev, torch.float32).reshape(t.shape[0], -1).to(wdt).contiguous())
+            return ops.PackedWeight(t.detach().to(dev, torch.float32).reshape(t.shape[0], -1).to(wdt).contiguous(), halves=hv)
 
         def vec(t):      # biases / LN parameters stay fp32
             return t.detach().to(dev, torch.float32).contiguous()
 
         def conv3(t):    # [Cout,Cin,3,3] -> [Cout, (ky,kx,ci)]
-            return ops.PackedWeight(t.detach().to(dev, torch.float32).permute(0, 2, 3, 1).reshape(t.shape[0], -1).to(wdt).contiguous())
+            return ops.PackedWeight(t.detach().to(dev, torch.float32).permute(0, 2, 3, 1).reshape(t.shape[0], -1).to(wdt).contiguous(), halves=hv)
 
         def convt(t):    # ConvTranspose2d [Cin,Cout,k,k] -> [(ky,kx,co), ci]
-            return ops.PackedWeight(t.detach().to(dev, torch.float32).permute(2, 3, 1, 0).reshape(-1, t.shape[0]).to(wdt).contiguous())
+            return ops.PackedWeight(t.detach().to(dev, torch.float32).permute(2, 3, 1, 0).reshape(-1, t.shape[0]).to(wdt).contiguous(), halves=hv)
 
         def fold(dst, weight, bias, norm):
             """LayerNorm folded into the consuming Linear (DESIGN.md "LN fold"): W' = gamma (.) W in the MFMA dtype,
@@ -121,7 +123,7 @@ class Engine:
             g = p[norm + ".weight"].detach().to(dev, torch.float32)
             beta = p[norm + ".bias"].detach().to(dev, torch.float32)
             Wf = (W * g[None, :]).to(wdt)
-            w[dst + ".w"] = ops.PackedWeight(Wf.contiguous())
+            w[dst + ".w"] = ops.PackedWeight(Wf.contiguous(), halves=hv)
             w[dst + ".s"] = Wf.float().sum(1).contiguous()
             w[dst + ".b"] = (bias.detach().to(dev, torch.float32) + W @ beta).contiguous()
 

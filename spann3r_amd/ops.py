@@ -318,7 +318,10 @@ class PackedWeight:
     """A weight matrix [N, K] re-ordered once into MFMA-fragment order (include/spann3r_hip.h: w_packed) so that
     every operand load of the GEMM is a fully coalesced, contiguous wave read."""
 
-    def __init__(self, w2d):
+    def __init__(self, w2d, halves=False):
+        """halves (fp32 weights of an f16x3 engine): every lane's 8 fp32 values of a k-block are stored as their two fp16 planes
+        (h = fp16(w) in the block's first KB, l = fp16((w - h) * 2^11) in the second; same bytes per block) -- the split the f16x3
+        product takes per use, taken once here; the GEMM is told by w_packed = 2 (include/spann3r_hip.h)."""
         N, K = w2d.shape
         self.N, self.K, self.dtype = N, K, w2d.dtype
         KB, CH = (64, 16) if w2d.dtype == torch.bfloat16 else (32, 8)
@@ -327,12 +330,18 @@ class PackedWeight:
         pad[:N, :K] = w2d
         # [nb, r, kb, g, h, e] -> [nb, kb, h, g, r, e]
         self.data = pad.view(nb, 16, nkb, 4, 2, CH // 2).permute(0, 2, 4, 3, 1, 5).contiguous()
+        self.halves = bool(halves) and w2d.dtype == torch.float32
+        if self.halves:
+            x8 = self.data.permute(0, 1, 3, 4, 2, 5).reshape(nb, nkb, 4, 16, 8)                   # [.., g, r, the lane's 8 k]
+            hi = x8.to(torch.float16)
+            lo = ((x8 - hi.float()) * 2048.0).to(torch.float16)
+            self.data = torch.stack([hi, lo], dim=2).contiguous().view(torch.float32).view(nb, nkb, 2, 4, 16, 4)
 
     @classmethod
     def wrap(cls, data, N, K):
         """a fragment-order [N, K] operand that already lives in `data` (e.g. a spatial-memory bank written by sp3_bank_write)"""
         w = object.__new__(cls)
-        w.N, w.K, w.dtype, w.data = N, K, data.dtype, data
+        w.N, w.K, w.dtype, w.data, w.halves = N, K, data.dtype, data, False
         return w
 
     def data_ptr(self):
@@ -347,6 +356,8 @@ class PackedWeightGroup(PackedWeight):
 
     def __init__(self, items):
         self.N, self.K, self.dtype = items[0].N, items[0].K, items[0].dtype
+        self.halves = items[0].halves
+        assert all(w.halves == self.halves for w in items)
         self.data = torch.stack([w.data for w in items]).contiguous()
         self.stride = items[0].data.numel()
 
@@ -396,9 +407,11 @@ class product_mode:
 def _w(d, W):
     """fills the W fields of a GemmDesc from a tensor or a PackedWeight"""
     d.W = W.data_ptr()
-    d.w_packed = int(isinstance(W, PackedWeight))
+    d.w_packed = (2 if getattr(W, "halves", False) else 1) if isinstance(W, PackedWeight) else 0
     d.wdtype = wdtype_of(W)
     d.f32x3 = get_product_mode() if d.wdtype == F32 else 0
+    if d.w_packed == 2 and d.f32x3 != PRODUCT_MODES["f16x3"]:
+        raise ValueError("a PackedWeight(halves=True) holds fp16 planes: only the f16x3 product mode reads it (mode %d is active)" % d.f32x3)
 
 
 class LnFold:

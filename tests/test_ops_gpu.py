@@ -906,6 +906,40 @@ def test_attention_and_gemm_f16x3():
     assert ea < 3e-6 and max(eg) < 3e-6, (ea, eg)
 
 
+def test_gemm_f16x3_presplit_weights_same_bits():
+    """ops.PackedWeight(halves=True) (the weights of an f16x3 engine: the (h, l) fp16 planes taken once at pack time, w_packed = 2) against
+    the same fragment-order fp32 weight split inside the K loop (w_packed = 1): the same two conversions, so the SAME BITS -- on every
+    register-ring tile, with a K that is not a whole k-block, and through the 3x3 convolution loader; any other product mode refuses
+    the planes."""
+    ops = _ops()
+    ops.set_product_mode("f16x3")
+    try:
+        for (M, N, K) in ((196, 768, 1024), (100, 200, 168)):
+            A, W, b = rnd(M, K, seed=1).to(DEV), (rnd(N, K, seed=2) * 0.05).to(DEV), rnd(N, seed=3).to(DEV)
+            W[0, :8] = torch.tensor([0.0, 1e-9, -3e-6, 6.1e-5, 1.0, -1000.0, 3.0e4, 1e-3], device=DEV)     # zeros, fp16 subnormals, large values
+            gref = A.double().cpu() @ W.double().cpu().T + b.double().cpu()
+            w1, w2 = ops.PackedWeight(W), ops.PackedWeight(W, halves=True)
+            assert not w1.halves and w2.halves and w1.data.shape == w2.data.shape and w1.data.dtype == w2.data.dtype
+            for tile in (0, 1, 2):
+                o1, o2 = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+                ops.gemm(A, w1, o1, M=M, N=N, K=K, lda=K, ldc=N, bias=b, tile=tile)
+                ops.gemm(A, w2, o2, M=M, N=N, K=K, lda=K, ldc=N, bias=b, tile=tile)
+                assert torch.equal(o1, o2), (M, N, K, tile)
+                assert rel_err(o2.cpu(), gref) < 3e-6
+        B, H, Wd, Cin, Cout = 1, 12, 10, 64, 32
+        x, wc, bc = rnd(B, H, Wd, Cin, seed=4).to(DEV), (rnd(Cout, 3, 3, Cin, seed=5) * 0.05).to(DEV), rnd(Cout, seed=6).to(DEV)
+        c1, c2 = torch.empty(B, H, Wd, Cout, device=DEV), torch.empty(B, H, Wd, Cout, device=DEV)
+        ops.conv3x3(x, ops.PackedWeight(wc.reshape(Cout, -1).contiguous()), c1, B=B, H=H, W_=Wd, Cin=Cin, Cout=Cout, bias=bc, splitk_ws=torch.empty(1 << 21, device=DEV))
+        ops.conv3x3(x, ops.PackedWeight(wc.reshape(Cout, -1).contiguous(), halves=True), c2, B=B, H=H, W_=Wd, Cin=Cin, Cout=Cout, bias=bc, splitk_ws=torch.empty(1 << 21, device=DEV))
+        assert torch.equal(c1, c2)
+        ref = F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), wc.permute(0, 3, 1, 2).double().cpu(), bc.double().cpu(), padding=1).permute(0, 2, 3, 1)
+        assert rel_err(c2.cpu(), ref) < 3e-6
+    finally:
+        ops.set_product_mode("fp32")
+    with pytest.raises(ValueError):
+        ops.gemm(A, w2, o2, M=M, N=N, K=K, lda=K, ldc=N, bias=b)            # fp32 products on fp16 planes: refused
+
+
 def test_gemm_f32x3_products():
     """fp32 operands through three bf16 MFMAs per k-block (sp3_gemm_desc.f32x3): ~16 mantissa bits per product, fp32 accumulate"""
     ops = _ops()
