@@ -1896,6 +1896,10 @@ static int gemm_prepare(sp3_gemm_desc& d, int& tile_out) {
       tile = 0;
     } else if (d.loader != SP3_LOAD_CONV3X3 && d.M >= 1024) {
       tile = 1;                                           // many rows, narrow N (also split-K partials): 64x64 register tiles
+      // fp32 operands (the fp32 / f32x6 / f16x3 modes' whole-sequence encoder): the register-ring tiles are bound by L2 -> CU bytes,
+      // the 64 x 128 tile moves a quarter fewer per product -- wide N only (f16x3 at 1960 rows: q/k/v 85.5 -> 72.4 us, fc1 113.5 ->
+      // 86.4; N = 1024 leaves 248 workgroups and loses: 102.8 -> 122.4 us; profiles/r06_f16x3_manyrow_tiles.txt)
+      if (d.wdtype == SP3_F32 && !d.a_bf16 && sk == 1 && d.epi != SP3_EPI_PARTIAL && d.N % 128 == 0 && t128 >= 512) tile = 2;
     } else if (lds_ok && d.M <= 224 && d.M > 112 && d.epi == SP3_EPI_PLAIN && d.N >= 3072 && d.K <= 1024 &&
                (!d.ln_stats || d.ln_nt <= 32)) {
       // the widest 196-row GEMMs (fc1 of the decoder pair and of the value encoder): 112x64 role tile -- consumers keep

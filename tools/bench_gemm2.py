@@ -19,9 +19,13 @@ ap.add_argument("--only", default="", help="comma list of op names")
 ap.add_argument("--tiles", default="")
 ap.add_argument("--mb", type=int, default=320, help="MB of distinct weight copies to cycle through")
 ap.add_argument("--train", action="store_true", help="the training step's Linear shapes at batch 4 (784 rows; dW: contraction over the rows), fp32 row-major output")
+ap.add_argument("--mode", default="", help="product mode of fp32 operands (f16x3, f32x3, f32x6): with --dtype fp32")
+ap.add_argument("--halves", action="store_true", help="f16x3: weights as their (h, l) fp16 planes (PackedWeight(halves=True))")
 ap.add_argument("--ksweep", action="store_true", help="one many-row shape at several K: fixed cost vs cost per k-block")
 args = ap.parse_args()
 dev = "cuda"
+if args.mode:
+    ops.set_product_mode(args.mode)
 DT = torch.bfloat16 if args.dtype == "bf16" else torch.float32
 ES = 2 if args.dtype == "bf16" else 4
 
@@ -55,7 +59,8 @@ if args.big:
               ("c3 dec fc2", 1024, 768, 3072, 2), ("c3 dec proj", 1024, 768, 768, 2), ("c3 val fc1", 1024, 4096, 1024, 1),
               ("c3 val proj", 1024, 1024, 1024, 1), ("c3 val fc2", 1024, 1024, 4096, 1), ("c3 key 2", 1024, 1024, 1792, 2)]
     shapes += [("enc16 qkv", 16384, 3072, 1024, 1), ("enc16 fc2", 16384, 1024, 4096, 1), ("read S", 1024, 50176, 1024, 1),
-               ("read PV", 1024, 1024, 50176, 1), ("train fc1", 784, 4096, 1024, 1), ("train dec", 784, 768, 3072, 2)]
+               ("read PV", 1024, 1024, 50176, 1), ("train fc1", 784, 4096, 1024, 1), ("train dec", 784, 768, 3072, 2),
+               ("sq4k", 4096, 4096, 4096, 1), ("sq8k", 8192, 4096, 4096, 1), ("enc16 fc1", 16384, 4096, 1024, 1)]
     tiles = [1, 5, 6, 20, 21, 22, 23]
 else:
     M = args.M
@@ -84,7 +89,7 @@ for name, M, N, K, G in shapes:
     ncopy = max(1, min(64, args.mb * (1 << 20) // wbytes))
     Ws = []
     for c in range(ncopy):
-        ws = [ops.PackedWeight((torch.randn(N, K, device=dev) * 0.05).to(DT)) for _ in range(G)]
+        ws = [ops.PackedWeight((torch.randn(N, K, device=dev) * 0.05).to(DT), halves=args.halves) for _ in range(G)]
         Ws.append(ops.PackedWeightGroup(ws) if G > 1 else ws[0])
     if G > 1:
         A = ops.PackedAct.group(G, M, K, DT, dev)
