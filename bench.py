@@ -357,7 +357,7 @@ def synth_training_batch(seq_id, n_frames, size, batch, dev):
     return frames, gts
 
 
-def train_measure(dev, steps, warmup, precision, batch, n_frames=5, size=224, world=1):
+def train_measure(dev, steps, warmup, precision, batch, n_frames=5, size=224, world=1, force_collectives=False):
     """seconds per training step of the full model on this rank (forward + ConfLoss + backward incl. bucket all-reduces + clip + AdamW)"""
     import torch
     import torch.distributed as dist
@@ -368,7 +368,9 @@ def train_measure(dev, steps, warmup, precision, batch, n_frames=5, size=224, wo
     model.load_state_dict(synth_state_dict(0, FULL), strict=True)
     model = model.to(dev)
     # one execution mode at every world size: the step (bucket all-reduces included) is captured into a hipGraph and replayed
-    ts = T.TrainStep(model, precision=precision, graph=True)
+    # force_collectives (world 1 only): the bucket all-reduces are issued on a one-rank RCCL group, i.e. the launches, their order and
+    # their place inside backward are those of an N-rank job; the data each moves is its own bucket
+    ts = T.TrainStep(model, precision=precision, graph=True, force_collectives=force_collectives)
     rank = int(os.environ.get("RANK", "0"))
     frames, gts = synth_training_batch(rank, n_frames, size, batch, dev)
     torch.cuda.reset_peak_memory_stats()
@@ -723,6 +725,24 @@ def _main(args, real_stdout):
         torch.cuda.empty_cache()
         print("bench.py: extras: training step", file=sys.stderr, flush=True)
         out["train"] = train_measure(dev, 3, 2, "bf16", 4)
+        # the same step with the data-parallel machinery live on ONE rank: RCCL group of size 1, every gradient bucket all-reduced from
+        # inside backward and captured into the step's hipGraph (what each of the 8 ranks of BASELINE config 5 executes)
+        try:
+            own_group = not dist.is_initialized()
+            if own_group:
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29543")
+                os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+                dist.init_process_group(backend="nccl", rank=0, world_size=1)
+            trf = train_measure(dev, 3, 2, "bf16", 4, force_collectives=True)
+            out["train"]["rccl_world1"] = {k: trf[k] for k in ("seconds_per_step", "frames_per_s", "buckets", "buckets_reduced_inside_backward",
+                                                                "hip_graph", "collectives_in_graph", "loss", "grad_norm")}
+            out["train"]["rccl_world1"]["what"] = ("the same step with its gradient buckets all-reduced over a ONE-rank RCCL group from inside backward "
+                                                   "(TrainStep(force_collectives=True)): the launch sequence of a rank of the 8-GPU job")
+            if own_group:
+                dist.destroy_process_group()
+        except Exception as e:       # the extra must never cost the line
+            out["train"]["rccl_world1"] = {"error": repr(e)[:300]}
 
     # ---- CPU baseline: the oracle (port of the reference algorithm) on this box's host cores, bounded sample
     if world == 1 and not args.no_cpu_baseline:
