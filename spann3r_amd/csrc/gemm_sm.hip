@@ -46,6 +46,7 @@ struct SmArgs {
   SmOp op[2];                       // op[1]: second group of problems of a paired launch (blockIdx.z >= z1)
   const float* cos; const float* sin; const int* pos;
   int M, rb_max, z1;
+  int mblk;                         // bm_kernel default map: 1 = blocks of 8 M-tiles x all z-slots in the XCD's dispatch order, see bm_kernel
   int xm;                           // bm_kernel: 1 = M-tiles across the XCDs (grid = (8, N-tiles x groups, ceil(M-tiles / 8))), see bm_kernel
   int tokens, heads, vt_ld;
   unsigned tok_magic;               // floor(2^32 / tokens) + 1: gm / tokens by one multiply-high (gm < 65536)
@@ -426,20 +427,38 @@ __global__ __launch_bounds__(64 * WM * WN) void bm_kernel(const SmArgs a) {
   // default map, the activation panel once per XCD).
   int tile_m, tile_n, grp;
   if (EPI != SM_ROPE && a.xm) {
-    const int nt = OPF(nt), y = blockIdx.y;
+    const int nt = OPF(nt);
+    int y = blockIdx.y, zm = blockIdx.z;
+    if (a.xm == 2) {
+      // many M-tiles AND many N-tiles (the 512 x 512 whole-sequence encoder: 64 x 32 tiles of 256 x 128): the 32 workgroups an XCD runs
+      // at a time were the 32 N-tiles of ONE M-tile -- the whole W (8 MB at N = 4096, twice the L2) re-streamed per M-tile.  Blocks of
+      // 4 M-tiles x 8 N-tiles instead (workgroup l = y + NT z of the XCD's dispatch order -> block l / 32): 2 MB of A + 2 MB of W
+      // resident, 4 MB fetched per 32 tiles instead of 8.5.  Host: NT % 8 == 0 and gridDim.z % 4 == 0.
+      const int NT = gridDim.y, l = y + NT * zm, b = l >> 5, r = l & 31, nb8 = NT >> 3;
+      y = (b % nb8) * 8 + (r & 7);
+      zm = (b / nb8) * 4 + (r >> 3);
+    }
     grp = y >= nt ? 1 : 0;
     tile_n = y - grp * nt;
-    tile_m = blockIdx.z * 8 + blockIdx.x;
+    tile_m = zm * 8 + blockIdx.x;
     if (tile_m * BM >= a.M) return;
   } else {
     // the (problem, N-tile) pairs of an op are numbered through (problem 0's tiles, then problem 1's) and dealt to the XCDs round robin:
     // pair p = 8 z + x.  (Per-problem z-slots left the XCDs 0 .. nt % 8 - 1 with one more N-tile PER PROBLEM: at N = 2304 / 1536 / 768 --
     // 18 / 12 / 12 tiles -- two XCDs ran 40 workgroups of a q/k/v + cross-k/v pair on their 32 CUs while four ran 24.)
-    const int z = (int)blockIdx.z - (second ? a.z1 : 0);
+    int z = (int)blockIdx.z - (second ? a.z1 : 0);
+    tile_m = blockIdx.y;
+    if (a.mblk) {
+      // one op, >= 16 M-tiles, <= 4 z-slots (the 512 x 512 whole-sequence encoder's q/k/v: 64 M-tiles x 3 slots per XCD): the XCD's
+      // workgroups in flight were 32 M-tiles of ONE N-tile, every A tile (512 KB) fetched again per N-tile.  Blocks of 8 M-tiles x all
+      // its z-slots instead: an A tile is fetched once per XCD.  Host: gridDim.y % 8 == 0.
+      const int nz = gridDim.z, l = tile_m + (int)gridDim.y * z, per = 8 * nz, b = l / per, r = l - b * per;
+      tile_m = b * 8 + (r & 7);
+      z = r >> 3;
+    }
     const int nt = OPF(nt), p = z * 8 + (int)blockIdx.x;
     if (p >= nt * OPF(ngrp)) return;
     grp = p >= nt ? 1 : 0;
-    tile_m = blockIdx.y;
     tile_n = p - grp * nt;
   }
   int N = OPF(N);
@@ -1687,6 +1706,15 @@ int sp3_gemm_sm_launch(const sp3_gemm_desc& d, const sp3_gemm_desc* pair, hipStr
   a.cos = d.rope_cos; a.sin = d.rope_sin; a.pos = d.pos;
   a.M = d.M;
   a.xm = (s->bm && s->epi != SM_ROPE && !pair && d.M > d.N) ? 1 : 0;     // more rows than columns: the activation panel is the larger operand
+  if (a.xm) {
+    const int NT = a.op[0].nt * a.op[0].ngrp, mt_ = (d.M + s->tile_m() - 1) / s->tile_m(), nzm = (mt_ + 7) / 8;
+    if (NT % 8 == 0 && NT > 8 && nzm % 4 == 0) a.xm = 2;                 // (N-tiles, M-tile slots) blocks of 8 x 4 per XCD, see bm_kernel
+  }
+  a.mblk = 0;
+  if (s->bm && !a.xm && !pair) {
+    const int mt_ = (d.M + s->tile_m() - 1) / s->tile_m();
+    if (mt_ >= 16 && mt_ % 8 == 0 && nz >= 2 && nz <= 4) a.mblk = 1;
+  }
   a.rb_max = (d.M + 15) / 16 - 1;
   a.tokens = d.tokens > 0 ? d.tokens : 1;
   a.heads = d.heads;

@@ -532,6 +532,36 @@ def test_xcd_maps_are_bijections():
                 seen.add((grp, tile_n))
                 per_xcd[x] += 1
         assert len(seen) == nt * G and max(per_xcd) - min(per_xcd) <= 1
+    # round 6, many M-tiles (the 512 x 512 whole-sequence encoder).  xm = 2: grid (8, NT, nzm), workgroup l = y + NT zm of an XCD's
+    # dispatch order -> blocks of 8 N-tiles x 4 M-tile slots (NT % 8 == 0, nzm % 4 == 0): every (N-tile, slot) once, and each run of 32
+    # consecutive workgroups of an XCD shares 4 A tiles and 8 W panels
+    for NT, nzm in ((32, 8), (24, 8), (16, 4), (32, 12)):
+        seen = {}
+        for zm in range(nzm):
+            for y in range(NT):
+                l = y + NT * zm
+                b, r, nb8 = l >> 5, l & 31, NT >> 3
+                yy, zz = (b % nb8) * 8 + (r & 7), (b // nb8) * 4 + (r >> 3)
+                assert (yy, zz) not in seen and 0 <= yy < NT and 0 <= zz < nzm
+                seen[(yy, zz)] = l
+        assert len(seen) == NT * nzm
+        inv = sorted(seen.items(), key=lambda kv: kv[1])
+        for b0 in range(0, NT * nzm, 32):
+            blk = [k for k, _ in inv[b0:b0 + 32]]
+            assert len({y for y, _ in blk}) == 8 and len({z for _, z in blk}) == 4
+    # mblk: grid (8, mt, nz), l = tile_m + mt z -> blocks of 8 M-tiles x all nz z-slots (mt % 8 == 0, 2 <= nz <= 4)
+    for mt, nz in ((64, 3), (64, 4), (16, 2), (24, 3)):
+        seen = set()
+        for z in range(nz):
+            for y in range(mt):
+                l = y + mt * z
+                per = 8 * nz
+                b = l // per
+                r = l - b * per
+                tm, zz = b * 8 + (r & 7), r >> 3
+                assert (tm, zz) not in seen and 0 <= tm < mt and 0 <= zz < nz
+                seen.add((tm, zz))
+        assert len(seen) == mt * nz
 
 
 def test_bench_kernel_symbols():

@@ -131,7 +131,10 @@ def test_lean_stream(M, N, K, G, res, stats, ln):
 
 
 @pytest.mark.parametrize("M,N,K,G,act", [(196, 4096, 1024, 1, "gelu"), (196, 3072, 768, 2, "gelu"), (196, 3072, 768, 1, "none"), (60, 4096, 1024, 1, "gelu"),
-                                         (1960, 4096, 1024, 1, "gelu"), (1024, 4096, 1024, 1, "gelu"), (1024, 3072, 768, 2, "gelu"), (500, 3072, 768, 1, "none")])
+                                         (1960, 4096, 1024, 1, "gelu"), (1024, 4096, 1024, 1, "gelu"), (1024, 3072, 768, 2, "gelu"), (500, 3072, 768, 1, "none"),
+                                         # >= 16 M-tiles of 256 rows (the 512 x 512 whole-sequence encoder): the blocked tile maps of bm_kernel
+                                         (4096, 4096, 1024, 1, "gelu"),      # M <= N: 8 M-tiles x all z-slots per block (mblk)
+                                         (8192, 2048, 1024, 1, "gelu")])     # M > N: 8 N-tiles x 4 M-tile slots per block (xm = 2)
 def test_lean_packed_fc1(M, N, K, G, act):
     """norm (folded) + fc1 + GELU into fragment order (croco/models/blocks.py:74-75,129)"""
     ops = _ops()
@@ -176,7 +179,8 @@ def _pos(B, nh, nw):
 @pytest.mark.parametrize("B,nh,nw,C,heads,kind", [(1, 14, 14, 1024, 16, "qkv"), (1, 14, 14, 768, 12, "qkv"), (1, 14, 14, 768, 12, "q"),
                                                    (2, 10, 10, 768, 12, "qkv"), (2, 8, 12, 1024, 16, "kv"),
                                                    (10, 14, 14, 1024, 16, "qkv"), (1, 32, 32, 1024, 16, "qkv"), (1, 32, 32, 768, 12, "qkv"),
-                                                   (1, 32, 32, 768, 12, "kv"), (1, 32, 32, 768, 12, "q"), (3, 14, 14, 768, 12, "qkv")])
+                                                   (1, 32, 32, 768, 12, "kv"), (1, 32, 32, 768, 12, "q"), (3, 14, 14, 768, 12, "qkv"),
+                                                   (4, 32, 32, 1024, 16, "qkv")])          # 16 M-tiles x 3 z-slots: bm_kernel's blocked map (mblk)
 def test_lean_rope_vt(B, nh, nw, C, heads, kind):
     """q/k/v projection with folded LayerNorm, bias, 2-D RoPE and the attention kernel's layouts: lean instance vs general kernel"""
     from spann3r_amd.engine import _rope_tables
