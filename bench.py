@@ -543,12 +543,19 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     # stdout carries exactly ONE line, the JSON record: anything the model prints on the way (the reference-style
-    # "Similarity detected" / "Memory pruned" notes of the memory policy) goes to stderr
-    real_stdout, sys.stdout = sys.stdout, sys.stderr
+    # "Similarity detected" / "Memory pruned" notes of the memory policy) goes to stderr -- and so does everything native code writes to
+    # file descriptor 1 (RCCL prints its version banner through C stdio when its first communicator comes up; buffered, it would land
+    # BEHIND the JSON line at exit): descriptor 1 points at stderr for the rest of the process, the record goes to a duplicate of the
+    # original descriptor
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    py_stdout, sys.stdout = sys.stdout, sys.stderr
     try:
         _main(args, real_stdout)
     finally:
-        sys.stdout = real_stdout
+        real_stdout.flush()
+        sys.stdout = py_stdout
 
 
 def _main(args, real_stdout):

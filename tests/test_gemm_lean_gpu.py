@@ -427,7 +427,8 @@ def test_bank_write_and_similarity_window_from_device_state(wdt):
         assert torch.equal(s1, s2) and float(s2[wm:].min() if wm < Tmax else 7.0) == 7.0      # entries past wm untouched
 
 
-@pytest.mark.parametrize("rows,M,S_k", [(320, 2240, 8), (1024, 4096, 8), (300, 2244, 16), (257, 640, 8)])
+@pytest.mark.parametrize("rows,M,S_k", [(320, 2240, 8), (1024, 4096, 8), (300, 2244, 16), (257, 640, 8),
+                                        (1024, 12292, 8)])      # 4 x 97 score tiles (more than one round of workgroups), ragged last tile
 def test_long_bank_read_without_a_score_matrix(rows, M, S_k):
     """The long-bank memory read of a > 256-row frame (spann3r/model.py:159-183 at attn_thresh = 0) as: score stage that writes
     bf16 p~ = exp(s - group max) + (max, sum) per 64-key group (tile 45), sp3_prob_merge, P.V stage with the groups' rescale in its loop
