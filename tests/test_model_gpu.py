@@ -984,8 +984,10 @@ def test_bench_self_spawn_one_rank_through_rccl(capsys):
     finally:
         os.environ.pop("SP3_FORCE_DIST", None)
     assert rc == 0
-    line = [l for l in capsys.readouterr().out.splitlines() if l.startswith("{")][-1]
-    out = json.loads(line)
+    lines = [l for l in capsys.readouterr().out.splitlines() if l.strip()]
+    # the record is the ONLY thing on stdout: RCCL's version banner (C stdio, flushed at exit) used to land behind it
+    assert len(lines) == 1 and lines[0].startswith("{"), lines
+    out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and out["rccl_ranks"] == 1 and out["value"] > 0 and len(out["per_rank_seconds"]) == 1
     assert bench.spawn_ranks(torch.cuda.device_count() + 1, _bench_argv(torch.cuda.device_count() + 1)) != 0     # never a smaller job
 
