@@ -426,7 +426,7 @@ __global__ __launch_bounds__(64 * WM * WN) void bm_kernel(const SmArgs a) {
   // owns the M-tiles {x, x + 8, ..} of every N-tile -- 1/8 of A and all of W (PMC: 158 MB -> fetched per fc2 launch with the
   // default map, the activation panel once per XCD).
   int tile_m, tile_n, grp;
-  if (EPI != SM_ROPE && a.xm) {
+  if (a.xm) {
     const int nt = OPF(nt);
     int y = blockIdx.y, zm = blockIdx.z;
     if (a.xm == 2) {
@@ -1705,8 +1705,9 @@ int sp3_gemm_sm_launch(const sp3_gemm_desc& d, const sp3_gemm_desc* pair, hipStr
   }
   a.cos = d.rope_cos; a.sin = d.rope_sin; a.pos = d.pos;
   a.M = d.M;
-  a.xm = (s->bm && s->epi != SM_ROPE && !pair && d.M > d.N) ? 1 : 0;     // more rows than columns: the activation panel is the larger operand
+  a.xm = (s->bm && !pair && d.M > d.N) ? 1 : 0;     // more rows than columns: the activation panel is the larger operand
   if (a.xm) {
+    a.z1 = 1 << 30;                                  // (one op: no workgroup belongs to a second group, whatever its blockIdx.z)
     const int NT = a.op[0].nt * a.op[0].ngrp, mt_ = (d.M + s->tile_m() - 1) / s->tile_m(), nzm = (mt_ + 7) / 8;
     if (NT % 8 == 0 && NT > 8 && nzm % 4 == 0) a.xm = 2;                 // (N-tiles, M-tile slots) blocks of 8 x 4 per XCD, see bm_kernel
   }

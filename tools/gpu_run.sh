@@ -12,6 +12,7 @@
 #   pmcbench  rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the bench (then tools/pmc_traffic_json.py)
 #   prof3     rocprofv3 kernel stats of config 3 (512 x 512, 50 frames)  pmcmemlong FETCH / WRITE of the long-bank memory read
 #   pmcattn   SQ / LDS / TA counters of tools/ubench/attn_qb.bin (long-sequence attention and its candidate variants)
+#   pmcmanyrow SQ / MFMA-busy / FETCH / WRITE counters of the many-row lean GEMMs at 8192 / 16384 rows (tools/bench_manyrow.py)
 set -u
 cd "$(dirname "$0")/.."
 TAG=$1; shift
@@ -34,6 +35,9 @@ for stage in "$@"; do
     pmcattn)    # SQ / LDS / TA counters of the packed attention at long sequences (product kernel, QB variants, v2): what the launch waits for
                 for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS" "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" "TA_BUSY_avr TA_TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum TCC_HIT_sum TCC_MISS_sum" ; do
                   n=$(echo $C | cut -d" " -f1); (cd /tmp && timeout 200 rocprofv3 --pmc $C -d "$OLDPWD/$OUT/pmca_$n" -o run --output-format csv -- "$OLDPWD/tools/ubench/attn_qb.bin" > "$OLDPWD/$OUT/pmca_$n.log" 2>&1); F=$(find "$OUT/pmca_$n" -name "*counter_collection.csv" | head -1); python tools/pmc_csv.py "$F" attention > "$OUT/pmca_$n.txt" 2>&1; cp "$F" "$OUT/pmca_$n.csv"; rm -rf "$OUT/pmca_$n"; cat "$OUT/pmca_$n.txt" | cut -c1-220; done ;;
+    pmcmanyrow) # SQ counters of the many-row lean GEMMs at 8192 / 16384 rows (tools/bench_manyrow.py): MFMA pipe busy next to wave / issue-stall cycles
+                for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
+                  n=$(echo $C | cut -d" " -f1); (cd /tmp && timeout 300 rocprofv3 --pmc $C -d "$OLDPWD/$OUT/pmcr_$n" -o run --output-format csv -- python "$OLDPWD/tools/bench_manyrow.py" --rows 16384,8192 > "$OLDPWD/$OUT/pmcr_$n.log" 2>&1); F=$(find "$OUT/pmcr_$n" -name "*counter_collection.csv" | head -1); python tools/pmc_csv.py "$F" bm_kernel > "$OUT/pmcmanyrow_$n.txt" 2>&1; rm -rf "$OUT/pmcr_$n"; cat "$OUT/pmcmanyrow_$n.txt" | cut -c1-160 | head -60; done ;;
     tracegemm)  for t in 20 22; do for a in gelu noact; do timeout 120 python tools/trace_gemm.py $t $a >> "$OUT/tracegemm.txt" 2>&1; done; done; cat "$OUT/tracegemm.txt" ;;
     bench)      timeout 900 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; head -c 1500 "$OUT/bench.json"; tail -3 "$OUT/bench.err" ;;
     benchfast)  timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > "$OUT/benchfast.json" 2> "$OUT/benchfast.err"; head -c 1200 "$OUT/benchfast.json"; tail -3 "$OUT/benchfast.err" ;;
