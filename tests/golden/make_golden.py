@@ -884,3 +884,15 @@ if __name__ == "__main__":
         # BASELINE config 3 at its benched length: 50 frames, bank up to 49152 tokens at the last read (split-K 16 plan);
         # frames / steps around T = 24 and T = 48 and the final state are kept
         make_sequence_fixture("spann3r_cfg3_512x50", 512, 512, 50, True, 8, keep={0, 23, 24, 25, 46, 47, 48, 49})
+    if "demo160" in what:
+        # what demo.py feeds for 4:3 photos (load_images(size=224): long side 224, short side a multiple of 16): 160 x 224 = 10 x 14 = 140
+        # tokens per frame -- fewer rows than the square benchmark geometry, a token count that is no multiple of 16; eval policy
+        make_sequence_fixture("spann3r_demo_160x224x6", 160, 224, 6, False, 4)
+    if "mid288" in what:
+        # a 16:9 geometry between the two benched ones: 288 x 512 = 18 x 32 = 576 tokens per frame (the 257..1535-row instances of the
+        # many-row families and the > 256-row memory read in the FULL model, which neither 196 nor 1024 tokens reach); growing bank
+        make_sequence_fixture("spann3r_mid_288x512x5", 288, 512, 5, True, 8)
+    if "portrait224" in what:
+        # the same 140-token geometry held upright (224 x 160): the FULL model through the landscape_only transposition of the heads
+        # (dust3r/utils/misc.py:79-80) and the axis-swapped pointmap the value encoder sees; eval policy
+        make_sequence_fixture("spann3r_portrait_224x160x4", 224, 160, 4, False, 4)

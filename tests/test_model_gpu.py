@@ -830,6 +830,27 @@ def test_cfg3_512x50_vs_reference(full_sd, precision, tol):
     assert max(err.values()) < tol, err
 
 
+@pytest.mark.parametrize("fixture", ["spann3r_demo_160x224x6.npz", "spann3r_mid_288x512x5.npz", "spann3r_portrait_224x160x4.npz"])
+@pytest.mark.parametrize("precision,tol", [("fp32", TOL_FP32), ("f16x3", 2e-4), ("bf16", TOL_BF16)])
+def test_other_geometries_vs_reference(full_sd, fixture, precision, tol):
+    """Two geometries between / below the benched ones, FULL model against dumps of the unmodified reference (make_golden.py demo160 /
+    mid288): 160 x 224 = 140 tokens per frame (what demo.py's load_images(size=224) makes of a 4:3 photo: fewer rows than any benched
+    launch, a token count that is no multiple of 16; eval policy with its similarity gate) and 288 x 512 = 576 tokens (the 257..1535-row
+    instances of the many-row families and the > 256-row memory read, which neither 196 nor 1024 tokens reach; growing bank); and the
+    140-token geometry held upright (224 x 160: the landscape_only transposition of the heads and the axis-swapped pointmap in front of
+    the value encoder, in the FULL model)."""
+    import os
+    if not os.path.exists(os.path.join(os.path.dirname(__file__), "golden", fixture)):
+        pytest.skip("fixture not generated (tests/golden/make_golden.py demo160 mid288 portrait224)")
+    err = _run_sequence_fixture(fixture, full_sd, precision)
+    ppmax = err.pop("pts_ppmax")
+    if precision == "bf16":
+        err.pop("pts_pp999")
+    else:
+        assert ppmax < 5 * tol, (ppmax, err)
+    assert max(err.values()) < tol, err
+
+
 @pytest.mark.parametrize("precision,tol", [("fp32", 5e-4), ("f32x6", 5e-4), ("f16x3", 5e-4), ("f32x3", 4e-3), ("bf16", None)])
 def test_stress_weights_224x6_vs_reference(precision, tol):
     """The parity claim of the fast fp32 modes on TRAINED-LIKE statistics (spann3r_amd.weights.stress_state_dict: per-channel weight
