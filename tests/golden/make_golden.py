@@ -261,7 +261,7 @@ def make_full():
     print("full224: %d arrays" % len(out))
 
 
-def make_sequence_fixture(name, H, W, NF, train_policy, S, keep=None, stress=False):
+def make_sequence_fixture(name, H, W, NF, train_policy, S, keep=None, stress=False, batch=1):
     """A whole benched configuration: outputs subsampled by S pixels, token tensors by (7, 16)."""
     cfg = FULL
     sd = synth_state_dict(0, cfg)
@@ -271,12 +271,12 @@ def make_sequence_fixture(name, H, W, NF, train_policy, S, keep=None, stress=Fal
     if train_policy:                      # growing bank, deterministic
         m.train()
         m.mem_dropout.eval()
-    frames = synth_frames(NF, H, W)
+    frames = synth_frames(NF, H, W, batch=batch)
     t = time.time()
     preds, preds_all, sp, steps = run_with_taps(m, frames)
     dt = time.time() - t
     print("%s: reference forward %.2f s (%.2f frames/s, %d threads)" % (name, dt, NF / dt, torch.get_num_threads()))
-    out = {"meta_hw": np.array([H, W]), "meta_frames": np.array(NF), "meta_seed": np.array(0), "meta_sub": np.array(S),
+    out = {"meta_hw": np.array([H, W]), "meta_frames": np.array(NF), "meta_seed": np.array(0), "meta_sub": np.array(S), "meta_batch": np.array(batch),
            "meta_train_policy": np.array(int(train_policy)), "fingerprint": np.array(state_dict_fingerprint(sd)),
            "ref_seconds": np.array(dt), "ref_threads": np.array(torch.get_num_threads())}
     if keep is not None:                  # long sequences: only the listed frames / steps are dumped (keeps the file small)
@@ -896,3 +896,7 @@ if __name__ == "__main__":
         # the same 140-token geometry held upright (224 x 160): the FULL model through the landscape_only transposition of the heads
         # (dust3r/utils/misc.py:79-80) and the axis-swapped pointmap the value encoder sees; eval policy
         make_sequence_fixture("spann3r_portrait_224x160x4", 224, 160, 4, False, 4)
+    if "batch4" in what:
+        # the bench line's `batch4` workload through the reference: four sequences per call (784 rows per launch: the many-row instances
+        # of the 224 x 224 step, per-sample banks, ONE similarity decision for the whole batch, spann3r/model.py:113-117); eval policy
+        make_sequence_fixture("spann3r_b4_224x5", 224, 224, 5, False, 4, batch=4)

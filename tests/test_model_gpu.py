@@ -680,7 +680,7 @@ def _run_sequence_fixture(name, full_sd, precision, switches_off=(), warm_calls=
     if bool(g["meta_train_policy"]):
         m.train()
         m.mem_dropout.eval()
-    frames = _with_true_shape(to_dev(synth_frames(n, H, W)), (H, W))
+    frames = _with_true_shape(to_dev(synth_frames(n, H, W, batch=int(g["meta_batch"]) if "meta_batch" in g.files else 1)), (H, W))
     for sw in switches_off:
         assert getattr(m, sw) is True, sw
         setattr(m, sw, False)
@@ -830,7 +830,7 @@ def test_cfg3_512x50_vs_reference(full_sd, precision, tol):
     assert max(err.values()) < tol, err
 
 
-@pytest.mark.parametrize("fixture", ["spann3r_demo_160x224x6.npz", "spann3r_mid_288x512x5.npz", "spann3r_portrait_224x160x4.npz"])
+@pytest.mark.parametrize("fixture", ["spann3r_demo_160x224x6.npz", "spann3r_mid_288x512x5.npz", "spann3r_portrait_224x160x4.npz", "spann3r_b4_224x5.npz"])
 @pytest.mark.parametrize("precision,tol", [("fp32", TOL_FP32), ("f16x3", 2e-4), ("bf16", TOL_BF16)])
 def test_other_geometries_vs_reference(full_sd, fixture, precision, tol):
     """Two geometries between / below the benched ones, FULL model against dumps of the unmodified reference (make_golden.py demo160 /
@@ -838,10 +838,11 @@ def test_other_geometries_vs_reference(full_sd, fixture, precision, tol):
     launch, a token count that is no multiple of 16; eval policy with its similarity gate) and 288 x 512 = 576 tokens (the 257..1535-row
     instances of the many-row families and the > 256-row memory read, which neither 196 nor 1024 tokens reach; growing bank); and the
     140-token geometry held upright (224 x 160: the landscape_only transposition of the heads and the axis-swapped pointmap in front of
-    the value encoder, in the FULL model)."""
+    the value encoder, in the FULL model); and the bench line's `batch4` workload (four 224 x 224 sequences per call: 784 rows per launch,
+    per-sample banks, ONE similarity decision for the batch)."""
     import os
     if not os.path.exists(os.path.join(os.path.dirname(__file__), "golden", fixture)):
-        pytest.skip("fixture not generated (tests/golden/make_golden.py demo160 mid288 portrait224)")
+        pytest.skip("fixture not generated (tests/golden/make_golden.py demo160 mid288 portrait224 batch4)")
     err = _run_sequence_fixture(fixture, full_sd, precision)
     ppmax = err.pop("pts_ppmax")
     if precision == "bf16":
