@@ -153,7 +153,7 @@ def _check_sequence_fixture(name, full_sd, tol=1e-4):
     assert state_dict_fingerprint(full_sd) == float(g["fingerprint"])
     H, W = map(int, g["meta_hw"])
     S = int(g["meta_sub"])
-    frames = synth_frames(int(g["meta_frames"]), H, W)
+    frames = synth_frames(int(g["meta_frames"]), H, W, batch=int(g["meta_batch"]) if "meta_batch" in g.files else 1)
     taps = {}
     preds, preds_all, mem = O.forward(frames, full_sd, FULL, training_policy=bool(g["meta_train_policy"]),
                                       return_memory=True, taps=taps)
@@ -173,6 +173,14 @@ def _check_sequence_fixture(name, full_sd, tol=1e-4):
 def test_cfg2_224x10(full_sd):
     """BASELINE config 2 (the bench workload): 10 frames of 224x224, eval policy."""
     _check_sequence_fixture("spann3r_cfg2_224x10.npz", full_sd)
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("name", ["spann3r_demo_160x224x6.npz", "spann3r_portrait_224x160x4.npz", "spann3r_mid_288x512x5.npz", "spann3r_b4_224x5.npz"])
+def test_other_geometries_and_batch4(full_sd, name):
+    """Round-6 fixtures: the FULL model at 140 tokens per frame (landscape and upright: the landscape_only transposition), at 576
+    tokens with a growing bank, and the bench line's batch-4 workload (one similarity decision for the whole batch)."""
+    _check_sequence_fixture(name, full_sd)
 
 
 @pytest.mark.slow
