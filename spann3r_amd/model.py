@@ -398,13 +398,16 @@ class SpatialMemory:
         self._push_state()
 
     # ------------------------------------------------------------------ similarity gate (:97-118)
-    def sim_scores(self, feat_k):
-        """[B, wm] mean cosine similarity of feat_k against each of the last `wm` stored frames."""
+    def sim_scores(self, feat_k, to_host=False):
+        """[B, wm] mean cosine similarity of feat_k against each of the last `wm` stored frames.
+        to_host (single-graph step, device-resident bank state): the reduction kernel stores the scores STRAIGHT into the pinned host
+        buffer the host polls (pinned memory is mapped into the device's address space) -- no copy node between the step's halves."""
         B, P, C = self.B, self.P, self.C
         n = self.wm * P
         for b in range(B):
             if self.state is not None:       # the window [M - wm P, M) comes from the device: the launch is sized for work_mem_size frames
-                ops.cos_sim_state(feat_k[b], self.bank["k_raw"][b], max(self.work_mem_size, 1), P, C, self.state, self._score[b], self._cos_scratch)
+                dst = self._host_scores()[b] if to_host else self._score[b]
+                ops.cos_sim_state(feat_k[b], self.bank["k_raw"][b], max(self.work_mem_size, 1), P, C, self.state, dst, self._cos_scratch)
             else:
                 ops.cos_sim(feat_k[b], self.bank["k_raw"][b, self.M - n:self.M], self.wm, P, C, self._score[b], self._cos_scratch)
         return self._score[:, :self.wm]
@@ -451,9 +454,10 @@ class SpatialMemory:
             view = self._score_host[:, :self.wm]
             t0 = time.perf_counter()
             while bool((view == self._SENTINEL).any()):
-                if time.perf_counter() - t0 > 0.25:          # (never observed: fall back to a stream sync + plain copy)
+                if time.perf_counter() - t0 > 0.25:          # (never observed: fall back to a stream sync)
                     torch.cuda.current_stream().synchronize()
-                    view = self._score[:, :self.wm].cpu()
+                    if bool((view == self._SENTINEL).any()):  # (the copy-node form: the scores are in the device buffer)
+                        view = self._score[:, :self.wm].cpu()
                     break
             mx = float(view.max())                 # (torch's max propagates NaN, as the reference's mean_corr.max() does: never 'similar')
         elif self._score_pending:
@@ -611,6 +615,7 @@ class _SequenceRunner:
         self.seen = set()
         self.length_keys, self.length_keys_eager = set(), False    # keys that carry the bank length; True: they run eagerly (see _graphed)
         self.out = None
+        self._scores_to_host = False  # set around _part1 by the single-graph step (SpatialMemory.sim_scores)
         self.batched = False          # True: the frames of the sequence were encoded up front (encode_sequence)
         self.img_all = self.feats = None
         self.defer2 = False           # True: the view-2 DPT head runs once for all steps after the loop (finish_head2)
@@ -870,7 +875,7 @@ class _SequenceRunner:
                 self.k2_aux = eng.encode_feat_key(self.feat2, dec2[-1], B * P, 2, self.k2, aux=True)
                 eng.encode_feat_key(self.feat1, dec1[-1], B * P, 1, self.k1)
         if not self.training and mem.sim_needed():
-            mem.sim_scores(self.k1)
+            mem.sim_scores(self.k1, to_host=self._scores_to_host and mem.state is not None)
         if has_next:
             main.wait_stream(st[3])
         self.dec = (dec1, dec2)
@@ -921,8 +926,12 @@ class _SequenceRunner:
                 mem.arm_score_poll()
 
             def whole():
-                self._part1(first, has_next)
-                if need_sim:
+                self._scores_to_host = need_sim                 # (device-resident bank state: cos_mean stores into the pinned buffer itself)
+                try:
+                    self._part1(first, has_next)
+                finally:
+                    self._scores_to_host = False
+                if need_sim and mem.state is None:
                     mem.copy_scores_in_graph()
                 self._part2()
             self._graphed(("whole", first, need_sim) + key, whole, use_graphs, per_length)
